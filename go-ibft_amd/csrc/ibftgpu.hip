@@ -1,0 +1,506 @@
+// ibftgpu.hip — host side of libibftgpu.so: the C ABI declared in include/ibftgpu.h.
+//
+// Product code.  No CPU verification path exists here on purpose: if the device or a
+// HIP call fails the entry point returns a negative code and the caller (the Go shim,
+// INTEGRATION.md) runs its own per-message Verifier for that batch.
+#include "../../include/ibftgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hip.h"
+
+namespace {
+
+constexpr uint32_t DEFAULT_MAX_ROWS = 65536;
+constexpr size_t PAYLOAD_SLACK = 1 << 20;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct ibft_ctx {
+  std::mutex mu;
+  int device = 0;
+  uint32_t flags = 0;
+  uint32_t max_rows = DEFAULT_MAX_ROWS;
+  uint32_t kernel = IBFT_KERNEL_LANE;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // columns in HBM
+  DevBuf d_hash, d_sig, d_signer, d_pre, d_hash_len, d_payload, d_off, d_raw;
+  DevBuf d_mask, d_vidx, d_tally, d_H;
+  // fixed-base table for G
+  DevBuf d_gtab;
+  // validator table
+  DevBuf d_vtab, d_vpower;
+  uint32_t vslot_mask = 0;
+  uint32_t n_validators = 0;
+  bool have_valset = false;
+  unsigned __int128 quorum = 0;
+  uint64_t height = 0;
+
+  // staged batch
+  uint32_t staged_n = 0;
+  bool staged_pre = false;
+
+  // pinned host mirrors for results
+  uint64_t *h_mask = nullptr;
+  uint64_t *h_tally = nullptr;
+
+  // dominant-kernel timing
+  std::vector<hipEvent_t> ev;  // pairs
+  uint32_t ev_used = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                        \
+  do {                                                                           \
+    hipError_t e_ = (expr);                                                      \
+    if (e_ != hipSuccess) {                                                      \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);     \
+      return IBFT_E_HIP;                                                         \
+    }                                                                            \
+  } while (0)
+
+int ensure(ibft_ctx *c, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return IBFT_OK;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes < 256 ? 256 : bytes;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    c->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return IBFT_E_NOMEM;
+  }
+  b.cap = want;
+  return IBFT_OK;
+}
+
+void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+int mask_words(size_t n) { return (int)((n + 63) / 64); }
+
+int alloc_rows(ibft_ctx *c) {
+  size_t m = c->max_rows;
+  int rc;
+  if ((rc = ensure(c, c->d_hash, m * 32))) return rc;
+  if ((rc = ensure(c, c->d_sig, m * 65 + 64))) return rc;
+  if ((rc = ensure(c, c->d_signer, m * 20))) return rc;
+  if ((rc = ensure(c, c->d_pre, m))) return rc;
+  if ((rc = ensure(c, c->d_hash_len, m))) return rc;
+  if ((rc = ensure(c, c->d_off, (m + 1) * 4))) return rc;
+  if ((rc = ensure(c, c->d_mask, (size_t)mask_words(m) * 8))) return rc;
+  if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
+  if ((rc = ensure(c, c->d_tally, 4 * 8))) return rc;
+  if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
+  return IBFT_OK;
+}
+
+ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre) {
+  ibftk::recover_args a{};
+  a.hash32 = (const uint8_t *)c->d_hash.p;
+  a.sig65 = (const uint8_t *)c->d_sig.p;
+  a.signer20 = (const uint8_t *)c->d_signer.p;
+  a.pre_flags = with_pre ? (const uint8_t *)c->d_pre.p : nullptr;
+  a.payload = (const uint8_t *)c->d_payload.p;
+  a.off = (const uint32_t *)c->d_off.p;
+  a.gtab = (const uint32_t *)c->d_gtab.p;
+  a.vtab = (const uint32_t *)c->d_vtab.p;
+  a.vslot_mask = c->vslot_mask;
+  a.n = n;
+  a.flags = c->flags;
+  a.mask = (uint64_t *)c->d_mask.p;
+  a.vidx = (int32_t *)c->d_vidx.p;
+  return a;
+}
+
+int next_events(ibft_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
+  if ((size_t)c->ev_used * 2 + 2 > c->ev.size()) {
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    c->ev.push_back(a);
+    c->ev.push_back(b);
+  }
+  *start = c->ev[(size_t)c->ev_used * 2];
+  *stop = c->ev[(size_t)c->ev_used * 2 + 1];
+  c->ev_used++;
+  return IBFT_OK;
+}
+
+// enqueue recover (+ tally) over the resident columns
+int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it) {
+  if (n == 0) return IBFT_OK;
+  ibftk::recover_args a = make_args(c, n, with_pre);
+  dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (time_it) {
+    int rc = next_events(c, &e0, &e1);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+  }
+  if (mode == 0)
+    hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<0>, grid, block, 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<1>, grid, block, 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
+  return IBFT_OK;
+}
+
+int enqueue_tally(ibft_ctx *c, uint32_t n) {
+  hipLaunchKernelGGL(ibftk::tally_kernel, dim3(1), dim3(ibftk::TALLY_THREADS), 0, c->stream,
+                     (const uint64_t *)c->d_mask.p, (const int32_t *)c->d_vidx.p,
+                     (const uint64_t *)c->d_vpower.p, n, c->n_validators, (uint64_t)c->quorum,
+                     (uint64_t)(c->quorum >> 64), (uint64_t *)c->d_tally.p);
+  HIPCHK(c, hipGetLastError());
+  return IBFT_OK;
+}
+
+int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tally, bool have_tally) {
+  size_t mw = (size_t)mask_words(n);
+  if (out_mask && mw)
+    HIPCHK(c, hipMemcpyAsync(c->h_mask, c->d_mask.p, mw * 8, hipMemcpyDeviceToHost, c->stream));
+  if (tally && have_tally)
+    HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (out_mask && mw) {
+    memcpy(out_mask, c->h_mask, mw * 8);
+    // clear the padding bits of the last word
+    if (n & 63) out_mask[mw - 1] &= (~0ull) >> (64 - (n & 63));
+  }
+  if (tally) {
+    memset(tally, 0, sizeof *tally);
+    tally->quorum_lo = (uint64_t)c->quorum;
+    tally->quorum_hi = (uint64_t)(c->quorum >> 64);
+    if (have_tally) {
+      tally->power_lo = c->h_tally[0];
+      tally->power_hi = c->h_tally[1];
+      tally->valid_rows = (uint32_t)(c->h_tally[2] & 0xFFFFFFFFull);
+      tally->distinct_senders = (uint32_t)(c->h_tally[2] >> 32);
+      tally->has_quorum = (uint32_t)c->h_tally[3];
+    }
+  }
+  return IBFT_OK;
+}
+
+int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+  if (!bytes) return IBFT_OK;
+  int rc = ensure(c, b, bytes);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return IBFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ibft_version(void) { return 1; }
+
+const char *ibft_strerror(int code) {
+  switch (code) {
+    case IBFT_OK: return "ok";
+    case IBFT_E_INVAL: return "invalid argument";
+    case IBFT_E_NODEVICE: return "no usable gfx950 device";
+    case IBFT_E_NOMEM: return "out of memory";
+    case IBFT_E_HIP: return "HIP runtime error";
+    case IBFT_E_NOVALSET: return "validator set not configured";
+    case IBFT_E_POWER: return "total voting power is zero or less";
+    case IBFT_E_TOOBIG: return "batch exceeds max_rows";
+    default: return "unknown error";
+  }
+}
+
+const char *ibft_last_error(const ibft_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
+  if (!out) return IBFT_E_INVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IBFT_E_NODEVICE;
+  int dev = cfg ? cfg->device : 0;
+  if (dev < 0 || dev >= ndev) return IBFT_E_NODEVICE;
+  if (hipSetDevice(dev) != hipSuccess) return IBFT_E_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return IBFT_E_NODEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return IBFT_E_NODEVICE;  // gfx950-only code object
+
+  ibft_ctx *c = new (std::nothrow) ibft_ctx();
+  if (!c) return IBFT_E_NOMEM;
+  c->device = dev;
+  c->flags = cfg ? cfg->flags : 0;
+  c->max_rows = (cfg && cfg->max_rows) ? cfg->max_rows : DEFAULT_MAX_ROWS;
+  c->kernel = (cfg && cfg->kernel) ? cfg->kernel : IBFT_KERNEL_LANE;
+  int rc = IBFT_OK;
+  do {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
+    if ((rc = alloc_rows(c))) break;
+    if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if (hipHostMalloc((void **)&c->h_tally, 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * 16 * 4))) break;
+    int threads = 64, total = ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES;
+    hipLaunchKernelGGL(ibftk::gtab_build_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0,
+                       c->stream, (uint32_t *)c->d_gtab.p);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = IBFT_E_HIP; break; }
+  } while (0);
+  if (rc) {
+    ibft_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return IBFT_OK;
+}
+
+void ibft_ctx_destroy(ibft_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
+                    &c->d_off, &c->d_raw, &c->d_mask, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
+                    &c->d_vtab, &c->d_vpower})
+    release(*b);
+  if (c->h_mask) (void)hipHostFree(c->h_mask);
+  if (c->h_tally) (void)hipHostFree(c->h_tally);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint64_t *power,
+                        size_t n) {
+  if (!c || (n && (!addrs20 || !power)) || n > (1u << 20)) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  // Host-side build of the open-addressing table; a repeated address keeps the LAST
+  // power (a Go map assignment in a loop), mirroring oracle/ibft_oracle.c.
+  uint32_t slots = 64;
+  while (slots < 2 * n + 2) slots <<= 1;
+  std::vector<uint32_t> tab((size_t)slots * 6, 0);
+  std::vector<uint64_t> pw;
+  pw.reserve(n ? n : 1);
+  for (size_t i = 0; i < n; i++) {
+    uint32_t a[5];
+    memcpy(a, addrs20 + 20 * i, 20);
+    uint32_t s = ibftk::addr_hash(a) & (slots - 1);
+    for (;;) {
+      uint32_t *e = &tab[(size_t)s * 6];
+      if (e[5] == 0) {
+        memcpy(e, a, 20);
+        pw.push_back(power[i]);
+        e[5] = (uint32_t)pw.size();
+        break;
+      }
+      if (memcmp(e, a, 20) == 0) {
+        pw[e[5] - 1] = power[i];
+        break;
+      }
+      s = (s + 1) & (slots - 1);
+    }
+  }
+  unsigned __int128 total = 0;
+  for (uint64_t p : pw) total += p;
+  if (total == 0) return IBFT_E_POWER;  // validator_manager.go:68-70
+  if (pw.size() > (size_t)ibftk::TALLY_SEEN_WORDS * 32) return IBFT_E_TOOBIG;
+  int rc;
+  if ((rc = upload(c, c->d_vtab, tab.data(), tab.size() * 4))) return rc;
+  if ((rc = upload(c, c->d_vpower, pw.data(), pw.size() * 8))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->vslot_mask = slots - 1;
+  c->n_validators = (uint32_t)pw.size();
+  c->quorum = (total * 2) / 3 + 1;  // calculateQuorum, validator_manager.go:130-135
+  c->height = height;
+  c->have_valset = true;
+  return IBFT_OK;
+}
+
+int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round, uint8_t out32[32]) {
+  if (!c || (raw_len && !raw) || !out32 || raw_len > (1ull << 31)) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint8_t> msg(raw_len + 8);
+  if (raw_len) memcpy(msg.data(), raw, raw_len);
+  for (int i = 0; i < 8; i++) msg[raw_len + i] = (uint8_t)(round >> (8 * (7 - i)));
+  int rc;
+  if ((rc = upload(c, c->d_raw, msg.data(), msg.size()))) return rc;
+  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->stream,
+                     (const uint8_t *)c->d_raw.p, (uint32_t)msg.size(), (uint64_t *)c->d_H.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_H.p, 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  memcpy(out32, c->h_tally, 32);
+  return IBFT_OK;
+}
+
+int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round,
+                       const uint8_t *hash32, const uint8_t *hash_len, size_t n, uint64_t *out_mask) {
+  if (!c || (raw_len && !raw) || (n && (!hash32 || !hash_len || !out_mask)) || raw_len > (1ull << 31))
+    return IBFT_E_INVAL;
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint8_t> msg(raw_len + 8);
+  if (raw_len) memcpy(msg.data(), raw, raw_len);
+  for (int i = 0; i < 8; i++) msg[raw_len + i] = (uint8_t)(round >> (8 * (7 - i)));
+  int rc;
+  if ((rc = upload(c, c->d_raw, msg.data(), msg.size()))) return rc;
+  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
+  if ((rc = upload(c, c->d_hash_len, hash_len, n))) return rc;
+  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->stream,
+                     (const uint8_t *)c->d_raw.p, (uint32_t)msg.size(), (uint64_t *)c->d_H.p);
+  HIPCHK(c, hipGetLastError());
+  if (n) {
+    hipLaunchKernelGGL(ibftk::hash_eq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint8_t *)c->d_hash.p, (const uint8_t *)c->d_hash_len.p,
+                       (const uint64_t *)c->d_H.p, (uint32_t)n, (uint64_t *)c->d_mask.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  return fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
+}
+
+int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                     const uint8_t *pre_flags, size_t n) {
+  if (!c || (n && (!hash32 || !sig65 || !signer20))) return IBFT_E_INVAL;
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
+  if ((rc = upload(c, c->d_sig, sig65, n * 65))) return rc;
+  if ((rc = upload(c, c->d_signer, signer20, n * 20))) return rc;
+  if (pre_flags && (rc = upload(c, c->d_pre, pre_flags, n))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->staged_n = (uint32_t)n;
+  c->staged_pre = pre_flags != nullptr;
+  return IBFT_OK;
+}
+
+int ibft_seals_launch(ibft_ctx *c, uint32_t repeat) {
+  if (!c) return IBFT_E_INVAL;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->ev_used = 0;
+  if (repeat == 0) repeat = 1;
+  for (uint32_t k = 0; k < repeat; k++) {
+    int rc;
+    if ((rc = enqueue_recover(c, c->staged_n, c->staged_pre, 0, true))) return rc;
+    if ((rc = enqueue_tally(c, c->staged_n))) return rc;
+  }
+  return IBFT_OK;
+}
+
+int ibft_seals_fetch(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  return fetch_results(c, c->staged_n, out_mask, tally, true);
+}
+
+int ibft_seals_device_ptrs(ibft_ctx *c, void **d_mask, size_t *mask_words_out, void **d_tally) {
+  if (!c) return IBFT_E_INVAL;
+  if (d_mask) *d_mask = c->d_mask.p;
+  if (mask_words_out) *mask_words_out = (size_t)mask_words(c->staged_n);
+  if (d_tally) *d_tally = c->d_tally.p;
+  return IBFT_OK;
+}
+
+int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
+  if (!c || !ms) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float total = 0.f;
+  for (uint32_t i = 0; i < c->ev_used; i++) {
+    float t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&t, c->ev[(size_t)i * 2], c->ev[(size_t)i * 2 + 1]));
+    total += t;
+  }
+  *ms = total;
+  if (launches) *launches = c->ev_used;
+  return IBFT_OK;
+}
+
+int ibft_sync(ibft_ctx *c) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return IBFT_OK;
+}
+
+int ibft_verify_seals(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                      const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (!c || (n && !out_mask)) return IBFT_E_INVAL;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  int rc;
+  if ((rc = ibft_seals_stage(c, hash32, sig65, signer20, pre_flags, n))) return rc;
+  if ((rc = ibft_seals_launch(c, 1))) return rc;
+  return ibft_seals_fetch(c, out_mask, tally);
+}
+
+int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,
+                        const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
+                        ibft_tally_t *tally) {
+  if (!c || (n && (!off || !sig65 || !from20 || !out_mask))) return IBFT_E_INVAL;
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  if (n && off[n] && !payload) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  size_t pbytes = n ? off[n] : 0;
+  if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
+  if (pbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, payload, pbytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = upload(c, c->d_off, off, (n + 1) * 4))) return rc;
+  if ((rc = upload(c, c->d_sig, sig65, n * 65))) return rc;
+  if ((rc = upload(c, c->d_signer, from20, n * 20))) return rc;
+  if (pre_flags && (rc = upload(c, c->d_pre, pre_flags, n))) return rc;
+  c->staged_n = (uint32_t)n;
+  c->staged_pre = pre_flags != nullptr;
+  c->ev_used = 0;
+  if ((rc = enqueue_recover(c, (uint32_t)n, pre_flags != nullptr, 1, true))) return rc;
+  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  return fetch_results(c, (uint32_t)n, out_mask, tally, true);
+}
+
+int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, ibft_tally_t *tally) {
+  if (!c || !tally || (n && (!sender20 || !mask))) return IBFT_E_INVAL;
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  // resolve sender -> validator index with a small lookup pass over the table in HBM
+  int rc;
+  if ((rc = upload(c, c->d_signer, sender20, n * 20))) return rc;
+  if ((rc = upload(c, c->d_mask, mask, (size_t)mask_words(n) * 8))) return rc;
+  if (n) {
+    hipLaunchKernelGGL(ibftk::lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint8_t *)c->d_signer.p, (const uint32_t *)c->d_vtab.p, c->vslot_mask,
+                       (uint32_t)n, (int32_t *)c->d_vidx.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  return fetch_results(c, (uint32_t)n, nullptr, tally, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// kernels.hip.h — gfx950 kernels of the batch verifier.
+//
+// Product code.  Rows are go-ibft messages flattened by the host into byte
+// columns; each kernel replaces the per-message callback loop of
+// /root/reference/messages/messages.go:183-191.
+//
+//   hash_eq_kernel        a1  IsValidProposalHash   (core/ibft.go:858-861, 938)
+//   proposal_hash_kernel      keccak256(raw ‖ BE64(round)), once per batch
+//   ecrecover_lane_kernel a2  IsValidCommittedSeal  (core/ibft.go:943)
+//                         a3  IsValidValidator      (core/ibft.go:1128)
+//   tally_kernel          a8  HasQuorum             (core/validator_manager.go:77-96)
+//   gtab_build_kernel         one-time fixed-base table for G
+//
+// Layout in HBM: one contiguous byte column per field (hash N×32, sig N×65,
+// signer N×20, pre_flags N) — structure-of-arrays at field granularity.  A block
+// stages its 64 rows through LDS with coalesced dword loads, then every lane
+// unpacks its own row into 32-bit limbs held in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "recover_dev.h"
+
+namespace ibftk {
+
+using secp::aff;
+using secp::jac;
+using secp::u256;
+
+constexpr int ROWS_PER_BLOCK = 64; // one wavefront per block in the lane kernel
+
+// ---- validator table lookup (open addressing, linear probing) ----------------------
+__device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, uint32_t slot_mask,
+                                             const uint32_t a[5]) {
+  uint32_t s = addr_hash(a) & slot_mask;
+  for (uint32_t probe = 0; probe <= slot_mask; probe++) {
+    const uint32_t *e = vtab + 6u * s;
+    uint32_t tag = e[5];
+    if (tag == 0) return -1;
+    if (e[0] == a[0] && e[1] == a[1] && e[2] == a[2] && e[3] == a[3] && e[4] == a[4])
+      return (int)tag - 1;
+    s = (s + 1) & slot_mask;
+  }
+  return -1;
+}
+
+// ---- fixed-base table build (entries computed by recover_dev.h:gtab_entry) ----------
+__global__ void gtab_build_kernel(uint32_t *__restrict__ gtab) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= GTAB_WINDOWS * GTAB_ENTRIES) return;
+  gtab_entry(tid / GTAB_ENTRIES, tid % GTAB_ENTRIES, gtab + 16 * tid);
+}
+
+// ---- proposal hash + a1 ---------------------------------------------------------------
+// One lane hashes raw ‖ BE64(round) (the 8 round bytes are appended by the host into
+// the staged buffer); Keccak is sequential over blocks, so a single lane walks it.
+__global__ void proposal_hash_kernel(const uint8_t *__restrict__ msg, uint32_t len,
+                                     uint64_t *__restrict__ out4) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint64_t d[4];
+    keccak::hash_bytes(msg, len, d);
+    for (int i = 0; i < 4; i++) out4[i] = d[i];
+  }
+}
+
+// bit i of mask = (hash_len[i] == 32 && hash32[i] == H); rows are 32 B so each lane
+// reads two 16-B vectors; the ballot packs 64 verdicts into one u64 per wavefront.
+__global__ void hash_eq_kernel(const uint8_t *__restrict__ hash32, const uint8_t *__restrict__ hash_len,
+                               const uint64_t *__restrict__ H4, uint32_t n,
+                               uint64_t *__restrict__ mask) {
+  uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (row < n) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(hash32 + 32ull * row);
+    uint4 a = p[0], b = p[1];
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(H4);
+    uint32_t diff = (a.x ^ h[0]) | (a.y ^ h[1]) | (a.z ^ h[2]) | (a.w ^ h[3]) | (b.x ^ h[4]) |
+                    (b.y ^ h[5]) | (b.z ^ h[6]) | (b.w ^ h[7]);
+    ok = diff == 0 && hash_len[row] == 32;
+  }
+  uint64_t bal = __ballot(ok);
+  if ((threadIdx.x & 63) == 0 && row < n) mask[row >> 6] = bal;
+}
+
+// ---- ECDSA recover, one lane per signature ----------------------------------------------
+struct recover_args {
+  const uint8_t *hash32;    // n×32   (seals: per-row proposalHash)
+  const uint8_t *sig65;     // n×65
+  const uint8_t *signer20;  // n×20
+  const uint8_t *pre_flags; // n or null
+  const uint8_t *payload;   // senders: concatenated PayloadNoSig
+  const uint32_t *off;      // senders: n+1 offsets
+  const uint32_t *gtab;     // GTAB_WINDOWS×GTAB_ENTRIES×16 dwords
+  const uint32_t *vtab;     // validator table
+  uint32_t vslot_mask;
+  uint32_t n;
+  uint32_t flags;           // IBFT_FLAG_*
+  uint64_t *mask;           // ⌈n/64⌉ verdict words
+  int32_t *vidx;            // n: validator index of the row's sender (or -1)
+};
+
+// MODE 0: seals (digest = hash32 row).  MODE 1: senders (digest = keccak256(payload row)).
+template <int MODE>
+__global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_args a) {
+  // LDS staging of the block's rows: coalesced dword loads, then per-lane unpack
+  __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS_PER_BLOCK * (65 + 32 + 20)];
+  uint8_t *l_sig = lds;
+  uint8_t *l_hash = lds + ROWS_PER_BLOCK * 65;
+  uint8_t *l_from = l_hash + ROWS_PER_BLOCK * 32;
+  const uint32_t row0 = blockIdx.x * ROWS_PER_BLOCK;
+  const uint32_t rows = min((uint32_t)ROWS_PER_BLOCK, a.n - row0);
+  const uint32_t lane = threadIdx.x;
+  {
+    // sig: rows*65 bytes starting at 65*row0 (a multiple of 4 because row0 % 64 == 0)
+    const uint32_t nb = rows * 65;
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(a.sig65 + 65ull * row0);
+    for (uint32_t i = lane; i < nb / 4; i += ROWS_PER_BLOCK) reinterpret_cast<uint32_t *>(l_sig)[i] = g[i];
+    for (uint32_t i = (nb & ~3u) + lane; i < nb; i += ROWS_PER_BLOCK) l_sig[i] = a.sig65[65ull * row0 + i];
+    const uint32_t *gf = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row0);
+    for (uint32_t i = lane; i < rows * 5; i += ROWS_PER_BLOCK) reinterpret_cast<uint32_t *>(l_from)[i] = gf[i];
+    if (MODE == 0) {
+      const uint4 *gh = reinterpret_cast<const uint4 *>(a.hash32 + 32ull * row0);
+      for (uint32_t i = lane; i < rows * 2; i += ROWS_PER_BLOCK) reinterpret_cast<uint4 *>(l_hash)[i] = gh[i];
+    }
+  }
+  __syncthreads();
+
+  const uint32_t row = row0 + lane;
+  const bool live = lane < rows;
+  const uint32_t lrow = live ? lane : 0;
+  bool ok = live && !(a.pre_flags && a.pre_flags[row] != 0);
+
+  u256 r = secp::from_be32(l_sig + 65 * lrow);
+  u256 s = secp::from_be32(l_sig + 65 * lrow + 32);
+  uint32_t v = l_sig[65 * lrow + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(l_hash + 32 * lrow);
+  } else {
+    uint64_t d[4];
+    uint32_t o0 = live ? a.off[row] : 0u, o1 = live ? a.off[row + 1] : 0u;
+    keccak::hash_bytes(a.payload + o0, o1 - o0, d);
+    keccak::digest_to_limbs(d, z.v);
+  }
+  uint32_t want[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(l_from)[5 * lrow + i];
+
+  uint32_t got[5];
+  bool rec = recover_address(a.gtab, z, r, s, v, a.flags, got);
+  ok = ok && rec;
+#pragma unroll
+  for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
+  // membership: "the signer address is one of the validators" (backend.go:44, 53-54)
+  int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  ok = ok && vi >= 0;
+  if (live) a.vidx[row] = vi;
+  uint64_t bal = __ballot(ok);
+  if (lane == 0) a.mask[row0 >> 6] = bal;
+}
+
+// ---- a8: weighted quorum tally ------------------------------------------------------------
+// One workgroup walks the verdict words; a validator's power is counted once (LDS
+// bitmap = the Go map's set semantics), lanes reduce with wave shuffles, waves through
+// LDS.  out[0..1] = power (128-bit), out[2] = valid_rows | distinct<<32, out[3] = has_quorum.
+constexpr int TALLY_THREADS = 1024;
+constexpr int TALLY_SEEN_WORDS = 32768;  // 1M validators in 128 KiB of LDS
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(TALLY_THREADS)
+tally_kernel(const uint64_t *__restrict__ mask, const int32_t *__restrict__ vidx,
+             const uint64_t *__restrict__ vpower, uint32_t n, uint32_t n_validators,
+             uint64_t quorum_lo, uint64_t quorum_hi, uint64_t *__restrict__ out) {
+  __shared__ uint32_t seen[TALLY_SEEN_WORDS];
+  __shared__ uint64_t part[4][TALLY_THREADS / 64];
+  const uint32_t words = (n_validators + 31) / 32;
+  for (uint32_t i = threadIdx.x; i < words; i += TALLY_THREADS) seen[i] = 0;
+  __syncthreads();
+  uint64_t p_lo = 0, p_hi = 0, valid = 0, distinct = 0;
+  for (uint32_t row = threadIdx.x; row < n; row += TALLY_THREADS) {
+    bool bit = (mask[row >> 6] >> (row & 63)) & 1ull;
+    if (!bit) continue;
+    valid++;
+    int vi = vidx[row];
+    if (vi < 0) continue;  // unknown senders contribute 0 (validator_manager.go:88-92)
+    uint32_t m = 1u << (vi & 31);
+    uint32_t old = atomicOr(&seen[vi >> 5], m);
+    if (old & m) continue;  // distinct-sender set (validator_manager.go:147-155)
+    distinct++;
+    uint64_t pw = vpower[vi];
+    uint64_t nl = p_lo + pw;
+    p_hi += nl < p_lo;
+    p_lo = nl;
+  }
+  // wave reduction of the 128-bit power: split into 32-bit pieces so lane sums cannot overflow
+  uint64_t a0 = wave_sum_u64(p_lo & 0xFFFFFFFFull), a1 = wave_sum_u64(p_lo >> 32);
+  uint64_t a2 = wave_sum_u64(p_hi);
+  uint64_t cnt = wave_sum_u64(valid | (distinct << 32));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    part[0][wave] = a0;
+    part[1][wave] = a1;
+    part[2][wave] = a2;
+    part[3][wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t s0 = 0, s1 = 0, s2 = 0, c = 0;
+    for (int w = 0; w < TALLY_THREADS / 64; w++) {
+      s0 += part[0][w];
+      s1 += part[1][w];
+      s2 += part[2][w];
+      c += part[3][w];
+    }
+    // power = s0 + s1*2^32 + s2*2^64
+    uint64_t lo = s0 + (s1 << 32);
+    uint64_t hi = s2 + (s1 >> 32) + (lo < s0 ? 1 : 0);
+    out[0] = lo;
+    out[1] = hi;
+    out[2] = c;
+    out[3] = (hi > quorum_hi || (hi == quorum_hi && lo >= quorum_lo)) ? 1 : 0;
+  }
+}
+
+// sender -> validator index, for ibft_tally() on a caller-supplied mask
+__global__ void lookup_kernel(const uint8_t *__restrict__ signer20, const uint32_t *__restrict__ vtab,
+                              uint32_t slot_mask, uint32_t n, int32_t *__restrict__ vidx) {
+  uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  uint32_t a[5];
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(signer20 + 20ull * row);
+  for (int i = 0; i < 5; i++) a[i] = p[i];
+  vidx[row] = valset_lookup(vtab, slot_mask, a);
+}
+
+}  // namespace ibftk

@@ -1,0 +1,127 @@
+// recover_dev.h — ECDSA recover -> address, the per-row body of the a2/a3 kernels.
+//
+// Product code (__host__ __device__ so tests can run the identical source on the CPU;
+// the shipped library only runs it on gfx950).  Follows SEC 1 v2 §4.1.6 with the
+// conventions of include/ibftgpu.h; the reference call sites it serves are
+// /root/reference/core/ibft.go:943 (IsValidCommittedSeal) and :1128 (IsValidValidator).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "keccak_dev.h"
+#include "secp256k1_dev.h"
+
+namespace ibftk {
+
+using secp::aff;
+using secp::jac;
+using secp::u256;
+
+constexpr int GTAB_WINDOWS = 32;   // 8-bit windows over a 256-bit scalar
+constexpr int GTAB_ENTRIES = 256;  // entry 0 unused
+
+// ---- validator table (open addressing, linear probing) ---------------------------
+// slot = 6 dwords: addr[5], index+1 (0 = empty)
+__host__ __device__ __forceinline__ uint32_t addr_hash(const uint32_t a[5]) {
+  uint32_t h = a[0] * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + a[1] * 0x85EBCA77u;
+  h = (h ^ (h >> 13)) + a[2] * 0xC2B2AE3Du;
+  h = (h ^ (h >> 16)) + a[3] * 0x27D4EB2Fu;
+  h = (h ^ (h >> 15)) + a[4] * 0x165667B1u;
+  return h ^ (h >> 16);
+}
+
+// ---- fixed-base table: gtab[w][e] = e * 2^(8w) * G, affine, 16 dwords each ----------
+__host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
+  if (e == 0) {
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    return;
+  }
+  // base = 2^(8w) G, then e*base by double-and-add (8 bits)
+  jac base = secp::jac_from_aff(secp::generator());
+  for (int k = 0; k < 8 * w; k++) base = secp::jac_dbl(base);
+  jac acc = secp::jac_inf();
+  for (int b = 7; b >= 0; b--) {
+    acc = secp::jac_dbl(acc);
+    if ((e >> b) & 1) acc = secp::jac_add(acc, base);
+  }
+  aff a;
+  secp::jac_to_aff(a, acc);
+  for (int i = 0; i < 8; i++) {
+    out[i] = a.x.v[i];
+    out[8 + i] = a.y.v[i];
+  }
+}
+
+// u1*G from the 8-bit-window table (32 mixed adds, no doublings)
+__host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ gtab, const u256 &k, jac acc) {
+  for (int w = 0; w < GTAB_WINDOWS; w++) {
+    uint32_t dgt = (k.v[w >> 2] >> (8 * (w & 3))) & 255u;
+    const uint4 *e = reinterpret_cast<const uint4 *>(gtab + 16u * (w * GTAB_ENTRIES + dgt));
+    aff q;
+    uint4 t0 = e[0], t1 = e[1], t2 = e[2], t3 = e[3];
+    q.x.v[0] = t0.x; q.x.v[1] = t0.y; q.x.v[2] = t0.z; q.x.v[3] = t0.w;
+    q.x.v[4] = t1.x; q.x.v[5] = t1.y; q.x.v[6] = t1.z; q.x.v[7] = t1.w;
+    q.y.v[0] = t2.x; q.y.v[1] = t2.y; q.y.v[2] = t2.z; q.y.v[3] = t2.w;
+    q.y.v[4] = t3.x; q.y.v[5] = t3.y; q.y.v[6] = t3.z; q.y.v[7] = t3.w;
+    jac sum = secp::jac_add_aff(acc, q);
+    if (dgt != 0) acc = sum;
+  }
+  return acc;
+}
+
+// u2*R with a per-lane table of 1..15 multiples (4-bit fixed windows, MSB first)
+__host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) {
+  jac tab[16];
+  tab[0] = secp::jac_inf();
+  tab[1] = secp::jac_from_aff(R);
+  tab[2] = secp::jac_dbl(tab[1]);
+  for (int i = 3; i < 16; i++) tab[i] = secp::jac_add_aff(tab[i - 1], R);
+  jac acc = secp::jac_inf();
+  for (int nib = 63; nib >= 0; nib--) {
+    for (int d = 0; d < 4; d++) acc = secp::jac_dbl(acc);
+    uint32_t dgt = secp::nibble(k, nib);
+    jac sum = secp::jac_add(acc, tab[dgt]);
+    if (dgt != 0) acc = sum;
+  }
+  return acc;
+}
+
+// Recover the signer address of (digest z, r, s, v); returns false if the signature
+// is rejected (same rejection list as oracle/secp256k1.c:orc_ecrecover).
+__host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restrict__ gtab, const u256 &z_raw,
+                                                const u256 &r, const u256 &s, uint32_t v,
+                                                uint32_t flags, uint32_t addr[5]) {
+  bool ok = v <= 1;
+  ok = ok && !secp::is_zero(r) && !secp::geq_const(r, secp::NL());
+  ok = ok && !secp::is_zero(s) && !secp::geq_const(s, secp::NL());
+  if (flags & 1u) {  // strict low-s: reject s > (n-1)/2, i.e. s >= (n-1)/2 + 1
+    u256 sm1;
+    secp::sub256(sm1, s, secp::one256());
+    ok = ok && !secp::geq_const(sm1, secp::NHL());
+  }
+  // R = (r, y), y^2 = r^3 + 7, parity(y) = v
+  u256 seven = secp::zero256();
+  seven.v[0] = 7;
+  u256 rhs = secp::fe_add(secp::fe_mul(secp::fe_sqr(r), r), seven);
+  u256 y = secp::fe_sqrt_candidate(rhs);
+  ok = ok && secp::eq(secp::fe_sqr(y), rhs);
+  u256 yneg = secp::fe_neg(y);
+  y = secp::select((y.v[0] & 1u) != v, yneg, y);
+  aff R;
+  R.x = r;
+  R.y = y;
+  // u1 = -z/r, u2 = s/r (mod n)
+  u256 z = secp::sc_normalize(z_raw);
+  u256 rinv = secp::sc_inv(r);
+  u256 u1 = secp::sc_neg(secp::sc_mul(z, rinv));
+  u256 u2 = secp::sc_mul(s, rinv);
+  jac Q = ecmult_var(R, u2);
+  Q = ecmult_gen(gtab, u1, Q);
+  aff Qa;
+  ok = secp::jac_to_aff(Qa, Q) && ok;
+  keccak::address_from_xy(Qa.x.v, Qa.y.v, addr);
+  return ok;
+}
+
+}  // namespace ibftk

@@ -1,0 +1,164 @@
+/*
+ * include/ibftgpu.h — C ABI of libibftgpu.so, the MI355X (gfx950) batch verifier
+ * that sits behind go-ibft's Verifier hooks.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * framework types.  The Go side keeps core/ibft.go's RunSequence untouched and
+ * calls these entry points through the cgo shim in shim/go/ (see INTEGRATION.md).
+ *
+ * Each entry point replaces a per-message interface call of the reference with one
+ * call per batch:
+ *
+ *   ibft_verify_hashes   <- Verifier.IsValidProposalHash(proposal, hash)
+ *                           /root/reference/core/backend.go:50-51; call sites
+ *                           /root/reference/core/ibft.go:545, 649, 781, 858, 938
+ *   ibft_verify_seals    <- Verifier.IsValidCommittedSeal(proposalHash, seal)
+ *                           /root/reference/core/backend.go:53-55; call site
+ *                           /root/reference/core/ibft.go:943
+ *   ibft_verify_senders  <- Verifier.IsValidValidator(msg)
+ *                           /root/reference/core/backend.go:41-45; call sites
+ *                           /root/reference/core/ibft.go:735, 1128, 1213, 1220
+ *   ibft_set_validators  <- ValidatorBackend.GetVotingPowers(height)
+ *                           /root/reference/core/validator_manager.go:17-20, 50-75
+ *   ibft_tally (+ the ibft_tally_t filled by the verify calls)
+ *                        <- ValidatorManager.HasQuorum
+ *                           /root/reference/core/validator_manager.go:77-96
+ *
+ * Conventions (the reference fixes none of the arithmetic; these are the
+ * Ethereum-style ones an IBFT backend uses, stated once, obeyed by CPU oracle and
+ * GPU alike):
+ *   proposal hash = keccak256(RawProposal ‖ BE64(Round));  seal digest = the 32-byte
+ *   proposalHash itself;  sender digest = keccak256(PayloadNoSig)
+ *   (/root/reference/messages/proto/helper.go:12-27);  signature = 65 B r‖s‖v with
+ *   r,s big-endian in [1,n-1] and v∈{0,1};  address = keccak256(X‖Y)[12:32].
+ *
+ * Verdict masks: bit i of out_mask[i/64] is row i's verdict (1 = the reference
+ * predicate would return true).  Rows the host already knows to be structurally
+ * invalid (nil payload, wrong length, a1 failed → a2 short-circuited,
+ * /root/reference/core/ibft.go:938-943) are passed with a non-zero pre_flags byte
+ * and come back 0 without touching the device arithmetic.
+ *
+ * Error behaviour: every call returns IBFT_OK (0) or a negative IBFT_E_* code and
+ * never synthesises verdicts on failure — the caller must then run its own CPU
+ * Verifier for that batch (all-false would stall liveness, all-true would break
+ * safety).  There is NO CPU fallback inside this library.
+ *
+ * Threading: a context is internally serialised (one mutex, one HIP stream); use
+ * one context per concurrent caller (the four goroutines of
+ * /root/reference/core/ibft.go:335-347 would each hold one).  Nothing is retained
+ * from caller memory after a call returns (cgo pointer rules).
+ */
+#ifndef IBFTGPU_H
+#define IBFTGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IBFT_OK 0
+#define IBFT_E_INVAL (-1)     /* bad argument                                   */
+#define IBFT_E_NODEVICE (-2)  /* no usable gfx950 device / HIP runtime error     */
+#define IBFT_E_NOMEM (-3)     /* host or device allocation failed                */
+#define IBFT_E_HIP (-4)       /* a HIP call failed; ibft_last_error() has detail */
+#define IBFT_E_NOVALSET (-5)  /* ibft_set_validators has not succeeded yet       */
+#define IBFT_E_POWER (-6)     /* total voting power is zero (errVotingPowerNotCorrect) */
+#define IBFT_E_TOOBIG (-7)    /* batch larger than cfg.max_rows                  */
+
+/* cfg.flags */
+#define IBFT_FLAG_STRICT_LOW_S 1u /* also reject s > n/2 (off: go-ethereum Ecrecover semantics) */
+
+/* pre_flags bits */
+#define IBFT_ROW_NIL 0x01u
+#define IBFT_ROW_BADLEN 0x02u
+#define IBFT_ROW_HASH_BAD 0x04u
+
+/* cfg.kernel: which ecrecover kernel the seal/sender paths launch */
+#define IBFT_KERNEL_AUTO 0u
+#define IBFT_KERNEL_LANE 1u /* one lane per signature (throughput at large N)      */
+#define IBFT_KERNEL_WAVE 2u /* one wavefront per signature (latency at small N)    */
+
+typedef struct ibft_ctx ibft_ctx;
+
+typedef struct {
+  int32_t device;    /* HIP device ordinal                                         */
+  uint32_t flags;    /* IBFT_FLAG_*                                                 */
+  uint32_t max_rows; /* largest batch this context will be asked for (0 = 65536)    */
+  uint32_t kernel;   /* IBFT_KERNEL_*                                               */
+} ibft_cfg;
+
+typedef struct {
+  uint64_t quorum_lo, quorum_hi; /* floor(2*total/3)+1 (validator_manager.go:130-135) */
+  uint64_t power_lo, power_hi;   /* Σ power over distinct valid senders ∈ validator set */
+  uint32_t valid_rows;           /* popcount of the verdict mask                        */
+  uint32_t distinct_senders;     /* distinct member senders among the valid rows        */
+  uint32_t has_quorum;           /* power >= quorum                                     */
+  uint32_t reserved;
+} ibft_tally_t;
+
+int ibft_version(void);
+const char *ibft_strerror(int code);
+/* last HIP error string seen by this context (thread-unsafe diagnostic) */
+const char *ibft_last_error(const ibft_ctx *ctx);
+
+int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out);
+void ibft_ctx_destroy(ibft_ctx *ctx);
+
+/* Replace the validator table (addresses n×20, powers n×u64) for `height`.
+ * Builds the device-side open-addressing table used for set membership and the
+ * weighted tally.  Powers are u64 here; a set whose powers do not fit must keep
+ * using the host big.Int path (validator_manager.go:19 uses *big.Int).            */
+int ibft_set_validators(ibft_ctx *ctx, uint64_t height, const uint8_t *addrs20,
+                        const uint64_t *power, size_t n);
+
+/* a1.  raw/raw_len/round: the proposal all rows are checked against.  hash32 is
+ * n×32 (zero-filled where absent), hash_len[i] the real byte length (0 = nil).    */
+int ibft_verify_hashes(ibft_ctx *ctx, const uint8_t *raw, size_t raw_len, uint64_t round,
+                       const uint8_t *hash32, const uint8_t *hash_len, size_t n,
+                       uint64_t *out_mask);
+/* keccak256(raw ‖ BE64(round)) computed on the device (what BuildPrepareMessage's
+ * caller would sign).                                                              */
+int ibft_proposal_hash(ibft_ctx *ctx, const uint8_t *raw, size_t raw_len, uint64_t round,
+                       uint8_t out32[32]);
+
+/* a2.  hash32 n×32 (per-row proposalHash from ExtractCommitHash), sig65 n×65,
+ * signer20 n×20 (msg.From).  tally may be NULL.                                   */
+int ibft_verify_seals(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
+                      const uint8_t *signer20, const uint8_t *pre_flags, size_t n,
+                      uint64_t *out_mask, ibft_tally_t *tally);
+
+/* a3.  payload = concatenated PayloadNoSig bytes; row i is payload[off[i]..off[i+1]);
+ * off has n+1 entries.                                                             */
+int ibft_verify_senders(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *off,
+                        const uint8_t *sig65, const uint8_t *from20, const uint8_t *pre_flags,
+                        size_t n, uint64_t *out_mask, ibft_tally_t *tally);
+
+/* a8 alone: HasQuorum over the rows whose bit is set in mask.                      */
+int ibft_tally(ibft_ctx *ctx, const uint8_t *sender20, const uint64_t *mask, size_t n,
+               ibft_tally_t *tally);
+
+/* ---- staged (device-resident) form of a2, used by bench.py and by multi-GPU ----
+ * stage:  copy the batch into the context's HBM columns (H2D, synchronous).
+ * launch: enqueue unpack → recover → tally on the context's stream (asynchronous);
+ *         `repeat` back-to-back passes over the resident batch (each pass is the
+ *         full computation; used to time K steps without host round trips).
+ * fetch:  wait for the stream, copy mask + tally back.                             */
+int ibft_seals_stage(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
+                     const uint8_t *signer20, const uint8_t *pre_flags, size_t n);
+int ibft_seals_launch(ibft_ctx *ctx, uint32_t repeat);
+int ibft_seals_fetch(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
+/* Device address of the resident verdict mask (⌈n/64⌉ u64 words) and of the two
+ * u64 tally accumulators {power, valid_rows|distinct<<32}: lets the caller run an
+ * RCCL all-reduce over validator shards without a host round trip.                 */
+int ibft_seals_device_ptrs(ibft_ctx *ctx, void **d_mask, size_t *mask_words, void **d_tally);
+/* HIP-event time (ms) of the dominant kernel summed over the last launch, and its
+ * launch count; measured on the context's own stream.                              */
+int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
+/* Block the host until the context's stream is idle.                               */
+int ibft_sync(ibft_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

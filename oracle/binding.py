@@ -1,0 +1,220 @@
+"""oracle/binding.py — ctypes binding of libibft_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libibft_oracle.so")
+_SRCS = ["keccak.c", "secp256k1.c", "ibft_oracle.c", "ibft_oracle.h"]
+
+FLAG_STRICT_LOW_S = 1
+ROW_NIL, ROW_BADLEN, ROW_HASH_BAD = 1, 2, 4
+
+
+def build(force: bool = False) -> str:
+    stale = force or not os.path.exists(_LIB) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB) for s in _SRCS)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "libibft_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class Tally(C.Structure):
+    _fields_ = [("quorum_lo", C.c_uint64), ("quorum_hi", C.c_uint64),
+                ("power_lo", C.c_uint64), ("power_hi", C.c_uint64),
+                ("valid_rows", C.c_uint32), ("distinct_senders", C.c_uint32),
+                ("has_quorum", C.c_uint32), ("reserved", C.c_uint32)]
+
+    @property
+    def power(self) -> int:
+        return self.power_lo | (self.power_hi << 64)
+
+    @property
+    def quorum(self) -> int:
+        return self.quorum_lo | (self.quorum_hi << 64)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        vp, u8p = C.c_void_p, C.c_char_p
+        L.orc_keccak256.argtypes = [u8p, C.c_size_t, u8p]
+        L.orc_pubkey.argtypes = [u8p, u8p]; L.orc_pubkey.restype = C.c_int
+        L.orc_address.argtypes = [u8p, u8p]
+        L.orc_sign.argtypes = [u8p, u8p, u8p]; L.orc_sign.restype = C.c_int
+        L.orc_ecrecover.argtypes = [u8p, u8p, C.c_uint32, u8p]; L.orc_ecrecover.restype = C.c_int
+        L.orc_recover_address.argtypes = [u8p, u8p, C.c_uint32, u8p]; L.orc_recover_address.restype = C.c_int
+        for f in (L.orc_fe_mul, L.orc_sc_mul):
+            f.argtypes = [u8p, u8p, u8p]
+        for f in (L.orc_fe_inv, L.orc_sc_inv):
+            f.argtypes = [u8p, u8p]
+        L.orc_fe_sqrt.argtypes = [u8p, u8p]; L.orc_fe_sqrt.restype = C.c_int
+        L.orc_ecmult2.argtypes = [u8p, u8p, u8p, u8p]; L.orc_ecmult2.restype = C.c_int
+        L.orc_valset_new.argtypes = [vp, vp, C.c_size_t]; L.orc_valset_new.restype = vp
+        L.orc_valset_free.argtypes = [vp]
+        L.orc_valset_index.argtypes = [vp, u8p]; L.orc_valset_index.restype = C.c_int
+        L.orc_valset_quorum.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_proposal_hash.argtypes = [u8p, C.c_size_t, C.c_uint64, u8p]
+        L.orc_verify_hashes.argtypes = [u8p, C.c_size_t, C.c_uint64, vp, vp, C.c_size_t, vp]
+        L.orc_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp]
+        L.orc_verify_seals_mt.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp, C.c_int]
+        L.orc_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_uint32, vp]
+        L.orc_tally.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(Tally)]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def keccak256(data: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_keccak256(bytes(data), len(data), out)
+    return out.raw
+
+
+def pubkey(sk32: bytes) -> bytes | None:
+    out = C.create_string_buffer(64)
+    return out.raw if lib().orc_pubkey(sk32, out) else None
+
+
+def address(pub64: bytes) -> bytes:
+    out = C.create_string_buffer(20)
+    lib().orc_address(pub64, out)
+    return out.raw
+
+
+def sign(sk32: bytes, digest32: bytes) -> bytes:
+    out = C.create_string_buffer(65)
+    if not lib().orc_sign(sk32, digest32, out):
+        raise ValueError("orc_sign failed")
+    return out.raw
+
+
+def ecrecover(digest32: bytes, sig65: bytes, flags: int = 0) -> bytes | None:
+    out = C.create_string_buffer(64)
+    return out.raw if lib().orc_ecrecover(digest32, sig65, flags, out) else None
+
+
+def recover_address(digest32: bytes, sig65: bytes, flags: int = 0) -> bytes | None:
+    out = C.create_string_buffer(20)
+    return out.raw if lib().orc_recover_address(digest32, sig65, flags, out) else None
+
+
+def _bin2(fn, a: bytes, b: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    fn(a, b, out)
+    return out.raw
+
+
+def fe_mul(a, b): return _bin2(lib().orc_fe_mul, a, b)
+def sc_mul(a, b): return _bin2(lib().orc_sc_mul, a, b)
+
+
+def fe_inv(a):
+    out = C.create_string_buffer(32); lib().orc_fe_inv(a, out); return out.raw
+
+
+def sc_inv(a):
+    out = C.create_string_buffer(32); lib().orc_sc_inv(a, out); return out.raw
+
+
+def fe_sqrt(a):
+    out = C.create_string_buffer(32)
+    return out.raw if lib().orc_fe_sqrt(a, out) else None
+
+
+def ecmult2(k1: bytes, k2: bytes, p64: bytes) -> bytes | None:
+    out = C.create_string_buffer(64)
+    return out.raw if lib().orc_ecmult2(k1, k2, p64, out) else None
+
+
+def proposal_hash(raw: bytes, round_: int) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_proposal_hash(raw, len(raw), round_, out)
+    return out.raw
+
+
+class ValSet:
+    """Validator set: addresses (n×20 uint8) and u64 voting powers."""
+
+    def __init__(self, addrs20: np.ndarray, power: np.ndarray):
+        self.addrs = _u8(addrs20, (-1, 20))
+        self.power = np.ascontiguousarray(power, dtype=np.uint64)
+        assert len(self.addrs) == len(self.power)
+        self.h = lib().orc_valset_new(_p(self.addrs), _p(self.power), len(self.power))
+        if not self.h:
+            raise ValueError("total voting power is zero or less")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_valset_free(self.h)
+            self.h = None
+
+    def index(self, addr20: bytes) -> int:
+        return lib().orc_valset_index(self.h, addr20)
+
+    @property
+    def quorum(self) -> int:
+        lo, hi = C.c_uint64(), C.c_uint64()
+        lib().orc_valset_quorum(self.h, C.byref(lo), C.byref(hi))
+        return lo.value | (hi.value << 64)
+
+
+def verify_hashes(raw: bytes, round_: int, hash32: np.ndarray, hash_len: np.ndarray) -> np.ndarray:
+    hash32 = _u8(hash32, (-1, 32)); hash_len = _u8(hash_len)
+    n = len(hash_len)
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_verify_hashes(raw, len(raw), round_, _p(hash32), _p(hash_len), n, _p(out))
+    return out
+
+
+def verify_seals(vs: ValSet, hash32, sig65, signer20, pre_flags=None, flags: int = 0,
+                 nthreads: int = 1) -> np.ndarray:
+    hash32 = _u8(hash32, (-1, 32)); sig65 = _u8(sig65, (-1, 65)); signer20 = _u8(signer20, (-1, 20))
+    n = len(sig65)
+    pre = None if pre_flags is None else _u8(pre_flags)
+    out = np.zeros(n, dtype=np.uint8)
+    if nthreads > 1:
+        lib().orc_verify_seals_mt(vs.h, _p(hash32), _p(sig65), _p(signer20), _p(pre), n, flags, _p(out), nthreads)
+    else:
+        lib().orc_verify_seals(vs.h, _p(hash32), _p(sig65), _p(signer20), _p(pre), n, flags, _p(out))
+    return out
+
+
+def verify_senders(vs: ValSet, payload: bytes, off: np.ndarray, sig65, from20, pre_flags=None,
+                   flags: int = 0) -> np.ndarray:
+    pl = np.frombuffer(bytes(payload) or b"\0", dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    sig65 = _u8(sig65, (-1, 65)); from20 = _u8(from20, (-1, 20))
+    n = len(sig65)
+    pre = None if pre_flags is None else _u8(pre_flags)
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_verify_senders(vs.h, _p(pl), _p(off), _p(sig65), _p(from20), _p(pre), n, flags, _p(out))
+    return out
+
+
+def tally(vs: ValSet | None, sender20, verdict) -> Tally:
+    sender20 = _u8(sender20, (-1, 20)); verdict = _u8(verdict)
+    t = Tally()
+    lib().orc_tally(vs.h if vs is not None else None, _p(sender20), _p(verdict), len(verdict), C.byref(t))
+    return t
