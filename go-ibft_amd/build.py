@@ -1,0 +1,43 @@
+"""Build libibftgpu.so for gfx950 with hipcc (in-tree, so it travels with gpurun)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libibftgpu.so")
+SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "secp256k1_dev.h", "keccak_dev.h",
+           os.path.join("..", "..", "include", "ibftgpu.h")]
+HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    if force or _stale(LIB, SOURCES):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+               "-o", LIB, os.path.join(CSRC, "ibftgpu.hip")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+def build_host_harness(force: bool = False) -> str:
+    """TEST-ONLY: the device arithmetic headers compiled for the CPU (hipcc host pass)."""
+    deps = ["host_arith_harness.hip", "recover_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
+    if force or _stale(HOST_HARNESS, deps):
+        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
+                               "-o", HOST_HARNESS, os.path.join(CSRC, "host_arith_harness.hip")], cwd=CSRC)
+    return HOST_HARNESS
+
+
+if __name__ == "__main__":
+    print(build_lib(verbose=True))

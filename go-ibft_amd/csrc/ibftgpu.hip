@@ -422,6 +422,19 @@ int ibft_seals_device_ptrs(ibft_ctx *c, void **d_mask, size_t *mask_words_out, v
   return IBFT_OK;
 }
 
+int ibft_seals_export(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t mw = (size_t)mask_words(c->staged_n);
+  if (d_mask_dst && mw)
+    HIPCHK(c, hipMemcpyAsync(d_mask_dst, c->d_mask.p, mw * 8, hipMemcpyDeviceToDevice, c->stream));
+  if (d_tally_dst)
+    HIPCHK(c, hipMemcpyAsync(d_tally_dst, c->d_tally.p, 4 * 8, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return IBFT_OK;
+}
+
 int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
   if (!c || !ms) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);

@@ -1,0 +1,234 @@
+"""ctypes mirror of include/ibftgpu.h — the batch form of go-ibft's Verifier.
+
+Method names follow the reference interface they replace
+(/root/reference/core/backend.go:37-56):
+
+    IsValidProposalHash(proposal, hash)        -> BatchVerifier.is_valid_proposal_hash(raw, round, hashes)
+    IsValidCommittedSeal(proposalHash, seal)   -> BatchVerifier.is_valid_committed_seal(hashes, seals, signers)
+    IsValidValidator(msg)                      -> BatchVerifier.is_valid_validator(payloads, sigs, froms)
+    ValidatorManager.HasQuorum(senders)        -> the Tally returned next to each verdict array
+
+Every method returns a numpy bool array (one verdict per row) — the value the
+per-message reference predicate would have returned.  No CPU fallback: a missing
+library or device raises ``GpuUnavailable``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB
+
+FLAG_STRICT_LOW_S = 1
+ROW_NIL, ROW_BADLEN, ROW_HASH_BAD = 1, 2, 4
+KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE = 0, 1, 2
+
+EXPORTS = [
+    "ibft_version", "ibft_strerror", "ibft_last_error", "ibft_ctx_create", "ibft_ctx_destroy",
+    "ibft_set_validators", "ibft_verify_hashes", "ibft_proposal_hash", "ibft_verify_seals",
+    "ibft_verify_senders", "ibft_tally", "ibft_seals_stage", "ibft_seals_launch", "ibft_seals_fetch",
+    "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_sync",
+]
+
+
+class GpuUnavailable(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("max_rows", C.c_uint32),
+                ("kernel", C.c_uint32)]
+
+
+class Tally(C.Structure):
+    _fields_ = [("quorum_lo", C.c_uint64), ("quorum_hi", C.c_uint64),
+                ("power_lo", C.c_uint64), ("power_hi", C.c_uint64),
+                ("valid_rows", C.c_uint32), ("distinct_senders", C.c_uint32),
+                ("has_quorum", C.c_uint32), ("reserved", C.c_uint32)]
+
+    @property
+    def power(self) -> int:
+        return self.power_lo | (self.power_hi << 64)
+
+    @property
+    def quorum(self) -> int:
+        return self.quorum_lo | (self.quorum_hi << 64)
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libibftgpu.so and declare the prototypes (works without a GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise GpuUnavailable(f"{LIB} is not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB)
+    vp = C.c_void_p
+    L.ibft_version.restype = C.c_int
+    L.ibft_strerror.argtypes = [C.c_int]; L.ibft_strerror.restype = C.c_char_p
+    L.ibft_last_error.argtypes = [vp]; L.ibft_last_error.restype = C.c_char_p
+    L.ibft_ctx_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+    L.ibft_ctx_destroy.argtypes = [vp]; L.ibft_ctx_destroy.restype = None
+    L.ibft_set_validators.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
+    L.ibft_verify_hashes.argtypes = [vp, vp, C.c_size_t, C.c_uint64, vp, vp, C.c_size_t, vp]
+    L.ibft_proposal_hash.argtypes = [vp, vp, C.c_size_t, C.c_uint64, vp]
+    L.ibft_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
+    L.ibft_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
+    L.ibft_tally.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(Tally)]
+    L.ibft_seals_stage.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
+    L.ibft_seals_launch.argtypes = [vp, C.c_uint32]
+    L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
+    L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
+    L.ibft_seals_export.argtypes = [vp, vp, vp]
+    L.ibft_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.ibft_sync.argtypes = [vp]
+    for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a.reshape(shape) if shape is not None else a
+
+
+def mask_to_bool(mask: np.ndarray, n: int) -> np.ndarray:
+    bits = np.unpackbits(mask.view(np.uint8), bitorder="little")
+    return bits[:n].astype(bool)
+
+
+def bool_to_mask(v: np.ndarray) -> np.ndarray:
+    n = len(v)
+    words = (n + 63) // 64
+    bits = np.zeros(words * 64, dtype=np.uint8)
+    bits[:n] = np.asarray(v, dtype=np.uint8)
+    return np.packbits(bits, bitorder="little").view(np.uint64).copy()
+
+
+class BatchVerifier:
+    """One ibft_ctx: one HIP stream + resident columns on one MI355X."""
+
+    def __init__(self, device: int = 0, flags: int = 0, max_rows: int = 65536, kernel: int = KERNEL_AUTO):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        cfg = Cfg(device, flags, max_rows, kernel)
+        rc = self._L.ibft_ctx_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise GpuUnavailable(f"ibft_ctx_create: {self._L.ibft_strerror(rc).decode()} ({rc})")
+        self.max_rows = max_rows
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.ibft_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _chk(self, rc: int, what: str):
+        if rc != 0:
+            detail = self._L.ibft_last_error(self._h).decode()
+            raise RuntimeError(f"{what}: {self._L.ibft_strerror(rc).decode()} ({rc}) {detail}")
+
+    # ValidatorBackend.GetVotingPowers -> device table
+    def set_validators(self, height: int, addrs20, power) -> None:
+        a = _u8(addrs20, (-1, 20)); p = np.ascontiguousarray(power, dtype=np.uint64)
+        assert len(a) == len(p)
+        self._chk(self._L.ibft_set_validators(self._h, height, _p(a), _p(p), len(p)), "ibft_set_validators")
+
+    def try_set_validators(self, height: int, addrs20, power) -> int:
+        a = _u8(addrs20, (-1, 20)); p = np.ascontiguousarray(power, dtype=np.uint64)
+        return self._L.ibft_set_validators(self._h, height, _p(a), _p(p), len(p))
+
+    def proposal_hash(self, raw: bytes, round_: int) -> bytes:
+        out = np.zeros(32, dtype=np.uint8)
+        r = np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
+        self._chk(self._L.ibft_proposal_hash(self._h, _p(r), len(raw), round_, _p(out)), "ibft_proposal_hash")
+        return out.tobytes()
+
+    # Verifier.IsValidProposalHash, batched
+    def is_valid_proposal_hash(self, raw: bytes, round_: int, hash32, hash_len) -> np.ndarray:
+        h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
+        n = len(hl)
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        r = np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
+        self._chk(self._L.ibft_verify_hashes(self._h, _p(r), len(raw), round_, _p(h), _p(hl), n, _p(mask)),
+                  "ibft_verify_hashes")
+        return mask_to_bool(mask, n)
+
+    # Verifier.IsValidCommittedSeal, batched
+    def is_valid_committed_seal(self, hash32, sig65, signer20, pre_flags=None):
+        h = _u8(hash32, (-1, 32)); s = _u8(sig65, (-1, 65)); f = _u8(signer20, (-1, 20))
+        n = len(s)
+        pre = None if pre_flags is None else _u8(pre_flags)
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_verify_seals(self._h, _p(h), _p(s), _p(f), _p(pre), n, _p(mask), C.byref(t)),
+                  "ibft_verify_seals")
+        return mask_to_bool(mask, n), t
+
+    # Verifier.IsValidValidator, batched
+    def is_valid_validator(self, payload: bytes, off, sig65, from20, pre_flags=None):
+        pl = np.frombuffer(bytes(payload) or b"\0", dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        s = _u8(sig65, (-1, 65)); f = _u8(from20, (-1, 20))
+        n = len(s)
+        pre = None if pre_flags is None else _u8(pre_flags)
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_verify_senders(self._h, _p(pl), _p(off), _p(s), _p(f), _p(pre), n, _p(mask),
+                                              C.byref(t)), "ibft_verify_senders")
+        return mask_to_bool(mask, n), t
+
+    # ValidatorManager.HasQuorum over a caller-supplied verdict array
+    def has_quorum(self, sender20, verdict) -> Tally:
+        f = _u8(sender20, (-1, 20))
+        m = bool_to_mask(np.asarray(verdict, dtype=bool))
+        t = Tally()
+        self._chk(self._L.ibft_tally(self._h, _p(f), _p(m), len(f), C.byref(t)), "ibft_tally")
+        return t
+
+    # staged / device-resident form of a2 (bench.py, multi-GPU)
+    def seals_stage(self, hash32, sig65, signer20, pre_flags=None) -> int:
+        h = _u8(hash32, (-1, 32)); s = _u8(sig65, (-1, 65)); f = _u8(signer20, (-1, 20))
+        pre = None if pre_flags is None else _u8(pre_flags)
+        self._chk(self._L.ibft_seals_stage(self._h, _p(h), _p(s), _p(f), _p(pre), len(s)), "ibft_seals_stage")
+        self._staged = len(s)
+        return len(s)
+
+    def seals_launch(self, repeat: int = 1) -> None:
+        self._chk(self._L.ibft_seals_launch(self._h, repeat), "ibft_seals_launch")
+
+    def seals_fetch(self):
+        n = self._staged
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_seals_fetch(self._h, _p(mask), C.byref(t)), "ibft_seals_fetch")
+        return mask_to_bool(mask, n), t
+
+    def seals_device_ptrs(self):
+        dm, dt, w = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._chk(self._L.ibft_seals_device_ptrs(self._h, C.byref(dm), C.byref(w), C.byref(dt)), "device_ptrs")
+        return dm.value, w.value, dt.value
+
+    def seals_export(self, d_mask_ptr: int | None, d_tally_ptr: int | None) -> None:
+        """D2D copy of mask/tally into caller-owned device memory (torch data_ptr), then sync."""
+        self._chk(self._L.ibft_seals_export(self._h, d_mask_ptr, d_tally_ptr), "ibft_seals_export")
+
+    def last_kernel_ms(self):
+        ms, k = C.c_float(), C.c_uint32()
+        self._chk(self._L.ibft_last_kernel_ms(self._h, C.byref(ms), C.byref(k)), "ibft_last_kernel_ms")
+        return ms.value, k.value
+
+    def sync(self):
+        self._chk(self._L.ibft_sync(self._h), "ibft_sync")

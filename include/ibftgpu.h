@@ -152,6 +152,11 @@ int ibft_seals_fetch(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
  * u64 tally accumulators {power, valid_rows|distinct<<32}: lets the caller run an
  * RCCL all-reduce over validator shards without a host round trip.                 */
 int ibft_seals_device_ptrs(ibft_ctx *ctx, void **d_mask, size_t *mask_words, void **d_tally);
+/* Copy the resident verdict mask (⌈n/64⌉ u64) and the 4 tally words {power_lo,
+ * power_hi, valid_rows|distinct<<32, has_quorum} into caller-owned DEVICE buffers
+ * (e.g. a torch tensor's data_ptr) and wait for the copy: the hand-off point to an
+ * RCCL all-reduce issued by the caller.  Either pointer may be NULL.               */
+int ibft_seals_export(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst);
 /* HIP-event time (ms) of the dominant kernel summed over the last launch, and its
  * launch count; measured on the context's own stream.                              */
 int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);

@@ -1,0 +1,186 @@
+"""GPU parity tests (run on the MI355X box with `pytest -m gpu`): the HIP path, called
+through the C ABI (libibftgpu.so), must agree BIT-FOR-BIT with the CPU oracle and with
+the committed golden fixtures.  Integer/byte work: exact equality, no tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name):
+    return np.load(os.path.join(HERE, "golden", name + ".npz"))
+
+
+def _check_round(bv, oracle, r, flags=0):
+    """r: oracle.workload.Round.  Compare every entry point with the oracle."""
+    vs = oracle.ValSet(r.addrs, r.power)
+    bv.set_validators(r.height, r.addrs, r.power)
+    got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+    exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, flags=flags, nthreads=8)
+    assert (got == exp.astype(bool)).all(), np.nonzero(got != exp.astype(bool))[0][:10]
+    te = oracle.tally(vs, r.signer20, exp)
+    assert (t.power, t.quorum, t.has_quorum, t.valid_rows, t.distinct_senders) == \
+           (te.power, te.quorum, te.has_quorum, te.valid_rows, te.distinct_senders)
+    return got, t
+
+
+@pytest.mark.parametrize("name", ["round_n64_honest", "round_n100_byz_weighted", "round_n256_byz"])
+def test_golden_fixtures(gpu_verifier, name):
+    g = _load(name)
+    bv = gpu_verifier
+    bv.set_validators(int(g["height"]), g["addrs"], g["power"])
+    raw = g["raw"].tobytes()
+    assert bv.proposal_hash(raw, int(g["round"])) == g["proposal_hash"].tobytes()
+    hashes = bv.is_valid_proposal_hash(raw, int(g["round"]), g["hash32"], g["hash_len"])
+    assert (hashes == g["exp_hashes"].astype(bool)).all()
+    seals, t = bv.is_valid_committed_seal(g["hash32"], g["seal65"], g["signer20"], g["pre_flags"])
+    assert (seals == g["exp_seals"].astype(bool)).all()
+    assert t.power == int(g["exp_power"][0]) | (int(g["exp_power"][1]) << 64)
+    assert t.quorum == int(g["exp_quorum"][0]) | (int(g["exp_quorum"][1]) << 64)
+    assert t.has_quorum == int(g["exp_has_quorum"]) and t.distinct_senders == int(g["exp_distinct"])
+    senders, _ = bv.is_valid_validator(g["payload"].tobytes(), g["off"], g["msg_sig65"], g["signer20"])
+    assert (senders == g["exp_senders"].astype(bool)).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_ragged_sizes_vs_oracle(gpu_verifier, oracle, n):
+    from oracle import workload as W
+    r = W.make_round(n, 100 + n, byzantine=True, weighted=True)
+    _check_round(gpu_verifier, oracle, r)
+
+
+def test_empty_batch(gpu_verifier, oracle):
+    from oracle import workload as W
+    r = W.make_round(4, 1)
+    bv = gpu_verifier
+    bv.set_validators(1, r.addrs, r.power)
+    z = np.zeros((0,), np.uint8)
+    got, t = bv.is_valid_committed_seal(z.reshape(0, 32), z.reshape(0, 65), z.reshape(0, 20))
+    assert len(got) == 0 and t.has_quorum == 0 and t.power == 0 and t.quorum == 3
+    assert len(bv.is_valid_proposal_hash(r.raw, 0, z.reshape(0, 32), z)) == 0
+
+
+def test_config2_n1024_commit_round(gpu_verifier, oracle):
+    """BASELINE config #2: N=1024 validators, single round of COMMIT seals."""
+    g = _load("bench_commit_n1024")
+    bv = gpu_verifier
+    bv.set_validators(1, g["addrs"], g["power"])
+    got, t = bv.is_valid_committed_seal(g["hash32"], g["seal65"], g["signer20"])
+    assert got.all() and t.has_quorum == 1 and t.power == 1024 and t.quorum == 683
+    vs = oracle.ValSet(g["addrs"], g["power"])
+    exp = oracle.verify_seals(vs, g["hash32"], g["seal65"], g["signer20"], nthreads=8)
+    assert (got == exp.astype(bool)).all()
+
+
+def test_config3_n4096_prepare_commit_sequence(gpu_verifier, oracle):
+    """BASELINE config #3: N=4096, PREPARE senders + hash check + COMMIT senders + seals."""
+    from oracle import workload as W
+    r = W.make_round(4096, 3, byzantine=True, with_envelopes=True)
+    got, t = _check_round(gpu_verifier, oracle, r)
+    vs = oracle.ValSet(r.addrs, r.power)
+    bv = gpu_verifier
+    hashes = bv.is_valid_proposal_hash(r.raw, r.round, r.hash32, r.hash_len)
+    assert (hashes == oracle.verify_hashes(r.raw, r.round, r.hash32, r.hash_len).astype(bool)).all()
+    senders, _ = bv.is_valid_validator(r.payload, r.off, r.msg_sig65, r.signer20)
+    assert (senders == oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)).all()
+    # the a1∧a2 composition of handleCommit (core/ibft.go:932-944)
+    assert ((hashes & got) == got).all()
+
+
+def test_quorum_boundary(gpu_verifier, oracle):
+    """Exactly quorum-1 and quorum valid seals (validator_manager.go:95: power >= quorum)."""
+    from oracle import workload as W
+    r = W.make_round(100, 77)
+    bv = gpu_verifier
+    vs = oracle.ValSet(r.addrs, r.power)
+    q = vs.quorum  # 67
+    for k, want in ((q - 1, 0), (q, 1)):
+        seal = r.seal65.copy()
+        seal[k:, 40] ^= 0xFF  # corrupt s of the rows beyond k
+        bv.set_validators(1, r.addrs, r.power)
+        got, t = bv.is_valid_committed_seal(r.hash32, seal, r.signer20)
+        exp = oracle.verify_seals(vs, r.hash32, seal, r.signer20)
+        assert (got == exp.astype(bool)).all() and int(got.sum()) == k
+        assert t.has_quorum == want and t.power == k
+
+
+def test_duplicates_nonmembers_and_tally_entry(gpu_verifier, oracle):
+    from oracle import workload as W
+    r = W.make_round(32, 5, weighted=True)
+    bv = gpu_verifier
+    # validator set = first 24 only: rows 24..31 are valid signatures by NON-members
+    bv.set_validators(1, r.addrs[:24], r.power[:24])
+    vs = oracle.ValSet(r.addrs[:24], r.power[:24])
+    got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)
+    exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20)
+    assert (got == exp.astype(bool)).all() and got[:24].all() and not got[24:].any()
+    # duplicate senders in one batch count once (map semantics, validator_manager.go:147-155)
+    idx = np.array([0, 1, 2, 0, 1, 2, 30, 31])
+    verdict = np.ones(8, bool)
+    tg = bv.has_quorum(r.signer20[idx], verdict)
+    te = oracle.tally(vs, r.signer20[idx], verdict.astype(np.uint8))
+    assert (tg.power, tg.distinct_senders, tg.valid_rows, tg.has_quorum) == \
+           (te.power, te.distinct_senders, te.valid_rows, te.has_quorum)
+    assert tg.distinct_senders == 3 and tg.power == int(r.power[:3].sum())
+
+
+def test_zero_power_and_missing_valset():
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    r = W.make_round(4, 9)
+    bv = V.BatchVerifier(max_rows=1024)
+    try:
+        with pytest.raises(RuntimeError, match="validator set not configured"):
+            bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)
+        assert bv.try_set_validators(1, r.addrs, np.zeros(4, np.uint64)) == -6  # errVotingPowerNotCorrect
+        with pytest.raises(RuntimeError, match="exceeds max_rows"):
+            bv.set_validators(1, r.addrs, r.power)
+            big = W.make_round(4, 9)
+            bv.is_valid_committed_seal(np.zeros((2000, 32), np.uint8), np.zeros((2000, 65), np.uint8),
+                                       np.zeros((2000, 20), np.uint8))
+    finally:
+        bv.close()
+
+
+def test_strict_low_s_flag(oracle):
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    n_order = W.N_ORDER
+    r = W.make_round(64, 21)
+    seal = r.seal65.copy()
+    for i in range(0, 64, 2):  # replace by the high-s twin
+        s = int.from_bytes(seal[i, 32:64].tobytes(), "big")
+        seal[i, 32:64] = np.frombuffer((n_order - s).to_bytes(32, "big"), np.uint8)
+        seal[i, 64] ^= 1
+    vs = oracle.ValSet(r.addrs, r.power)
+    for flags in (0, V.FLAG_STRICT_LOW_S):
+        bv = V.BatchVerifier(flags=flags, max_rows=1024)
+        try:
+            bv.set_validators(1, r.addrs, r.power)
+            got, _ = bv.is_valid_committed_seal(r.hash32, seal, r.signer20)
+            exp = oracle.verify_seals(vs, r.hash32, seal, r.signer20, flags=flags)
+            assert (got == exp.astype(bool)).all()
+            assert got[1::2].all() and got[0::2].all() == (flags == 0)
+        finally:
+            bv.close()
+
+
+def test_large_n_properties(gpu_verifier, oracle):
+    """N=16384 (one GPU's shard of configs 4/5): full oracle comparison is affordable with
+    8 host threads; also size-independent properties — the verdict of a row is independent
+    of its neighbours (permutation equivariance) and idempotent across repeated launches."""
+    from oracle import workload as W
+    r = W.make_round(16384, 4, byzantine=True)
+    got, t = _check_round(gpu_verifier, oracle, r)
+    bv = gpu_verifier
+    perm = np.random.default_rng(0).permutation(r.n)
+    got_p, t_p = bv.is_valid_committed_seal(r.hash32[perm], r.seal65[perm], r.signer20[perm], r.pre_flags[perm])
+    assert (got_p == got[perm]).all() and t_p.power == t.power and t_p.has_quorum == t.has_quorum
+    bv.seals_stage(r.hash32, r.seal65, r.signer20, r.pre_flags)
+    bv.seals_launch(3)
+    again, t3 = bv.seals_fetch()
+    assert (again == got).all() and t3.power == t.power

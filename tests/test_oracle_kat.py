@@ -1,0 +1,82 @@
+"""Pin the CPU oracle (oracle/*.c) with public known-answer vectors.
+
+The reference pins none of this arithmetic, so these KATs + the
+independent derivations in test_oracle_xcheck.py are what anchors it.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_keccak_kats(oracle):
+    assert oracle.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert oracle.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    # NOT NIST SHA3-256 (0x06 padding): the two must differ
+    import hashlib
+    assert oracle.keccak256(b"") != hashlib.sha3_256(b"").digest()
+    # well-known Ethereum vectors
+    assert oracle.keccak256(b"hello").hex() == "1c8aff950685c2ed4bc3174f3472287b56d9517b9c948127319a09a7a36deac8"
+    assert oracle.keccak256(b"transfer(address,uint256)").hex()[:8] == "a9059cbb"
+
+
+def test_curve_kats(oracle):
+    one = (1).to_bytes(32, "big")
+    pub = oracle.pubkey(one)
+    assert pub.hex() == ("79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798"
+                         "483ada7726a3c4655da4fbfc0e1108a8fd17b448a68554199c47d08ffb10d4b8")
+    assert oracle.address(pub).hex() == "7e5f4552091a69125d5dfcb7b8c2659029395bdf"
+    two = oracle.pubkey((2).to_bytes(32, "big"))
+    assert two.hex() == ("c6047f9441ed7d6d3045406e95c07cd85c778e4b8cef3ca7abac09b95c709ee5"
+                         "1ae168fea63dc339a3c58419466ceaeef7f632653266d0e1236431a950cfe52a")
+    assert oracle.address(two).hex() == "2b5ad5c4795c026514f8317c7a215e218dccd6cf"
+    # n*G = infinity, (n-1)*G = -G
+    n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    assert oracle.pubkey(n.to_bytes(32, "big")) is None and oracle.pubkey(bytes(32)) is None
+    neg = oracle.pubkey((n - 1).to_bytes(32, "big"))
+    p = 2**256 - 2**32 - 977
+    assert neg[:32] == pub[:32] and int.from_bytes(neg[32:], "big") == p - int.from_bytes(pub[32:], "big")
+
+
+def test_committed_kats_match(oracle):
+    k = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+    one = (1).to_bytes(32, "big")
+    assert oracle.keccak256(b"").hex() == k["keccak256_empty"]
+    assert oracle.pubkey(one).hex() == k["sk1_pub"]
+    d = bytes.fromhex(k["digest"])
+    assert oracle.sign(one, d).hex() == k["sk1_sig"]
+    assert oracle.recover_address(d, bytes.fromhex(k["sk1_sig"])).hex() == k["sk1_addr"]
+
+
+def test_sign_recover_roundtrip_and_rejections(oracle):
+    n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+    rng = np.random.default_rng(5)
+    for i in range(40):
+        sk = (int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1).to_bytes(32, "big")
+        d = rng.bytes(32)
+        sig = oracle.sign(sk, d)
+        addr = oracle.address(oracle.pubkey(sk))
+        assert oracle.recover_address(d, sig) == addr
+        assert int.from_bytes(sig[32:64], "big") <= n // 2  # signer emits low-s
+        # flipped v recovers a different key
+        assert oracle.recover_address(d, sig[:64] + bytes([sig[64] ^ 1])) != addr
+        # high-s twin: accepted by default (go-ethereum Ecrecover semantics), rejected when strict
+        s = int.from_bytes(sig[32:64], "big")
+        twin = sig[:32] + (n - s).to_bytes(32, "big") + bytes([sig[64] ^ 1])
+        assert oracle.recover_address(d, twin) == addr
+        assert oracle.recover_address(d, twin, oracle.FLAG_STRICT_LOW_S) is None
+        for bad in (bytes(32) + sig[32:], sig[:32] + bytes(32) + sig[64:], n.to_bytes(32, "big") + sig[32:],
+                    sig[:32] + n.to_bytes(32, "big") + sig[64:], sig[:64] + b"\x02", sig[:64] + b"\x1b"):
+            assert oracle.recover_address(d, bad) is None
+
+
+@pytest.mark.parametrize("total,quorum", [(4, 3), (6, 5), (9, 7), (10, 7), (21, 15)])
+def test_quorum_table(oracle, total, quorum):
+    """Totals/quorums of /root/reference/core/validator_manager_test.go:18-187."""
+    addrs = np.arange(total * 20, dtype=np.uint64).astype(np.uint8).reshape(total, 20)
+    addrs[:, 0] = np.arange(total)
+    vs = oracle.ValSet(addrs, np.ones(total, dtype=np.uint64))
+    assert vs.quorum == quorum
