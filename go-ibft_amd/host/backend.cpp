@@ -1,0 +1,195 @@
+// backend.cpp — see backend.hpp.
+#include "backend.hpp"
+
+#include <cstring>
+
+namespace ibft {
+
+static void put_fixed(std::vector<uint8_t> &col, const bytes *src, size_t width, bool &bad) {
+  size_t base = col.size();
+  col.resize(base + width, 0);
+  if (src && src->size() == width)
+    memcpy(col.data() + base, src->data(), width);
+  else
+    bad = true;
+}
+
+void flatten_commits(const std::vector<MsgPtr> &msgs, SealColumns &c) {
+  c = SealColumns{};
+  c.n = msgs.size();
+  for (const auto &m : msgs) {
+    const bytes *hash = extract_commit_hash(*m);             // nil if wrong type/payload
+    std::optional<CommittedSeal> seal = extract_committed_seal(*m);
+    uint8_t pre = 0;
+    bool bad = false;
+    put_fixed(c.hash32, hash, 32, bad);
+    c.hash_len.push_back(hash ? (uint8_t)(hash->size() > 255 ? 255 : hash->size()) : 0);
+    if (!hash || !seal) pre |= IBFT_ROW_NIL;
+    bad = false;
+    put_fixed(c.sig65, seal ? &seal->signature : nullptr, 65, bad);
+    if (bad) pre |= IBFT_ROW_BADLEN;
+    bad = false;
+    put_fixed(c.signer20, seal ? &seal->signer : nullptr, 20, bad);
+    if (bad) pre |= IBFT_ROW_BADLEN;
+    c.pre_flags.push_back(pre);
+  }
+}
+
+void flatten_prepares(const std::vector<MsgPtr> &msgs, SealColumns &c) {
+  c = SealColumns{};
+  c.n = msgs.size();
+  for (const auto &m : msgs) {
+    const bytes *hash = extract_prepare_hash(*m);
+    bool bad = false;
+    put_fixed(c.hash32, hash, 32, bad);
+    c.hash_len.push_back(hash ? (uint8_t)(hash->size() > 255 ? 255 : hash->size()) : 0);
+  }
+}
+
+void flatten_senders(const std::vector<MsgPtr> &msgs, SenderColumns &c) {
+  c = SenderColumns{};
+  c.n = msgs.size();
+  c.off.push_back(0);
+  for (const auto &m : msgs) {
+    bytes pns = payload_no_sig(*m);
+    c.payload.insert(c.payload.end(), pns.begin(), pns.end());
+    c.off.push_back((uint32_t)c.payload.size());
+    uint8_t pre = 0;
+    bool bad = false;
+    put_fixed(c.sig65, &m->signature, 65, bad);
+    put_fixed(c.from20, &m->from, 20, bad);
+    if (bad) pre |= IBFT_ROW_BADLEN;
+    c.pre_flags.push_back(pre);
+  }
+}
+
+static void unpack_mask(const std::vector<uint64_t> &mask, size_t n, std::vector<uint8_t> &v) {
+  v.assign(n, 0);
+  for (size_t i = 0; i < n; i++) v[i] = (mask[i >> 6] >> (i & 63)) & 1;
+}
+
+bool GpuBackend::VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
+                                    std::vector<uint8_t> &verdict) {
+  verdict.assign(msgs.size(), 0);
+  if (!proposal || msgs.empty()) return true;  // nil proposal: every hash check is false
+  SealColumns c;
+  flatten_prepares(msgs, c);
+  std::vector<uint64_t> mask((c.n + 63) / 64, 0);
+  last_rc = ibft_verify_hashes(ctx_, (const uint8_t *)proposal->raw_proposal.data(), proposal->raw_proposal.size(),
+                               proposal->round, c.hash32.data(), c.hash_len.data(), c.n, mask.data());
+  if (last_rc != IBFT_OK) return false;
+  unpack_mask(mask, c.n, verdict);
+  return true;
+}
+
+bool GpuBackend::VerifyCommitBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
+                                   std::vector<uint8_t> &verdict) {
+  verdict.assign(msgs.size(), 0);
+  if (!proposal || msgs.empty()) return true;
+  SealColumns c;
+  flatten_commits(msgs, c);
+  std::vector<uint64_t> m1((c.n + 63) / 64, 0), m2((c.n + 63) / 64, 0);
+  last_rc = ibft_verify_hashes(ctx_, (const uint8_t *)proposal->raw_proposal.data(), proposal->raw_proposal.size(),
+                               proposal->round, c.hash32.data(), c.hash_len.data(), c.n, m1.data());
+  if (last_rc != IBFT_OK) return false;
+  // a2 is skipped where a1 failed (ibft.go:938-943): mark those rows so the device does no work
+  for (size_t i = 0; i < c.n; i++)
+    if (!((m1[i >> 6] >> (i & 63)) & 1)) c.pre_flags[i] |= IBFT_ROW_HASH_BAD;
+  last_rc = ibft_verify_seals(ctx_, c.hash32.data(), c.sig65.data(), c.signer20.data(), c.pre_flags.data(), c.n,
+                              m2.data(), nullptr);
+  if (last_rc != IBFT_OK) return false;
+  unpack_mask(m2, c.n, verdict);
+  return true;
+}
+
+bool GpuBackend::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &verdict) {
+  verdict.assign(msgs.size(), 0);
+  if (msgs.empty()) return true;
+  SenderColumns c;
+  flatten_senders(msgs, c);
+  std::vector<uint64_t> mask((c.n + 63) / 64, 0);
+  last_rc = ibft_verify_senders(ctx_, c.payload.data(), c.off.data(), c.sig65.data(), c.from20.data(),
+                                c.pre_flags.data(), c.n, mask.data(), nullptr);
+  if (last_rc != IBFT_OK) return false;
+  unpack_mask(mask, c.n, verdict);
+  return true;
+}
+
+bool HotPath::isAcceptableMessage(const IbftMessage &m) {
+  if (!verifier || !verifier->IsValidValidator(m)) return false;  // ibft.go:1128
+  if (!m.view) return false;                                       // :1133
+  if (height > m.view->height) return false;                       // :1139
+  if (height == m.view->height) return m.view->round >= round;     // :1144
+  return true;
+}
+
+bool HotPath::hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type) {
+  switch (type) {
+    case PREPREPARE: return msgs.size() >= 1;
+    case PREPARE: return validatorManager.HasPrepareQuorum(proposalMessage.get(), msgs);
+    case ROUND_CHANGE:
+    case COMMIT: return validatorManager.HasQuorum(convertMessageToAddressSet(msgs));
+    default: return false;
+  }
+}
+
+int HotPath::AddMessage(MsgPtr m) {
+  if (!m) return 0;
+  if (!isAcceptableMessage(*m)) return 0;
+  View view = *m->view;
+  uint32_t type = m->type;
+  messages.AddMessage(m);
+  if (view.height == height) {  // ibft.go:1113-1120
+    auto msgs = messages.GetValidMessages(view, (MessageType)type, [](const IbftMessage &) { return true; });
+    if (hasQuorumByMsgType(msgs, type)) return 2;
+  }
+  return 1;
+}
+
+bool HotPath::handlePrepare(const View &view) {
+  std::vector<MsgPtr> prepareMessages;
+  const Proposal *proposal = getProposal();
+  if (use_batch && batch) {
+    prepareMessages = messages.GetValidMessagesBatch(view, PREPARE, [&](const std::vector<MsgPtr> &all) {
+      std::vector<uint8_t> v;
+      if (!batch->VerifyPrepareBatch(proposal, all, v)) v.clear();
+      return v;
+    });
+  } else {
+    prepareMessages = messages.GetValidMessages(view, PREPARE, [&](const IbftMessage &m) {
+      return verifier->IsValidProposalHash(proposal, extract_prepare_hash(m));
+    });
+  }
+  if (!hasQuorumByMsgType(prepareMessages, PREPARE)) return false;
+  // sendCommitMessage(view) is the Go side's business; finalizePrepare: state.go
+  preparedMessages = prepareMessages;
+  stateName = StateName::commit;
+  return true;
+}
+
+bool HotPath::handleCommit(const View &view) {
+  std::vector<MsgPtr> commitMessages;
+  const Proposal *proposal = getProposal();
+  if (use_batch && batch) {
+    commitMessages = messages.GetValidMessagesBatch(view, COMMIT, [&](const std::vector<MsgPtr> &all) {
+      std::vector<uint8_t> v;
+      if (!batch->VerifyCommitBatch(proposal, all, v)) v.clear();
+      return v;
+    });
+  } else {
+    commitMessages = messages.GetValidMessages(view, COMMIT, [&](const IbftMessage &m) {
+      const bytes *proposalHash = extract_commit_hash(m);
+      std::optional<CommittedSeal> seal = extract_committed_seal(m);
+      if (!verifier->IsValidProposalHash(proposal, proposalHash)) return false;
+      return verifier->IsValidCommittedSeal(proposalHash, seal ? &*seal : nullptr);
+    });
+  }
+  if (!hasQuorumByMsgType(commitMessages, COMMIT)) return false;
+  std::vector<std::optional<CommittedSeal>> seals;
+  if (!extract_committed_seals(commitMessages, seals)) return false;  // safe check, ibft.go:952-958
+  committedSeals = std::move(seals);
+  stateName = StateName::fin;
+  return true;
+}
+
+}  // namespace ibft

@@ -1,0 +1,96 @@
+// backend.hpp — the Verifier boundary as the host sees it, and the hot-path callers.
+//
+// Product host code.
+//   Verifier        = core.Verifier, per message (/root/reference/core/backend.go:37-56)
+//   BatchVerifier   = the OPTIONAL batch interface INTEGRATION.md adds next to it; one call
+//                     per GetValidMessages walk instead of one per message
+//   GpuBackend      = BatchVerifier on top of libibftgpu.so (include/ibftgpu.h): flattens
+//                     messages into byte columns (SoA), one C-ABI call per batch
+//   HotPath         = the callers around the boundary, restated from core/ibft.go:
+//                     AddMessage :1101-1123, isAcceptableMessage :1126-1149,
+//                     handlePrepare :855-889, handleCommit :931-967,
+//                     hasQuorumByMsgType :1273-1284.  RunSequence itself is untouched Go.
+#pragma once
+#include <memory>
+
+#include "../../include/ibftgpu.h"
+#include "messages.hpp"
+
+namespace ibft {
+
+struct Verifier {
+  virtual ~Verifier() = default;
+  // nil-able arguments are pointers, exactly like the Go interface
+  virtual bool IsValidProposalHash(const Proposal *proposal, const bytes *hash) = 0;
+  virtual bool IsValidCommittedSeal(const bytes *proposalHash, const CommittedSeal *seal) = 0;
+  virtual bool IsValidValidator(const IbftMessage &msg) = 0;
+};
+
+struct BatchVerifier {
+  virtual ~BatchVerifier() = default;
+  // verdict[i] == what handlePrepare's closure would return for msgs[i] (ibft.go:856-862)
+  virtual bool VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
+                                  std::vector<uint8_t> &verdict) = 0;
+  // verdict[i] == handleCommit's closure (ibft.go:932-944): a1 ∧ a2 with a2 short-circuited
+  virtual bool VerifyCommitBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
+                                 std::vector<uint8_t> &verdict) = 0;
+  // verdict[i] == IsValidValidator(msgs[i]) (ibft.go:1128)
+  virtual bool VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &verdict) = 0;
+};
+
+// SoA columns handed to the C ABI (plain bytes, no pointers inside: cgo-safe layout)
+struct SealColumns {
+  std::vector<uint8_t> hash32, hash_len, sig65, signer20, pre_flags;
+  size_t n = 0;
+};
+struct SenderColumns {
+  std::vector<uint8_t> payload, sig65, from20, pre_flags;
+  std::vector<uint32_t> off;
+  size_t n = 0;
+};
+// Flatten COMMIT messages (ExtractCommitHash / ExtractCommittedSeal) into columns; rows the
+// reference would reject without calling the crypto (nil payload, wrong lengths) get pre_flags.
+void flatten_commits(const std::vector<MsgPtr> &msgs, SealColumns &out);
+void flatten_prepares(const std::vector<MsgPtr> &msgs, SealColumns &out);  // hash32/hash_len only
+void flatten_senders(const std::vector<MsgPtr> &msgs, SenderColumns &out);
+
+class GpuBackend : public BatchVerifier {
+ public:
+  explicit GpuBackend(ibft_ctx *ctx) : ctx_(ctx) {}
+  bool VerifyPrepareBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  bool VerifyCommitBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  int last_rc = 0;
+
+ private:
+  ibft_ctx *ctx_;
+};
+
+enum class StateName { newRound, prepare, commit, fin };
+
+class HotPath {
+ public:
+  Messages messages;
+  ValidatorManager validatorManager;
+  Verifier *verifier = nullptr;     // stock path
+  BatchVerifier *batch = nullptr;   // optional; used when set and use_batch is true
+  bool use_batch = false;
+  // the slice of core/state.go the hot path reads
+  uint64_t height = 0, round = 0;
+  StateName stateName = StateName::newRound;
+  MsgPtr proposalMessage;  // state.getProposalMessage()
+  std::vector<std::optional<CommittedSeal>> committedSeals;
+  std::vector<MsgPtr> preparedMessages;  // PC.PrepareMessages after finalizePrepare
+
+  const Proposal *getProposal() const {  // state.go:135-144
+    return proposalMessage ? extract_proposal(*proposalMessage) : nullptr;
+  }
+  // IBFT.AddMessage: 0 = rejected, 1 = stored, 2 = stored and SignalEvent fired
+  int AddMessage(MsgPtr m);
+  bool isAcceptableMessage(const IbftMessage &m);
+  bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
+  bool handlePrepare(const View &view);
+  bool handleCommit(const View &view);
+};
+
+}  // namespace ibft

@@ -1,0 +1,271 @@
+// host_capi.cpp — C ABI of the host mirror (include/ibft_host.h).
+#include "../../include/ibft_host.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "backend.hpp"
+
+using namespace ibft;
+
+namespace {
+
+struct CallbackVerifier : Verifier {
+  ibft_host_verifier cb{};
+  bool IsValidProposalHash(const Proposal *p, const bytes *hash) override {
+    if (!cb.is_valid_proposal_hash) return true;  // mockBackend default (mock_test.go:105-151)
+    return cb.is_valid_proposal_hash(cb.user, p != nullptr, p ? (const uint8_t *)p->raw_proposal.data() : nullptr,
+                                     p ? p->raw_proposal.size() : 0, p ? p->round : 0, hash != nullptr,
+                                     hash ? (const uint8_t *)hash->data() : nullptr, hash ? hash->size() : 0) != 0;
+  }
+  bool IsValidCommittedSeal(const bytes *hash, const CommittedSeal *seal) override {
+    if (!cb.is_valid_committed_seal) return true;
+    return cb.is_valid_committed_seal(cb.user, hash != nullptr, hash ? (const uint8_t *)hash->data() : nullptr,
+                                      hash ? hash->size() : 0, seal != nullptr,
+                                      seal ? (const uint8_t *)seal->signer.data() : nullptr,
+                                      seal ? seal->signer.size() : 0,
+                                      seal ? (const uint8_t *)seal->signature.data() : nullptr,
+                                      seal ? seal->signature.size() : 0) != 0;
+  }
+  bool IsValidValidator(const IbftMessage &m) override {
+    if (!cb.is_valid_validator) return true;
+    bytes w = encode(m);
+    return cb.is_valid_validator(cb.user, (const uint8_t *)w.data(), w.size()) != 0;
+  }
+};
+
+void pack_bytes(bytes &o, const bytes &item) {
+  uint32_t l = (uint32_t)item.size();
+  o.append((const char *)&l, 4);
+  o += item;
+}
+bool unpack_list(const uint8_t *p, size_t len, std::vector<bytes> &out) {
+  size_t pos = 0;
+  while (pos < len) {
+    if (len - pos < 4) return false;
+    uint32_t l;
+    memcpy(&l, p + pos, 4);
+    pos += 4;
+    if (len - pos < l) return false;
+    out.emplace_back((const char *)p + pos, l);
+    pos += l;
+  }
+  return true;
+}
+bool unpack_msgs(const uint8_t *p, size_t len, std::vector<MsgPtr> &out) {
+  std::vector<bytes> items;
+  if (!unpack_list(p, len, items)) return false;
+  for (auto &w : items) {
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode((const uint8_t *)w.data(), w.size(), *m)) return false;
+    out.push_back(std::move(m));
+  }
+  return true;
+}
+void to_buf(const bytes &o, size_t count, ibft_host_buf *out) {
+  out->data = (uint8_t *)malloc(o.size() ? o.size() : 1);
+  memcpy(out->data, o.data(), o.size());
+  out->len = o.size();
+  out->count = count;
+}
+void msgs_to_buf(const std::vector<MsgPtr> &msgs, ibft_host_buf *out) {
+  bytes o;
+  for (auto &m : msgs) pack_bytes(o, encode(*m));
+  to_buf(o, msgs.size(), out);
+}
+void seals_to_buf(const std::vector<std::optional<CommittedSeal>> &seals, ibft_host_buf *out) {
+  bytes o;
+  for (auto &s : seals) {
+    o.push_back(s ? 1 : 0);
+    pack_bytes(o, s ? s->signer : bytes());
+    pack_bytes(o, s ? s->signature : bytes());
+  }
+  to_buf(o, seals.size(), out);
+}
+
+}  // namespace
+
+struct ibft_host {
+  HotPath hp;
+  CallbackVerifier cbv;
+  std::unique_ptr<GpuBackend> gpu;
+};
+
+extern "C" {
+
+ibft_host *ibft_host_new(void) {
+  auto *h = new ibft_host();
+  h->hp.verifier = &h->cbv;
+  return h;
+}
+void ibft_host_free(ibft_host *h) { delete h; }
+void ibft_host_buf_free(ibft_host_buf *b) {
+  if (b && b->data) free(b->data);
+  if (b) *b = ibft_host_buf{nullptr, 0, 0};
+}
+
+int ibft_host_payload_no_sig(const uint8_t *wire, size_t len, ibft_host_buf *out) {
+  IbftMessage m;
+  if (!decode(wire, len, m)) return -1;
+  to_buf(payload_no_sig(m), 1, out);
+  return 0;
+}
+int ibft_host_reencode(const uint8_t *wire, size_t len, ibft_host_buf *out) {
+  IbftMessage m;
+  if (!decode(wire, len, m)) return -1;
+  to_buf(encode(m), 1, out);
+  return 0;
+}
+
+int ibft_host_store_add(ibft_host *h, const uint8_t *wire, size_t len) {
+  auto m = std::make_shared<IbftMessage>();
+  if (!decode(wire, len, *m)) return -1;
+  h->hp.messages.AddMessage(std::move(m));
+  return 0;
+}
+size_t ibft_host_store_num(ibft_host *h, uint64_t height, uint64_t round, uint32_t type) {
+  return h->hp.messages.numMessages(View{height, round, {}}, (MessageType)type);
+}
+void ibft_host_store_prune(ibft_host *h, uint64_t height) { h->hp.messages.PruneByHeight(height); }
+
+int ibft_host_store_get_valid(ibft_host *h, uint64_t height, uint64_t round, uint32_t type,
+                              ibft_host_msg_pred pred, void *user, ibft_host_buf *out) {
+  auto msgs = h->hp.messages.GetValidMessages(View{height, round, {}}, (MessageType)type, [&](const IbftMessage &m) {
+    if (!pred) return true;
+    bytes w = encode(m);
+    return pred(user, (const uint8_t *)w.data(), w.size()) != 0;
+  });
+  msgs_to_buf(msgs, out);
+  return 0;
+}
+int ibft_host_store_get_extended_rcc(ibft_host *h, uint64_t height, ibft_host_msg_pred pred,
+                                     ibft_host_rcc_pred rcc_pred, void *user, ibft_host_buf *out) {
+  auto msgs = h->hp.messages.GetExtendedRCC(
+      height,
+      [&](const IbftMessage &m) {
+        if (!pred) return true;
+        bytes w = encode(m);
+        return pred(user, (const uint8_t *)w.data(), w.size()) != 0;
+      },
+      [&](uint64_t round, const std::vector<MsgPtr> &v) { return rcc_pred ? rcc_pred(user, round, v.size()) != 0 : true; });
+  msgs_to_buf(msgs, out);
+  return 0;
+}
+int ibft_host_store_get_most_rc(ibft_host *h, uint64_t min_round, uint64_t height, ibft_host_buf *out) {
+  msgs_to_buf(h->hp.messages.GetMostRoundChangeMessages(min_round, height), out);
+  return 0;
+}
+
+int ibft_host_has_unique_senders(const uint8_t *packed, size_t len) {
+  std::vector<MsgPtr> msgs;
+  if (!unpack_msgs(packed, len, msgs)) return -1;
+  return has_unique_senders(msgs) ? 1 : 0;
+}
+int ibft_host_are_valid_pc_messages(const uint8_t *packed, size_t len, uint64_t height, uint64_t round_limit) {
+  std::vector<MsgPtr> msgs;
+  if (!unpack_msgs(packed, len, msgs)) return -1;
+  return are_valid_pc_messages(msgs, height, round_limit) ? 1 : 0;
+}
+int ibft_host_extract_committed_seals(const uint8_t *packed, size_t len, ibft_host_buf *out) {
+  std::vector<MsgPtr> msgs;
+  if (!unpack_msgs(packed, len, msgs)) return -2;
+  std::vector<std::optional<CommittedSeal>> seals;
+  if (!extract_committed_seals(msgs, seals)) return -1;
+  seals_to_buf(seals, out);
+  return 0;
+}
+
+int ibft_host_vm_init(ibft_host *h, const uint8_t *packed_addrs, size_t len, const uint64_t *power, size_t n) {
+  std::vector<bytes> addrs;
+  if (!unpack_list(packed_addrs, len, addrs) || addrs.size() != n) return -2;
+  std::vector<std::pair<bytes, uint64_t>> p;
+  for (size_t i = 0; i < n; i++) p.emplace_back(addrs[i], power[i]);
+  return h->hp.validatorManager.Init(p) ? 0 : -1;
+}
+int ibft_host_vm_has_quorum(ibft_host *h, const uint8_t *packed_senders, size_t len) {
+  std::vector<bytes> s;
+  if (!unpack_list(packed_senders, len, s)) return -1;
+  return h->hp.validatorManager.HasQuorum(std::set<bytes>(s.begin(), s.end())) ? 1 : 0;
+}
+int ibft_host_vm_has_prepare_quorum(ibft_host *h, const uint8_t *proposal_wire, size_t proposal_len,
+                                    const uint8_t *packed_msgs, size_t len) {
+  std::vector<MsgPtr> msgs;
+  if (!unpack_msgs(packed_msgs, len, msgs)) return -1;
+  IbftMessage pm;
+  const IbftMessage *pp = nullptr;
+  if (proposal_wire) {
+    if (!decode(proposal_wire, proposal_len, pm)) return -1;
+    pp = &pm;
+  }
+  return h->hp.validatorManager.HasPrepareQuorum(pp, msgs) ? 1 : 0;
+}
+void ibft_host_vm_quorum(ibft_host *h, uint64_t *lo, uint64_t *hi) {
+  unsigned __int128 q = h->hp.validatorManager.quorum();
+  *lo = (uint64_t)q;
+  *hi = (uint64_t)(q >> 64);
+}
+
+int ibft_host_set_state(ibft_host *h, uint64_t height, uint64_t round, const uint8_t *proposal_wire,
+                        size_t proposal_len) {
+  h->hp.height = height;
+  h->hp.round = round;
+  h->hp.proposalMessage.reset();
+  if (proposal_wire) {
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode(proposal_wire, proposal_len, *m)) return -1;
+    h->hp.proposalMessage = std::move(m);
+  }
+  return 0;
+}
+void ibft_host_set_verifier(ibft_host *h, const ibft_host_verifier *v) {
+  h->cbv.cb = v ? *v : ibft_host_verifier{};
+}
+void ibft_host_attach_gpu(ibft_host *h, ibft_ctx *ctx) {
+  h->gpu = ctx ? std::make_unique<GpuBackend>(ctx) : nullptr;
+  h->hp.batch = h->gpu.get();
+}
+void ibft_host_use_batch(ibft_host *h, int on) { h->hp.use_batch = on != 0; }
+
+int ibft_host_add_message(ibft_host *h, const uint8_t *wire, size_t len) {
+  auto m = std::make_shared<IbftMessage>();
+  if (!decode(wire, len, *m)) return -1;
+  return h->hp.AddMessage(std::move(m));
+}
+
+int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n) {
+  std::vector<MsgPtr> msgs;
+  if (!unpack_msgs(packed, len, msgs) || msgs.size() != n) return -1;
+  if (!h->hp.batch) return -2;
+  std::vector<uint8_t> ok;
+  if (!h->hp.batch->VerifySenderBatch(msgs, ok)) return -3;
+  // Replay IBFT.AddMessage per message with IsValidValidator answered from the verdict table
+  struct TableVerifier : Verifier {
+    Verifier *inner;
+    bool verdict = false;
+    bool IsValidProposalHash(const Proposal *p, const bytes *hsh) override { return inner->IsValidProposalHash(p, hsh); }
+    bool IsValidCommittedSeal(const bytes *hsh, const CommittedSeal *s) override { return inner->IsValidCommittedSeal(hsh, s); }
+    bool IsValidValidator(const IbftMessage &) override { return verdict; }
+  } tv;
+  tv.inner = h->hp.verifier;
+  Verifier *saved = h->hp.verifier;
+  h->hp.verifier = &tv;
+  for (size_t i = 0; i < n; i++) {
+    tv.verdict = ok[i] != 0;
+    results[i] = (uint8_t)h->hp.AddMessage(msgs[i]);
+  }
+  h->hp.verifier = saved;
+  return 0;
+}
+
+int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared) {
+  bool q = h->hp.handlePrepare(View{height, round, {}});
+  if (prepared) msgs_to_buf(q ? h->hp.preparedMessages : std::vector<MsgPtr>{}, prepared);
+  return q ? 1 : 0;
+}
+int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals) {
+  bool q = h->hp.handleCommit(View{height, round, {}});
+  if (seals) seals_to_buf(q ? h->hp.committedSeals : std::vector<std::optional<CommittedSeal>>{}, seals);
+  return q ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// messages.cpp — see messages.hpp for the reference lines each method follows.
+#include "messages.hpp"
+
+namespace ibft {
+
+void Messages::AddMessage(MsgPtr m) {
+  int s = slot(m->type);
+  if (s < 0 || !m->view) return;  // the reference would panic on an unknown type / nil view
+  std::unique_lock lk(mux_[s]);
+  maps_[s][m->view->height][m->view->round][m->from] = std::move(m);
+}
+
+size_t Messages::numMessages(const View &view, MessageType type) {
+  int s = slot(type);
+  if (s < 0) return 0;
+  std::shared_lock lk(mux_[s]);
+  auto h = maps_[s].find(view.height);
+  if (h == maps_[s].end()) return 0;
+  auto r = h->second.find(view.round);
+  return r == h->second.end() ? 0 : r->second.size();
+}
+
+void Messages::PruneByHeight(uint64_t height) {
+  for (int s = 0; s < 4; s++) {
+    std::unique_lock lk(mux_[s]);
+    auto &m = maps_[s];
+    m.erase(m.begin(), m.lower_bound(height));  // delete every msgHeight < height
+  }
+}
+
+std::vector<MsgPtr> Messages::GetValidMessages(const View &view, MessageType type, const Predicate &isValid) {
+  std::vector<MsgPtr> valid;
+  int s = slot(type);
+  if (s < 0) return valid;
+  std::unique_lock lk(mux_[s]);  // write lock held across the callbacks, messages.go:174-176
+  auto h = maps_[s].find(view.height);
+  if (h == maps_[s].end()) return valid;
+  auto r = h->second.find(view.round);
+  if (r == h->second.end()) return valid;
+  for (auto it = r->second.begin(); it != r->second.end();) {
+    if (!isValid(*it->second)) {
+      it = r->second.erase(it);  // prune out invalid messages, messages.go:193-196
+    } else {
+      valid.push_back(it->second);
+      ++it;
+    }
+  }
+  return valid;
+}
+
+std::vector<MsgPtr> Messages::GetValidMessagesBatch(const View &view, MessageType type,
+                                                    const BatchPredicate &verdicts) {
+  std::vector<MsgPtr> valid;
+  int s = slot(type);
+  if (s < 0) return valid;
+  std::unique_lock lk(mux_[s]);
+  auto h = maps_[s].find(view.height);
+  if (h == maps_[s].end()) return valid;
+  auto r = h->second.find(view.round);
+  if (r == h->second.end()) return valid;
+  std::vector<MsgPtr> all;
+  all.reserve(r->second.size());
+  for (auto &kv : r->second) all.push_back(kv.second);
+  std::vector<uint8_t> v = verdicts(all);
+  if (v.size() != all.size()) return valid;  // backend failure: nothing pruned, nothing returned
+  size_t i = 0;
+  for (auto it = r->second.begin(); it != r->second.end(); ++i) {
+    if (!v[i]) {
+      it = r->second.erase(it);
+    } else {
+      valid.push_back(it->second);
+      ++it;
+    }
+  }
+  return valid;
+}
+
+std::vector<MsgPtr> Messages::GetExtendedRCC(
+    uint64_t height, const Predicate &isValidMessage,
+    const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC) {
+  std::unique_lock lk(mux_[ROUND_CHANGE]);
+  std::vector<MsgPtr> extended;
+  auto h = maps_[ROUND_CHANGE].find(height);
+  if (h == maps_[ROUND_CHANGE].end()) return extended;
+  uint64_t highest = 0;
+  for (auto &rm : h->second) {
+    const uint64_t round = rm.first;
+    if (round <= highest) continue;  // messages.go:222-224 (so round 0 is never considered)
+    std::vector<MsgPtr> valid;
+    for (auto &kv : rm.second)
+      if (isValidMessage(*kv.second)) valid.push_back(kv.second);
+    if (!isValidRCC(round, valid)) continue;
+    highest = round;
+    extended = std::move(valid);
+  }
+  return extended;
+}
+
+std::vector<MsgPtr> Messages::GetMostRoundChangeMessages(uint64_t minRound, uint64_t height) {
+  std::shared_lock lk(mux_[ROUND_CHANGE]);
+  std::vector<MsgPtr> out;
+  auto h = maps_[ROUND_CHANGE].find(height);
+  if (h == maps_[ROUND_CHANGE].end()) return out;
+  uint64_t best = 0;
+  size_t best_count = 0;
+  for (auto &rm : h->second) {
+    if (rm.first < minRound) continue;
+    if (rm.second.size() > best_count) {  // strict: ties keep the first seen (map order is random in Go)
+      best = rm.first;
+      best_count = rm.second.size();
+    }
+  }
+  if (best == 0) return out;  // "no messages found" — also when the best round IS 0, messages.go:273-276
+  for (auto &kv : h->second[best]) out.push_back(kv.second);
+  return out;
+}
+
+bool ValidatorManager::Init(const std::vector<std::pair<bytes, uint64_t>> &powers) {
+  std::map<bytes, uint64_t> p;
+  for (auto &kv : powers) p[kv.first] = kv.second;
+  unsigned __int128 total = 0;
+  for (auto &kv : p) total += kv.second;
+  if (total == 0) return false;  // errVotingPowerNotCorrect: state is left unchanged
+  power_ = std::move(p);
+  quorum_ = (total * 2) / 3 + 1;  // calculateQuorum :130-135
+  initialized_ = true;
+  return true;
+}
+
+bool ValidatorManager::HasQuorum(const std::set<bytes> &senders) const {
+  if (!initialized_) return false;  // :82-84
+  unsigned __int128 sum = 0;
+  for (auto &s : senders) {
+    auto it = power_.find(s);
+    if (it != power_.end()) sum += it->second;
+  }
+  return sum >= quorum_;
+}
+
+bool ValidatorManager::HasPrepareQuorum(const IbftMessage *proposal, const std::vector<MsgPtr> &msgs) const {
+  if (!proposal) return false;
+  std::set<bytes> senders{proposal->from};
+  for (auto &m : msgs) {
+    if (m->from == proposal->from) return false;  // proposer among PREPARE signers :117-121
+    senders.insert(m->from);
+  }
+  return HasQuorum(senders);
+}
+
+std::set<bytes> convertMessageToAddressSet(const std::vector<MsgPtr> &msgs) {
+  std::set<bytes> s;
+  for (auto &m : msgs) s.insert(m->from);
+  return s;
+}
+
+}  // namespace ibft

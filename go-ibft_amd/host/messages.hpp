@@ -1,0 +1,70 @@
+// messages.hpp — C++ mirror of messages.Messages (the store) and ValidatorManager.
+//
+// Product host code.  Semantics follow /root/reference/messages/messages.go:54-65
+// (AddMessage: last writer wins per sender), :96-119 (numMessages), :123-148
+// (PruneByHeight), :169-199 (GetValidMessages: invalid messages are DELETED), :202-245
+// (GetExtendedRCC: non-pruning; round 0 can never be returned because of the
+// `round <= highestRound` test), :249-286 (GetMostRoundChangeMessages) and
+// /root/reference/core/validator_manager.go:50-155.
+//
+// Iteration order: Go map iteration is random, so callers may only rely on the SET of
+// returned messages; this mirror iterates in sender-byte order (deterministic).
+#pragma once
+#include <functional>
+#include <map>
+#include <mutex>
+#include <set>
+#include <shared_mutex>
+
+#include "proto.hpp"
+
+namespace ibft {
+
+using Predicate = std::function<bool(const IbftMessage &)>;
+
+class Messages {
+ public:
+  void AddMessage(MsgPtr m);
+  size_t numMessages(const View &view, MessageType type);
+  void PruneByHeight(uint64_t height);
+  std::vector<MsgPtr> GetValidMessages(const View &view, MessageType type, const Predicate &isValid);
+  // Batched form used by the GPU backend: `verdicts(msgs)` is called ONCE with every stored
+  // message of the view (under the same per-type lock the reference holds across its
+  // callback loop) and returns one verdict per message; rejected ones are deleted.
+  using BatchPredicate = std::function<std::vector<uint8_t>(const std::vector<MsgPtr> &)>;
+  std::vector<MsgPtr> GetValidMessagesBatch(const View &view, MessageType type, const BatchPredicate &verdicts);
+  std::vector<MsgPtr> GetExtendedRCC(uint64_t height, const Predicate &isValidMessage,
+                                     const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC);
+  std::vector<MsgPtr> GetMostRoundChangeMessages(uint64_t minRound, uint64_t height);
+
+ private:
+  using protoMessages = std::map<bytes, MsgPtr>;             // sender -> message
+  using roundMessageMap = std::map<uint64_t, protoMessages>;  // round -> ...
+  using heightMessageMap = std::map<uint64_t, roundMessageMap>;
+  heightMessageMap maps_[4];
+  std::shared_mutex mux_[4];
+  static int slot(uint32_t type) { return type <= 3 ? (int)type : -1; }
+};
+
+// core/validator_manager.go.  Powers are u64 here (128-bit sums); the reference uses
+// *big.Int — sets that need more must stay on the Go path (include/ibftgpu.h).
+class ValidatorManager {
+ public:
+  // setCurrentVotingPower (:61-75); false = errVotingPowerNotCorrect
+  bool Init(const std::vector<std::pair<bytes, uint64_t>> &powers);
+  bool HasQuorum(const std::set<bytes> &senders) const;                                  // :77-96
+  // :99-127.  proposal == nullptr -> false
+  bool HasPrepareQuorum(const IbftMessage *proposal, const std::vector<MsgPtr> &msgs) const;
+  unsigned __int128 quorum() const { return quorum_; }
+  bool initialized() const { return initialized_; }
+  const std::map<bytes, uint64_t> &powers() const { return power_; }
+
+ private:
+  std::map<bytes, uint64_t> power_;
+  unsigned __int128 quorum_ = 0;
+  bool initialized_ = false;
+};
+
+std::set<bytes> convertMessageToAddressSet(const std::vector<MsgPtr> &msgs);  // :147-155
+
+}  // namespace ibft

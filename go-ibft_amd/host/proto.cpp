@@ -1,0 +1,486 @@
+// proto.cpp — wire encode/decode + Extract* helpers (see proto.hpp for the reference lines).
+#include "proto.hpp"
+
+#include <set>
+
+namespace ibft {
+
+namespace {
+
+void put_varint(bytes &o, uint64_t v) {
+  while (v >= 0x80) {
+    o.push_back((char)(uint8_t)(v | 0x80));
+    v >>= 7;
+  }
+  o.push_back((char)(uint8_t)v);
+}
+void put_len_field(bytes &o, uint32_t num, const bytes &data) {
+  put_varint(o, ((uint64_t)num << 3) | 2);
+  put_varint(o, data.size());
+  o += data;
+}
+void put_bytes_field(bytes &o, uint32_t num, const bytes &data) {  // proto3: empty omitted
+  if (!data.empty()) put_len_field(o, num, data);
+}
+void put_varint_field(bytes &o, uint32_t num, uint64_t v) {  // proto3: zero omitted
+  if (v) {
+    put_varint(o, (uint64_t)num << 3);
+    put_varint(o, v);
+  }
+}
+
+struct Reader {
+  const uint8_t *p, *end;
+  bool varint(uint64_t &v) {
+    v = 0;
+    for (int shift = 0; shift < 64; shift += 7) {
+      if (p >= end) return false;
+      uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7F) << shift;
+      if (!(b & 0x80)) return true;
+    }
+    return false;
+  }
+  bool len_delim(const uint8_t *&q, size_t &n) {
+    uint64_t l;
+    if (!varint(l) || l > (uint64_t)(end - p)) return false;
+    q = p;
+    n = (size_t)l;
+    p += l;
+    return true;
+  }
+};
+
+// Skip (and copy verbatim into `unknown`) one field whose tag has just been read.
+bool keep_unknown(Reader &r, uint64_t tag, const uint8_t *field_start, bytes &unknown) {
+  uint64_t v;
+  const uint8_t *q;
+  size_t n;
+  switch (tag & 7) {
+    case 0:
+      if (!r.varint(v)) return false;
+      break;
+    case 1:
+      if (r.end - r.p < 8) return false;
+      r.p += 8;
+      break;
+    case 2:
+      if (!r.len_delim(q, n)) return false;
+      break;
+    case 5:
+      if (r.end - r.p < 4) return false;
+      r.p += 4;
+      break;
+    default:
+      return false;  // groups / invalid wire types
+  }
+  unknown.append((const char *)field_start, (size_t)(r.p - field_start));
+  return true;
+}
+
+bool decode_view(const uint8_t *p, size_t n, View &v) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    if (tag == ((1u << 3) | 0)) {
+      if (!r.varint(v.height)) return false;
+    } else if (tag == ((2u << 3) | 0)) {
+      if (!r.varint(v.round)) return false;
+    } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
+      return false;  // known field, wrong wire type
+    } else if (!keep_unknown(r, tag, start, v.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_proposal(const uint8_t *p, size_t n, Proposal &o) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      o.raw_proposal.assign((const char *)q, l);
+    } else if (tag == ((2u << 3) | 0)) {
+      if (!r.varint(o.round)) return false;
+    } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, o.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_msg(const uint8_t *p, size_t n, IbftMessage &m, int depth);
+
+bool decode_pc(const uint8_t *p, size_t n, PreparedCertificate &pc, int depth) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      if (!pc.proposal_message) pc.proposal_message = std::make_shared<IbftMessage>();
+      if (!decode_msg(q, l, *pc.proposal_message, depth + 1)) return false;
+    } else if (tag == ((2u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      auto m = std::make_shared<IbftMessage>();
+      if (!decode_msg(q, l, *m, depth + 1)) return false;
+      pc.prepare_messages.push_back(std::move(m));
+    } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, pc.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_rcc(const uint8_t *p, size_t n, RoundChangeCertificate &rcc, int depth) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      auto m = std::make_shared<IbftMessage>();
+      if (!decode_msg(q, l, *m, depth + 1)) return false;
+      rcc.round_change_messages.push_back(std::move(m));
+    } else if ((tag >> 3) == 1) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, rcc.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_preprepare(const uint8_t *p, size_t n, PrePrepareMessage &o, int depth) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      if (!o.proposal) o.proposal.emplace();
+      if (!decode_proposal(q, l, *o.proposal)) return false;
+    } else if (tag == ((2u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      o.proposal_hash.assign((const char *)q, l);
+    } else if (tag == ((3u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      if (!o.certificate) o.certificate.emplace();
+      if (!decode_rcc(q, l, *o.certificate, depth)) return false;
+    } else if ((tag >> 3) >= 1 && (tag >> 3) <= 3) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, o.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_prepare(const uint8_t *p, size_t n, PrepareMessage &o) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      o.proposal_hash.assign((const char *)q, l);
+    } else if ((tag >> 3) == 1) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, o.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_commit(const uint8_t *p, size_t n, CommitMessage &o) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      o.proposal_hash.assign((const char *)q, l);
+    } else if (tag == ((2u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      o.committed_seal.assign((const char *)q, l);
+    } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, o.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_round_change(const uint8_t *p, size_t n, RoundChangeMessage &o, int depth) {
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    if (tag == ((1u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      if (!o.last_prepared_proposal) o.last_prepared_proposal.emplace();
+      if (!decode_proposal(q, l, *o.last_prepared_proposal)) return false;
+    } else if (tag == ((2u << 3) | 2)) {
+      if (!r.len_delim(q, l)) return false;
+      if (!o.latest_prepared_certificate) o.latest_prepared_certificate.emplace();
+      if (!decode_pc(q, l, *o.latest_prepared_certificate, depth)) return false;
+    } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
+      return false;
+    } else if (!keep_unknown(r, tag, start, o.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool decode_msg(const uint8_t *p, size_t n, IbftMessage &m, int depth) {
+  if (depth > 64) return false;  // protobuf-go's default recursion limit is far above any real nesting
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    const uint8_t *start = r.p;
+    uint64_t tag;
+    if (!r.varint(tag)) return false;
+    const uint8_t *q;
+    size_t l;
+    const uint32_t num = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+    if (num == 1 && wt == 2) {
+      if (!r.len_delim(q, l)) return false;
+      if (!m.view) m.view.emplace();
+      if (!decode_view(q, l, *m.view)) return false;
+    } else if (num == 2 && wt == 2) {
+      if (!r.len_delim(q, l)) return false;
+      m.from.assign((const char *)q, l);
+    } else if (num == 3 && wt == 2) {
+      if (!r.len_delim(q, l)) return false;
+      m.signature.assign((const char *)q, l);
+    } else if (num == 4 && wt == 0) {
+      uint64_t v;
+      if (!r.varint(v)) return false;
+      m.type = (uint32_t)v;
+    } else if (num >= 5 && num <= 8 && wt == 2) {
+      if (!r.len_delim(q, l)) return false;
+      // oneof: the last member on the wire wins; a repeated member merges
+      PayloadKind k = num == 5 ? PayloadKind::PREPREPARE : num == 6 ? PayloadKind::PREPARE
+                      : num == 7 ? PayloadKind::COMMIT : PayloadKind::ROUND_CHANGE;
+      if (m.kind != k) {
+        m.preprepare = {};
+        m.prepare = {};
+        m.commit = {};
+        m.round_change = {};
+        m.kind = k;
+      }
+      bool ok = k == PayloadKind::PREPREPARE  ? decode_preprepare(q, l, m.preprepare, depth)
+                : k == PayloadKind::PREPARE   ? decode_prepare(q, l, m.prepare)
+                : k == PayloadKind::COMMIT    ? decode_commit(q, l, m.commit)
+                                              : decode_round_change(q, l, m.round_change, depth);
+      if (!ok) return false;
+    } else if (num >= 1 && num <= 8) {
+      return false;  // known field with the wrong wire type
+    } else if (!keep_unknown(r, tag, start, m.unknown)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+bytes encode(const View &v) {
+  bytes o;
+  put_varint_field(o, 1, v.height);
+  put_varint_field(o, 2, v.round);
+  o += v.unknown;
+  return o;
+}
+bytes encode(const Proposal &p) {
+  bytes o;
+  put_bytes_field(o, 1, p.raw_proposal);
+  put_varint_field(o, 2, p.round);
+  o += p.unknown;
+  return o;
+}
+bytes encode(const PreparedCertificate &pc) {
+  bytes o;
+  if (pc.proposal_message) put_len_field(o, 1, encode(*pc.proposal_message));
+  for (const auto &m : pc.prepare_messages) put_len_field(o, 2, m ? encode(*m) : bytes());
+  o += pc.unknown;
+  return o;
+}
+bytes encode(const RoundChangeCertificate &rcc) {
+  bytes o;
+  for (const auto &m : rcc.round_change_messages) put_len_field(o, 1, m ? encode(*m) : bytes());
+  o += rcc.unknown;
+  return o;
+}
+static bytes encode(const PrePrepareMessage &p) {
+  bytes o;
+  if (p.proposal) put_len_field(o, 1, encode(*p.proposal));
+  put_bytes_field(o, 2, p.proposal_hash);
+  if (p.certificate) put_len_field(o, 3, encode(*p.certificate));
+  o += p.unknown;
+  return o;
+}
+static bytes encode(const PrepareMessage &p) {
+  bytes o;
+  put_bytes_field(o, 1, p.proposal_hash);
+  o += p.unknown;
+  return o;
+}
+static bytes encode(const CommitMessage &c) {
+  bytes o;
+  put_bytes_field(o, 1, c.proposal_hash);
+  put_bytes_field(o, 2, c.committed_seal);
+  o += c.unknown;
+  return o;
+}
+static bytes encode(const RoundChangeMessage &r) {
+  bytes o;
+  if (r.last_prepared_proposal) put_len_field(o, 1, encode(*r.last_prepared_proposal));
+  if (r.latest_prepared_certificate) put_len_field(o, 2, encode(*r.latest_prepared_certificate));
+  o += r.unknown;
+  return o;
+}
+
+bytes encode(const IbftMessage &m, bool with_signature) {
+  bytes o;
+  if (m.view) put_len_field(o, 1, encode(*m.view));
+  put_bytes_field(o, 2, m.from);
+  if (with_signature) put_bytes_field(o, 3, m.signature);
+  put_varint_field(o, 4, m.type);
+  switch (m.kind) {
+    case PayloadKind::PREPREPARE: put_len_field(o, 5, encode(m.preprepare)); break;
+    case PayloadKind::PREPARE: put_len_field(o, 6, encode(m.prepare)); break;
+    case PayloadKind::COMMIT: put_len_field(o, 7, encode(m.commit)); break;
+    case PayloadKind::ROUND_CHANGE: put_len_field(o, 8, encode(m.round_change)); break;
+    case PayloadKind::NONE: break;
+  }
+  o += m.unknown;
+  return o;
+}
+
+bool decode(const uint8_t *p, size_t n, IbftMessage &out) {
+  out = IbftMessage{};
+  return decode_msg(p, n, out, 0);
+}
+
+// ---- Extract* ------------------------------------------------------------------------------
+const bytes *extract_commit_hash(const IbftMessage &m) {
+  if (m.type != COMMIT || m.kind != PayloadKind::COMMIT) return nullptr;
+  return &m.commit.proposal_hash;
+}
+std::optional<CommittedSeal> extract_committed_seal(const IbftMessage &m) {
+  if (m.kind != PayloadKind::COMMIT) return std::nullopt;  // only the payload is checked (helpers.go:39-42)
+  return CommittedSeal{m.from, m.commit.committed_seal};
+}
+const bytes *extract_prepare_hash(const IbftMessage &m) {
+  if (m.type != PREPARE || m.kind != PayloadKind::PREPARE) return nullptr;
+  return &m.prepare.proposal_hash;
+}
+const Proposal *extract_proposal(const IbftMessage &m) {
+  if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
+  return m.preprepare.proposal ? &*m.preprepare.proposal : nullptr;
+}
+const bytes *extract_proposal_hash(const IbftMessage &m) {
+  if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
+  return &m.preprepare.proposal_hash;
+}
+const RoundChangeCertificate *extract_round_change_certificate(const IbftMessage &m) {
+  if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
+  return m.preprepare.certificate ? &*m.preprepare.certificate : nullptr;
+}
+const PreparedCertificate *extract_latest_pc(const IbftMessage &m) {
+  if (m.type != ROUND_CHANGE || m.kind != PayloadKind::ROUND_CHANGE) return nullptr;
+  return m.round_change.latest_prepared_certificate ? &*m.round_change.latest_prepared_certificate : nullptr;
+}
+const Proposal *extract_last_prepared_proposal(const IbftMessage &m) {
+  if (m.type != ROUND_CHANGE || m.kind != PayloadKind::ROUND_CHANGE) return nullptr;
+  return m.round_change.last_prepared_proposal ? &*m.round_change.last_prepared_proposal : nullptr;
+}
+
+bool extract_committed_seals(const std::vector<MsgPtr> &msgs, std::vector<std::optional<CommittedSeal>> &out) {
+  out.clear();
+  for (const auto &m : msgs) {
+    if (m->type != COMMIT) {  // safe check, helpers.go:26-29
+      out.clear();
+      return false;
+    }
+    out.push_back(extract_committed_seal(*m));
+  }
+  return true;
+}
+
+bool has_unique_senders(const std::vector<MsgPtr> &msgs) {
+  if (msgs.empty()) return false;
+  std::set<bytes> seen;
+  for (const auto &m : msgs)
+    if (!seen.insert(m->from).second) return false;
+  return true;
+}
+
+static bool bytes_equal(const bytes *a, const bytes *b) {  // bytes.Equal: nil == empty
+  static const bytes empty;
+  return (a ? *a : empty) == (b ? *b : empty);
+}
+
+bool are_valid_pc_messages(const std::vector<MsgPtr> &msgs, uint64_t height, uint64_t round_limit) {
+  if (msgs.empty()) return false;
+  // messages[0].View.Round: a nil View would panic in the reference; treat as invalid
+  if (!msgs[0]->view) return false;
+  const uint64_t round = msgs[0]->view->round;
+  std::set<bytes> senders;
+  const bytes *hash = nullptr;
+  for (const auto &m : msgs) {
+    if (!m->view) return false;
+    if (m->view->height != height) return false;
+    if (m->view->round != round || m->view->round >= round_limit) return false;
+    const bytes *extracted = nullptr;
+    bool ok = false;
+    if (m->type == PREPREPARE) {
+      extracted = extract_proposal_hash(*m);
+      ok = true;
+    } else if (m->type == PREPARE) {
+      extracted = extract_prepare_hash(*m);
+      ok = true;
+    }
+    // `if hash == nil { hash = extractedHash }` — an absent proto3 bytes field is nil in Go;
+    // an explicitly-encoded empty one is indistinguishable here and treated as nil too
+    if (hash == nullptr || hash->empty()) hash = extracted;
+    if (!ok || !bytes_equal(hash, extracted)) return false;
+    if (!senders.insert(m->from).second) return false;
+  }
+  return true;
+}
+
+}  // namespace ibft

@@ -1,0 +1,114 @@
+// proto.hpp — C++ mirror of go-ibft's wire types (messages/proto/messages.proto).
+//
+// Product host code.  Field numbers and zero/empty omission follow
+// /root/reference/messages/proto/messages.proto:7-110 (proto3); PayloadNoSig follows
+// /root/reference/messages/proto/helper.go:12-27 (marshal of the message with Signature
+// cleared).  The encoder emits what protobuf-go emits for these messages: known fields in
+// field-number order, minimal varints, zero scalars / empty bytes omitted, present
+// sub-messages emitted even when empty, unknown fields preserved and appended last.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <string>
+#include <vector>
+
+namespace ibft {
+
+using bytes = std::string;  // byte strings; std::string gives value semantics + hashing
+
+enum MessageType : uint32_t { PREPREPARE = 0, PREPARE = 1, COMMIT = 2, ROUND_CHANGE = 3 };
+
+struct View {
+  uint64_t height = 0, round = 0;
+  bytes unknown;
+};
+
+struct Proposal {
+  bytes raw_proposal;
+  uint64_t round = 0;
+  bytes unknown;
+};
+
+struct IbftMessage;
+using MsgPtr = std::shared_ptr<IbftMessage>;
+
+struct PreparedCertificate {
+  MsgPtr proposal_message;               // nil-able
+  std::vector<MsgPtr> prepare_messages;  // repeated
+  bytes unknown;
+};
+
+struct RoundChangeCertificate {
+  std::vector<MsgPtr> round_change_messages;
+  bytes unknown;
+};
+
+struct PrePrepareMessage {
+  std::optional<Proposal> proposal;
+  bytes proposal_hash;
+  std::optional<RoundChangeCertificate> certificate;
+  bytes unknown;
+};
+struct PrepareMessage {
+  bytes proposal_hash;
+  bytes unknown;
+};
+struct CommitMessage {
+  bytes proposal_hash;
+  bytes committed_seal;
+  bytes unknown;
+};
+struct RoundChangeMessage {
+  std::optional<Proposal> last_prepared_proposal;
+  std::optional<PreparedCertificate> latest_prepared_certificate;
+  bytes unknown;
+};
+
+// Which member of the `payload` oneof is set (messages.proto:36-43); NONE = nil Payload.
+enum class PayloadKind { NONE, PREPREPARE, PREPARE, COMMIT, ROUND_CHANGE };
+
+struct IbftMessage {
+  std::optional<View> view;  // nil-able pointer in Go
+  bytes from;
+  bytes signature;
+  uint32_t type = PREPREPARE;
+  PayloadKind kind = PayloadKind::NONE;
+  PrePrepareMessage preprepare;
+  PrepareMessage prepare;
+  CommitMessage commit;
+  RoundChangeMessage round_change;
+  bytes unknown;
+};
+
+// ---- wire encoding ---------------------------------------------------------------------
+bytes encode(const IbftMessage &m, bool with_signature = true);
+inline bytes payload_no_sig(const IbftMessage &m) { return encode(m, false); }
+bytes encode(const View &v);
+bytes encode(const Proposal &p);
+bytes encode(const PreparedCertificate &pc);
+bytes encode(const RoundChangeCertificate &rcc);
+
+// ---- wire decoding (what proto.Unmarshal does for these messages) -------------------------
+// Returns false on malformed input (truncated varint/length, bad wire type for a known field).
+bool decode(const uint8_t *p, size_t n, IbftMessage &out);
+
+// ---- messages/helpers.go Extract* ------------------------------------------------------------
+// A null pointer return mirrors a nil []byte / nil pointer in the reference.
+struct CommittedSeal {  // messages/helpers.go:15-19
+  bytes signer, signature;
+};
+const bytes *extract_commit_hash(const IbftMessage &m);        // helpers.go:51-62
+std::optional<CommittedSeal> extract_committed_seal(const IbftMessage &m);  // helpers.go:38-48
+const bytes *extract_prepare_hash(const IbftMessage &m);       // helpers.go:107-118
+const Proposal *extract_proposal(const IbftMessage &m);        // helpers.go:65-76
+const bytes *extract_proposal_hash(const IbftMessage &m);      // helpers.go:79-90
+const RoundChangeCertificate *extract_round_change_certificate(const IbftMessage &m);  // :93-104
+const PreparedCertificate *extract_latest_pc(const IbftMessage &m);                    // :121-132
+const Proposal *extract_last_prepared_proposal(const IbftMessage &m);                  // :135-146
+// helpers.go:22-35: false = ErrWrongCommitMessageType
+bool extract_committed_seals(const std::vector<MsgPtr> &msgs, std::vector<std::optional<CommittedSeal>> &out);
+bool has_unique_senders(const std::vector<MsgPtr> &msgs);                                // :149-166
+bool are_valid_pc_messages(const std::vector<MsgPtr> &msgs, uint64_t height, uint64_t round_limit);  // :169-213
+
+}  // namespace ibft

@@ -1,0 +1,261 @@
+"""ctypes mirror of include/ibft_host.h — the host-side store / quorum / hot-path callers.
+
+Names follow the reference: ``Host.store_*`` = messages.Messages
+(/root/reference/messages/messages.go), ``Host.vm_*`` = core.ValidatorManager,
+``Host.add_message`` / ``handle_prepare`` / ``handle_commit`` = core/ibft.go:1101, :855, :931.
+Messages cross the boundary as protobuf wire bytes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+import subprocess
+
+from .build import CSRC, HERE, build_lib
+
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HOST_DIR, "libibft_host.so")
+HOST_SRCS = ["proto.cpp", "messages.cpp", "backend.cpp", "host_capi.cpp"]
+HOST_DEPS = HOST_SRCS + ["proto.hpp", "messages.hpp", "backend.hpp"]
+
+
+def build_host(force: bool = False) -> str:
+    build_lib()
+    stale = force or not os.path.exists(HOST_LIB) or any(
+        os.path.getmtime(os.path.join(HOST_DIR, d)) > os.path.getmtime(HOST_LIB) for d in HOST_DEPS)
+    inc = os.path.join(HERE, "..", "include", "ibft_host.h")
+    stale = stale or os.path.getmtime(inc) > os.path.getmtime(HOST_LIB)
+    if stale:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, *HOST_SRCS,
+                               "-L" + CSRC, "-libftgpu", "-Wl,-rpath,$ORIGIN/../csrc"], cwd=HOST_DIR)
+    return HOST_LIB
+
+
+class Buf(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("len", C.c_size_t), ("count", C.c_size_t)]
+
+
+PROP_HASH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint64, C.c_int,
+                           C.POINTER(C.c_uint8), C.c_size_t)
+SEAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int,
+                      C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t)
+VALIDATOR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+MSG_PRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+RCC_PRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_size_t)
+
+
+class VerifierCB(C.Structure):
+    _fields_ = [("is_valid_proposal_hash", PROP_HASH_FN), ("is_valid_committed_seal", SEAL_FN),
+                ("is_valid_validator", VALIDATOR_FN), ("user", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build_host())
+        vp, bp = C.c_void_p, C.POINTER(Buf)
+        L.ibft_host_new.restype = vp
+        L.ibft_host_free.argtypes = [vp]
+        L.ibft_host_buf_free.argtypes = [bp]
+        L.ibft_host_payload_no_sig.argtypes = [C.c_char_p, C.c_size_t, bp]
+        L.ibft_host_reencode.argtypes = [C.c_char_p, C.c_size_t, bp]
+        L.ibft_host_store_add.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.ibft_host_store_num.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32]; L.ibft_host_store_num.restype = C.c_size_t
+        L.ibft_host_store_prune.argtypes = [vp, C.c_uint64]
+        L.ibft_host_store_get_valid.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, MSG_PRED, vp, bp]
+        L.ibft_host_store_get_extended_rcc.argtypes = [vp, C.c_uint64, MSG_PRED, RCC_PRED, vp, bp]
+        L.ibft_host_store_get_most_rc.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
+        L.ibft_host_has_unique_senders.argtypes = [C.c_char_p, C.c_size_t]
+        L.ibft_host_are_valid_pc_messages.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]
+        L.ibft_host_extract_committed_seals.argtypes = [C.c_char_p, C.c_size_t, bp]
+        L.ibft_host_vm_init.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t]
+        L.ibft_host_vm_has_quorum.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.ibft_host_vm_has_prepare_quorum.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.ibft_host_vm_quorum.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ibft_host_set_state.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_char_p, C.c_size_t]
+        L.ibft_host_set_verifier.argtypes = [vp, C.POINTER(VerifierCB)]
+        L.ibft_host_attach_gpu.argtypes = [vp, vp]
+        L.ibft_host_use_batch.argtypes = [vp, C.c_int]
+        L.ibft_host_add_message.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.ibft_host_add_messages_batch.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.ibft_host_handle_prepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
+        L.ibft_host_handle_commit.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
+        _lib = L
+    return _lib
+
+
+def pack(items) -> bytes:
+    return b"".join(struct.pack("<I", len(x)) + bytes(x) for x in items)
+
+
+def unpack(raw: bytes) -> list[bytes]:
+    out, pos = [], 0
+    while pos < len(raw):
+        (ln,) = struct.unpack_from("<I", raw, pos)
+        out.append(raw[pos + 4: pos + 4 + ln])
+        pos += 4 + ln
+    return out
+
+
+def _take(buf: Buf) -> bytes:
+    raw = C.string_at(buf.data, buf.len) if buf.len else b""
+    lib().ibft_host_buf_free(C.byref(buf))
+    return raw
+
+
+def unpack_seals(raw: bytes):
+    out, pos = [], 0
+    while pos < len(raw):
+        present = raw[pos]; pos += 1
+        (l1,) = struct.unpack_from("<I", raw, pos); signer = raw[pos + 4: pos + 4 + l1]; pos += 4 + l1
+        (l2,) = struct.unpack_from("<I", raw, pos); sig = raw[pos + 4: pos + 4 + l2]; pos += 4 + l2
+        out.append((signer, sig) if present else None)
+    return out
+
+
+def payload_no_sig(wire: bytes) -> bytes | None:
+    b = Buf()
+    return _take(b) if lib().ibft_host_payload_no_sig(wire, len(wire), C.byref(b)) == 0 else None
+
+
+def reencode(wire: bytes) -> bytes | None:
+    b = Buf()
+    return _take(b) if lib().ibft_host_reencode(wire, len(wire), C.byref(b)) == 0 else None
+
+
+def has_unique_senders(msgs) -> bool:
+    p = pack(msgs)
+    return lib().ibft_host_has_unique_senders(p, len(p)) == 1
+
+
+def are_valid_pc_messages(msgs, height: int, round_limit: int) -> bool:
+    p = pack(msgs)
+    return lib().ibft_host_are_valid_pc_messages(p, len(p), height, round_limit) == 1
+
+
+def extract_committed_seals(msgs):
+    p = pack(msgs)
+    b = Buf()
+    rc = lib().ibft_host_extract_committed_seals(p, len(p), C.byref(b))
+    if rc != 0:
+        return None  # ErrWrongCommitMessageType
+    return unpack_seals(_take(b))
+
+
+class Host:
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.ibft_host_new())
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.ibft_host_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # --- messages.Messages
+    def store_add(self, wire: bytes) -> int:
+        return self.L.ibft_host_store_add(self.h, wire, len(wire))
+
+    def store_num(self, height, round_, type_) -> int:
+        return self.L.ibft_host_store_num(self.h, height, round_, type_)
+
+    def store_prune(self, height):
+        self.L.ibft_host_store_prune(self.h, height)
+
+    def store_get_valid(self, height, round_, type_, pred=None) -> list[bytes]:
+        cb = MSG_PRED(lambda u, p, n: int(bool(pred(C.string_at(p, n))))) if pred else MSG_PRED()
+        b = Buf()
+        self.L.ibft_host_store_get_valid(self.h, height, round_, type_, cb, None, C.byref(b))
+        return unpack(_take(b))
+
+    def store_get_extended_rcc(self, height, pred, rcc_pred) -> list[bytes]:
+        cb = MSG_PRED(lambda u, p, n: int(bool(pred(C.string_at(p, n)))))
+        rcb = RCC_PRED(lambda u, r, n: int(bool(rcc_pred(r, n))))
+        b = Buf()
+        self.L.ibft_host_store_get_extended_rcc(self.h, height, cb, rcb, None, C.byref(b))
+        return unpack(_take(b))
+
+    def store_get_most_rc(self, min_round, height) -> list[bytes]:
+        b = Buf()
+        self.L.ibft_host_store_get_most_rc(self.h, min_round, height, C.byref(b))
+        return unpack(_take(b))
+
+    # --- core.ValidatorManager
+    def vm_init(self, powers: dict) -> bool:
+        addrs = list(powers.keys())
+        p = pack(addrs)
+        arr = (C.c_uint64 * max(len(addrs), 1))(*[powers[a] for a in addrs])
+        return self.L.ibft_host_vm_init(self.h, p, len(p), arr, len(addrs)) == 0
+
+    def vm_has_quorum(self, senders) -> bool:
+        p = pack(list(senders))
+        return self.L.ibft_host_vm_has_quorum(self.h, p, len(p)) == 1
+
+    def vm_has_prepare_quorum(self, proposal_wire, msgs) -> bool:
+        p = pack(msgs)
+        return self.L.ibft_host_vm_has_prepare_quorum(self.h, proposal_wire, len(proposal_wire or b""), p, len(p)) == 1
+
+    def vm_quorum(self) -> int:
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self.L.ibft_host_vm_quorum(self.h, C.byref(lo), C.byref(hi))
+        return lo.value | (hi.value << 64)
+
+    # --- state + verifier
+    def set_state(self, height, round_, proposal_wire: bytes | None):
+        return self.L.ibft_host_set_state(self.h, height, round_, proposal_wire, len(proposal_wire or b""))
+
+    def set_verifier(self, is_valid_proposal_hash=None, is_valid_committed_seal=None, is_valid_validator=None):
+        """Callbacks receive Python values; None arguments mirror Go nils."""
+        def ph(u, hp, raw, rl, rnd, hh, hsh, hl):
+            prop = (C.string_at(raw, rl) if rl else b"", rnd) if hp else None
+            return int(bool(is_valid_proposal_hash(prop, (C.string_at(hsh, hl) if hl else b"") if hh else None)))
+
+        def sl(u, hh, hsh, hl, hs, sg, sgl, sig, sigl):
+            seal = ((C.string_at(sg, sgl) if sgl else b""), (C.string_at(sig, sigl) if sigl else b"")) if hs else None
+            return int(bool(is_valid_committed_seal((C.string_at(hsh, hl) if hl else b"") if hh else None, seal)))
+
+        def vv(u, p, n):
+            return int(bool(is_valid_validator(C.string_at(p, n))))
+
+        cb = VerifierCB(PROP_HASH_FN(ph) if is_valid_proposal_hash else PROP_HASH_FN(),
+                        SEAL_FN(sl) if is_valid_committed_seal else SEAL_FN(),
+                        VALIDATOR_FN(vv) if is_valid_validator else VALIDATOR_FN(), None)
+        self._keep.append(cb)
+        self.L.ibft_host_set_verifier(self.h, C.byref(cb))
+
+    def attach_gpu(self, batch_verifier):
+        """batch_verifier: go_ibft_amd.verifier.BatchVerifier (its ibft_ctx is borrowed)."""
+        self._keep.append(batch_verifier)
+        self.L.ibft_host_attach_gpu(self.h, batch_verifier._h)
+
+    def use_batch(self, on: bool):
+        self.L.ibft_host_use_batch(self.h, int(on))
+
+    # --- core/ibft.go hot-path callers
+    def add_message(self, wire: bytes) -> int:
+        return self.L.ibft_host_add_message(self.h, wire, len(wire))
+
+    def add_messages_batch(self, wires) -> list[int]:
+        p = pack(wires)
+        res = C.create_string_buffer(len(wires))
+        rc = self.L.ibft_host_add_messages_batch(self.h, p, len(p), res, len(wires))
+        if rc != 0:
+            raise RuntimeError(f"ibft_host_add_messages_batch rc={rc}")
+        return list(res.raw)
+
+    def handle_prepare(self, height, round_):
+        b = Buf()
+        q = self.L.ibft_host_handle_prepare(self.h, height, round_, C.byref(b))
+        return bool(q), unpack(_take(b))
+
+    def handle_commit(self, height, round_):
+        b = Buf()
+        q = self.L.ibft_host_handle_commit(self.h, height, round_, C.byref(b))
+        return bool(q), unpack_seals(_take(b))

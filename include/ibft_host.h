@@ -1,0 +1,100 @@
+/*
+ * include/ibft_host.h — C ABI of libibft_host.so: the host-side mirror of go-ibft's
+ * message store, quorum manager and hot-path callers, sitting ABOVE include/ibftgpu.h.
+ *
+ * In production this layer is Go (messages/messages.go, core/validator_manager.go,
+ * core/ibft.go stay as they are; INTEGRATION.md shows the few lines that change).  This
+ * image has no Go toolchain, so the same semantics are provided in C++ and exported here
+ * so that the parity tests can drive them exactly like the reference's own unit tests
+ * drive the Go code (mock backend via callbacks, or the GPU backend).
+ *
+ * Messages cross this ABI as protobuf wire bytes (messages/proto/messages.proto).
+ * Message lists are packed as repeated { u32 little-endian length, bytes }.
+ * Seal lists are packed as repeated { u8 present, u32 signer_len, signer, u32 sig_len, sig }.
+ * Returned buffers are owned by the caller: release with ibft_host_buf_free.
+ */
+#ifndef IBFT_HOST_H
+#define IBFT_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ibftgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ibft_host ibft_host;
+
+typedef struct {
+  uint8_t *data;
+  size_t len;
+  size_t count; /* number of packed items */
+} ibft_host_buf;
+
+/* Mock/stock Verifier (core/backend.go:37-56) as callbacks; has_* = 0 means a nil argument. */
+typedef struct {
+  int (*is_valid_proposal_hash)(void *user, int has_proposal, const uint8_t *raw, size_t raw_len,
+                                uint64_t round, int has_hash, const uint8_t *hash, size_t hash_len);
+  int (*is_valid_committed_seal)(void *user, int has_hash, const uint8_t *hash, size_t hash_len,
+                                 int has_seal, const uint8_t *signer, size_t signer_len,
+                                 const uint8_t *sig, size_t sig_len);
+  int (*is_valid_validator)(void *user, const uint8_t *wire, size_t len);
+  void *user;
+} ibft_host_verifier;
+
+typedef int (*ibft_host_msg_pred)(void *user, const uint8_t *wire, size_t len);
+typedef int (*ibft_host_rcc_pred)(void *user, uint64_t round, size_t n_messages);
+
+ibft_host *ibft_host_new(void);
+void ibft_host_free(ibft_host *h);
+void ibft_host_buf_free(ibft_host_buf *b);
+
+/* wire helpers: PayloadNoSig (messages/proto/helper.go:12-27) and canonical re-encode */
+int ibft_host_payload_no_sig(const uint8_t *wire, size_t len, ibft_host_buf *out);
+int ibft_host_reencode(const uint8_t *wire, size_t len, ibft_host_buf *out);
+
+/* messages.Messages (messages/messages.go) */
+int ibft_host_store_add(ibft_host *h, const uint8_t *wire, size_t len);
+size_t ibft_host_store_num(ibft_host *h, uint64_t height, uint64_t round, uint32_t type);
+void ibft_host_store_prune(ibft_host *h, uint64_t height);
+int ibft_host_store_get_valid(ibft_host *h, uint64_t height, uint64_t round, uint32_t type,
+                              ibft_host_msg_pred pred, void *user, ibft_host_buf *out);
+int ibft_host_store_get_extended_rcc(ibft_host *h, uint64_t height, ibft_host_msg_pred pred,
+                                     ibft_host_rcc_pred rcc_pred, void *user, ibft_host_buf *out);
+int ibft_host_store_get_most_rc(ibft_host *h, uint64_t min_round, uint64_t height, ibft_host_buf *out);
+
+/* messages/helpers.go */
+int ibft_host_has_unique_senders(const uint8_t *packed, size_t len);
+int ibft_host_are_valid_pc_messages(const uint8_t *packed, size_t len, uint64_t height, uint64_t round_limit);
+/* returns 0 and fills out on success, -1 on ErrWrongCommitMessageType */
+int ibft_host_extract_committed_seals(const uint8_t *packed, size_t len, ibft_host_buf *out);
+
+/* core.ValidatorManager: addresses packed as repeated { u32 len, bytes } */
+int ibft_host_vm_init(ibft_host *h, const uint8_t *packed_addrs, size_t len, const uint64_t *power, size_t n);
+int ibft_host_vm_has_quorum(ibft_host *h, const uint8_t *packed_senders, size_t len);
+int ibft_host_vm_has_prepare_quorum(ibft_host *h, const uint8_t *proposal_wire, size_t proposal_len,
+                                    const uint8_t *packed_msgs, size_t len);
+void ibft_host_vm_quorum(ibft_host *h, uint64_t *lo, uint64_t *hi);
+
+/* the slice of core/state.go the hot path reads */
+int ibft_host_set_state(ibft_host *h, uint64_t height, uint64_t round, const uint8_t *proposal_wire,
+                        size_t proposal_len);
+void ibft_host_set_verifier(ibft_host *h, const ibft_host_verifier *v);
+/* Attach the GPU batch backend (BatchVerifier); ctx stays owned by the caller. */
+void ibft_host_attach_gpu(ibft_host *h, ibft_ctx *ctx);
+void ibft_host_use_batch(ibft_host *h, int on);
+
+/* IBFT.AddMessage (core/ibft.go:1101-1123): 0 rejected, 1 stored, 2 stored + SignalEvent */
+int ibft_host_add_message(ibft_host *h, const uint8_t *wire, size_t len);
+/* Batched ingest: IsValidValidator for many messages in one device call,
+ * then the same store/probe logic per accepted message; results[i] as above. */
+int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n);
+/* handlePrepare / handleCommit (core/ibft.go:855-889, 931-967): 1 = quorum reached */
+int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared);
+int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

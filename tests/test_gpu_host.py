@@ -1,0 +1,134 @@
+"""GPU + host mirror: handlePrepare / handleCommit / batched ingest through the C++ host
+(libibft_host.so) with the GPU BatchVerifier must give the same surviving-sender set,
+quorum decision and seal list as the stock per-message path whose Verifier is the CPU
+oracle (what an application's crypto Backend would answer)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _build_round(oracle, n, seed, byzantine):
+    from oracle import wire as W, workload as WL
+    r = WL.make_round(n, seed, byzantine=byzantine, with_envelopes=False)
+    proposer = r.addrs[0].tobytes()
+    proposal = W.IbftMessage(view=W.View(r.height, r.round), sender=proposer, type=W.PREPREPARE,
+                             payload=W.preprepare_body(W.Proposal(r.raw, r.round), r.proposal_hash, None))
+    proposal.signature = oracle.sign(r.sks[0], oracle.keccak256(proposal.payload_no_sig()))
+    commits, prepares = [], []
+    for i in range(n):
+        kind = r.kinds[i]
+        hsh = r.hash32[i].tobytes()[: int(r.hash_len[i])]
+        seal = r.seal65[i].tobytes()
+        if kind == "len64":
+            seal = seal[:64]
+        body = None if kind == "nil_payload" else W.commit_body(hsh, seal)
+        m = W.IbftMessage(view=W.View(r.height, r.round), sender=r.addrs[i].tobytes(), type=W.COMMIT, payload=body)
+        m.signature = oracle.sign(r.sks[i], oracle.keccak256(m.payload_no_sig()))
+        if kind == "stolen_seal":           # also make the envelope signature wrong for the ingest test
+            m.signature = oracle.sign(r.sks[(i + 1) % n], oracle.keccak256(m.payload_no_sig()))
+        commits.append(m)
+        if i:                               # PREPAREs come from everyone but the proposer
+            p = W.IbftMessage(view=W.View(r.height, r.round), sender=r.addrs[i].tobytes(), type=W.PREPARE,
+                              payload=W.prepare_body(hsh if kind != "nil_payload" else r.proposal_hash))
+            p.signature = oracle.sign(r.sks[i], oracle.keccak256(p.payload_no_sig()))
+            prepares.append(p)
+    return r, proposal, prepares, commits
+
+
+def _oracle_verifier(oracle, r):
+    """The per-message Verifier an application would implement, answered by the CPU oracle."""
+    vs = oracle.ValSet(r.addrs, r.power)
+
+    def is_valid_proposal_hash(prop, hsh):
+        return prop is not None and hsh is not None and hsh == oracle.proposal_hash(prop[0], prop[1])
+
+    def is_valid_committed_seal(hsh, seal):
+        if hsh is None or seal is None or len(hsh) != 32 or len(seal[1]) != 65 or len(seal[0]) != 20:
+            return False
+        a = oracle.recover_address(hsh, seal[1])
+        return a is not None and a == seal[0] and vs.index(a) >= 0
+
+    def is_valid_validator(wire):
+        import go_ibft_amd.hostlib as H
+        from oracle import pyref  # noqa: F401  (kept for parity with the CPU tests' imports)
+        pns = H.payload_no_sig(wire)
+        sig, frm = _sig_from(wire)
+        if len(sig) != 65 or len(frm) != 20:
+            return False
+        a = oracle.recover_address(oracle.keccak256(pns), sig)
+        return a is not None and a == frm and vs.index(a) >= 0
+    return is_valid_proposal_hash, is_valid_committed_seal, is_valid_validator
+
+
+def _sig_from(wire):
+    """Pull `from` (field 2) and `signature` (field 3) out of top-level wire bytes."""
+    pos, frm, sig = 0, b"", b""
+    while pos < len(wire):
+        tag = wire[pos]; pos += 1
+        if tag & 7 == 2:
+            ln, shift = 0, 0
+            while True:
+                b = wire[pos]; pos += 1
+                ln |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80:
+                    break
+            val = wire[pos:pos + ln]; pos += ln
+            if tag >> 3 == 2: frm = val
+            if tag >> 3 == 3: sig = val
+        else:
+            while wire[pos] & 0x80: pos += 1
+            pos += 1
+    return sig, frm
+
+
+@pytest.mark.parametrize("n,byz", [(16, False), (100, True), (300, True)])
+def test_handle_prepare_commit_batch_equals_stock(gpu_verifier, oracle, n, byz):
+    import go_ibft_amd.hostlib as H
+    r, proposal, prepares, commits = _build_round(oracle, n, 900 + n, byz)
+    gpu_verifier.set_validators(r.height, r.addrs, r.power)
+    powers = {r.addrs[i].tobytes(): int(r.power[i]) for i in range(n)}
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    results = []
+    for batch in (False, True):
+        h = H.Host()
+        assert h.vm_init(powers)
+        h.set_state(r.height, r.round, proposal.encode())
+        h.set_verifier(f1, f2, f3)
+        h.attach_gpu(gpu_verifier)
+        h.use_batch(batch)
+        for m in prepares + commits:
+            assert h.store_add(m.encode()) == 0
+        okp, prepared = h.handle_prepare(r.height, r.round)
+        okc, seals = h.handle_commit(r.height, r.round)
+        results.append((okp, sorted(prepared), okc, sorted(seals), h.store_num(r.height, r.round, 1),
+                        h.store_num(r.height, r.round, 2)))
+        h.close()
+    assert results[0] == results[1]
+    okp, prepared, okc, seals, n_pr, n_cm = results[1]
+    assert okc and okp
+    honest = [i for i in range(n) if r.kinds[i] == ""]
+    assert sorted(seals) == sorted((r.addrs[i].tobytes(), r.seal65[i].tobytes()) for i in honest)
+    assert n_cm == len(honest)
+
+
+def test_batched_ingest_equals_per_message(gpu_verifier, oracle):
+    """IsValidValidator for a burst of incoming messages in one device call."""
+    import go_ibft_amd.hostlib as H
+    n = 64
+    r, proposal, prepares, commits = _build_round(oracle, n, 4242, True)
+    gpu_verifier.set_validators(r.height, r.addrs, r.power)
+    powers = {r.addrs[i].tobytes(): int(r.power[i]) for i in range(n)}
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    wires = [m.encode() for m in commits]
+    h1, h2 = H.Host(), H.Host()
+    for h in (h1, h2):
+        h.vm_init(powers)
+        h.set_state(r.height, r.round, proposal.encode())
+        h.set_verifier(f1, f2, f3)
+    h2.attach_gpu(gpu_verifier)
+    stock = [h1.add_message(w) for w in wires]
+    batched = h2.add_messages_batch(wires)
+    assert stock == batched
+    assert 0 in stock and 2 in stock          # some rejected senders, and the quorum signal fired
+    assert h1.store_num(r.height, r.round, 2) == h2.store_num(r.height, r.round, 2)
