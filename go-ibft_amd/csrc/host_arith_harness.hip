@@ -17,34 +17,39 @@ static std::vector<uint32_t> g_gtab;
 
 extern "C" {
 
-void dev_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) {
-  secp::to_be32(out, secp::fe_mul(secp::from_be32(a), secp::from_be32(b)));
-}
-void dev_fe_sqr(const uint8_t *a, uint8_t *out) { secp::to_be32(out, secp::fe_sqr(secp::from_be32(a))); }
-void dev_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *out) {
-  secp::to_be32(out, secp::fe_add(secp::from_be32(a), secp::from_be32(b)));
-}
-void dev_fe_sub(const uint8_t *a, const uint8_t *b, uint8_t *out) {
-  secp::to_be32(out, secp::fe_sub(secp::from_be32(a), secp::from_be32(b)));
-}
-void dev_fe_inv(const uint8_t *a, uint8_t *out) { secp::to_be32(out, secp::fe_inv(secp::from_be32(a))); }
+static secp::fe fin(const uint8_t *a) { return secp::fe_from_u256(secp::from_be32(a)); }
+static void fout(uint8_t *out, const secp::fe &v) { secp::to_be32(out, secp::fe_to_u256(v)); }
+static secp::sc sin_(const uint8_t *a) { return secp::sc_from_u256(secp::from_be32(a)); }
+static void sout(uint8_t *out, const secp::sc &v) { secp::to_be32(out, secp::sc_canon(v)); }
+
+void dev_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { fout(out, secp::fe_mul(fin(a), fin(b))); }
+void dev_fe_sqr(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_sqr(fin(a))); }
+void dev_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *out) { fout(out, secp::fe_add(fin(a), fin(b))); }
+void dev_fe_sub(const uint8_t *a, const uint8_t *b, uint8_t *out) { fout(out, secp::fe_sub(fin(a), fin(b), 1)); }
+void dev_fe_inv(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv(fin(a))); }
 int dev_fe_sqrt(const uint8_t *a, uint8_t *out) {
-  u256 x = secp::from_be32(a);
-  u256 y = secp::fe_sqrt_candidate(x);
-  secp::to_be32(out, y);
-  return secp::eq(secp::fe_sqr(y), x) ? 1 : 0;
+  secp::fe x = fin(a);
+  secp::fe y = secp::fe_sqrt_candidate(x);
+  fout(out, y);
+  return secp::fe_equal(secp::fe_sqr(y), x, 1) ? 1 : 0;
 }
-void dev_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) {
-  secp::to_be32(out, secp::sc_mul(secp::from_be32(a), secp::from_be32(b)));
+// stress the lazy representation: ((a+b)*k - c)^2 * (a - b) with un-normalised intermediates
+void dev_fe_lazy(const uint8_t *a, const uint8_t *b, const uint8_t *c, uint32_t k, uint8_t *out) {
+  secp::fe A = fin(a), B = fin(b), Cc = fin(c);
+  secp::fe t = secp::fe_add(secp::fe_mul_int(secp::fe_add(A, B), k), secp::fe_neg(Cc, 1));  // 2k + 2
+  secp::fe u = secp::fe_sub(A, B, 1);                                                       // 3
+  fout(out, secp::fe_mul(secp::fe_sqr(t), u));
 }
-void dev_sc_sqr(const uint8_t *a, uint8_t *out) { secp::to_be32(out, secp::sc_sqr(secp::from_be32(a))); }
-void dev_sc_inv(const uint8_t *a, uint8_t *out) { secp::to_be32(out, secp::sc_inv(secp::from_be32(a))); }
+int dev_fe_equal(const uint8_t *a, const uint8_t *b) { return secp::fe_equal(fin(a), fin(b), 1) ? 1 : 0; }
+void dev_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { sout(out, secp::sc_mul(sin_(a), sin_(b))); }
+void dev_sc_sqr(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_sqr(sin_(a))); }
+void dev_sc_inv(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv(sin_(a))); }
 
 void dev_gtab_init(void) {
   if (!g_gtab.empty()) return;
-  g_gtab.resize((size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * 16);
+  g_gtab.resize((size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS);
   for (int t = 0; t < ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES; t++)
-    ibftk::gtab_entry(t / ibftk::GTAB_ENTRIES, t % ibftk::GTAB_ENTRIES, g_gtab.data() + 16 * t);
+    ibftk::gtab_entry(t / ibftk::GTAB_ENTRIES, t % ibftk::GTAB_ENTRIES, g_gtab.data() + ibftk::GTAB_ENTRY_DWORDS * t);
 }
 const uint32_t *dev_gtab_ptr(void) {
   dev_gtab_init();

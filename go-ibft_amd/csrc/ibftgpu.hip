@@ -255,7 +255,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
     if ((rc = alloc_rows(c))) break;
     if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_tally, 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
-    if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * 16 * 4))) break;
+    if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
     int threads = 64, total = ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES;
     hipLaunchKernelGGL(ibftk::gtab_build_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0,
                        c->stream, (uint32_t *)c->d_gtab.p);

@@ -48,7 +48,7 @@ __device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, 
 __global__ void gtab_build_kernel(uint32_t *__restrict__ gtab) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= GTAB_WINDOWS * GTAB_ENTRIES) return;
-  gtab_entry(tid / GTAB_ENTRIES, tid % GTAB_ENTRIES, gtab + 16 * tid);
+  gtab_entry(tid / GTAB_ENTRIES, tid % GTAB_ENTRIES, gtab + GTAB_ENTRY_DWORDS * tid);
 }
 
 // ---- proposal hash + a1 ---------------------------------------------------------------

@@ -31,10 +31,14 @@ __host__ __device__ __forceinline__ uint32_t addr_hash(const uint32_t a[5]) {
   return h ^ (h >> 16);
 }
 
-// ---- fixed-base table: gtab[w][e] = e * 2^(8w) * G, affine, 16 dwords each ----------
+// ---- fixed-base table: gtab[w][e] = e * 2^(8w) * G, affine ------------------------------
+// Each entry is 20 dwords: x then y, ten 26-bit limbs each (the kernels' native form, so a
+// lookup is five 16-byte loads and no repacking).
+constexpr int GTAB_ENTRY_DWORDS = 20;
+
 __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
   if (e == 0) {
-    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (int i = 0; i < GTAB_ENTRY_DWORDS; i++) out[i] = 0;
     return;
   }
   // base = 2^(8w) G, then e*base by double-and-add (8 bits)
@@ -47,9 +51,9 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
   }
   aff a;
   secp::jac_to_aff(a, acc);
-  for (int i = 0; i < 8; i++) {
-    out[i] = a.x.v[i];
-    out[8 + i] = a.y.v[i];
+  for (int i = 0; i < 10; i++) {
+    out[i] = a.x.n[i];
+    out[10 + i] = a.y.n[i];
   }
 }
 
@@ -57,13 +61,14 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
 __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ gtab, const u256 &k, jac acc) {
   for (int w = 0; w < GTAB_WINDOWS; w++) {
     uint32_t dgt = (k.v[w >> 2] >> (8 * (w & 3))) & 255u;
-    const uint4 *e = reinterpret_cast<const uint4 *>(gtab + 16u * (w * GTAB_ENTRIES + dgt));
+    const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * (w * GTAB_ENTRIES + dgt));
+    uint4 t0 = e[0], t1 = e[1], t2 = e[2], t3 = e[3], t4 = e[4];
     aff q;
-    uint4 t0 = e[0], t1 = e[1], t2 = e[2], t3 = e[3];
-    q.x.v[0] = t0.x; q.x.v[1] = t0.y; q.x.v[2] = t0.z; q.x.v[3] = t0.w;
-    q.x.v[4] = t1.x; q.x.v[5] = t1.y; q.x.v[6] = t1.z; q.x.v[7] = t1.w;
-    q.y.v[0] = t2.x; q.y.v[1] = t2.y; q.y.v[2] = t2.z; q.y.v[3] = t2.w;
-    q.y.v[4] = t3.x; q.y.v[5] = t3.y; q.y.v[6] = t3.z; q.y.v[7] = t3.w;
+    q.x.n[0] = t0.x; q.x.n[1] = t0.y; q.x.n[2] = t0.z; q.x.n[3] = t0.w;
+    q.x.n[4] = t1.x; q.x.n[5] = t1.y; q.x.n[6] = t1.z; q.x.n[7] = t1.w;
+    q.x.n[8] = t2.x; q.x.n[9] = t2.y; q.y.n[0] = t2.z; q.y.n[1] = t2.w;
+    q.y.n[2] = t3.x; q.y.n[3] = t3.y; q.y.n[4] = t3.z; q.y.n[5] = t3.w;
+    q.y.n[6] = t4.x; q.y.n[7] = t4.y; q.y.n[8] = t4.z; q.y.n[9] = t4.w;
     jac sum = secp::jac_add_aff(acc, q);
     if (dgt != 0) acc = sum;
   }
@@ -90,37 +95,39 @@ __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) 
 // Recover the signer address of (digest z, r, s, v); returns false if the signature
 // is rejected (same rejection list as oracle/secp256k1.c:orc_ecrecover).
 __host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restrict__ gtab, const u256 &z_raw,
-                                                const u256 &r, const u256 &s, uint32_t v,
-                                                uint32_t flags, uint32_t addr[5]) {
+                                                         const u256 &r, const u256 &s, uint32_t v,
+                                                         uint32_t flags, uint32_t addr[5]) {
   bool ok = v <= 1;
   ok = ok && !secp::is_zero(r) && !secp::geq_const(r, secp::NL());
   ok = ok && !secp::is_zero(s) && !secp::geq_const(s, secp::NL());
-  if (flags & 1u) {  // strict low-s: reject s > (n-1)/2, i.e. s >= (n-1)/2 + 1
+  if (flags & 1u) {  // strict low-s: reject s > (n-1)/2, i.e. s - 1 >= (n-1)/2
     u256 sm1;
     secp::sub256(sm1, s, secp::one256());
     ok = ok && !secp::geq_const(sm1, secp::NHL());
   }
-  // R = (r, y), y^2 = r^3 + 7, parity(y) = v
-  u256 seven = secp::zero256();
-  seven.v[0] = 7;
-  u256 rhs = secp::fe_add(secp::fe_mul(secp::fe_sqr(r), r), seven);
-  u256 y = secp::fe_sqrt_candidate(rhs);
-  ok = ok && secp::eq(secp::fe_sqr(y), rhs);
-  u256 yneg = secp::fe_neg(y);
-  y = secp::select((y.v[0] & 1u) != v, yneg, y);
+  // R = (r, y), y^2 = r^3 + 7, parity(y) = v        (r < n < p, so x = r)
+  secp::fe rx = secp::fe_from_u256(r);
+  secp::fe seven = secp::fe_zero();
+  seven.n[0] = 7;
+  secp::fe rhs = secp::fe_add(secp::fe_mul(secp::fe_sqr(rx), rx), seven);  // magnitude 2
+  secp::fe y = secp::fe_sqrt_candidate(rhs);
+  ok = ok && secp::fe_equal(secp::fe_sqr(y), rhs, 2);
+  y = secp::fe_normalize(y);
+  secp::fe yneg = secp::fe_normalize_weak(secp::fe_neg(y, 1));
+  y = secp::l26_select((y.n[0] & 1u) != v, yneg, y);
   aff R;
-  R.x = r;
+  R.x = rx;
   R.y = y;
   // u1 = -z/r, u2 = s/r (mod n)
-  u256 z = secp::sc_normalize(z_raw);
-  u256 rinv = secp::sc_inv(r);
-  u256 u1 = secp::sc_neg(secp::sc_mul(z, rinv));
-  u256 u2 = secp::sc_mul(s, rinv);
+  secp::sc rinv = secp::sc_inv(secp::sc_from_u256(r));
+  u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
+  u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   jac Q = ecmult_var(R, u2);
   Q = ecmult_gen(gtab, u1, Q);
   aff Qa;
   ok = secp::jac_to_aff(Qa, Q) && ok;
-  keccak::address_from_xy(Qa.x.v, Qa.y.v, addr);
+  u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
+  keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
 }
 

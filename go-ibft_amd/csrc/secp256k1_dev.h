@@ -1,20 +1,28 @@
 // secp256k1_dev.h — 256-bit field / scalar / group arithmetic for the gfx950 kernels.
 //
-// Product code (go-ibft_amd).  Implements what an application's Backend does
-// behind go-ibft's Verifier.IsValidCommittedSeal / IsValidValidator
-// (/root/reference/core/backend.go:41-45, 53-55): secp256k1 ECDSA public-key
-// recovery.  The reference ships no arithmetic; conventions are fixed in
-// include/ibftgpu.h and DESIGN.md.
+// Product code (go-ibft_amd).  Implements what an application's Backend does behind
+// go-ibft's Verifier.IsValidCommittedSeal / IsValidValidator
+// (/root/reference/core/backend.go:41-45, 53-55): secp256k1 ECDSA public-key recovery.
+// The reference ships no arithmetic; conventions are fixed in include/ibftgpu.h.
 //
-// Representation: 8 × 32-bit little-endian limbs held in VGPRs, one value per lane
-// (lane-per-signature kernels) — every function here is straight-line, fully
-// unrolled and branch-free on data except the rare exceptional-point paths, so
-// all 64 lanes of a wavefront stay converged.  Integer work only: v_mad_u64_u32 +
-// carry chains; there is no dense contraction here, so no MFMA.
+// Representation — chosen from measurements on MI355X (profiles/r01_ubench_int.txt and
+// the ISA of the first version): v_mad_u64_u32 issues at the same rate as a carry-add,
+// every VCC carry dependency costs two wait states (`s_nop 1`), and 64-bit C accumulators
+// over saturated 32-bit limbs compile into ~230 v_mov per multiply.  So field elements
+// and scalars use a REDUCED RADIX: 10 limbs of 26 bits in 32-bit VGPRs, lazily carried.
+//   * products accumulate in 64-bit columns with pure v_mad_u64_u32 chains
+//     (10 × 2^30·2^30 < 2^64: no carry flags anywhere in the hot path),
+//   * add / negate are 10 plain 32-bit VALU ops,
+//   * reduction folds 2^260 ≡ 0x3D10 + 0x400·2^26 (mod p) with two more mads per limb.
+// "magnitude m" below means: every limb ≤ 2m·(2^26−1) (limb 9: 2m·(2^22−1)).
+// fe_mul / fe_sqr take magnitude ≤ 8 and return magnitude 1.
+//
+// One value per lane, straight-line unrolled code, branch-free on data except the rare
+// exceptional-point paths, so a wavefront stays converged.  Integer only: no MFMA.
 //
 // Everything is __host__ __device__ so the same source is unit-tested on the CPU
-// (tests/test_dev_arith_host.py builds csrc/host_arith_harness.hip with hipcc's
-// host pass); the shipped library only ever runs it on the device.
+// (tests/test_dev_arith_host.py builds csrc/host_arith_harness.hip with hipcc's host
+// pass); the shipped library only ever runs it on the device.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,29 +31,32 @@
 
 namespace secp {
 
+// ------------------------------------------------------------------ 8×32 "canonical" integers
+// Used at the edges only (unpack, range checks, digit extraction, hashing).
 struct u256 {
   uint32_t v[8];
 };
 
-// p = 2^256 - 2^32 - 977
-HD uint32_t P_LIMB(int i) { return i == 0 ? 0xFFFFFC2Fu : (i == 1 ? 0xFFFFFFFEu : 0xFFFFFFFFu); }
-// n (group order)
 HD uint32_t N_LIMB(int i) {
   const uint32_t n[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                          0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   return n[i];
 }
-// 2^256 - n  (129 bits: 5 limbs, top limb = 1)
-HD uint32_t NC_LIMB(int i) {
-  const uint32_t c[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u};
-  return c[i];
-}
-// (n-1)/2
-HD uint32_t NHALF_LIMB(int i) {
+HD uint32_t NHALF_LIMB(int i) {  // (n-1)/2
   const uint32_t h[8] = {0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u,
                          0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu};
   return h[i];
 }
+HD uint32_t P_LIMB(int i) { return i == 0 ? 0xFFFFFC2Fu : (i == 1 ? 0xFFFFFFFEu : 0xFFFFFFFFu); }
+struct NL {
+  HD uint32_t operator()(int i) const { return N_LIMB(i); }
+};
+struct NHL {
+  HD uint32_t operator()(int i) const { return NHALF_LIMB(i); }
+};
+struct PL {
+  HD uint32_t operator()(int i) const { return P_LIMB(i); }
+};
 
 HD bool is_zero(const u256 &a) {
   uint32_t o = 0;
@@ -70,13 +81,12 @@ HD u256 one256() {
   r.v[0] = 1;
   return r;
 }
-HD u256 select(bool c, const u256 &a, const u256 &b) {  // c ? a : b
+HD u256 select(bool c, const u256 &a, const u256 &b) {
   u256 r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
   return r;
 }
-// big-endian 32 bytes -> limbs
 HD u256 from_be32(const uint8_t *b) {
   u256 r;
 #pragma unroll
@@ -96,366 +106,455 @@ HD void to_be32(uint8_t *b, const u256 &a) {
     q[3] = (uint8_t)a.v[i];
   }
 }
-
-// r = a + b, returns carry
-HD uint32_t add256(u256 &r, const u256 &a, const u256 &b) {
-  uint64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (uint64_t)a.v[i] + b.v[i];
-    r.v[i] = (uint32_t)c;
-    c >>= 32;
-  }
-  return (uint32_t)c;
+// explicit carry chains (edge code only: each step costs a VCC wait state on gfx950)
+HD uint32_t addc(uint32_t a, uint32_t b, uint32_t &c) {
+  unsigned co;
+  uint32_t r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
 }
-// r = a - b, returns borrow
-HD uint32_t sub256(u256 &r, const u256 &a, const u256 &b) {
-  uint64_t br = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
-    r.v[i] = (uint32_t)t;
-    br = (t >> 32) & 1;
-  }
-  return (uint32_t)br;
+HD uint32_t subb(uint32_t a, uint32_t b, uint32_t &c) {
+  unsigned co;
+  uint32_t r = __builtin_subc(a, b, c, &co);
+  c = co;
+  return r;
 }
 template <typename LIMB>
 HD bool geq_const(const u256 &a, LIMB limb) {  // a >= constant
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t t = (uint64_t)a.v[i] - limb(i) - br;
-    br = (t >> 32) & 1;
-  }
+  for (int i = 0; i < 8; i++) (void)subb(a.v[i], limb(i), br);
   return br == 0;
 }
 template <typename LIMB>
 HD void sub_const_if(u256 &a, bool c, LIMB limb) {  // a -= c ? constant : 0
-  uint64_t br = 0;
+  uint32_t br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t t = (uint64_t)a.v[i] - (c ? limb(i) : 0u) - br;
-    a.v[i] = (uint32_t)t;
-    br = (t >> 32) & 1;
-  }
+  for (int i = 0; i < 8; i++) a.v[i] = subb(a.v[i], c ? limb(i) : 0u, br);
 }
-template <typename LIMB>
-HD void add_const_if(u256 &a, bool c, LIMB limb) {  // a += c ? constant : 0 (mod 2^256)
-  uint64_t cy = 0;
+HD uint32_t sub256(u256 &r, const u256 &a, const u256 &b) {
+  uint32_t br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    cy += (uint64_t)a.v[i] + (c ? limb(i) : 0u);
-    a.v[i] = (uint32_t)cy;
-    cy >>= 32;
-  }
+  for (int i = 0; i < 8; i++) r.v[i] = subb(a.v[i], b.v[i], br);
+  return br;
 }
-struct PL {
-  HD uint32_t operator()(int i) const { return P_LIMB(i); }
-};
-struct NL {
-  HD uint32_t operator()(int i) const { return N_LIMB(i); }
-};
-struct NHL {
-  HD uint32_t operator()(int i) const { return NHALF_LIMB(i); }
-};
-
-// 8x8 limbs -> 16 limbs, operand scanning; each step a*b + r + carry < 2^64
-HD void mul_wide(uint32_t r[16], const u256 &a, const u256 &b) {
-#pragma unroll
-  for (int i = 0; i < 16; i++) r[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint32_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      uint64_t t = (uint64_t)a.v[i] * b.v[j] + r[i + j] + carry;
-      r[i + j] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
-    r[i + 8] = carry;
-  }
-}
-// 36 products instead of 64: off-diagonal once, doubled, plus the diagonal
-HD void sqr_wide(uint32_t r[16], const u256 &a) {
-#pragma unroll
-  for (int i = 0; i < 16; i++) r[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 7; i++) {
-    uint32_t carry = 0;
-#pragma unroll
-    for (int j = i + 1; j < 8; j++) {
-      uint64_t t = (uint64_t)a.v[i] * a.v[j] + r[i + j] + carry;
-      r[i + j] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
-    r[i + 8] = carry;
-  }
-  // double
-  uint32_t top = 0;
-#pragma unroll
-  for (int i = 1; i < 16; i++) {
-    uint32_t nt = r[i] >> 31;
-    r[i] = (r[i] << 1) | top;
-    top = nt;
-  }
-  // add the squares
-  uint64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t sq = (uint64_t)a.v[i] * a.v[i];
-    c += (uint64_t)r[2 * i] + (uint32_t)sq;
-    r[2 * i] = (uint32_t)c;
-    c >>= 32;
-    c += (uint64_t)r[2 * i + 1] + (uint32_t)(sq >> 32);
-    r[2 * i + 1] = (uint32_t)c;
-    c >>= 32;
-  }
+HD uint32_t nibble(const u256 &k, int idx) {  // idx 0 = least significant 4 bits
+  return (k.v[idx >> 3] >> (4 * (idx & 7))) & 15u;
 }
 
-// ---------------------------------------------------------------- field mod p
-// 512 -> 256 bits using 2^256 ≡ 2^32 + 977 (mod p); result fully reduced
-HD u256 fe_reduce(const uint32_t w[16]) {
-  u256 t;
-  uint64_t c = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    c += (uint64_t)w[k] + (uint64_t)w[8 + k] * 977u + (k > 0 ? w[8 + k - 1] : 0u);
-    t.v[k] = (uint32_t)c;
-    c >>= 32;
-  }
-  uint64_t top = c + w[15];  // < 2^34
-  uint64_t m = top * 977u;   // < 2^44
-  c = (uint64_t)t.v[0] + (uint32_t)m;
-  t.v[0] = (uint32_t)c;
-  c >>= 32;
-  c += (uint64_t)t.v[1] + (m >> 32) + (uint32_t)top;
-  t.v[1] = (uint32_t)c;
-  c >>= 32;
-  c += (uint64_t)t.v[2] + (top >> 32);
-  t.v[2] = (uint32_t)c;
-  c >>= 32;
-#pragma unroll
-  for (int k = 3; k < 8; k++) {
-    c += t.v[k];
-    t.v[k] = (uint32_t)c;
-    c >>= 32;
-  }
-  // a carry out means the value wrapped past 2^256 once more: add 2^32+977
-  uint32_t wrap = (uint32_t)c;
-  c = (uint64_t)t.v[0] + (wrap ? 977u : 0u);
-  t.v[0] = (uint32_t)c;
-  c >>= 32;
-  c += (uint64_t)t.v[1] + wrap;
-  t.v[1] = (uint32_t)c;
-  c >>= 32;
-#pragma unroll
-  for (int k = 2; k < 8; k++) {
-    c += t.v[k];
-    t.v[k] = (uint32_t)c;
-    c >>= 32;
-  }
-  sub_const_if(t, geq_const(t, PL()), PL());
-  return t;
-}
-HD u256 fe_mul(const u256 &a, const u256 &b) {
-  uint32_t w[16];
-  mul_wide(w, a, b);
-  return fe_reduce(w);
-}
-HD u256 fe_sqr(const u256 &a) {
-  uint32_t w[16];
-  sqr_wide(w, a);
-  return fe_reduce(w);
-}
-HD u256 fe_add(const u256 &a, const u256 &b) {
-  u256 r;
-  uint32_t c = add256(r, a, b);
-  sub_const_if(r, c || geq_const(r, PL()), PL());
+// ------------------------------------------------------------------ 10×26 limbs
+constexpr uint32_t M26 = 0x3FFFFFFu;
+constexpr uint32_t M22 = 0x03FFFFFu;
+
+struct l26 {  // 260-bit container: Σ n[i]·2^(26i)
+  uint32_t n[10];
+};
+using fe = l26;  // field element mod p (magnitude-tracked, lazily reduced)
+using sc = l26;  // scalar mod n ("weak": limbs < 2^26, value < 2^260)
+
+HD l26 l26_from_u256(const u256 &a) {
+  l26 r;
+  r.n[0] = a.v[0] & M26;
+  r.n[1] = ((a.v[0] >> 26) | (a.v[1] << 6)) & M26;
+  r.n[2] = ((a.v[1] >> 20) | (a.v[2] << 12)) & M26;
+  r.n[3] = ((a.v[2] >> 14) | (a.v[3] << 18)) & M26;
+  r.n[4] = ((a.v[3] >> 8) | (a.v[4] << 24)) & M26;
+  r.n[5] = (a.v[4] >> 2) & M26;
+  r.n[6] = ((a.v[4] >> 28) | (a.v[5] << 4)) & M26;
+  r.n[7] = ((a.v[5] >> 22) | (a.v[6] << 10)) & M26;
+  r.n[8] = ((a.v[6] >> 16) | (a.v[7] << 16)) & M26;
+  r.n[9] = a.v[7] >> 10;
   return r;
 }
-HD u256 fe_sub(const u256 &a, const u256 &b) {
+// requires limbs < 2^26 and value < 2^256
+HD u256 l26_to_u256(const l26 &a) {
   u256 r;
-  uint32_t br = sub256(r, a, b);
-  add_const_if(r, br != 0, PL());
+  r.v[0] = a.n[0] | (a.n[1] << 26);
+  r.v[1] = (a.n[1] >> 6) | (a.n[2] << 20);
+  r.v[2] = (a.n[2] >> 12) | (a.n[3] << 14);
+  r.v[3] = (a.n[3] >> 18) | (a.n[4] << 8);
+  r.v[4] = (a.n[4] >> 24) | (a.n[5] << 2) | (a.n[6] << 28);
+  r.v[5] = (a.n[6] >> 4) | (a.n[7] << 22);
+  r.v[6] = (a.n[7] >> 10) | (a.n[8] << 16);
+  r.v[7] = (a.n[8] >> 16) | (a.n[9] << 10);
   return r;
 }
-HD u256 fe_neg(const u256 &a) { return fe_sub(zero256(), a); }
-HD u256 fe_dbl(const u256 &a) { return fe_add(a, a); }
-HD u256 fe_sqr_n(u256 a, int n) {
+HD l26 l26_select(bool c, const l26 &a, const l26 &b) {
+  l26 r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = c ? a.n[i] : b.n[i];
+  return r;
+}
+
+// 19 column sums C[k] = Σ_{i+j=k} a_i·b_j; limbs ≤ 2^30 keep every column < 2^64
+HD void mul_columns(uint64_t C[19], const l26 &a, const l26 &b) {
+#pragma unroll
+  for (int k = 0; k < 19; k++) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < 10) acc += (uint64_t)a.n[i] * b.n[j];
+    }
+    C[k] = acc;
+  }
+}
+// squaring: off-diagonal products once against the pre-doubled operand (55 mads, not 100)
+HD void sqr_columns(uint64_t C[19], const l26 &a) {
+  uint32_t d[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) d[i] = a.n[i] << 1;  // ≤ 2^31
+#pragma unroll
+  for (int k = 0; k < 19; k++) {
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      const int j = k - i;
+      if (j >= 0 && j < 10 && i < j) acc += (uint64_t)d[i] * a.n[j];
+    }
+    if ((k & 1) == 0) acc += (uint64_t)a.n[k / 2] * a.n[k / 2];
+    C[k] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ field mod p = 2^256 − 2^32 − 977
+// 2^260 ≡ 16·(2^32 + 977) = R0 + R1·2^26
+constexpr uint32_t FE_R0 = 0x3D10u, FE_R1 = 0x400u;
+
+HD uint32_t P26(int i) { return i == 0 ? 0x3FFFC2Fu : (i == 1 ? 0x3FFFFBFu : (i == 9 ? M22 : M26)); }
+
+// columns (19 × <2^64) -> magnitude-1 element
+HD fe fe_reduce_columns(uint64_t C[19]) {
+  // (1) normalise the high columns 10..18 to 26-bit limbs U[10..20]
+  uint32_t U[11];
+#pragma unroll
+  for (int k = 10; k < 18; k++) {
+    U[k - 10] = (uint32_t)C[k] & M26;
+    C[k + 1] += C[k] >> 26;
+  }
+  U[8] = (uint32_t)C[18] & M26;
+  uint64_t top = C[18] >> 26;  // < 2^38
+  U[9] = (uint32_t)top & M26;
+  U[10] = (uint32_t)(top >> 26);  // < 2^12
+  // (2) fold: limb k gets R0·U[k+10] + R1·U[k+9]
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    C[k] += (uint64_t)U[k] * FE_R0;
+    if (k >= 1) C[k] += (uint64_t)U[k - 1] * FE_R1;
+  }
+  // what lands on limbs 10 and 11 (≥ 2^260 again) is folded once more; both are < 2^38
+  uint64_t L10 = (uint64_t)U[9] * FE_R1 + (uint64_t)U[10] * FE_R0;
+  uint64_t L11 = (uint64_t)U[10] * FE_R1;
+  C[0] += L10 * FE_R0;
+  C[1] += L10 * FE_R1 + L11 * FE_R0;
+  C[2] += L11 * FE_R1;
+  // (3) carry the low ten columns
+  fe r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    r.n[k] = (uint32_t)C[k] & M26;
+    C[k + 1] += C[k] >> 26;
+  }
+  // (4) limb 9 holds bits ≥ 234; everything above bit 256 folds with 2^256 ≡ 977 + 2^6·2^26
+  uint64_t x = C[9] >> 22;  // < 2^42
+  r.n[9] = (uint32_t)C[9] & M22;
+  uint64_t t0 = (uint64_t)r.n[0] + x * 977u;
+  r.n[0] = (uint32_t)t0 & M26;
+  uint64_t t1 = (uint64_t)r.n[1] + (x << 6) + (t0 >> 26);
+  r.n[1] = (uint32_t)t1 & M26;
+  uint64_t t2 = (uint64_t)r.n[2] + (t1 >> 26);  // ≤ 2^26 + 2^22: magnitude 1 allows it
+  r.n[2] = (uint32_t)t2;
+  return r;
+}
+HD fe fe_mul(const fe &a, const fe &b) {
+  uint64_t C[19];
+  mul_columns(C, a, b);
+  return fe_reduce_columns(C);
+}
+HD fe fe_sqr(const fe &a) {
+  uint64_t C[19];
+  sqr_columns(C, a);
+  return fe_reduce_columns(C);
+}
+HD fe fe_add(const fe &a, const fe &b) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = a.n[i] + b.n[i];
+  return r;
+}
+// −a for a of magnitude ≤ m; result magnitude m+1
+HD fe fe_neg(const fe &a, uint32_t m) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = 2u * (m + 1u) * P26(i) - a.n[i];
+  return r;
+}
+// a − b for b of magnitude ≤ mb; result magnitude ma + mb + 1
+HD fe fe_sub(const fe &a, const fe &b, uint32_t mb) { return fe_add(a, fe_neg(b, mb)); }
+HD fe fe_mul_int(const fe &a, uint32_t k) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = a.n[i] * k;
+  return r;
+}
+// magnitude ≤ 32 -> magnitude 1 (one carry pass + one fold of the bits above 2^256)
+HD fe fe_normalize_weak(const fe &a) {
+  fe r;
+  uint32_t x = a.n[9] >> 22;
+  uint32_t t = a.n[0] + x * 977u;
+  r.n[0] = t & M26;
+  t = a.n[1] + (x << 6) + (t >> 26);
+  r.n[1] = t & M26;
+#pragma unroll
+  for (int i = 2; i < 9; i++) {
+    t = a.n[i] + (t >> 26);
+    r.n[i] = t & M26;
+  }
+  r.n[9] = (a.n[9] & M22) + (t >> 26);
+  return r;
+}
+// any magnitude ≤ 32 -> the canonical representative in [0, p), limbs < 2^26
+HD fe fe_normalize(const fe &a) {
+  fe r = fe_normalize_weak(a);
+  // value < 2^256 + 2^240 < 2p after the weak pass: subtract p once if value ≥ p.
+  // value ≥ p  ⇔  value + 2^32 + 977 ≥ 2^256
+  uint32_t u[10];
+  uint32_t t = r.n[0] + 977u;
+  u[0] = t & M26;
+  t = r.n[1] + 64u + (t >> 26);
+  u[1] = t & M26;
+#pragma unroll
+  for (int i = 2; i < 9; i++) {
+    t = r.n[i] + (t >> 26);
+    u[i] = t & M26;
+  }
+  t = r.n[9] + (t >> 26);
+  u[9] = t & M22;
+  bool ge = (t >> 22) != 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = ge ? u[i] : r.n[i];
+  return r;
+}
+HD bool fe_is_zero(const fe &a) {  // a of magnitude ≤ 32: value ≡ 0 (mod p)?
+  // after one weak pass the value is in [0, 2^256 + 2^240) with limbs 0..8 < 2^26, so it is a
+  // multiple of p only as the all-zero pattern or exactly p's limb pattern
+  fe r = fe_normalize_weak(a);
+  uint32_t z0 = 0, z1 = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    z0 |= r.n[i];
+    z1 |= r.n[i] ^ P26(i);
+  }
+  return z0 == 0 || z1 == 0;
+}
+HD bool fe_equal(const fe &a, const fe &b, uint32_t mb) { return fe_is_zero(fe_sub(a, b, mb)); }
+HD bool fe_is_odd(const fe &a_normalized) { return (a_normalized.n[0] & 1u) != 0; }
+HD fe fe_from_u256(const u256 &a) { return l26_from_u256(a); }     // a < p assumed by callers
+HD u256 fe_to_u256(const fe &a) { return l26_to_u256(fe_normalize(a)); }
+HD fe fe_zero() {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = 0;
+  return r;
+}
+HD fe fe_one() {
+  fe r = fe_zero();
+  r.n[0] = 1;
+  return r;
+}
+HD fe fe_sqr_n(fe a, int n) {
   for (int i = 0; i < n; i++) a = fe_sqr(a);
   return a;
 }
-// shared prefix of the p-2 and (p+1)/4 addition chains: x223 = a^(2^223-1) etc.
+// shared prefix of the p−2 and (p+1)/4 addition chains: x223 = a^(2^223 − 1) etc.
 struct fe_chain {
-  u256 x2, x3, x22, x223;
+  fe x2, x3, x22, x223;
 };
-HD fe_chain fe_chain_223(const u256 &a) {
+HD fe_chain fe_chain_223(const fe &a) {
   fe_chain ch;
   ch.x2 = fe_mul(fe_sqr(a), a);
   ch.x3 = fe_mul(fe_sqr(ch.x2), a);
-  u256 x6 = fe_mul(fe_sqr_n(ch.x3, 3), ch.x3);
-  u256 x9 = fe_mul(fe_sqr_n(x6, 3), ch.x3);
-  u256 x11 = fe_mul(fe_sqr_n(x9, 2), ch.x2);
+  fe x6 = fe_mul(fe_sqr_n(ch.x3, 3), ch.x3);
+  fe x9 = fe_mul(fe_sqr_n(x6, 3), ch.x3);
+  fe x11 = fe_mul(fe_sqr_n(x9, 2), ch.x2);
   ch.x22 = fe_mul(fe_sqr_n(x11, 11), x11);
-  u256 x44 = fe_mul(fe_sqr_n(ch.x22, 22), ch.x22);
-  u256 x88 = fe_mul(fe_sqr_n(x44, 44), x44);
-  u256 x176 = fe_mul(fe_sqr_n(x88, 88), x88);
-  u256 x220 = fe_mul(fe_sqr_n(x176, 44), x44);
+  fe x44 = fe_mul(fe_sqr_n(ch.x22, 22), ch.x22);
+  fe x88 = fe_mul(fe_sqr_n(x44, 44), x44);
+  fe x176 = fe_mul(fe_sqr_n(x88, 88), x88);
+  fe x220 = fe_mul(fe_sqr_n(x176, 44), x44);
   ch.x223 = fe_mul(fe_sqr_n(x220, 3), ch.x3);
   return ch;
 }
-// a^(p-2): exponent bits = 223 ones, 0, 22 ones, 0000101101
-HD u256 fe_inv(const u256 &a) {
+// a^(p−2): exponent bits = 223 ones, 0, 22 ones, 0000101101   (a of magnitude ≤ 8)
+HD fe fe_inv(const fe &a) {
   fe_chain ch = fe_chain_223(a);
-  u256 t = fe_mul(fe_sqr_n(ch.x223, 23), ch.x22);
+  fe t = fe_mul(fe_sqr_n(ch.x223, 23), ch.x22);
   t = fe_mul(fe_sqr_n(t, 5), a);
   t = fe_mul(fe_sqr_n(t, 3), ch.x2);
   t = fe_mul(fe_sqr_n(t, 2), a);
   return t;
 }
-// a^((p+1)/4): exponent bits = 223 ones, 0, 22 ones, 00001100; caller checks r^2 == a
-HD u256 fe_sqrt_candidate(const u256 &a) {
+// a^((p+1)/4): exponent bits = 223 ones, 0, 22 ones, 00001100; caller checks r² == a
+HD fe fe_sqrt_candidate(const fe &a) {
   fe_chain ch = fe_chain_223(a);
-  u256 t = fe_mul(fe_sqr_n(ch.x223, 23), ch.x22);
+  fe t = fe_mul(fe_sqr_n(ch.x223, 23), ch.x22);
   t = fe_mul(fe_sqr_n(t, 6), ch.x2);
   return fe_sqr_n(t, 2);
 }
 
-// ---------------------------------------------------------------- scalars mod n
-// 512 -> 256 bits using 2^256 ≡ c (mod n), c = 2^256 - n (129 bits)
-HD u256 sc_reduce(const uint32_t w[16]) {
-  // pass 1: x = lo + hi*c, hi = w[8..15] (8 limbs) * c (5 limbs) -> 13 limbs
-  uint32_t x[14];
+// ------------------------------------------------------------------ scalars mod n
+// 2^260 ≡ 16·(2^256 − n) = K (133 bits, six 26-bit limbs)
+HD uint32_t SC_K(int i) {
+  // 16·(2^256 − n) = 0x14551231950B75FC4402DA1732FC9BEBF0 in 26-bit limbs
+  const uint32_t k[6] = {0x09BEBF0u, 0x285CCBFu, 0x3C4402Du, 0x2542DD7u, 0x0551231u, 0x5u};
+  return k[i];
+}
+
+// generic: fold limbs [10, 10+nh) of L (26-bit each) down with K; L has room for the result
+template <int NH>
+HD void sc_fold(uint64_t *E, const uint32_t *hi) {
+  // E[k] += Σ_{i+j=k} hi[i]·K[j]
 #pragma unroll
-  for (int i = 0; i < 14; i++) x[i] = i < 8 ? w[i] : 0u;
+  for (int i = 0; i < NH; i++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) E[i + j] += (uint64_t)hi[i] * SC_K(j);
+}
+// carry-normalise NC 64-bit columns into NC+1 26-bit limbs
+template <int NC>
+HD void sc_carry(uint32_t *L, uint64_t *E) {
+#pragma unroll
+  for (int k = 0; k < NC - 1; k++) {
+    L[k] = (uint32_t)E[k] & M26;
+    E[k + 1] += E[k] >> 26;
+  }
+  L[NC - 1] = (uint32_t)E[NC - 1] & M26;
+  L[NC] = (uint32_t)(E[NC - 1] >> 26);
+}
+// 19 product columns -> weak scalar (limbs < 2^26, value < 2^260, ≡ product mod n)
+HD sc sc_reduce_columns(uint64_t C[19]) {
+  uint32_t L[20];
+  sc_carry<19>(L, C);  // 20 limbs; L[19] < 2^26
+  // round 1: hi = L[10..19] (10 limbs) × K -> columns 0..14
+  uint64_t E[15];
+#pragma unroll
+  for (int k = 0; k < 15; k++) E[k] = k < 10 ? L[k] : 0;
+  sc_fold<10>(E, L + 10);
+  uint32_t L2[16];
+  sc_carry<15>(L2, E);  // 16 limbs
+  // round 2: hi = L2[10..15] (6 limbs) × K -> columns 0..10
+  uint64_t F[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) F[k] = k < 10 ? L2[k] : 0;
+  sc_fold<6>(F, L2 + 10);
+  uint32_t L3[12];
+  sc_carry<11>(L3, F);  // 12 limbs: value < 2^260 + 2^(156+133)
+  // round 3: hi = L3[10..11] (≤ 2^29·…) × K -> columns 0..6
+  uint64_t G[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) G[k] = L3[k];
+  sc_fold<2>(G, L3 + 10);
+  uint32_t L4[11];
+  sc_carry<10>(L4, G);  // L4[10] ∈ {0,1}
+  // round 4: one last unit of 2^260
+  uint64_t H[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) H[k] = L4[k];
+#pragma unroll
+  for (int j = 0; j < 6; j++) H[j] += (uint64_t)L4[10] * SC_K(j);
+  uint32_t L5[11];
+  sc_carry<10>(L5, H);
+  sc r;
+#pragma unroll
+  for (int k = 0; k < 10; k++) r.n[k] = L5[k];
+  return r;
+}
+HD sc sc_mul(const sc &a, const sc &b) {
+  uint64_t C[19];
+  mul_columns(C, a, b);
+  return sc_reduce_columns(C);
+}
+HD sc sc_sqr(const sc &a) {
+  uint64_t C[19];
+  sqr_columns(C, a);
+  return sc_reduce_columns(C);
+}
+HD sc sc_from_u256(const u256 &a) { return l26_from_u256(a); }  // any 256-bit value
+// weak scalar -> canonical [0, n) in 8×32 words
+HD u256 sc_canon(const sc &a) {
+  // value = low256 + x·2^256, x = a.n[9] >> 22 (≤ 4 bits); 2^256 ≡ c = 2^256 − n (129 bits)
+  uint32_t x = a.n[9] >> 22;
+  l26 lo = a;
+  lo.n[9] &= M22;
+  u256 r = l26_to_u256(lo);
+  const uint32_t c[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u};
+  uint32_t carry = 0, mc = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    uint32_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      uint64_t t = (uint64_t)w[8 + i] * NC_LIMB(j) + x[i + j] + carry;
-      x[i + j] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
-    // propagate the row carry (x may already hold data above i+5 from lo / earlier rows)
-#pragma unroll
-    for (int k = i + 5; k < 14; k++) {
-      uint64_t t = (uint64_t)x[k] + carry;
-      x[k] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
+    uint64_t m = (i < 5 ? (uint64_t)c[i] * x : 0ull) + mc;  // x·c word i (+ carry of the product)
+    mc = (uint32_t)(m >> 32);
+    r.v[i] = addc(r.v[i], (uint32_t)m, carry);
   }
-  // pass 2: hi2 = x[8..13] (≤ 2^(130+1)) * c -> fold again
-  uint32_t y[14];
+  // a carry out of 2^256 (rare) is one more c
+  uint32_t wrap = carry;
+  carry = 0;
 #pragma unroll
-  for (int i = 0; i < 14; i++) y[i] = i < 8 ? x[i] : 0u;
-#pragma unroll
-  for (int i = 0; i < 5; i++) {  // x[8..12]; x[13] is always 0 (value < 2^(256+130))
-    uint32_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      uint64_t t = (uint64_t)x[8 + i] * NC_LIMB(j) + y[i + j] + carry;
-      y[i + j] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
-#pragma unroll
-    for (int k = i + 5; k < 14; k++) {
-      uint64_t t = (uint64_t)y[k] + carry;
-      y[k] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
-  }
-  // pass 3: y < 2^256 + 2^(131+129): y[8] small (fits one limb), y[9..] = 0
-  u256 r;
-  {
-    uint32_t h = y[8];
-    uint32_t carry = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      uint64_t t = (uint64_t)h * (j < 5 ? NC_LIMB(j) : 0u) + y[j] + carry;
-      r.v[j] = (uint32_t)t;
-      carry = (uint32_t)(t >> 32);
-    }
-    // pass 4: a final wrap adds c once more (value then < 2^256 for sure)
-    uint64_t cy = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      cy += (uint64_t)r.v[j] + ((carry && j < 5) ? NC_LIMB(j) : 0u);
-      r.v[j] = (uint32_t)cy;
-      cy >>= 32;
-    }
-  }
+  for (int i = 0; i < 8; i++) r.v[i] = addc(r.v[i], (wrap && i < 5) ? c[i] : 0u, carry);
   sub_const_if(r, geq_const(r, NL()), NL());
   sub_const_if(r, geq_const(r, NL()), NL());
   return r;
 }
-HD u256 sc_mul(const u256 &a, const u256 &b) {
-  uint32_t w[16];
-  mul_wide(w, a, b);
-  return sc_reduce(w);
-}
-HD u256 sc_sqr(const u256 &a) {
-  uint32_t w[16];
-  sqr_wide(w, a);
-  return sc_reduce(w);
-}
-HD u256 sc_neg(const u256 &a) {  // a in [0,n)
-  u256 r;
-  u256 nn;
+HD u256 sc_neg_canon(const u256 &a) {  // a in [0,n)
+  u256 nn, r;
 #pragma unroll
   for (int i = 0; i < 8; i++) nn.v[i] = N_LIMB(i);
   sub256(r, nn, a);
   return select(is_zero(a), a, r);
 }
-HD u256 sc_normalize(const u256 &a) {  // any 256-bit value -> [0,n)
-  u256 r = a;
-  sub_const_if(r, geq_const(r, NL()), NL());
-  return r;
-}
-HD u256 sc_sqr_n(u256 a, int n) {
+HD sc sc_sqr_n(sc a, int n) {
   for (int i = 0; i < n; i++) a = sc_sqr(a);
   return a;
 }
-// a^(n-2) mod n.  n-2 = [127 ones][0] ‖ 0xBAAEDCE6AF48A03BBFD25E8CD036413F; the top
-// run uses an addition chain, the low 128 bits a plain left-to-right scan.
-HD u256 sc_inv(const u256 &a) {
-  u256 x2 = sc_mul(sc_sqr(a), a);
-  u256 x3 = sc_mul(sc_sqr(x2), a);
-  u256 x6 = sc_mul(sc_sqr_n(x3, 3), x3);
-  u256 x12 = sc_mul(sc_sqr_n(x6, 6), x6);
-  u256 x24 = sc_mul(sc_sqr_n(x12, 12), x12);
-  u256 x48 = sc_mul(sc_sqr_n(x24, 24), x24);
-  u256 x96 = sc_mul(sc_sqr_n(x48, 48), x48);
-  u256 x120 = sc_mul(sc_sqr_n(x96, 24), x24);
-  u256 x126 = sc_mul(sc_sqr_n(x120, 6), x6);
-  u256 t = sc_mul(sc_sqr(x126), a);  // x127
-  t = sc_sqr(t);                     // the single 0 bit (bit 128)
+// a^(n−2) mod n.  n−2 = [127 ones][0] ‖ 0xBAAEDCE6AF48A03BBFD25E8CD036413F: the run of ones
+// by an addition chain, the low 128 bits with 4-bit fixed windows over {a^1..a^15}.
+HD sc sc_inv(const sc &a) {
+  sc x2 = sc_mul(sc_sqr(a), a);
+  sc x3 = sc_mul(sc_sqr(x2), a);
+  sc x6 = sc_mul(sc_sqr_n(x3, 3), x3);
+  sc x12 = sc_mul(sc_sqr_n(x6, 6), x6);
+  sc x24 = sc_mul(sc_sqr_n(x12, 12), x12);
+  sc x48 = sc_mul(sc_sqr_n(x24, 24), x24);
+  sc x96 = sc_mul(sc_sqr_n(x48, 48), x48);
+  sc x120 = sc_mul(sc_sqr_n(x96, 24), x24);
+  sc x126 = sc_mul(sc_sqr_n(x120, 6), x6);
+  sc t = sc_mul(sc_sqr(x126), a);  // x127
+  t = sc_sqr(t);                   // the single 0 bit (bit 128)
   const uint32_t low[4] = {0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u};
   for (int w = 3; w >= 0; w--) {
     uint32_t bits = low[w];
     for (int b = 31; b >= 0; b--) {
       t = sc_sqr(t);
-      u256 tm = sc_mul(t, a);
-      t = select(((bits >> b) & 1u) != 0, tm, t);
+      sc tm = sc_mul(t, a);
+      t = l26_select(((bits >> b) & 1u) != 0, tm, t);
     }
   }
   return t;
 }
 
-// ---------------------------------------------------------------- group (Jacobian, a = 0)
+// ------------------------------------------------------------------ group (Jacobian, a = 0)
+// Coordinates are kept at magnitude 1 between operations.
 struct jac {
-  u256 x, y, z;
+  fe x, y, z;
   bool inf;
 };
 struct aff {
-  u256 x, y;
+  fe x, y;
 };
 
 HD jac jac_inf() {
   jac r;
-  r.x = zero256();
-  r.y = zero256();
-  r.z = zero256();
+  r.x = fe_zero();
+  r.y = fe_zero();
+  r.z = fe_zero();
   r.inf = true;
   return r;
 }
@@ -463,104 +562,111 @@ HD jac jac_from_aff(const aff &a) {
   jac r;
   r.x = a.x;
   r.y = a.y;
-  r.z = one256();
+  r.z = fe_one();
   r.inf = false;
   return r;
 }
-// dbl-2009-l: 2M + 5S
+// dbl-2009-l: 2M + 5S.  Magnitudes in comments.
 HD jac jac_dbl(const jac &p) {
-  u256 A = fe_sqr(p.x);
-  u256 B = fe_sqr(p.y);
-  u256 C = fe_sqr(B);
-  u256 t = fe_sqr(fe_add(p.x, B));
-  t = fe_sub(fe_sub(t, A), C);
-  u256 D = fe_dbl(t);
-  u256 E = fe_add(fe_dbl(A), A);
-  u256 F = fe_sqr(E);
+  fe A = fe_sqr(p.x);                                   // 1
+  fe B = fe_sqr(p.y);                                   // 1
+  fe C = fe_sqr(B);                                     // 1
+  fe t = fe_sqr(fe_add(p.x, B));                        // in 2 -> 1
+  t = fe_add(fe_add(t, fe_neg(A, 1)), fe_neg(C, 1));    // 1+2+2 = 5
+  fe D = fe_normalize_weak(fe_mul_int(t, 2));           // 10 -> 1
+  fe E = fe_mul_int(A, 3);                              // 3
+  fe F = fe_sqr(E);                                     // 1
   jac r;
-  r.x = fe_sub(fe_sub(F, D), D);
-  u256 C8 = fe_dbl(fe_dbl(fe_dbl(C)));
-  r.y = fe_sub(fe_mul(E, fe_sub(D, r.x)), C8);
-  r.z = fe_dbl(fe_mul(p.y, p.z));
-  r.inf = p.inf || is_zero(p.y);
+  r.x = fe_normalize_weak(fe_add(F, fe_neg(fe_mul_int(D, 2), 2)));       // 1 + 3 = 4 -> 1
+  fe C8 = fe_mul_int(C, 8);                                              // 8
+  fe y3 = fe_add(fe_mul(E, fe_add(D, fe_neg(r.x, 1))), fe_neg(C8, 8));   // E:3, D−X3: 1+2=3; 1 + 9 = 10
+  r.y = fe_normalize_weak(y3);
+  r.z = fe_mul(fe_mul_int(p.y, 2), p.z);                                 // in 2,1 -> 1
+  r.inf = p.inf;  // no point of order 2 on this curve: y = 0 cannot occur for on-curve input
   return r;
 }
-// add-2007-bl: 11M + 5S, with the exceptional cases handled (rare, divergent)
+// add-2007-bl: 11M + 5S, exceptional cases handled (rare, divergent)
 HD jac jac_add(const jac &p, const jac &q) {
-  u256 z1z1 = fe_sqr(p.z);
-  u256 z2z2 = fe_sqr(q.z);
-  u256 u1 = fe_mul(p.x, z2z2);
-  u256 u2 = fe_mul(q.x, z1z1);
-  u256 s1 = fe_mul(fe_mul(p.y, q.z), z2z2);
-  u256 s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
-  u256 h = fe_sub(u2, u1);
-  u256 rr = fe_sub(s2, s1);
-  u256 i = fe_sqr(fe_dbl(h));
-  u256 j = fe_mul(h, i);
-  u256 r2 = fe_dbl(rr);
-  u256 v = fe_mul(u1, i);
+  fe z1z1 = fe_sqr(p.z);
+  fe z2z2 = fe_sqr(q.z);
+  fe u1 = fe_mul(p.x, z2z2);
+  fe u2 = fe_mul(q.x, z1z1);
+  fe s1 = fe_mul(fe_mul(p.y, q.z), z2z2);
+  fe s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
+  fe h = fe_add(u2, fe_neg(u1, 1));    // 3
+  fe rr = fe_add(s2, fe_neg(s1, 1));   // 3
+  fe i = fe_sqr(fe_mul_int(h, 2));     // in 6 -> 1
+  fe j = fe_mul(h, i);                 // 1
+  fe r2 = fe_mul_int(rr, 2);           // 6
+  fe v = fe_mul(u1, i);                // 1
   jac r;
-  r.x = fe_sub(fe_sub(fe_sub(fe_sqr(r2), j), v), v);
-  r.y = fe_sub(fe_mul(r2, fe_sub(v, r.x)), fe_dbl(fe_mul(s1, j)));
-  r.z = fe_mul(fe_sub(fe_sub(fe_sqr(fe_add(p.z, q.z)), z1z1), z2z2), h);
+  // X3 = r2² − J − 2V
+  r.x = fe_normalize_weak(fe_add(fe_add(fe_sqr(r2), fe_neg(j, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // 1+2+3 = 6 -> 1
+  // Y3 = r2·(V − X3) − 2·S1·J
+  fe s1j2 = fe_mul_int(fe_mul(s1, j), 2);                                                          // 2
+  r.y = fe_normalize_weak(fe_add(fe_mul(r2, fe_add(v, fe_neg(r.x, 1))), fe_neg(s1j2, 2)));         // 1 + 3 -> 1
+  // Z3 = ((Z1+Z2)² − Z1Z1 − Z2Z2)·H
+  fe zz = fe_add(fe_add(fe_sqr(fe_add(p.z, q.z)), fe_neg(z1z1, 1)), fe_neg(z2z2, 1));              // 5
+  r.z = fe_mul(zz, h);                                                                             // in 5,3 -> 1
   r.inf = false;
   if (p.inf) return q;
   if (q.inf) return p;
-  if (is_zero(h)) {
-    if (is_zero(rr)) return jac_dbl(p);
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) return jac_dbl(p);
     return jac_inf();
   }
   return r;
 }
 // madd-2007-bl: 7M + 4S (q affine, never infinity)
 HD jac jac_add_aff(const jac &p, const aff &q) {
-  u256 z1z1 = fe_sqr(p.z);
-  u256 u2 = fe_mul(q.x, z1z1);
-  u256 s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
-  u256 h = fe_sub(u2, p.x);
-  u256 rr = fe_sub(s2, p.y);
-  u256 hh = fe_sqr(h);
-  u256 i = fe_dbl(fe_dbl(hh));
-  u256 j = fe_mul(h, i);
-  u256 r2 = fe_dbl(rr);
-  u256 v = fe_mul(p.x, i);
+  fe z1z1 = fe_sqr(p.z);
+  fe u2 = fe_mul(q.x, z1z1);
+  fe s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
+  fe h = fe_add(u2, fe_neg(p.x, 1));   // 3
+  fe rr = fe_add(s2, fe_neg(p.y, 1));  // 3
+  fe hh = fe_sqr(h);                   // 1
+  fe i = fe_mul_int(hh, 4);            // 4
+  fe j = fe_mul(h, i);                 // 1
+  fe r2 = fe_mul_int(rr, 2);           // 6
+  fe v = fe_mul(p.x, i);               // 1
   jac r;
-  r.x = fe_sub(fe_sub(fe_sub(fe_sqr(r2), j), v), v);
-  r.y = fe_sub(fe_mul(r2, fe_sub(v, r.x)), fe_dbl(fe_mul(p.y, j)));
-  r.z = fe_sub(fe_sub(fe_sqr(fe_add(p.z, h)), z1z1), hh);
+  r.x = fe_normalize_weak(fe_add(fe_add(fe_sqr(r2), fe_neg(j, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // 6 -> 1
+  fe y1j2 = fe_mul_int(fe_mul(p.y, j), 2);                                                         // 2
+  r.y = fe_normalize_weak(fe_add(fe_mul(r2, fe_add(v, fe_neg(r.x, 1))), fe_neg(y1j2, 2)));         // 4 -> 1
+  // Z3 = (Z1+H)² − Z1Z1 − HH
+  r.z = fe_normalize_weak(fe_add(fe_add(fe_sqr(fe_add(p.z, h)), fe_neg(z1z1, 1)), fe_neg(hh, 1)));  // in 4; 5 -> 1
   r.inf = false;
   if (p.inf) return jac_from_aff(q);
-  if (is_zero(h)) {
-    if (is_zero(rr)) return jac_dbl(jac_from_aff(q));
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) return jac_dbl(jac_from_aff(q));
     return jac_inf();
   }
   return r;
 }
-// returns false if p is infinity
+// returns false if p is infinity; r.x / r.y are canonical (fully normalised)
 HD bool jac_to_aff(aff &r, const jac &p) {
-  u256 zi = fe_inv(p.z);
-  u256 zi2 = fe_sqr(zi);
-  r.x = fe_mul(p.x, zi2);
-  r.y = fe_mul(p.y, fe_mul(zi2, zi));
-  return !(p.inf || is_zero(p.z));
+  fe zi = fe_inv(p.z);
+  fe zi2 = fe_sqr(zi);
+  r.x = fe_normalize(fe_mul(p.x, zi2));
+  r.y = fe_normalize(fe_mul(p.y, fe_mul(zi2, zi)));
+  return !(p.inf || fe_is_zero(p.z));
 }
 
 HD aff generator() {
-  aff g;
-  const uint32_t gx[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu,
-                          0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
-  const uint32_t gy[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u,
-                          0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
+  u256 gx, gy;
+  const uint32_t x[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu,
+                         0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
+  const uint32_t y[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u,
+                         0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    g.x.v[i] = gx[i];
-    g.y.v[i] = gy[i];
+    gx.v[i] = x[i];
+    gy.v[i] = y[i];
   }
+  aff g;
+  g.x = fe_from_u256(gx);
+  g.y = fe_from_u256(gy);
   return g;
-}
-
-HD uint32_t nibble(const u256 &k, int idx) {  // idx 0 = least significant 4 bits
-  return (k.v[idx >> 3] >> (4 * (idx & 7))) & 15u;
 }
 
 }  // namespace secp

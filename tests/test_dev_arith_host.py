@@ -50,6 +50,24 @@ def test_field_and_scalar_ops(dev):
         assert _c1(dev.dev_sc_sqr, b32(a)) == a * a % N
 
 
+def test_lazy_magnitudes_and_noncanonical_inputs(dev):
+    """The 10x26 representation is lazily reduced: un-normalised intermediates of magnitude up
+    to 2k+2 feed fe_sqr/fe_mul directly; inputs >= p are legal encodings of their residue."""
+    rng = np.random.default_rng(12)
+    edge = [0, 1, P - 1, P, P + 1, 2**256 - 1, 2**255, 2**234 - 1, 2**234, (1 << 26) - 1, 1 << 26]
+    vals = edge + [int.from_bytes(rng.bytes(32), "big") for _ in range(60)]
+    for a in vals:
+        for b in vals[::9]:
+            for k in (1, 2, 3):
+                c = vals[(a + b + k) % len(vals)]
+                o = C.create_string_buffer(32)
+                dev.dev_fe_lazy(b32(a), b32(b), b32(c), k, o)
+                assert int.from_bytes(o.raw, "big") == pow(((a + b) * k - c), 2, P) * (a - b) % P
+            assert bool(dev.dev_fe_equal(b32(a), b32(b))) == ((a - b) % P == 0)
+            assert _c2(dev.dev_fe_mul, b32(a), b32(b)) == a * b % P      # non-canonical inputs
+        assert _c1(dev.dev_fe_sqr, b32(a)) == a * a % P
+
+
 def test_inverse_and_sqrt_chains(dev):
     rng = np.random.default_rng(8)
     vals = [1, 2, P - 1, N - 1, 2**255] + [int.from_bytes(rng.bytes(32), "big") for _ in range(40)]
