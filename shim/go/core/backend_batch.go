@@ -1,0 +1,92 @@
+//go:build ibftgpu
+
+// backend_batch.go — lives in package core next to backend.go.  Adds the OPTIONAL batch
+// interface; a Backend that does not implement it keeps the stock per-message path, so
+// RunSequence and every existing Backend keep working unchanged.
+//
+// NOT COMPILED HERE (no Go toolchain in the build image).  The identical control flow is
+// implemented and tested in C++: go-ibft_amd/host/backend.cpp (HotPath::handlePrepare /
+// handleCommit, GpuBackend).
+package core
+
+import (
+	"github.com/0xPolygon/go-ibft/messages"
+	"github.com/0xPolygon/go-ibft/messages/proto"
+)
+
+// BatchVerifier is type-asserted on the Backend passed to NewIBFT.
+type BatchVerifier interface {
+	// verdicts[i] == IsValidProposalHash(proposal, ExtractPrepareHash(msgs[i]))
+	VerifyPrepareBatch(proposal *proto.Proposal, msgs []*proto.IbftMessage) (verdicts []bool, ok bool)
+	// verdicts[i] == IsValidProposalHash(proposal, ExtractCommitHash(msgs[i])) &&
+	//                IsValidCommittedSeal(ExtractCommitHash(msgs[i]), ExtractCommittedSeal(msgs[i]))
+	VerifyCommitBatch(proposal *proto.Proposal, msgs []*proto.IbftMessage) (verdicts []bool, ok bool)
+	// verdicts[i] == IsValidValidator(msgs[i])
+	VerifySenderBatch(msgs []*proto.IbftMessage) (verdicts []bool, ok bool)
+}
+
+// batchStore is implemented by messages.Messages (shim/go/messages/soa.go).
+type batchStore interface {
+	GetValidMessagesBatch(view *proto.View, t proto.MessageType,
+		verdicts func([]*proto.IbftMessage) []bool) []*proto.IbftMessage
+}
+
+// commitMessagesFor replaces the first statement of handleCommit (core/ibft.go:931-946):
+//
+//	commitMessages := i.commitMessagesFor(view)
+//
+// With a BatchVerifier the whole view is verified in one device call; without one (or when the
+// device path reports !ok) the stock closure runs, message by message.
+func (i *IBFT) commitMessagesFor(view *proto.View) []*proto.IbftMessage {
+	isValidCommit := func(message *proto.IbftMessage) bool {
+		proposalHash := messages.ExtractCommitHash(message)
+		committedSeal := messages.ExtractCommittedSeal(message)
+		if !i.backend.IsValidProposalHash(i.state.getProposal(), proposalHash) {
+			return false
+		}
+		return i.backend.IsValidCommittedSeal(proposalHash, committedSeal)
+	}
+	bv, hasBatch := i.backend.(BatchVerifier)
+	store, storeOK := i.messages.(batchStore)
+	if hasBatch && storeOK {
+		fellBack := false
+		msgs := store.GetValidMessagesBatch(view, proto.MessageType_COMMIT,
+			func(all []*proto.IbftMessage) []bool {
+				verdicts, ok := bv.VerifyCommitBatch(i.state.getProposal(), all)
+				if !ok { // device unavailable: answer with the per-message verifier, same lock held
+					fellBack = true
+					verdicts = make([]bool, len(all))
+					for k, m := range all {
+						verdicts[k] = isValidCommit(m)
+					}
+				}
+				return verdicts
+			})
+		_ = fellBack // exported as a metric in a real integration
+		return msgs
+	}
+	return i.messages.GetValidMessages(view, proto.MessageType_COMMIT, isValidCommit)
+}
+
+// prepareMessagesFor is the same change for handlePrepare (core/ibft.go:855-868).
+func (i *IBFT) prepareMessagesFor(view *proto.View) []*proto.IbftMessage {
+	isValidPrepare := func(message *proto.IbftMessage) bool {
+		return i.backend.IsValidProposalHash(i.state.getProposal(), messages.ExtractPrepareHash(message))
+	}
+	bv, hasBatch := i.backend.(BatchVerifier)
+	store, storeOK := i.messages.(batchStore)
+	if hasBatch && storeOK {
+		return store.GetValidMessagesBatch(view, proto.MessageType_PREPARE,
+			func(all []*proto.IbftMessage) []bool {
+				verdicts, ok := bv.VerifyPrepareBatch(i.state.getProposal(), all)
+				if !ok {
+					verdicts = make([]bool, len(all))
+					for k, m := range all {
+						verdicts[k] = isValidPrepare(m)
+					}
+				}
+				return verdicts
+			})
+	}
+	return i.messages.GetValidMessages(view, proto.MessageType_PREPARE, isValidPrepare)
+}

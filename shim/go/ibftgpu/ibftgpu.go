@@ -1,0 +1,135 @@
+//go:build ibftgpu
+
+// Package ibftgpu is the thin cgo binding of libibftgpu.so (include/ibftgpu.h).
+//
+// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain.  It is the
+// reference-side stub a go-ibft maintainer adds; the C side it binds is exercised through the
+// same C ABI by tests/ (ctypes) and by go-ibft_amd/host (C++).
+//
+// cgo rules honoured: every slice handed to C is a flat []byte/[]uint32/[]uint64 without Go
+// pointers inside; C copies it to HBM before returning and retains nothing.
+package ibftgpu
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../go-ibft_amd/csrc -libftgpu -Wl,-rpath,${SRCDIR}/../../../go-ibft_amd/csrc
+#include <stdlib.h>
+#include "ibftgpu.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+)
+
+// ErrFallback tells the caller to run its own per-message Verifier for this batch.
+// The library never synthesises verdicts on failure (all-false stalls liveness,
+// all-true breaks safety).
+var ErrFallback = errors.New("ibftgpu: device path unavailable, use the CPU verifier")
+
+const (
+	RowNil     = C.IBFT_ROW_NIL
+	RowBadLen  = C.IBFT_ROW_BADLEN
+	RowHashBad = C.IBFT_ROW_HASH_BAD
+)
+
+// Tally mirrors ibft_tally_t (ValidatorManager.HasQuorum over the valid rows).
+type Tally struct {
+	QuorumLo, QuorumHi uint64
+	PowerLo, PowerHi   uint64
+	ValidRows          uint32
+	DistinctSenders    uint32
+	HasQuorum          bool
+}
+
+// Ctx owns one ibft_ctx (one HIP stream, resident columns on one GPU).  Use one Ctx per
+// concurrent caller: AddMessage goroutines, the round goroutine and the two watcher
+// goroutines of core/ibft.go:335-347 each hold their own (a sync.Pool works well).
+type Ctx struct{ h *C.ibft_ctx }
+
+func New(device int, maxRows uint32, strictLowS bool) (*Ctx, error) {
+	cfg := C.ibft_cfg{device: C.int32_t(device), max_rows: C.uint32_t(maxRows)}
+	if strictLowS {
+		cfg.flags = C.IBFT_FLAG_STRICT_LOW_S
+	}
+	var h *C.ibft_ctx
+	if rc := C.ibft_ctx_create(&cfg, &h); rc != C.IBFT_OK {
+		return nil, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	c := &Ctx{h: h}
+	runtime.SetFinalizer(c, (*Ctx).Close)
+	return c, nil
+}
+
+func (c *Ctx) Close() {
+	if c.h != nil {
+		C.ibft_ctx_destroy(c.h)
+		c.h = nil
+	}
+}
+
+func ptr8(b []byte) *C.uint8_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&b[0]))
+}
+
+func (c *Ctx) check(rc C.int) error {
+	if rc == C.IBFT_OK {
+		return nil
+	}
+	return fmt.Errorf("%w: %s %s", ErrFallback, C.GoString(C.ibft_strerror(rc)), C.GoString(C.ibft_last_error(c.h)))
+}
+
+// SetValidators uploads the table GetVotingPowers(height) returned (20-byte addresses, u64
+// powers; callers whose powers exceed u64 must stay on the *big.Int path).
+func (c *Ctx) SetValidators(height uint64, addrs20 []byte, power []uint64) error {
+	n := len(power)
+	var pp *C.uint64_t
+	if n > 0 {
+		pp = (*C.uint64_t)(unsafe.Pointer(&power[0]))
+	}
+	return c.check(C.ibft_set_validators(c.h, C.uint64_t(height), ptr8(addrs20), pp, C.size_t(n)))
+}
+
+// VerifyHashes = IsValidProposalHash over a batch (core/ibft.go:858-861, 938).
+func (c *Ctx) VerifyHashes(raw []byte, round uint64, hash32, hashLen []byte) ([]uint64, error) {
+	n := len(hashLen)
+	mask := make([]uint64, (n+63)/64+1)
+	rc := C.ibft_verify_hashes(c.h, ptr8(raw), C.size_t(len(raw)), C.uint64_t(round), ptr8(hash32), ptr8(hashLen),
+		C.size_t(n), (*C.uint64_t)(unsafe.Pointer(&mask[0])))
+	return mask, c.check(rc)
+}
+
+// VerifySeals = IsValidCommittedSeal over a batch (core/ibft.go:943).
+func (c *Ctx) VerifySeals(hash32, sig65, signer20, preFlags []byte) ([]uint64, Tally, error) {
+	n := len(sig65) / 65
+	mask := make([]uint64, (n+63)/64+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_verify_seals(c.h, ptr8(hash32), ptr8(sig65), ptr8(signer20), ptr8(preFlags), C.size_t(n),
+		(*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
+	return mask, tally(t), c.check(rc)
+}
+
+// VerifySenders = IsValidValidator over a batch (core/ibft.go:1128); payload is the
+// concatenation of msg.PayloadNoSig(), off its n+1 offsets.
+func (c *Ctx) VerifySenders(payload []byte, off []uint32, sig65, from20, preFlags []byte) ([]uint64, Tally, error) {
+	n := len(off) - 1
+	mask := make([]uint64, (n+63)/64+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_verify_senders(c.h, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0])), ptr8(sig65), ptr8(from20),
+		ptr8(preFlags), C.size_t(n), (*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
+	return mask, tally(t), c.check(rc)
+}
+
+func tally(t C.ibft_tally_t) Tally {
+	return Tally{uint64(t.quorum_lo), uint64(t.quorum_hi), uint64(t.power_lo), uint64(t.power_hi),
+		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0}
+}
+
+// Bit reports row i's verdict.
+func Bit(mask []uint64, i int) bool { return mask[i>>6]>>(uint(i)&63)&1 == 1 }
