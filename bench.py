@@ -104,16 +104,20 @@ def main():
     bv = V.BatchVerifier(device=local, max_rows=max(rows, 1024))  # raises without the HIP lib / GPU
     bv.set_validators(1, addrs, power)
     bv.seals_stage(hash32, seal65, signer20)                      # H2D once: inputs resident in HBM
-    words = (rows + 63) // 64
-    # all-reduce buffer: [mask words of every shard | power_lo, power_hi, valid|distinct<<32, has_quorum]
-    ar = torch.zeros(words * world + 4, dtype=torch.int64, device=dev) if dist else None
+    import go_ibft_amd.shard as S
+    words = S.words_per_rank(n_total, world)
+    slots, tally_off = S.exchange_layout(n_total, world)
+    assert S.shard_range(n_total, rank, world) == (lo, hi)
+    # exchange buffer: [mask words of every shard | power_lo, power_hi, valid|distinct<<32] (+1 spare:
+    # the library exports 4 tally words, the 4th — has_quorum — is recomputed after the merge)
+    ar = torch.zeros(slots + 1, dtype=torch.int64, device=dev) if dist else None
 
     def step():
         bv.seals_launch(1)
         if dist is None:
             return bv.seals_fetch()
         ar.zero_()
-        bv.seals_export(ar[rank * words:].data_ptr(), ar[words * world:].data_ptr())
+        bv.seals_export(ar[rank * words:].data_ptr(), ar[tally_off:].data_ptr())
         dist.all_reduce(ar)  # disjoint shards: sum == OR; tally partials add
         return ar
 
@@ -150,10 +154,9 @@ def main():
         verdict, tally = out
         assert verdict.all() and tally.has_quorum == 1 and tally.power == int(power.sum())
     else:
-        host = ar.cpu().numpy()
-        valid = sum(bin(int(w) & (2**64 - 1)).count("1") for w in host[:words * world])
-        assert valid == n_total, (valid, n_total)
-        assert int(host[words * world]) == int(power.sum())
+        quorum = 2 * int(power.sum()) // 3 + 1
+        verdict, pw, valid, distinct, hq = S.merge(ar.cpu().numpy()[:slots], n_total, world, quorum)
+        assert verdict.all() and valid == n_total and pw == int(power.sum()) and hq
 
     if rank == 0:
         verifies = n_total * args.steps
