@@ -67,5 +67,5 @@ def test_shard_ranges_cover_and_align():
             ranges = [S.shard_range(n, r, w) for r in range(w)]
             assert ranges[0][0] == 0 and ranges[-1][1] == n
             for (a, b), (c, d) in zip(ranges, ranges[1:]):
-                assert b == c and a % 64 == 0 and (c % 64 == 0 or d == c)   # empty tail shards may be unaligned
+                assert b == c and (a % 64 == 0 or b == a) and (c % 64 == 0 or d == c)   # empty tail shards may be unaligned
             assert all(hi - lo <= S.words_per_rank(n, w) * 64 for lo, hi in ranges)
