@@ -45,6 +45,26 @@ void dev_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { sout(out, se
 void dev_sc_sqr(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_sqr(sin_(a))); }
 void dev_sc_inv(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv(sin_(a))); }
 
+// GLV split: out = k1(32 BE) ‖ k2(32 BE), returns neg1 | neg2<<1
+int dev_glv_split(const uint8_t *k, uint8_t *out64) {
+  secp::glv_split s = secp::sc_split_lambda(secp::from_be32(k));
+  secp::to_be32(out64, s.k1);
+  secp::to_be32(out64 + 32, s.k2);
+  return (s.neg1 ? 1 : 0) | (s.neg2 ? 2 : 0);
+}
+// out = k * P (affine, 64 BE bytes) through ecmult_var; returns 0 for infinity
+int dev_ecmult_var(const uint8_t *k, const uint8_t *p64, uint8_t *out64) {
+  ibftk::aff P;
+  P.x = fin(p64);
+  P.y = fin(p64 + 32);
+  ibftk::jac q = ibftk::ecmult_var(P, secp::from_be32(k));
+  ibftk::aff a;
+  bool ok = secp::jac_to_aff(a, q);
+  secp::to_be32(out64, secp::l26_to_u256(a.x));
+  secp::to_be32(out64 + 32, secp::l26_to_u256(a.y));
+  return ok ? 1 : 0;
+}
+
 void dev_gtab_init(void) {
   if (!g_gtab.empty()) return;
   g_gtab.resize((size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS);

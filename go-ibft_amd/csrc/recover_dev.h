@@ -75,19 +75,31 @@ __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ 
   return acc;
 }
 
-// u2*R with a per-lane table of 1..15 multiples (4-bit fixed windows, MSB first)
+// u2*R through the GLV split: u2 = k1 + k2·λ with 128-bit |k1|, |k2|, so 128 doublings instead
+// of 256.  One per-lane table of j·(±R), j = 1..15; the λ-multiple of an entry is (β·X, Y, Z),
+// its sign is folded into Y.  4-bit fixed windows, MSB first, both scalars share the doublings.
 __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) {
+  secp::glv_split sp = secp::sc_split_lambda(k);
+  aff R1 = R;
+  R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
+  const bool flip2 = sp.neg1 != sp.neg2;
+  const secp::fe beta = secp::GLV_CONST(1);
   jac tab[16];
   tab[0] = secp::jac_inf();
-  tab[1] = secp::jac_from_aff(R);
+  tab[1] = secp::jac_from_aff(R1);
   tab[2] = secp::jac_dbl(tab[1]);
-  for (int i = 3; i < 16; i++) tab[i] = secp::jac_add_aff(tab[i - 1], R);
+  for (int i = 3; i < 16; i++) tab[i] = secp::jac_add_aff(tab[i - 1], R1);
   jac acc = secp::jac_inf();
-  for (int nib = 63; nib >= 0; nib--) {
+  for (int nib = 31; nib >= 0; nib--) {
     for (int d = 0; d < 4; d++) acc = secp::jac_dbl(acc);
-    uint32_t dgt = secp::nibble(k, nib);
-    jac sum = secp::jac_add(acc, tab[dgt]);
-    if (dgt != 0) acc = sum;
+    uint32_t d1 = secp::nibble(sp.k1, nib), d2 = secp::nibble(sp.k2, nib);
+    jac s1 = secp::jac_add(acc, tab[d1]);
+    if (d1 != 0) acc = s1;
+    jac q = tab[d2];
+    q.x = secp::fe_mul(q.x, beta);
+    q.y = secp::l26_select(flip2, secp::fe_neg(q.y, 1), q.y);  // magnitude ≤ 2
+    jac s2 = secp::jac_add(acc, q);
+    if (d2 != 0) acc = s2;
   }
   return acc;
 }

@@ -540,6 +540,85 @@ HD sc sc_inv(const sc &a) {
   return t;
 }
 
+// ------------------------------------------------------------------ GLV endomorphism
+// λ·(x, y) = (β·x, y) with λ³ ≡ 1 (mod n), β³ ≡ 1 (mod p).  Any scalar k splits as
+// k ≡ k1 + k2·λ (mod n) with |k1|, |k2| < 2^128 (lattice basis (a1,b1),(a2,b2) of the
+// endomorphism; g1, g2 = round(2^384·b2/n), round(2^384·(−b1)/n)), which halves the number of
+// doublings of the variable-base multiplication.  Constants are the curve's standard ones
+// (checked in tests/test_dev_arith_host.py: λ·G = (β·Gx, Gy), k1 + k2·λ ≡ k, 128-bit bounds).
+HD l26 GLV_CONST(int which) {
+  const uint32_t c[6][10] = {
+      // λ
+      {0x323BD72u, 0x0A59F06u, 0x2678DF0u, 0x3A88205u, 0x2122E22u, 0x2049916u, 0x261C028u, 0x0C38294u, 0x14CC05Cu, 0x014D8EBu},
+      // β
+      {0x19501EEu, 0x25B0A1Cu, 0x0995C13u, 0x1D44BD6u, 0x19CF049u, 0x30D0D3Au, 0x24479EAu, 0x01C41B9u, 0x22B657Cu, 0x01EBA5Au},
+      // −b1
+      {0x2BFE4C3u, 0x11FEA42u, 0x08286F5u, 0x358043Au, 0x0E4437Eu, 0, 0, 0, 0, 0},
+      // −b2 (= n − b2)
+      {0x1B1562Cu, 0x1736A0Fu, 0x346DD76u, 0x3141DD0u, 0x28A280Au, 0x3FFFFFFu, 0x3FFFFFFu, 0x3FFFFFFu, 0x3FFFFFFu, 0x03FFFFFu},
+      // g1
+      {0x1DBB031u, 0x0C82691u, 0x0A7FE89u, 0x051C7A3u, 0x13DAA8Au, 0x0A13AC5u, 0x2C90E49u, 0x1AF37A1u, 0x221A7D4u, 0x00C21B4u},
+      // g2
+      {0x2C47F71u, 0x06D2BA2u, 0x06C6157u, 0x2B277D4u, 0x0221208u, 0x2AFF931u, 0x147FA90u, 0x220A1BDu, 0x2D6010Eu, 0x03910DFu}};
+  l26 r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) r.n[i] = c[which][i];
+  return r;
+}
+// round(k·g / 2^384) for 256-bit k, g (exact 512-bit product, no modular reduction)
+HD sc mul_shift_384(const sc &k, const sc &g) {
+  uint64_t C[19];
+  mul_columns(C, k, g);
+  uint32_t L[20];
+  sc_carry<19>(L, C);
+  // bit 384 = limb 14, bit 20; rounding bit 383 = limb 14, bit 19
+  sc r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    uint32_t lo = (14 + i < 20) ? (L[14 + i] >> 20) : 0u;
+    uint32_t hi = (15 + i < 20) ? (L[15 + i] << 6) : 0u;
+    r.n[i] = (lo | hi) & M26;
+  }
+  r.n[0] += (L[14] >> 19) & 1u;  // ≤ 2^26: still a legal sc_mul operand
+  return r;
+}
+HD u256 n256() {
+  u256 r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = N_LIMB(i);
+  return r;
+}
+HD u256 add_mod_n(const u256 &a, const u256 &b) {  // a, b in [0, n)
+  u256 r;
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = addc(a.v[i], b.v[i], c);
+  sub_const_if(r, c != 0 || geq_const(r, NL()), NL());
+  return r;
+}
+struct glv_split {
+  u256 k1, k2;  // magnitudes, < 2^128
+  bool neg1, neg2;
+};
+HD glv_split sc_split_lambda(const u256 &k) {  // k in [0, n)
+  sc ks = sc_from_u256(k);
+  sc c1 = sc_mul(mul_shift_384(ks, GLV_CONST(4)), GLV_CONST(2));
+  sc c2 = sc_mul(mul_shift_384(ks, GLV_CONST(5)), GLV_CONST(3));
+  u256 r2 = add_mod_n(sc_canon(c1), sc_canon(c2));
+  u256 t = sc_canon(sc_mul(sc_from_u256(r2), GLV_CONST(0)));
+  u256 r1 = add_mod_n(k, sc_neg_canon(t));
+  glv_split s;
+  // a "negative" residue is one above (n−1)/2: x − 1 ≥ (n−1)/2  ⇔  x > (n−1)/2
+  u256 m1;
+  sub256(m1, r1, one256());
+  s.neg1 = !is_zero(r1) && geq_const(m1, NHL());
+  sub256(m1, r2, one256());
+  s.neg2 = !is_zero(r2) && geq_const(m1, NHL());
+  s.k1 = select(s.neg1, sc_neg_canon(r1), r1);
+  s.k2 = select(s.neg2, sc_neg_canon(r2), r2);
+  return s;
+}
+
 // ------------------------------------------------------------------ group (Jacobian, a = 0)
 // Coordinates are kept at magnitude 1 between operations.
 struct jac {

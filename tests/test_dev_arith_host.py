@@ -85,6 +85,31 @@ def test_inverse_and_sqrt_chains(dev):
             assert int.from_bytes(o.raw, "big") == y
 
 
+def test_glv_split_and_variable_base_mult(dev):
+    """k ≡ k1 + k2·λ (mod n) with 128-bit halves; λ·G = (β·Gx, Gy); ecmult_var(k, P) == k·P."""
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    beta = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+    assert pow(lam, 3, N) == 1 and pow(beta, 3, P) == 1
+    assert R.pt_mul(lam, R.G) == (beta * R.G[0] % P, R.G[1])
+    rng = np.random.default_rng(11)
+    ks = [0, 1, 2, N - 1, N - 2, N // 2, N // 2 + 1, lam, N - lam, 2**128, 2**128 - 1, 2**255] + \
+        [int.from_bytes(rng.bytes(32), "big") % N for _ in range(1500)]
+    for k in ks:
+        o = C.create_string_buffer(64)
+        f = dev.dev_glv_split(b32(k), o)
+        k1, k2 = int.from_bytes(o.raw[:32], "big"), int.from_bytes(o.raw[32:], "big")
+        assert k1 < 2**128 and k2 < 2**128
+        assert ((-k1 if f & 1 else k1) + (-k2 if f & 2 else k2) * lam) % N == k
+    for k in ks[:30]:
+        pt = R.pt_mul(int.from_bytes(rng.bytes(24), "big") + 1, R.G)
+        o = C.create_string_buffer(64)
+        ok = dev.dev_ecmult_var(b32(k), R.pub_bytes(pt), o)
+        exp = R.pt_mul(k, pt)
+        assert bool(ok) == (exp is not None)
+        if exp is not None:
+            assert o.raw == R.pub_bytes(exp)
+
+
 def test_keccak_streaming(dev, oracle):
     rng = np.random.default_rng(9)
     for ln in [0, 1, 55, 64, 131, 135, 136, 137, 200, 271, 272, 273, 1032]:
