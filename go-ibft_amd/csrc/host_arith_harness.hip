@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "recover_dev.h"
+#include "modinv_dev.h"
 
 using secp::u256;
 
@@ -45,6 +46,8 @@ void dev_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { sout(out, se
 void dev_sc_sqr(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_sqr(sin_(a))); }
 void dev_sc_inv(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv(sin_(a))); }
 
+void dev_fe_inv_safegcd(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv_safegcd(fin(a))); }
+void dev_sc_inv_safegcd(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv_safegcd(sin_(a))); }
 // GLV split: out = k1(32 BE) ‖ k2(32 BE), returns neg1 | neg2<<1
 int dev_glv_split(const uint8_t *k, uint8_t *out64) {
   secp::glv_split s = secp::sc_split_lambda(secp::from_be32(k));

@@ -10,6 +10,7 @@
 
 #include "keccak_dev.h"
 #include "secp256k1_dev.h"
+#include "modinv_dev.h"
 
 namespace ibftk {
 
@@ -50,7 +51,7 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
     if ((e >> b) & 1) acc = secp::jac_add(acc, base);
   }
   aff a;
-  secp::jac_to_aff(a, acc);
+  secp::jac_to_aff_fast(a, acc);
   for (int i = 0; i < 10; i++) {
     out[i] = a.x.n[i];
     out[10 + i] = a.y.n[i];
@@ -131,13 +132,13 @@ __host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restr
   R.x = rx;
   R.y = y;
   // u1 = -z/r, u2 = s/r (mod n)
-  secp::sc rinv = secp::sc_inv(secp::sc_from_u256(r));
+  secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));  // r is canonical, in [1, n)
   u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   jac Q = ecmult_var(R, u2);
   Q = ecmult_gen(gtab, u1, Q);
   aff Qa;
-  ok = secp::jac_to_aff(Qa, Q) && ok;
+  ok = secp::jac_to_aff_fast(Qa, Q) && ok;
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;

@@ -266,16 +266,39 @@ HD fe fe_reduce_columns(uint64_t C[19]) {
   r.n[2] = (uint32_t)t2;
   return r;
 }
-HD fe fe_mul(const fe &a, const fe &b) {
+HD fe fe_mul_inl(const fe &a, const fe &b) {
   uint64_t C[19];
   mul_columns(C, a, b);
   return fe_reduce_columns(C);
 }
-HD fe fe_sqr(const fe &a) {
+HD fe fe_sqr_inl(const fe &a) {
   uint64_t C[19];
   sqr_columns(C, a);
   return fe_reduce_columns(C);
 }
+// On the device the multiply / square bodies are REAL functions (s_swappc), not inlined: the
+// fully inlined kernel was 53 k instructions (420 KB) with a 100 KB main-loop body, far beyond
+// the 64 KB instruction cache, and instruction fetch — not the VALU — set the time.  Arguments
+// are passed as 20 scalars so they travel in VGPRs (a by-value struct pair goes through scratch).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SECP_ARGS10(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, \
+                       uint32_t p##5, uint32_t p##6, uint32_t p##7, uint32_t p##8, uint32_t p##9
+#define SECP_PACK10(p) {{p##0, p##1, p##2, p##3, p##4, p##5, p##6, p##7, p##8, p##9}}
+#define SECP_PASS10(x) x.n[0], x.n[1], x.n[2], x.n[3], x.n[4], x.n[5], x.n[6], x.n[7], x.n[8], x.n[9]
+static __device__ __attribute__((noinline)) fe fe_mul_fn(SECP_ARGS10(a), SECP_ARGS10(b)) {
+  fe a = SECP_PACK10(a), b = SECP_PACK10(b);
+  return fe_mul_inl(a, b);
+}
+static __device__ __attribute__((noinline)) fe fe_sqr_fn(SECP_ARGS10(a)) {
+  fe a = SECP_PACK10(a);
+  return fe_sqr_inl(a);
+}
+HD fe fe_mul(const fe &a, const fe &b) { return fe_mul_fn(SECP_PASS10(a), SECP_PASS10(b)); }
+HD fe fe_sqr(const fe &a) { return fe_sqr_fn(SECP_PASS10(a)); }
+#else
+HD fe fe_mul(const fe &a, const fe &b) { return fe_mul_inl(a, b); }
+HD fe fe_sqr(const fe &a) { return fe_sqr_inl(a); }
+#endif
 HD fe fe_add(const fe &a, const fe &b) {
   fe r;
 #pragma unroll
@@ -468,16 +491,31 @@ HD sc sc_reduce_columns(uint64_t C[19]) {
   for (int k = 0; k < 10; k++) r.n[k] = L5[k];
   return r;
 }
-HD sc sc_mul(const sc &a, const sc &b) {
+HD sc sc_mul_inl(const sc &a, const sc &b) {
   uint64_t C[19];
   mul_columns(C, a, b);
   return sc_reduce_columns(C);
 }
-HD sc sc_sqr(const sc &a) {
+HD sc sc_sqr_inl(const sc &a) {
   uint64_t C[19];
   sqr_columns(C, a);
   return sc_reduce_columns(C);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __attribute__((noinline)) sc sc_mul_fn(SECP_ARGS10(a), SECP_ARGS10(b)) {
+  sc a = SECP_PACK10(a), b = SECP_PACK10(b);
+  return sc_mul_inl(a, b);
+}
+static __device__ __attribute__((noinline)) sc sc_sqr_fn(SECP_ARGS10(a)) {
+  sc a = SECP_PACK10(a);
+  return sc_sqr_inl(a);
+}
+HD sc sc_mul(const sc &a, const sc &b) { return sc_mul_fn(SECP_PASS10(a), SECP_PASS10(b)); }
+HD sc sc_sqr(const sc &a) { return sc_sqr_fn(SECP_PASS10(a)); }
+#else
+HD sc sc_mul(const sc &a, const sc &b) { return sc_mul_inl(a, b); }
+HD sc sc_sqr(const sc &a) { return sc_sqr_inl(a); }
+#endif
 HD sc sc_from_u256(const u256 &a) { return l26_from_u256(a); }  // any 256-bit value
 // weak scalar -> canonical [0, n) in 8×32 words
 HD u256 sc_canon(const sc &a) {

@@ -85,6 +85,24 @@ def test_inverse_and_sqrt_chains(dev):
             assert int.from_bytes(o.raw, "big") == y
 
 
+def test_safegcd_inversion(dev):
+    """modinv_dev.h (divsteps, 20 batches of 30) against pow(x, -1, M) for both moduli, and the
+    radix-2^30 constants it hard-codes."""
+    for M, limbs, inv in ((P, [0x3FFFFC2F, 0x3FFFFFFB] + [0x3FFFFFFF] * 6 + [0xFFFF], 0x2DDACACF),
+                          (N, [0x10364141, 0x3F497A33, 0x348A03BB, 0x2BB739AB, 0x3FFFFEBA] + [0x3FFFFFFF] * 3 + [0xFFFF],
+                           0x2A774EC1)):
+        assert sum(l << (30 * i) for i, l in enumerate(limbs)) == M and pow(M, -1, 2**30) == inv
+    rng = np.random.default_rng(13)
+    edge = [0, 1, 2, 3, P - 1, P - 2, N - 1, N - 2, 2**255, 2**128, 2**30, 2**30 - 1, 2**60 + 1, (P + 1) // 2,
+            (N + 1) // 2, P // 3, N // 3]
+    vals = edge + [int.from_bytes(rng.bytes(32), "big") for _ in range(1500)] + \
+        [int.from_bytes(rng.bytes(32), "big") >> s for s in range(1, 256, 5)]
+    for a in vals:
+        ap, an = a % P, a % N
+        assert _c1(dev.dev_fe_inv_safegcd, b32(ap)) == (pow(ap, -1, P) if ap else 0)
+        assert _c1(dev.dev_sc_inv_safegcd, b32(an)) == (pow(an, -1, N) if an else 0)
+
+
 def test_glv_split_and_variable_base_mult(dev):
     """k ≡ k1 + k2·λ (mod n) with 128-bit halves; λ·G = (β·Gx, Gy); ecmult_var(k, P) == k·P."""
     lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
