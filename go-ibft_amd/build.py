@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libibftgpu.so")
-SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "secp256k1_dev.h", "keccak_dev.h",
+SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h",
            os.path.join("..", "..", "include", "ibftgpu.h")]
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 
@@ -30,9 +30,21 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+DEVTEST = os.path.join(CSRC, "libibft_devtest.so")
+
+
+def build_devtest(force: bool = False) -> str:
+    """TEST-ONLY: single arithmetic primitives as gfx950 kernels (tests/test_gpu_arith.py)."""
+    deps = ["devtest.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
+    if force or _stale(DEVTEST, deps):
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-w",
+                               "-o", DEVTEST, os.path.join(CSRC, "devtest.hip")], cwd=CSRC)
+    return DEVTEST
+
+
 def build_host_harness(force: bool = False) -> str:
     """TEST-ONLY: the device arithmetic headers compiled for the CPU (hipcc host pass)."""
-    deps = ["host_arith_harness.hip", "recover_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
+    deps = ["host_arith_harness.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
     if force or _stale(HOST_HARNESS, deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
                                "-o", HOST_HARNESS, os.path.join(CSRC, "host_arith_harness.hip")], cwd=CSRC)

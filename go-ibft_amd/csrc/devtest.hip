@@ -1,0 +1,133 @@
+// devtest.hip — TEST-ONLY library (libibft_devtest.so): runs single arithmetic primitives of
+// secp256k1_dev.h / modinv_dev.h ON THE GPU so tests/test_gpu_arith.py can compare the gfx950
+// code object op by op with Python big integers.  Not part of libibftgpu.so.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "modinv_dev.h"
+#include "recover_dev.h"
+#include "secp256k1_dev.h"
+
+using namespace secp;
+
+__global__ void devtest_kernel(int op, int n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u256 x = from_be32(a + 32 * i), y = from_be32(b + 32 * i);
+  u256 r = zero256();
+  switch (op) {
+    case 0: r = fe_to_u256(fe_mul(fe_from_u256(x), fe_from_u256(y))); break;
+    case 1: r = fe_to_u256(fe_sqr(fe_from_u256(x))); break;
+    case 2: r = fe_to_u256(fe_inv(fe_from_u256(x))); break;
+    case 3: r = fe_to_u256(fe_inv_safegcd(fe_from_u256(x))); break;
+    case 4: r = sc_canon(sc_mul(sc_from_u256(x), sc_from_u256(y))); break;
+    case 5: r = sc_canon(sc_inv(sc_from_u256(x))); break;
+    case 6: r = sc_canon(sc_inv_safegcd(sc_from_u256(x))); break;
+    case 7: r = fe_to_u256(fe_sqrt_candidate(fe_from_u256(x))); break;
+    case 8: {
+      glv_split s = sc_split_lambda(x);
+      r = s.k1;
+      to_be32(out + 32 * (n + i), s.k2);
+      out[64 * n + i] = (uint8_t)((s.neg1 ? 1 : 0) | (s.neg2 ? 2 : 0));
+      break;
+    }
+    case 12: case 13: {  // x = number of doublings of G; out = affine x of 2^k G (12: Fermat, 13: safegcd)
+      jac base = jac_from_aff(generator());
+      for (uint32_t k = 0; k < x.v[0]; k++) base = jac_dbl(base);
+      aff af;
+      if (op == 12) jac_to_aff(af, base); else jac_to_aff_fast(af, base);
+      r = l26_to_u256(af.x);
+      break;
+    }
+    case 14: {  // gtab_entry(w = x.v[0], e = y.v[0]) -> x coordinate
+      uint32_t ent[20];
+      ibftk::gtab_entry((int)x.v[0], (int)y.v[0], ent);
+      l26 t;
+      for (int k = 0; k < 10; k++) t.n[k] = ent[k];
+      r = l26_to_u256(t);
+      break;
+    }
+    case 15: case 16: {  // x = k1, y = k2: affine x of k1·G + k2·G through jac_add (15) / jac_add_aff (16); 0 = infinity
+      aff g = generator();
+      jac p1 = ibftk::ecmult_var(g, x), p2 = ibftk::ecmult_var(g, y);
+      jac sum;
+      if (op == 15) {
+        sum = jac_add(p1, p2);
+      } else {
+        aff a2;
+        bool fin2 = jac_to_aff_fast(a2, p2);
+        jac viaaff = jac_add_aff(p1, a2);
+        sum = jac_select(fin2, viaaff, p1);  // an infinite q is not representable in affine form
+      }
+      aff af;
+      bool fin = jac_to_aff_fast(af, sum);
+      r = fin ? l26_to_u256(af.x) : zero256();
+      break;
+    }
+    case 9: r = modinv<ModP>(x); break;
+    case 10: r = modinv<ModN>(x); break;
+    case 11: {  // one batch: divsteps + both updates, output d (as raw 9 limbs packed little-endian 36 B -> first 32)
+      s30 d, e, f, g = s30_from_u256(x);
+      for (int k = 0; k < 9; k++) { d.v[k] = 0; e.v[k] = 0; f.v[k] = ModN::limb(k); }
+      e.v[0] = 1;
+      trans2x2 t;
+      int32_t zeta = divsteps_30(-1, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+      update_de_30<ModN>(d, e, t);
+      update_fg_30(f, g, t);
+      r.v[0] = (uint32_t)t.u; r.v[1] = (uint32_t)t.v; r.v[2] = (uint32_t)t.q; r.v[3] = (uint32_t)t.r;
+      r.v[4] = (uint32_t)zeta; r.v[5] = (uint32_t)f.v[0]; r.v[6] = (uint32_t)g.v[0]; r.v[7] = (uint32_t)e.v[0];
+      break;
+    }
+  }
+  to_be32(out + 32 * i, r);
+}
+
+__global__ void devtest_gtab_kernel(uint32_t *gtab) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES) return;
+  ibftk::gtab_entry(tid / ibftk::GTAB_ENTRIES, tid % ibftk::GTAB_ENTRIES, gtab + ibftk::GTAB_ENTRY_DWORDS * tid);
+}
+// digest (a), sig r (b), sig s (c), v: out = 20-byte address + ok flag, 32 B per row
+__global__ void devtest_recover_kernel(int n, const uint32_t *gtab, const uint8_t *dig, const uint8_t *r,
+                                       const uint8_t *s, const uint8_t *v, uint8_t *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t addr[5];
+  bool ok = ibftk::recover_address(gtab, from_be32(dig + 32 * i), from_be32(r + 32 * i), from_be32(s + 32 * i),
+                                   v[i], 0, addr);
+  for (int k = 0; k < 5; k++) reinterpret_cast<uint32_t *>(out + 32 * i)[k] = addr[k];
+  out[32 * i + 20] = ok ? 1 : 0;
+}
+extern "C" int devtest_recover(int n, const uint8_t *dig, const uint8_t *r, const uint8_t *s, const uint8_t *v,
+                               uint8_t *out, uint32_t *gtab_out) {
+  uint8_t *dd, *dr, *ds, *dv, *dout;
+  uint32_t *dg;
+  size_t gbytes = (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4;
+  if (hipMalloc(&dg, gbytes) != hipSuccess) return -1;
+  (void)hipMalloc(&dd, 32 * n); (void)hipMalloc(&dr, 32 * n); (void)hipMalloc(&ds, 32 * n);
+  (void)hipMalloc(&dv, n); (void)hipMalloc(&dout, 32 * n);
+  (void)hipMemcpy(dd, dig, 32 * n, hipMemcpyHostToDevice); (void)hipMemcpy(dr, r, 32 * n, hipMemcpyHostToDevice);
+  (void)hipMemcpy(ds, s, 32 * n, hipMemcpyHostToDevice); (void)hipMemcpy(dv, v, n, hipMemcpyHostToDevice);
+  devtest_gtab_kernel<<<(8192 + 63) / 64, 64>>>(dg);
+  devtest_recover_kernel<<<(n + 63) / 64, 64>>>(n, dg, dd, dr, ds, dv, dout);
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  (void)hipMemcpy(out, dout, 32 * n, hipMemcpyDeviceToHost);
+  if (gtab_out) (void)hipMemcpy(gtab_out, dg, gbytes, hipMemcpyDeviceToHost);
+  (void)hipFree(dd); (void)hipFree(dr); (void)hipFree(ds); (void)hipFree(dv); (void)hipFree(dout); (void)hipFree(dg);
+  return rc;
+}
+
+extern "C" int devtest_run(int op, int n, const uint8_t *a, const uint8_t *b, uint8_t *out, int out_bytes) {
+  uint8_t *da, *db, *dout;
+  if (hipMalloc(&da, 32 * n) != hipSuccess) return -1;
+  hipMalloc(&db, 32 * n);
+  hipMalloc(&dout, out_bytes);
+  hipMemcpy(da, a, 32 * n, hipMemcpyHostToDevice);
+  hipMemcpy(db, b, 32 * n, hipMemcpyHostToDevice);
+  hipMemset(dout, 0, out_bytes);
+  devtest_kernel<<<(n + 63) / 64, 64>>>(op, n, da, db, dout);
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  hipMemcpy(out, dout, out_bytes, hipMemcpyDeviceToHost);
+  hipFree(da); hipFree(db); hipFree(dout);
+  return rc;
+}

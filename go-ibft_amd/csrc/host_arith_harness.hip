@@ -68,6 +68,24 @@ int dev_ecmult_var(const uint8_t *k, const uint8_t *p64, uint8_t *out64) {
   return ok ? 1 : 0;
 }
 
+// affine x of k1·G + k2·G through jac_add (via_aff = 0) or jac_add_aff (1); returns 0 for infinity
+int dev_point_add_case(const uint8_t *k1, const uint8_t *k2, int via_aff, uint8_t *out32) {
+  ibftk::aff g = secp::generator();
+  ibftk::jac p1 = ibftk::ecmult_var(g, secp::from_be32(k1)), p2 = ibftk::ecmult_var(g, secp::from_be32(k2));
+  ibftk::jac sum;
+  if (!via_aff) {
+    sum = secp::jac_add(p1, p2);
+  } else {
+    ibftk::aff a2;
+    bool fin2 = secp::jac_to_aff_fast(a2, p2);
+    sum = fin2 ? secp::jac_add_aff(p1, a2) : p1;
+  }
+  ibftk::aff af;
+  bool fin = secp::jac_to_aff_fast(af, sum);
+  secp::to_be32(out32, fin ? secp::l26_to_u256(af.x) : secp::zero256());
+  return fin ? 1 : 0;
+}
+
 void dev_gtab_init(void) {
   if (!g_gtab.empty()) return;
   g_gtab.resize((size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS);

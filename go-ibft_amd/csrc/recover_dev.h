@@ -48,7 +48,10 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
   jac acc = secp::jac_inf();
   for (int b = 7; b >= 0; b--) {
     acc = secp::jac_dbl(acc);
-    if ((e >> b) & 1) acc = secp::jac_add(acc, base);
+    // branch-free: the add is always computed and then selected, so no function call ever
+    // executes under a partial EXEC mask (lanes of one wavefront hold different e)
+    jac sum = secp::jac_add(acc, base);
+    acc = secp::jac_select(((e >> b) & 1) != 0, sum, acc);
   }
   aff a;
   secp::jac_to_aff_fast(a, acc);

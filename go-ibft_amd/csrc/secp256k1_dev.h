@@ -657,6 +657,19 @@ HD glv_split sc_split_lambda(const u256 &k) {  // k in [0, n)
   return s;
 }
 
+// true if the predicate holds on ANY lane of the wavefront (host build: the single "lane").
+// Used to turn the rare exceptional-point paths into WAVE-UNIFORM branches: measured on
+// gfx950 / ROCm 7.2, a call to an outlined device function that executes under a partial EXEC
+// mask can return wrong values (tests/test_gpu_arith.py::test_gtab_and_full_recover_on_gpu
+// caught it), so no function call in this code base may sit under divergent control flow.
+HD bool wave_any(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any(c ? 1 : 0) != 0;
+#else
+  return c;
+#endif
+}
+
 // ------------------------------------------------------------------ group (Jacobian, a = 0)
 // Coordinates are kept at magnitude 1 between operations.
 struct jac {
@@ -673,6 +686,14 @@ HD jac jac_inf() {
   r.y = fe_zero();
   r.z = fe_zero();
   r.inf = true;
+  return r;
+}
+HD jac jac_select(bool c, const jac &a, const jac &b) {
+  jac r;
+  r.x = l26_select(c, a.x, b.x);
+  r.y = l26_select(c, a.y, b.y);
+  r.z = l26_select(c, a.z, b.z);
+  r.inf = c ? a.inf : b.inf;
   return r;
 }
 HD jac jac_from_aff(const aff &a) {
@@ -726,12 +747,15 @@ HD jac jac_add(const jac &p, const jac &q) {
   fe zz = fe_add(fe_add(fe_sqr(fe_add(p.z, q.z)), fe_neg(z1z1, 1)), fe_neg(z2z2, 1));              // 5
   r.z = fe_mul(zz, h);                                                                             // in 5,3 -> 1
   r.inf = false;
-  if (p.inf) return q;
-  if (q.inf) return p;
-  if (fe_is_zero(h)) {
-    if (fe_is_zero(rr)) return jac_dbl(p);
-    return jac_inf();
-  }
+  // exceptional cases, branch-free per lane; the doubling runs for the whole wave if any lane needs it
+  const bool both = !p.inf && !q.inf;
+  const bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
+  const bool same = both && hz && rz;       // P == Q
+  const bool opposite = both && hz && !rz;  // P == −Q
+  if (wave_any(same)) r = jac_select(same, jac_dbl(p), r);
+  r = jac_select(opposite, jac_inf(), r);
+  r = jac_select(q.inf, p, r);
+  r = jac_select(p.inf, q, r);
   return r;
 }
 // madd-2007-bl: 7M + 4S (q affine, never infinity)
@@ -753,11 +777,13 @@ HD jac jac_add_aff(const jac &p, const aff &q) {
   // Z3 = (Z1+H)² − Z1Z1 − HH
   r.z = fe_normalize_weak(fe_add(fe_add(fe_sqr(fe_add(p.z, h)), fe_neg(z1z1, 1)), fe_neg(hh, 1)));  // in 4; 5 -> 1
   r.inf = false;
-  if (p.inf) return jac_from_aff(q);
-  if (fe_is_zero(h)) {
-    if (fe_is_zero(rr)) return jac_dbl(jac_from_aff(q));
-    return jac_inf();
-  }
+  const bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
+  const bool same = !p.inf && hz && rz;
+  const bool opposite = !p.inf && hz && !rz;
+  const jac qj = jac_from_aff(q);
+  if (wave_any(same)) r = jac_select(same, jac_dbl(qj), r);
+  r = jac_select(opposite, jac_inf(), r);
+  r = jac_select(p.inf, qj, r);
   return r;
 }
 // returns false if p is infinity; r.x / r.y are canonical (fully normalised)

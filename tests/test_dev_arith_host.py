@@ -128,6 +128,27 @@ def test_glv_split_and_variable_base_mult(dev):
             assert o.raw == R.pub_bytes(exp)
 
 
+def _point_add_cases():
+    rng = np.random.default_rng(21)
+    ks = [int.from_bytes(rng.bytes(32), "big") % N for _ in range(6)] + [1, 2, N - 1]
+    cases = []
+    for k in ks:
+        cases += [(k, k), (k, N - k), (k, 0), (0, k), (k, (k * 7 + 3) % N), (k, 1)]
+    return cases + [(0, 0)]
+
+
+def test_exceptional_point_additions(dev):
+    """P+P, P+(−P), ∞+P, P+∞ through jac_add and jac_add_aff (wave-uniform exceptional paths)."""
+    for k1, k2 in _point_add_cases():
+        exp = R.pt_mul((k1 + k2) % N, R.G)
+        for via_aff in (0, 1):
+            o = C.create_string_buffer(32)
+            ok = dev.dev_point_add_case(b32(k1), b32(k2), via_aff, o)
+            assert bool(ok) == (exp is not None), (k1, k2, via_aff)
+            if exp is not None:
+                assert int.from_bytes(o.raw, "big") == exp[0], (k1, k2, via_aff)
+
+
 def test_keccak_streaming(dev, oracle):
     rng = np.random.default_rng(9)
     for ln in [0, 1, 55, 64, 131, 135, 136, 137, 200, 271, 272, 273, 1032]:
