@@ -85,7 +85,7 @@ __global__ void devtest_kernel(int op, int n, const uint8_t *a, const uint8_t *b
 __global__ void devtest_gtab_kernel(uint32_t *gtab) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES) return;
-  ibftk::gtab_entry(tid / ibftk::GTAB_ENTRIES, tid % ibftk::GTAB_ENTRIES, gtab + ibftk::GTAB_ENTRY_DWORDS * tid);
+  ibftk::gtab_entry(tid / ibftk::GTAB_ENTRIES, tid % ibftk::GTAB_ENTRIES, gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * tid);
 }
 // digest (a), sig r (b), sig s (c), v: out = 20-byte address + ok flag, 32 B per row
 __global__ void devtest_recover_kernel(int n, const uint32_t *gtab, const uint8_t *dig, const uint8_t *r,
@@ -108,13 +108,19 @@ extern "C" int devtest_recover(int n, const uint8_t *dig, const uint8_t *r, cons
   (void)hipMalloc(&dv, n); (void)hipMalloc(&dout, 32 * n);
   (void)hipMemcpy(dd, dig, 32 * n, hipMemcpyHostToDevice); (void)hipMemcpy(dr, r, 32 * n, hipMemcpyHostToDevice);
   (void)hipMemcpy(ds, s, 32 * n, hipMemcpyHostToDevice); (void)hipMemcpy(dv, v, n, hipMemcpyHostToDevice);
-  devtest_gtab_kernel<<<(8192 + 63) / 64, 64>>>(dg);
+  devtest_gtab_kernel<<<(ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES + 63) / 64, 64>>>(dg);
   devtest_recover_kernel<<<(n + 63) / 64, 64>>>(n, dg, dd, dr, ds, dv, dout);
   int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
   (void)hipMemcpy(out, dout, 32 * n, hipMemcpyDeviceToHost);
   if (gtab_out) (void)hipMemcpy(gtab_out, dg, gbytes, hipMemcpyDeviceToHost);
   (void)hipFree(dd); (void)hipFree(dr); (void)hipFree(ds); (void)hipFree(dv); (void)hipFree(dout); (void)hipFree(dg);
   return rc;
+}
+
+extern "C" void devtest_gtab_dims(int *windows, int *entries, int *bits) {
+  *windows = ibftk::GTAB_WINDOWS;
+  *entries = ibftk::GTAB_ENTRIES;
+  *bits = ibftk::GTAB_BITS;
 }
 
 extern "C" int devtest_run(int op, int n, const uint8_t *a, const uint8_t *b, uint8_t *out, int out_bytes) {

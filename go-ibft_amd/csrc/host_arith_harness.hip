@@ -3,6 +3,7 @@
 // on the CPU so tests/test_dev_arith_host.py can compare the exact kernel source
 // against the oracle in this GPU-less container.  Built with hipcc's host pass;
 // never linked into libibftgpu.so and never used as a fallback.
+#define IBFT_GTAB_BITS 8  // small table for the CPU harness (see recover_dev.h)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>

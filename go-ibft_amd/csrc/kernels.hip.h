@@ -48,7 +48,7 @@ __device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, 
 __global__ void gtab_build_kernel(uint32_t *__restrict__ gtab) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= GTAB_WINDOWS * GTAB_ENTRIES) return;
-  gtab_entry(tid / GTAB_ENTRIES, tid % GTAB_ENTRIES, gtab + GTAB_ENTRY_DWORDS * tid);
+  gtab_entry(tid / GTAB_ENTRIES, tid % GTAB_ENTRIES, gtab + (size_t)GTAB_ENTRY_DWORDS * tid);
 }
 
 // ---- proposal hash + a1 ---------------------------------------------------------------
@@ -90,7 +90,7 @@ struct recover_args {
   const uint8_t *pre_flags; // n or null
   const uint8_t *payload;   // senders: concatenated PayloadNoSig
   const uint32_t *off;      // senders: n+1 offsets
-  const uint32_t *gtab;     // GTAB_WINDOWS×GTAB_ENTRIES×16 dwords
+  const uint32_t *gtab;     // GTAB_WINDOWS×GTAB_ENTRIES×20 dwords
   const uint32_t *vtab;     // validator table
   uint32_t vslot_mask;
   uint32_t n;

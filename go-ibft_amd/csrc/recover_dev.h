@@ -18,8 +18,18 @@ using secp::aff;
 using secp::jac;
 using secp::u256;
 
-constexpr int GTAB_WINDOWS = 32;   // 8-bit windows over a 256-bit scalar
-constexpr int GTAB_ENTRIES = 256;  // entry 0 unused
+// Fixed-base window width for u1·G.  16-bit windows: 16 lookups + 16 mixed additions per
+// signature from an 84 MB table (16 × 65 536 affine points × 80 B) that lives in HBM and is
+// served from the 256 MB Infinity Cache — memory is the cheap resource on this part, VALU
+// issue slots are not.  (The CPU test harness builds the same code with 8-bit windows so that
+// its table takes 0.4 s instead of a minute to fill.)
+#ifndef IBFT_GTAB_BITS
+#define IBFT_GTAB_BITS 16
+#endif
+constexpr int GTAB_BITS = IBFT_GTAB_BITS;
+constexpr int GTAB_WINDOWS = 256 / GTAB_BITS;
+constexpr int GTAB_ENTRIES = 1 << GTAB_BITS;  // entry 0 unused
+static_assert(32 % GTAB_BITS == 0, "a window must not straddle a 32-bit word");
 
 // ---- validator table (open addressing, linear probing) ---------------------------
 // slot = 6 dwords: addr[5], index+1 (0 = empty)
@@ -32,7 +42,7 @@ __host__ __device__ __forceinline__ uint32_t addr_hash(const uint32_t a[5]) {
   return h ^ (h >> 16);
 }
 
-// ---- fixed-base table: gtab[w][e] = e * 2^(8w) * G, affine ------------------------------
+// ---- fixed-base table: gtab[w][e] = e * 2^(B·w) * G, affine ------------------------------
 // Each entry is 20 dwords: x then y, ten 26-bit limbs each (the kernels' native form, so a
 // lookup is five 16-byte loads and no repacking).
 constexpr int GTAB_ENTRY_DWORDS = 20;
@@ -42,11 +52,11 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
     for (int i = 0; i < GTAB_ENTRY_DWORDS; i++) out[i] = 0;
     return;
   }
-  // base = 2^(8w) G, then e*base by double-and-add (8 bits)
+  // base = 2^(B·w) G, then e*base by double-and-add (B bits)
   jac base = secp::jac_from_aff(secp::generator());
-  for (int k = 0; k < 8 * w; k++) base = secp::jac_dbl(base);
+  for (int k = 0; k < GTAB_BITS * w; k++) base = secp::jac_dbl(base);
   jac acc = secp::jac_inf();
-  for (int b = 7; b >= 0; b--) {
+  for (int b = GTAB_BITS - 1; b >= 0; b--) {
     acc = secp::jac_dbl(acc);
     // branch-free: the add is always computed and then selected, so no function call ever
     // executes under a partial EXEC mask (lanes of one wavefront hold different e)
@@ -61,11 +71,11 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
   }
 }
 
-// u1*G from the 8-bit-window table (32 mixed adds, no doublings)
+// u1*G from the fixed-base table (GTAB_WINDOWS mixed adds, no doublings)
 __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ gtab, const u256 &k, jac acc) {
   for (int w = 0; w < GTAB_WINDOWS; w++) {
-    uint32_t dgt = (k.v[w >> 2] >> (8 * (w & 3))) & 255u;
-    const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * (w * GTAB_ENTRIES + dgt));
+    uint32_t dgt = (k.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+    const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
     uint4 t0 = e[0], t1 = e[1], t2 = e[2], t3 = e[3], t4 = e[4];
     aff q;
     q.x.n[0] = t0.x; q.x.n[1] = t0.y; q.x.n[2] = t0.z; q.x.n[3] = t0.w;

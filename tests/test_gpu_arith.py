@@ -90,12 +90,15 @@ def test_gtab_and_full_recover_on_gpu(dt, oracle):
         dig += d; rr += sig[:32]; ss += sig[32:64]; vv += sig[64:]
         exp.append(oracle.recover_address(d, sig))
     out = C.create_string_buffer(32 * n)
-    gt = (C.c_uint32 * (32 * 256 * 20))()
+    nw, ne, nb = C.c_int(), C.c_int(), C.c_int()
+    dt.devtest_gtab_dims(C.byref(nw), C.byref(ne), C.byref(nb))
+    nw, ne, nb = nw.value, ne.value, nb.value
+    gt = np.zeros(nw * ne * 20, dtype=np.uint32)
     dt.devtest_recover.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p]
-    assert dt.devtest_recover(n, dig, rr, ss, vv, out, gt) == 0
-    g = np.frombuffer(gt, dtype=np.uint32).reshape(32, 256, 20)
-    for w, e in ((0, 1), (0, 2), (0, 255), (1, 1), (5, 77), (31, 255), (31, 1)):
-        pt = R.pt_mul(e << (8 * w), R.G)
+    assert dt.devtest_recover(n, dig, rr, ss, vv, out, gt.ctypes.data_as(C.c_void_p)) == 0
+    g = gt.reshape(nw, ne, 20)
+    for w, e in ((0, 1), (0, 2), (0, 255), (1, 1), (5, 77), (nw - 1, ne - 1), (nw - 1, 1), (nw // 2, ne // 2 + 1)):
+        pt = R.pt_mul(e << (nb * w), R.G)
         x = sum(int(g[w, e, i]) << (26 * i) for i in range(10))
         y = sum(int(g[w, e, 10 + i]) << (26 * i) for i in range(10))
         assert (x, y) == pt, (w, e)
