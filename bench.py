@@ -47,16 +47,19 @@ def load_rows(n_total: int, lo: int, hi: int):
 
 def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0):
     """The CPU oracle (a port — the reference has no implementation of this path and no
-    Go toolchain exists here) timed on this box's host cores over a bounded sample."""
+    Go toolchain exists here) timed on this box's host cores over a bounded sample: the
+    same COMMIT rows tiled so that every pthread gets ≥64 rows per call."""
     from oracle import binding as B
     cores = os.cpu_count() or 1
     vs = B.ValSet(addrs, power)
     n = len(seal65)
-    B.verify_seals(vs, hash32[:64], seal65[:64], signer20[:64], nthreads=cores)  # warm tables
+    reps = max(1, (64 * cores + n - 1) // n)
+    h, s, f = np.tile(hash32, (reps, 1)), np.tile(seal65, (reps, 1)), np.tile(signer20, (reps, 1))
+    B.verify_seals(vs, h[:cores], s[:cores], f[:cores], nthreads=cores)  # warm tables / spawn once
     done, t0 = 0, time.perf_counter()
     while True:
-        v = B.verify_seals(vs, hash32, seal65, signer20, nthreads=cores)
-        done += n
+        v = B.verify_seals(vs, h, s, f, nthreads=cores)
+        done += len(v)
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
@@ -65,8 +68,8 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
     B.verify_seals(vs, hash32[:256], seal65[:256], signer20[:256], nthreads=1)
     single = 256 / (time.perf_counter() - t1)
     return {"value": done / el, "unit": "verifies/s", "cores": cores, "kind": "port",
-            "sample": f"{done} seal verifies (the N={n} COMMIT batch repeated for {el:.1f} s, "
-                      f"{cores} pthreads); 1 thread: {single:.0f} verifies/s"}
+            "sample": f"{done} seal verifies (the N={n} COMMIT batch tiled x{reps} per call, repeated for "
+                      f"{el:.1f} s, {cores} pthreads); 1 thread: {single:.0f} verifies/s"}
 
 
 def main():
