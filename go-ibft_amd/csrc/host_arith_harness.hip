@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "recover_dev.h"
+#include "verify_dev.h"
 #include "modinv_dev.h"
 
 using secp::u256;
@@ -85,6 +86,34 @@ int dev_point_add_case(const uint8_t *k1, const uint8_t *k2, int via_aff, uint8_
   bool fin = secp::jac_to_aff_fast(af, sum);
   secp::to_be32(out32, fin ? secp::l26_to_u256(af.x) : secp::zero256());
   return fin ? 1 : 0;
+}
+
+// warm path on the host: build the per-key table (cached for the last key) and verify
+static std::vector<uint32_t> g_qtab;
+static uint8_t g_qtab_key[64];
+static bool g_qtab_valid = false;
+void dev_gtab_init(void);
+int dev_verify_known(const uint8_t *digest32, const uint8_t *sig65, const uint8_t *pub64, uint32_t flags) {
+  dev_gtab_init();
+  if (!g_qtab_valid || memcmp(g_qtab_key, pub64, 64) != 0) {
+    g_qtab.assign(ibftk::QTAB_DWORDS_PER_VALIDATOR, 0);
+    ibftk::aff Q;
+    Q.x = fin(pub64);
+    Q.y = fin(pub64 + 32);
+    for (int w = 0; w < ibftk::QTAB_WINDOWS; w++)
+      ibftk::qtab_build_window(Q, w, g_qtab.data() + (size_t)ibftk::GTAB_ENTRY_DWORDS * ibftk::QTAB_ENTRIES * w, true);
+    memcpy(g_qtab_key, pub64, 64);
+    g_qtab_valid = true;
+  }
+  return ibftk::verify_known(g_gtab.data(), g_qtab.data(), secp::from_be32(digest32), secp::from_be32(sig65),
+                             secp::from_be32(sig65 + 32), sig65[64], flags) ? 1 : 0;
+}
+// table entry (w, e) of the last key: x ‖ y big-endian
+void dev_qtab_entry(int w, int e, uint8_t *out64) {
+  const uint32_t *p = g_qtab.data() + (size_t)ibftk::GTAB_ENTRY_DWORDS * (w * ibftk::QTAB_ENTRIES + e);
+  ibftk::aff a = ibftk::load_affine(p);
+  secp::to_be32(out64, secp::l26_to_u256(a.x));
+  secp::to_be32(out64 + 32, secp::l26_to_u256(a.y));
 }
 
 void dev_gtab_init(void) {

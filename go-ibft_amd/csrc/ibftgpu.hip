@@ -50,6 +50,14 @@ struct ibft_ctx {
   unsigned __int128 quorum = 0;
   uint64_t height = 0;
 
+  // warm path (IBFT_FLAG_PUBKEY_CACHE): recovered keys + per-validator fixed-base tables
+  bool cache_on = false;       // flag set AND the tables fit the memory budget for this validator set
+  DevBuf d_pub, d_pub_state, d_learned, d_qtab, d_warm_done;
+  uint32_t learned_seen = 0;   // keys whose tables are built (or being built, stream-ordered)
+  uint32_t dummy_validator = 0;
+  std::vector<uint8_t> valset_addrs;  // last address list, to keep the cache across identical sets
+  uint32_t warm_passes = 0, cold_passes = 0;
+
   // staged batch
   uint32_t staged_n = 0;
   bool staged_pre = false;
@@ -110,6 +118,7 @@ int alloc_rows(ibft_ctx *c) {
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
   if ((rc = ensure(c, c->d_tally, 4 * 8))) return rc;
   if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
+  if ((rc = ensure(c, c->d_warm_done, m))) return rc;
   return IBFT_OK;
 }
 
@@ -128,6 +137,13 @@ ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre) {
   a.flags = c->flags;
   a.mask = (uint64_t *)c->d_mask.p;
   a.vidx = (int32_t *)c->d_vidx.p;
+  if (c->cache_on) {
+    a.pub = (uint32_t *)c->d_pub.p;
+    a.pub_state = (uint8_t *)c->d_pub_state.p;
+    a.learned = (uint32_t *)c->d_learned.p;
+    a.qtab = (const uint32_t *)c->d_qtab.p;
+    a.dummy_validator = c->dummy_validator;
+  }
   return a;
 }
 
@@ -145,23 +161,61 @@ int next_events(ibft_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
   return IBFT_OK;
 }
 
-// enqueue recover (+ tally) over the resident columns
+// enqueue the verdict kernels over the resident columns: warm kernel first when tables exist
+// (its rows are then skipped by the recover kernel), recover kernel for everything else
 int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it) {
   if (n == 0) return IBFT_OK;
   ibftk::recover_args a = make_args(c, n, with_pre);
-  dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (time_it) {
     int rc = next_events(c, &e0, &e1);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
+  const bool warm = c->cache_on && c->learned_seen > 0;
+  if (warm) {
+    a.warm_done = (uint8_t *)c->d_warm_done.p;
+    const bool wave = c->kernel == IBFT_KERNEL_WAVE || (c->kernel != IBFT_KERNEL_LANE && n <= 2048);
+    if (wave) {
+      HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
+      if (mode == 0)
+        hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<0>, dim3(n), dim3(64), 0, c->stream, a);
+      else
+        hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<1>, dim3(n), dim3(64), 0, c->stream, a);
+    } else {
+      dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
+      if (mode == 0)
+        hipLaunchKernelGGL(ibftk::verify_known_lane_kernel<0>, grid, block, 0, c->stream, a);
+      else
+        hipLaunchKernelGGL(ibftk::verify_known_lane_kernel<1>, grid, block, 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->warm_passes++;
+  } else {
+    c->cold_passes++;
+  }
+  dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
   if (mode == 0)
     hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<0>, grid, block, 0, c->stream, a);
   else
     hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<1>, grid, block, 0, c->stream, a);
   HIPCHK(c, hipGetLastError());
   if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
+  return IBFT_OK;
+}
+
+// after a fetch: build tables for keys learned since the last build (stream-ordered, asynchronous)
+int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator) {
+  if (!c->cache_on || learned_total <= c->learned_seen) return IBFT_OK;
+  const uint32_t nv = c->n_validators;
+  hipLaunchKernelGGL(ibftk::qtab_build_kernel, dim3(((nv + 63) / 64) * ibftk::QTAB_WINDOWS), dim3(64), 0, c->stream,
+                     (const uint32_t *)c->d_pub.p, (const uint8_t *)c->d_pub_state.p, (uint32_t *)c->d_qtab.p, nv);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(ibftk::qtab_commit_kernel, dim3((nv + 255) / 256), dim3(256), 0, c->stream,
+                     (uint8_t *)c->d_pub_state.p, nv);
+  HIPCHK(c, hipGetLastError());
+  c->learned_seen = learned_total;
+  c->dummy_validator = any_validator;
   return IBFT_OK;
 }
 
@@ -180,7 +234,14 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
     HIPCHK(c, hipMemcpyAsync(c->h_mask, c->d_mask.p, mw * 8, hipMemcpyDeviceToHost, c->stream));
   if (tally && have_tally)
     HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 4 * 8, hipMemcpyDeviceToHost, c->stream));
+  if (c->cache_on)
+    HIPCHK(c, hipMemcpyAsync(c->h_tally + 4, c->d_learned.p, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->cache_on) {
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(c->h_tally + 4);
+    int rcb = build_new_tables(c, lw[0], lw[1]);
+    if (rcb) return rcb;
+  }
   if (out_mask && mw) {
     memcpy(out_mask, c->h_mask, mw * 8);
     // clear the padding bits of the last word
@@ -254,7 +315,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
     if ((rc = alloc_rows(c))) break;
     if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
-    if (hipHostMalloc((void **)&c->h_tally, 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if (hipHostMalloc((void **)&c->h_tally, 128) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
     int threads = 64, total = ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES;
     hipLaunchKernelGGL(ibftk::gtab_build_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0,
@@ -275,7 +336,8 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
-                    &c->d_vtab, &c->d_vpower})
+                    &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_learned, &c->d_qtab,
+                    &c->d_warm_done})
     release(*b);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_tally) (void)hipHostFree(c->h_tally);
@@ -323,6 +385,25 @@ int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, co
   if ((rc = upload(c, c->d_vtab, tab.data(), tab.size() * 4))) return rc;
   if ((rc = upload(c, c->d_vpower, pw.data(), pw.size() * 8))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  // warm-path cache: kept when the address list is unchanged, rebuilt otherwise
+  const bool same_set = c->valset_addrs.size() == n * 20 && (n == 0 || memcmp(c->valset_addrs.data(), addrs20, n * 20) == 0);
+  if ((c->flags & IBFT_FLAG_PUBKEY_CACHE) && !(same_set && c->cache_on)) {
+    c->cache_on = false;
+    c->learned_seen = 0;
+    const size_t nv = pw.size();
+    const size_t qbytes = nv * ibftk::QTAB_DWORDS_PER_VALIDATOR * 4;
+    size_t budget = 64ull << 30;
+    if (const char *e = getenv("IBFT_QTAB_BUDGET_GB")) budget = (size_t)strtoull(e, nullptr, 10) << 30;
+    if (nv > 0 && qbytes <= budget && ensure(c, c->d_qtab, qbytes) == IBFT_OK &&
+        ensure(c, c->d_pub, nv * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK && ensure(c, c->d_pub_state, nv) == IBFT_OK &&
+        ensure(c, c->d_learned, 8) == IBFT_OK) {
+      HIPCHK(c, hipMemsetAsync(c->d_pub_state.p, 0, nv, c->stream));
+      HIPCHK(c, hipMemsetAsync(c->d_learned.p, 0, 8, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->cache_on = true;
+    }
+  }
+  c->valset_addrs.assign(addrs20, addrs20 + n * 20);
   c->vslot_mask = slots - 1;
   c->n_validators = (uint32_t)pw.size();
   c->quorum = (total * 2) / 3 + 1;  // calculateQuorum, validator_manager.go:130-135
@@ -448,6 +529,14 @@ int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
   }
   *ms = total;
   if (launches) *launches = c->ev_used;
+  return IBFT_OK;
+}
+
+int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes) {
+  if (!c) return IBFT_E_INVAL;
+  if (tables) *tables = c->cache_on ? c->learned_seen : 0;
+  if (warm_passes) *warm_passes = c->warm_passes;
+  if (cold_passes) *cold_passes = c->cold_passes;
   return IBFT_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "recover_dev.h"
+#include "verify_dev.h"
 
 namespace ibftk {
 
@@ -82,7 +83,7 @@ __global__ void hash_eq_kernel(const uint8_t *__restrict__ hash32, const uint8_t
   if ((threadIdx.x & 63) == 0 && row < n) mask[row >> 6] = bal;
 }
 
-// ---- ECDSA recover, one lane per signature ----------------------------------------------
+// ---- ECDSA recover (cold path), one lane per signature ------------------------------------
 struct recover_args {
   const uint8_t *hash32;    // n×32   (seals: per-row proposalHash)
   const uint8_t *sig65;     // n×65
@@ -97,13 +98,25 @@ struct recover_args {
   uint32_t flags;           // IBFT_FLAG_*
   uint64_t *mask;           // ⌈n/64⌉ verdict words
   int32_t *vidx;            // n: validator index of the row's sender (or -1)
+  // warm path (null / 0 when the key cache is off)
+  uint32_t *pub;            // n_validators × 20 dwords: recovered public keys (affine, 10×26 limbs)
+  uint8_t *pub_state;       // n_validators: 0 unknown, 1 key known, 2 table built
+  uint32_t *learned;        // counter of keys learned (host reads it with the tally)
+  const uint32_t *qtab;     // n_validators × 32 × 256 × 20 dwords
+  uint8_t *warm_done;       // n: 1 = the warm kernel already produced this row's verdict
+  uint32_t dummy_validator; // a validator whose table is built (operand for lanes with no work)
 };
 
-// MODE 0: seals (digest = hash32 row).  MODE 1: senders (digest = keccak256(payload row)).
+// Stage the block's rows through LDS (coalesced dword loads) and unpack this lane's row.
+struct row_regs {
+  u256 r, s, z;
+  uint32_t v;
+  uint32_t want[5];
+  bool live, pre;
+  uint32_t row;
+};
 template <int MODE>
-__global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_args a) {
-  // LDS staging of the block's rows: coalesced dword loads, then per-lane unpack
-  __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS_PER_BLOCK * (65 + 32 + 20)];
+__device__ __forceinline__ row_regs stage_rows(const recover_args &a, uint8_t *lds) {
   uint8_t *l_sig = lds;
   uint8_t *l_hash = lds + ROWS_PER_BLOCK * 65;
   uint8_t *l_from = l_hash + ROWS_PER_BLOCK * 32;
@@ -124,39 +137,176 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_
     }
   }
   __syncthreads();
-
-  const uint32_t row = row0 + lane;
-  const bool live = lane < rows;
-  const uint32_t lrow = live ? lane : 0;
-  bool ok = live && !(a.pre_flags && a.pre_flags[row] != 0);
-
-  u256 r = secp::from_be32(l_sig + 65 * lrow);
-  u256 s = secp::from_be32(l_sig + 65 * lrow + 32);
-  uint32_t v = l_sig[65 * lrow + 64];
-  u256 z;
+  row_regs q;
+  q.row = row0 + lane;
+  q.live = lane < rows;
+  const uint32_t lrow = q.live ? lane : 0;
+  q.pre = q.live && a.pre_flags && a.pre_flags[q.row] != 0;
+  q.r = secp::from_be32(l_sig + 65 * lrow);
+  q.s = secp::from_be32(l_sig + 65 * lrow + 32);
+  q.v = l_sig[65 * lrow + 64];
   if (MODE == 0) {
-    z = secp::from_be32(l_hash + 32 * lrow);
+    q.z = secp::from_be32(l_hash + 32 * lrow);
   } else {
     uint64_t d[4];
-    uint32_t o0 = live ? a.off[row] : 0u, o1 = live ? a.off[row + 1] : 0u;
+    uint32_t o0 = q.live ? a.off[q.row] : 0u, o1 = q.live ? a.off[q.row + 1] : 0u;
     keccak::hash_bytes(a.payload + o0, o1 - o0, d);
+    keccak::digest_to_limbs(d, q.z.v);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) q.want[i] = reinterpret_cast<const uint32_t *>(l_from)[5 * lrow + i];
+  return q;
+}
+
+// MODE 0: seals (digest = hash32 row).  MODE 1: senders (digest = keccak256(payload row)).
+template <int MODE>
+__global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_args a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS_PER_BLOCK * (65 + 32 + 20)];
+  row_regs q = stage_rows<MODE>(a, lds);
+  const uint32_t lane = threadIdx.x;
+  // rows the warm kernel already decided keep their bit; a wavefront with nothing left exits
+  const bool done = a.warm_done && q.live && a.warm_done[q.row] != 0;
+  const bool need = q.live && !done;
+  if (!__any(need ? 1 : 0)) return;
+
+  uint32_t got[5];
+  aff Qa;
+  bool rec = recover_pubkey(a.gtab, q.z, q.r, q.s, q.v, a.flags, got, Qa);
+  bool ok = need && !q.pre && rec;
+#pragma unroll
+  for (int i = 0; i < 5; i++) ok = ok && (got[i] == q.want[i]);
+  // membership: "the signer address is one of the validators" (backend.go:44, 53-54)
+  int vi = valset_lookup(a.vtab, a.vslot_mask, q.want);
+  ok = ok && vi >= 0;
+  if (need) a.vidx[q.row] = vi;
+  // a key that hashes to a member's address is remembered for the warm path
+  if (ok && a.pub_state && a.pub_state[vi] == 0) {
+    store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
+    __threadfence();
+    a.pub_state[vi] = 1;
+    atomicAdd(a.learned, 1u);
+    a.learned[1] = (uint32_t)vi;  // any learned validator: operand for idle lanes of the warm kernel
+  }
+  uint64_t bal = __ballot(ok);
+  uint64_t keep = __ballot(done);
+  if (lane == 0) {
+    uint64_t *w = a.mask + (blockIdx.x * (uint32_t)ROWS_PER_BLOCK >> 6);
+    *w = keep ? ((*w & keep) | (bal & ~keep)) : bal;
+  }
+}
+
+// ---- warm path, one lane per signature ----------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(ROWS_PER_BLOCK) verify_known_lane_kernel(recover_args a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS_PER_BLOCK * (65 + 32 + 20)];
+  row_regs q = stage_rows<MODE>(a, lds);
+  const uint32_t lane = threadIdx.x;
+  int vi = valset_lookup(a.vtab, a.vslot_mask, q.want);
+  const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
+  // decided here: pre-flagged rows and non-members (verdict false), and rows whose validator has a table
+  const bool decided = q.live && (q.pre || vi < 0 || have_table);
+  const bool crypto = q.live && !q.pre && have_table;
+  bool ok = false;
+  if (__any(crypto ? 1 : 0)) {  // wave-uniform: every lane runs the arithmetic, idle ones on a dummy table
+    const uint32_t tv = crypto ? (uint32_t)vi : a.dummy_validator;
+    ok = verify_known(a.gtab, a.qtab + QTAB_DWORDS_PER_VALIDATOR * tv, q.z, q.r, q.s, q.v, a.flags) && crypto;
+  }
+  if (q.live) {
+    a.warm_done[q.row] = decided ? 1 : 0;
+    if (decided) a.vidx[q.row] = vi;
+  }
+  uint64_t bal = __ballot(ok);
+  if (lane == 0) a.mask[blockIdx.x * (uint32_t)ROWS_PER_BLOCK >> 6] = bal;
+}
+
+// ---- warm path, ONE WAVEFRONT PER SIGNATURE -------------------------------------------------
+// Lanes 0..31 fetch the 32 window points of u2·Q from the validator's table, lanes 32..47 the 16
+// window points of u1·G, the rest hold ∞; a 6-level xor-butterfly of Jacobian additions sums
+// them (every lane ends with the total).  The scalar work (s⁻¹ mod n, final Z⁻¹) is wave-uniform.
+__device__ __forceinline__ jac shfl_xor_jac(const jac &p, int off) {
+  jac r;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    r.x.n[i] = __shfl_xor(p.x.n[i], off, 64);
+    r.y.n[i] = __shfl_xor(p.y.n[i], off, 64);
+    r.z.n[i] = __shfl_xor(p.z.n[i], off, 64);
+  }
+  r.inf = __shfl_xor(p.inf ? 1 : 0, off, 64) != 0;
+  return r;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) verify_known_wave_kernel(recover_args a) {
+  const uint32_t row = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const bool pre = a.pre_flags && a.pre_flags[row] != 0;
+  u256 r = secp::from_be32(a.sig65 + 65ull * row);
+  u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
+  const uint32_t v = a.sig65[65ull * row + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(a.hash32 + 32ull * row);
+  } else {
+    uint64_t d[4];
+    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
     keccak::digest_to_limbs(d, z.v);
   }
   uint32_t want[5];
 #pragma unroll
-  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(l_from)[5 * lrow + i];
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
+  const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
+  const bool decided = pre || vi < 0 || have_table;
+  if (lane == 0) {
+    a.warm_done[row] = decided ? 1 : 0;
+    if (decided) a.vidx[row] = vi;
+  }
+  if (pre || !have_table) return;  // wave-uniform exit: verdict bit stays 0 (mask was cleared)
 
-  uint32_t got[5];
-  bool rec = recover_address(a.gtab, z, r, s, v, a.flags, got);
-  ok = ok && rec;
-#pragma unroll
-  for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
-  // membership: "the signer address is one of the validators" (backend.go:44, 53-54)
-  int vi = valset_lookup(a.vtab, a.vslot_mask, want);
-  ok = ok && vi >= 0;
-  if (live) a.vidx[row] = vi;
-  uint64_t bal = __ballot(ok);
-  if (lane == 0) a.mask[row0 >> 6] = bal;
+  bool ok = sig_in_range(r, s, v, a.flags);
+  u256 u1, u2;
+  verify_scalars(z, r, s, u1, u2);
+  jac acc = secp::jac_inf();
+  if (lane < (uint32_t)QTAB_WINDOWS) {
+    const uint32_t w = lane;
+    const uint32_t dgt = (u2.v[w >> 2] >> (8 * (w & 3))) & 255u;
+    aff pt = load_affine(a.qtab + QTAB_DWORDS_PER_VALIDATOR * (uint32_t)vi + (size_t)GTAB_ENTRY_DWORDS * (w * QTAB_ENTRIES + dgt));
+    jac j = secp::jac_from_aff(pt);
+    j.inf = dgt == 0;
+    acc = j;
+  } else if (lane < (uint32_t)(QTAB_WINDOWS + GTAB_WINDOWS)) {
+    const uint32_t w = lane - QTAB_WINDOWS;
+    const uint32_t dgt = (u1.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+    aff pt = load_affine(a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
+    jac j = secp::jac_from_aff(pt);
+    j.inf = dgt == 0;
+    acc = j;
+  }
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) {
+    jac other = shfl_xor_jac(acc, off);
+    acc = secp::jac_add(acc, other);
+  }
+  ok = verify_finish(acc, r, v) && ok;
+  if (lane == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+}
+
+// ---- warm path table build -------------------------------------------------------------------
+// Lane ↔ (validator, window): a wavefront holds ONE window index for 64 consecutive validators so
+// that the doubling loop's trip count is wave-uniform.
+__global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restrict__ pub, const uint8_t *__restrict__ pub_state,
+                                                        uint32_t *__restrict__ qtab, uint32_t n_validators) {
+  const uint32_t w = blockIdx.x % QTAB_WINDOWS;
+  const uint32_t v = (blockIdx.x / QTAB_WINDOWS) * 64 + threadIdx.x;
+  const bool work = v < n_validators && pub_state[v] == 1;
+  if (!__any(work ? 1 : 0)) return;
+  aff Q = work ? load_affine(pub + (size_t)GTAB_ENTRY_DWORDS * v) : secp::generator();
+  uint32_t *out = qtab + QTAB_DWORDS_PER_VALIDATOR * (work ? v : 0u) + (size_t)GTAB_ENTRY_DWORDS * QTAB_ENTRIES * w;
+  qtab_build_window(Q, (int)w, out, work);
+}
+__global__ void qtab_commit_kernel(uint8_t *__restrict__ pub_state, uint32_t n_validators) {
+  uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n_validators && pub_state[v] == 1) pub_state[v] = 2;
 }
 
 // ---- a8: weighted quorum tally ------------------------------------------------------------

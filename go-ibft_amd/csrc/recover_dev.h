@@ -120,9 +120,9 @@ __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) 
 
 // Recover the signer address of (digest z, r, s, v); returns false if the signature
 // is rejected (same rejection list as oracle/secp256k1.c:orc_ecrecover).
-__host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restrict__ gtab, const u256 &z_raw,
-                                                         const u256 &r, const u256 &s, uint32_t v,
-                                                         uint32_t flags, uint32_t addr[5]) {
+__host__ __device__ __forceinline__ bool recover_pubkey(const uint32_t *__restrict__ gtab, const u256 &z_raw,
+                                                        const u256 &r, const u256 &s, uint32_t v,
+                                                        uint32_t flags, uint32_t addr[5], aff &Qa) {
   bool ok = v <= 1;
   ok = ok && !secp::is_zero(r) && !secp::geq_const(r, secp::NL());
   ok = ok && !secp::is_zero(s) && !secp::geq_const(s, secp::NL());
@@ -150,11 +150,16 @@ __host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restr
   u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   jac Q = ecmult_var(R, u2);
   Q = ecmult_gen(gtab, u1, Q);
-  aff Qa;
   ok = secp::jac_to_aff_fast(Qa, Q) && ok;
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
+}
+__host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restrict__ gtab, const u256 &z_raw,
+                                                         const u256 &r, const u256 &s, uint32_t v,
+                                                         uint32_t flags, uint32_t addr[5]) {
+  aff Qa;
+  return recover_pubkey(gtab, z_raw, r, s, v, flags, addr, Qa);
 }
 
 }  // namespace ibftk

@@ -22,6 +22,7 @@ import numpy as np
 from .build import LIB
 
 FLAG_STRICT_LOW_S = 1
+FLAG_PUBKEY_CACHE = 2   # warm path: verify against per-validator tables once a key has been recovered
 ROW_NIL, ROW_BADLEN, ROW_HASH_BAD = 1, 2, 4
 KERNEL_AUTO, KERNEL_LANE, KERNEL_WAVE = 0, 1, 2
 
@@ -29,7 +30,7 @@ EXPORTS = [
     "ibft_version", "ibft_strerror", "ibft_last_error", "ibft_ctx_create", "ibft_ctx_destroy",
     "ibft_set_validators", "ibft_verify_hashes", "ibft_proposal_hash", "ibft_verify_seals",
     "ibft_verify_senders", "ibft_tally", "ibft_seals_stage", "ibft_seals_launch", "ibft_seals_fetch",
-    "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_sync",
+    "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_cache_stats", "ibft_sync",
 ]
 
 
@@ -86,6 +87,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.ibft_cache_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_sync.argtypes = [vp]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
@@ -229,6 +231,12 @@ class BatchVerifier:
         ms, k = C.c_float(), C.c_uint32()
         self._chk(self._L.ibft_last_kernel_ms(self._h, C.byref(ms), C.byref(k)), "ibft_last_kernel_ms")
         return ms.value, k.value
+
+    def cache_stats(self):
+        """(validators with a built table, verdict passes that used the warm kernel, cold passes)."""
+        t, w, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self._L.ibft_cache_stats(self._h, C.byref(t), C.byref(w), C.byref(c)), "ibft_cache_stats")
+        return t.value, w.value, c.value
 
     def sync(self):
         self._chk(self._L.ibft_sync(self._h), "ibft_sync")

@@ -68,6 +68,12 @@ extern "C" {
 
 /* cfg.flags */
 #define IBFT_FLAG_STRICT_LOW_S 1u /* also reject s > n/2 (off: go-ethereum Ecrecover semantics) */
+/* Warm path: remember each validator's public key the first time it is recovered (and hashes to
+ * its address), build per-validator fixed-base tables in HBM (655 KB per validator, budget
+ * IBFT_QTAB_BUDGET_GB, default 64) and VERIFY later signatures of that validator against them
+ * instead of recovering — identical verdicts (csrc/verify_dev.h), ~4-10x less work.  The cache
+ * lives as long as ibft_set_validators keeps receiving the same address list.               */
+#define IBFT_FLAG_PUBKEY_CACHE 2u
 
 /* pre_flags bits */
 #define IBFT_ROW_NIL 0x01u
@@ -76,8 +82,9 @@ extern "C" {
 
 /* cfg.kernel: which ecrecover kernel the seal/sender paths launch */
 #define IBFT_KERNEL_AUTO 0u
-#define IBFT_KERNEL_LANE 1u /* one lane per signature (throughput at large N)      */
-#define IBFT_KERNEL_WAVE 2u /* one wavefront per signature (latency at small N)    */
+#define IBFT_KERNEL_LANE 1u /* warm path: one lane per signature (throughput at large N)       */
+#define IBFT_KERNEL_WAVE 2u /* warm path: one wavefront per signature (latency at small N; AUTO
+                               picks it for batches of <= 2048 rows)                             */
 
 typedef struct ibft_ctx ibft_ctx;
 
@@ -160,6 +167,9 @@ int ibft_seals_export(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst);
 /* HIP-event time (ms) of the dominant kernel summed over the last launch, and its
  * launch count; measured on the context's own stream.                              */
 int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
+/* Warm-path statistics: validators whose table is built, and how many verdict passes ran with
+ * / without the warm kernel since the context was created.                                   */
+int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes);
 /* Block the host until the context's stream is idle.                               */
 int ibft_sync(ibft_ctx *ctx);
 

@@ -149,6 +149,35 @@ def test_exceptional_point_additions(dev):
                 assert int.from_bytes(o.raw, "big") == exp[0], (k1, k2, via_aff)
 
 
+def test_warm_path_verify_equals_recover_and_compare(dev, oracle):
+    """verify_dev.h: per-key table build + verify_known gives the verdict of recover-and-compare
+    for valid, tampered, out-of-range, wrong-key and high-s signatures (both low-s policies)."""
+    rng = np.random.default_rng(14)
+    for key in range(2):
+        sk = b32(int.from_bytes(rng.bytes(32), "big") % (N - 1) + 1)
+        pub, addr = oracle.pubkey(sk), oracle.address(oracle.pubkey(sk))
+        for i in range(48):
+            d = rng.bytes(32)
+            sig = oracle.sign(sk, d)
+            if i % 5 == 1: sig = sig[:64] + bytes([sig[64] ^ 1])
+            if i % 7 == 2: sig = rng.bytes(64) + bytes([i & 1])
+            if i % 11 == 3: sig = bytes(32) + sig[32:]
+            if i % 13 == 4: sig = sig[:32] + b32(N) + sig[64:]
+            if i % 17 == 5: sig = sig[:64] + b"\x02"
+            if i % 19 == 6:
+                s_ = int.from_bytes(sig[32:64], "big")
+                sig = sig[:32] + b32(N - s_) + bytes([sig[64] ^ 1])
+            if i % 23 == 7: sig = oracle.sign(b32(4242 + i), d)          # valid, but another key
+            for fl in (0, 1):
+                rec = oracle.recover_address(d, sig, fl)
+                assert dev.dev_verify_known(d, sig, pub, fl) == int(rec is not None and rec == addr), (key, i, fl)
+        P_ = (int.from_bytes(pub[:32], "big"), int.from_bytes(pub[32:], "big"))
+        for w, e in ((0, 1), (0, 2), (0, 255), (1, 1), (31, 255), (17, 100)):
+            o = C.create_string_buffer(64)
+            dev.dev_qtab_entry(w, e, o)
+            assert o.raw == R.pub_bytes(R.pt_mul(e << (8 * w), P_))
+
+
 def test_keccak_streaming(dev, oracle):
     rng = np.random.default_rng(9)
     for ln in [0, 1, 55, 64, 131, 135, 136, 137, 200, 271, 272, 273, 1032]:

@@ -1,0 +1,127 @@
+"""GPU: the warm path (IBFT_FLAG_PUBKEY_CACHE) — keys learned by the recover kernel, per-validator
+tables, then wave-per-signature / lane-per-signature VERIFY kernels — must give exactly the
+verdicts of the cold recover path and of the CPU oracle, pass after pass."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(flags_extra=0, kernel=0, max_rows=8192):
+    import go_ibft_amd.verifier as V
+    return V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE | flags_extra, max_rows=max_rows, kernel=kernel)
+
+
+def _expect(oracle, vs, r, hash32=None, seal=None, flags=0):
+    return oracle.verify_seals(vs, r.hash32 if hash32 is None else hash32, r.seal65 if seal is None else seal,
+                               r.signer20, r.pre_flags, flags=flags, nthreads=8).astype(bool)
+
+
+@pytest.mark.parametrize("kernel,n", [(2, 200), (1, 200), (0, 1000), (1, 3000), (2, 65)])
+def test_cold_then_warm_rounds_match_oracle(oracle, kernel, n):
+    """kernel: 0 auto, 1 lane, 2 wave.  Round 1 is cold (learns keys), later rounds are warm; every
+    round has a fresh proposal hash, Byzantine rows, and is compared with the oracle."""
+    from oracle import workload as W
+    bv = _mk(kernel=kernel)
+    try:
+        base = W.make_round(n, 500 + n, byzantine=True, weighted=True, with_envelopes=True)
+        vs = oracle.ValSet(base.addrs, base.power)
+        bv.set_validators(1, base.addrs, base.power)
+        honest = sum(1 for k in base.kinds if k == "")
+        for rnd in range(4):
+            r = W.make_round(n, 500 + n, round_=rnd, byzantine=True, weighted=True, with_envelopes=True)
+            assert (r.addrs == base.addrs).all()            # same validators, new proposal hash / seals
+            got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+            exp = _expect(oracle, vs, r)
+            assert (got == exp).all(), (rnd, np.nonzero(got != exp)[0][:8])
+            te = oracle.tally(vs, r.signer20, exp.astype(np.uint8))
+            assert (t.power, t.has_quorum, t.valid_rows, t.distinct_senders) == \
+                   (te.power, te.has_quorum, te.valid_rows, te.distinct_senders)
+            senders, _ = bv.is_valid_validator(r.payload, r.off, r.msg_sig65, r.signer20)
+            es = oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)
+            assert (senders == es).all(), rnd
+        tables, warm, cold = bv.cache_stats()
+        assert tables == n            # every validator signed its envelope correctly at least once
+        assert cold >= 1 and warm >= 5
+    finally:
+        bv.close()
+
+
+def test_warm_path_rejects_what_recover_rejects(oracle):
+    """After warm-up: stolen seals (validator j's seal under From = i), seals over another hash,
+    flipped v, high-s twins under both policies, out-of-range r/s, non-members."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    n = 96
+    r = W.make_round(n, 777)
+    vs = oracle.ValSet(r.addrs[:80], r.power[:80])          # last 16 signers are NOT validators
+    for flags in (0, V.FLAG_STRICT_LOW_S):
+        for kernel in (1, 2):
+            bv = _mk(flags_extra=flags, kernel=kernel)
+            try:
+                bv.set_validators(1, r.addrs[:80], r.power[:80])
+                got, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)      # cold: learn 80 keys
+                assert got[:80].all() and not got[80:].any()
+                seal = r.seal65.copy()
+                hash32 = r.hash32.copy()
+                for i in range(80):
+                    k = i % 8
+                    if k == 1: seal[i] = r.seal65[(i + 1) % 80]                           # stolen seal
+                    if k == 2: hash32[i, 5] ^= 1                                           # other digest
+                    if k == 3: seal[i, 64] ^= 1                                            # flipped v
+                    if k == 4:                                                             # high-s twin
+                        s = int.from_bytes(seal[i, 32:64].tobytes(), "big")
+                        seal[i, 32:64] = np.frombuffer((W.N_ORDER - s).to_bytes(32, "big"), np.uint8)
+                        seal[i, 64] ^= 1
+                    if k == 5: seal[i, :32] = 0                                            # r = 0
+                    if k == 6: seal[i, 32:64] = np.frombuffer(W.N_ORDER.to_bytes(32, "big"), np.uint8)  # s = n
+                    if k == 7: seal[i, 64] = 2                                             # v = 2
+                got, t = bv.is_valid_committed_seal(hash32, seal, r.signer20)              # warm
+                exp = oracle.verify_seals(vs, hash32, seal, r.signer20, flags=flags).astype(bool)
+                assert (got == exp).all(), (flags, kernel, np.nonzero(got != exp)[0][:8])
+                assert bv.cache_stats()[0] == 80 and bv.cache_stats()[1] >= 1
+            finally:
+                bv.close()
+
+
+def test_cache_follows_the_validator_set(oracle):
+    from oracle import workload as W
+    bv = _mk()
+    try:
+        a = W.make_round(64, 31)
+        b = W.make_round(64, 32)                      # a different validator set
+        for r in (a, a, b, b, a):
+            bv.set_validators(1, r.addrs, r.power)
+            before = bv.cache_stats()[0]
+            got, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)
+            assert got.all()
+        # identical address list => cache kept; changed list => rebuilt from zero
+        bv.set_validators(2, a.addrs, a.power)
+        assert bv.cache_stats()[0] == 64
+        bv.set_validators(3, b.addrs, b.power)
+        assert bv.cache_stats()[0] == 0
+    finally:
+        bv.close()
+
+
+def test_partial_knowledge_mixed_wave(oracle):
+    """Half the validators known, half new, interleaved inside the same wavefronts: warm and
+    cold kernels each decide their own rows and the mask words are merged correctly."""
+    from oracle import workload as W
+    r = W.make_round(256, 91, byzantine=True)
+    vs = oracle.ValSet(r.addrs, r.power)
+    for kernel in (1, 2):
+        bv = _mk(kernel=kernel)
+        try:
+            bv.set_validators(1, r.addrs, r.power)
+            even = np.arange(0, 256, 2)
+            got, _ = bv.is_valid_committed_seal(r.hash32[even], r.seal65[even], r.signer20[even], r.pre_flags[even])
+            exp_all = _expect(oracle, vs, r)
+            assert (got == exp_all[even]).all()
+            got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)   # mixed
+            assert (got == exp_all).all()
+            got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)   # all warm now
+            assert (got == exp_all).all()
+            assert t.valid_rows == int(exp_all.sum())
+        finally:
+            bv.close()
