@@ -33,7 +33,7 @@ struct ibft_ctx {
   int device = 0;
   uint32_t flags = 0;
   uint32_t max_rows = DEFAULT_MAX_ROWS;
-  uint32_t kernel = IBFT_KERNEL_LANE;
+  uint32_t kernel = IBFT_KERNEL_AUTO;
   hipStream_t stream = nullptr;
   std::string last_error;
 
@@ -56,7 +56,7 @@ struct ibft_ctx {
   uint32_t learned_seen = 0;   // keys whose tables are built (or being built, stream-ordered)
   uint32_t dummy_validator = 0;
   std::vector<uint8_t> valset_addrs;  // last address list, to keep the cache across identical sets
-  uint32_t warm_passes = 0, cold_passes = 0;
+  uint32_t warm_passes = 0, cold_passes = 0, last_group = 0;
 
   // staged batch
   uint32_t staged_n = 0;
@@ -175,13 +175,31 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   const bool warm = c->cache_on && c->learned_seen > 0;
   if (warm) {
     a.warm_done = (uint8_t *)c->d_warm_done.p;
-    const bool wave = c->kernel == IBFT_KERNEL_WAVE || (c->kernel != IBFT_KERNEL_LANE && n <= 2048);
-    if (wave) {
+    // lanes per signature: ≈ one wavefront per SIMD (1024 SIMDs × 64 lanes / n rows), a power of two
+    uint32_t G = 1;
+    if (c->kernel == IBFT_KERNEL_WAVE) {
+      G = 64;
+    } else if (c->kernel != IBFT_KERNEL_LANE) {
+      while (G < 64 && (uint64_t)n * (G * 2) <= 65536ull) G *= 2;
+    }
+    if (G > 1) {
       HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
-      if (mode == 0)
-        hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<0>, dim3(n), dim3(64), 0, c->stream, a);
-      else
-        hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<1>, dim3(n), dim3(64), 0, c->stream, a);
+      const uint32_t rows_per_wave = 64 / G;
+      dim3 grid((n + rows_per_wave - 1) / rows_per_wave), block(64);
+#define IBFT_LAUNCH_GROUP(GG)                                                                                  \
+  if (mode == 0)                                                                                               \
+    hipLaunchKernelGGL((ibftk::verify_known_group_kernel<0, GG>), grid, block, 0, c->stream, a);               \
+  else                                                                                                         \
+    hipLaunchKernelGGL((ibftk::verify_known_group_kernel<1, GG>), grid, block, 0, c->stream, a);
+      switch (G) {
+        case 64: IBFT_LAUNCH_GROUP(64) break;
+        case 32: IBFT_LAUNCH_GROUP(32) break;
+        case 16: IBFT_LAUNCH_GROUP(16) break;
+        case 8: IBFT_LAUNCH_GROUP(8) break;
+        case 4: IBFT_LAUNCH_GROUP(4) break;
+        default: IBFT_LAUNCH_GROUP(2) break;
+      }
+#undef IBFT_LAUNCH_GROUP
     } else {
       dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
       if (mode == 0)
@@ -189,6 +207,7 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
       else
         hipLaunchKernelGGL(ibftk::verify_known_lane_kernel<1>, grid, block, 0, c->stream, a);
     }
+    c->last_group = G;
     HIPCHK(c, hipGetLastError());
     c->warm_passes++;
   } else {
@@ -309,7 +328,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->device = dev;
   c->flags = cfg ? cfg->flags : 0;
   c->max_rows = (cfg && cfg->max_rows) ? cfg->max_rows : DEFAULT_MAX_ROWS;
-  c->kernel = (cfg && cfg->kernel) ? cfg->kernel : IBFT_KERNEL_LANE;
+  c->kernel = cfg ? cfg->kernel : IBFT_KERNEL_AUTO;
   int rc = IBFT_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
@@ -532,11 +551,13 @@ int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
   return IBFT_OK;
 }
 
-int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes) {
+int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes,
+                     uint32_t *lanes_per_signature) {
   if (!c) return IBFT_E_INVAL;
   if (tables) *tables = c->cache_on ? c->learned_seen : 0;
   if (warm_passes) *warm_passes = c->warm_passes;
   if (cold_passes) *cold_passes = c->cold_passes;
+  if (lanes_per_signature) *lanes_per_signature = c->last_group;
   return IBFT_OK;
 }
 

@@ -219,10 +219,13 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) verify_known_lane_kernel(recov
   if (lane == 0) a.mask[blockIdx.x * (uint32_t)ROWS_PER_BLOCK >> 6] = bal;
 }
 
-// ---- warm path, ONE WAVEFRONT PER SIGNATURE -------------------------------------------------
-// Lanes 0..31 fetch the 32 window points of u2·Q from the validator's table, lanes 32..47 the 16
-// window points of u1·G, the rest hold ∞; a 6-level xor-butterfly of Jacobian additions sums
-// them (every lane ends with the total).  The scalar work (s⁻¹ mod n, final Z⁻¹) is wave-uniform.
+// ---- warm path, G LANES PER SIGNATURE (G = 64: one wavefront per signature) -------------------
+// The 32 window points of u2·Q (validator's table) and the 16 window points of u1·G are dealt
+// round-robin to the G lanes of a group; each lane sums its share with mixed additions, then a
+// log2(G)-level xor-butterfly of Jacobian additions leaves the total in every lane.  The scalar
+// work (s⁻¹ mod n, final Z⁻¹) is replicated across the group.  G is chosen by the host so that a
+// batch of n rows yields about one wavefront per SIMD (n·G/64 ≈ 1024): G = 64 up to 1 024 rows,
+// 16 at 4 096, 4 at 16 384, and the LDS-staged lane kernel (G = 1) beyond.
 __device__ __forceinline__ jac shfl_xor_jac(const jac &p, int off) {
   jac r;
 #pragma unroll
@@ -235,10 +238,15 @@ __device__ __forceinline__ jac shfl_xor_jac(const jac &p, int off) {
   return r;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(64) verify_known_wave_kernel(recover_args a) {
-  const uint32_t row = blockIdx.x;
+template <int MODE, int G>
+__global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) {
+  constexpr int ROWS = 64 / G;                    // signatures per wavefront
+  constexpr int POINTS = QTAB_WINDOWS + GTAB_WINDOWS;
   const uint32_t lane = threadIdx.x;
+  const uint32_t sub = lane % G;
+  const uint32_t row_raw = blockIdx.x * ROWS + lane / G;
+  const bool live = row_raw < a.n;
+  const uint32_t row = live ? row_raw : a.n - 1;  // idle groups recompute the last row, store nothing
   const bool pre = a.pre_flags && a.pre_flags[row] != 0;
   u256 r = secp::from_be32(a.sig65 + 65ull * row);
   u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
@@ -257,38 +265,44 @@ __global__ void __launch_bounds__(64) verify_known_wave_kernel(recover_args a) {
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
   const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
   const bool decided = pre || vi < 0 || have_table;
-  if (lane == 0) {
+  const bool crypto = live && !pre && have_table;
+  if (live && sub == 0) {
     a.warm_done[row] = decided ? 1 : 0;
     if (decided) a.vidx[row] = vi;
   }
-  if (pre || !have_table) return;  // wave-uniform exit: verdict bit stays 0 (mask was cleared)
+  if (!__any(crypto ? 1 : 0)) return;  // wave-uniform: from here every lane runs the same stream
 
   bool ok = sig_in_range(r, s, v, a.flags);
   u256 u1, u2;
   verify_scalars(z, r, s, u1, u2);
+  const uint32_t *qt = a.qtab + QTAB_DWORDS_PER_VALIDATOR * (crypto ? (uint32_t)vi : a.dummy_validator);
   jac acc = secp::jac_inf();
-  if (lane < (uint32_t)QTAB_WINDOWS) {
-    const uint32_t w = lane;
-    const uint32_t dgt = (u2.v[w >> 2] >> (8 * (w & 3))) & 255u;
-    aff pt = load_affine(a.qtab + QTAB_DWORDS_PER_VALIDATOR * (uint32_t)vi + (size_t)GTAB_ENTRY_DWORDS * (w * QTAB_ENTRIES + dgt));
-    jac j = secp::jac_from_aff(pt);
-    j.inf = dgt == 0;
-    acc = j;
-  } else if (lane < (uint32_t)(QTAB_WINDOWS + GTAB_WINDOWS)) {
-    const uint32_t w = lane - QTAB_WINDOWS;
-    const uint32_t dgt = (u1.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
-    aff pt = load_affine(a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
-    jac j = secp::jac_from_aff(pt);
-    j.inf = dgt == 0;
-    acc = j;
+#pragma unroll 1
+  for (int it = 0; it < (POINTS + G - 1) / G; it++) {  // wave-uniform trip count
+    const int p = it * G + (int)sub;
+    const bool has = p < POINTS;
+    const int pp = has ? p : 0;
+    uint32_t dgt;
+    const uint32_t *entry;
+    if (pp < QTAB_WINDOWS) {
+      dgt = (u2.v[pp >> 2] >> (8 * (pp & 3))) & 255u;
+      entry = qt + (size_t)GTAB_ENTRY_DWORDS * (pp * QTAB_ENTRIES + dgt);
+    } else {
+      const int w = pp - QTAB_WINDOWS;
+      dgt = (u1.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+      entry = a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt);
+    }
+    aff pt = load_affine(entry);
+    jac sum = secp::jac_add_aff(acc, pt);
+    acc = secp::jac_select(has && dgt != 0, sum, acc);
   }
 #pragma unroll 1
-  for (int off = 32; off >= 1; off >>= 1) {
+  for (int off = G / 2; off >= 1; off >>= 1) {
     jac other = shfl_xor_jac(acc, off);
     acc = secp::jac_add(acc, other);
   }
-  ok = verify_finish(acc, r, v) && ok;
-  if (lane == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+  ok = verify_finish(acc, r, v) && ok && crypto;
+  if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 
 // ---- warm path table build -------------------------------------------------------------------

@@ -87,7 +87,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
-    L.ibft_cache_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ibft_cache_stats.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.ibft_sync.argtypes = [vp]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
@@ -234,8 +234,9 @@ class BatchVerifier:
 
     def cache_stats(self):
         """(validators with a built table, verdict passes that used the warm kernel, cold passes)."""
-        t, w, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        self._chk(self._L.ibft_cache_stats(self._h, C.byref(t), C.byref(w), C.byref(c)), "ibft_cache_stats")
+        t, w, c, g = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self._L.ibft_cache_stats(self._h, C.byref(t), C.byref(w), C.byref(c), C.byref(g)), "ibft_cache_stats")
+        self.lanes_per_signature = g.value
         return t.value, w.value, c.value
 
     def sync(self):

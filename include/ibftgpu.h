@@ -83,8 +83,9 @@ extern "C" {
 /* cfg.kernel: which ecrecover kernel the seal/sender paths launch */
 #define IBFT_KERNEL_AUTO 0u
 #define IBFT_KERNEL_LANE 1u /* warm path: one lane per signature (throughput at large N)       */
-#define IBFT_KERNEL_WAVE 2u /* warm path: one wavefront per signature (latency at small N; AUTO
-                               picks it for batches of <= 2048 rows)                             */
+#define IBFT_KERNEL_WAVE 2u /* warm path: one wavefront per signature (latency at small N).  AUTO
+                               uses G = 64,32,...,2,1 lanes per signature so that a batch gives
+                               about one wavefront per SIMD: 64 up to 1024 rows, 1 from 65536.   */
 
 typedef struct ibft_ctx ibft_ctx;
 
@@ -167,9 +168,11 @@ int ibft_seals_export(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst);
 /* HIP-event time (ms) of the dominant kernel summed over the last launch, and its
  * launch count; measured on the context's own stream.                              */
 int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
-/* Warm-path statistics: validators whose table is built, and how many verdict passes ran with
- * / without the warm kernel since the context was created.                                   */
-int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes);
+/* Warm-path statistics: validators whose table is built, how many verdict passes ran with /
+ * without the warm kernel since the context was created, and the lanes-per-signature (64 = one
+ * wavefront per signature … 1 = lane kernel) the last warm pass used.                         */
+int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes,
+                     uint32_t *lanes_per_signature);
 /* Block the host until the context's stream is idle.                               */
 int ibft_sync(ibft_ctx *ctx);
 

@@ -17,12 +17,12 @@ def _expect(oracle, vs, r, hash32=None, seal=None, flags=0):
                                r.signer20, r.pre_flags, flags=flags, nthreads=8).astype(bool)
 
 
-@pytest.mark.parametrize("kernel,n", [(2, 200), (1, 200), (0, 1000), (1, 3000), (2, 65)])
+@pytest.mark.parametrize("kernel,n", [(2, 200), (1, 200), (0, 1000), (1, 3000), (2, 65), (0, 3000), (0, 9000), (0, 20000)])
 def test_cold_then_warm_rounds_match_oracle(oracle, kernel, n):
     """kernel: 0 auto, 1 lane, 2 wave.  Round 1 is cold (learns keys), later rounds are warm; every
     round has a fresh proposal hash, Byzantine rows, and is compared with the oracle."""
     from oracle import workload as W
-    bv = _mk(kernel=kernel)
+    bv = _mk(kernel=kernel, max_rows=32768)
     try:
         base = W.make_round(n, 500 + n, byzantine=True, weighted=True, with_envelopes=True)
         vs = oracle.ValSet(base.addrs, base.power)
