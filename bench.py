@@ -178,7 +178,9 @@ def main():
         avg_kernel_s = (kernel_ms / 1e3) / max(kernel_launches, 1)
         if args.path == "warm":
             bv.cache_stats()
-        kname = "ecrecover_lane_kernel<0>" if args.path == "cold" else (
+        cold_lanes = bv.last_dispatch()[0]
+        kname = ("ecrecover_lane_kernel<0>" if cold_lanes == 1 else f"ecrecover_group_kernel<0,{cold_lanes}>") \
+            if args.path == "cold" else (
             f"verify_known_group_kernel<0,{bv.lanes_per_signature}>" if bv.lanes_per_signature > 1
             else "verify_known_lane_kernel<0>")
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank

@@ -56,7 +56,8 @@ struct ibft_ctx {
   uint32_t learned_seen = 0;   // keys whose tables are built (or being built, stream-ordered)
   uint32_t dummy_validator = 0;
   std::vector<uint8_t> valset_addrs;  // last address list, to keep the cache across identical sets
-  uint32_t warm_passes = 0, cold_passes = 0, last_group = 0;
+  uint32_t warm_passes = 0, cold_passes = 0, last_group = 0, last_cold_group = 1;
+  bool cold_group_auto = true;
 
   // staged batch
   uint32_t staged_n = 0;
@@ -213,11 +214,38 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   } else {
     c->cold_passes++;
   }
-  dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
-  if (mode == 0)
-    hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<0>, grid, block, 0, c->stream, a);
-  else
-    hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<1>, grid, block, 0, c->stream, a);
+  // cold kernel: lane groups when the batch is too small to fill the chip (and nothing is warm:
+  // with a warm kernel in front only the stragglers are left and the group kernel's atomicOr
+  // merge needs the mask it already holds)
+  uint32_t CG = 1;
+  if (c->cold_group_auto) {
+    if ((uint64_t)n * 8 <= 65536ull) CG = 8;
+    else if ((uint64_t)n * 4 <= 65536ull) CG = 4;
+    else if ((uint64_t)n * 2 <= 65536ull) CG = 2;
+  }
+  if (CG > 1) {
+    if (!warm) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
+    const uint32_t rows_per_wave = 64 / CG;
+    dim3 cgrid((n + rows_per_wave - 1) / rows_per_wave), cblock(64);
+#define IBFT_LAUNCH_COLD(GG)                                                                         \
+  if (mode == 0)                                                                                     \
+    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<0, GG>), cgrid, cblock, 0, c->stream, a);      \
+  else                                                                                               \
+    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<1, GG>), cgrid, cblock, 0, c->stream, a);
+    switch (CG) {
+      case 8: IBFT_LAUNCH_COLD(8) break;
+      case 4: IBFT_LAUNCH_COLD(4) break;
+      default: IBFT_LAUNCH_COLD(2) break;
+    }
+#undef IBFT_LAUNCH_COLD
+  } else {
+    dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
+    if (mode == 0)
+      hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<0>, grid, block, 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<1>, grid, block, 0, c->stream, a);
+  }
+  c->last_cold_group = CG;
   HIPCHK(c, hipGetLastError());
   if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
   return IBFT_OK;
@@ -329,6 +357,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->flags = cfg ? cfg->flags : 0;
   c->max_rows = (cfg && cfg->max_rows) ? cfg->max_rows : DEFAULT_MAX_ROWS;
   c->kernel = cfg ? cfg->kernel : IBFT_KERNEL_AUTO;
+  c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
   int rc = IBFT_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
@@ -558,6 +587,13 @@ int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint3
   if (warm_passes) *warm_passes = c->warm_passes;
   if (cold_passes) *cold_passes = c->cold_passes;
   if (lanes_per_signature) *lanes_per_signature = c->last_group;
+  return IBFT_OK;
+}
+
+int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) {
+  if (!c) return IBFT_E_INVAL;
+  if (cold_lanes) *cold_lanes = c->last_cold_group;
+  if (warm_lanes) *warm_lanes = c->last_group;
   return IBFT_OK;
 }
 

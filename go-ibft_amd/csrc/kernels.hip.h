@@ -305,6 +305,140 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
   if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 
+// ---- cold path with G = 2, 4 or 8 lanes per signature ----------------------------------------
+// The GLV split already yields two independent halves (k1·R, k2·λR); each half is cut into
+// P = G/2 pieces of 128/P bits with bases 2^(j·128/P)·R, so a lane does 128/P doublings instead of
+// 128 and the pieces are joined by a log2(G)-level butterfly.  Everything that does not split
+// (√, r⁻¹, the prefix doublings that produce the bases, the per-lane table, Z⁻¹, Keccak) is
+// replicated across the group, so the critical path shrinks from ≈676 k to ≈520 k (G = 2),
+// ≈440 k (G = 4), ≈410 k (G = 8) VALU instructions: worth it exactly when the batch is too small
+// to fill the chip (host picks G so that n·G/64 ≤ 1024 wavefronts).
+template <int MODE, int G>
+__global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
+  constexpr int ROWS = 64 / G;
+  constexpr int P = G / 2;            // pieces per GLV half
+  constexpr int PIECE_BITS = 128 / P; // 128, 64 or 32 ... (G = 2, 4, 8)
+  constexpr int NIBS = PIECE_BITS / 4;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t sub = lane % G;
+  const uint32_t half = sub & 1u;     // 0: k1 on ±R, 1: k2 on λ(±R)
+  const uint32_t piece = sub >> 1;    // which 128/P-bit piece of that half
+  const uint32_t row_raw = blockIdx.x * ROWS + lane / G;
+  const bool live = row_raw < a.n;
+  const uint32_t row = live ? row_raw : a.n - 1;
+  const bool pre = a.pre_flags && a.pre_flags[row] != 0;
+  const bool done = a.warm_done && a.warm_done[row] != 0;
+  const bool need = live && !done;
+  if (!__any(need ? 1 : 0)) return;
+
+  u256 r = secp::from_be32(a.sig65 + 65ull * row);
+  u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
+  const uint32_t v = a.sig65[65ull * row + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(a.hash32 + 32ull * row);
+  } else {
+    uint64_t d[4];
+    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    keccak::digest_to_limbs(d, z.v);
+  }
+  uint32_t want[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
+
+  bool ok = sig_in_range(r, s, v, a.flags);
+  // R = (r, y), y² = r³ + 7, parity(y) = v
+  secp::fe rx = secp::fe_from_u256(r);
+  secp::fe seven = secp::fe_zero();
+  seven.n[0] = 7;
+  secp::fe rhs = secp::fe_add(secp::fe_mul(secp::fe_sqr(rx), rx), seven);
+  secp::fe y = secp::fe_sqrt_candidate(rhs);
+  ok = ok && secp::fe_equal(secp::fe_sqr(y), rhs, 2);
+  y = secp::fe_normalize(y);
+  y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
+  // u1 = −z/r, u2 = s/r, u2 = k1 + k2·λ
+  secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));
+  u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z), rinv)));
+  u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+  secp::glv_split sp = secp::sc_split_lambda(u2);
+  // this lane's base: ±R doubled piece·PIECE_BITS times (uniform trip count: every lane runs the
+  // longest prefix and keeps the intermediate it needs)
+  aff R1;
+  R1.x = rx;
+  R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
+  jac base = secp::jac_from_aff(R1);
+  if (P > 1) {
+    jac run = base;
+#pragma unroll 1
+    for (int j = 1; j < P; j++) {
+#pragma unroll 1
+      for (int d = 0; d < PIECE_BITS; d++) run = secp::jac_dbl(run);
+      base = secp::jac_select(piece >= (uint32_t)j && piece == (uint32_t)j, run, base);
+    }
+  }
+  // per-lane table of 1..15 multiples of the base (Jacobian)
+  jac tab[16];
+  tab[0] = secp::jac_inf();
+  tab[1] = base;
+  tab[2] = secp::jac_dbl(base);
+#pragma unroll 1
+  for (int i = 3; i < 16; i++) tab[i] = secp::jac_add(tab[i - 1], base);
+  // this lane's scalar piece
+  const u256 &kk = half ? sp.k2 : sp.k1;
+  const bool flip = half && (sp.neg1 != sp.neg2);
+  const secp::fe beta = secp::GLV_CONST(1);
+  jac acc = secp::jac_inf();
+#pragma unroll 1
+  for (int nib = NIBS - 1; nib >= 0; nib--) {
+#pragma unroll 1
+    for (int d = 0; d < 4; d++) acc = secp::jac_dbl(acc);
+    const uint32_t dg = secp::nibble(kk, (int)(piece * NIBS) + nib);
+    jac q = tab[dg];
+    secp::fe bx = secp::fe_mul(q.x, beta);
+    q.x = secp::l26_select(half != 0, bx, q.x);
+    q.y = secp::l26_select(flip, secp::fe_neg(q.y, 1), q.y);
+    jac sum = secp::jac_add(acc, q);
+    acc = secp::jac_select(dg != 0, sum, acc);
+  }
+  // u1·G: the fixed-base windows are dealt to the lanes of the group
+#pragma unroll 1
+  for (int it = 0; it < (GTAB_WINDOWS + G - 1) / G; it++) {
+    const int w = it * G + (int)sub;
+    const bool has = w < GTAB_WINDOWS;
+    const int ww = has ? w : 0;
+    const uint32_t dg = (u1.v[(ww * GTAB_BITS) >> 5] >> ((ww * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+    aff pt = load_affine(a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)ww * GTAB_ENTRIES + dg));
+    jac sum = secp::jac_add_aff(acc, pt);
+    acc = secp::jac_select(has && dg != 0, sum, acc);
+  }
+#pragma unroll 1
+  for (int off = G / 2; off >= 1; off >>= 1) {
+    jac other = shfl_xor_jac(acc, off);
+    acc = secp::jac_add(acc, other);
+  }
+  aff Qa;
+  ok = secp::jac_to_aff_fast(Qa, acc) && ok;
+  u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
+  uint32_t got[5];
+  keccak::address_from_xy(qx.v, qy.v, got);
+  ok = ok && need && !pre;
+#pragma unroll
+  for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
+  int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  ok = ok && vi >= 0;
+  if (sub == 0 && need) {
+    a.vidx[row] = vi;
+    if (ok && a.pub_state && a.pub_state[vi] == 0) {
+      store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
+      __threadfence();
+      a.pub_state[vi] = 1;
+      atomicAdd(a.learned, 1u);
+      a.learned[1] = (uint32_t)vi;
+    }
+    if (ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+  }
+}
+
 // ---- warm path table build -------------------------------------------------------------------
 // Lane ↔ (validator, window): a wavefront holds ONE window index for 64 consecutive validators so
 // that the doubling loop's trip count is wave-uniform.

@@ -30,7 +30,7 @@ EXPORTS = [
     "ibft_version", "ibft_strerror", "ibft_last_error", "ibft_ctx_create", "ibft_ctx_destroy",
     "ibft_set_validators", "ibft_verify_hashes", "ibft_proposal_hash", "ibft_verify_seals",
     "ibft_verify_senders", "ibft_tally", "ibft_seals_stage", "ibft_seals_launch", "ibft_seals_fetch",
-    "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_cache_stats", "ibft_sync",
+    "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_cache_stats", "ibft_last_dispatch", "ibft_sync",
 ]
 
 
@@ -88,6 +88,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.ibft_cache_stats.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
+    L.ibft_last_dispatch.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_sync.argtypes = [vp]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
@@ -238,6 +239,12 @@ class BatchVerifier:
         self._chk(self._L.ibft_cache_stats(self._h, C.byref(t), C.byref(w), C.byref(c), C.byref(g)), "ibft_cache_stats")
         self.lanes_per_signature = g.value
         return t.value, w.value, c.value
+
+    def last_dispatch(self):
+        """(cold lanes per signature, warm lanes per signature) of the last verdict pass."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._chk(self._L.ibft_last_dispatch(self._h, C.byref(a), C.byref(b)), "ibft_last_dispatch")
+        return a.value, b.value
 
     def sync(self):
         self._chk(self._L.ibft_sync(self._h), "ibft_sync")

@@ -173,6 +173,9 @@ int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
  * wavefront per signature … 1 = lane kernel) the last warm pass used.                         */
 int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes,
                      uint32_t *lanes_per_signature);
+/* Lanes per signature used by the last verdict pass: cold kernel (1 = ecrecover_lane_kernel,
+ * 2/4/8 = ecrecover_group_kernel) and warm kernel (0 = none ran, 1 = lane, 2..64 = group).     */
+int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);
 /* Block the host until the context's stream is idle.                               */
 int ibft_sync(ibft_ctx *ctx);
 

@@ -26,3 +26,13 @@ def gpu_verifier():
     bv = V.BatchVerifier(device=0, max_rows=65536)
     yield bv
     bv.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_verifier_lane():
+    """Same, but pinned to the lane-per-signature kernels (IBFT_KERNEL_LANE): the default context
+    uses 2/4/8-lane groups for small batches, this one keeps the G = 1 kernels covered."""
+    import go_ibft_amd.verifier as V
+    bv = V.BatchVerifier(device=0, max_rows=65536, kernel=V.KERNEL_LANE)
+    yield bv
+    bv.close()

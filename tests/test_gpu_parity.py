@@ -46,11 +46,33 @@ def test_golden_fixtures(gpu_verifier, name):
     assert (senders == g["exp_senders"].astype(bool)).all()
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
-def test_ragged_sizes_vs_oracle(gpu_verifier, oracle, n):
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 1000])
+def test_ragged_sizes_vs_oracle(gpu_verifier, gpu_verifier_lane, oracle, n):
+    """Default context: 8 lanes per signature at these sizes (8 rows per wavefront, ragged tails);
+    lane context: 64 rows per wavefront."""
     from oracle import workload as W
-    r = W.make_round(n, 100 + n, byzantine=True, weighted=True)
-    _check_round(gpu_verifier, oracle, r)
+    r = W.make_round(n, 100 + n, byzantine=True, weighted=True, with_envelopes=True)
+    vs = oracle.ValSet(r.addrs, r.power)
+    for bv in (gpu_verifier, gpu_verifier_lane):
+        _check_round(bv, oracle, r)
+        senders, _ = bv.is_valid_validator(r.payload, r.off, r.msg_sig65, r.signer20)
+        assert (senders == oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)).all()
+
+
+@pytest.mark.parametrize("n,expect_group", [(8192, 8), (12000, 4), (20000, 2), (40000, 1)])
+def test_cold_group_sizes(oracle, n, expect_group):
+    """AUTO picks 8/4/2/1 lanes per signature for the cold kernel so that n·G/64 ≤ 1024 wavefronts;
+    each choice is compared with the oracle on a Byzantine round."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    assert (8 if n * 8 <= 65536 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
+    r = W.make_round(n, 3000 + n, byzantine=True)
+    bv = V.BatchVerifier(max_rows=65536)
+    try:
+        _check_round(bv, oracle, r)
+        assert bv.last_dispatch() == (expect_group, 0)
+    finally:
+        bv.close()
 
 
 def test_empty_batch(gpu_verifier, oracle):
