@@ -50,7 +50,15 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
     Go toolchain exists here) timed on this box's host cores over a bounded sample: the
     same COMMIT rows tiled so that every pthread gets ≥64 rows per call."""
     from oracle import binding as B
-    cores = os.cpu_count() or 1
+    # usable cores: affinity mask ∧ cgroup CPU quota (the GPU box exposes 256 hardware threads but
+    # grants this container a 16-CPU quota), not the socket's thread count
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
     vs = B.ValSet(addrs, power)
     n = len(seal65)
     reps = max(1, (512 * cores + n - 1) // n)   # ≥512 rows per thread so pthread spawn is amortised
@@ -67,7 +75,7 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
     t1 = time.perf_counter()
     B.verify_seals(vs, hash32[:256], seal65[:256], signer20[:256], nthreads=1)
     single = 256 / (time.perf_counter() - t1)
-    return {"value": done / el, "unit": "verifies/s", "cores": cores, "kind": "port",
+    return {"value": done / el, "unit": "verifies/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{done} seal verifies (the N={n} COMMIT batch tiled x{reps} per call, repeated for "
                       f"{el:.1f} s, {cores} pthreads); 1 thread: {single:.0f} verifies/s"}
 
