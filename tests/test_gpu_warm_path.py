@@ -125,3 +125,30 @@ def test_partial_knowledge_mixed_wave(oracle):
             assert t.valid_rows == int(exp_all.sum())
         finally:
             bv.close()
+
+
+def test_config5_n65536_byzantine_cold_and_warm(oracle):
+    """BASELINE config #5 on one GPU's worth of rows: N = 65 536 validators, 20 % bad seals
+    (12 corruption kinds).  Cold pass (lane kernel), then warm passes against 43 GB of per-validator
+    tables; verdict set, quorum flag and power must equal the oracle's every time."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    n = 65536
+    r0 = W.make_round(n, 5, round_=0, byzantine=True)
+    r1 = W.make_round(n, 5, round_=1, byzantine=True)
+    vs = oracle.ValSet(r0.addrs, r0.power)
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=n)
+    try:
+        bv.set_validators(1, r0.addrs, r0.power)
+        for i, r in enumerate((r0, r1, r0)):
+            got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+            exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=16).astype(bool)
+            assert (got == exp).all(), (i, np.nonzero(got != exp)[0][:8])
+            te = oracle.tally(vs, r.signer20, exp.astype(np.uint8))
+            assert (t.power, t.has_quorum, t.distinct_senders) == (te.power, te.has_quorum, te.distinct_senders)
+            assert 0.75 < got.mean() < 0.85 and t.has_quorum == 1
+        tables, warm, cold = bv.cache_stats()
+        assert tables == int(exp.sum()) or tables >= int(0.75 * n)   # every honest validator learned
+        assert bv.last_dispatch() == (1, 1)
+    finally:
+        bv.close()
