@@ -19,7 +19,6 @@
 namespace {
 
 constexpr uint32_t DEFAULT_MAX_ROWS = 65536;
-constexpr size_t PAYLOAD_SLACK = 1 << 20;
 
 struct DevBuf {
   void *p = nullptr;
@@ -52,7 +51,7 @@ struct ibft_ctx {
 
   // warm path (IBFT_FLAG_PUBKEY_CACHE): recovered keys + per-validator fixed-base tables
   bool cache_on = false;       // flag set AND the tables fit the memory budget for this validator set
-  DevBuf d_pub, d_pub_state, d_learned, d_qtab, d_warm_done;
+  DevBuf d_pub, d_pub_state, d_qtab, d_warm_done;
   uint32_t learned_seen = 0;   // keys whose tables are built (or being built, stream-ordered)
   uint32_t dummy_validator = 0;
   std::vector<uint8_t> valset_addrs;  // last address list, to keep the cache across identical sets
@@ -117,7 +116,7 @@ int alloc_rows(ibft_ctx *c) {
   if ((rc = ensure(c, c->d_off, (m + 1) * 4))) return rc;
   if ((rc = ensure(c, c->d_mask, (size_t)mask_words(m) * 8))) return rc;
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
-  if ((rc = ensure(c, c->d_tally, 4 * 8))) return rc;
+  if ((rc = ensure(c, c->d_tally, 8 * 8))) return rc;
   if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
   if ((rc = ensure(c, c->d_warm_done, m))) return rc;
   return IBFT_OK;
@@ -141,7 +140,7 @@ ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre) {
   if (c->cache_on) {
     a.pub = (uint32_t *)c->d_pub.p;
     a.pub_state = (uint8_t *)c->d_pub_state.p;
-    a.learned = (uint32_t *)c->d_learned.p;
+    a.learned = (uint32_t *)((uint64_t *)c->d_tally.p + 4);
     a.qtab = (const uint32_t *)c->d_qtab.p;
     a.dummy_validator = c->dummy_validator;
   }
@@ -214,6 +213,12 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   } else {
     c->cold_passes++;
   }
+  if (warm && c->learned_seen >= c->n_validators) {
+    // every validator has a table: the warm kernel decides every row (non-members included)
+    if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
+    c->last_cold_group = 0;
+    return IBFT_OK;
+  }
   // cold kernel: lane groups when the batch is too small to fill the chip (and nothing is warm:
   // with a warm kernel in front only the stragglers are left and the group kernel's atomicOr
   // merge needs the mask it already holds)
@@ -279,10 +284,9 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
   size_t mw = (size_t)mask_words(n);
   if (out_mask && mw)
     HIPCHK(c, hipMemcpyAsync(c->h_mask, c->d_mask.p, mw * 8, hipMemcpyDeviceToHost, c->stream));
-  if (tally && have_tally)
-    HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 4 * 8, hipMemcpyDeviceToHost, c->stream));
-  if (c->cache_on)
-    HIPCHK(c, hipMemcpyAsync(c->h_tally + 4, c->d_learned.p, 8, hipMemcpyDeviceToHost, c->stream));
+  // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator}: one copy
+  if ((tally && have_tally) || c->cache_on)
+    HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 5 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->cache_on) {
     const uint32_t *lw = reinterpret_cast<const uint32_t *>(c->h_tally + 4);
@@ -384,7 +388,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
-                    &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_learned, &c->d_qtab,
+                    &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done})
     release(*b);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
@@ -443,10 +447,9 @@ int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, co
     size_t budget = 64ull << 30;
     if (const char *e = getenv("IBFT_QTAB_BUDGET_GB")) budget = (size_t)strtoull(e, nullptr, 10) << 30;
     if (nv > 0 && qbytes <= budget && ensure(c, c->d_qtab, qbytes) == IBFT_OK &&
-        ensure(c, c->d_pub, nv * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK && ensure(c, c->d_pub_state, nv) == IBFT_OK &&
-        ensure(c, c->d_learned, 8) == IBFT_OK) {
+        ensure(c, c->d_pub, nv * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK && ensure(c, c->d_pub_state, nv) == IBFT_OK) {
       HIPCHK(c, hipMemsetAsync(c->d_pub_state.p, 0, nv, c->stream));
-      HIPCHK(c, hipMemsetAsync(c->d_learned.p, 0, 8, c->stream));
+      HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_tally.p + 4, 0, 8, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       c->cache_on = true;
     }
