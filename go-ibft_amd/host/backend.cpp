@@ -146,6 +146,47 @@ int HotPath::AddMessage(MsgPtr m) {
   return 1;
 }
 
+void HotPath::EnableQuorumIndex() {
+  messages.SetHooks(
+      [this](uint32_t type, uint64_t h, uint64_t r, const bytes &from, int delta) {
+        quorumIndex.OnSender(type, h, r, from, delta, validatorManager);
+      },
+      [this](uint64_t below) { quorumIndex.OnPrune(below); });
+}
+
+int HotPath::AddMessageFast(MsgPtr m) {
+  if (!m) return 0;
+  if (!isAcceptableMessage(*m)) return 0;
+  const View view = *m->view;
+  const uint32_t type = m->type;
+  messages.AddMessage(m);
+  if (view.height != height) return 1;
+  // hasQuorumByMsgType over the stored (unverified) messages of the view, without walking them
+  auto rebuild = [&]() {
+    std::vector<bytes> senders;
+    for (auto &x : messages.GetValidMessages(view, (MessageType)type, [](const IbftMessage &) { return true; }))
+      senders.push_back(x->from);
+    return senders;
+  };
+  auto pc = quorumIndex.Get(type, view.height, view.round, rebuild, validatorManager);
+  bool q = false;
+  switch (type) {
+    case PREPREPARE: q = pc.second >= 1; break;
+    case PREPARE: {  // HasPrepareQuorum: proposer joins the set; a PREPARE from the proposer voids it
+      if (!proposalMessage) break;
+      if (messages.Has(view, PREPARE, proposalMessage->from)) break;
+      auto p = validatorManager.powers().find(proposalMessage->from);
+      unsigned __int128 w = p == validatorManager.powers().end() ? 0 : p->second;
+      q = validatorManager.initialized() && pc.first + w >= validatorManager.quorum();
+      break;
+    }
+    case ROUND_CHANGE:
+    case COMMIT: q = validatorManager.initialized() && pc.first >= validatorManager.quorum(); break;
+    default: break;
+  }
+  return q ? 2 : 1;
+}
+
 bool HotPath::handlePrepare(const View &view) {
   std::vector<MsgPtr> prepareMessages;
   const Proposal *proposal = getProposal();

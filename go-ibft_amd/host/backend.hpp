@@ -87,6 +87,12 @@ class HotPath {
   }
   // IBFT.AddMessage: 0 = rejected, 1 = stored, 2 = stored and SignalEvent fired
   int AddMessage(MsgPtr m);
+  // Same decisions with the O(1) quorum probe (QuorumIndex) instead of the O(#stored) walk;
+  // call EnableQuorumIndex() once, and NotifyValidatorSetChanged() after validatorManager.Init.
+  int AddMessageFast(MsgPtr m);
+  void EnableQuorumIndex();
+  void NotifyValidatorSetChanged() { quorumIndex.Invalidate(); }
+  QuorumIndex quorumIndex;
   bool isAcceptableMessage(const IbftMessage &m);
   bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
   bool handlePrepare(const View &view);

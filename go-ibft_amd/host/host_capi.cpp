@@ -180,7 +180,9 @@ int ibft_host_vm_init(ibft_host *h, const uint8_t *packed_addrs, size_t len, con
   if (!unpack_list(packed_addrs, len, addrs) || addrs.size() != n) return -2;
   std::vector<std::pair<bytes, uint64_t>> p;
   for (size_t i = 0; i < n; i++) p.emplace_back(addrs[i], power[i]);
-  return h->hp.validatorManager.Init(p) ? 0 : -1;
+  bool ok = h->hp.validatorManager.Init(p);
+  if (ok) h->hp.NotifyValidatorSetChanged();
+  return ok ? 0 : -1;
 }
 int ibft_host_vm_has_quorum(ibft_host *h, const uint8_t *packed_senders, size_t len) {
   std::vector<bytes> s;
@@ -230,6 +232,13 @@ int ibft_host_add_message(ibft_host *h, const uint8_t *wire, size_t len) {
   auto m = std::make_shared<IbftMessage>();
   if (!decode(wire, len, *m)) return -1;
   return h->hp.AddMessage(std::move(m));
+}
+
+void ibft_host_enable_quorum_index(ibft_host *h) { h->hp.EnableQuorumIndex(); }
+int ibft_host_add_message_fast(ibft_host *h, const uint8_t *wire, size_t len) {
+  auto m = std::make_shared<IbftMessage>();
+  if (!decode(wire, len, *m)) return -1;
+  return h->hp.AddMessageFast(std::move(m));
 }
 
 int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n) {

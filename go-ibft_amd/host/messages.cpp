@@ -7,7 +7,26 @@ void Messages::AddMessage(MsgPtr m) {
   int s = slot(m->type);
   if (s < 0 || !m->view) return;  // the reference would panic on an unknown type / nil view
   std::unique_lock lk(mux_[s]);
-  maps_[s][m->view->height][m->view->round][m->from] = std::move(m);
+  auto &view_msgs = maps_[s][m->view->height][m->view->round];
+  const uint64_t h = m->view->height, r = m->view->round;
+  auto it = view_msgs.find(m->from);
+  if (it == view_msgs.end()) {
+    const bytes from = m->from;
+    view_msgs.emplace(from, std::move(m));
+    if (sender_hook_) sender_hook_((uint32_t)s, h, r, from, +1);
+  } else {
+    it->second = std::move(m);  // last writer wins, sender set unchanged
+  }
+}
+
+bool Messages::Has(const View &view, MessageType type, const bytes &from) {
+  int s = slot(type);
+  if (s < 0) return false;
+  std::shared_lock lk(mux_[s]);
+  auto h = maps_[s].find(view.height);
+  if (h == maps_[s].end()) return false;
+  auto r = h->second.find(view.round);
+  return r != h->second.end() && r->second.count(from) != 0;
 }
 
 size_t Messages::numMessages(const View &view, MessageType type) {
@@ -26,6 +45,7 @@ void Messages::PruneByHeight(uint64_t height) {
     auto &m = maps_[s];
     m.erase(m.begin(), m.lower_bound(height));  // delete every msgHeight < height
   }
+  if (height_hook_) height_hook_(height);
 }
 
 std::vector<MsgPtr> Messages::GetValidMessages(const View &view, MessageType type, const Predicate &isValid) {
@@ -39,6 +59,7 @@ std::vector<MsgPtr> Messages::GetValidMessages(const View &view, MessageType typ
   if (r == h->second.end()) return valid;
   for (auto it = r->second.begin(); it != r->second.end();) {
     if (!isValid(*it->second)) {
+      if (sender_hook_) sender_hook_((uint32_t)s, view.height, view.round, it->first, -1);
       it = r->second.erase(it);  // prune out invalid messages, messages.go:193-196
     } else {
       valid.push_back(it->second);
@@ -66,6 +87,7 @@ std::vector<MsgPtr> Messages::GetValidMessagesBatch(const View &view, MessageTyp
   size_t i = 0;
   for (auto it = r->second.begin(); it != r->second.end(); ++i) {
     if (!v[i]) {
+      if (sender_hook_) sender_hook_((uint32_t)s, view.height, view.round, it->first, -1);
       it = r->second.erase(it);
     } else {
       valid.push_back(it->second);
@@ -145,6 +167,46 @@ bool ValidatorManager::HasPrepareQuorum(const IbftMessage *proposal, const std::
     senders.insert(m->from);
   }
   return HasQuorum(senders);
+}
+
+void QuorumIndex::OnSender(uint32_t type, uint64_t height, uint64_t round, const bytes &from, int delta,
+                           const ValidatorManager &vm) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = e_.find({type, height, round});
+  if (it == e_.end() || !it->second.valid || it->second.epoch != epoch_) return;  // stale: rebuilt on demand
+  auto p = vm.powers().find(from);
+  unsigned __int128 w = p == vm.powers().end() ? 0 : p->second;  // unknown senders contribute 0
+  if (delta > 0) {
+    it->second.power += w;
+    it->second.count++;
+  } else {
+    it->second.power -= w;
+    it->second.count--;
+  }
+}
+
+void QuorumIndex::OnPrune(uint64_t below_height) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto it = e_.begin(); it != e_.end();)
+    it = std::get<1>(it->first) < below_height ? e_.erase(it) : std::next(it);
+}
+
+std::pair<unsigned __int128, size_t> QuorumIndex::Get(uint32_t type, uint64_t height, uint64_t round,
+                                                      const std::function<std::vector<bytes>()> &rebuild,
+                                                      const ValidatorManager &vm) {
+  std::lock_guard<std::mutex> lk(mu_);
+  Entry &e = e_[{type, height, round}];
+  if (!e.valid || e.epoch != epoch_) {
+    e = Entry{};
+    for (const bytes &from : rebuild()) {
+      auto p = vm.powers().find(from);
+      if (p != vm.powers().end()) e.power += p->second;
+      e.count++;
+    }
+    e.valid = true;
+    e.epoch = epoch_;
+  }
+  return {e.power, e.count};
 }
 
 std::set<bytes> convertMessageToAddressSet(const std::vector<MsgPtr> &msgs) {

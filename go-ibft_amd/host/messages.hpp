@@ -24,6 +24,18 @@ using Predicate = std::function<bool(const IbftMessage &)>;
 
 class Messages {
  public:
+  // Observer of the sender SET of a view: called with +1 when a sender appears in
+  // [type][height][round] (not when it overwrites its own message) and −1 when one is removed by
+  // the prune-on-invalid of GetValidMessages.  PruneByHeight reports whole heights instead.
+  // Lets a caller keep Σ power per view incrementally (QuorumIndex below) instead of re-walking
+  // the view on every AddMessage (/root/reference/core/ibft.go:1113-1120).
+  using SenderHook = std::function<void(uint32_t type, uint64_t height, uint64_t round, const bytes &from, int delta)>;
+  using HeightHook = std::function<void(uint64_t below_height)>;
+  void SetHooks(SenderHook s, HeightHook h) {
+    sender_hook_ = std::move(s);
+    height_hook_ = std::move(h);
+  }
+  bool Has(const View &view, MessageType type, const bytes &from);
   void AddMessage(MsgPtr m);
   size_t numMessages(const View &view, MessageType type);
   void PruneByHeight(uint64_t height);
@@ -43,6 +55,8 @@ class Messages {
   using heightMessageMap = std::map<uint64_t, roundMessageMap>;
   heightMessageMap maps_[4];
   std::shared_mutex mux_[4];
+  SenderHook sender_hook_;
+  HeightHook height_hook_;
   static int slot(uint32_t type) { return type <= 3 ? (int)type : -1; }
 };
 
@@ -66,5 +80,31 @@ class ValidatorManager {
 };
 
 std::set<bytes> convertMessageToAddressSet(const std::vector<MsgPtr> &msgs);  // :147-155
+
+// Σ voting power of the distinct senders stored per (type, height, round), maintained from the
+// store's hooks: the O(1) replacement of the per-message GetValidMessages + HasQuorum probe of
+// IBFT.AddMessage.  Rebuilt lazily when the validator set changes.
+class QuorumIndex {
+ public:
+  void OnSender(uint32_t type, uint64_t height, uint64_t round, const bytes &from, int delta,
+                const ValidatorManager &vm);
+  void OnPrune(uint64_t below_height);
+  void Invalidate() { epoch_++; }  // validator set changed: sums are recomputed on next use
+  // (Σ power, number of stored senders); `rebuild` lists the view's senders when the entry is stale
+  std::pair<unsigned __int128, size_t> Get(uint32_t type, uint64_t height, uint64_t round,
+                                           const std::function<std::vector<bytes>()> &rebuild,
+                                           const ValidatorManager &vm);
+
+ private:
+  struct Entry {
+    unsigned __int128 power = 0;
+    size_t count = 0;
+    uint64_t epoch = 0;
+    bool valid = false;
+  };
+  std::map<std::tuple<uint32_t, uint64_t, uint64_t>, Entry> e_;
+  uint64_t epoch_ = 1;
+  std::mutex mu_;
+};
 
 }  // namespace ibft

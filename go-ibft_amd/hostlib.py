@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
         L.ibft_host_attach_gpu.argtypes = [vp, vp]
         L.ibft_host_use_batch.argtypes = [vp, C.c_int]
         L.ibft_host_add_message.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.ibft_host_enable_quorum_index.argtypes = [vp]
+        L.ibft_host_add_message_fast.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.ibft_host_add_messages_batch.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.ibft_host_handle_prepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         L.ibft_host_handle_commit.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
@@ -241,6 +243,12 @@ class Host:
     # --- core/ibft.go hot-path callers
     def add_message(self, wire: bytes) -> int:
         return self.L.ibft_host_add_message(self.h, wire, len(wire))
+
+    def enable_quorum_index(self):
+        self.L.ibft_host_enable_quorum_index(self.h)
+
+    def add_message_fast(self, wire: bytes) -> int:
+        return self.L.ibft_host_add_message_fast(self.h, wire, len(wire))
 
     def add_messages_batch(self, wires) -> list[int]:
         p = pack(wires)

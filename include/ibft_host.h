@@ -87,6 +87,12 @@ void ibft_host_use_batch(ibft_host *h, int on);
 
 /* IBFT.AddMessage (core/ibft.go:1101-1123): 0 rejected, 1 stored, 2 stored + SignalEvent */
 int ibft_host_add_message(ibft_host *h, const uint8_t *wire, size_t len);
+/* Same decisions as ibft_host_add_message with the O(1) incremental quorum probe (Σ power per
+ * view maintained from the store's insert/prune hooks) instead of re-walking the view on every
+ * message (core/ibft.go:1113-1120 is O(#stored) per call, O(N²) per phase).  Call
+ * ibft_host_enable_quorum_index once after ibft_host_new; ibft_host_vm_init invalidates it.   */
+void ibft_host_enable_quorum_index(ibft_host *h);
+int ibft_host_add_message_fast(ibft_host *h, const uint8_t *wire, size_t len);
 /* Batched ingest: IsValidValidator for many messages in one device call,
  * then the same store/probe logic per accepted message; results[i] as above. */
 int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n);

@@ -380,3 +380,74 @@ def test_handle_prepare():
     # a PREPARE from the proposer itself voids the quorum (validator_manager.go:117-121)
     h.store_add(W.IbftMessage(view=W.View(1, 0), sender=nodes[0], type=PR, payload=W.prepare_body(good)).encode())
     assert h.handle_prepare(1, 0)[0] is False
+
+
+# ---------------------------------------------------------------- incremental quorum probe (§8f rank 1)
+def test_add_message_fast_equals_stock_on_random_streams():
+    """AddMessageFast (O(1) Σ-power index fed by the store's insert/prune hooks) returns the same
+    0/1/2 as the stock AddMessage (re-walk of the view, core/ibft.go:1113-1120) on random streams
+    with duplicates, overwrites, unknown senders, proposer PREPAREs, prunes, validator-set changes
+    and interleaved handleCommit pruning."""
+    rng = random.Random(11)
+    nodes = _node_set(9) + [b"stranger 1", b"stranger 2"]
+    for trial in range(6):
+        powers = {a: rng.randrange(1, 6) for a in nodes[:9]}
+        hosts = [H.Host(), H.Host()]
+        hosts[1].enable_quorum_index()
+        proposal = W.IbftMessage(view=W.View(1, 0), sender=nodes[0], type=PP,
+                                 payload=W.preprepare_body(W.Proposal(b"blk", 0), b"h", None)).encode()
+        for h in hosts:
+            assert h.vm_init(powers)
+            h.set_state(1, 0, proposal if trial % 2 == 0 else None)
+            h.set_verifier(is_valid_validator=lambda w: b"bad-sender" not in w,
+                           is_valid_committed_seal=lambda hsh, seal: seal is not None and seal[1] != b"bad seal",
+                           is_valid_proposal_hash=lambda prop, hsh: True)
+        for step in range(300):
+            op = rng.random()
+            if op < 0.85:
+                t = rng.choice([PP, PR, CM, CM, RC])
+                view = (rng.choice([1, 1, 1, 2]), rng.choice([0, 0, 1]))
+                frm = rng.choice(nodes)
+                body = {PP: W.preprepare_body(None, b"h", None), PR: W.prepare_body(b"h"),
+                        CM: W.commit_body(b"h", rng.choice([b"seal", b"bad seal"])),
+                        RC: W.round_change_body(None, None)}[t]
+                m = W.IbftMessage(view=W.View(*view), sender=frm, type=t, payload=body,
+                                  signature=rng.choice([b"ok", b"bad-sender"]))
+                w = m.encode()
+                assert hosts[0].add_message(w) == hosts[1].add_message_fast(w), (trial, step)
+            elif op < 0.92:
+                r0, r1 = hosts[0].handle_commit(1, 0), hosts[1].handle_commit(1, 0)
+                assert r0[0] == r1[0] and sorted(r0[1]) == sorted(r1[1])
+            elif op < 0.96:
+                below = rng.choice([1, 2])
+                for h in hosts:
+                    h.store_prune(below)
+            else:
+                powers = {a: rng.randrange(1, 6) for a in rng.sample(nodes[:9], 7)}
+                for h in hosts:
+                    assert h.vm_init(powers)
+            for t in range(4):
+                assert hosts[0].store_num(1, 0, t) == hosts[1].store_num(1, 0, t)
+
+
+def test_ingest_cost_quadratic_vs_incremental():
+    """The reference's ingest is O(N²) per phase (every accepted message re-walks the view); the
+    incremental probe is O(N log N).  Same signal sequence, measured ratio grows with N."""
+    import time
+    def run(n, fast):
+        nodes = [i.to_bytes(4, "big") * 5 for i in range(n)]
+        h = H.Host()
+        if fast:
+            h.enable_quorum_index()
+        h.vm_init({a: 1 for a in nodes})
+        h.set_state(1, 0, None)
+        wires = [W.IbftMessage(view=W.View(1, 0), sender=a, type=CM, payload=W.commit_body(b"h" * 32, b"s" * 65)).encode()
+                 for a in nodes]
+        t0 = time.perf_counter()
+        out = [h.add_message_fast(w) if fast else h.add_message(w) for w in wires]
+        return out, time.perf_counter() - t0
+    for n in (256, 2048):
+        slow, ts = run(n, False)
+        fast, tf = run(n, True)
+        assert slow == fast and slow.count(2) == n - (2 * n // 3 + 1) + 1
+    assert ts / tf > 5          # at N = 2048 the re-walk dominates by far more than this

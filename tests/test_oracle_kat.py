@@ -80,3 +80,13 @@ def test_quorum_table(oracle, total, quorum):
     addrs[:, 0] = np.arange(total)
     vs = oracle.ValSet(addrs, np.ones(total, dtype=np.uint64))
     assert vs.quorum == quorum
+
+
+def test_oracle_selftest_under_asan_ubsan():
+    """The C oracle is clean under AddressSanitizer + UBSan on a Byzantine round that exercises
+    every batch entry point (oracle/selftest.c)."""
+    import subprocess
+    d = os.path.join(os.path.dirname(HERE), "oracle")
+    subprocess.check_call(["make", "-C", d, "asan_selftest"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(d, "asan_selftest")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "selftest: ok" in out.stdout, out.stdout + out.stderr
