@@ -266,15 +266,77 @@ HD fe fe_reduce_columns(uint64_t C[19]) {
   r.n[2] = (uint32_t)t2;
   return r;
 }
+// Opaque constant: keeps the compiler from strength-reducing ·0x400 into a 64-bit shift + add
+// (3 instructions) where a single v_mad_u64_u32 with the constant in an SGPR does it.
+HD uint32_t opaque_const(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+s"(x));
+#endif
+  return x;
+}
+
+// Fused multiply: one running 64-bit accumulator walks the high columns (10..18), emitting the
+// 26-bit limbs U[] that fold back with 2^260 ≡ R0 + R1·2^26, then walks the low columns (0..9)
+// adding products, folds and the carry in the same v_mad_u64_u32 chain — no separate carry adds.
+// PROD(k) must add Σ_{i+j=k} a_i·b_j to acc.  Bounds: products < 2^63.3, everything else < 2^51.
+#define SECP_FE_FUSED_BODY(PROD)                                                                  \
+  const uint32_t R0 = FE_R0, R1 = opaque_const(FE_R1);                                            \
+  const uint32_t R0R1 = FE_R0 * FE_R1, R0R0 = FE_R0 * FE_R0, R1R1 = opaque_const(FE_R1 * FE_R1);   \
+  uint32_t U[11];                                                                                 \
+  uint64_t acc = 0;                                                                               \
+  _Pragma("unroll") for (int k = 10; k <= 18; k++) {                                              \
+    PROD(k);                                                                                      \
+    U[k - 10] = (uint32_t)acc & M26;                                                              \
+    acc >>= 26;                                                                                   \
+  }                                                                                               \
+  U[9] = (uint32_t)acc & M26; /* acc < 2^38 */                                                    \
+  U[10] = (uint32_t)(acc >> 26);                                                                  \
+  fe r;                                                                                           \
+  acc = 0;                                                                                        \
+  _Pragma("unroll") for (int k = 0; k <= 9; k++) {                                                \
+    PROD(k);                                                                                      \
+    acc += (uint64_t)U[k] * R0;                                                                   \
+    if (k >= 1) acc += (uint64_t)U[k - 1] * R1;                                                   \
+    /* limbs 10 and 11 of the first fold (U9·R1 + U10·R0, U10·R1) folded once more */             \
+    if (k == 0) acc += (uint64_t)U[9] * R0R1 + (uint64_t)U[10] * R0R0;                            \
+    if (k == 1) acc += (uint64_t)U[9] * R1R1 + (uint64_t)U[10] * (2u * R0R1);                      \
+    if (k == 2) acc += (uint64_t)U[10] * R1R1;                                                    \
+    if (k < 9) {                                                                                  \
+      r.n[k] = (uint32_t)acc & M26;                                                               \
+      acc >>= 26;                                                                                 \
+    }                                                                                             \
+  }                                                                                               \
+  /* column 9 holds bits ≥ 234: everything above bit 256 folds with 2^256 ≡ 977 + 2^6·2^26 */     \
+  uint64_t x = acc >> 22; /* < 2^42 */                                                            \
+  r.n[9] = (uint32_t)acc & M22;                                                                   \
+  uint64_t t0 = (uint64_t)r.n[0] + x * 977u;                                                      \
+  r.n[0] = (uint32_t)t0 & M26;                                                                    \
+  uint64_t t1 = (uint64_t)r.n[1] + (x << 6) + (t0 >> 26);                                         \
+  r.n[1] = (uint32_t)t1 & M26;                                                                    \
+  r.n[2] += (uint32_t)(t1 >> 26); /* ≤ 2^26 + 2^23: magnitude 1 allows it */                      \
+  return r;
+
 HD fe fe_mul_inl(const fe &a, const fe &b) {
-  uint64_t C[19];
-  mul_columns(C, a, b);
-  return fe_reduce_columns(C);
+#define SECP_PROD_MUL(k)                                              \
+  _Pragma("unroll") for (int i = 0; i < 10; i++) {                    \
+    const int j = (k)-i;                                              \
+    if (j >= 0 && j < 10) acc += (uint64_t)a.n[i] * b.n[j];           \
+  }
+  SECP_FE_FUSED_BODY(SECP_PROD_MUL)
+#undef SECP_PROD_MUL
 }
 HD fe fe_sqr_inl(const fe &a) {
-  uint64_t C[19];
-  sqr_columns(C, a);
-  return fe_reduce_columns(C);
+  uint32_t d[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) d[i] = a.n[i] << 1;  // ≤ 2^31
+#define SECP_PROD_SQR(k)                                              \
+  _Pragma("unroll") for (int i = 0; i < 10; i++) {                    \
+    const int j = (k)-i;                                              \
+    if (j >= 0 && j < 10 && i < j) acc += (uint64_t)d[i] * a.n[j];    \
+  }                                                                   \
+  if (((k)&1) == 0) acc += (uint64_t)a.n[(k) / 2] * a.n[(k) / 2];
+  SECP_FE_FUSED_BODY(SECP_PROD_SQR)
+#undef SECP_PROD_SQR
 }
 // On the device the multiply / square bodies are REAL functions (s_swappc), not inlined: the
 // fully inlined kernel was 53 k instructions (420 KB) with a 100 KB main-loop body, far beyond
