@@ -200,6 +200,17 @@ def main():
             f"verify_known_group_kernel<0,{bv.lanes_per_signature}>" if bv.lanes_per_signature > 1
             else "verify_known_lane_kernel<0>")
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
+        # the per-launch value measured with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this
+        # same command, profiles/r01_traffic.json) is attached when kernel and batch size match.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            ent = tj.get("ibftk::" + kname.replace(",", ", "))
+            if ent and ent.get("rows") == rows:
+                traffic = ent["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         rec = {
             "metric": "committed_seal_verifies_per_sec", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -212,7 +223,7 @@ def main():
             "quorum_latency_ms_p50": float(np.median(lat) * 1e3),
             "quorum_latency_ms_p50_incl_h2d": float(np.median(lat_h2d) * 1e3) if lat_h2d else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
                          "note": "integer-VALU-bound path: HBM fraction is reported as required, "
