@@ -1,0 +1,43 @@
+"""Re-entrancy: the Verifier is called concurrently from several goroutines
+(/root/reference/core/ibft.go:335-347, 1128); each caller holds its own ibft_ctx.  Four host
+threads hammer four contexts (two cold, two warm) at once and every result must equal the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_contexts(oracle):
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    rounds = [W.make_round(300 + 40 * i, 60 + i, byzantine=True, weighted=True) for i in range(4)]
+    exps = []
+    for r in rounds:
+        vs = oracle.ValSet(r.addrs, r.power)
+        exps.append(oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=4).astype(bool))
+    errors = []
+
+    def worker(i):
+        try:
+            r = rounds[i]
+            bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE if i % 2 else 0, max_rows=4096)
+            bv.set_validators(1, r.addrs, r.power)
+            for _ in range(12):
+                got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+                if not (got == exps[i]).all():
+                    errors.append((i, "verdict mismatch"))
+                h = bv.is_valid_proposal_hash(r.raw, r.round, r.hash32, r.hash_len)
+                if h.sum() != (r.hash_len == 32).sum() - sum(1 for k in r.kinds if k == "wrong_hash_field"):
+                    errors.append((i, "hash mismatch"))
+            bv.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
