@@ -234,3 +234,170 @@ bool HotPath::handleCommit(const View &view) {
 }
 
 }  // namespace ibft
+
+// ---- certificate checks ------------------------------------------------------------------------
+namespace ibft {
+
+bool HotPath::isValidValidatorCached(const IbftMessage &m) {
+  auto it = sender_verdict_.find(&m);
+  if (it != sender_verdict_.end()) return it->second;
+  return verifier->IsValidValidator(m);
+}
+
+void HotPath::prefetchSenders(const std::vector<const IbftMessage *> &msgs) {
+  sender_verdict_.clear();
+  last_cert_senders = 0;
+  if (!(use_batch && batch) || msgs.empty()) return;
+  std::vector<MsgPtr> owned;
+  owned.reserve(msgs.size());
+  for (const IbftMessage *m : msgs) owned.push_back(MsgPtr(MsgPtr(), const_cast<IbftMessage *>(m)));  // non-owning alias
+  std::vector<uint8_t> v;
+  if (!batch->VerifySenderBatch(owned, v) || v.size() != msgs.size()) return;  // device unavailable: stock path
+  for (size_t i = 0; i < msgs.size(); i++) sender_verdict_[msgs[i]] = v[i] != 0;
+  last_cert_senders = msgs.size();
+}
+
+static void collect_pc(const PreparedCertificate *pc, std::vector<const IbftMessage *> &out) {
+  if (!pc) return;
+  if (pc->proposal_message) out.push_back(pc->proposal_message.get());
+  for (auto &m : pc->prepare_messages)
+    if (m) out.push_back(m.get());
+}
+
+bool HotPath::validPC(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height) {
+  std::vector<const IbftMessage *> need;
+  collect_pc(certificate, need);
+  prefetchSenders(need);
+  bool ok = validPCImpl(certificate, roundLimit, height);
+  sender_verdict_.clear();
+  return ok;
+}
+
+bool HotPath::validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height) {
+  if (!certificate) return true;  // PCs that are not set are valid by default
+  // "either both the proposal message and the prepare messages are set together": a repeated
+  // field that is empty on the wire decodes to nil, so empty == nil here
+  if (!certificate->proposal_message || certificate->prepare_messages.empty()) return false;
+  std::vector<MsgPtr> all;
+  all.push_back(certificate->proposal_message);
+  for (auto &m : certificate->prepare_messages) all.push_back(m);
+  if (!validatorManager.HasQuorum(convertMessageToAddressSet(all))) return false;
+  if (certificate->proposal_message->type != PREPREPARE) return false;
+  for (auto &m : certificate->prepare_messages)
+    if (m->type != PREPARE) return false;
+  if (!are_valid_pc_messages(all, height, roundLimit)) return false;
+  const IbftMessage &proposal = *certificate->proposal_message;
+  if (!verifier->IsProposer(proposal.from, proposal.view->height, proposal.view->round)) return false;
+  if (!isValidValidatorCached(proposal)) return false;
+  for (auto &m : certificate->prepare_messages) {
+    if (!isValidValidatorCached(*m)) return false;
+    if (verifier->IsProposer(m->from, m->view->height, m->view->round)) return false;
+  }
+  return true;
+}
+
+bool HotPath::proposalMatchesCertificate(const Proposal *proposal, const PreparedCertificate *certificate) {
+  if (!proposal && !certificate) return true;
+  if (!certificate) return false;
+  std::vector<const bytes *> hashes;
+  // ExtractProposalHash on a nil message would panic in the reference; treat as a nil hash
+  hashes.push_back(certificate->proposal_message ? extract_proposal_hash(*certificate->proposal_message) : nullptr);
+  for (auto &m : certificate->prepare_messages) hashes.push_back(m ? extract_prepare_hash(*m) : nullptr);
+  last_cert_hashes = 0;
+  if (use_batch && batch && proposal) {
+    // one hash batch: reuse VerifyPrepareBatch's column path through synthetic PREPARE messages
+    std::vector<MsgPtr> synth;
+    for (const bytes *h : hashes) {
+      auto m = std::make_shared<IbftMessage>();
+      m->type = PREPARE;
+      if (h) {
+        m->kind = PayloadKind::PREPARE;
+        m->prepare.proposal_hash = *h;
+      }
+      synth.push_back(std::move(m));
+    }
+    std::vector<uint8_t> v;
+    if (batch->VerifyPrepareBatch(proposal, synth, v) && v.size() == synth.size()) {
+      last_cert_hashes = synth.size();
+      for (uint8_t ok : v)
+        if (!ok) return false;
+      return true;
+    }
+  }
+  for (const bytes *h : hashes)
+    if (!verifier->IsValidProposalHash(proposal, h)) return false;
+  return true;
+}
+
+bool HotPath::validateProposalCommon(const IbftMessage &msg, const View &view) {
+  const Proposal *proposal = extract_proposal(msg);
+  const bytes *proposalHash = extract_proposal_hash(msg);
+  if (!proposal) return false;  // the reference dereferences it; a nil proposal cannot be valid
+  if (proposal->round != view.round) return false;
+  if (!verifier->IsProposer(msg.from, view.height, view.round)) return false;
+  if (!verifier->IsValidProposalHash(proposal, proposalHash)) return false;
+  return verifier->IsValidProposal(proposal->raw_proposal);
+}
+
+bool HotPath::validateProposal0(const IbftMessage &msg, const View &view) {
+  if (!msg.view || msg.view->round != 0) return false;
+  if (!validateProposalCommon(msg, view)) return false;
+  if (verifier->IsProposer(verifier->ID(), view.height, view.round)) return false;
+  return true;
+}
+
+bool HotPath::validateProposal(const IbftMessage &msg, const View &view) {
+  const uint64_t height = view.height, round = view.round;
+  const Proposal *proposal = extract_proposal(msg);
+  const RoundChangeCertificate *rcc = extract_round_change_certificate(msg);
+  if (!validateProposalCommon(msg, view)) return false;
+  if (!rcc) return false;
+  std::vector<MsgPtr> rcs;
+  for (auto &m : rcc->round_change_messages)
+    if (m) rcs.push_back(m);
+  if (!has_unique_senders(rcs)) return false;
+  if (!hasQuorumByMsgType(rcs, ROUND_CHANGE)) return false;
+  if (verifier->IsProposer(verifier->ID(), height, round)) return false;
+  // batch pre-pass: every signature this walk can ask about — the RC envelopes and the messages
+  // of their prepared certificates (worst case O(N²) signatures per round change)
+  {
+    std::vector<const IbftMessage *> need;
+    for (auto &rc : rcs) {
+      need.push_back(rc.get());
+      collect_pc(extract_latest_pc(*rc), need);
+    }
+    prefetchSenders(need);
+  }
+  for (auto &rc : rcs) {
+    if (rc->type != ROUND_CHANGE) return false;
+    if (!rc->view || rc->view->height != height) return false;
+    if (rc->view->round != round) return false;
+    if (!isValidValidatorCached(*rc)) return false;
+  }
+  struct RoundHash {
+    uint64_t round;
+    const bytes *hash;
+  };
+  std::vector<RoundHash> tuples;
+  for (auto &rc : rcs) {
+    const PreparedCertificate *cert = extract_latest_pc(*rc);
+    if (cert && msg.view && validPCImpl(cert, msg.view->round, height)) {
+      tuples.push_back({cert->proposal_message->view->round, extract_proposal_hash(*cert->proposal_message)});
+    }
+  }
+  sender_verdict_.clear();
+  if (tuples.empty()) return true;
+  uint64_t maxRound = 0;
+  const bytes *expected = nullptr;
+  for (auto &t : tuples)
+    if (t.round >= maxRound) {
+      maxRound = t.round;
+      expected = t.hash;
+    }
+  Proposal p2;
+  p2.raw_proposal = proposal->raw_proposal;
+  p2.round = maxRound;
+  return verifier->IsValidProposalHash(&p2, expected);
+}
+
+}  // namespace ibft

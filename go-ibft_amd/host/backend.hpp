@@ -24,6 +24,10 @@ struct Verifier {
   virtual bool IsValidProposalHash(const Proposal *proposal, const bytes *hash) = 0;
   virtual bool IsValidCommittedSeal(const bytes *proposalHash, const CommittedSeal *seal) = 0;
   virtual bool IsValidValidator(const IbftMessage &msg) = 0;
+  // the rest of core.Verifier / Backend that the certificate checks consult (cold path, per node)
+  virtual bool IsProposer(const bytes & /*id*/, uint64_t /*height*/, uint64_t /*round*/) { return false; }  // mock default
+  virtual bool IsValidProposal(const bytes & /*rawProposal*/) { return true; }                               // mock default
+  virtual bytes ID() { return bytes(); }
 };
 
 struct BatchVerifier {
@@ -97,6 +101,28 @@ class HotPath {
   bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
   bool handlePrepare(const View &view);
   bool handleCommit(const View &view);
+  // Certificate checks (§8f rank 2), restated from core/ibft.go: validPC :1162-1231,
+  // proposalMatchesCertificate :516-551, validateProposalCommon :629-655, validateProposal0
+  // :658-680, validateProposal :683-788.  With use_batch, every IsValidValidator /
+  // IsValidProposalHash the walk can reach is answered from ONE device batch gathered up front
+  // (the predicates are pure, so evaluating verdicts the short-circuit would have skipped cannot
+  // change the result).
+  bool validPC(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);  // batches on its own when called directly
+  bool proposalMatchesCertificate(const Proposal *proposal, const PreparedCertificate *certificate);
+  bool validateProposalCommon(const IbftMessage &msg, const View &view);
+  bool validateProposal0(const IbftMessage &msg, const View &view);
+  bool validateProposal(const IbftMessage &msg, const View &view);
+  // number of sender signatures / hashes the last batched certificate check sent to the device
+  size_t last_cert_senders = 0, last_cert_hashes = 0;
+
+ private:
+  // verdict tables filled by the batch pre-pass; empty = ask the per-message verifier
+  std::map<const IbftMessage *, bool> sender_verdict_;
+  bool isValidValidatorCached(const IbftMessage &m);
+  bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
+  void prefetchSenders(const std::vector<const IbftMessage *> &msgs);
+
+ public:
 };
 
 }  // namespace ibft

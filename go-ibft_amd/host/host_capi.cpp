@@ -32,6 +32,16 @@ struct CallbackVerifier : Verifier {
     bytes w = encode(m);
     return cb.is_valid_validator(cb.user, (const uint8_t *)w.data(), w.size()) != 0;
   }
+  bool IsProposer(const bytes &id, uint64_t height, uint64_t round) override {
+    if (!cb.is_proposer) return false;
+    return cb.is_proposer(cb.user, (const uint8_t *)id.data(), id.size(), height, round) != 0;
+  }
+  bool IsValidProposal(const bytes &raw) override {
+    if (!cb.is_valid_proposal) return true;
+    return cb.is_valid_proposal(cb.user, (const uint8_t *)raw.data(), raw.size()) != 0;
+  }
+  bytes ID() override { return id; }
+  bytes id;
 };
 
 void pack_bytes(bytes &o, const bytes &item) {
@@ -254,6 +264,9 @@ int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len
     bool IsValidProposalHash(const Proposal *p, const bytes *hsh) override { return inner->IsValidProposalHash(p, hsh); }
     bool IsValidCommittedSeal(const bytes *hsh, const CommittedSeal *s) override { return inner->IsValidCommittedSeal(hsh, s); }
     bool IsValidValidator(const IbftMessage &) override { return verdict; }
+    bool IsProposer(const bytes &id, uint64_t hh, uint64_t rr) override { return inner->IsProposer(id, hh, rr); }
+    bool IsValidProposal(const bytes &raw) override { return inner->IsValidProposal(raw); }
+    bytes ID() override { return inner->ID(); }
   } tv;
   tv.inner = h->hp.verifier;
   Verifier *saved = h->hp.verifier;
@@ -264,6 +277,36 @@ int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len
   }
   h->hp.verifier = saved;
   return 0;
+}
+
+void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len) { h->cbv.id.assign((const char *)id, len); }
+int ibft_host_valid_pc(ibft_host *h, const uint8_t *pc_wire, size_t len, uint64_t round_limit, uint64_t height) {
+  if (!pc_wire) return h->hp.validPC(nullptr, round_limit, height) ? 1 : 0;
+  PreparedCertificate pc;
+  if (!decode(pc_wire, len, pc)) return -1;
+  return h->hp.validPC(&pc, round_limit, height) ? 1 : 0;
+}
+int ibft_host_proposal_matches_certificate(ibft_host *h, const uint8_t *proposal_wire, size_t plen,
+                                           const uint8_t *pc_wire, size_t clen) {
+  Proposal p;
+  PreparedCertificate pc;
+  if (proposal_wire && !decode(proposal_wire, plen, p)) return -1;
+  if (pc_wire && !decode(pc_wire, clen, pc)) return -1;
+  return h->hp.proposalMatchesCertificate(proposal_wire ? &p : nullptr, pc_wire ? &pc : nullptr) ? 1 : 0;
+}
+int ibft_host_validate_proposal0(ibft_host *h, const uint8_t *msg_wire, size_t len, uint64_t height, uint64_t round) {
+  IbftMessage m;
+  if (!decode(msg_wire, len, m)) return -1;
+  return h->hp.validateProposal0(m, View{height, round, {}}) ? 1 : 0;
+}
+int ibft_host_validate_proposal(ibft_host *h, const uint8_t *msg_wire, size_t len, uint64_t height, uint64_t round) {
+  IbftMessage m;
+  if (!decode(msg_wire, len, m)) return -1;
+  return h->hp.validateProposal(m, View{height, round, {}}) ? 1 : 0;
+}
+void ibft_host_last_cert_batch(ibft_host *h, size_t *senders, size_t *hashes) {
+  if (senders) *senders = h->hp.last_cert_senders;
+  if (hashes) *hashes = h->hp.last_cert_hashes;
 }
 
 int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared) {

@@ -394,6 +394,14 @@ bool decode(const uint8_t *p, size_t n, IbftMessage &out) {
   out = IbftMessage{};
   return decode_msg(p, n, out, 0);
 }
+bool decode(const uint8_t *p, size_t n, PreparedCertificate &out) {
+  out = PreparedCertificate{};
+  return decode_pc(p, n, out, 0);
+}
+bool decode(const uint8_t *p, size_t n, Proposal &out) {
+  out = Proposal{};
+  return decode_proposal(p, n, out);
+}
 
 // ---- Extract* ------------------------------------------------------------------------------
 const bytes *extract_commit_hash(const IbftMessage &m) {

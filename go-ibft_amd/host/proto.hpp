@@ -92,6 +92,8 @@ bytes encode(const RoundChangeCertificate &rcc);
 // ---- wire decoding (what proto.Unmarshal does for these messages) -------------------------
 // Returns false on malformed input (truncated varint/length, bad wire type for a known field).
 bool decode(const uint8_t *p, size_t n, IbftMessage &out);
+bool decode(const uint8_t *p, size_t n, PreparedCertificate &out);
+bool decode(const uint8_t *p, size_t n, Proposal &out);
 
 // ---- messages/helpers.go Extract* ------------------------------------------------------------
 // A null pointer return mirrors a nil []byte / nil pointer in the reference.

@@ -45,9 +45,14 @@ MSG_PRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 RCC_PRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_size_t)
 
 
+PROPOSER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.c_uint64, C.c_uint64)
+VALID_PROPOSAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+
+
 class VerifierCB(C.Structure):
     _fields_ = [("is_valid_proposal_hash", PROP_HASH_FN), ("is_valid_committed_seal", SEAL_FN),
-                ("is_valid_validator", VALIDATOR_FN), ("user", C.c_void_p)]
+                ("is_valid_validator", VALIDATOR_FN), ("user", C.c_void_p),
+                ("is_proposer", PROPOSER_FN), ("is_valid_proposal", VALID_PROPOSAL_FN)]
 
 
 _lib = None
@@ -84,6 +89,12 @@ def lib() -> C.CDLL:
         L.ibft_host_enable_quorum_index.argtypes = [vp]
         L.ibft_host_add_message_fast.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.ibft_host_add_messages_batch.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.ibft_host_set_id.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.ibft_host_valid_pc.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]
+        L.ibft_host_proposal_matches_certificate.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.ibft_host_validate_proposal0.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]
+        L.ibft_host_validate_proposal.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]
+        L.ibft_host_last_cert_batch.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.ibft_host_handle_prepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         L.ibft_host_handle_commit.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         _lib = L
@@ -213,7 +224,8 @@ class Host:
     def set_state(self, height, round_, proposal_wire: bytes | None):
         return self.L.ibft_host_set_state(self.h, height, round_, proposal_wire, len(proposal_wire or b""))
 
-    def set_verifier(self, is_valid_proposal_hash=None, is_valid_committed_seal=None, is_valid_validator=None):
+    def set_verifier(self, is_valid_proposal_hash=None, is_valid_committed_seal=None, is_valid_validator=None,
+                     is_proposer=None, is_valid_proposal=None):
         """Callbacks receive Python values; None arguments mirror Go nils."""
         def ph(u, hp, raw, rl, rnd, hh, hsh, hl):
             prop = (C.string_at(raw, rl) if rl else b"", rnd) if hp else None
@@ -226,9 +238,17 @@ class Host:
         def vv(u, p, n):
             return int(bool(is_valid_validator(C.string_at(p, n))))
 
+        def ip(u, p, n, hh, rr):
+            return int(bool(is_proposer(C.string_at(p, n) if n else b"", hh, rr)))
+
+        def vpr(u, p, n):
+            return int(bool(is_valid_proposal(C.string_at(p, n) if n else b"")))
+
         cb = VerifierCB(PROP_HASH_FN(ph) if is_valid_proposal_hash else PROP_HASH_FN(),
                         SEAL_FN(sl) if is_valid_committed_seal else SEAL_FN(),
-                        VALIDATOR_FN(vv) if is_valid_validator else VALIDATOR_FN(), None)
+                        VALIDATOR_FN(vv) if is_valid_validator else VALIDATOR_FN(), None,
+                        PROPOSER_FN(ip) if is_proposer else PROPOSER_FN(),
+                        VALID_PROPOSAL_FN(vpr) if is_valid_proposal else VALID_PROPOSAL_FN())
         self._keep.append(cb)
         self.L.ibft_host_set_verifier(self.h, C.byref(cb))
 
@@ -257,6 +277,28 @@ class Host:
         if rc != 0:
             raise RuntimeError(f"ibft_host_add_messages_batch rc={rc}")
         return list(res.raw)
+
+    # --- certificate checks (core/ibft.go: validPC, proposalMatchesCertificate, validateProposal*)
+    def set_id(self, node_id: bytes):
+        self.L.ibft_host_set_id(self.h, node_id, len(node_id))
+
+    def valid_pc(self, pc_wire, round_limit: int, height: int) -> bool:
+        return self.L.ibft_host_valid_pc(self.h, pc_wire, len(pc_wire or b""), round_limit, height) == 1
+
+    def proposal_matches_certificate(self, proposal_wire, pc_wire) -> bool:
+        return self.L.ibft_host_proposal_matches_certificate(self.h, proposal_wire, len(proposal_wire or b""),
+                                                             pc_wire, len(pc_wire or b"")) == 1
+
+    def validate_proposal0(self, msg_wire: bytes, height: int, round_: int) -> bool:
+        return self.L.ibft_host_validate_proposal0(self.h, msg_wire, len(msg_wire), height, round_) == 1
+
+    def validate_proposal(self, msg_wire: bytes, height: int, round_: int) -> bool:
+        return self.L.ibft_host_validate_proposal(self.h, msg_wire, len(msg_wire), height, round_) == 1
+
+    def last_cert_batch(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self.L.ibft_host_last_cert_batch(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def handle_prepare(self, height, round_):
         b = Buf()

@@ -41,6 +41,10 @@ typedef struct {
                                  const uint8_t *sig, size_t sig_len);
   int (*is_valid_validator)(void *user, const uint8_t *wire, size_t len);
   void *user;
+  /* consulted by the certificate checks only; NULL = mock defaults (IsProposer false,
+   * IsValidProposal true), core/mock_test.go:105-151 */
+  int (*is_proposer)(void *user, const uint8_t *id, size_t id_len, uint64_t height, uint64_t round);
+  int (*is_valid_proposal)(void *user, const uint8_t *raw, size_t raw_len);
 } ibft_host_verifier;
 
 typedef int (*ibft_host_msg_pred)(void *user, const uint8_t *wire, size_t len);
@@ -96,6 +100,17 @@ int ibft_host_add_message_fast(ibft_host *h, const uint8_t *wire, size_t len);
 /* Batched ingest: IsValidValidator for many messages in one device call,
  * then the same store/probe logic per accepted message; results[i] as above. */
 int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n);
+/* Certificate checks (core/ibft.go: validPC :1162-1231, proposalMatchesCertificate :516-551,
+ * validateProposal0 :658-680, validateProposal :683-788).  NULL wire pointers are Go nils.  With
+ * ibft_host_use_batch(1) and a GPU attached, all sender signatures / hashes of the certificate go
+ * to the device in one batch; ibft_host_last_cert_batch reports how many.  Return 1/0, -1 = undecodable. */
+void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len);
+int ibft_host_valid_pc(ibft_host *h, const uint8_t *pc_wire, size_t len, uint64_t round_limit, uint64_t height);
+int ibft_host_proposal_matches_certificate(ibft_host *h, const uint8_t *proposal_wire, size_t plen,
+                                           const uint8_t *pc_wire, size_t clen);
+int ibft_host_validate_proposal0(ibft_host *h, const uint8_t *msg_wire, size_t len, uint64_t height, uint64_t round);
+int ibft_host_validate_proposal(ibft_host *h, const uint8_t *msg_wire, size_t len, uint64_t height, uint64_t round);
+void ibft_host_last_cert_batch(ibft_host *h, size_t *senders, size_t *hashes);
 /* handlePrepare / handleCommit (core/ibft.go:855-889, 931-967): 1 = quorum reached */
 int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared);
 int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals);

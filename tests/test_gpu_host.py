@@ -132,3 +132,75 @@ def test_batched_ingest_equals_per_message(gpu_verifier, oracle):
     assert stock == batched
     assert 0 in stock and 2 in stock          # some rejected senders, and the quorum signal fired
     assert h1.store_num(r.height, r.round, 2) == h2.store_num(r.height, r.round, 2)
+
+
+def test_round_change_certificate_batch_equals_stock(gpu_verifier, oracle):
+    """§8f rank 2: validateProposal on a PREPREPARE for round 1 whose RoundChangeCertificate holds a
+    quorum of ROUND-CHANGE messages, each carrying a PreparedCertificate (proposal + quorum of
+    PREPAREs) — O(N²) nested signatures.  Batch mode sends all of them to the device in ONE call and
+    must decide like the stock per-message walk (oracle-backed Verifier), for a valid certificate
+    and for single corrupted signatures at every nesting level."""
+    import go_ibft_amd.hostlib as H
+    from oracle import wire as W, workload as WL
+    n = 40
+    r = WL.make_round(n, 2024)
+    addrs = [r.addrs[i].tobytes() for i in range(n)]
+    quorum = 2 * n // 3 + 1
+    raw = r.raw
+    proposer = lambda rnd: addrs[rnd % n]
+
+    def signed(m, i):
+        m.signature = oracle.sign(r.sks[i], oracle.keccak256(m.payload_no_sig()))
+        return m
+    h0 = oracle.proposal_hash(raw, 0)
+    pp0 = signed(W.IbftMessage(view=W.View(1, 0), sender=addrs[0], type=W.PREPREPARE,
+                               payload=W.preprepare_body(W.Proposal(raw, 0), h0, None)), 0)
+    prepares0 = [signed(W.IbftMessage(view=W.View(1, 0), sender=addrs[i], type=W.PREPARE, payload=W.prepare_body(h0)), i)
+                 for i in range(1, quorum)]
+
+    def build(corrupt=None):
+        prs = list(prepares0)
+        pp = pp0
+        if corrupt == "nested_prepare":
+            bad = W.IbftMessage(view=W.View(1, 0), sender=addrs[5], type=W.PREPARE, payload=W.prepare_body(h0))
+            bad.signature = prepares0[5].signature      # someone else's signature
+            prs[4] = bad
+        if corrupt == "nested_proposal":
+            pp = W.IbftMessage(view=W.View(1, 0), sender=addrs[0], type=W.PREPREPARE,
+                               payload=W.preprepare_body(W.Proposal(raw, 0), h0, None), signature=prepares0[0].signature)
+        pc = W.prepared_certificate(pp, prs)
+        rcs = []
+        for i in range(quorum):
+            m = W.IbftMessage(view=W.View(1, 1), sender=addrs[i + 2], type=W.ROUND_CHANGE,
+                              payload=W.round_change_body(W.Proposal(raw, 0), pc))
+            signed(m, i + 2)
+            if corrupt == "rc_envelope" and i == 7:
+                m.signature = bytes(65)
+            rcs.append(m)
+        h1 = oracle.proposal_hash(raw, 0)            # hash of (raw, maxRound = 0) is what round 1 must carry
+        top = W.IbftMessage(view=W.View(1, 1), sender=proposer(1), type=W.PREPREPARE,
+                            payload=W.preprepare_body(W.Proposal(raw, 1), oracle.proposal_hash(raw, 1),
+                                                      W.round_change_certificate(rcs)))
+        return signed(top, 1).encode(), h1
+
+    gpu_verifier.set_validators(1, r.addrs, r.power)
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    powers = {a: 1 for a in addrs}
+    for corrupt, expect in ((None, True), ("rc_envelope", False), ("nested_prepare", True), ("nested_proposal", True)):
+        # a bad signature inside ONE rc's PC only invalidates that PC (validPC false -> PC ignored); with all
+        # PCs identical every PC is dropped, no (round, hash) tuple remains and the proposal is accepted
+        wire, _ = build(corrupt)
+        out = []
+        for batch in (False, True):
+            h = H.Host()
+            assert h.vm_init(powers)
+            h.set_id(addrs[n - 1])
+            h.set_verifier(f1, f2, f3, is_proposer=lambda who, hh, rr: who == proposer(rr))
+            h.attach_gpu(gpu_verifier)
+            h.use_batch(batch)
+            out.append(h.validate_proposal(wire, 1, 1))
+            if batch:
+                senders, _ = h.last_cert_batch()
+                assert senders == quorum + quorum * (1 + len(prepares0))      # every nested signature, one batch
+            h.close()
+        assert out[0] == out[1] == expect, (corrupt, out)
