@@ -4,17 +4,22 @@
 // columns; each kernel replaces the per-message callback loop of
 // /root/reference/messages/messages.go:183-191.
 //
-//   hash_eq_kernel        a1  IsValidProposalHash   (core/ibft.go:858-861, 938)
-//   proposal_hash_kernel      keccak256(raw ‖ BE64(round)), once per batch
-//   ecrecover_lane_kernel a2  IsValidCommittedSeal  (core/ibft.go:943)
-//                         a3  IsValidValidator      (core/ibft.go:1128)
-//   tally_kernel          a8  HasQuorum             (core/validator_manager.go:77-96)
-//   gtab_build_kernel         one-time fixed-base table for G
+//   hash_eq_kernel              a1  IsValidProposalHash   (core/ibft.go:858-861, 938)
+//   proposal_hash_kernel            keccak256(raw ‖ BE64(round)), once per batch
+//   ecrecover_lane_kernel       a2  IsValidCommittedSeal  (core/ibft.go:943)      cold path,
+//   ecrecover_group_kernel<G>   a3  IsValidValidator      (core/ibft.go:1128)     1 / 2,4,8 lanes per signature
+//   verify_known_lane_kernel    a2/a3 against the validator's known key (warm path), 1 lane per signature
+//   verify_known_group_kernel<G>    same, G = 2..64 lanes per signature (64 = one wavefront per signature)
+//   tally_kernel                a8  HasQuorum             (core/validator_manager.go:77-96)
+//   gtab_build_kernel, qtab_build_kernel, qtab_commit_kernel   one-time fixed-base tables
+//   lookup_kernel                   sender → validator index for ibft_tally()
 //
-// Layout in HBM: one contiguous byte column per field (hash N×32, sig N×65,
-// signer N×20, pre_flags N) — structure-of-arrays at field granularity.  A block
-// stages its 64 rows through LDS with coalesced dword loads, then every lane
-// unpacks its own row into 32-bit limbs held in VGPRs.
+// Layout in HBM: one contiguous byte column per field (hash N×32, sig N×65, signer N×20,
+// pre_flags N) — structure-of-arrays at field granularity.  The lane kernels stage a block's
+// 64 rows through LDS with coalesced dword loads and each lane unpacks its own row into limbs held
+// in VGPRs; the group kernels read their row directly (the G lanes of a group share the address).
+// Rule for every kernel here: no call to an outlined device function under a partial EXEC mask
+// (see secp256k1_dev.h:wave_any) — idle lanes compute on dummy operands and skip only stores.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -50,10 +50,23 @@ type Tally struct {
 // goroutines of core/ibft.go:335-347 each hold their own (a sync.Pool works well).
 type Ctx struct{ h *C.ibft_ctx }
 
-func New(device int, maxRows uint32, strictLowS bool) (*Ctx, error) {
-	cfg := C.ibft_cfg{device: C.int32_t(device), max_rows: C.uint32_t(maxRows)}
-	if strictLowS {
-		cfg.flags = C.IBFT_FLAG_STRICT_LOW_S
+// Options mirrors ibft_cfg.  KeyCache turns on the warm path (IBFT_FLAG_PUBKEY_CACHE): the
+// first valid signature of a validator teaches the device its public key, later ones are verified
+// against a per-validator table in HBM (655 KB per validator) — identical verdicts, 4-10x less work.
+type Options struct {
+	Device     int
+	MaxRows    uint32
+	StrictLowS bool
+	KeyCache   bool
+}
+
+func New(o Options) (*Ctx, error) {
+	cfg := C.ibft_cfg{device: C.int32_t(o.Device), max_rows: C.uint32_t(o.MaxRows)}
+	if o.StrictLowS {
+		cfg.flags |= C.IBFT_FLAG_STRICT_LOW_S
+	}
+	if o.KeyCache {
+		cfg.flags |= C.IBFT_FLAG_PUBKEY_CACHE
 	}
 	var h *C.ibft_ctx
 	if rc := C.ibft_ctx_create(&cfg, &h); rc != C.IBFT_OK {
