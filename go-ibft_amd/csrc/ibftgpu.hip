@@ -507,11 +507,10 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
   return fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
 }
 
-int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
-                     const uint8_t *pre_flags, size_t n) {
-  if (!c || (n && (!hash32 || !sig65 || !signer20))) return IBFT_E_INVAL;
+static int seals_stage_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                              const uint8_t *pre_flags, size_t n) {
+  if (n && (!hash32 || !sig65 || !signer20)) return IBFT_E_INVAL;
   if (n > c->max_rows) return IBFT_E_TOOBIG;
-  std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
@@ -524,10 +523,15 @@ int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, c
   return IBFT_OK;
 }
 
-int ibft_seals_launch(ibft_ctx *c, uint32_t repeat) {
+int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                     const uint8_t *pre_flags, size_t n) {
   if (!c) return IBFT_E_INVAL;
-  if (!c->have_valset) return IBFT_E_NOVALSET;
   std::lock_guard<std::mutex> lk(c->mu);
+  return seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n);
+}
+
+static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
+  if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
   c->ev_used = 0;
   if (repeat == 0) repeat = 1;
@@ -537,6 +541,12 @@ int ibft_seals_launch(ibft_ctx *c, uint32_t repeat) {
     if ((rc = enqueue_tally(c, c->staged_n))) return rc;
   }
   return IBFT_OK;
+}
+
+int ibft_seals_launch(ibft_ctx *c, uint32_t repeat) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return seals_launch_locked(c, repeat);
 }
 
 int ibft_seals_fetch(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
@@ -611,11 +621,12 @@ int ibft_sync(ibft_ctx *c) {
 int ibft_verify_seals(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
                       const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c || (n && !out_mask)) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);  // one critical section: stage + launch + fetch
   if (!c->have_valset) return IBFT_E_NOVALSET;
   int rc;
-  if ((rc = ibft_seals_stage(c, hash32, sig65, signer20, pre_flags, n))) return rc;
-  if ((rc = ibft_seals_launch(c, 1))) return rc;
-  return ibft_seals_fetch(c, out_mask, tally);
+  if ((rc = seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n))) return rc;
+  if ((rc = seals_launch_locked(c, 1))) return rc;
+  return fetch_results(c, c->staged_n, out_mask, tally, true);
 }
 
 int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,

@@ -381,29 +381,49 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
       base = secp::jac_select(piece >= (uint32_t)j && piece == (uint32_t)j, run, base);
     }
   }
-  // per-lane table of 1..15 multiples of the base (Jacobian)
-  jac tab[16];
-  tab[0] = secp::jac_inf();
-  tab[1] = base;
-  tab[2] = secp::jac_dbl(base);
-#pragma unroll 1
-  for (int i = 3; i < 16; i++) tab[i] = secp::jac_add(tab[i - 1], base);
-  // this lane's scalar piece
+  // per-lane window table over the base (Jacobian).  G = 8 (32-bit pieces): 2-bit windows, the three
+  // entries {B, 2B, 3B} live in VGPRs and are picked with selects — no scratch traffic at all
+  // (the 4-bit table is 1.9 KB per lane in scratch: 16 MB written + re-read per launch at
+  // N = 1024, G = 8).  G = 2, 4 (128/64-bit pieces): 4-bit windows, table in scratch.
+  constexpr int WBITS = (G == 8) ? 2 : 4;
+  constexpr int DIGITS = PIECE_BITS / WBITS;
   const u256 &kk = half ? sp.k2 : sp.k1;
   const bool flip = half && (sp.neg1 != sp.neg2);
   const secp::fe beta = secp::GLV_CONST(1);
   jac acc = secp::jac_inf();
+  if (WBITS == 2) {
+    const jac b1 = base, b2 = secp::jac_dbl(base), b3 = secp::jac_add(b2, base);
 #pragma unroll 1
-  for (int nib = NIBS - 1; nib >= 0; nib--) {
+    for (int dgi = DIGITS - 1; dgi >= 0; dgi--) {
+      acc = secp::jac_dbl(secp::jac_dbl(acc));
+      const int bit = (int)(piece * PIECE_BITS) + 2 * dgi;
+      const uint32_t dg = (kk.v[bit >> 5] >> (bit & 31)) & 3u;
+      jac q = secp::jac_select(dg == 1, b1, secp::jac_select(dg == 2, b2, b3));
+      secp::fe bx = secp::fe_mul(q.x, beta);
+      q.x = secp::l26_select(half != 0, bx, q.x);
+      q.y = secp::l26_select(flip, secp::fe_neg(q.y, 1), q.y);
+      jac sum = secp::jac_add(acc, q);
+      acc = secp::jac_select(dg != 0, sum, acc);
+    }
+  } else {
+    jac tab[16];
+    tab[0] = secp::jac_inf();
+    tab[1] = base;
+    tab[2] = secp::jac_dbl(base);
 #pragma unroll 1
-    for (int d = 0; d < 4; d++) acc = secp::jac_dbl(acc);
-    const uint32_t dg = secp::nibble(kk, (int)(piece * NIBS) + nib);
-    jac q = tab[dg];
-    secp::fe bx = secp::fe_mul(q.x, beta);
-    q.x = secp::l26_select(half != 0, bx, q.x);
-    q.y = secp::l26_select(flip, secp::fe_neg(q.y, 1), q.y);
-    jac sum = secp::jac_add(acc, q);
-    acc = secp::jac_select(dg != 0, sum, acc);
+    for (int i = 3; i < 16; i++) tab[i] = secp::jac_add(tab[i - 1], base);
+#pragma unroll 1
+    for (int nib = NIBS - 1; nib >= 0; nib--) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) acc = secp::jac_dbl(acc);
+      const uint32_t dg = secp::nibble(kk, (int)(piece * NIBS) + nib);
+      jac q = tab[dg];
+      secp::fe bx = secp::fe_mul(q.x, beta);
+      q.x = secp::l26_select(half != 0, bx, q.x);
+      q.y = secp::l26_select(flip, secp::fe_neg(q.y, 1), q.y);
+      jac sum = secp::jac_add(acc, q);
+      acc = secp::jac_select(dg != 0, sum, acc);
+    }
   }
   // u1·G: the fixed-base windows are dealt to the lanes of the group
 #pragma unroll 1

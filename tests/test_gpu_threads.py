@@ -41,3 +41,34 @@ def test_concurrent_contexts(oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_one_context_shared_by_threads(oracle):
+    """A single ibft_ctx used from several threads: calls serialise on the context mutex
+    (ibft_verify_seals is one critical section) and still return oracle-exact verdicts."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    r = W.make_round(500, 71, byzantine=True)
+    vs = oracle.ValSet(r.addrs, r.power)
+    exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=4).astype(bool)
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=4096)
+    bv.set_validators(1, r.addrs, r.power)
+    errors = []
+
+    def worker(k):
+        try:
+            for j in range(10):
+                lo = (37 * (k + j)) % 300
+                got, _ = bv.is_valid_committed_seal(r.hash32[lo:lo + 200], r.seal65[lo:lo + 200],
+                                                    r.signer20[lo:lo + 200], r.pre_flags[lo:lo + 200])
+                if not (got == exp[lo:lo + 200]).all():
+                    errors.append((k, j))
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    bv.close()
+    assert not errors, errors
