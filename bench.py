@@ -202,13 +202,16 @@ def main():
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
         # the per-launch value measured with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this
-        # same command, profiles/r01_traffic.json) is attached when kernel and batch size match.
+        # same command by tools/profile.sh, newest profiles/r*_traffic.json) is attached when kernel and batch size match.
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            ent = tj.get("ibftk::" + kname.replace(",", ", "))
-            if ent and ent.get("rows") == rows:
-                traffic = ent["hbm_bytes_per_launch"]
+            import glob
+            needle = "ibftk::" + kname.replace(",", ", ")
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+                ent = next((v for k, v in json.load(open(path)).items() if needle in k), None)
+                if ent and ent.get("rows") == rows:
+                    traffic = ent["hbm_bytes_per_launch"]
+                    break
         except (OSError, ValueError):
             pass
         rec = {
