@@ -10,6 +10,7 @@ LIB = os.path.join(CSRC, "libibftgpu.so")
 SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h",
            os.path.join("..", "..", "include", "ibftgpu.h")]
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
+WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
 
 
 def _stale(target: str, deps: list[str]) -> bool:
@@ -35,7 +36,7 @@ DEVTEST = os.path.join(CSRC, "libibft_devtest.so")
 
 def build_devtest(force: bool = False) -> str:
     """TEST-ONLY: single arithmetic primitives as gfx950 kernels (tests/test_gpu_arith.py)."""
-    deps = ["devtest.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
+    deps = ["devtest.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h", "wave_fe_dev.h", "verify_dev.h"]
     if force or _stale(DEVTEST, deps):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-w",
                                "-o", DEVTEST, os.path.join(CSRC, "devtest.hip")], cwd=CSRC)
@@ -49,6 +50,16 @@ def build_host_harness(force: bool = False) -> str:
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
                                "-o", HOST_HARNESS, os.path.join(CSRC, "host_arith_harness.hip")], cwd=CSRC)
     return HOST_HARNESS
+
+
+def build_wave_harness(force: bool = False) -> str:
+    """TEST-ONLY: wave_fe_dev.h (one wavefront per signature) on the CPU through wave_emul.h."""
+    deps = ["host_wave_harness.hip", "wave_fe_dev.h", "wave_emul.h", "recover_dev.h", "verify_dev.h",
+            "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
+    if force or _stale(WAVE_HARNESS, deps):
+        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
+                               "-o", WAVE_HARNESS, os.path.join(CSRC, "host_wave_harness.hip")], cwd=CSRC)
+    return WAVE_HARNESS
 
 
 if __name__ == "__main__":

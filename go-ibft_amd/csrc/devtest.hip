@@ -137,3 +137,103 @@ extern "C" int devtest_run(int op, int n, const uint8_t *a, const uint8_t *b, ui
   hipFree(da); hipFree(db); hipFree(dout);
   return rc;
 }
+
+// ---- wave_fe_dev.h primitives (one wavefront per job; same op numbers as host_wave_harness.hip) ----
+#include "wave_fe_dev.h"
+
+__global__ void __launch_bounds__(64) devtest_wave_fe_kernel(int op, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+  const wv::wk k = wv::wk_init();
+  const uint32_t *ja = a + 40 * blockIdx.x, *jb = b + 40 * blockIdx.x;
+  const uint32_t x = k.li < 10 ? ja[k.row * 10 + k.li] : 0u;
+  const uint32_t y = k.li < 10 ? jb[k.row * 10 + k.li] : 0u;
+  uint32_t r = 0;
+  switch (op) {  // wave-uniform
+    case 0: r = wv::wfe_mul(x, y, k); break;
+    case 1: r = wv::wfe_weak(x, k); break;
+    case 2: r = wv::wfe_neg1(x, k) + y; break;
+    case 3: r = wv::wfe_neg2(x, k) + y; break;
+    case 4: r = wv::wfe_neg8(x, k) + y; break;
+    case 5: r = wv::wfe_sqrt_candidate(x, k); break;
+    case 6: r = wv::scatter(wv::gather(x), k); break;
+    case 7: r = wv::wfe_is_zero(x) ? 1u : 0u; break;
+  }
+  out[64 * blockIdx.x + threadIdx.x] = r;
+}
+__device__ __forceinline__ wv::wjac devtest_load_pt(const uint32_t *src, const wv::wk &k) {
+  const uint32_t *r = src + 31 * k.row;
+  wv::wjac p;
+  p.x = k.li < 10 ? r[k.li] : 0u;
+  p.y = k.li < 10 ? r[10 + k.li] : 0u;
+  p.z = k.li < 10 ? r[20 + k.li] : 0u;
+  p.inf = r[30] != 0;
+  return p;
+}
+__global__ void __launch_bounds__(64) devtest_wave_pt_kernel(int op, const uint32_t *pp, const uint32_t *qq, uint32_t *out) {
+  const wv::wk k = wv::wk_init();
+  wv::wjac p = devtest_load_pt(pp + 124 * blockIdx.x, k), q = devtest_load_pt(qq + 124 * blockIdx.x, k), r;
+  switch (op) {
+    case 0: r = wv::wjac_dbl(p, k); break;
+    case 1: r = wv::wjac_add(p, q, k); break;
+    case 2: r = wv::wjac_add_aff(p, wv::waff{q.x, q.y}, k); break;
+    default: r = wv::wjac_add(p, wv::wjac_lane_xor(p, 16), k); break;
+  }
+  uint32_t *o = out + 124 * blockIdx.x + 31 * k.row;
+  if (k.li < 10) {
+    o[k.li] = r.x;
+    o[10 + k.li] = r.y;
+    o[20 + k.li] = r.z;
+  }
+  if (k.li == 0) o[30] = r.inf ? 1u : 0u;
+}
+// one wavefront per signature; out: [n][64][24] bytes = every lane's 20-byte address + ok flag
+__global__ void __launch_bounds__(64) devtest_wave_recover_kernel(const uint32_t *gtab, const uint8_t *dig, const uint8_t *sig65,
+                                                                uint32_t flags, uint8_t *out) {
+  const int i = blockIdx.x;
+  uint32_t addr[5];
+  aff Q;
+  bool ok = wv::recover_pubkey_wave(gtab, from_be32(dig + 32 * i), from_be32(sig65 + 65 * i), from_be32(sig65 + 65 * i + 32),
+                                    sig65[65 * i + 64], flags, addr, Q);
+  uint8_t *o = out + (size_t)24 * (64 * i + threadIdx.x);
+  for (int k = 0; k < 5; k++) reinterpret_cast<uint32_t *>(o)[k] = addr[k];
+  o[20] = ok ? 1 : 0;
+}
+
+template <typename T>
+static T *dev_copy(const T *h, size_t n) {
+  T *d = nullptr;
+  if (hipMalloc(&d, n * sizeof(T)) != hipSuccess) return nullptr;
+  (void)hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice);
+  return d;
+}
+extern "C" int devtest_wave_fe(int op, int jobs, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+  uint32_t *da = dev_copy(a, (size_t)40 * jobs), *db = dev_copy(b, (size_t)40 * jobs), *dout;
+  if (!da || !db || hipMalloc(&dout, (size_t)256 * jobs) != hipSuccess) return -1;
+  devtest_wave_fe_kernel<<<jobs, 64>>>(op, da, db, dout);
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  (void)hipMemcpy(out, dout, (size_t)256 * jobs, hipMemcpyDeviceToHost);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return rc;
+}
+extern "C" int devtest_wave_pt(int op, int jobs, const uint32_t *p, const uint32_t *q, uint32_t *out) {
+  uint32_t *dp = dev_copy(p, (size_t)124 * jobs), *dq = dev_copy(q, (size_t)124 * jobs), *dout;
+  if (!dp || !dq || hipMalloc(&dout, (size_t)496 * jobs) != hipSuccess) return -1;
+  (void)hipMemset(dout, 0, (size_t)496 * jobs);
+  devtest_wave_pt_kernel<<<jobs, 64>>>(op, dp, dq, dout);
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  (void)hipMemcpy(out, dout, (size_t)496 * jobs, hipMemcpyDeviceToHost);
+  (void)hipFree(dp); (void)hipFree(dq); (void)hipFree(dout);
+  return rc;
+}
+extern "C" int devtest_wave_recover(int n, const uint8_t *dig, const uint8_t *sig65, uint32_t flags, uint8_t *out) {
+  uint32_t *dg;
+  size_t gbytes = (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4;
+  if (hipMalloc(&dg, gbytes) != hipSuccess) return -1;
+  uint8_t *dd = dev_copy(dig, (size_t)32 * n), *ds = dev_copy(sig65, (size_t)65 * n), *dout;
+  if (!dd || !ds || hipMalloc(&dout, (size_t)24 * 64 * n) != hipSuccess) return -1;
+  devtest_gtab_kernel<<<(ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES + 63) / 64, 64>>>(dg);
+  devtest_wave_recover_kernel<<<n, 64>>>(dg, dd, ds, flags, dout);
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  (void)hipMemcpy(out, dout, (size_t)24 * 64 * n, hipMemcpyDeviceToHost);
+  (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
+  return rc;
+}

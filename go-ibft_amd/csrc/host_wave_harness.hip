@@ -1,0 +1,121 @@
+// host_wave_harness.hip — TEST-ONLY: runs wave_fe_dev.h (one wavefront per signature, limbs spread
+// over lanes with DPP) on the CPU through the 64-coroutine lockstep emulator in wave_emul.h, so
+// tests/test_dev_wave_host.py can check the exact kernel source in this GPU-less container.
+// Built with hipcc's host pass; never linked into libibftgpu.so, never a fallback.
+#define IBFT_GTAB_BITS 8
+#define IBFT_WAVE_EMUL 1
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "wave_fe_dev.h"
+
+using secp::u256;
+
+static std::vector<uint32_t> g_gtab;
+
+namespace {
+
+// limbs in / out: [row][10] little-endian 26-bit-radix limbs (any 32-bit values)
+struct mul_job {
+  const uint32_t *a, *b;  // [4][10]
+  uint32_t *out;          // [4][16]  all 16 lanes of each row, so tests can check idle lanes are zero
+  int op;
+};
+void lane_mul(void *p) {
+  mul_job *j = (mul_job *)p;
+  const wv::wk k = wv::wk_init();
+  const uint32_t a = k.li < 10 ? j->a[k.row * 10 + k.li] : 0u;
+  const uint32_t b = k.li < 10 ? j->b[k.row * 10 + k.li] : 0u;
+  uint32_t r = 0;
+  switch (j->op) {
+    case 0: r = wv::wfe_mul(a, b, k); break;
+    case 1: r = wv::wfe_weak(a, k); break;
+    case 2: r = wv::wfe_neg1(a, k) + b; break;
+    case 3: r = wv::wfe_neg2(a, k) + b; break;
+    case 4: r = wv::wfe_neg8(a, k) + b; break;
+    case 5: r = wv::wfe_sqrt_candidate(a, k); break;
+    case 6: r = wv::scatter(wv::gather(a), k); break;
+    case 7: r = wv::wfe_is_zero(a) ? 1u : 0u; break;
+  }
+  j->out[k.row * 16 + k.li] = r;
+}
+
+struct pt_job {
+  const uint32_t *p, *q;  // [4][31]: x[10] y[10] z[10] inf
+  uint32_t *out;          // [4][31]
+  int op;
+};
+wv::wjac load_pt(const uint32_t *src, const wv::wk &k) {
+  const uint32_t *r = src + 31 * k.row;
+  wv::wjac p;
+  p.x = k.li < 10 ? r[k.li] : 0u;
+  p.y = k.li < 10 ? r[10 + k.li] : 0u;
+  p.z = k.li < 10 ? r[20 + k.li] : 0u;
+  p.inf = r[30] != 0;
+  return p;
+}
+void lane_pt(void *vp) {
+  pt_job *j = (pt_job *)vp;
+  const wv::wk k = wv::wk_init();
+  wv::wjac p = load_pt(j->p, k), q = load_pt(j->q, k), r;
+  switch (j->op) {
+    case 0: r = wv::wjac_dbl(p, k); break;
+    case 1: r = wv::wjac_add(p, q, k); break;
+    case 2: r = wv::wjac_add_aff(p, wv::waff{q.x, q.y}, k); break;
+    default: r = wv::wjac_add(p, wv::wjac_lane_xor(p, 16), k); break;
+  }
+  uint32_t *o = j->out + 31 * k.row;
+  if (k.li < 10) {
+    o[k.li] = r.x;
+    o[10 + k.li] = r.y;
+    o[20 + k.li] = r.z;
+  }
+  if (k.li == 0) o[30] = r.inf ? 1u : 0u;
+}
+
+struct rec_job {
+  const uint8_t *hash32, *sig65;
+  uint32_t flags;
+  uint8_t *addr20;  // [64][20]  every lane's answer
+  int *ok;          // [64]
+};
+void lane_rec(void *vp) {
+  rec_job *j = (rec_job *)vp;
+  u256 z = secp::from_be32(j->hash32), r = secp::from_be32(j->sig65), s = secp::from_be32(j->sig65 + 32);
+  uint32_t a[5];
+  secp::aff Q;
+  bool ok = wv::recover_pubkey_wave(g_gtab.data(), z, r, s, j->sig65[64], j->flags, a, Q);
+  const int l = wave_emul::lane();
+  memcpy(j->addr20 + 20 * l, a, 20);
+  j->ok[l] = ok ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void wvh_init_gtab(void) {
+  if (!g_gtab.empty()) return;
+  g_gtab.resize((size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS);
+  for (int t = 0; t < ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES; t++)
+    ibftk::gtab_entry(t / ibftk::GTAB_ENTRIES, t % ibftk::GTAB_ENTRIES,
+                      g_gtab.data() + (size_t)ibftk::GTAB_ENTRY_DWORDS * t);
+}
+void wvh_fe_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out64) {
+  mul_job j{a, b, out64, op};
+  wave_emul::run(lane_mul, &j);
+}
+void wvh_pt_op(int op, const uint32_t *p, const uint32_t *q, uint32_t *out) {
+  pt_job j{p, q, out, op};
+  wave_emul::run(lane_pt, &j);
+}
+void wvh_recover(const uint8_t *hash32, const uint8_t *sig65, uint32_t flags, uint8_t *addr64x20, int *ok64) {
+  rec_job j{hash32, sig65, flags, addr64x20, ok64};
+  wave_emul::run(lane_rec, &j);
+}
+uint32_t wvh_neg_limb(int which, int i) { return wv::wneg_limb(which, i); }
+
+}  // extern "C"

@@ -57,6 +57,8 @@ struct ibft_ctx {
   std::vector<uint8_t> valset_addrs;  // last address list, to keep the cache across identical sets
   uint32_t warm_passes = 0, cold_passes = 0, last_group = 0, last_cold_group = 1;
   bool cold_group_auto = true;
+  uint32_t cold_group_force = 0;  // IBFT_COLD_LANES=1|2|4|8|64 (experiments: pin the cold kernel variant)
+  uint32_t wave_rows_max = 2048;  // AUTO: one wavefront per signature up to this many rows
 
   // staged batch
   uint32_t staged_n = 0;
@@ -223,12 +225,21 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   // with a warm kernel in front only the stragglers are left and the group kernel's atomicOr
   // merge needs the mask it already holds)
   uint32_t CG = 1;
-  if (c->cold_group_auto) {
-    if ((uint64_t)n * 8 <= 65536ull) CG = 8;
+  if (c->cold_group_force) {
+    CG = c->cold_group_force;
+  } else if (c->cold_group_auto) {
+    if ((uint64_t)n <= c->wave_rows_max) CG = 64;
+    else if ((uint64_t)n * 8 <= 65536ull) CG = 8;
     else if ((uint64_t)n * 4 <= 65536ull) CG = 4;
     else if ((uint64_t)n * 2 <= 65536ull) CG = 2;
   }
-  if (CG > 1) {
+  if (CG == 64) {
+    if (!warm) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
+    if (mode == 0)
+      hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<0>, dim3(n), dim3(64), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<1>, dim3(n), dim3(64), 0, c->stream, a);
+  } else if (CG > 1) {
     if (!warm) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
     const uint32_t rows_per_wave = 64 / CG;
     dim3 cgrid((n + rows_per_wave - 1) / rows_per_wave), cblock(64);
@@ -362,6 +373,11 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->max_rows = (cfg && cfg->max_rows) ? cfg->max_rows : DEFAULT_MAX_ROWS;
   c->kernel = cfg ? cfg->kernel : IBFT_KERNEL_AUTO;
   c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
+  if (const char *e = getenv("IBFT_COLD_LANES")) {
+    const int g = atoi(e);
+    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 64) c->cold_group_force = (uint32_t)g;
+  }
+  if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }

@@ -8,6 +8,7 @@
 //   proposal_hash_kernel            keccak256(raw ‖ BE64(round)), once per batch
 //   ecrecover_lane_kernel       a2  IsValidCommittedSeal  (core/ibft.go:943)      cold path,
 //   ecrecover_group_kernel<G>   a3  IsValidValidator      (core/ibft.go:1128)     1 / 2,4,8 lanes per signature
+//   ecrecover_wave_kernel           same, one wavefront per signature (limbs spread over lanes, wave_fe_dev.h)
 //   verify_known_lane_kernel    a2/a3 against the validator's known key (warm path), 1 lane per signature
 //   verify_known_group_kernel<G>    same, G = 2..64 lanes per signature (64 = one wavefront per signature)
 //   tally_kernel                a8  HasQuorum             (core/validator_manager.go:77-96)
@@ -26,6 +27,7 @@
 
 #include "recover_dev.h"
 #include "verify_dev.h"
+#include "wave_fe_dev.h"
 
 namespace ibftk {
 
@@ -461,6 +463,50 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
       a.learned[1] = (uint32_t)vi;
     }
     if (ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+  }
+}
+
+// ---- cold path, ONE WAVEFRONT PER SIGNATURE (wave_fe_dev.h) --------------------------------------
+// For batches that leave most of the chip idle (n ≤ 2 048: at most two wavefronts per SIMD).  A
+// field element is one VGPR spread over the 16 lanes of a DPP row, a multiplication costs ≈86
+// instructions for four independent products, and the four rows carry the four 64-bit pieces
+// of the GLV-split scalar.  All control flow is uniform: the wavefront holds a single signature.
+template <int MODE>
+__global__ void __launch_bounds__(64) ecrecover_wave_kernel(recover_args a) {
+  const uint32_t row = blockIdx.x;
+  if (a.warm_done && a.warm_done[row] != 0) return;  // decided by the warm kernel
+  uint32_t want[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
+  const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  const bool pre = a.pre_flags && a.pre_flags[row] != 0;
+  if (threadIdx.x == 0) a.vidx[row] = vi;
+  if (pre || vi < 0) return;  // verdict stays 0 (mask was cleared by the host before the launch)
+  const u256 r = secp::from_be32(a.sig65 + 65ull * row);
+  const u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
+  const uint32_t v = a.sig65[65ull * row + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(a.hash32 + 32ull * row);
+  } else {
+    uint64_t d[4];
+    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    keccak::digest_to_limbs(d, z.v);
+  }
+  uint32_t got[5];
+  aff Qa;
+  bool ok = wv::recover_pubkey_wave(a.gtab, z, r, s, v, a.flags, got, Qa);
+#pragma unroll
+  for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
+  if (threadIdx.x == 0 && ok) {
+    if (a.pub_state && a.pub_state[vi] == 0) {
+      store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
+      __threadfence();
+      a.pub_state[vi] = 1;
+      atomicAdd(a.learned, 1u);
+      a.learned[1] = (uint32_t)vi;
+    }
+    atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
   }
 }
 

@@ -1,0 +1,482 @@
+// wave_fe_dev.h — ONE WAVEFRONT PER SIGNATURE: field elements spread over the lanes of a row.
+//
+// Product code (the host build exists only for tests, through wave_emul.h).  The lane- and
+// group-kernels keep a whole field element in one lane (10 VGPRs) and pay ≈224 dependent VALU
+// instructions per multiplication; at N = 1 024 rows the chip (1 024 SIMDs) has exactly one
+// SIMD per signature, so what matters is the LATENCY of one signature, not lane throughput.
+// Here a field element is one VGPR: lane 16·ρ + i of DPP row ρ holds limb i (radix 2^26,
+// i = 0..9; lanes 10..15 of every row hold 0).  A multiplication is then
+//   ten broadcasts of a_i (row_newbcast) × ten row-shifted copies of b (row_shr) feeding one
+//   v_mad_u64_u32 each — lane k accumulates column k, lanes 10..15 the columns 10..15, three more
+//   mads give columns 16..18 — and a carry-save reduction with 2^260 ≡ 0x3D10 + 0x400·2^26,
+// ≈86 instructions for FOUR independent products (one per row) instead of 224 for one.  The
+// four rows carry four independent pieces of the scalar multiplication (GLV half × upper /
+// lower 64 bits), so the per-row instruction stream is an ordinary sequential point formula
+// and every branch is wave-uniform by construction (a wavefront holds one signature).
+//
+// Magnitudes: U = 2^26 + 2^20; "magnitude m" = every limb ≤ m·U.  wfe_mul accepts magnitudes
+// ≤ 15 on both inputs (10·(15U)² < 2^64) and returns magnitude 1; wfe_neg(a, m) = K_m − a with
+// K_m ≡ 0 (mod p), K_m,i ∈ [m·U, m·U + 2^26), so the result has magnitude m + 1.
+#pragma once
+#include "modinv_dev.h"
+#include "recover_dev.h"
+#include "verify_dev.h"
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(IBFT_WAVE_EMUL)
+#include "wave_emul.h"  // tests only: 64 lockstep coroutines stand in for the lanes
+#endif
+
+// big functions: forced inline on the device (the only outlined piece is wfe_mul_fn), ordinary
+// inline + an outlined multiply in the host test build (forcing them there makes the compile explode)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WVF __host__ __device__ __forceinline__
+#else
+#define WVF __host__ __device__ inline
+#endif
+
+namespace wv {
+
+using secp::aff;
+using secp::fe;
+using secp::jac;
+using secp::M26;
+using secp::u256;
+
+// ---- cross-lane primitives -----------------------------------------------------------------
+HD uint32_t lane_id() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __lane_id();
+#elif defined(IBFT_WAVE_EMUL)
+  return (uint32_t)wave_emul::lane();
+#else
+  return 0;  // host pass of the product build: never called
+#endif
+}
+// lane k of a row ← lane k − N (zero shifted in)
+template <int N>
+HD uint32_t row_shr(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true);
+#elif defined(IBFT_WAVE_EMUL)
+  const int l = wave_emul::lane();
+  return wave_emul::xchg(v, (l & 15) >= N ? l - N : -1);
+#else
+  return v;
+#endif
+}
+// lane k of a row ← lane k + N (zero shifted in)
+template <int N>
+HD uint32_t row_shl(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
+#elif defined(IBFT_WAVE_EMUL)
+  const int l = wave_emul::lane();
+  return wave_emul::xchg(v, (l & 15) + N <= 15 ? l + N : -1);
+#else
+  return v;
+#endif
+}
+// every lane of a row ← lane N of that row (gfx90a+ row_newbcast)
+template <int N>
+HD uint32_t row_bcast(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, true);
+#elif defined(IBFT_WAVE_EMUL)
+  const int l = wave_emul::lane();
+  return wave_emul::xchg(v, (l & ~15) + N);
+#else
+  return v;
+#endif
+}
+HD uint32_t lane_xor(uint32_t v, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__shfl_xor((int)v, off, 64);
+#elif defined(IBFT_WAVE_EMUL)
+  return wave_emul::xchg(v, wave_emul::lane() ^ off);
+#else
+  return v + (uint32_t)off;
+#endif
+}
+HD bool any(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any(c ? 1 : 0) != 0;
+#elif defined(IBFT_WAVE_EMUL)
+  return wave_emul::ballot(c) != 0;
+#else
+  return c;
+#endif
+}
+
+// ---- per-lane constants ----------------------------------------------------------------------
+constexpr uint32_t WFE_U = (1u << 26) + (1u << 20);
+HD uint32_t wneg_limb(int which, int i) {  // K_1, K_2, K_8 (tests/test_dev_wave_host.py re-derives them)
+  const uint32_t K[3][10] = {
+      {0x07FFBF1Fu, 0x07FFFBBEu, 0x07FFFFFEu, 0x07FFFFFEu, 0x07FFFFFEu, 0x07FFFFFEu, 0x07FFFFFEu, 0x07FFFFFEu,
+       0x07FFFFFEu, 0x043FFFFEu},
+      {0x0BFF820Fu, 0x0BFFF7BDu, 0x0BFFFFFDu, 0x0BFFFFFDu, 0x0BFFFFFDu, 0x0BFFFFFDu, 0x0BFFFFFDu, 0x0BFFFFFDu,
+       0x0BFFFFFDu, 0x083FFFFDu},
+      {0x23FE0C0Du, 0x23FFDF37u, 0x23FFFFF7u, 0x23FFFFF7u, 0x23FFFFF7u, 0x23FFFFF7u, 0x23FFFFF7u, 0x23FFFFF7u,
+       0x23FFFFF7u, 0x20BFFFF7u}};
+  return K[which][i];
+}
+struct wk {
+  uint32_t li;    // lane within the row
+  uint32_t row;   // 0..3
+  uint32_t act;   // all ones on limb lanes (li < 10)
+  uint32_t m3;    // li < 3 ? M26 : all ones
+  uint32_t lt3;   // all ones for li < 3
+  uint32_t lt9;   // all ones for li < 9
+  uint32_t kr;    // 2^260 mod p as limbs: 0x3D10 in lane 0, 0x400 in lane 1
+  uint32_t k1, k2, k8;  // negation constants
+};
+HD wk wk_init() {
+  wk k;
+  const uint32_t l = lane_id();
+  k.li = l & 15u;
+  k.row = l >> 4;
+  k.act = k.li < 10 ? 0xFFFFFFFFu : 0u;
+  k.m3 = k.li < 3 ? M26 : 0xFFFFFFFFu;
+  k.lt3 = k.li < 3 ? 0xFFFFFFFFu : 0u;
+  k.lt9 = k.li < 9 ? 0xFFFFFFFFu : 0u;
+  k.kr = k.li == 0 ? 0x3D10u : (k.li == 1 ? 0x400u : 0u);
+  k.k1 = k.k2 = k.k8 = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    k.k1 = k.li == (uint32_t)i ? wneg_limb(0, i) : k.k1;
+    k.k2 = k.li == (uint32_t)i ? wneg_limb(1, i) : k.k2;
+    k.k8 = k.li == (uint32_t)i ? wneg_limb(2, i) : k.k8;
+  }
+  return k;
+}
+
+// ---- multiplication --------------------------------------------------------------------------
+HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+HD uint32_t mul24(uint32_t a, uint32_t b) {  // both < 2^24
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
+
+template <int I>
+HD void wfe_mul_step(uint32_t a, uint32_t b, uint64_t &lo, uint64_t &hi) {
+  const uint32_t ai = row_bcast<I>(a);
+  const uint32_t tl = row_shr<(I == 0 ? 1 : I)>(b);  // (I == 0 uses b itself below)
+  lo = mad64(ai, I == 0 ? b : tl, lo);
+  if (I >= 7) hi = mad64(ai, row_shl<16 - (I >= 7 ? I : 7)>(b), hi);  // columns 16..18 in lanes 0..2
+}
+
+// both inputs of magnitude ≤ 15 with zero idle lanes; result magnitude 1 (< 2^26 + 2^16), idle lanes zero
+HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint32_t lt3) {
+  uint64_t lo = 0, hi = 0;
+  {
+    const uint32_t a0 = row_bcast<0>(a);
+    lo = mad64(a0, b, lo);
+  }
+  wfe_mul_step<1>(a, b, lo, hi);
+  wfe_mul_step<2>(a, b, lo, hi);
+  wfe_mul_step<3>(a, b, lo, hi);
+  wfe_mul_step<4>(a, b, lo, hi);
+  wfe_mul_step<5>(a, b, lo, hi);
+  wfe_mul_step<6>(a, b, lo, hi);
+  wfe_mul_step<7>(a, b, lo, hi);
+  wfe_mul_step<8>(a, b, lo, hi);
+  wfe_mul_step<9>(a, b, lo, hi);
+  // lane k of lo = column k (k = 0..15), lane k of hi = column 16 + k (k = 0..2): cut into 26-bit chunks
+  const uint32_t c0 = (uint32_t)lo & M26, c1 = (uint32_t)(lo >> 26) & M26, c2 = (uint32_t)(lo >> 52);
+  const uint32_t h0 = (uint32_t)hi & M26, h1 = (uint32_t)(hi >> 26) & M26, h2 = (uint32_t)(hi >> 52);
+  // S: positions 0..15, T: positions 16..20 (lane j = position 16 + j)
+  const uint32_t S = c0 + row_shr<1>(c1) + row_shr<2>(c2);
+  const uint32_t T = h0 + row_shr<1>(h1) + row_shr<2>(h2) + row_shl<15>(c1) + row_shl<14>(c2);
+  // H: lane j = position 10 + j (j = 0..10); fold with 2^260 ≡ 0x3D10 + 0x400·2^26
+  const uint32_t H = row_shl<10>(S) + row_shr<6>(T);
+  uint64_t V = mad64(H, 0x3D10u, (uint64_t)(S & act));
+  V = mad64(row_shr<1>(H), 0x400u, V);  // < 2^42 in lanes 0..11
+  const uint32_t U = ((uint32_t)V & M26) + row_shr<1>((uint32_t)(V >> 26));  // positions 0..11
+  // positions 10, 11 once more
+  const uint32_t H2 = row_shl<10>(U);  // lanes 0, 1
+  uint64_t V2 = mad64(H2, 0x3D10u, (uint64_t)(U & act));
+  V2 = mad64(row_shr<1>(H2), 0x400u, V2);  // lanes 0..2 < 2^41, lanes 3..9 = U
+  return ((uint32_t)V2 & m3) + row_shr<1>((uint32_t)(V2 >> 26) & lt3);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint32_t b, uint32_t act, uint32_t m3,
+                                                               uint32_t lt3) {
+  return wfe_mul_body(a, b, act, m3, lt3);
+}
+HD uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) { return wfe_mul_fn(a, b, k.act, k.m3, k.lt3); }
+#else
+static __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint32_t lt3) {
+  return wfe_mul_body(a, b, act, m3, lt3);
+}
+inline uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) { return wfe_mul_fn(a, b, k.act, k.m3, k.lt3); }
+#endif
+HD uint32_t wfe_sqr(uint32_t a, const wk &k) { return wfe_mul(a, a, k); }
+HD uint32_t wfe_sqr_n(uint32_t a, int n, const wk &k) {
+  for (int i = 0; i < n; i++) a = wfe_sqr(a, k);
+  return a;
+}
+
+// ---- linear operations -------------------------------------------------------------------------
+HD uint32_t wfe_neg1(uint32_t a, const wk &k) { return k.k1 - a; }  // a magnitude ≤ 1 → 2
+HD uint32_t wfe_neg2(uint32_t a, const wk &k) { return k.k2 - a; }  // ≤ 2 → 3
+HD uint32_t wfe_neg8(uint32_t a, const wk &k) { return k.k8 - a; }  // ≤ 8 → 9
+// any limbs < 2^32 → magnitude 1: one carry pass, the carry out of limb 9 folded with 2^260 mod p
+HD uint32_t wfe_weak(uint32_t v, const wk &k) {
+  const uint32_t c = v >> 26;
+  const uint32_t c9 = row_bcast<9>(c);
+  return (v & M26) + row_shr<1>(c & k.lt9) + mul24(c9, k.kr);
+}
+
+// ---- row layout ↔ lane layout -------------------------------------------------------------------
+// every lane of the row gets the whole element
+HD fe gather(uint32_t w) {
+  fe r;
+  r.n[0] = row_bcast<0>(w);
+  r.n[1] = row_bcast<1>(w);
+  r.n[2] = row_bcast<2>(w);
+  r.n[3] = row_bcast<3>(w);
+  r.n[4] = row_bcast<4>(w);
+  r.n[5] = row_bcast<5>(w);
+  r.n[6] = row_bcast<6>(w);
+  r.n[7] = row_bcast<7>(w);
+  r.n[8] = row_bcast<8>(w);
+  r.n[9] = row_bcast<9>(w);
+  return r;
+}
+// a identical in all lanes of the row (or at least: lane i holds the right n[i])
+HD uint32_t scatter(const fe &a, const wk &k) {
+  uint32_t w = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) w = k.li == (uint32_t)i ? a.n[i] : w;
+  return w;
+}
+HD bool wfe_is_zero(uint32_t w) { return secp::fe_is_zero(gather(w)); }  // magnitude ≤ 31
+
+// ---- group law (Jacobian, a = 0), one point per row ------------------------------------------------
+struct wjac {
+  uint32_t x, y, z;
+  bool inf;  // uniform within a row
+};
+struct waff {
+  uint32_t x, y;
+};
+HD wjac wjac_inf() { return wjac{0u, 0u, 0u, true}; }
+HD wjac wjac_select(bool c, const wjac &a, const wjac &b) {
+  wjac r;
+  r.x = c ? a.x : b.x;
+  r.y = c ? a.y : b.y;
+  r.z = c ? a.z : b.z;
+  r.inf = c ? a.inf : b.inf;
+  return r;
+}
+HD wjac wjac_from_aff(const waff &a, const wk &k) { return wjac{a.x, a.y, k.li == 0 ? 1u : 0u, false}; }
+
+// dbl-2009-l (same formula and magnitude bookkeeping as secp::jac_dbl)
+WVF wjac wjac_dbl(const wjac &p, const wk &k) {
+  const uint32_t A = wfe_sqr(p.x, k);
+  const uint32_t B = wfe_sqr(p.y, k);
+  const uint32_t C = wfe_sqr(B, k);
+  uint32_t t = wfe_sqr(p.x + B, k);                      // in 2
+  t = t + wfe_neg1(A, k) + wfe_neg1(C, k);               // 5
+  const uint32_t D = wfe_weak(2u * t, k);                // 10 → 1
+  const uint32_t E = 3u * A;                             // 3
+  const uint32_t F = wfe_sqr(E, k);
+  wjac r;
+  r.x = wfe_weak(F + wfe_neg2(2u * D, k), k);            // 4 → 1
+  r.y = wfe_weak(wfe_mul(E, D + wfe_neg1(r.x, k), k) + wfe_neg8(8u * C, k), k);  // in 3,3; 10 → 1
+  r.z = wfe_mul(2u * p.y, p.z, k);
+  r.inf = p.inf;
+  return r;
+}
+// add-2007-bl with the exceptional cases (P = Q, P = −Q, ∞) resolved per row
+WVF wjac wjac_add(const wjac &p, const wjac &q, const wk &k) {
+  const uint32_t z1z1 = wfe_sqr(p.z, k), z2z2 = wfe_sqr(q.z, k);
+  const uint32_t u1 = wfe_mul(p.x, z2z2, k), u2 = wfe_mul(q.x, z1z1, k);
+  const uint32_t s1 = wfe_mul(wfe_mul(p.y, q.z, k), z2z2, k);
+  const uint32_t s2 = wfe_mul(wfe_mul(q.y, p.z, k), z1z1, k);
+  const uint32_t h = u2 + wfe_neg1(u1, k);   // 3
+  const uint32_t rr = s2 + wfe_neg1(s1, k);  // 3
+  const uint32_t i = wfe_sqr(2u * h, k);     // in 6
+  const uint32_t j = wfe_mul(h, i, k);
+  const uint32_t r2 = 2u * rr;               // 6
+  const uint32_t v = wfe_mul(u1, i, k);
+  wjac r;
+  r.x = wfe_weak(wfe_sqr(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);                 // 6 → 1
+  const uint32_t s1j2 = 2u * wfe_mul(s1, j, k);                                            // 2
+  r.y = wfe_weak(wfe_mul(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(s1j2, k), k);              // 4 → 1
+  const uint32_t zz = wfe_sqr(p.z + q.z, k) + wfe_neg1(z1z1, k) + wfe_neg1(z2z2, k);        // 5
+  r.z = wfe_mul(zz, h, k);
+  r.inf = false;
+  const bool both = !p.inf && !q.inf;
+  const bool hz = wfe_is_zero(h);
+  bool rz = false;
+  if (any(both && hz)) rz = wfe_is_zero(rr);
+  const bool same = both && hz && rz, opposite = both && hz && !rz;
+  if (any(same)) r = wjac_select(same, wjac_dbl(p, k), r);
+  r = wjac_select(opposite, wjac_inf(), r);
+  r = wjac_select(q.inf, p, r);
+  r = wjac_select(p.inf, q, r);
+  return r;
+}
+// madd-2007-bl (q affine, never infinity)
+WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
+  const uint32_t z1z1 = wfe_sqr(p.z, k);
+  const uint32_t u2 = wfe_mul(q.x, z1z1, k);
+  const uint32_t s2 = wfe_mul(wfe_mul(q.y, p.z, k), z1z1, k);
+  const uint32_t h = u2 + wfe_neg1(p.x, k);   // 3
+  const uint32_t rr = s2 + wfe_neg2(p.y, k);  // 4 (p.y may be a negated table entry: magnitude ≤ 2)
+  const uint32_t hh = wfe_sqr(h, k);
+  const uint32_t i = 4u * hh;                 // 4
+  const uint32_t j = wfe_mul(h, i, k);
+  const uint32_t r2 = 2u * rr;                // 8
+  const uint32_t v = wfe_mul(p.x, i, k);
+  wjac r;
+  r.x = wfe_weak(wfe_sqr(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);
+  const uint32_t y1j2 = 2u * wfe_mul(p.y, j, k);
+  r.y = wfe_weak(wfe_mul(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(y1j2, k), k);
+  r.z = wfe_weak(wfe_sqr(p.z + h, k) + wfe_neg1(z1z1, k) + wfe_neg1(hh, k), k);  // in 4; 5 → 1
+  r.inf = false;
+  const bool hz = wfe_is_zero(h);
+  bool rz = false;
+  if (any(!p.inf && hz)) rz = wfe_is_zero(rr);
+  const bool same = !p.inf && hz && rz, opposite = !p.inf && hz && !rz;
+  const wjac qj = wjac_from_aff(q, k);
+  if (any(same)) r = wjac_select(same, wjac_dbl(qj, k), r);
+  r = wjac_select(opposite, wjac_inf(), r);
+  r = wjac_select(p.inf, qj, r);
+  return r;
+}
+HD wjac wjac_lane_xor(const wjac &p, int off) {
+  wjac r;
+  r.x = lane_xor(p.x, off);
+  r.y = lane_xor(p.y, off);
+  r.z = lane_xor(p.z, off);
+  r.inf = lane_xor(p.inf ? 1u : 0u, off) != 0;
+  return r;
+}
+HD jac wjac_gather(const wjac &p) {
+  jac r;
+  r.x = gather(p.x);
+  r.y = gather(p.y);
+  r.z = gather(p.z);
+  r.inf = p.inf;
+  return r;
+}
+
+// a^((p+1)/4), same addition chain as secp::fe_sqrt_candidate (a of magnitude ≤ 8)
+WVF uint32_t wfe_sqrt_candidate(uint32_t a, const wk &k) {
+  const uint32_t x2 = wfe_mul(wfe_sqr(a, k), a, k);
+  const uint32_t x3 = wfe_mul(wfe_sqr(x2, k), a, k);
+  const uint32_t x6 = wfe_mul(wfe_sqr_n(x3, 3, k), x3, k);
+  const uint32_t x9 = wfe_mul(wfe_sqr_n(x6, 3, k), x3, k);
+  const uint32_t x11 = wfe_mul(wfe_sqr_n(x9, 2, k), x2, k);
+  const uint32_t x22 = wfe_mul(wfe_sqr_n(x11, 11, k), x11, k);
+  const uint32_t x44 = wfe_mul(wfe_sqr_n(x22, 22, k), x22, k);
+  const uint32_t x88 = wfe_mul(wfe_sqr_n(x44, 44, k), x44, k);
+  const uint32_t x176 = wfe_mul(wfe_sqr_n(x88, 88, k), x88, k);
+  const uint32_t x220 = wfe_mul(wfe_sqr_n(x176, 44, k), x44, k);
+  const uint32_t x223 = wfe_mul(wfe_sqr_n(x220, 3, k), x3, k);
+  uint32_t t = wfe_mul(wfe_sqr_n(x223, 23, k), x22, k);
+  t = wfe_mul(wfe_sqr_n(t, 6, k), x2, k);
+  return wfe_sqr_n(t, 2, k);
+}
+
+// ---- the recover, one signature per wavefront -------------------------------------------------------
+// Same contract and rejection list as ibftk::recover_pubkey (recover_dev.h); every lane of the
+// wavefront passes the same (z, r, s, v) and gets the same answer.
+//
+// Row ρ computes the piece (half = ρ & 1, upper = ρ >> 1) of u2·R = k1·(±R) + k2·λ(±R): 64 bits of
+// the 128-bit |k_half| in signed radix-16 digits on the base 2^(64·upper)·(β^half·x, ±y), then
+// four of the u1·G window points; two row-xor additions join the four rows.
+WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
+                            uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa) {
+  const wk k = wk_init();
+  bool ok = ibftk::sig_in_range(r, s, v, flags);
+  // R = (r, y), y² = r³ + 7, parity(y) = v
+  const fe rx = secp::fe_from_u256(r);
+  const uint32_t X = scatter(rx, k);
+  const uint32_t rhs = wfe_mul(wfe_sqr(X, k), X, k) + (k.li == 0 ? 7u : 0u);  // magnitude 2
+  const uint32_t Yc = wfe_sqrt_candidate(rhs, k);
+  ok = ok && wfe_is_zero(wfe_sqr(Yc, k) + wfe_neg2(rhs, k));
+  fe y = secp::fe_normalize(gather(Yc));
+  const fe yneg = secp::fe_normalize_weak(secp::fe_neg(y, 1));
+  y = secp::l26_select((y.n[0] & 1u) != v, yneg, y);
+  // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
+  const secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));
+  const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
+  const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+  const secp::glv_split sp = secp::sc_split_lambda(u2);
+  const bool half = (k.row & 1u) != 0, upper = (k.row & 2u) != 0;
+  // signed radix-16 digits of this row's |k|: k + 0x88…8 has nibbles d_j + 8, bit 128 is the top digit
+  uint32_t w[5];
+  {
+    const u256 &kk = half ? sp.k2 : sp.k1;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = secp::addc(kk.v[i], 0x88888888u, c);
+    w[4] = c;
+  }
+  const uint32_t d_lo = upper ? w[2] : w[0], d_hi = upper ? w[3] : w[1];
+  const bool top = upper && w[4] != 0;
+  // this row's base point
+  const bool negy = half ? sp.neg2 : sp.neg1;
+  const fe ysel = secp::l26_select(negy, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
+  const fe xsel = secp::l26_select(half, secp::fe_mul(rx, secp::GLV_CONST(1)), rx);
+  wjac base = wjac{scatter(xsel, k), scatter(ysel, k), k.li == 0 ? 1u : 0u, false};
+  {
+    wjac b64 = base;
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) b64 = wjac_dbl(b64, k);
+    base = wjac_select(upper, b64, base);
+  }
+  // table 1..8 of the base
+  wjac T[9];
+  T[1] = base;
+  T[2] = wjac_dbl(T[1], k);
+  T[3] = wjac_add(T[2], T[1], k);
+  T[4] = wjac_dbl(T[2], k);
+  T[5] = wjac_add(T[4], T[1], k);
+  T[6] = wjac_dbl(T[3], k);
+  T[7] = wjac_add(T[6], T[1], k);
+  T[8] = wjac_dbl(T[4], k);
+  wjac acc = wjac_select(top, T[1], wjac_inf());
+#pragma unroll 1
+  for (int jd = 15; jd >= 0; jd--) {
+#pragma unroll 1
+    for (int d = 0; d < 4; d++) acc = wjac_dbl(acc, k);
+    const uint32_t word = jd >= 8 ? d_hi : d_lo;
+    const int dg = (int)((word >> (4 * (jd & 7))) & 15u) - 8;
+    const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+    wjac q = T[1];
+#pragma unroll
+    for (int e = 2; e <= 8; e++) q = wjac_select(mag == (uint32_t)e, T[e], q);
+    q.y = dg < 0 ? wfe_neg1(q.y, k) : q.y;  // magnitude ≤ 2
+    const wjac sum = wjac_add(acc, q, k);
+    acc = wjac_select(mag != 0, sum, acc);
+  }
+  // u1·G: the fixed-base windows are dealt to the rows
+  constexpr int WPR = ibftk::GTAB_WINDOWS / 4;
+#pragma unroll 1
+  for (int t = 0; t < WPR; t++) {
+    const int win = (int)k.row * WPR + t;
+    const int bit = win * ibftk::GTAB_BITS;
+    const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    const uint32_t *e = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt);
+    const uint32_t ld = k.li < 10 ? k.li : 0u;
+    waff pt;
+    pt.x = e[ld] & k.act;
+    pt.y = e[10 + ld] & k.act;
+    const wjac sum = wjac_add_aff(acc, pt, k);
+    acc = wjac_select(dgt != 0, sum, acc);
+  }
+  acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
+  acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
+  const jac Q = wjac_gather(acc);
+  ok = secp::jac_to_aff_fast(Qa, Q) && ok;
+  u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
+  keccak::address_from_xy(qx.v, qy.v, addr);
+  return ok;
+}
+
+}  // namespace wv

@@ -126,3 +126,40 @@ def test_exceptional_point_additions_mixed_lanes_on_gpu(dt):
         exp.append(pt[0] if pt is not None else 0)
     assert run(dt, 15, k1s, k2s)[0] == exp
     assert run(dt, 16, k1s, k2s)[0] == exp
+
+
+# ---- wave_fe_dev.h: one wavefront per signature (the same cases as tests/test_dev_wave_host.py) ----
+def _wave_ops(dt):
+    vp = C.c_void_p
+
+    def fe_op(op, a_rows, b_rows=None):
+        a = np.array(a_rows, dtype=np.uint32).reshape(4, 10)
+        b = np.array(b_rows if b_rows is not None else a_rows, dtype=np.uint32).reshape(4, 10)
+        out = np.zeros((4, 16), dtype=np.uint32)
+        assert dt.devtest_wave_fe(op, 1, a.ctypes.data_as(vp), b.ctypes.data_as(vp), out.ctypes.data_as(vp)) == 0
+        return out
+
+    def pt_op(op, p, q):
+        out = np.zeros((4, 31), dtype=np.uint32)
+        assert dt.devtest_wave_pt(op, 1, p.ctypes.data_as(vp), q.ctypes.data_as(vp), out.ctypes.data_as(vp)) == 0
+        return out
+    return fe_op, pt_op
+
+
+@pytest.mark.parametrize("case", ["mul_matches_bigint_at_every_magnitude", "weak_normalise_and_negate",
+                                  "gather_scatter_and_is_zero", "sqrt_chain", "point_double_add_madd",
+                                  "point_exceptional_cases_mixed_over_rows"])
+def test_wave_arithmetic_on_gpu(dt, case):
+    import wave_cases as WC
+    getattr(WC, "check_" + case)(*_wave_ops(dt))
+
+
+def test_wave_recover_on_gpu(dt, oracle):
+    import wave_cases as WC
+
+    def recover(h, sig, flags=0):
+        out = np.zeros((64, 24), dtype=np.uint8)
+        assert dt.devtest_wave_recover(1, h, sig, flags, out.ctypes.data_as(C.c_void_p)) == 0
+        assert (out[:, :21] == out[0, :21]).all(), "lanes of the wavefront disagree"  # bytes 21..23 are padding
+        return bool(out[0, 20]), out[0, :20].tobytes()
+    WC.check_full_recover_matches_oracle(recover, oracle, rounds=4)

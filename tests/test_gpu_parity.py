@@ -59,13 +59,37 @@ def test_ragged_sizes_vs_oracle(gpu_verifier, gpu_verifier_lane, oracle, n):
         assert (senders == oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)).all()
 
 
-@pytest.mark.parametrize("n,expect_group", [(8192, 8), (12000, 4), (20000, 2), (40000, 1)])
-def test_cold_group_sizes(oracle, n, expect_group):
-    """AUTO picks 8/4/2/1 lanes per signature for the cold kernel so that n·G/64 ≤ 1024 wavefronts;
-    each choice is compared with the oracle on a Byzantine round."""
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 64])
+def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
+    """IBFT_COLD_LANES pins the cold kernel: lane kernel, 2/4/8-lane groups, one wavefront per
+    signature (64).  Same Byzantine round, seals and senders, strict-low-s on and off."""
     import go_ibft_amd.verifier as V
     from oracle import workload as W
-    assert (8 if n * 8 <= 65536 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    r = W.make_round(333, 4100 + lanes, byzantine=True, weighted=True, with_envelopes=True)
+    vs = oracle.ValSet(r.addrs, r.power)
+    for flags in (0, V.FLAG_STRICT_LOW_S):
+        bv = V.BatchVerifier(flags=flags, max_rows=4096)
+        try:
+            bv.set_validators(1, r.addrs, r.power)
+            got, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+            assert bv.last_dispatch() == (lanes, 0)
+            exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, flags=flags).astype(bool)
+            assert (got == exp).all(), np.nonzero(got != exp)[0][:10]
+            senders, _ = bv.is_valid_validator(r.payload, r.off, r.msg_sig65, r.signer20)
+            exp = oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20, flags=flags).astype(bool)
+            assert (senders == exp).all()
+        finally:
+            bv.close()
+
+
+@pytest.mark.parametrize("n,expect_group", [(1500, 64), (8192, 8), (12000, 4), (20000, 2), (40000, 1)])
+def test_cold_group_sizes(oracle, n, expect_group):
+    """AUTO picks one wavefront per signature up to 2 048 rows, then 8/4/2/1 lanes per signature so
+    that n·G/64 ≤ 1024 wavefronts; each choice is compared with the oracle on a Byzantine round."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    assert (64 if n <= 2048 else 8 if n * 8 <= 65536 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
     r = W.make_round(n, 3000 + n, byzantine=True)
     bv = V.BatchVerifier(max_rows=65536)
     try:
