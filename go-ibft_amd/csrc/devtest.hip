@@ -186,12 +186,13 @@ __global__ void __launch_bounds__(64) devtest_wave_pt_kernel(int op, const uint3
   if (k.li == 0) o[30] = r.inf ? 1u : 0u;
 }
 // one wavefront per signature; out: [n][64][24] bytes = every lane's 20-byte address + ok flag
+template <int STOP>
 __global__ void __launch_bounds__(64) devtest_wave_recover_kernel(const uint32_t *gtab, const uint8_t *dig, const uint8_t *sig65,
                                                                 uint32_t flags, uint8_t *out) {
   const int i = blockIdx.x;
-  uint32_t addr[5];
+  uint32_t addr[5] = {0, 0, 0, 0, 0};
   aff Q;
-  bool ok = wv::recover_pubkey_wave(gtab, from_be32(dig + 32 * i), from_be32(sig65 + 65 * i), from_be32(sig65 + 65 * i + 32),
+  bool ok = wv::recover_pubkey_wave<STOP>(gtab, from_be32(dig + 32 * i), from_be32(sig65 + 65 * i), from_be32(sig65 + 65 * i + 32),
                                     sig65[65 * i + 64], flags, addr, Q);
   uint8_t *o = out + (size_t)24 * (64 * i + threadIdx.x);
   for (int k = 0; k < 5; k++) reinterpret_cast<uint32_t *>(o)[k] = addr[k];
@@ -231,9 +232,34 @@ extern "C" int devtest_wave_recover(int n, const uint8_t *dig, const uint8_t *si
   uint8_t *dd = dev_copy(dig, (size_t)32 * n), *ds = dev_copy(sig65, (size_t)65 * n), *dout;
   if (!dd || !ds || hipMalloc(&dout, (size_t)24 * 64 * n) != hipSuccess) return -1;
   devtest_gtab_kernel<<<(ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES + 63) / 64, 64>>>(dg);
-  devtest_wave_recover_kernel<<<n, 64>>>(dg, dd, ds, flags, dout);
+  devtest_wave_recover_kernel<99><<<n, 64>>>(dg, dd, ds, flags, dout);
   int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
   (void)hipMemcpy(out, dout, (size_t)24 * 64 * n, hipMemcpyDeviceToHost);
+  (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
+  return rc;
+}
+
+// timing breakdown: the recover cut short after stage 1..6 (and complete = 99), ms per launch of n waves
+extern "C" int devtest_wave_stage_ms(int n, const uint8_t *dig, const uint8_t *sig65, float *ms7) {
+  uint32_t *dg;
+  size_t gbytes = (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4;
+  if (hipMalloc(&dg, gbytes) != hipSuccess) return -1;
+  uint8_t *dd = dev_copy(dig, (size_t)32 * n), *ds = dev_copy(sig65, (size_t)65 * n), *dout;
+  if (!dd || !ds || hipMalloc(&dout, (size_t)24 * 64 * n) != hipSuccess) return -1;
+  devtest_gtab_kernel<<<(ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES + 63) / 64, 64>>>(dg);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+#define STAGE_RUN(idx, S)                                                              \
+  for (int rep = 0; rep < 3; rep++) {                                                  \
+    (void)hipEventRecord(e0, 0);                                                       \
+    devtest_wave_recover_kernel<S><<<n, 64>>>(dg, dd, ds, 0, dout);                    \
+    (void)hipEventRecord(e1, 0);                                                       \
+    (void)hipEventSynchronize(e1);                                                     \
+    (void)hipEventElapsedTime(&ms7[idx], e0, e1);                                      \
+  }
+  STAGE_RUN(0, 1) STAGE_RUN(1, 2) STAGE_RUN(2, 3) STAGE_RUN(3, 4) STAGE_RUN(4, 5) STAGE_RUN(5, 6) STAGE_RUN(6, 99)
+#undef STAGE_RUN
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
   (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
   return rc;
 }

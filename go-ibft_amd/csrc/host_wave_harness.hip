@@ -93,9 +93,32 @@ void lane_rec(void *vp) {
   j->ok[l] = ok ? 1 : 0;
 }
 
+struct pre_job {
+  const uint32_t *x;  // [10]
+  uint32_t *out;      // [4][16] PX, then PY, PZ, yc : 4 × 64
+  int ndbl;
+};
+void lane_prefix(void *vp) {
+  pre_job *j = (pre_job *)vp;
+  const wv::wk k = wv::wk_init();
+  const uint32_t x = k.li < 10 ? j->x[k.li] : 0u;
+  const uint32_t w = wv::wfe_weak(wv::wfe_mul(wv::wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u), k);
+  uint32_t PX = wv::wfe_mul(w, x, k), PY = wv::wfe_sqr(w, k), PZ, root;
+  wv::prefix_and_sqrt(PX, PY, PZ, root, w, j->ndbl, k);
+  const int l = wave_emul::lane();
+  j->out[l] = PX;
+  j->out[64 + l] = PY;
+  j->out[128 + l] = PZ;
+  j->out[192 + l] = root;
+}
+
 }  // namespace
 
 extern "C" {
+void wvh_prefix(const uint32_t *x10, int ndbl, uint32_t *out256) {
+  pre_job j{x10, out256, ndbl};
+  wave_emul::run(lane_prefix, &j);
+}
 
 void wvh_init_gtab(void) {
   if (!g_gtab.empty()) return;

@@ -26,6 +26,7 @@ struct state {
   ucontext_t main_ctx, lane_ctx[LANES];
   char *stacks = nullptr;
   uint32_t buf[2][LANES];
+  uint32_t tag[2][LANES];  // which primitive each lane thinks this rendezvous is
   uint64_t phase[LANES];
   bool alive[LANES];
   int cur = -1;
@@ -57,14 +58,28 @@ inline void yield_to_next() {
 }
 
 // value of `v` held by lane `src` at this rendezvous (src < 0: zero)
-inline uint32_t xchg(uint32_t v, int src) {
+inline void check_same_primitive(state &s, int me, uint64_t ph, uint32_t tag) {
+  // the code under test must be wave-uniform around cross-lane operations: every live lane has to
+  // arrive at THIS rendezvous through the same primitive (a divergent `c ? f(dpp) : x` is caught here)
+  for (int l = 0; l < LANES; l++)
+    if (s.alive[l] && s.tag[ph & 1][l] != tag) {
+      fprintf(stderr, "wave_emul: divergent cross-lane op (lane %d op %#x, lane %d op %#x)\n", me, tag, l,
+              s.tag[ph & 1][l]);
+      abort();
+    }
+}
+inline uint32_t xchg(uint32_t v, int src, uint32_t tag) {
   state &s = S();
   const int me = s.cur;
   const uint64_t ph = s.phase[me]++;
   s.buf[ph & 1][me] = v;
+  s.tag[ph & 1][me] = tag;
   yield_to_next();
+  check_same_primitive(s, me, ph, tag);
+  // strict lockstep: lanes resumed before me in this round are one rendezvous further, the others
+  // have just written this one — anything else means the code under test diverged around a cross-lane op
   for (int l = 0; l < LANES; l++)
-    if (s.alive[l] && s.phase[l] != ph + 1 && s.phase[l] != ph + 2) {
+    if (s.alive[l] && s.phase[l] != (l < me ? ph + 2 : ph + 1)) {
       fprintf(stderr, "wave_emul: lanes out of lockstep (lane %d phase %llu, lane %d phase %llu)\n", me,
               (unsigned long long)ph, l, (unsigned long long)s.phase[l]);
       abort();
@@ -76,7 +91,9 @@ inline uint64_t ballot(bool c) {
   const int me = s.cur;
   const uint64_t ph = s.phase[me]++;
   s.buf[ph & 1][me] = c ? 1u : 0u;
+  s.tag[ph & 1][me] = 0xBA110000u;
   yield_to_next();
+  check_same_primitive(s, me, ph, 0xBA110000u);
   uint64_t m = 0;
   for (int l = 0; l < LANES; l++) m |= (uint64_t)(s.buf[ph & 1][l] & 1u) << l;
   return m;

@@ -58,7 +58,7 @@ HD uint32_t row_shr(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true);
 #elif defined(IBFT_WAVE_EMUL)
   const int l = wave_emul::lane();
-  return wave_emul::xchg(v, (l & 15) >= N ? l - N : -1);
+  return wave_emul::xchg(v, (l & 15) >= N ? l - N : -1, 0x100u + N);
 #else
   return v;
 #endif
@@ -70,7 +70,7 @@ HD uint32_t row_shl(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xF, 0xF, true);
 #elif defined(IBFT_WAVE_EMUL)
   const int l = wave_emul::lane();
-  return wave_emul::xchg(v, (l & 15) + N <= 15 ? l + N : -1);
+  return wave_emul::xchg(v, (l & 15) + N <= 15 ? l + N : -1, 0x200u + N);
 #else
   return v;
 #endif
@@ -82,7 +82,7 @@ HD uint32_t row_bcast(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, true);
 #elif defined(IBFT_WAVE_EMUL)
   const int l = wave_emul::lane();
-  return wave_emul::xchg(v, (l & ~15) + N);
+  return wave_emul::xchg(v, (l & ~15) + N, 0x300u + N);
 #else
   return v;
 #endif
@@ -91,9 +91,19 @@ HD uint32_t lane_xor(uint32_t v, int off) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (uint32_t)__shfl_xor((int)v, off, 64);
 #elif defined(IBFT_WAVE_EMUL)
-  return wave_emul::xchg(v, wave_emul::lane() ^ off);
+  return wave_emul::xchg(v, wave_emul::lane() ^ off, 0x400u + (uint32_t)off);
 #else
   return v + (uint32_t)off;
+#endif
+}
+// value of v held by lane `src` (any lane of the wavefront; ds_bpermute)
+HD uint32_t lane_perm(uint32_t v, uint32_t src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+#elif defined(IBFT_WAVE_EMUL)
+  return wave_emul::xchg(v, (int)src, 0x500u);
+#else
+  return v + src;
 #endif
 }
 HD bool any(bool c) {
@@ -199,19 +209,31 @@ HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint
   V2 = mad64(row_shr<1>(H2), 0x400u, V2);  // lanes 0..2 < 2^41, lanes 3..9 = U
   return ((uint32_t)V2 & m3) + row_shr<1>((uint32_t)(V2 >> 26) & lt3);
 }
+// INL = true pastes the 72 VALU instructions in place (hot loops: no call/return, no argument moves,
+// and the scheduler can fill the DPP wait states across neighbouring multiplications); INL = false
+// calls one outlined copy (straight-line code that runs once — table, G additions, joins — where
+// 500-byte bodies would only thrash the 64 KB instruction cache: measured +0.03 ms when inlined).
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint32_t b, uint32_t act, uint32_t m3,
                                                                uint32_t lt3) {
   return wfe_mul_body(a, b, act, m3, lt3);
 }
-HD uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) { return wfe_mul_fn(a, b, k.act, k.m3, k.lt3); }
+template <bool INL = false>
+HD uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) {
+  return INL ? wfe_mul_body(a, b, k.act, k.m3, k.lt3) : wfe_mul_fn(a, b, k.act, k.m3, k.lt3);
+}
 #else
-static __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint32_t lt3) {
+static __host__ __device__ __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint32_t b, uint32_t act,
+                                                                        uint32_t m3, uint32_t lt3) {
   return wfe_mul_body(a, b, act, m3, lt3);
 }
-inline uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) { return wfe_mul_fn(a, b, k.act, k.m3, k.lt3); }
+template <bool INL = false>
+__host__ __device__ inline uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) {
+  return wfe_mul_fn(a, b, k.act, k.m3, k.lt3);
+}
 #endif
-HD uint32_t wfe_sqr(uint32_t a, const wk &k) { return wfe_mul(a, a, k); }
+template <bool INL = false>
+HD uint32_t wfe_sqr(uint32_t a, const wk &k) { return wfe_mul<INL>(a, a, k); }
 HD uint32_t wfe_sqr_n(uint32_t a, int n, const wk &k) {
   for (int i = 0; i < n; i++) a = wfe_sqr(a, k);
   return a;
@@ -273,76 +295,79 @@ HD wjac wjac_select(bool c, const wjac &a, const wjac &b) {
 HD wjac wjac_from_aff(const waff &a, const wk &k) { return wjac{a.x, a.y, k.li == 0 ? 1u : 0u, false}; }
 
 // dbl-2009-l (same formula and magnitude bookkeeping as secp::jac_dbl)
+template <bool INL = false>
 WVF wjac wjac_dbl(const wjac &p, const wk &k) {
-  const uint32_t A = wfe_sqr(p.x, k);
-  const uint32_t B = wfe_sqr(p.y, k);
-  const uint32_t C = wfe_sqr(B, k);
-  uint32_t t = wfe_sqr(p.x + B, k);                      // in 2
+  const uint32_t A = wfe_sqr<INL>(p.x, k);
+  const uint32_t B = wfe_sqr<INL>(p.y, k);
+  const uint32_t C = wfe_sqr<INL>(B, k);
+  uint32_t t = wfe_sqr<INL>(p.x + B, k);                      // in 2
   t = t + wfe_neg1(A, k) + wfe_neg1(C, k);               // 5
   const uint32_t D = wfe_weak(2u * t, k);                // 10 → 1
   const uint32_t E = 3u * A;                             // 3
-  const uint32_t F = wfe_sqr(E, k);
+  const uint32_t F = wfe_sqr<INL>(E, k);
   wjac r;
   r.x = wfe_weak(F + wfe_neg2(2u * D, k), k);            // 4 → 1
-  r.y = wfe_weak(wfe_mul(E, D + wfe_neg1(r.x, k), k) + wfe_neg8(8u * C, k), k);  // in 3,3; 10 → 1
-  r.z = wfe_mul(2u * p.y, p.z, k);
+  r.y = wfe_weak(wfe_mul<INL>(E, D + wfe_neg1(r.x, k), k) + wfe_neg8(8u * C, k), k);  // in 3,3; 10 → 1
+  r.z = wfe_mul<INL>(2u * p.y, p.z, k);
   r.inf = p.inf;
   return r;
 }
 // add-2007-bl with the exceptional cases (P = Q, P = −Q, ∞) resolved per row
+template <bool INL = false>
 WVF wjac wjac_add(const wjac &p, const wjac &q, const wk &k) {
-  const uint32_t z1z1 = wfe_sqr(p.z, k), z2z2 = wfe_sqr(q.z, k);
-  const uint32_t u1 = wfe_mul(p.x, z2z2, k), u2 = wfe_mul(q.x, z1z1, k);
-  const uint32_t s1 = wfe_mul(wfe_mul(p.y, q.z, k), z2z2, k);
-  const uint32_t s2 = wfe_mul(wfe_mul(q.y, p.z, k), z1z1, k);
+  const uint32_t z1z1 = wfe_sqr<INL>(p.z, k), z2z2 = wfe_sqr<INL>(q.z, k);
+  const uint32_t u1 = wfe_mul<INL>(p.x, z2z2, k), u2 = wfe_mul<INL>(q.x, z1z1, k);
+  const uint32_t s1 = wfe_mul<INL>(wfe_mul<INL>(p.y, q.z, k), z2z2, k);
+  const uint32_t s2 = wfe_mul<INL>(wfe_mul<INL>(q.y, p.z, k), z1z1, k);
   const uint32_t h = u2 + wfe_neg1(u1, k);   // 3
   const uint32_t rr = s2 + wfe_neg1(s1, k);  // 3
-  const uint32_t i = wfe_sqr(2u * h, k);     // in 6
-  const uint32_t j = wfe_mul(h, i, k);
+  const uint32_t i = wfe_sqr<INL>(2u * h, k);     // in 6
+  const uint32_t j = wfe_mul<INL>(h, i, k);
   const uint32_t r2 = 2u * rr;               // 6
-  const uint32_t v = wfe_mul(u1, i, k);
+  const uint32_t v = wfe_mul<INL>(u1, i, k);
   wjac r;
-  r.x = wfe_weak(wfe_sqr(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);                 // 6 → 1
-  const uint32_t s1j2 = 2u * wfe_mul(s1, j, k);                                            // 2
-  r.y = wfe_weak(wfe_mul(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(s1j2, k), k);              // 4 → 1
-  const uint32_t zz = wfe_sqr(p.z + q.z, k) + wfe_neg1(z1z1, k) + wfe_neg1(z2z2, k);        // 5
-  r.z = wfe_mul(zz, h, k);
+  r.x = wfe_weak(wfe_sqr<INL>(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);                 // 6 → 1
+  const uint32_t s1j2 = 2u * wfe_mul<INL>(s1, j, k);                                            // 2
+  r.y = wfe_weak(wfe_mul<INL>(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(s1j2, k), k);              // 4 → 1
+  const uint32_t zz = wfe_sqr<INL>(p.z + q.z, k) + wfe_neg1(z1z1, k) + wfe_neg1(z2z2, k);        // 5
+  r.z = wfe_mul<INL>(zz, h, k);
   r.inf = false;
   const bool both = !p.inf && !q.inf;
   const bool hz = wfe_is_zero(h);
   bool rz = false;
   if (any(both && hz)) rz = wfe_is_zero(rr);
   const bool same = both && hz && rz, opposite = both && hz && !rz;
-  if (any(same)) r = wjac_select(same, wjac_dbl(p, k), r);
+  if (any(same)) r = wjac_select(same, wjac_dbl<false>(p, k), r);
   r = wjac_select(opposite, wjac_inf(), r);
   r = wjac_select(q.inf, p, r);
   r = wjac_select(p.inf, q, r);
   return r;
 }
 // madd-2007-bl (q affine, never infinity)
+template <bool INL = false>
 WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
-  const uint32_t z1z1 = wfe_sqr(p.z, k);
-  const uint32_t u2 = wfe_mul(q.x, z1z1, k);
-  const uint32_t s2 = wfe_mul(wfe_mul(q.y, p.z, k), z1z1, k);
+  const uint32_t z1z1 = wfe_sqr<INL>(p.z, k);
+  const uint32_t u2 = wfe_mul<INL>(q.x, z1z1, k);
+  const uint32_t s2 = wfe_mul<INL>(wfe_mul<INL>(q.y, p.z, k), z1z1, k);
   const uint32_t h = u2 + wfe_neg1(p.x, k);   // 3
   const uint32_t rr = s2 + wfe_neg2(p.y, k);  // 4 (p.y may be a negated table entry: magnitude ≤ 2)
-  const uint32_t hh = wfe_sqr(h, k);
+  const uint32_t hh = wfe_sqr<INL>(h, k);
   const uint32_t i = 4u * hh;                 // 4
-  const uint32_t j = wfe_mul(h, i, k);
+  const uint32_t j = wfe_mul<INL>(h, i, k);
   const uint32_t r2 = 2u * rr;                // 8
-  const uint32_t v = wfe_mul(p.x, i, k);
+  const uint32_t v = wfe_mul<INL>(p.x, i, k);
   wjac r;
-  r.x = wfe_weak(wfe_sqr(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);
-  const uint32_t y1j2 = 2u * wfe_mul(p.y, j, k);
-  r.y = wfe_weak(wfe_mul(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(y1j2, k), k);
-  r.z = wfe_weak(wfe_sqr(p.z + h, k) + wfe_neg1(z1z1, k) + wfe_neg1(hh, k), k);  // in 4; 5 → 1
+  r.x = wfe_weak(wfe_sqr<INL>(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);
+  const uint32_t y1j2 = 2u * wfe_mul<INL>(p.y, j, k);
+  r.y = wfe_weak(wfe_mul<INL>(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(y1j2, k), k);
+  r.z = wfe_weak(wfe_sqr<INL>(p.z + h, k) + wfe_neg1(z1z1, k) + wfe_neg1(hh, k), k);  // in 4; 5 → 1
   r.inf = false;
   const bool hz = wfe_is_zero(h);
   bool rz = false;
   if (any(!p.inf && hz)) rz = wfe_is_zero(rr);
   const bool same = !p.inf && hz && rz, opposite = !p.inf && hz && !rz;
   const wjac qj = wjac_from_aff(q, k);
-  if (any(same)) r = wjac_select(same, wjac_dbl(qj, k), r);
+  if (any(same)) r = wjac_select(same, wjac_dbl<false>(qj, k), r);
   r = wjac_select(opposite, wjac_inf(), r);
   r = wjac_select(p.inf, qj, r);
   return r;
@@ -382,54 +407,172 @@ WVF uint32_t wfe_sqrt_candidate(uint32_t a, const wk &k) {
   return wfe_sqr_n(t, 2, k);
 }
 
+// ---- √ on a spare row ------------------------------------------------------------------------------
+// The a^((p+1)/4) chain (secp::fe_sqrt_candidate) is 266 dependent multiplications — but it needs
+// only ONE row.  While rows 0..2 run the 64 prefix doublings (three wfe_mul each, below), row 3
+// feeds its own operands into the very same wfe_mul calls: chain step t = 3·i + j rides on call j
+// of doubling i.  Every step squares the running value except
+//   step   1    3    7   11   14   26   49   94  183 | 228  232  256  263      (266 steps in all)
+//   (i,j) 0,1  1,0  2,1  3,2  4,2  8,2 16,1 31,1 61,0 | after the loop (sqrt_side_tail)
+//   by     a    a   x3   x3   x2  x11  x22  x44  x88 | x44   x3  x22   x2
+//   save  x2   x3    –    –  x11  x22  x44  x88    – |   –    –    –    –
+// so only the doublings i ∈ {0,1,2,3,4,8,16,31,61} (SPECIAL) carry the operand selects.
+struct sqrt_side {
+  uint32_t cur, a, x2, x3, x11, x22, x44, x88;  // row-3 values (other rows: don't care)
+};
+HD sqrt_side sqrt_side_init(uint32_t a) { return sqrt_side{a, a, 0u, 0u, 0u, 0u, 0u, 0u}; }
+HD bool sqrt_side_special(int i) { return ((0x200000008001011Full >> i) & 1ull) != 0; }  // bits 0,1,2,3,4,8,16,31,61
+
+// one wfe_mul shared by the doubling (rows 0..2: a·b) and the chain (row 3); i is wave-uniform
+template <int J, bool SPECIAL>
+WVF uint32_t mul_with_side(uint32_t a, uint32_t b, sqrt_side &sd, int i, const wk &k) {
+  uint32_t so = sd.cur;
+  if (SPECIAL) {
+    if (J == 0) {
+      so = i == 1 ? sd.a : so;
+      so = i == 61 ? sd.x88 : so;
+    } else if (J == 1) {
+      so = i == 0 ? sd.a : so;
+      so = i == 2 ? sd.x3 : so;
+      so = i == 16 ? sd.x22 : so;
+      so = i == 31 ? sd.x44 : so;
+    } else {
+      so = i == 3 ? sd.x3 : so;
+      so = i == 4 ? sd.x2 : so;
+      so = i == 8 ? sd.x11 : so;
+    }
+  }
+  const bool side = k.row == 3;
+  const uint32_t m = wfe_mul<true>(side ? sd.cur : a, side ? so : b, k);
+  sd.cur = m;
+  if (SPECIAL) {
+    if (J == 0) {
+      sd.x3 = i == 1 ? m : sd.x3;
+    } else if (J == 1) {
+      sd.x2 = i == 0 ? m : sd.x2;
+      sd.x44 = i == 16 ? m : sd.x44;
+      sd.x88 = i == 31 ? m : sd.x88;
+    } else {
+      sd.x11 = i == 4 ? m : sd.x11;
+      sd.x22 = i == 8 ? m : sd.x22;
+    }
+  }
+  return m;
+}
+// steps 192..265 (after 64 doublings): 36 squarings, ·x44, 3, ·x3, 23, ·x22, 6, ·x2, 2
+WVF uint32_t sqrt_side_tail(const sqrt_side &sd, const wk &k) {
+  uint32_t t = wfe_mul(wfe_sqr_n(sd.cur, 36, k), sd.x44, k);
+  t = wfe_mul(wfe_sqr_n(t, 3, k), sd.x3, k);
+  t = wfe_mul(wfe_sqr_n(t, 23, k), sd.x22, k);
+  t = wfe_mul(wfe_sqr_n(t, 6, k), sd.x2, k);
+  return wfe_sqr_n(t, 2, k);
+}
+
+// ---- prefix doublings with the three rows working on ONE point ----------------------------------------
+// dbl-2009-l has three dependent levels of multiplications: {X², Y², 2Y·Z} → {B², (X+B)², (3A)²} →
+// {E·(D − X3)}.  Rows 0..2 take one product each, ds_bpermute moves the results between rows: three
+// wfe_mul per doubling instead of seven.  In: X, Y valid in rows 0..2 (replicated), Z valid in row 2.
+template <bool SPECIAL>
+WVF void prefix_dbl(uint32_t &X, uint32_t &Y, uint32_t &Z, sqrt_side &sd, int i, const wk &k) {
+  const bool r0 = k.row == 0, r1 = k.row == 1, r2 = k.row == 2;
+  // level 1: row 0: A = X², row 1: B = Y², row 2: Z3 = 2Y·Z
+  const uint32_t m1 = mul_with_side<0, SPECIAL>(r0 ? X : (r2 ? 2u * Y : Y), r0 ? X : (r2 ? Z : Y), sd, i, k);
+  // row 0 ← B (row 1), row 2 ← A (row 0)
+  const uint32_t v1 = lane_perm(m1, ((r0 ? 1u : (r2 ? 0u : k.row)) << 4) | k.li);
+  // level 2: row 0: C = B², row 1: (X + B)², row 2: F = (3A)²
+  const uint32_t o2 = r1 ? X + v1 : (r2 ? 3u * v1 : v1);  // magnitudes 1, 2, 3
+  const uint32_t m2 = mul_with_side<1, SPECIAL>(o2, o2, sd, i, k);
+  const uint32_t A = lane_perm(m1, k.li), C = lane_perm(m2, k.li);
+  const uint32_t T = lane_perm(m2, 16u | k.li), F = lane_perm(m2, 32u | k.li);
+  const uint32_t t = T + wfe_neg1(A, k) + wfe_neg1(C, k);    // 5
+  const uint32_t D = wfe_weak(2u * t, k);                    // 10 → 1
+  const uint32_t X3 = wfe_weak(F + wfe_neg2(2u * D, k), k);  // 4 → 1
+  // level 3 (every row): Y3 = E·(D − X3) − 8C
+  const uint32_t m3 = mul_with_side<2, SPECIAL>(3u * A, D + wfe_neg1(X3, k), sd, i, k);
+  X = X3;
+  Y = wfe_weak(m3 + wfe_neg8(8u * C, k), k);
+  Z = m1;  // row 2
+}
+// (X, Y, 1) → 2^ndbl·(X, Y, 1) in every row, and w^((p+1)/4) in every row — the latter only for
+// ndbl = 64, the schedule the chain is laid out on (tests use smaller ndbl to check the doublings)
+WVF void prefix_and_sqrt(uint32_t &X, uint32_t &Y, uint32_t &Z, uint32_t &root, uint32_t w, int ndbl, const wk &k) {
+  sqrt_side sd = sqrt_side_init(w);
+  Z = k.li == 0 ? 1u : 0u;
+#pragma unroll 1
+  for (int i = 0; i < ndbl; i++) {
+    if (sqrt_side_special(i))
+      prefix_dbl<true>(X, Y, Z, sd, i, k);
+    else
+      prefix_dbl<false>(X, Y, Z, sd, i, k);
+  }
+  const uint32_t rt = sqrt_side_tail(sd, k);
+  X = lane_perm(X, k.li);
+  Y = lane_perm(Y, k.li);
+  Z = lane_perm(Z, 32u | k.li);
+  root = lane_perm(rt, 48u | k.li);
+}
+
 // ---- the recover, one signature per wavefront -------------------------------------------------------
 // Same contract and rejection list as ibftk::recover_pubkey (recover_dev.h); every lane of the
 // wavefront passes the same (z, r, s, v) and gets the same answer.
 //
 // Row ρ computes the piece (half = ρ & 1, upper = ρ >> 1) of u2·R = k1·(±R) + k2·λ(±R): 64 bits of
 // the 128-bit |k_half| in signed radix-16 digits on the base 2^(64·upper)·(β^half·x, ±y), then
-// four of the u1·G window points; two row-xor additions join the four rows.
+// its share of the u1·G window points; two row-xor additions join the four rows.
+//
+// y = √(x³ + 7) is NOT on the critical path: with w = x³ + 7 the Jacobian triple (w·x, w², y)
+// is the point (x, y), and the a = 0 formulas never look at the curve constant, so everything up to
+// the G additions runs on (w·x, w², 1) — the isomorphic curve y² = x³ + 7w³ — and the accumulator's Z
+// is multiplied by y once the chain (computed by row 3 during the prefix doublings) has delivered it.
+// STOP < 99 cuts the function short after a stage (devtest timing breakdown only; addr then holds junk).
+template <int STOP = 99>
 WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
                             uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa) {
+#define WV_STAGE(n, keep)     \
+  if (STOP == (n)) {          \
+    addr[0] = (keep);         \
+    return ok;                \
+  }
   const wk k = wk_init();
   bool ok = ibftk::sig_in_range(r, s, v, flags);
-  // R = (r, y), y² = r³ + 7, parity(y) = v
   const fe rx = secp::fe_from_u256(r);
-  const uint32_t X = scatter(rx, k);
-  const uint32_t rhs = wfe_mul(wfe_sqr(X, k), X, k) + (k.li == 0 ? 7u : 0u);  // magnitude 2
-  const uint32_t Yc = wfe_sqrt_candidate(rhs, k);
-  ok = ok && wfe_is_zero(wfe_sqr(Yc, k) + wfe_neg2(rhs, k));
-  fe y = secp::fe_normalize(gather(Yc));
-  const fe yneg = secp::fe_normalize_weak(secp::fe_neg(y, 1));
-  y = secp::l26_select((y.n[0] & 1u) != v, yneg, y);
+  const uint32_t x = scatter(rx, k);
+  const uint32_t one = k.li == 0 ? 1u : 0u;
+  const uint32_t w = wfe_weak(wfe_mul(wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u), k);  // magnitude 1
+  const uint32_t X0 = wfe_mul(w, x, k), Y0 = wfe_sqr(w, k);
+  // prefix: 2^64·(X0, Y0, 1) on rows 0..2, √w on row 3
+  uint32_t PX = X0, PY = Y0, PZ, yc;
+  prefix_and_sqrt(PX, PY, PZ, yc, w, 64, k);
+  WV_STAGE(1, PX ^ PY ^ PZ ^ yc)
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
   const secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   const secp::glv_split sp = secp::sc_split_lambda(u2);
+  WV_STAGE(2, PX ^ PY ^ PZ ^ yc ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
   const bool half = (k.row & 1u) != 0, upper = (k.row & 2u) != 0;
   // signed radix-16 digits of this row's |k|: k + 0x88…8 has nibbles d_j + 8, bit 128 is the top digit
-  uint32_t w[5];
+  uint32_t dw[5];
   {
     const u256 &kk = half ? sp.k2 : sp.k1;
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = secp::addc(kk.v[i], 0x88888888u, c);
-    w[4] = c;
+    for (int i = 0; i < 4; i++) dw[i] = secp::addc(kk.v[i], 0x88888888u, c);
+    dw[4] = c;
   }
-  const uint32_t d_lo = upper ? w[2] : w[0], d_hi = upper ? w[3] : w[1];
-  const bool top = upper && w[4] != 0;
-  // this row's base point
-  const bool negy = half ? sp.neg2 : sp.neg1;
-  const fe ysel = secp::l26_select(negy, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
-  const fe xsel = secp::l26_select(half, secp::fe_mul(rx, secp::GLV_CONST(1)), rx);
-  wjac base = wjac{scatter(xsel, k), scatter(ysel, k), k.li == 0 ? 1u : 0u, false};
+  const uint32_t d_lo = upper ? dw[2] : dw[0], d_hi = upper ? dw[3] : dw[1];
+  const bool top = upper && dw[4] != 0;
+  // this row's base: (β^half · X, ±Y, Z) of the point or of its 2^64-multiple
+  wjac base;
+  const uint32_t beta = scatter(secp::GLV_CONST(1), k);
+  base.x = wfe_mul(upper ? PX : X0, half ? beta : one, k);
+  base.y = upper ? PY : Y0;
   {
-    wjac b64 = base;
-#pragma unroll 1
-    for (int i = 0; i < 64; i++) b64 = wjac_dbl(b64, k);
-    base = wjac_select(upper, b64, base);
+    const uint32_t yn = wfe_weak(wfe_neg1(base.y, k), k);  // cross-lane ops: computed by every row, then selected
+    base.y = (half ? sp.neg2 : sp.neg1) ? yn : base.y;
   }
+  base.z = upper ? PZ : one;
+  base.inf = false;
   // table 1..8 of the base
   wjac T[9];
   T[1] = base;
@@ -440,11 +583,12 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   T[6] = wjac_dbl(T[3], k);
   T[7] = wjac_add(T[6], T[1], k);
   T[8] = wjac_dbl(T[4], k);
+  WV_STAGE(3, T[3].x ^ T[5].y ^ T[6].z ^ T[7].x ^ T[8].y ^ yc ^ u1.v[0])
   wjac acc = wjac_select(top, T[1], wjac_inf());
 #pragma unroll 1
   for (int jd = 15; jd >= 0; jd--) {
 #pragma unroll 1
-    for (int d = 0; d < 4; d++) acc = wjac_dbl(acc, k);
+    for (int d = 0; d < 4; d++) acc = wjac_dbl<true>(acc, k);
     const uint32_t word = jd >= 8 ? d_hi : d_lo;
     const int dg = (int)((word >> (4 * (jd & 7))) & 15u) - 8;
     const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
@@ -452,9 +596,15 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
 #pragma unroll
     for (int e = 2; e <= 8; e++) q = wjac_select(mag == (uint32_t)e, T[e], q);
     q.y = dg < 0 ? wfe_neg1(q.y, k) : q.y;  // magnitude ≤ 2
-    const wjac sum = wjac_add(acc, q, k);
+    const wjac sum = wjac_add<true>(acc, q, k);
     acc = wjac_select(mag != 0, sum, acc);
   }
+  WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ yc ^ u1.v[0])
+  // back to the real curve: y² = w ?  parity(y) = v; Z ← Z·y
+  ok = ok && wfe_is_zero(wfe_sqr(yc, k) + wfe_neg1(w, k));
+  fe y = secp::fe_normalize(gather(yc));
+  y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
+  acc.z = wfe_mul(acc.z, scatter(y, k), k);
   // u1·G: the fixed-base windows are dealt to the rows
   constexpr int WPR = ibftk::GTAB_WINDOWS / 4;
 #pragma unroll 1
@@ -472,11 +622,14 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   }
   acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
   acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
+  WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
   const jac Q = wjac_gather(acc);
   ok = secp::jac_to_aff_fast(Qa, Q) && ok;
+  WV_STAGE(6, Qa.x.n[0] ^ Qa.y.n[1])
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
+#undef WV_STAGE
 }
 
 }  // namespace wv

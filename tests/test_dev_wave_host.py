@@ -57,3 +57,24 @@ def test_full_recover_matches_oracle(wh, oracle):
         assert (ok == ok[0]).all() and (addr == addr[0]).all(), "lanes of the wavefront disagree"
         return bool(ok[0]), addr[0].tobytes()
     WC.check_full_recover_matches_oracle(recover, oracle)
+
+
+def test_prefix_doublings_with_sqrt_on_the_spare_row(wh):
+    """prefix_dbl: rows 0..2 share ONE doubling (three multiplications instead of seven) on the
+    isomorphic curve (w·x, w², 1) while row 3 runs the √w chain through the same wfe_mul calls."""
+    from oracle import pyref
+    P = pyref.P
+    for k, nd in ((123456789, 0), (123456789, 1), (987654321987654321, 5), (31337, 64)):
+        x, y = pyref.pt_mul(k, pyref.G)
+        xl = np.array(WC.limbs(x), dtype=np.uint32)
+        out = np.zeros(256, dtype=np.uint32)
+        wh.wvh_prefix(xl.ctypes.data_as(ctypes.c_void_p), nd, out.ctypes.data_as(ctypes.c_void_p))
+        o = out.reshape(4, 4, 16)
+        px, py, pz = (WC.value(o[0, 0, :10]) % P, WC.value(o[1, 0, :10]) % P, WC.value(o[2, 2, :10]) % P)
+        if nd == 64:  # the √ chain is scheduled on exactly 64 doublings
+            assert all(WC.value(o[3, r, :10]) % P in (y, P - y) for r in range(4))
+        zi = pow(pz * y % P, -1, P)  # the true Z is Z'·y
+        assert (px * zi * zi % P, py * zi * zi * zi % P) == pyref.pt_mul(2**nd, (x, y))
+        assert all(WC.value(o[0, r, :10]) % P == px for r in range(4))
+        assert all(WC.value(o[1, r, :10]) % P == py for r in range(4))
+        assert all(WC.value(o[2, r, :10]) % P == pz for r in range(4))
