@@ -49,6 +49,14 @@ void dev_sc_sqr(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_sqr(sin_(a)
 void dev_sc_inv(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv(sin_(a))); }
 
 void dev_fe_inv_safegcd(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv_safegcd(fin(a))); }
+void dev_fe_inv_var(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv_safegcd_var(fin(a))); }
+void dev_sc_inv_var(const uint8_t *a, uint8_t *out) { secp::to_be32(out, secp::modinv_var<secp::ModN>(secp::from_be32(a))); }
+// one batch of variable-time divsteps against the constant-time one: returns 1 if (ζ, u, v, q, r) agree
+int dev_divsteps_agree(int32_t zeta, uint32_t f0, uint32_t g0) {
+  secp::trans2x2 a, b;
+  int32_t za = secp::divsteps_30(zeta, f0, g0, a), zb = secp::divsteps_30_var(zeta, f0, g0, b);
+  return za == zb && a.u == b.u && a.v == b.v && a.q == b.q && a.r == b.r;
+}
 void dev_sc_inv_safegcd(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv_safegcd(sin_(a))); }
 // GLV split: out = k1(32 BE) ‖ k2(32 BE), returns neg1 | neg2<<1
 int dev_glv_split(const uint8_t *k, uint8_t *out64) {

@@ -545,7 +545,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   prefix_and_sqrt(PX, PY, PZ, yc, w, 64, k);
   WV_STAGE(1, PX ^ PY ^ PZ ^ yc)
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
-  const secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));
+  const secp::sc rinv = secp::sc_from_u256(secp::modinv_var<secp::ModN>(r));  // one value per wavefront
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   const secp::glv_split sp = secp::sc_split_lambda(u2);
@@ -624,7 +624,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
   WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
   const jac Q = wjac_gather(acc);
-  ok = secp::jac_to_aff_fast(Qa, Q) && ok;
+  ok = secp::jac_to_aff_fast<true>(Qa, Q) && ok;  // every row holds the same point after the joins
   WV_STAGE(6, Qa.x.n[0] ^ Qa.y.n[1])
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);

@@ -101,6 +101,8 @@ def test_safegcd_inversion(dev):
         ap, an = a % P, a % N
         assert _c1(dev.dev_fe_inv_safegcd, b32(ap)) == (pow(ap, -1, P) if ap else 0)
         assert _c1(dev.dev_sc_inv_safegcd, b32(an)) == (pow(an, -1, N) if an else 0)
+        assert _c1(dev.dev_fe_inv_var, b32(ap)) == (pow(ap, -1, P) if ap else 0)
+        assert _c1(dev.dev_sc_inv_var, b32(an)) == (pow(an, -1, N) if an else 0)
 
 
 def test_glv_split_and_variable_base_mult(dev):
@@ -211,3 +213,15 @@ def test_recover_address_matches_oracle(dev, oracle):
             assert (ref is not None) == bool(ok), (i, fl)
             if ref is not None:
                 assert o.raw == ref, (i, fl)
+
+
+def test_variable_time_divsteps_match_constant_time(dev):
+    """divsteps_30_var strips runs of even g with one ctz; batch by batch it must produce the same
+    ζ and transition matrix as the constant-time form (all the update code is shared)."""
+    rng = np.random.default_rng(77)
+    dev.dev_divsteps_agree.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
+    cases = [(-1, 1, 0), (-1, 0xFFFFFC2F, 0), (5, 3, 2**31), (-7, 0xFFFFFFFF, 0xFFFFFFFF), (0, 1, 1), (-1, 1, 2**30)]
+    for _ in range(4000):
+        cases.append((int(rng.integers(-40, 40)), int(rng.integers(0, 2**32)) | 1, int(rng.integers(0, 2**32))))
+    for zeta, f0, g0 in cases:
+        assert dev.dev_divsteps_agree(zeta, f0, g0) == 1, (zeta, f0, g0)
