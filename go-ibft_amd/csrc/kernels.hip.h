@@ -245,18 +245,6 @@ __device__ __forceinline__ jac shfl_xor_jac(const jac &p, int off) {
   return r;
 }
 
-__device__ __forceinline__ jac shfl_xor_jac_bcast0(const jac &p) {  // lane 0's copy in every lane
-  jac r;
-#pragma unroll
-  for (int i = 0; i < 10; i++) {
-    r.x.n[i] = __builtin_amdgcn_readfirstlane(p.x.n[i]);
-    r.y.n[i] = __builtin_amdgcn_readfirstlane(p.y.n[i]);
-    r.z.n[i] = __builtin_amdgcn_readfirstlane(p.z.n[i]);
-  }
-  r.inf = __builtin_amdgcn_readfirstlane(p.inf ? 1 : 0) != 0;
-  return r;
-}
-
 template <int MODE, int G>
 __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) {
   constexpr int ROWS = 64 / G;                    // signatures per wavefront
@@ -293,7 +281,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
 
   bool ok = sig_in_range(r, s, v, a.flags);
   u256 u1, u2;
-  verify_scalars<G == 64>(z, r, s, u1, u2);
+  verify_scalars(z, r, s, u1, u2);
   const uint32_t *qt = a.qtab + QTAB_DWORDS_PER_VALIDATOR * (crypto ? (uint32_t)vi : a.dummy_validator);
   jac acc = secp::jac_inf();
 #pragma unroll 1
@@ -320,8 +308,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
     jac other = shfl_xor_jac(acc, off);
     acc = secp::jac_add(acc, other);
   }
-  if (G == 64) acc = shfl_xor_jac_bcast0(acc);  // one representative: the inversion below is then wave-uniform
-  ok = verify_finish<G == 64>(acc, r, v) && ok && crypto;
+  ok = verify_finish(acc, r, v) && ok && crypto;
   if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 

@@ -58,20 +58,17 @@ __host__ __device__ __forceinline__ bool sig_in_range(const u256 &r, const u256 
 }
 
 // u1 = z/s, u2 = r/s (mod n), canonical
-// VAR: variable-time inversions — only where the whole wavefront holds one signature (G = 64)
-template <bool VAR = false>
 __host__ __device__ __forceinline__ void verify_scalars(const u256 &z_raw, const u256 &r, const u256 &s, u256 &u1,
                                                         u256 &u2) {
-  secp::sc sinv = secp::sc_from_u256(VAR ? secp::modinv_var<secp::ModN>(s) : secp::modinv<secp::ModN>(s));
+  secp::sc sinv = secp::sc_from_u256(secp::modinv<secp::ModN>(s));
   u1 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), sinv));
   u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(r), sinv));
 }
 
 // final check on R' = u1·G + u2·Q
-template <bool VAR = false>
 __host__ __device__ __forceinline__ bool verify_finish(const jac &Rp, const u256 &r, uint32_t v) {
   aff A;
-  bool fin = secp::jac_to_aff_fast<VAR>(A, Rp);
+  bool fin = secp::jac_to_aff_fast(A, Rp);
   secp::fe rx = secp::fe_from_u256(r);  // r < n < p: canonical limbs
   uint32_t diff = 0;
 #pragma unroll
