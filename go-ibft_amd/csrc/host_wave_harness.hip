@@ -112,9 +112,51 @@ void lane_prefix(void *vp) {
   j->out[192 + l] = root;
 }
 
+struct inv_job {
+  const uint8_t *x32;
+  uint8_t *out;  // [64][32]
+  int which;
+};
+void lane_inv(void *vp) {
+  inv_job *j = (inv_job *)vp;
+  const wv::wk k = wv::wk_init();
+  const u256 x = secp::from_be32(j->x32);
+  const u256 r = j->which == 0 ? wv::modinv_wave<secp::ModP>(x, k) : wv::modinv_wave<secp::ModN>(x, k);
+  secp::to_be32(j->out + 32 * wave_emul::lane(), r);
+}
+
+struct vk_job {
+  const uint32_t *qtab;
+  const uint8_t *hash32, *sig65;
+  uint32_t flags;
+  int *ok;  // [64]
+};
+void lane_vk(void *vp) {
+  vk_job *j = (vk_job *)vp;
+  u256 z = secp::from_be32(j->hash32), r = secp::from_be32(j->sig65), s = secp::from_be32(j->sig65 + 32);
+  bool ok = wv::verify_known_wave(g_gtab.data(), j->qtab, z, r, s, j->sig65[64], j->flags);
+  j->ok[wave_emul::lane()] = ok ? 1 : 0;
+}
+
 }  // namespace
 
 extern "C" {
+// per-validator fixed-base table (32 windows × 256 entries × 20 dwords) for the public key X‖Y (64 BE bytes)
+void wvh_build_qtab(const uint8_t *pub64, uint32_t *qtab) {
+  secp::aff Q;
+  Q.x = secp::fe_from_u256(secp::from_be32(pub64));
+  Q.y = secp::fe_from_u256(secp::from_be32(pub64 + 32));
+  for (int w = 0; w < ibftk::QTAB_WINDOWS; w++)
+    ibftk::qtab_build_window(Q, w, qtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ibftk::QTAB_ENTRIES * w, true);
+}
+void wvh_modinv(int which, const uint8_t *x32, uint8_t *out64x32) {
+  inv_job j{x32, out64x32, which};
+  wave_emul::run(lane_inv, &j);
+}
+void wvh_verify_known(const uint32_t *qtab, const uint8_t *hash32, const uint8_t *sig65, uint32_t flags, int *ok64) {
+  vk_job j{qtab, hash32, sig65, flags, ok64};
+  wave_emul::run(lane_vk, &j);
+}
 void wvh_prefix(const uint32_t *x10, int ndbl, uint32_t *out256) {
   pre_job j{x10, out256, ndbl};
   wave_emul::run(lane_prefix, &j);

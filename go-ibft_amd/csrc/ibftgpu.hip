@@ -194,7 +194,12 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   else                                                                                                         \
     hipLaunchKernelGGL((ibftk::verify_known_group_kernel<1, GG>), grid, block, 0, c->stream, a);
       switch (G) {
-        case 64: IBFT_LAUNCH_GROUP(64) break;
+        case 64:
+          if (mode == 0)
+            hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<0>, dim3(n), block, 0, c->stream, a);
+          else
+            hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<1>, dim3(n), block, 0, c->stream, a);
+          break;
         case 32: IBFT_LAUNCH_GROUP(32) break;
         case 16: IBFT_LAUNCH_GROUP(16) break;
         case 8: IBFT_LAUNCH_GROUP(8) break;

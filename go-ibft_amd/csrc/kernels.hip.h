@@ -10,7 +10,8 @@
 //   ecrecover_group_kernel<G>   a3  IsValidValidator      (core/ibft.go:1128)     1 / 2,4,8 lanes per signature
 //   ecrecover_wave_kernel           same, one wavefront per signature (limbs spread over lanes, wave_fe_dev.h)
 //   verify_known_lane_kernel    a2/a3 against the validator's known key (warm path), 1 lane per signature
-//   verify_known_group_kernel<G>    same, G = 2..64 lanes per signature (64 = one wavefront per signature)
+//   verify_known_group_kernel<G>    same, G = 2..32 lanes per signature
+//   verify_known_wave_kernel        same, one wavefront per signature in the row layout of wave_fe_dev.h
 //   tally_kernel                a8  HasQuorum             (core/validator_manager.go:77-96)
 //   gtab_build_kernel, qtab_build_kernel, qtab_commit_kernel   one-time fixed-base tables
 //   lookup_kernel                   sender → validator index for ibft_tally()
@@ -310,6 +311,38 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
   }
   ok = verify_finish(acc, r, v) && ok && crypto;
   if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+}
+
+// ---- warm path, one wavefront per signature with the limbs spread over lanes (wave_fe_dev.h) ----
+// Replaces verify_known_group_kernel<·,64>: same prologue, the point sum runs in the row layout.
+template <int MODE>
+__global__ void __launch_bounds__(64) verify_known_wave_kernel(recover_args a) {
+  const uint32_t row = blockIdx.x;
+  const bool pre = a.pre_flags && a.pre_flags[row] != 0;
+  const u256 r = secp::from_be32(a.sig65 + 65ull * row);
+  const u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
+  const uint32_t v = a.sig65[65ull * row + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(a.hash32 + 32ull * row);
+  } else {
+    uint64_t d[4];
+    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    keccak::digest_to_limbs(d, z.v);
+  }
+  uint32_t want[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
+  const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
+  const bool decided = pre || vi < 0 || have_table;
+  if (threadIdx.x == 0) {
+    a.warm_done[row] = decided ? 1 : 0;
+    if (decided) a.vidx[row] = vi;
+  }
+  if (pre || !have_table) return;  // wave-uniform: the wavefront holds one row
+  const bool ok = wv::verify_known_wave(a.gtab, a.qtab + QTAB_DWORDS_PER_VALIDATOR * (uint32_t)vi, z, r, s, v, a.flags);
+  if (threadIdx.x == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 
 // ---- cold path with G = 2, 4 or 8 lanes per signature ----------------------------------------

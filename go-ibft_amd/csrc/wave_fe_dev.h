@@ -512,6 +512,88 @@ WVF void prefix_and_sqrt(uint32_t &X, uint32_t &Y, uint32_t &Z, uint32_t &root, 
   root = lane_perm(rt, 48u | k.li);
 }
 
+// ---- modular inversion with the limbs of d, e, f, g spread over lanes ---------------------------------
+// safegcd as in modinv_dev.h, for ONE value per wavefront.  The 30 divsteps of a batch look only at
+// the low words and stay scalar-like (every lane computes the same 2×2 matrix, variable-time form);
+// but applying the matrix to the four 9-limb numbers — two thirds of the lane-layout cost — becomes
+// four/six v_mad_i64_i32 per lane: lane i holds limb i (radix 2^30, signed) of d, e, f and g.
+// Carries are not rippled: column c_i = lo30 + 2^30·hi gives limb_j = lo_{j+1} + hi_j, one more
+// parallel pass leaves limbs in [−4, 2^30 + 4) (top limb unmasked) — bounded, not canonical, which is
+// all the next batch needs (only f, g mod 2^30 and the sign of the top limbs of d, e are read).
+template <int WITH_MOD>
+WVF int32_t modinv_wave_apply(int32_t m1, int32_t a, int32_t m2, int32_t b, int32_t mod_limb, int32_t mm,
+                              const wk &k) {
+  int64_t c = (int64_t)m1 * a + (int64_t)m2 * b;
+  if (WITH_MOD) c += (int64_t)mod_limb * mm;
+  const uint32_t lo = (uint32_t)c & (uint32_t)secp::M30;
+  const int64_t n = (int64_t)row_shl<1>(lo) + (c >> 30);  // limb j = lo_{j+1} + hi_j  (exact: lo_0 = 0)
+  const bool top = k.li >= 8;
+  const int32_t carry = top ? 0 : (int32_t)(n >> 30);
+  const int32_t keep = top ? (int32_t)n : (int32_t)((uint32_t)n & (uint32_t)secp::M30);
+  return keep + (int32_t)row_shr<1>((uint32_t)carry);
+}
+template <class MOD>
+WVF u256 modinv_wave(const u256 &x, const wk &k) {
+  const secp::s30 xs = secp::s30_from_u256(x);
+  int32_t f = 0, g = 0, d = 0, e = k.li == 0 ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    f = k.li == (uint32_t)i ? MOD::limb(i) : f;
+    g = k.li == (uint32_t)i ? xs.v[i] : g;
+  }
+  const int32_t mod_limb = f;
+  int32_t zeta = -1;
+#pragma unroll 1
+  for (int b = 0; b < 20; b++) {
+    secp::trans2x2 t;
+    zeta = secp::divsteps_30_var(zeta, row_bcast<0>((uint32_t)f), row_bcast<0>((uint32_t)g), t);
+    // (d, e) ← t·(d, e)/2^30 mod M: the multiple of M that makes it divisible (modinv_dev.h:update_de_30)
+    const int32_t d0 = (int32_t)row_bcast<0>((uint32_t)d), e0 = (int32_t)row_bcast<0>((uint32_t)e);
+    const int32_t sd = (int32_t)row_bcast<8>((uint32_t)d) >> 31, se = (int32_t)row_bcast<8>((uint32_t)e) >> 31;
+    int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+    const uint32_t cd0 = (uint32_t)t.u * (uint32_t)d0 + (uint32_t)t.v * (uint32_t)e0;
+    const uint32_t ce0 = (uint32_t)t.q * (uint32_t)d0 + (uint32_t)t.r * (uint32_t)e0;
+    md -= (int32_t)((MOD::inv30() * cd0 + (uint32_t)md) & (uint32_t)secp::M30);
+    me -= (int32_t)((MOD::inv30() * ce0 + (uint32_t)me) & (uint32_t)secp::M30);
+    const int32_t nd = modinv_wave_apply<1>(t.u, d, t.v, e, mod_limb, md, k);
+    const int32_t ne = modinv_wave_apply<1>(t.q, d, t.r, e, mod_limb, me, k);
+    const int32_t nf = modinv_wave_apply<0>(t.u, f, t.v, g, 0, 0, k);
+    const int32_t ng = modinv_wave_apply<0>(t.q, f, t.r, g, 0, 0, k);
+    d = nd;
+    e = ne;
+    f = nf;
+    g = ng;
+    if (!any(g != 0)) break;
+  }
+  // collect d (and the sign of f = ±1: −1 ≡ 3 mod 4 whatever the limb form), ripple the carries once
+  secp::s30 D;
+  D.v[0] = (int32_t)row_bcast<0>((uint32_t)d);
+  D.v[1] = (int32_t)row_bcast<1>((uint32_t)d);
+  D.v[2] = (int32_t)row_bcast<2>((uint32_t)d);
+  D.v[3] = (int32_t)row_bcast<3>((uint32_t)d);
+  D.v[4] = (int32_t)row_bcast<4>((uint32_t)d);
+  D.v[5] = (int32_t)row_bcast<5>((uint32_t)d);
+  D.v[6] = (int32_t)row_bcast<6>((uint32_t)d);
+  D.v[7] = (int32_t)row_bcast<7>((uint32_t)d);
+  D.v[8] = (int32_t)row_bcast<8>((uint32_t)d);
+  const bool fneg = (row_bcast<0>((uint32_t)f) & 3u) == 3u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    D.v[i + 1] += D.v[i] >> 30;
+    D.v[i] &= secp::M30;
+  }
+  secp::normalize_30<MOD>(D, fneg);
+  return secp::s30_to_u256(D);
+}
+// Jacobian (lane layout, the same in every lane) → affine; r.x / r.y canonical; false for infinity
+WVF bool jac_to_aff_wave(aff &r, const jac &p, const wk &k) {
+  const fe zi = secp::fe_from_u256(modinv_wave<secp::ModP>(secp::fe_to_u256(p.z), k));
+  const fe zi2 = secp::fe_sqr(zi);
+  r.x = secp::fe_normalize(secp::fe_mul(p.x, zi2));
+  r.y = secp::fe_normalize(secp::fe_mul(p.y, secp::fe_mul(zi2, zi)));
+  return !(p.inf || secp::fe_is_zero(p.z));
+}
+
 // ---- the recover, one signature per wavefront -------------------------------------------------------
 // Same contract and rejection list as ibftk::recover_pubkey (recover_dev.h); every lane of the
 // wavefront passes the same (z, r, s, v) and gets the same answer.
@@ -545,7 +627,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   prefix_and_sqrt(PX, PY, PZ, yc, w, 64, k);
   WV_STAGE(1, PX ^ PY ^ PZ ^ yc)
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
-  const secp::sc rinv = secp::sc_from_u256(secp::modinv_var<secp::ModN>(r));  // one value per wavefront
+  const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   const secp::glv_split sp = secp::sc_split_lambda(u2);
@@ -624,12 +706,64 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
   WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
   const jac Q = wjac_gather(acc);
-  ok = secp::jac_to_aff_fast<true>(Qa, Q) && ok;  // every row holds the same point after the joins
+  ok = jac_to_aff_wave(Qa, Q, k) && ok;  // every row holds the same point after the joins
   WV_STAGE(6, Qa.x.n[0] ^ Qa.y.n[1])
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
 #undef WV_STAGE
+}
+
+// ---- the warm path, one signature per wavefront --------------------------------------------------------
+// Same contract as ibftk::verify_known (verify_dev.h): accept ⇔ R′ = (z/s)·G + (r/s)·Q is finite,
+// R′.x = r and parity(R′.y) = v.  The 32 + GTAB_WINDOWS table points are dealt to the four rows;
+// a row adds its share with mixed additions (11 multiplications of ≈72 instructions for the four
+// rows together, against 11 × 224 per lane in the lane layout), two row-xor additions join them.
+WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
+  const uint32_t ld = k.li < 10 ? k.li : 0u;
+  waff pt;
+  pt.x = e20[ld] & k.act;
+  pt.y = e20[10 + ld] & k.act;
+  return pt;
+}
+WVF bool verify_known_wave(const uint32_t *__restrict__ gtab, const uint32_t *__restrict__ qtab_v, const u256 &z_raw,
+                           const u256 &r, const u256 &s, uint32_t v, uint32_t flags) {
+  const wk k = wk_init();
+  const bool ok = ibftk::sig_in_range(r, s, v, flags);
+  // u1 = z/s, u2 = r/s (mod n)
+  const secp::sc sinv = secp::sc_from_u256(modinv_wave<secp::ModN>(s, k));
+  const u256 u1 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), sinv));
+  const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(r), sinv));
+  constexpr int POINTS = ibftk::QTAB_WINDOWS + ibftk::GTAB_WINDOWS;
+  static_assert(POINTS % 4 == 0, "points are dealt to four rows");
+  wjac acc = wjac_inf();
+#pragma unroll 1
+  for (int it = 0; it < POINTS / 4; it++) {
+    const int p = 4 * it + (int)k.row;  // rows interleave, so every row mixes Q- and G-table points
+    uint32_t dgt;
+    const uint32_t *entry;
+    if (p < ibftk::QTAB_WINDOWS) {
+      dgt = (u2.v[p >> 2] >> (8 * (p & 3))) & 255u;
+      entry = qtab_v + (size_t)ibftk::GTAB_ENTRY_DWORDS * (p * ibftk::QTAB_ENTRIES + dgt);
+    } else {
+      const int w = p - ibftk::QTAB_WINDOWS;
+      const int bit = w * ibftk::GTAB_BITS;
+      dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+      entry = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)w * ibftk::GTAB_ENTRIES + dgt);
+    }
+    const waff pt = load_waff(entry, k);
+    const wjac sum = wjac_add_aff<true>(acc, pt, k);
+    acc = wjac_select(dgt != 0, sum, acc);
+  }
+  acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
+  acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
+  aff A;
+  const bool fin = jac_to_aff_wave(A, wjac_gather(acc), k);
+  const fe rx = secp::fe_from_u256(r);  // r < n < p: canonical limbs
+  uint32_t diff = 0;
+#pragma unroll
+  for (int i = 0; i < 10; i++) diff |= A.x.n[i] ^ rx.n[i];
+  return fin && diff == 0 && (A.y.n[0] & 1u) == v && ok;
 }
 
 }  // namespace wv

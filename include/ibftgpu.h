@@ -80,12 +80,18 @@ extern "C" {
 #define IBFT_ROW_BADLEN 0x02u
 #define IBFT_ROW_HASH_BAD 0x04u
 
-/* cfg.kernel: which ecrecover kernel the seal/sender paths launch */
+/* cfg.kernel: how many lanes work on one signature.  The verdicts never depend on it.
+ *   AUTO  cold path (recover): one wavefront per signature up to 2048 rows, then 8 / 4 / 2 lanes
+ *         per signature while rows*lanes <= 65536, one lane beyond;
+ *         warm path (known keys): G = 64,32,...,2 lanes per signature so that a batch gives about
+ *         one wavefront per SIMD (64 up to 1024 rows), one lane from 65536 rows.
+ *   LANE  always one lane per signature (throughput form, both paths).
+ *   WAVE  warm path pinned to one wavefront per signature.
+ * Experiments only: the environment variable IBFT_COLD_LANES = 1|2|4|8|64 pins the cold variant,
+ * IBFT_WAVE_ROWS_MAX moves the AUTO threshold of the one-wavefront form (read at ibft_ctx_create). */
 #define IBFT_KERNEL_AUTO 0u
-#define IBFT_KERNEL_LANE 1u /* warm path: one lane per signature (throughput at large N)       */
-#define IBFT_KERNEL_WAVE 2u /* warm path: one wavefront per signature (latency at small N).  AUTO
-                               uses G = 64,32,...,2,1 lanes per signature so that a batch gives
-                               about one wavefront per SIMD: 64 up to 1024 rows, 1 from 65536.   */
+#define IBFT_KERNEL_LANE 1u
+#define IBFT_KERNEL_WAVE 2u
 
 typedef struct ibft_ctx ibft_ctx;
 

@@ -78,3 +78,57 @@ def test_prefix_doublings_with_sqrt_on_the_spare_row(wh):
         assert all(WC.value(o[0, r, :10]) % P == px for r in range(4))
         assert all(WC.value(o[1, r, :10]) % P == py for r in range(4))
         assert all(WC.value(o[2, r, :10]) % P == pz for r in range(4))
+
+
+def test_warm_verify_in_the_row_layout(wh, oracle):
+    """verify_known_wave: R′ = (z/s)·G + (r/s)·Q from table points dealt to the four rows; verdicts
+    must equal 'the recovered address is the key's address' for good, corrupted and wrong-key rows."""
+    import random
+    from oracle import pyref
+    wh.wvh_init_gtab()
+    rng = random.Random(19)
+    sk = rng.randrange(1, pyref.N).to_bytes(32, "big")
+    pub = oracle.pubkey(sk)
+    qtab = np.zeros(32 * 256 * 20, dtype=np.uint32)
+    wh.wvh_build_qtab(pub, qtab.ctypes.data_as(ctypes.c_void_p))
+
+    def verify(h, sig, flags=0):
+        ok = np.zeros(64, dtype=np.int32)
+        wh.wvh_verify_known(qtab.ctypes.data_as(ctypes.c_void_p), h, sig, flags, ok.ctypes.data_as(ctypes.c_void_p))
+        assert (ok == ok[0]).all()
+        return bool(ok[0])
+    addr = oracle.address(pub)
+    for it in range(4):
+        h = rng.randrange(2**256).to_bytes(32, "big")
+        sig = oracle.sign(sk, h)
+        assert verify(h, sig) is True
+        bad = bytearray(sig)
+        bad[40] ^= 1                                     # s changed: recovers some other key
+        assert verify(h, bytes(bad)) == (oracle.recover_address(h, bytes(bad)) == addr) is False
+        flip = bytearray(sig)
+        flip[64] ^= 1                                    # wrong parity
+        assert verify(h, bytes(flip)) is False
+        other = oracle.sign(rng.randrange(1, pyref.N).to_bytes(32, "big"), h)
+        assert verify(h, other) is False                 # valid signature of another key
+        hs = bytearray(sig)                              # high-s twin: accepted unless strict
+        s_ = pyref.N - int.from_bytes(sig[32:64], "big")
+        hs[32:64] = s_.to_bytes(32, "big")
+        hs[64] ^= 1
+        assert verify(h, bytes(hs)) is True
+        low = int.from_bytes(sig[32:64], "big") <= (pyref.N - 1) // 2
+        assert verify(h, bytes(hs), 1) is (not low) and verify(h, sig, 1) is low
+
+
+def test_lane_parallel_modular_inverse(wh):
+    """modinv_wave: safegcd with the limbs of d, e, f, g spread over lanes (carry-save updates)."""
+    import random
+    from oracle import pyref
+    rng = random.Random(23)
+    for which, m in ((0, pyref.P), (1, pyref.N)):
+        xs = [0, 1, 2, m - 1, m - 2, (m + 1) // 2, 2**255 % m, 2**30, 2**30 - 1, 2**240, 3] + \
+            [rng.randrange(m) for _ in range(60)] + [rng.randrange(m) >> sh for sh in range(3, 250, 17)]
+        for x in xs:
+            out = np.zeros((64, 32), dtype=np.uint8)
+            wh.wvh_modinv(which, x.to_bytes(32, "big"), out.ctypes.data_as(ctypes.c_void_p))
+            assert (out == out[0]).all()
+            assert int.from_bytes(out[0].tobytes(), "big") == (pow(x, -1, m) if x else 0), (which, hex(x))
