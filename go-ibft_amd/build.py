@@ -45,7 +45,7 @@ def build_devtest(force: bool = False) -> str:
 
 def build_host_harness(force: bool = False) -> str:
     """TEST-ONLY: the device arithmetic headers compiled for the CPU (hipcc host pass)."""
-    deps = ["host_arith_harness.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h"]
+    deps = ["host_arith_harness.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h", "wire_dev.h", "verify_dev.h"]
     if force or _stale(HOST_HARNESS, deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
                                "-o", HOST_HARNESS, os.path.join(CSRC, "host_arith_harness.hip")], cwd=CSRC)

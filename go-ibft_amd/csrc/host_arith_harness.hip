@@ -13,6 +13,7 @@
 #include "recover_dev.h"
 #include "verify_dev.h"
 #include "modinv_dev.h"
+#include "wire_dev.h"
 
 using secp::u256;
 
@@ -161,5 +162,13 @@ uint32_t dev_addr_hash(const uint8_t *addr20) {
   uint32_t a[5];
   memcpy(a, addr20, 20);
   return ibftk::addr_hash(a);
+}
+
+// §8f rank 3: the device wire walker on the CPU.  out: row_info (80 B) ‖ digest (32) ‖ sig (65) ‖ from (20)
+// ‖ seal (65) ‖ pre_flag (1) = 263 bytes
+void dev_wire_row(const uint8_t *m, uint32_t n, uint8_t *out263) {
+  wire::row_info ri;
+  wire::process_row(m, n, &ri, out263 + 80, out263 + 112, out263 + 177, out263 + 197, out263 + 262);
+  memcpy(out263, &ri, 80);
 }
 }

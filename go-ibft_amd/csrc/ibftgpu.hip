@@ -39,6 +39,9 @@ struct ibft_ctx {
   // columns in HBM
   DevBuf d_hash, d_sig, d_signer, d_pre, d_hash_len, d_payload, d_off, d_raw;
   DevBuf d_mask, d_vidx, d_tally, d_H;
+  DevBuf d_wire_rows, d_seal;  // §8f rank 3: per-row parse results and the COMMIT seals found in the wire bytes
+  uint32_t wire_n = 0;         // rows of the last ibft_verify_senders_wire
+  bool wire_valid = false;     // its columns are still the resident ones
   // fixed-base table for G
   DevBuf d_gtab;
   // validator table
@@ -513,6 +516,7 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
   if (raw_len) memcpy(msg.data(), raw, raw_len);
   for (int i = 0; i < 8; i++) msg[raw_len + i] = (uint8_t)(round >> (8 * (7 - i)));
   int rc;
+  c->wire_valid = false;
   if ((rc = upload(c, c->d_raw, msg.data(), msg.size()))) return rc;
   if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
   if ((rc = upload(c, c->d_hash_len, hash_len, n))) return rc;
@@ -534,6 +538,7 @@ static int seals_stage_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t 
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  c->wire_valid = false;
   if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
   if ((rc = upload(c, c->d_sig, sig65, n * 65))) return rc;
   if ((rc = upload(c, c->d_signer, signer20, n * 20))) return rc;
@@ -662,6 +667,7 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
+  c->wire_valid = false;
   size_t pbytes = n ? off[n] : 0;
   if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
   if (pbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, payload, pbytes, hipMemcpyHostToDevice, c->stream));
@@ -677,6 +683,60 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
   return fetch_results(c, (uint32_t)n, out_mask, tally, true);
 }
 
+int ibft_verify_senders_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint32_t *off, size_t n, uint64_t *out_mask,
+                             ibft_wire_row_t *out_rows, ibft_tally_t *tally) {
+  static_assert(sizeof(ibft_wire_row_t) == sizeof(wire::row_info), "ABI");
+  if (!c || (n && (!off || !out_mask))) return IBFT_E_INVAL;
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  const size_t wbytes = n ? off[n] : 0;
+  if ((rc = ensure(c, c->d_payload, wbytes + 256))) return rc;
+  if ((rc = ensure(c, c->d_wire_rows, (size_t)c->max_rows * sizeof(wire::row_info)))) return rc;
+  if ((rc = ensure(c, c->d_seal, (size_t)c->max_rows * 65 + 64))) return rc;
+  if (wbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, wire_bytes, wbytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = upload(c, c->d_off, off, (n + 1) * 4))) return rc;
+  c->staged_n = (uint32_t)n;
+  c->staged_pre = true;
+  c->wire_n = (uint32_t)n;
+  c->wire_valid = true;
+  c->ev_used = 0;
+  if (n) {
+    hipLaunchKernelGGL(ibftk::wire_parse_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
+                       (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n,
+                       (wire::row_info *)c->d_wire_rows.p, (uint8_t *)c->d_hash.p, (uint8_t *)c->d_sig.p,
+                       (uint8_t *)c->d_signer.p, (uint8_t *)c->d_seal.p, (uint8_t *)c->d_pre.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  // the digest column now holds keccak256(PayloadNoSig): the sender check is the seal-style pass (mode 0)
+  if ((rc = enqueue_recover(c, (uint32_t)n, true, 0, true))) return rc;
+  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  if (out_rows && n)
+    HIPCHK(c, hipMemcpyAsync(out_rows, c->d_wire_rows.p, n * sizeof(ibft_wire_row_t), hipMemcpyDeviceToHost, c->stream));
+  return fetch_results(c, (uint32_t)n, out_mask, tally, true);
+}
+
+int ibft_wire_stage_seals(ibft_ctx *c) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->wire_valid) return IBFT_E_INVAL;  // no parsed batch resident (another call restaged the columns)
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t n = c->wire_n;
+  if (n) {
+    hipLaunchKernelGGL(ibftk::wire_stage_seals_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                       (const wire::row_info *)c->d_wire_rows.p, (const uint8_t *)c->d_seal.p, n,
+                       (uint8_t *)c->d_hash.p, (uint8_t *)c->d_sig.p, (uint8_t *)c->d_pre.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  c->staged_pre = true;
+  return IBFT_OK;
+}
+
 int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, ibft_tally_t *tally) {
   if (!c || !tally || (n && (!sender20 || !mask))) return IBFT_E_INVAL;
   if (n > c->max_rows) return IBFT_E_TOOBIG;
@@ -685,6 +745,7 @@ int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_
   HIPCHK(c, hipSetDevice(c->device));
   // resolve sender -> validator index with a small lookup pass over the table in HBM
   int rc;
+  c->wire_valid = false;
   if ((rc = upload(c, c->d_signer, sender20, n * 20))) return rc;
   if ((rc = upload(c, c->d_mask, mask, (size_t)mask_words(n) * 8))) return rc;
   if (n) {

@@ -15,6 +15,7 @@
 //   tally_kernel                a8  HasQuorum             (core/validator_manager.go:77-96)
 //   gtab_build_kernel, qtab_build_kernel, qtab_commit_kernel   one-time fixed-base tables
 //   lookup_kernel                   sender → validator index for ibft_tally()
+//   wire_parse_kernel, wire_stage_seals_kernel   §8f rank 3: wire bytes → columns on the device (wire_dev.h)
 //
 // Layout in HBM: one contiguous byte column per field (hash N×32, sig N×65, signer N×20,
 // pre_flags N) — structure-of-arrays at field granularity.  The lane kernels stage a block's
@@ -29,6 +30,7 @@
 #include "recover_dev.h"
 #include "verify_dev.h"
 #include "wave_fe_dev.h"
+#include "wire_dev.h"
 
 namespace ibftk {
 
@@ -559,6 +561,34 @@ __global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restri
 __global__ void qtab_commit_kernel(uint8_t *__restrict__ pub_state, uint32_t n_validators) {
   uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n_validators && pub_state[v] == 1) pub_state[v] = 2;
+}
+
+// ---- §8f rank 3: IbftMessage wire bytes → verifier columns (wire_dev.h) -----------------------------
+// One lane per message: canonical-form walk, Keccak of PayloadNoSig, scatter into the columns.
+__global__ void wire_parse_kernel(const uint8_t *__restrict__ wire_bytes, const uint32_t *__restrict__ off, uint32_t n,
+                                  wire::row_info *__restrict__ rows, uint8_t *__restrict__ digest32,
+                                  uint8_t *__restrict__ sig65, uint8_t *__restrict__ from20,
+                                  uint8_t *__restrict__ seal65, uint8_t *__restrict__ pre_flags) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const uint32_t o0 = off[row], o1 = off[row + 1];
+  wire::process_row(wire_bytes + o0, o1 - o0, rows + row, digest32 + 32ull * row, sig65 + 65ull * row,
+                    from20 + 20ull * row, seal65 + 65ull * row, pre_flags + row);
+}
+// After the sender pass: make the COMMIT seals found by wire_parse_kernel the resident seal batch
+// (hash column ← proposal hash, signature column ← committed seal, From stays).  Rows that are not
+// canonical COMMIT messages with a 32-byte hash and a 65-byte seal are pre-flagged.
+__global__ void wire_stage_seals_kernel(const wire::row_info *__restrict__ rows, const uint8_t *__restrict__ seal65,
+                                        uint32_t n, uint8_t *__restrict__ hash32, uint8_t *__restrict__ sig65,
+                                        uint8_t *__restrict__ pre_flags) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const wire::row_info &ri = rows[row];
+  const bool ok = ri.status == wire::STATUS_OK && ri.payload_kind == wire::KIND_COMMIT && ri.type == 2 &&
+                  ri.hash_len == 32 && ri.seal_len == 65 && ri.from_len == 20;
+  for (int i = 0; i < 32; i++) hash32[32ull * row + i] = ri.proposal_hash[i];
+  for (int i = 0; i < 65; i++) sig65[65ull * row + i] = seal65[65ull * row + i];
+  pre_flags[row] = ok ? 0 : 1;
 }
 
 // ---- a8: weighted quorum tally ------------------------------------------------------------

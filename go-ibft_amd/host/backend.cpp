@@ -1,6 +1,8 @@
 // backend.cpp — see backend.hpp.
 #include "backend.hpp"
 
+#include <chrono>
+
 #include <cstring>
 
 namespace ibft {
@@ -112,6 +114,37 @@ bool GpuBackend::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<
                                 c.pre_flags.data(), c.n, mask.data(), nullptr);
   if (last_rc != IBFT_OK) return false;
   unpack_mask(mask, c.n, verdict);
+  return true;
+}
+
+bool GpuBackend::VerifySendersWire(const uint8_t *wire, const uint32_t *off, size_t n, std::vector<uint8_t> &verdict,
+                                   WireStats *stats) {
+  verdict.assign(n, 0);
+  if (n == 0) return true;
+  std::vector<uint64_t> mask((n + 63) / 64, 0);
+  std::vector<ibft_wire_row_t> rows(n);
+  last_rc = ibft_verify_senders_wire(ctx_, wire, off, n, mask.data(), rows.data(), nullptr);
+  if (last_rc != IBFT_OK) return false;
+  unpack_mask(mask, n, verdict);
+  // the rows the device would not vouch for: stock route
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<size_t> idx;
+  std::vector<MsgPtr> msgs;
+  for (size_t i = 0; i < n; i++) {
+    if (rows[i].status == IBFT_WIRE_OK) continue;
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode(wire + off[i], off[i + 1] - off[i], *m)) continue;  // proto.Unmarshal error: dropped
+    idx.push_back(i);
+    msgs.push_back(std::move(m));
+  }
+  if (stats) {
+    stats->host_rows = idx.size();
+    stats->host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  if (msgs.empty()) return true;
+  std::vector<uint8_t> v2;
+  if (!VerifySenderBatch(msgs, v2)) return false;
+  for (size_t j = 0; j < idx.size(); j++) verdict[idx[j]] = v2[j];
   return true;
 }
 

@@ -64,6 +64,18 @@ class GpuBackend : public BatchVerifier {
   bool VerifyPrepareBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifyCommitBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  // §8f rank 3: IsValidValidator for n messages straight from their wire bytes.  The device walks,
+  // hashes and verifies the PREPARE/COMMIT rows it can vouch for (ibft_verify_senders_wire); rows
+  // it flags (other payload kinds, unknown fields, non-canonical encodings) take the stock route —
+  // proto decode, PayloadNoSig re-marshal, ibft_verify_senders — and rows that do not decode are
+  // verdict 0 (the reference drops them before AddMessage).  Same verdicts as VerifySenderBatch on
+  // the decoded messages.  stats (optional): rows sent to the host route, host milliseconds.
+  struct WireStats {
+    size_t host_rows = 0;
+    double host_ms = 0.0;
+  };
+  bool VerifySendersWire(const uint8_t *wire, const uint32_t *off, size_t n, std::vector<uint8_t> &verdict,
+                         WireStats *stats = nullptr);
   int last_rc = 0;
 
  private:

@@ -6,6 +6,8 @@
 
 #include "backend.hpp"
 
+#include <chrono>
+
 using namespace ibft;
 
 namespace {
@@ -112,6 +114,45 @@ void ibft_host_free(ibft_host *h) { delete h; }
 void ibft_host_buf_free(ibft_host_buf *b) {
   if (b && b->data) free(b->data);
   if (b) *b = ibft_host_buf{nullptr, 0, 0};
+}
+
+int ibft_host_verify_senders_wire(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int mode,
+                                  uint8_t *verdict, double *host_ms, size_t *host_rows) {
+  if (!ctx || (n && (!off || !verdict))) return IBFT_E_INVAL;
+  GpuBackend gb(ctx);
+  std::vector<uint8_t> v;
+  GpuBackend::WireStats st;
+  if (mode == 0) {
+    if (!gb.VerifySendersWire(wire, off, n, v, &st)) return gb.last_rc ? gb.last_rc : IBFT_E_INVAL;
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<size_t> idx;
+    std::vector<MsgPtr> msgs;
+    for (size_t i = 0; i < n; i++) {
+      auto m = std::make_shared<IbftMessage>();
+      if (!decode(wire + off[i], off[i + 1] - off[i], *m)) continue;
+      idx.push_back(i);
+      msgs.push_back(std::move(m));
+    }
+    SenderColumns c;
+    flatten_senders(msgs, c);
+    st.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    st.host_rows = idx.size();
+    std::vector<uint8_t> v2(msgs.size(), 0);
+    if (!msgs.empty()) {
+      std::vector<uint64_t> mask((c.n + 63) / 64, 0);
+      const int rc = ibft_verify_senders(ctx, c.payload.data(), c.off.data(), c.sig65.data(), c.from20.data(),
+                                         c.pre_flags.data(), c.n, mask.data(), nullptr);
+      if (rc != IBFT_OK) return rc;
+      for (size_t j = 0; j < c.n; j++) v2[j] = (mask[j >> 6] >> (j & 63)) & 1;
+    }
+    v.assign(n, 0);
+    for (size_t j = 0; j < idx.size(); j++) v[idx[j]] = v2[j];
+  }
+  for (size_t i = 0; i < n; i++) verdict[i] = v[i];
+  if (host_ms) *host_ms = st.host_ms;
+  if (host_rows) *host_rows = st.host_rows;
+  return 0;
 }
 
 int ibft_host_payload_no_sig(const uint8_t *wire, size_t len, ibft_host_buf *out) {

@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         L.ibft_host_set_state.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_char_p, C.c_size_t]
         L.ibft_host_set_verifier.argtypes = [vp, C.POINTER(VerifierCB)]
         L.ibft_host_attach_gpu.argtypes = [vp, vp]
+        L.ibft_host_verify_senders_wire.argtypes = [vp, C.c_char_p, vp, C.c_size_t, C.c_int, vp,
+                                                    C.POINTER(C.c_double), C.POINTER(C.c_size_t)]
         L.ibft_host_use_batch.argtypes = [vp, C.c_int]
         L.ibft_host_add_message.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.ibft_host_enable_quorum_index.argtypes = [vp]
@@ -138,6 +140,22 @@ def payload_no_sig(wire: bytes) -> bytes | None:
 def reencode(wire: bytes) -> bytes | None:
     b = Buf()
     return _take(b) if lib().ibft_host_reencode(wire, len(wire), C.byref(b)) == 0 else None
+
+
+def verify_senders_wire(batch_verifier, wire: bytes, off, stock: bool = False):
+    """§8f rank 3 through the host mirror: device wire walk with the stock route for the rows it flags
+    (stock=True: every row takes the stock route).  Returns (verdict bool[n], host_ms, host_rows)."""
+    import numpy as np
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    n = len(off) - 1
+    verdict = np.zeros(max(n, 1), dtype=np.uint8)
+    ms, rows = C.c_double(0.0), C.c_size_t(0)
+    rc = lib().ibft_host_verify_senders_wire(batch_verifier._h, bytes(wire) or b"\0", off.ctypes.data_as(C.c_void_p), n,
+                                             1 if stock else 0, verdict.ctypes.data_as(C.c_void_p), C.byref(ms),
+                                             C.byref(rows))
+    if rc != 0:
+        raise RuntimeError(f"ibft_host_verify_senders_wire: {rc}")
+    return verdict[:n].astype(bool), ms.value, rows.value
 
 
 def has_unique_senders(msgs) -> bool:

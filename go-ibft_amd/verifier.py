@@ -31,7 +31,15 @@ EXPORTS = [
     "ibft_set_validators", "ibft_verify_hashes", "ibft_proposal_hash", "ibft_verify_seals",
     "ibft_verify_senders", "ibft_tally", "ibft_seals_stage", "ibft_seals_launch", "ibft_seals_fetch",
     "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_cache_stats", "ibft_last_dispatch", "ibft_sync",
+    "ibft_verify_senders_wire", "ibft_wire_stage_seals",
 ]
+
+WIRE_OK, WIRE_NEEDS_HOST = 0, 1
+# ibft_wire_row_t (include/ibftgpu.h)
+WIRE_ROW = np.dtype([("height", "<u8"), ("round", "<u8"), ("status", "u1"), ("type", "u1"), ("payload_kind", "u1"),
+                     ("has_view", "u1"), ("hash_len", "u1"), ("seal_len", "u1"), ("from_len", "u1"), ("sig_len", "u1"),
+                     ("from", "u1", 20), ("proposal_hash", "u1", 32), ("pad", "u1", 4)])
+assert WIRE_ROW.itemsize == 80
 
 
 class GpuUnavailable(RuntimeError):
@@ -90,6 +98,8 @@ def load_library() -> C.CDLL:
     L.ibft_cache_stats.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.ibft_last_dispatch.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_sync.argtypes = [vp]
+    L.ibft_verify_senders_wire.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(Tally)]
+    L.ibft_wire_stage_seals.argtypes = [vp]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
     _lib = L
@@ -192,6 +202,24 @@ class BatchVerifier:
         self._chk(self._L.ibft_verify_senders(self._h, _p(pl), _p(off), _p(s), _p(f), _p(pre), n, _p(mask),
                                               C.byref(t)), "ibft_verify_senders")
         return mask_to_bool(mask, n), t
+
+    # §8f rank 3: a3 straight from the wire bytes (PREPARE / COMMIT); rows["status"] == WIRE_NEEDS_HOST
+    # are not judged (verdict 0) and go through the protobuf runtime + is_valid_validator
+    def is_valid_validator_wire(self, wire: bytes, off):
+        wb = np.frombuffer(bytes(wire) or b"\0", dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = len(off) - 1
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        rows = np.zeros(n, dtype=WIRE_ROW)
+        t = Tally()
+        self._chk(self._L.ibft_verify_senders_wire(self._h, _p(wb), _p(off), n, _p(mask), _p(rows) if n else None,
+                                                   C.byref(t)), "ibft_verify_senders_wire")
+        self._staged = n
+        return mask_to_bool(mask, n), rows, t
+
+    def wire_stage_seals(self):
+        """the COMMIT seals of the last is_valid_validator_wire batch become the resident seal batch"""
+        self._chk(self._L.ibft_wire_stage_seals(self._h), "ibft_wire_stage_seals")
 
     # ValidatorManager.HasQuorum over a caller-supplied verdict array
     def has_quorum(self, sender20, verdict) -> Tally:

@@ -54,6 +54,15 @@ ibft_host *ibft_host_new(void);
 void ibft_host_free(ibft_host *h);
 void ibft_host_buf_free(ibft_host_buf *b);
 
+/* SURVEY.md §8f rank 3 — IsValidValidator (core/backend.go:41-45) for n messages given as wire bytes
+ * (row i = wire[off[i]..off[i+1])).  mode 0: device walk (ibft_verify_senders_wire) with the stock
+ * route for the rows it flags; mode 1: stock route for every row (decode, PayloadNoSig, flatten,
+ * ibft_verify_senders) — the "before" the walk replaces.  verdict: n bytes.  host_ms (optional):
+ * milliseconds spent in proto decode + re-marshal + flattening on the host; host_rows (optional): rows
+ * that took the stock route.  Returns 0, or the negative libibftgpu code.                       */
+int ibft_host_verify_senders_wire(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int mode,
+                                  uint8_t *verdict, double *host_ms, size_t *host_rows);
+
 /* wire helpers: PayloadNoSig (messages/proto/helper.go:12-27) and canonical re-encode */
 int ibft_host_payload_no_sig(const uint8_t *wire, size_t len, ibft_host_buf *out);
 int ibft_host_reencode(const uint8_t *wire, size_t len, ibft_host_buf *out);

@@ -148,6 +148,40 @@ int ibft_verify_senders(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *o
                         const uint8_t *sig65, const uint8_t *from20, const uint8_t *pre_flags,
                         size_t n, uint64_t *out_mask, ibft_tally_t *tally);
 
+/* ---- the wire bytes themselves ---------------------------------------
+ * Rows are IbftMessage protobuf bytes as the transport delivers them
+ * (/root/reference/messages/proto/messages.proto:24-44); row i is wire[off[i]..off[i+1]).
+ * Replaces, for PREPARE and COMMIT messages, the host's proto.Unmarshal + PayloadNoSig re-marshal
+ * (/root/reference/messages/proto/helper.go:12-27) + column flattening in front of a3: the device
+ * walks the fields, vouches that the bytes are the canonical encoding (so that "wire minus the
+ * signature field" IS PayloadNoSig), hashes them, extracts From / Signature / view / proposal hash
+ * / committed seal and verifies the sender.  out_rows (n entries, may be NULL) tells the host what
+ * was found.  A row with status IBFT_WIRE_NEEDS_HOST (PREPREPARE / ROUND_CHANGE payloads, unknown
+ * fields, any non-canonical encoding, truncated input) is NOT judged: its verdict bit is 0 and the
+ * caller must decode it with the protobuf runtime and use ibft_verify_senders.                  */
+#define IBFT_WIRE_OK 0u
+#define IBFT_WIRE_NEEDS_HOST 1u
+typedef struct {
+  uint64_t height, round;    /* View (0 when absent / omitted)                              */
+  uint8_t status;            /* IBFT_WIRE_*                                                  */
+  uint8_t type;              /* IbftMessage.type                                             */
+  uint8_t payload_kind;      /* oneof member: 0 none, 6 PrepareMessage, 7 CommitMessage      */
+  uint8_t has_view;
+  uint8_t hash_len;          /* bytes of proposal_hash present (<= 32)                       */
+  uint8_t seal_len;          /* bytes of committed_seal present (255 = more)                 */
+  uint8_t from_len, sig_len; /* 255 = more                                                   */
+  uint8_t from[20];
+  uint8_t proposal_hash[32];
+  uint8_t pad[4];
+} ibft_wire_row_t;
+int ibft_verify_senders_wire(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n,
+                             uint64_t *out_mask, ibft_wire_row_t *out_rows, ibft_tally_t *tally);
+/* Make the COMMIT seals found by the last ibft_verify_senders_wire the resident seal batch
+ * (hash column <- proposal hash, signature column <- committed seal, signer <- From): follow with
+ * ibft_seals_launch + ibft_seals_fetch — a2 without another upload.  Rows that are not canonical
+ * COMMIT messages (type COMMIT, 32-byte hash, 65-byte seal, 20-byte From) are pre-flagged.      */
+int ibft_wire_stage_seals(ibft_ctx *ctx);
+
 /* a8 alone: HasQuorum over the rows whose bit is set in mask.                      */
 int ibft_tally(ibft_ctx *ctx, const uint8_t *sender20, const uint64_t *mask, size_t n,
                ibft_tally_t *tally);
