@@ -139,6 +139,37 @@ func (c *Ctx) VerifySenders(payload []byte, off []uint32, sig65, from20, preFlag
 	return mask, tally(t), c.check(rc)
 }
 
+// WireRow is what the device found in one IbftMessage (ibft_wire_row_t).
+type WireRow struct {
+	Height, Round                            uint64
+	Status, Type, PayloadKind, HasView       uint8
+	HashLen, SealLen, FromLen, SigLen        uint8
+	From                                     [20]byte
+	ProposalHash                             [32]byte
+	_                                        [4]byte
+}
+
+// WireNeedsHost marks a row the device did not judge (PREPREPARE / ROUND_CHANGE payloads, unknown
+// fields, non-canonical encodings): decode it with proto.Unmarshal and use VerifySenders.
+const WireNeedsHost = 1
+
+// VerifySendersWire = IsValidValidator (core/ibft.go:1128) for n messages given as the bytes the
+// transport delivered; wire is their concatenation, off the n+1 offsets.  Replaces proto.Unmarshal +
+// PayloadNoSig (messages/proto/helper.go:12-27) + flattening for PREPARE and COMMIT messages.
+func (c *Ctx) VerifySendersWire(wire []byte, off []uint32) ([]uint64, []WireRow, Tally, error) {
+	n := len(off) - 1
+	mask := make([]uint64, (n+63)/64+1)
+	rows := make([]WireRow, n+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_verify_senders_wire(c.h, ptr8(wire), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(n),
+		(*C.uint64_t)(unsafe.Pointer(&mask[0])), (*C.ibft_wire_row_t)(unsafe.Pointer(&rows[0])), &t)
+	return mask, rows[:n], tally(t), c.check(rc)
+}
+
+// StageWireSeals makes the COMMIT seals found by the last VerifySendersWire the resident seal batch;
+// follow with SealsLaunch + SealsFetch (IsValidCommittedSeal without a second upload).
+func (c *Ctx) StageWireSeals() error { return c.check(C.ibft_wire_stage_seals(c.h)) }
+
 func tally(t C.ibft_tally_t) Tally {
 	return Tally{uint64(t.quorum_lo), uint64(t.quorum_hi), uint64(t.power_lo), uint64(t.power_hi),
 		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0}
