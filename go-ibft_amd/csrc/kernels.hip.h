@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
 }
 
 // ---- cold path, ONE WAVEFRONT PER SIGNATURE (wave_fe_dev.h) --------------------------------------
-// For batches that leave most of the chip idle (n ≤ 2 048: at most two wavefronts per SIMD).  A
+// For batches that leave most of the chip idle (n ≤ 3 072: at most three wavefronts per SIMD).  A
 // field element is one VGPR spread over the 16 lanes of a DPP row, a multiplication costs ≈86
 // instructions for four independent products, and the four rows carry the four 64-bit pieces
 // of the GLV-split scalar.  All control flow is uniform: the wavefront holds a single signature.

@@ -81,7 +81,7 @@ extern "C" {
 #define IBFT_ROW_HASH_BAD 0x04u
 
 /* cfg.kernel: how many lanes work on one signature.  The verdicts never depend on it.
- *   AUTO  cold path (recover): one wavefront per signature up to 2048 rows, then 8 / 4 / 2 lanes
+ *   AUTO  cold path (recover): one wavefront per signature up to 3072 rows, then 8 / 4 / 2 lanes
  *         per signature while rows*lanes <= 65536, one lane beyond;
  *         warm path (known keys): G = 64,32,...,2 lanes per signature so that a batch gives about
  *         one wavefront per SIMD (64 up to 1024 rows), one lane from 65536 rows.
