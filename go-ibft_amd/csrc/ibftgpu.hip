@@ -71,6 +71,8 @@ struct ibft_ctx {
   // pinned host mirrors for results
   uint64_t *h_mask = nullptr;
   uint64_t *h_tally = nullptr;
+  uint64_t *dh_mask = nullptr, *dh_tally = nullptr;  // the same pinned buffers as the device sees them
+  bool host_direct = false;                          // the last tally kernel delivered its results there
 
   // dominant-kernel timing
   std::vector<hipEvent_t> ev;  // pairs
@@ -295,18 +297,23 @@ int enqueue_tally(ibft_ctx *c, uint32_t n) {
   hipLaunchKernelGGL(ibftk::tally_kernel, dim3(1), dim3(ibftk::TALLY_THREADS), 0, c->stream,
                      (const uint64_t *)c->d_mask.p, (const int32_t *)c->d_vidx.p,
                      (const uint64_t *)c->d_vpower.p, n, c->n_validators, (uint64_t)c->quorum,
-                     (uint64_t)(c->quorum >> 64), (uint64_t *)c->d_tally.p);
+                     (uint64_t)(c->quorum >> 64), (uint64_t *)c->d_tally.p, c->dh_mask, c->dh_tally);
   HIPCHK(c, hipGetLastError());
+  c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally
   return IBFT_OK;
 }
 
 int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tally, bool have_tally) {
   size_t mw = (size_t)mask_words(n);
-  if (out_mask && mw)
-    HIPCHK(c, hipMemcpyAsync(c->h_mask, c->d_mask.p, mw * 8, hipMemcpyDeviceToHost, c->stream));
-  // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator}: one copy
-  if ((tally && have_tally) || c->cache_on)
-    HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+  const bool direct = c->host_direct && have_tally;  // the tally kernel already wrote h_mask / h_tally
+  c->host_direct = false;
+  if (!direct) {
+    if (out_mask && mw)
+      HIPCHK(c, hipMemcpyAsync(c->h_mask, c->d_mask.p, mw * 8, hipMemcpyDeviceToHost, c->stream));
+    // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator}: one copy
+    if ((tally && have_tally) || c->cache_on)
+      HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->cache_on) {
     const uint32_t *lw = reinterpret_cast<const uint32_t *>(c->h_tally + 4);
@@ -393,6 +400,15 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
     if ((rc = alloc_rows(c))) break;
     if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_tally, 128) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    // zero-copy result delivery (tally_kernel writes the verdict words and its own result into the
+    // pinned buffers); IBFT_NO_HOST_DIRECT=1 keeps the two device-to-host copies instead
+    if (!getenv("IBFT_NO_HOST_DIRECT")) {
+      void *dm = nullptr, *dt = nullptr;
+      if (hipHostGetDevicePointer(&dm, c->h_mask, 0) == hipSuccess && hipHostGetDevicePointer(&dt, c->h_tally, 0) == hipSuccess) {
+        c->dh_mask = (uint64_t *)dm;
+        c->dh_tally = (uint64_t *)dt;
+      }
+    }
     if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
     int threads = 64, total = ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES;
     hipLaunchKernelGGL(ibftk::gtab_build_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0,

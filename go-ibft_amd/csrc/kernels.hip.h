@@ -607,7 +607,13 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 __global__ void __launch_bounds__(TALLY_THREADS)
 tally_kernel(const uint64_t *__restrict__ mask, const int32_t *__restrict__ vidx,
              const uint64_t *__restrict__ vpower, uint32_t n, uint32_t n_validators,
-             uint64_t quorum_lo, uint64_t quorum_hi, uint64_t *__restrict__ out) {
+             uint64_t quorum_lo, uint64_t quorum_hi, uint64_t *__restrict__ out,
+             uint64_t *__restrict__ host_mask, uint64_t *__restrict__ host_tally) {
+  // host_mask / host_tally (nullable): pinned host memory mapped into the device.  The tally reads every
+  // verdict word anyway, so it also delivers them — and its own five result words — straight to
+  // the host: the step needs no device-to-host copy commands, only the stream synchronisation.
+  if (host_mask)
+    for (uint32_t i = threadIdx.x; i < (n + 63) / 64; i += TALLY_THREADS) host_mask[i] = mask[i];
   __shared__ uint32_t seen[TALLY_SEEN_WORDS];
   __shared__ uint64_t part[4][TALLY_THREADS / 64];
   const uint32_t words = (n_validators + 31) / 32;
@@ -655,7 +661,15 @@ tally_kernel(const uint64_t *__restrict__ mask, const int32_t *__restrict__ vidx
     out[0] = lo;
     out[1] = hi;
     out[2] = c;
-    out[3] = (hi > quorum_hi || (hi == quorum_hi && lo >= quorum_lo)) ? 1 : 0;
+    const uint64_t hq = (hi > quorum_hi || (hi == quorum_hi && lo >= quorum_lo)) ? 1 : 0;
+    out[3] = hq;
+    if (host_tally) {
+      host_tally[0] = lo;
+      host_tally[1] = hi;
+      host_tally[2] = c;
+      host_tally[3] = hq;
+      host_tally[4] = out[4];  // keys learned | a learned validator, written by the recover kernels
+    }
   }
 }
 
