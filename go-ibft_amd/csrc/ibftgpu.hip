@@ -39,6 +39,8 @@ struct ibft_ctx {
   // columns in HBM
   DevBuf d_hash, d_sig, d_signer, d_pre, d_hash_len, d_payload, d_off, d_raw;
   DevBuf d_mask, d_vidx, d_tally, d_H;
+  DevBuf d_mask_out;        // verdict words after the tally consumed d_mask (what fetch / export read)
+  bool mask_clean = false;  // d_mask is all zero (the tally left it so): no memset before atomicOr kernels
   DevBuf d_wire_rows, d_seal;  // §8f rank 3: per-row parse results and the COMMIT seals found in the wire bytes
   uint32_t wire_n = 0;         // rows of the last ibft_verify_senders_wire
   bool wire_valid = false;     // its columns are still the resident ones
@@ -123,6 +125,8 @@ int alloc_rows(ibft_ctx *c) {
   if ((rc = ensure(c, c->d_hash_len, m))) return rc;
   if ((rc = ensure(c, c->d_off, (m + 1) * 4))) return rc;
   if ((rc = ensure(c, c->d_mask, (size_t)mask_words(m) * 8))) return rc;
+  if ((rc = ensure(c, c->d_mask_out, (size_t)mask_words(m) * 8))) return rc;
+  c->mask_clean = false;
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
   if ((rc = ensure(c, c->d_tally, 8 * 8))) return rc;
   if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
@@ -174,6 +178,10 @@ int next_events(ibft_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
 int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it) {
   if (n == 0) return IBFT_OK;
   ibftk::recover_args a = make_args(c, n, with_pre);
+  struct dirty_on_exit {  // whatever is launched below writes verdict bits into d_mask
+    ibft_ctx *c;
+    ~dirty_on_exit() { c->mask_clean = false; }
+  } mark_dirty{c};
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (time_it) {
     int rc = next_events(c, &e0, &e1);
@@ -191,7 +199,7 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
       while (G < 64 && (uint64_t)n * (G * 2) <= 65536ull) G *= 2;
     }
     if (G > 1) {
-      HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
+      if (!c->mask_clean) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
       const uint32_t rows_per_wave = 64 / G;
       dim3 grid((n + rows_per_wave - 1) / rows_per_wave), block(64);
 #define IBFT_LAUNCH_GROUP(GG)                                                                                  \
@@ -245,13 +253,13 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     else if ((uint64_t)n * 2 <= 65536ull) CG = 2;
   }
   if (CG == 64) {
-    if (!warm) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
+    if (!warm && !c->mask_clean) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
     if (mode == 0)
       hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<0>, dim3(n), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<1>, dim3(n), dim3(64), 0, c->stream, a);
   } else if (CG > 1) {
-    if (!warm) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(n) * 8, c->stream));
+    if (!warm && !c->mask_clean) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
     const uint32_t rows_per_wave = 64 / CG;
     dim3 cgrid((n + rows_per_wave - 1) / rows_per_wave), cblock(64);
 #define IBFT_LAUNCH_COLD(GG)                                                                         \
@@ -295,11 +303,12 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator
 
 int enqueue_tally(ibft_ctx *c, uint32_t n) {
   hipLaunchKernelGGL(ibftk::tally_kernel, dim3(1), dim3(ibftk::TALLY_THREADS), 0, c->stream,
-                     (const uint64_t *)c->d_mask.p, (const int32_t *)c->d_vidx.p,
+                     (uint64_t *)c->d_mask.p, (uint64_t *)c->d_mask_out.p, (const int32_t *)c->d_vidx.p,
                      (const uint64_t *)c->d_vpower.p, n, c->n_validators, (uint64_t)c->quorum,
                      (uint64_t)(c->quorum >> 64), (uint64_t *)c->d_tally.p, c->dh_mask, c->dh_tally);
   HIPCHK(c, hipGetLastError());
   c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally
+  c->mask_clean = true;                    // ... and it zeroed the words it consumed
   return IBFT_OK;
 }
 
@@ -309,7 +318,8 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
   c->host_direct = false;
   if (!direct) {
     if (out_mask && mw)
-      HIPCHK(c, hipMemcpyAsync(c->h_mask, c->d_mask.p, mw * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_mask, have_tally ? c->d_mask_out.p : c->d_mask.p, mw * 8, hipMemcpyDeviceToHost,
+                               c->stream));
     // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator}: one copy
     if ((tally && have_tally) || c->cache_on)
       HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 5 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -428,7 +438,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
-                    &c->d_off, &c->d_raw, &c->d_mask, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
+                    &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done})
     release(*b);
@@ -545,6 +555,7 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
                        (const uint8_t *)c->d_hash.p, (const uint8_t *)c->d_hash_len.p,
                        (const uint64_t *)c->d_H.p, (uint32_t)n, (uint64_t *)c->d_mask.p);
     HIPCHK(c, hipGetLastError());
+    c->mask_clean = false;  // ballot words, and no tally follows to consume them
   }
   return fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
 }
@@ -601,7 +612,7 @@ int ibft_seals_fetch(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
 
 int ibft_seals_device_ptrs(ibft_ctx *c, void **d_mask, size_t *mask_words_out, void **d_tally) {
   if (!c) return IBFT_E_INVAL;
-  if (d_mask) *d_mask = c->d_mask.p;
+  if (d_mask) *d_mask = c->d_mask_out.p;
   if (mask_words_out) *mask_words_out = (size_t)mask_words(c->staged_n);
   if (d_tally) *d_tally = c->d_tally.p;
   return IBFT_OK;
@@ -613,7 +624,7 @@ int ibft_seals_export(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst) {
   HIPCHK(c, hipSetDevice(c->device));
   size_t mw = (size_t)mask_words(c->staged_n);
   if (d_mask_dst && mw)
-    HIPCHK(c, hipMemcpyAsync(d_mask_dst, c->d_mask.p, mw * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_mask_dst, c->d_mask_out.p, mw * 8, hipMemcpyDeviceToDevice, c->stream));
   if (d_tally_dst)
     HIPCHK(c, hipMemcpyAsync(d_tally_dst, c->d_tally.p, 4 * 8, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -764,6 +775,7 @@ int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_
   int rc;
   c->wire_valid = false;
   if ((rc = upload(c, c->d_signer, sender20, n * 20))) return rc;
+  c->mask_clean = false;
   if ((rc = upload(c, c->d_mask, mask, (size_t)mask_words(n) * 8))) return rc;
   if (n) {
     hipLaunchKernelGGL(ibftk::lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,

@@ -605,15 +605,20 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 }
 
 __global__ void __launch_bounds__(TALLY_THREADS)
-tally_kernel(const uint64_t *__restrict__ mask, const int32_t *__restrict__ vidx,
+tally_kernel(uint64_t *__restrict__ work_mask, uint64_t *__restrict__ mask, const int32_t *__restrict__ vidx,
              const uint64_t *__restrict__ vpower, uint32_t n, uint32_t n_validators,
              uint64_t quorum_lo, uint64_t quorum_hi, uint64_t *__restrict__ out,
              uint64_t *__restrict__ host_mask, uint64_t *__restrict__ host_tally) {
-  // host_mask / host_tally (nullable): pinned host memory mapped into the device.  The tally reads every
-  // verdict word anyway, so it also delivers them — and its own five result words — straight to
-  // the host: the step needs no device-to-host copy commands, only the stream synchronisation.
-  if (host_mask)
-    for (uint32_t i = threadIdx.x; i < (n + 63) / 64; i += TALLY_THREADS) host_mask[i] = mask[i];
+  // The verdict kernels accumulate into work_mask (atomicOr / ballot words).  The tally CONSUMES it:
+  // the words move to `mask` (what fetch / export read), to host_mask when given — pinned host memory
+  // mapped into the device, like host_tally: the step then needs no device-to-host copy commands —
+  // and work_mask is left zeroed for the next launch, so no memset sits in front of the kernels.
+  for (uint32_t i = threadIdx.x; i < (n + 63) / 64; i += TALLY_THREADS) {
+    const uint64_t w = work_mask[i];
+    work_mask[i] = 0;
+    mask[i] = w;
+    if (host_mask) host_mask[i] = w;
+  }
   __shared__ uint32_t seen[TALLY_SEEN_WORDS];
   __shared__ uint64_t part[4][TALLY_THREADS / 64];
   const uint32_t words = (n_validators + 31) / 32;
