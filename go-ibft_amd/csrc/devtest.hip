@@ -64,8 +64,6 @@ __global__ void devtest_kernel(int op, int n, const uint8_t *a, const uint8_t *b
       r = fin ? l26_to_u256(af.x) : zero256();
       break;
     }
-    case 17: r = modinv_var<ModP>(x); break;
-    case 18: r = modinv_var<ModN>(x); break;
     case 9: r = modinv<ModP>(x); break;
     case 10: r = modinv<ModN>(x); break;
     case 11: {  // one batch: divsteps + both updates, output d (as raw 9 limbs packed little-endian 36 B -> first 32)

@@ -50,8 +50,6 @@ void dev_sc_sqr(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_sqr(sin_(a)
 void dev_sc_inv(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv(sin_(a))); }
 
 void dev_fe_inv_safegcd(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv_safegcd(fin(a))); }
-void dev_fe_inv_var(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv_safegcd_var(fin(a))); }
-void dev_sc_inv_var(const uint8_t *a, uint8_t *out) { secp::to_be32(out, secp::modinv_var<secp::ModN>(secp::from_be32(a))); }
 // one batch of variable-time divsteps against the constant-time one: returns 1 if (ζ, u, v, q, r) agree
 int dev_divsteps_agree(int32_t zeta, uint32_t f0, uint32_t g0) {
   secp::trans2x2 a, b;

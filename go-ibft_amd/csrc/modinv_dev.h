@@ -202,12 +202,12 @@ HD u256 modinv(const u256 &x) {
   return s30_to_u256(d);
 }
 
-// ---- variable-time variant -------------------------------------------------------------------------
-// Same divsteps, but runs of even g are stripped with one count-trailing-zeros and the loop stops as
-// soon as g = 0.  Control flow depends on the data, so this is for kernels where a whole wavefront
-// works on ONE value (ecrecover_wave_kernel): every branch is then wave-uniform.  Worth ≈3 % of that
-// kernel; on the warm one-wavefront kernel it measured no gain and is not used.  (Nothing here is secret — signatures and public keys — so timing is not a concern;
-// the constant-time form above is used where lanes hold different values because it never diverges.)
+// ---- variable-time divsteps ----------------------------------------------------------------------------
+// Same 30 divsteps, but runs of even g are stripped with one count-trailing-zeros.  Control flow
+// depends on the data, so this is for code where a whole wavefront works on ONE value
+// (wave_fe_dev.h:modinv_wave): every branch is then wave-uniform.  Nothing here is secret —
+// signatures and public keys — so timing is not a concern; the constant-time form above is used where
+// lanes hold different values because it never diverges.
 HD int32_t divsteps_30_var(int32_t zeta, uint32_t f0, uint32_t g0, trans2x2 &t) {
   uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
   int i = 30;
@@ -243,43 +243,14 @@ HD int32_t divsteps_30_var(int32_t zeta, uint32_t f0, uint32_t g0, trans2x2 &t) 
   t.r = (int32_t)r;
   return zeta;
 }
-template <class MOD>
-HD u256 modinv_var(const u256 &x) {
-  s30 d, e, f, g = s30_from_u256(x);
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    d.v[i] = 0;
-    e.v[i] = 0;
-    f.v[i] = MOD::limb(i);
-  }
-  e.v[0] = 1;
-  int32_t zeta = -1;
-#pragma unroll 1
-  for (int b = 0; b < 20; b++) {  // 600 divsteps is the proven worst case; typical inputs need ≈ 530
-    trans2x2 t;
-    zeta = divsteps_30_var(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
-    update_de_30<MOD>(d, e, t);
-    update_fg_30(f, g, t);
-    int32_t nz = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) nz |= g.v[i];
-    if (nz == 0) break;
-  }
-  normalize_30<MOD>(d, f.v[8] < 0);
-  return s30_to_u256(d);
-}
-
 HD fe fe_inv_safegcd(const fe &a) {  // a of magnitude ≤ 32
   return fe_from_u256(modinv<ModP>(fe_to_u256(a)));
 }
 HD sc sc_inv_safegcd(const sc &a) { return sc_from_u256(modinv<ModN>(sc_canon(a))); }
 
-HD fe fe_inv_safegcd_var(const fe &a) { return fe_from_u256(modinv_var<ModP>(fe_to_u256(a))); }
-// Jacobian → affine with the safegcd inverse; r.x / r.y canonical; false for infinity.
-// VAR: variable-time inverse (wave-uniform input only, see modinv_var)
-template <bool VAR = false>
+// Jacobian → affine with the safegcd inverse; r.x / r.y canonical; false for infinity
 HD bool jac_to_aff_fast(aff &r, const jac &p) {
-  fe zi = VAR ? fe_inv_safegcd_var(p.z) : fe_inv_safegcd(p.z);
+  fe zi = fe_inv_safegcd(p.z);
   fe zi2 = fe_sqr(zi);
   r.x = fe_normalize(fe_mul(p.x, zi2));
   r.y = fe_normalize(fe_mul(p.y, fe_mul(zi2, zi)));

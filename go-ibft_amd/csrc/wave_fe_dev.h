@@ -9,10 +9,18 @@
 //   ten broadcasts of a_i (row_newbcast) × ten row-shifted copies of b (row_shr) feeding one
 //   v_mad_u64_u32 each — lane k accumulates column k, lanes 10..15 the columns 10..15, three more
 //   mads give columns 16..18 — and a carry-save reduction with 2^260 ≡ 0x3D10 + 0x400·2^26,
-// ≈86 instructions for FOUR independent products (one per row) instead of 224 for one.  The
+// 72 VALU instructions for FOUR independent products (one per row) instead of 224 for one.  The
 // four rows carry four independent pieces of the scalar multiplication (GLV half × upper /
 // lower 64 bits), so the per-row instruction stream is an ordinary sequential point formula
 // and every branch is wave-uniform by construction (a wavefront holds one signature).
+//
+// Contents: cross-lane primitives · wfe_mul / linear ops · row ↔ lane layout · group law per row ·
+// √ chain riding on the 3-row prefix doublings · modinv_wave (safegcd, limbs over lanes) ·
+// recover_pubkey_wave (cold path) · verify_known_wave (warm path).  DESIGN.md §4 has the measurements.
+//
+// RULE: a cross-lane primitive must never sit under lane-dependent control flow (`c ? f(dpp) : x` with
+// a per-row c executes the DPP in some rows only).  The host emulator tags every rendezvous with its
+// primitive and aborts the test when lanes disagree.
 //
 // Magnitudes: U = 2^26 + 2^20; "magnitude m" = every limb ≤ m·U.  wfe_mul accepts magnitudes
 // ≤ 15 on both inputs (10·(15U)² < 2^64) and returns magnitude 1; wfe_neg(a, m) = K_m − a with

@@ -101,8 +101,6 @@ def test_safegcd_inversion(dev):
         ap, an = a % P, a % N
         assert _c1(dev.dev_fe_inv_safegcd, b32(ap)) == (pow(ap, -1, P) if ap else 0)
         assert _c1(dev.dev_sc_inv_safegcd, b32(an)) == (pow(an, -1, N) if an else 0)
-        assert _c1(dev.dev_fe_inv_var, b32(ap)) == (pow(ap, -1, P) if ap else 0)
-        assert _c1(dev.dev_sc_inv_var, b32(an)) == (pow(an, -1, N) if an else 0)
 
 
 def test_glv_split_and_variable_base_mult(dev):
