@@ -10,6 +10,8 @@ mask and the quorum flag.  Inputs are resident in HBM when the timed region star
   N>1 : weak scaling — every rank verifies its own 1024-row validator shard of a
         1024·N-validator set, then the verdict-mask words and tally partials are
         all-reduced over RCCL (disjoint shards: sum ≡ OR), as BASELINE configs #4/#5 do.
+        The exchange of pass k runs on its own stream behind a results-ready event and overlaps
+        with the kernels of pass k+1; the host consumes every merged result one pass later.
 
 Prints ONE JSON line on rank 0.
 """
@@ -133,16 +135,38 @@ def main():
     assert S.shard_range(n_total, rank, world) == (lo, hi)
     # exchange buffer: [mask words of every shard | power_lo, power_hi, valid|distinct<<32] (+1 spare:
     # the library exports 4 tally words, the 4th — has_quorum — is recomputed after the merge)
-    ar = torch.zeros(slots + 1, dtype=torch.int64, device=dev) if dist else None
+    ar = [torch.zeros(slots + 1, dtype=torch.int64, device=dev) for _ in range(2)] if dist else None
+    evs = [torch.cuda.Event() for _ in range(2)] if dist else None
+    # the exchange (zero, copies, all-reduce) lives on its own stream: on torch's legacy default stream it
+    # serialised against the library's stream (0.361 vs 0.346 ms per pass with one rank)
+    xstream = torch.cuda.Stream(device=dev) if dist else None
 
-    def step():
+    def step():  # N = 1: one synchronous pass, results on the host when it returns
         bv.seals_launch(1)
-        if dist is None:
-            return bv.seals_fetch()
-        ar.zero_()
-        bv.seals_export(ar[rank * words:].data_ptr(), ar[tally_off:].data_ptr())
-        dist.all_reduce(ar)  # disjoint shards: sum == OR; tally partials add
-        return ar
+        return bv.seals_fetch()
+
+    def exchange(k):
+        """hand shard k's verdict words + tally partials to the collective: copies and all-reduce run on
+        torch's stream behind a results-ready event, the library's own stream is free for the next batch"""
+        buf = ar[k & 1]
+        with torch.cuda.stream(xstream):
+            buf.zero_()
+            bv.seals_export_on(buf[rank * words:].data_ptr(), buf[tally_off:].data_ptr(), xstream.cuda_stream)
+            dist.all_reduce(buf)  # disjoint shards: sum == OR; tally partials add
+            evs[k & 1].record()
+
+    def run_sharded(k_steps):
+        """k_steps passes; the exchange of pass k overlaps with the kernels of pass k+1, and the host
+        consumes every merged result one pass later (bounded pipeline, depth 1)"""
+        bv.seals_launch(1)
+        for k in range(k_steps):
+            exchange(k)
+            if k + 1 < k_steps:
+                bv.seals_launch(1)
+            if k >= 1:
+                evs[(k - 1) & 1].synchronize()
+        evs[(k_steps - 1) & 1].synchronize()
+        return ar[(k_steps - 1) & 1]
 
     def fence():
         if dist is not None:
@@ -150,8 +174,11 @@ def main():
         torch.cuda.synchronize()
         bv.sync()
 
-    for _ in range(args.warmup):
-        step()
+    if dist is None:
+        for _ in range(args.warmup):
+            step()
+    elif args.warmup:
+        run_sharded(args.warmup)
     fence()
     # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed
     # loop costs ≈40 ms (seen as one 43 ms step).  Collect now, keep the collector off while timing.
@@ -160,21 +187,29 @@ def main():
     lat = []
     kernel_ms, kernel_launches = 0.0, 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s0 = time.perf_counter()
-        out = step()
-        if dist is not None:
-            torch.cuda.synchronize()
-        lat.append(time.perf_counter() - s0)
-        ms, k = bv.last_kernel_ms()
-        kernel_ms += ms
-        kernel_launches += k
+    if dist is None:
+        for _ in range(args.steps):
+            s0 = time.perf_counter()
+            out = step()
+            lat.append(time.perf_counter() - s0)
+            ms, k = bv.last_kernel_ms()
+            kernel_ms += ms
+            kernel_launches += k
+    else:
+        out = run_sharded(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        kernel_ms, kernel_launches = bv.last_kernel_ms()  # the last pass's kernels (events are per launch)
+        for k in range(min(args.steps, 20)):              # latency of one synchronous pass incl. the exchange
+            s0 = time.perf_counter()
+            bv.seals_launch(1)
+            exchange(k)
+            evs[k & 1].synchronize()
+            lat.append(time.perf_counter() - s0)
 
     # quorum latency including the host→device copies (reported with and without H2D)
     lat_h2d = []
@@ -190,7 +225,7 @@ def main():
         assert verdict.all() and tally.has_quorum == 1 and tally.power == int(power.sum())
     else:
         quorum = 2 * int(power.sum()) // 3 + 1
-        verdict, pw, valid, distinct, hq = S.merge(ar.cpu().numpy()[:slots], n_total, world, quorum)
+        verdict, pw, valid, distinct, hq = S.merge(out.cpu().numpy()[:slots], n_total, world, quorum)
         assert verdict.all() and valid == n_total and pw == int(power.sum()) and hq
 
     if rank == 0:

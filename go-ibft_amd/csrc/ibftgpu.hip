@@ -75,6 +75,8 @@ struct ibft_ctx {
   uint64_t *h_tally = nullptr;
   uint64_t *dh_mask = nullptr, *dh_tally = nullptr;  // the same pinned buffers as the device sees them
   bool host_direct = false;                          // the last tally kernel delivered its results there
+  hipEvent_t ev_ready = nullptr, ev_read = nullptr;  // ibft_seals_export_on: results ready / results read
+  bool read_pending = false;                         // the next tally must wait for ev_read
 
   // dominant-kernel timing
   std::vector<hipEvent_t> ev;  // pairs
@@ -302,6 +304,10 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator
 }
 
 int enqueue_tally(ibft_ctx *c, uint32_t n) {
+  if (c->read_pending) {  // a consumer stream is still copying the previous results (ibft_seals_export_on)
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_read, 0));
+    c->read_pending = false;
+  }
   hipLaunchKernelGGL(ibftk::tally_kernel, dim3(1), dim3(ibftk::TALLY_THREADS), 0, c->stream,
                      (uint64_t *)c->d_mask.p, (uint64_t *)c->d_mask_out.p, (const int32_t *)c->d_vidx.p,
                      (const uint64_t *)c->d_vpower.p, n, c->n_validators, (uint64_t)c->quorum,
@@ -442,6 +448,8 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done})
     release(*b);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_read) (void)hipEventDestroy(c->ev_read);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_tally) (void)hipHostFree(c->h_tally);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -628,6 +636,25 @@ int ibft_seals_export(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst) {
   if (d_tally_dst)
     HIPCHK(c, hipMemcpyAsync(d_tally_dst, c->d_tally.p, 4 * 8, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return IBFT_OK;
+}
+
+int ibft_seals_export_on(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst, void *consumer_stream) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t cs = (hipStream_t)consumer_stream;
+  if (!c->ev_ready) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
+  }
+  HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));  // everything launched so far, the tally included
+  HIPCHK(c, hipStreamWaitEvent(cs, c->ev_ready, 0));
+  size_t mw = (size_t)mask_words(c->staged_n);
+  if (d_mask_dst && mw) HIPCHK(c, hipMemcpyAsync(d_mask_dst, c->d_mask_out.p, mw * 8, hipMemcpyDeviceToDevice, cs));
+  if (d_tally_dst) HIPCHK(c, hipMemcpyAsync(d_tally_dst, c->d_tally.p, 4 * 8, hipMemcpyDeviceToDevice, cs));
+  HIPCHK(c, hipEventRecord(c->ev_read, cs));
+  c->read_pending = true;  // enqueue_tally: the next tally overwrites d_mask_out / d_tally only after ev_read
   return IBFT_OK;
 }
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "ibft_set_validators", "ibft_verify_hashes", "ibft_proposal_hash", "ibft_verify_seals",
     "ibft_verify_senders", "ibft_tally", "ibft_seals_stage", "ibft_seals_launch", "ibft_seals_fetch",
     "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_cache_stats", "ibft_last_dispatch", "ibft_sync",
-    "ibft_verify_senders_wire", "ibft_wire_stage_seals",
+    "ibft_verify_senders_wire", "ibft_wire_stage_seals", "ibft_seals_export_on",
 ]
 
 WIRE_OK, WIRE_NEEDS_HOST = 0, 1
@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
+    L.ibft_seals_export_on.argtypes = [vp, vp, vp, vp]
     L.ibft_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.ibft_cache_stats.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.ibft_last_dispatch.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -255,6 +256,11 @@ class BatchVerifier:
     def seals_export(self, d_mask_ptr: int | None, d_tally_ptr: int | None) -> None:
         """D2D copy of mask/tally into caller-owned device memory (torch data_ptr), then sync."""
         self._chk(self._L.ibft_seals_export(self._h, d_mask_ptr, d_tally_ptr), "ibft_seals_export")
+
+    def seals_export_on(self, d_mask_ptr: int | None, d_tally_ptr: int | None, stream: int) -> None:
+        """the same copies enqueued on the caller's stream (hipStream_t handle) behind a results-ready event:
+        no host wait; the caller's collective overlaps with the next seals_launch"""
+        self._chk(self._L.ibft_seals_export_on(self._h, d_mask_ptr, d_tally_ptr, stream), "ibft_seals_export_on")
 
     def last_kernel_ms(self):
         ms, k = C.c_float(), C.c_uint32()

@@ -205,6 +205,12 @@ int ibft_seals_device_ptrs(ibft_ctx *ctx, void **d_mask, size_t *mask_words, voi
  * (e.g. a torch tensor's data_ptr) and wait for the copy: the hand-off point to an
  * RCCL all-reduce issued by the caller.  Either pointer may be NULL.               */
 int ibft_seals_export(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst);
+/* Same hand-off without a host round trip: the copies are enqueued on the CALLER's stream (a
+ * hipStream_t, e.g. torch.cuda.current_stream().cuda_stream — the one the collective will run on)
+ * behind an event that marks the last launch's results ready, and the context's next tally waits
+ * (on the device) until they have been read.  The caller's collective then overlaps with the next
+ * ibft_seals_launch on the context's own stream.                                                  */
+int ibft_seals_export_on(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst, void *consumer_stream);
 /* HIP-event time (ms) of the dominant kernel summed over the last launch, and its
  * launch count; measured on the context's own stream.                              */
 int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
