@@ -103,3 +103,27 @@ def test_against_the_protobuf_runtime(dev):
         assert digest == OB.keccak256(g.SerializeToString(deterministic=True)), m.hex()
         checked += 1
     assert checked > 50
+
+
+def test_golden_wire_rows(dev):
+    """tests/golden/wire_rows.json (make_wire_rows.py: oracle expectation cross-checked with the protobuf
+    runtime at generation time) — the walker alone against committed vectors."""
+    import json
+    import os
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wire_rows.json")))
+    assert len(rows) > 150
+    for o in rows:
+        m = bytes.fromhex(o["wire"])
+        ri, digest, sig, frm, seal, pre = dev_row(dev, m)
+        assert int(ri["status"]) == o["status"] and (pre != 0) == bool(o["pre_flag"]), o["label"]
+        if o["status"] != WP.OK:
+            continue
+        assert digest.hex() == o["digest"], o["label"]
+        assert (int(ri["height"]), int(ri["round"]), int(ri["type"]), int(ri["payload_kind"]), int(ri["has_view"])) == \
+            (o["height"], o["round"], o["type"], o["payload_kind"], o["has_view"]), o["label"]
+        ph = bytes.fromhex(o["proposal_hash"])
+        assert int(ri["hash_len"]) == len(ph) and ri["proposal_hash"].tobytes()[:len(ph)] == ph
+        if len(o["signature"]) == 130 and len(o["from"]) == 40:
+            assert sig.hex() == o["signature"] and frm.hex() == o["from"]
+        if o["payload_kind"] == 7 and len(o["committed_seal"]) == 130:
+            assert seal.hex() == o["committed_seal"]

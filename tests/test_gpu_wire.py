@@ -119,3 +119,30 @@ def test_host_mirror_wire_route_equals_stock_route(gpu_verifier, oracle):
     assert (fast == stock).all(), np.nonzero(fast != stock)[0][:10]
     assert 0 < host_rows < stock_rows <= len(rows_bytes)
     assert fast.sum() > 50
+
+
+def test_golden_wire_rows_on_gpu(oracle):
+    """the committed wire vectors through ibft_verify_senders_wire: status, extracted fields and — via the
+    verdicts — the digest of every accepted row (a wrong PayloadNoSig hash cannot recover the sender)."""
+    import json
+    import os
+    import go_ibft_amd.verifier as V
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wire_rows.json")))
+    msgs = [bytes.fromhex(o["wire"]) for o in rows]
+    r = W.make_round(12, 9001, height=5, round_=1, byzantine=True)  # the round the generator used
+    vs = oracle.ValSet(r.addrs, r.power)
+    want = np.zeros(len(rows), dtype=bool)
+    for i, o in enumerate(rows):
+        if o["status"] == 0 and not o["pre_flag"]:
+            frm = bytes.fromhex(o["from"])
+            got = oracle.recover_address(bytes.fromhex(o["digest"]), bytes.fromhex(o["signature"]))
+            want[i] = got == frm and vs.index(frm) >= 0
+    wire, off = WCASE.pack(msgs)
+    bv = V.BatchVerifier(max_rows=1024)
+    try:
+        bv.set_validators(1, r.addrs, r.power)
+        got, info, _ = bv.is_valid_validator_wire(wire, off)
+    finally:
+        bv.close()
+    assert [int(s) for s in info["status"]] == [o["status"] for o in rows]
+    assert (got == want).all() and want.sum() >= 10
