@@ -238,7 +238,8 @@ def main():
         kname = ("ecrecover_lane_kernel<0>" if cold_lanes == 1 else "ecrecover_wave_kernel<0>" if cold_lanes == 64
                  else f"ecrecover_group_kernel<0,{cold_lanes}>") \
             if args.path == "cold" else (
-            f"verify_known_group_kernel<0,{bv.lanes_per_signature}>" if bv.lanes_per_signature > 1
+            "verify_known_wave_kernel<0>" if bv.lanes_per_signature == 64
+            else f"verify_known_group_kernel<0,{bv.lanes_per_signature}>" if bv.lanes_per_signature > 1
             else "verify_known_lane_kernel<0>")
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
@@ -300,7 +301,8 @@ def main():
                                 "quorum_latency_ms_p50": float(np.median(wlat) * 1e3),
                                 "tables_bytes": int(wv.cache_stats()[0]) * 32 * 256 * 80,
                                 "lanes_per_signature": wv.lanes_per_signature,
-                                "kernel": (f"verify_known_group_kernel<0,{wv.lanes_per_signature}>"
+                                "kernel": ("verify_known_wave_kernel<0>" if wv.lanes_per_signature == 64
+                                           else f"verify_known_group_kernel<0,{wv.lanes_per_signature}>"
                                            if wv.lanes_per_signature > 1 else "verify_known_lane_kernel<0>"),
                                 "note": "keys learned by an earlier cold pass; identical verdicts (csrc/verify_dev.h)"}
             wv.close()
