@@ -11,8 +11,11 @@
  *     three verifiers are interface methods (/root/reference/core/backend.go:37-56)
  *     whose only in-repo implementation is the byte-comparing test mock
  *     (/root/reference/core/mock_test.go:105-151).  Pinned instead by public
- *     KATs, a pure-Python big-int re-derivation (oracle/pyref.py) and OpenSSL
- *     libcrypto's secp256k1 (oracle/openssl_xcheck.c).
+ *     known answers (Keccak-256 vectors; G, 2G; sk = 1, 2 -> address; go-ethereum's
+ *     signature test triple msg/sig/pubkey and the ecrecover-precompile example:
+ *     tests/golden/kats.json, tests/test_oracle_kat.py), a pure-Python big-int
+ *     re-derivation (oracle/pyref.py) and OpenSSL libcrypto's secp256k1
+ *     (oracle/openssl_xcheck.c).
  *   semantics (which verifier is called with what, nil handling, quorum rule,
  *     dedup by sender): pinned by the reference's own unit tables, replayed in
  *     tests/test_semantics_*.py.

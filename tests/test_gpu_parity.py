@@ -230,3 +230,28 @@ def test_large_n_properties(gpu_verifier, oracle):
     bv.seals_launch(3)
     again, t3 = bv.seals_fetch()
     assert (again == got).all() and t3.power == t.power
+
+
+@pytest.mark.parametrize("lanes", [1, 8, 64])
+def test_public_recover_vectors_on_gpu(lanes, monkeypatch):
+    """go-ethereum's signature test vector and the ecrecover-precompile example (tests/golden/kats.json)
+    through the cold kernels (lane, 8-lane, one wavefront) and then the warm path: the signer must
+    verify as the published address and as no other."""
+    import json
+    import go_ibft_amd.verifier as V
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))["public_recover_vectors"]
+    addrs = np.array([np.frombuffer(bytes.fromhex(v["address"]), dtype=np.uint8) for v in k])
+    other = addrs.copy()
+    other[:, 19] ^= 1
+    valset = np.concatenate([addrs, other])
+    h = np.array([np.frombuffer(bytes.fromhex(v["digest"]), dtype=np.uint8) for v in k] * 2)
+    s = np.array([np.frombuffer(bytes.fromhex(v["sig65"]), dtype=np.uint8) for v in k] * 2)
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=1024)
+    try:
+        bv.set_validators(1, valset, np.ones(len(valset), dtype=np.uint64))
+        for _ in range(2):  # cold, then warm for the learned keys
+            got, _ = bv.is_valid_committed_seal(h, s, valset)
+            assert got.tolist() == [True] * len(k) + [False] * len(k)
+    finally:
+        bv.close()
