@@ -132,3 +132,24 @@ def test_lane_parallel_modular_inverse(wh):
             wh.wvh_modinv(which, x.to_bytes(32, "big"), out.ctypes.data_as(ctypes.c_void_p))
             assert (out == out[0]).all()
             assert int.from_bytes(out[0].tobytes(), "big") == (pow(x, -1, m) if x else 0), (which, hex(x))
+
+
+def test_full_recover_with_crafted_scalars(wh, oracle):
+    """u2 = s/r of extreme shapes (tiny, around 2^64 / 2^128, n − small) and a zero digest through the
+    emulated one-wavefront recover: mostly-zero digit strings, accumulators at infinity, top digits."""
+    from oracle import pyref
+    wh.wvh_init_gtab()
+    n = pyref.N
+    rng = np.random.default_rng(99)
+    for i, t in enumerate([1, 16, 2**64 - 1, 2**64, 2**128 - 1, n - 1, n - 2**64, int("8" * 64, 16) % n]):
+        k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        x, _ = pyref.pt_mul(k, pyref.G)
+        r = x % n
+        z = 0 if i == 0 else int.from_bytes(rng.bytes(32), "big")
+        sig = r.to_bytes(32, "big") + ((t * r) % n).to_bytes(32, "big") + bytes([i & 1])
+        h = z.to_bytes(32, "big")
+        addr = np.zeros((64, 20), dtype=np.uint8)
+        ok = np.zeros(64, dtype=np.int32)
+        wh.wvh_recover(h, sig, 0, addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+        want = oracle.recover_address(h, sig)
+        assert want is not None and ok.all() and (addr == addr[0]).all() and addr[0].tobytes() == want, hex(t)

@@ -63,3 +63,48 @@ def test_fuzz_rows_vs_oracle(oracle, flags, kernel, n_rows):
             assert 0.2 < got.mean() < 0.5          # the mix really contains both verdicts
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 64])
+def test_crafted_scalars_all_variants(oracle, lanes, monkeypatch):
+    """Signatures built so that u2 = s/r (and u1 = −z/r) take extreme shapes: tiny, ±1 around 2^64 and
+    2^128 (the piece boundaries of the lane groups and of the one-wavefront kernel), n − small, all-ones
+    windows, zero digest.  Most window digits are then zero, accumulators stay at infinity for long
+    stretches, top digits and carries of the signed recoding fire — every kernel variant must still
+    name the same signer as the oracle, cold and then warm."""
+    import go_ibft_amd.verifier as V
+    from oracle import pyref
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    n = pyref.N
+    rng = np.random.default_rng(4242)
+    ts = [1, 2, 3, 7, 8, 9, 15, 16, 17, 255, 256, 2**16 - 1, 2**32, 2**63, 2**64 - 1, 2**64, 2**64 + 1, 2**127,
+          2**128 - 1, 2**128, 2**128 + 1, 2**192, n - 1, n - 2, n - 16, n - 2**64, (n - 1) // 2, (n + 1) // 2,
+          int("8" * 64, 16) % n, int("7" * 64, 16), int("f" * 32, 16)]
+    hs, sigs, addrs = [], [], []
+    for i, t in enumerate(ts):
+        k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        x, y = pyref.pt_mul(k, pyref.G)
+        r = x % n
+        if r == 0 or r != x:
+            continue
+        z = 0 if i % 5 == 0 else (r * ts[(i * 7) % len(ts)]) % n if i % 5 == 1 else int.from_bytes(rng.bytes(32), "big")
+        sig = r.to_bytes(32, "big") + ((t * r) % n).to_bytes(32, "big") + bytes([i & 1])
+        h = z.to_bytes(32, "big")
+        a = oracle.recover_address(h, sig)
+        assert a is not None and a == pyref.recover_address(h, sig)
+        hs.append(np.frombuffer(h, dtype=np.uint8)); sigs.append(np.frombuffer(sig, dtype=np.uint8))
+        addrs.append(np.frombuffer(a, dtype=np.uint8))
+    hs, sigs, addrs = np.array(hs), np.array(sigs), np.array(addrs)
+    assert len(addrs) >= 28 and len(np.unique(addrs, axis=0)) == len(addrs)
+    wrong = addrs.copy()
+    wrong[:, 0] ^= 0x80
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=1024)
+    try:
+        bv.set_validators(1, np.concatenate([addrs, wrong]), np.ones(2 * len(addrs), dtype=np.uint64))
+        for _ in range(2):
+            got, _ = bv.is_valid_committed_seal(np.concatenate([hs, hs]), np.concatenate([sigs, sigs]),
+                                                np.concatenate([addrs, wrong]))
+            assert got[:len(addrs)].all() and not got[len(addrs):].any()
+        assert bv.cache_stats()[0] == len(addrs)
+    finally:
+        bv.close()
