@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -40,7 +41,9 @@ struct ibft_ctx {
   DevBuf d_hash, d_sig, d_signer, d_pre, d_hash_len, d_payload, d_off, d_raw;
   DevBuf d_mask, d_vidx, d_tally, d_H;
   DevBuf d_mask_out;        // verdict words after the tally consumed d_mask (what fetch / export read)
-  bool mask_clean = false;  // d_mask is all zero (the tally left it so): no memset before atomicOr kernels
+  // d_mask words [0, mask_dirty_words) may hold bits; 0 = the whole work mask is zero (the tally left it so)
+  // and no memset is needed in front of the atomicOr kernels
+  uint32_t mask_dirty_words = ~0u;
   DevBuf d_wire_rows, d_seal;  // §8f rank 3: per-row parse results and the COMMIT seals found in the wire bytes
   uint32_t wire_n = 0;         // rows of the last ibft_verify_senders_wire
   bool wire_valid = false;     // its columns are still the resident ones
@@ -128,7 +131,7 @@ int alloc_rows(ibft_ctx *c) {
   if ((rc = ensure(c, c->d_off, (m + 1) * 4))) return rc;
   if ((rc = ensure(c, c->d_mask, (size_t)mask_words(m) * 8))) return rc;
   if ((rc = ensure(c, c->d_mask_out, (size_t)mask_words(m) * 8))) return rc;
-  c->mask_clean = false;
+  c->mask_dirty_words = ~0u;
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
   if ((rc = ensure(c, c->d_tally, 8 * 8))) return rc;
   if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
@@ -175,15 +178,25 @@ int next_events(ibft_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
   return IBFT_OK;
 }
 
+// zero the work mask unless the last tally already left it zero
+int clean_mask(ibft_ctx *c) {
+  if (c->mask_dirty_words == 0) return IBFT_OK;
+  HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
+  c->mask_dirty_words = 0;
+  return IBFT_OK;
+}
+
 // enqueue the verdict kernels over the resident columns: warm kernel first when tables exist
 // (its rows are then skipped by the recover kernel), recover kernel for everything else
 int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it) {
   if (n == 0) return IBFT_OK;
   ibftk::recover_args a = make_args(c, n, with_pre);
-  struct dirty_on_exit {  // whatever is launched below writes verdict bits into d_mask
+  struct dirty_on_exit {  // whatever is launched below writes verdict bits into the first ⌈n/64⌉ words of d_mask
     ibft_ctx *c;
-    ~dirty_on_exit() { c->mask_clean = false; }
-  } mark_dirty{c};
+    uint32_t words;
+    ~dirty_on_exit() { c->mask_dirty_words = std::max(c->mask_dirty_words, words); }
+  } mark_dirty{c, (uint32_t)mask_words(n)};
+  int rc_clean = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (time_it) {
     int rc = next_events(c, &e0, &e1);
@@ -201,7 +214,7 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
       while (G < 64 && (uint64_t)n * (G * 2) <= 65536ull) G *= 2;
     }
     if (G > 1) {
-      if (!c->mask_clean) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
+      if ((rc_clean = clean_mask(c))) return rc_clean;
       const uint32_t rows_per_wave = 64 / G;
       dim3 grid((n + rows_per_wave - 1) / rows_per_wave), block(64);
 #define IBFT_LAUNCH_GROUP(GG)                                                                                  \
@@ -255,13 +268,13 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     else if ((uint64_t)n * 2 <= 65536ull) CG = 2;
   }
   if (CG == 64) {
-    if (!warm && !c->mask_clean) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
+    if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     if (mode == 0)
       hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<0>, dim3(n), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<1>, dim3(n), dim3(64), 0, c->stream, a);
   } else if (CG > 1) {
-    if (!warm && !c->mask_clean) HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
+    if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     const uint32_t rows_per_wave = 64 / CG;
     dim3 cgrid((n + rows_per_wave - 1) / rows_per_wave), cblock(64);
 #define IBFT_LAUNCH_COLD(GG)                                                                         \
@@ -314,7 +327,7 @@ int enqueue_tally(ibft_ctx *c, uint32_t n) {
                      (uint64_t)(c->quorum >> 64), (uint64_t *)c->d_tally.p, c->dh_mask, c->dh_tally);
   HIPCHK(c, hipGetLastError());
   c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally
-  c->mask_clean = true;                    // ... and it zeroed the words it consumed
+  if ((uint32_t)mask_words(n) >= c->mask_dirty_words) c->mask_dirty_words = 0;  // ... and it zeroed every word that held bits
   return IBFT_OK;
 }
 
@@ -563,7 +576,7 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
                        (const uint8_t *)c->d_hash.p, (const uint8_t *)c->d_hash_len.p,
                        (const uint64_t *)c->d_H.p, (uint32_t)n, (uint64_t *)c->d_mask.p);
     HIPCHK(c, hipGetLastError());
-    c->mask_clean = false;  // ballot words, and no tally follows to consume them
+    c->mask_dirty_words = std::max(c->mask_dirty_words, (uint32_t)mask_words(n));  // ballot words, no tally follows
   }
   return fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
 }
@@ -802,7 +815,7 @@ int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_
   int rc;
   c->wire_valid = false;
   if ((rc = upload(c, c->d_signer, sender20, n * 20))) return rc;
-  c->mask_clean = false;
+  c->mask_dirty_words = std::max(c->mask_dirty_words, (uint32_t)mask_words(n));
   if ((rc = upload(c, c->d_mask, mask, (size_t)mask_words(n) * 8))) return rc;
   if (n) {
     hipLaunchKernelGGL(ibftk::lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,

@@ -255,3 +255,27 @@ def test_public_recover_vectors_on_gpu(lanes, monkeypatch):
             assert got.tolist() == [True] * len(k) + [False] * len(k)
     finally:
         bv.close()
+
+
+def test_stale_work_mask_bits_do_not_leak(oracle):
+    """The tally leaves the work mask zeroed only for the words it consumed.  A hash pass over many rows
+    (ballot words, no tally) followed by a small ibft_tally must not let the next seal pass — whose
+    kernels OR their verdicts into the work mask without a memset — inherit stale bits."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    r = W.make_round(3000, 811, byzantine=True)
+    vs = oracle.ValSet(r.addrs, r.power)
+    exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags).astype(bool)
+    bv = V.BatchVerifier(max_rows=4096)
+    try:
+        bv.set_validators(1, r.addrs, r.power)
+        for _ in range(2):
+            hashes = bv.is_valid_proposal_hash(r.raw, r.round, r.hash32, r.hash_len)   # all-ones words, no tally
+            assert hashes.sum() > 2000
+            t = bv.has_quorum(r.signer20[:100], np.ones(100, dtype=bool))               # consumes two words only
+            assert t.valid_rows == 100
+            got, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+            assert (got == exp).all(), np.nonzero(got != exp)[0][:10]
+            assert (~exp).sum() > 100
+    finally:
+        bv.close()
