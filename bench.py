@@ -256,6 +256,25 @@ def main():
                     break
         except (OSError, ValueError):
             pass
+        # the bound that matters for this kernel: VALU issue.  Wavefront-instructions per launch come from
+        # the PMC pass of the same command (tools/pmc_wave.sh → profiles/r*_pmc_instruction_mix.txt, rows =
+        # 1024), the time is the live kernel time; peak = 1024 SIMDs × one wave64 VALU instruction per 4 cycles
+        valu = None
+        try:
+            import glob
+            import re
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instruction_mix.txt")), reverse=True):
+                m = re.search(re.escape(kname.split("<")[0]) + r"<[^>]*>\s+SQ_INSTS_VALU\s+([0-9.]+) per launch",
+                              open(path).read())
+                if m and rows == 1024:
+                    insts = float(m.group(1))
+                    peak = 1024 * 2.4e9 / 4
+                    valu = {"wave_insts_per_launch": insts, "achieved_ginst_s": insts / avg_kernel_s / 1e9,
+                            "peak_ginst_s": peak / 1e9, "frac": insts / avg_kernel_s / peak,
+                            "source": os.path.relpath(path, ROOT)}
+                    break
+        except (OSError, ValueError):
+            pass
         rec = {
             "metric": "committed_seal_verifies_per_sec", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,8 +290,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
-                         "note": "integer-VALU-bound path: HBM fraction is reported as required, "
-                                 "see DESIGN.md for the int-op ceiling"},
+                         "valu_issue": valu,
+                         "note": "integer-VALU-bound path: HBM fraction is reported as required; valu_issue is "
+                                 "the bound that applies (DESIGN.md §5)"},
         }
         if world == 1 and args.path == "cold":
             # extra, NOT the headline: the same batch once every validator's key is known (steady state)
