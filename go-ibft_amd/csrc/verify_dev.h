@@ -13,10 +13,11 @@
 // (a different key with the same address would be a Keccak collision).  Both bases are now
 // FIXED, so with per-validator tables Q·e·2^(8w) (32 windows × 256 affine points = 655 KB per
 // validator; 1 024 validators = 0.67 GB, 65 536 = 43 GB of the 288 GB HBM) there are no
-// doublings at all: 32 + 16 table points are summed.  That sum is a reduction, so one
-// wavefront can take one signature: 48 lanes fetch one point each and a 6-level butterfly of
-// point additions finishes it (verify_known_wave, kernels.hip.h); the lane-per-signature form
-// below is used when there are enough rows to fill the chip anyway.
+// doublings at all: 32 + 16 table points are summed.  That sum is a reduction, so several lanes
+// can share one signature: G lanes fetch their share of the points and a log2(G)-level butterfly of
+// point additions finishes it (verify_known_group_kernel, kernels.hip.h); with one wavefront per
+// signature the sum runs in the row layout of wave_fe_dev.h (verify_known_wave); the lane-per-
+// signature form below is used when there are enough rows to fill the chip anyway.
 #pragma once
 #include "recover_dev.h"
 
