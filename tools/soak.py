@@ -1,0 +1,75 @@
+"""SURVEY.md §8d soak (run on the GPU box): bit-identical verdicts and quorum decisions over many synthetic
+rounds.  Default: 10 000 rounds at N = 64 with seeds 1…10000 (every validator key, proposal and the 20 %
+Byzantine mix derive from the seed; odd seeds use weighted voting power) + 100 rounds at each larger N.
+Every round goes through ibft_verify_seals twice on a key-caching context (first pass: recover kernels,
+second pass: known-key kernels) and is compared with the CPU oracle: verdict of every row, Σ power, valid
+rows, distinct senders, quorum flag.  Workers generate rounds and oracle answers in parallel; the GPU
+consumer is this process.  Prints one JSON object."""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make(job):
+    n, seed = job
+    from oracle import binding as B
+    from oracle import workload as W
+    r = W.make_round(n, seed, byzantine=True, weighted=bool(seed & 1))
+    vs = B.ValSet(r.addrs, r.power)
+    exp = B.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=1)
+    t = B.tally(vs, r.signer20, exp)
+    return (n, seed, r.addrs, r.power, r.hash32, r.seal65, r.signer20, r.pre_flags, exp.astype(bool),
+            (t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=10000)
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--large", type=str, default="256,1024,4096")
+    ap.add_argument("--large-rounds", type=int, default=100)
+    ap.add_argument("--procs", type=int, default=0)
+    args = ap.parse_args()
+    import go_ibft_amd.verifier as V
+    jobs = [(args.n, s) for s in range(1, args.rounds + 1)]
+    for n in [int(x) for x in args.large.split(",") if x]:
+        jobs += [(n, s) for s in range(1, args.large_rounds + 1)]
+    procs = args.procs or min(16, len(os.sched_getaffinity(0)))
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=8192)
+    stat = {}
+    t0 = time.time()
+    with mp.get_context("fork").Pool(procs) as pool:
+        for (n, seed, addrs, power, h, s, f, pre, exp, et) in pool.imap(make, jobs, chunksize=8):
+            st = stat.setdefault(n, {"rounds": 0, "rows": 0, "bad_rows": 0, "verdict_row_mismatches": 0,
+                                     "tally_mismatches": 0, "quorum_mismatches": 0, "quorum_true": 0,
+                                     "passes": 0})
+            bv.set_validators(seed, addrs, power)
+            for _ in range(2):  # recover kernels, then known-key kernels for the keys just learned
+                got, t = bv.is_valid_committed_seal(h, s, f, pre)
+                st["verdict_row_mismatches"] += int((got != exp).sum())
+                st["tally_mismatches"] += int((t.power, t.quorum, t.valid_rows, t.distinct_senders) != et[:4])
+                st["quorum_mismatches"] += int(t.has_quorum != et[4])
+                st["passes"] += 1
+            st["rounds"] += 1
+            st["rows"] += n
+            st["bad_rows"] += int((~exp).sum())
+            st["quorum_true"] += int(et[4])
+    bv.close()
+    out = {"seconds": round(time.time() - t0, 1), "procs": procs, "by_n": {str(k): v for k, v in sorted(stat.items())},
+           "total_rounds": sum(v["rounds"] for v in stat.values()),
+           "total_mismatches": sum(v["verdict_row_mismatches"] + v["tally_mismatches"] + v["quorum_mismatches"]
+                                   for v in stat.values())}
+    print(json.dumps(out))
+    sys.exit(0 if out["total_mismatches"] == 0 else 1)
+
+
+if __name__ == "__main__":
+    main()
