@@ -78,7 +78,25 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
     t1 = time.perf_counter()
     B.verify_seals(vs, hash32[:256], seal65[:256], signer20[:256], nthreads=1)
     single = 256 / (time.perf_counter() - t1)
+    # secondary, independent CPU number: OpenSSL's EC_POINT arithmetic doing the recover, 1 thread
+    ossl_rate = None
+    try:
+        import ctypes
+        import subprocess
+        odir = os.path.join(ROOT, "oracle")
+        subprocess.run(["make", "-C", odir, "libopenssl_xcheck.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        ol = ctypes.CDLL(os.path.join(odir, "libopenssl_xcheck.so"))
+        pub = ctypes.create_string_buffer(64)
+        t2, k2 = time.perf_counter(), 0
+        while time.perf_counter() - t2 < 1.0:
+            i = k2 % n
+            assert ol.ossl_ecrecover(hash32[i].tobytes(), seal65[i].tobytes(), pub) == 1
+            k2 += 1
+        ossl_rate = k2 / (time.perf_counter() - t2)
+    except (OSError, AssertionError, AttributeError):
+        pass
     return {"value": done / el, "unit": "verifies/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "openssl_ec_recover_1thread": ossl_rate,
             "sample": f"{done} seal verifies (the N={n} COMMIT batch tiled x{reps} per call, repeated for "
                       f"{el:.1f} s, {cores} pthreads); 1 thread: {single:.0f} verifies/s"}
 
