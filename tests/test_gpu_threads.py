@@ -72,3 +72,53 @@ def test_one_context_shared_by_threads(oracle):
         t.join()
     bv.close()
     assert not errors, errors
+
+
+_EXPORT_ON_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                                  # before libibftgpu.so: one HIP runtime per process, torch's
+torch.cuda.init()
+sys.path.insert(0, sys.argv[1])
+import go_ibft_amd.verifier as V
+from oracle import binding as oracle, workload as W
+r = W.make_round(1500, 91, byzantine=True, weighted=True)
+vs = oracle.ValSet(r.addrs, r.power)
+exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=4).astype(bool)
+et = oracle.tally(vs, r.signer20, exp.astype(np.uint8))
+words = (r.n + 63) // 64
+bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=4096)
+side = torch.cuda.Stream()
+bufs = [torch.zeros(words + 4, dtype=torch.int64, device="cuda") for _ in range(6)]
+bv.set_validators(1, r.addrs, r.power)
+bv.seals_stage(r.hash32, r.seal65, r.signer20, r.pre_flags)
+bv.seals_launch(1)
+for k, b in enumerate(bufs):                  # cold pass first, known-key passes after
+    bv.seals_export_on(b.data_ptr(), b[words:].data_ptr(), side.cuda_stream)
+    if k + 1 < len(bufs):
+        bv.seals_launch(1)                    # enqueued before the copies of pass k have run
+side.synchronize()
+bv.sync()
+for b in bufs:
+    h = b.cpu().numpy().view(np.uint64)
+    got = V.mask_to_bool(h[:words].copy(), r.n)
+    assert (got == exp).all()
+    assert int(h[words]) | (int(h[words + 1]) << 64) == et.power
+    assert int(h[words + 2]) & 0xFFFFFFFF == et.valid_rows and int(h[words + 3]) == et.has_quorum
+bv.close()
+print("EXPORT_ON_OK")
+"""
+
+
+def test_export_on_a_consumer_stream():
+    """ibft_seals_export_on: the verdict words and tally partials reach caller-owned device buffers through
+    the caller's stream (no host wait inside the call), launches keep flowing on the context's own stream,
+    and the next tally waits for the copies — what bench.py's sharded loop relies on.  Runs in its own
+    process with torch imported first (as bench.py does): loading torch's bundled HIP runtime after
+    libibftgpu.so has initialised the system one leaves torch without a device."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _EXPORT_ON_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "EXPORT_ON_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
