@@ -222,12 +222,13 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     hipLaunchKernelGGL((ibftk::verify_known_group_kernel<0, GG>), grid, block, 0, c->stream, a);               \
   else                                                                                                         \
     hipLaunchKernelGGL((ibftk::verify_known_group_kernel<1, GG>), grid, block, 0, c->stream, a);
+      const dim3 wgrid((n + ibftk::WAVE_KERNEL_WAVES - 1) / ibftk::WAVE_KERNEL_WAVES), wblock(64 * ibftk::WAVE_KERNEL_WAVES);
       switch (G) {
         case 64:
           if (mode == 0)
-            hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<0>, dim3(n), block, 0, c->stream, a);
+            hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<0>, wgrid, wblock, 0, c->stream, a);
           else
-            hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<1>, dim3(n), block, 0, c->stream, a);
+            hipLaunchKernelGGL(ibftk::verify_known_wave_kernel<1>, wgrid, wblock, 0, c->stream, a);
           break;
         case 32: IBFT_LAUNCH_GROUP(32) break;
         case 16: IBFT_LAUNCH_GROUP(16) break;
@@ -270,9 +271,11 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   if (CG == 64) {
     if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     if (mode == 0)
-      hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<0>, dim3(n), dim3(64), 0, c->stream, a);
+      hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<0>, dim3((n + ibftk::WAVE_KERNEL_WAVES - 1) / ibftk::WAVE_KERNEL_WAVES),
+                         dim3(64 * ibftk::WAVE_KERNEL_WAVES), 0, c->stream, a);
     else
-      hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<1>, dim3(n), dim3(64), 0, c->stream, a);
+      hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<1>, dim3((n + ibftk::WAVE_KERNEL_WAVES - 1) / ibftk::WAVE_KERNEL_WAVES),
+                         dim3(64 * ibftk::WAVE_KERNEL_WAVES), 0, c->stream, a);
   } else if (CG > 1) {
     if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     const uint32_t rows_per_wave = 64 / CG;

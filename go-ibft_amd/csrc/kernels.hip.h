@@ -315,11 +315,17 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
   if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 
+// WAVE_KERNEL_WAVES wavefronts (= signatures) per workgroup: the four wavefronts of a workgroup land on
+// the four SIMDs of one CU, so a 1 024-row launch is exactly one wavefront per SIMD by construction
+// instead of by the dispatcher's choice.
+constexpr int WAVE_KERNEL_WAVES = 4;
 // ---- warm path, one wavefront per signature with the limbs spread over lanes (wave_fe_dev.h) ----
 // Replaces verify_known_group_kernel<·,64>: same prologue, the point sum runs in the row layout.
 template <int MODE>
-__global__ void __launch_bounds__(64) verify_known_wave_kernel(recover_args a) {
-  const uint32_t row = blockIdx.x;
+__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) verify_known_wave_kernel(recover_args a) {
+  const uint32_t row = blockIdx.x * WAVE_KERNEL_WAVES + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (row >= a.n) return;  // whole wavefront
   const bool pre = a.pre_flags && a.pre_flags[row] != 0;
   const u256 r = secp::from_be32(a.sig65 + 65ull * row);
   const u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
@@ -338,13 +344,13 @@ __global__ void __launch_bounds__(64) verify_known_wave_kernel(recover_args a) {
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
   const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
   const bool decided = pre || vi < 0 || have_table;
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     a.warm_done[row] = decided ? 1 : 0;
     if (decided) a.vidx[row] = vi;
   }
   if (pre || !have_table) return;  // wave-uniform: the wavefront holds one row
   const bool ok = wv::verify_known_wave(a.gtab, a.qtab + QTAB_DWORDS_PER_VALIDATOR * (uint32_t)vi, z, r, s, v, a.flags);
-  if (threadIdx.x == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+  if (lane == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 
 // ---- cold path with G = 2, 4 or 8 lanes per signature ----------------------------------------
@@ -507,15 +513,17 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
 // instructions for four independent products, and the four rows carry the four 64-bit pieces
 // of the GLV-split scalar.  All control flow is uniform: the wavefront holds a single signature.
 template <int MODE>
-__global__ void __launch_bounds__(64) ecrecover_wave_kernel(recover_args a) {
-  const uint32_t row = blockIdx.x;
+__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(recover_args a) {
+  const uint32_t row = blockIdx.x * WAVE_KERNEL_WAVES + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (row >= a.n) return;                            // whole wavefront
   if (a.warm_done && a.warm_done[row] != 0) return;  // decided by the warm kernel
   uint32_t want[5];
 #pragma unroll
   for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
   const bool pre = a.pre_flags && a.pre_flags[row] != 0;
-  if (threadIdx.x == 0) a.vidx[row] = vi;
+  if (lane == 0) a.vidx[row] = vi;
   if (pre || vi < 0) return;  // verdict stays 0 (mask was cleared by the host before the launch)
   const u256 r = secp::from_be32(a.sig65 + 65ull * row);
   const u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
@@ -533,7 +541,7 @@ __global__ void __launch_bounds__(64) ecrecover_wave_kernel(recover_args a) {
   bool ok = wv::recover_pubkey_wave(a.gtab, z, r, s, v, a.flags, got, Qa);
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
-  if (threadIdx.x == 0 && ok) {
+  if (lane == 0 && ok) {
     if (a.pub_state && a.pub_state[vi] == 0) {
       store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
       __threadfence();
