@@ -254,6 +254,7 @@ def main():
             bv.cache_stats()
         cold_lanes = bv.last_dispatch()[0]
         kname = ("ecrecover_lane_kernel<0>" if cold_lanes == 1 else "ecrecover_wave_kernel<0>" if cold_lanes == 64
+                 else "ecrecover_rows_kernel<0>" if cold_lanes == 16
                  else f"ecrecover_group_kernel<0,{cold_lanes}>") \
             if args.path == "cold" else (
             "verify_known_wave_kernel<0>" if bv.lanes_per_signature == 64

@@ -112,6 +112,23 @@ void lane_prefix(void *vp) {
   j->out[192 + l] = root;
 }
 
+struct rec4_job {
+  const uint8_t *hash32x4, *sig65x4;  // four signatures, one per row
+  uint8_t *addr20;                    // [64][20]
+  int *ok;                            // [64]
+};
+void lane_rec4(void *vp) {
+  rec4_job *j = (rec4_job *)vp;
+  const int l = wave_emul::lane(), row = l >> 4;
+  const uint8_t *h = j->hash32x4 + 32 * row, *sg = j->sig65x4 + 65 * row;
+  u256 z = secp::from_be32(h), r = secp::from_be32(sg), s = secp::from_be32(sg + 32);
+  uint32_t a[5];
+  secp::aff Q;
+  bool ok = wv::recover_pubkey_row(g_gtab.data(), z, r, s, sg[64], 0, a, Q);
+  memcpy(j->addr20 + 20 * l, a, 20);
+  j->ok[l] = ok ? 1 : 0;
+}
+
 struct inv_job {
   const uint8_t *x32;
   uint8_t *out;  // [64][32]
@@ -148,6 +165,10 @@ void wvh_build_qtab(const uint8_t *pub64, uint32_t *qtab) {
   Q.y = secp::fe_from_u256(secp::from_be32(pub64 + 32));
   for (int w = 0; w < ibftk::QTAB_WINDOWS; w++)
     ibftk::qtab_build_window(Q, w, qtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ibftk::QTAB_ENTRIES * w, true);
+}
+void wvh_recover4(const uint8_t *hash32x4, const uint8_t *sig65x4, uint8_t *addr64x20, int *ok64) {
+  rec4_job j{hash32x4, sig65x4, addr64x20, ok64};
+  wave_emul::run(lane_rec4, &j);
 }
 void wvh_modinv(int which, const uint8_t *x32, uint8_t *out64x32) {
   inv_job j{x32, out64x32, which};

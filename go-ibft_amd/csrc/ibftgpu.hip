@@ -66,6 +66,8 @@ struct ibft_ctx {
   uint32_t warm_passes = 0, cold_passes = 0, last_group = 0, last_cold_group = 1;
   bool cold_group_auto = true;
   uint32_t cold_group_force = 0;  // IBFT_COLD_LANES=1|2|4|8|64 (experiments: pin the cold kernel variant)
+  uint32_t rows_kernel_max = 8192;  // AUTO: a DPP row per signature above wave_rows_max up to this many rows
+                                    // (4 096 rows: 0.55 ms vs 0.84 ms for the 8-lane kernel; 8 192: 0.84 vs 0.86)
   uint32_t wave_rows_max = 3072;  // AUTO: one wavefront per signature up to this many rows (3 per SIMD: 0.67 ms vs 0.84 ms
                                   // for the 8-lane kernel at 3072 rows; a tie at 4096)
 
@@ -264,11 +266,20 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     CG = c->cold_group_force;
   } else if (c->cold_group_auto) {
     if ((uint64_t)n <= c->wave_rows_max) CG = 64;
+    else if ((uint64_t)n <= c->rows_kernel_max) CG = 16;
     else if ((uint64_t)n * 8 <= 65536ull) CG = 8;
     else if ((uint64_t)n * 4 <= 65536ull) CG = 4;
     else if ((uint64_t)n * 2 <= 65536ull) CG = 2;
   }
-  if (CG == 64) {
+  if (CG == 16) {
+    if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
+    const uint32_t waves = (n + 3) / 4;
+    const dim3 rgrid((waves + ibftk::WAVE_KERNEL_WAVES - 1) / ibftk::WAVE_KERNEL_WAVES), rblock(64 * ibftk::WAVE_KERNEL_WAVES);
+    if (mode == 0)
+      hipLaunchKernelGGL(ibftk::ecrecover_rows_kernel<0>, rgrid, rblock, 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(ibftk::ecrecover_rows_kernel<1>, rgrid, rblock, 0, c->stream, a);
+  } else if (CG == 64) {
     if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     if (mode == 0)
       hipLaunchKernelGGL(ibftk::ecrecover_wave_kernel<0>, dim3((n + ibftk::WAVE_KERNEL_WAVES - 1) / ibftk::WAVE_KERNEL_WAVES),
@@ -423,9 +434,10 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
   if (const char *e = getenv("IBFT_COLD_LANES")) {
     const int g = atoi(e);
-    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 64) c->cold_group_force = (uint32_t)g;
+    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64) c->cold_group_force = (uint32_t)g;
   }
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("IBFT_ROWS_KERNEL_MAX")) c->rows_kernel_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }

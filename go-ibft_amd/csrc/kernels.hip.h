@@ -9,6 +9,7 @@
 //   ecrecover_lane_kernel       a2  IsValidCommittedSeal  (core/ibft.go:943)      cold path,
 //   ecrecover_group_kernel<G>   a3  IsValidValidator      (core/ibft.go:1128)     1 / 2,4,8 lanes per signature
 //   ecrecover_wave_kernel           same, one wavefront per signature (limbs spread over lanes, wave_fe_dev.h)
+//   ecrecover_rows_kernel           same, sixteen lanes (one DPP row) per signature, four signatures per wavefront
 //   verify_known_lane_kernel    a2/a3 against the validator's known key (warm path), 1 lane per signature
 //   verify_known_group_kernel<G>    same, G = 2..32 lanes per signature
 //   verify_known_wave_kernel        same, one wavefront per signature in the row layout of wave_fe_dev.h
@@ -542,6 +543,55 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
   if (lane == 0 && ok) {
+    if (a.pub_state && a.pub_state[vi] == 0) {
+      store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
+      __threadfence();
+      a.pub_state[vi] = 1;
+      atomicAdd(a.learned, 1u);
+      a.learned[1] = (uint32_t)vi;
+    }
+    atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+  }
+}
+
+// ---- cold path, SIXTEEN LANES PER SIGNATURE: every row of a wavefront recovers its own signature ------
+// (wave_fe_dev.h:recover_pubkey_row).  n = 4 096 is one wavefront per SIMD again; used for
+// 3 072 < n ≤ 8 192.  Rows beyond n recompute the last row and store nothing.
+template <int MODE>
+__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_rows_kernel(recover_args a) {
+  const uint32_t wave = blockIdx.x * WAVE_KERNEL_WAVES + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (wave * 4u >= a.n) return;  // whole wavefront
+  const uint32_t row_raw = wave * 4u + (lane >> 4);
+  const bool live = row_raw < a.n;
+  const uint32_t row = live ? row_raw : a.n - 1;
+  uint32_t want[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
+  const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  const bool pre = a.pre_flags && a.pre_flags[row] != 0;
+  const bool done = a.warm_done && a.warm_done[row] != 0;
+  const bool need = live && !done;
+  if (need && (lane & 15u) == 0) a.vidx[row] = vi;
+  if (!__any((need && !pre && vi >= 0) ? 1 : 0)) return;  // nothing in this wavefront needs the curve
+  const u256 r = secp::from_be32(a.sig65 + 65ull * row);
+  const u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
+  const uint32_t v = a.sig65[65ull * row + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(a.hash32 + 32ull * row);
+  } else {
+    uint64_t d[4];
+    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    keccak::digest_to_limbs(d, z.v);
+  }
+  uint32_t got[5];
+  aff Qa;
+  bool ok = wv::recover_pubkey_row(a.gtab, z, r, s, v, a.flags, got, Qa);
+  ok = ok && need && !pre && vi >= 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
+  if ((lane & 15u) == 0 && ok) {
     if (a.pub_state && a.pub_state[vi] == 0) {
       store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
       __threadfence();

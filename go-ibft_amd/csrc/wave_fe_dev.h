@@ -722,11 +722,6 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
 #undef WV_STAGE
 }
 
-// ---- the warm path, one signature per wavefront --------------------------------------------------------
-// Same contract as ibftk::verify_known (verify_dev.h): accept ⇔ R′ = (z/s)·G + (r/s)·Q is finite,
-// R′.x = r and parity(R′.y) = v.  The 32 + GTAB_WINDOWS table points are dealt to the four rows;
-// a row adds its share with mixed additions (11 multiplications of ≈72 instructions for the four
-// rows together, against 11 × 224 per lane in the lane layout), two row-xor additions join them.
 WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
   const uint32_t ld = k.li < 10 ? k.li : 0u;
   waff pt;
@@ -734,6 +729,105 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
   pt.y = e20[10 + ld] & k.act;
   return pt;
 }
+// ---- sixteen lanes per signature: every ROW of the wavefront recovers its own signature -------------------
+// For batches between the one-wavefront form (n ≤ 3 072) and the point where eight lanes per signature
+// fill the chip (n = 8 192): four signatures per wavefront, so n = 4 096 is again one wavefront per SIMD.
+// Nothing is shared between rows, so there are no pieces, no prefix and no joins: a row runs the
+// textbook interleaved GLV multiplication — 128 doublings shared by k1 and k2, two signed radix-16
+// tables (the λ table is the first one with X·β), 33 digits each — then its sixteen G-table additions.
+// Lane-layout values (r, s, z, the scalars, the digits) simply differ from row to row; the only wave-wide
+// operations are the `any` votes, which merely make every row wait for the slowest one.
+WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
+                           uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa) {
+  const wk k = wk_init();
+  bool ok = ibftk::sig_in_range(r, s, v, flags);
+  const fe rx = secp::fe_from_u256(r);
+  const uint32_t x = scatter(rx, k);
+  const uint32_t one = k.li == 0 ? 1u : 0u;
+  const uint32_t rhs = wfe_mul(wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u);  // magnitude 2
+  const uint32_t yc = wfe_sqrt_candidate(rhs, k);
+  ok = ok && wfe_is_zero(wfe_sqr(yc, k) + wfe_neg2(rhs, k));
+  fe y = secp::fe_normalize(gather(yc));
+  y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
+  // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
+  const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
+  const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
+  const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+  const secp::glv_split sp = secp::sc_split_lambda(u2);
+  // signed radix-16 digits of |k1|, |k2|: k + 0x88…8 has nibbles d_j + 8, bit 128 is digit 32
+  uint32_t w1[5], w2[5];
+  {
+    uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      w1[i] = secp::addc(sp.k1.v[i], 0x88888888u, c1);
+      w2[i] = secp::addc(sp.k2.v[i], 0x88888888u, c2);
+    }
+    w1[4] = c1;
+    w2[4] = c2;
+  }
+  // tables 1..8 of R (affine start: mixed additions) and, through X·β, of λR
+  const waff R1 = waff{x, scatter(y, k)};
+  wjac T[9];
+  T[1] = wjac_from_aff(R1, k);
+  T[2] = wjac_dbl(T[1], k);
+  T[3] = wjac_add_aff(T[2], R1, k);
+  T[4] = wjac_dbl(T[2], k);
+  T[5] = wjac_add_aff(T[4], R1, k);
+  T[6] = wjac_dbl(T[3], k);
+  T[7] = wjac_add_aff(T[6], R1, k);
+  T[8] = wjac_dbl(T[4], k);
+  const uint32_t beta = scatter(secp::GLV_CONST(1), k);
+  uint32_t TX[9];
+#pragma unroll
+  for (int e = 1; e <= 8; e++) TX[e] = wfe_mul(T[e].x, beta, k);
+  wjac acc = wjac_inf();
+#pragma unroll 1
+  for (int jd = 32; jd >= 0; jd--) {
+    if (jd < 32) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) acc = wjac_dbl<true>(acc, k);
+    }
+    // digit jd of both scalars (digit 32 is the carry bit, never negative)
+    const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
+    const int d1 = jd == 32 ? (int)(w1[4] & 1u) : n1 - 8, d2 = jd == 32 ? (int)(w2[4] & 1u) : n2 - 8;
+    const uint32_t m1 = (uint32_t)(d1 < 0 ? -d1 : d1), m2 = (uint32_t)(d2 < 0 ? -d2 : d2);
+    wjac q1 = T[1], q2 = T[1];
+    uint32_t x2 = TX[1];
+#pragma unroll
+    for (int e = 2; e <= 8; e++) {
+      q1 = wjac_select(m1 == (uint32_t)e, T[e], q1);
+      q2 = wjac_select(m2 == (uint32_t)e, T[e], q2);
+      x2 = m2 == (uint32_t)e ? TX[e] : x2;
+    }
+    q2.x = x2;
+    q1.y = ((d1 < 0) != sp.neg1) ? wfe_neg1(q1.y, k) : q1.y;  // magnitude ≤ 2
+    q2.y = ((d2 < 0) != sp.neg2) ? wfe_neg1(q2.y, k) : q2.y;
+    const wjac s1 = wjac_add<true>(acc, q1, k);
+    acc = wjac_select(m1 != 0, s1, acc);
+    const wjac s2 = wjac_add<true>(acc, q2, k);
+    acc = wjac_select(m2 != 0, s2, acc);
+  }
+  // u1·G: all the fixed-base windows in this row
+#pragma unroll 1
+  for (int win = 0; win < ibftk::GTAB_WINDOWS; win++) {
+    const int bit = win * ibftk::GTAB_BITS;
+    const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    const waff pt = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt), k);
+    const wjac sum = wjac_add_aff<true>(acc, pt, k);
+    acc = wjac_select(dgt != 0, sum, acc);
+  }
+  ok = jac_to_aff_wave(Qa, wjac_gather(acc), k) && ok;
+  u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
+  keccak::address_from_xy(qx.v, qy.v, addr);
+  return ok;
+}
+
+// ---- the warm path, one signature per wavefront --------------------------------------------------------
+// Same contract as ibftk::verify_known (verify_dev.h): accept ⇔ R′ = (z/s)·G + (r/s)·Q is finite,
+// R′.x = r and parity(R′.y) = v.  The 32 + GTAB_WINDOWS table points are dealt to the four rows;
+// a row adds its share with mixed additions (11 multiplications of ≈72 instructions for the four
+// rows together, against 11 × 224 per lane in the lane layout), two row-xor additions join them.
 WVF bool verify_known_wave(const uint32_t *__restrict__ gtab, const uint32_t *__restrict__ qtab_v, const u256 &z_raw,
                            const u256 &r, const u256 &s, uint32_t v, uint32_t flags) {
   const wk k = wk_init();

@@ -81,14 +81,16 @@ extern "C" {
 #define IBFT_ROW_HASH_BAD 0x04u
 
 /* cfg.kernel: how many lanes work on one signature.  The verdicts never depend on it.
- *   AUTO  cold path (recover): one wavefront per signature up to 3072 rows, then 8 / 4 / 2 lanes
- *         per signature while rows*lanes <= 65536, one lane beyond;
+ *   AUTO  cold path (recover): one wavefront per signature up to 3072 rows, one DPP row (16 lanes) per
+ *         signature up to 8192 rows, then 4 / 2 lanes per signature while rows*lanes <= 65536, one
+ *         lane beyond (the 8-lane form remains selectable);
  *         warm path (known keys): G = 64,32,...,2 lanes per signature so that a batch gives about
  *         one wavefront per SIMD (64 up to 1024 rows), one lane from 65536 rows.
  *   LANE  always one lane per signature (throughput form, both paths).
  *   WAVE  warm path pinned to one wavefront per signature.
- * Experiments only: the environment variable IBFT_COLD_LANES = 1|2|4|8|64 pins the cold variant,
- * IBFT_WAVE_ROWS_MAX moves the AUTO threshold of the one-wavefront form (read at ibft_ctx_create). */
+ * Experiments only: the environment variable IBFT_COLD_LANES = 1|2|4|8|16|64 pins the cold variant,
+ * IBFT_WAVE_ROWS_MAX / IBFT_ROWS_KERNEL_MAX move the AUTO thresholds of the one-wavefront and the
+ * row-per-signature forms (read at ibft_ctx_create). */
 #define IBFT_KERNEL_AUTO 0u
 #define IBFT_KERNEL_LANE 1u
 #define IBFT_KERNEL_WAVE 2u

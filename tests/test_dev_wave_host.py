@@ -153,3 +153,32 @@ def test_full_recover_with_crafted_scalars(wh, oracle):
         wh.wvh_recover(h, sig, 0, addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
         want = oracle.recover_address(h, sig)
         assert want is not None and ok.all() and (addr == addr[0]).all() and addr[0].tobytes() == want, hex(t)
+
+
+def test_row_per_signature_recover(wh, oracle):
+    """recover_pubkey_row: four different signatures in the four rows of one emulated wavefront — a good one,
+    a crafted tiny u2, an invalid x (no square root), a zero digest — each row must answer for its own."""
+    from oracle import pyref
+    wh.wvh_init_gtab()
+    rng = np.random.default_rng(2024)
+    n = pyref.N
+    hs, sigs = [], []
+    sk = (int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1).to_bytes(32, "big")
+    h0 = rng.bytes(32)
+    hs.append(h0); sigs.append(oracle.sign(sk, h0))
+    x, _ = pyref.pt_mul(int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1, pyref.G)
+    hs.append(rng.bytes(32)); sigs.append((x % n).to_bytes(32, "big") + ((17 * x) % n).to_bytes(32, "big") + b"\x01")
+    hs.append(rng.bytes(32)); sigs.append((5).to_bytes(32, "big") + sigs[0][32:64] + b"\x00")   # x = 5: not on the curve
+    sk2 = (int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1).to_bytes(32, "big")
+    hs.append(bytes(32)); sigs.append(oracle.sign(sk2, bytes(32)))
+    addr = np.zeros((64, 20), dtype=np.uint8)
+    ok = np.zeros(64, dtype=np.int32)
+    wh.wvh_recover4(b"".join(hs), b"".join(sigs), addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+    for row in range(4):
+        want = oracle.recover_address(hs[row], sigs[row])
+        lanes = slice(16 * row, 16 * row + 16)
+        assert (ok[lanes] == ok[16 * row]).all() and (addr[lanes] == addr[16 * row]).all()
+        assert bool(ok[16 * row]) == (want is not None), row
+        if want is not None:
+            assert addr[16 * row].tobytes() == want, row
+    assert [bool(ok[16 * r]) for r in range(4)] == [True, True, False, True]

@@ -59,10 +59,10 @@ def test_ragged_sizes_vs_oracle(gpu_verifier, gpu_verifier_lane, oracle, n):
         assert (senders == oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)).all()
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
 def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
-    """IBFT_COLD_LANES pins the cold kernel: lane kernel, 2/4/8-lane groups, one wavefront per
-    signature (64).  Same Byzantine round, seals and senders, strict-low-s on and off."""
+    """IBFT_COLD_LANES pins the cold kernel: lane kernel, 2/4/8-lane groups, one DPP row per
+    signature (16), one wavefront per signature (64).  Same Byzantine round, seals and senders, strict-low-s on and off."""
     import go_ibft_amd.verifier as V
     from oracle import workload as W
     monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
@@ -83,13 +83,14 @@ def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
             bv.close()
 
 
-@pytest.mark.parametrize("n,expect_group", [(1500, 64), (8192, 8), (12000, 4), (20000, 2), (40000, 1)])
+@pytest.mark.parametrize("n,expect_group", [(1500, 64), (5000, 16), (8192, 16), (12000, 4), (20000, 2), (40000, 1)])
 def test_cold_group_sizes(oracle, n, expect_group):
-    """AUTO picks one wavefront per signature up to 3 072 rows, then 8/4/2/1 lanes per signature so
+    """AUTO picks one wavefront per signature up to 3 072 rows, one DPP row per signature up to 8 192,
+    then 4/2/1 lanes per signature so
     that n·G/64 ≤ 1024 wavefronts; each choice is compared with the oracle on a Byzantine round."""
     import go_ibft_amd.verifier as V
     from oracle import workload as W
-    assert (64 if n <= 3072 else 8 if n * 8 <= 65536 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
+    assert (64 if n <= 3072 else 16 if n <= 8192 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
     r = W.make_round(n, 3000 + n, byzantine=True)
     bv = V.BatchVerifier(max_rows=65536)
     try:
