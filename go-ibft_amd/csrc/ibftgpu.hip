@@ -68,8 +68,8 @@ struct ibft_ctx {
   uint32_t cold_group_force = 0;  // IBFT_COLD_LANES=1|2|4|8|64 (experiments: pin the cold kernel variant)
   uint32_t rows_kernel_max = 8192;  // AUTO: a DPP row per signature above wave_rows_max up to this many rows
                                     // (4 096 rows: 0.55 ms vs 0.84 ms for the 8-lane kernel; 8 192: 0.84 vs 0.86)
-  uint32_t wave_rows_max = 3072;  // AUTO: one wavefront per signature up to this many rows (3 per SIMD: 0.67 ms vs 0.84 ms
-                                  // for the 8-lane kernel at 3072 rows; a tie at 4096)
+  uint32_t wave_rows_max = 2048;  // AUTO: one wavefront per signature up to this many rows (two per SIMD: 0.45 ms); the
+                                  // row-per-signature kernel (0.55 ms up to 4 096 rows) wins from there
 
   // staged batch
   uint32_t staged_n = 0;

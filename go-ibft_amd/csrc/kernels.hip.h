@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
 }
 
 // ---- cold path, ONE WAVEFRONT PER SIGNATURE (wave_fe_dev.h) --------------------------------------
-// For batches that leave most of the chip idle (n ≤ 3 072: at most three wavefronts per SIMD).  A
+// For batches that leave most of the chip idle (n ≤ 2 048: at most two wavefronts per SIMD).  A
 // field element is one VGPR spread over the 16 lanes of a DPP row, a multiplication costs ≈86
 // instructions for four independent products, and the four rows carry the four 64-bit pieces
 // of the GLV-split scalar.  All control flow is uniform: the wavefront holds a single signature.
@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
 
 // ---- cold path, SIXTEEN LANES PER SIGNATURE: every row of a wavefront recovers its own signature ------
 // (wave_fe_dev.h:recover_pubkey_row).  n = 4 096 is one wavefront per SIMD again; used for
-// 3 072 < n ≤ 8 192.  Rows beyond n recompute the last row and store nothing.
+// 2 048 < n ≤ 8 192.  Rows beyond n recompute the last row and store nothing.
 template <int MODE>
 __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_rows_kernel(recover_args a) {
   const uint32_t wave = blockIdx.x * WAVE_KERNEL_WAVES + (threadIdx.x >> 6);

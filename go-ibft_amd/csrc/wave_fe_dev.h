@@ -730,7 +730,7 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
   return pt;
 }
 // ---- sixteen lanes per signature: every ROW of the wavefront recovers its own signature -------------------
-// For batches between the one-wavefront form (n ≤ 3 072) and the point where eight lanes per signature
+// For batches between the one-wavefront form (n ≤ 2 048) and the point where eight lanes per signature
 // fill the chip (n = 8 192): four signatures per wavefront, so n = 4 096 is again one wavefront per SIMD.
 // Nothing is shared between rows, so there are no pieces, no prefix and no joins: a row runs the
 // textbook interleaved GLV multiplication — 128 doublings shared by k1 and k2, two signed radix-16

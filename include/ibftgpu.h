@@ -81,7 +81,7 @@ extern "C" {
 #define IBFT_ROW_HASH_BAD 0x04u
 
 /* cfg.kernel: how many lanes work on one signature.  The verdicts never depend on it.
- *   AUTO  cold path (recover): one wavefront per signature up to 3072 rows, one DPP row (16 lanes) per
+ *   AUTO  cold path (recover): one wavefront per signature up to 2048 rows, one DPP row (16 lanes) per
  *         signature up to 8192 rows, then 4 / 2 lanes per signature while rows*lanes <= 65536, one
  *         lane beyond (the 8-lane form remains selectable);
  *         warm path (known keys): G = 64,32,...,2 lanes per signature so that a batch gives about

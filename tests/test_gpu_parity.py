@@ -83,14 +83,14 @@ def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
             bv.close()
 
 
-@pytest.mark.parametrize("n,expect_group", [(1500, 64), (5000, 16), (8192, 16), (12000, 4), (20000, 2), (40000, 1)])
+@pytest.mark.parametrize("n,expect_group", [(1500, 64), (3000, 16), (5000, 16), (8192, 16), (12000, 4), (20000, 2), (40000, 1)])
 def test_cold_group_sizes(oracle, n, expect_group):
-    """AUTO picks one wavefront per signature up to 3 072 rows, one DPP row per signature up to 8 192,
+    """AUTO picks one wavefront per signature up to 2 048 rows, one DPP row per signature up to 8 192,
     then 4/2/1 lanes per signature so
     that n·G/64 ≤ 1024 wavefronts; each choice is compared with the oracle on a Byzantine round."""
     import go_ibft_amd.verifier as V
     from oracle import workload as W
-    assert (64 if n <= 3072 else 16 if n <= 8192 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
+    assert (64 if n <= 2048 else 16 if n <= 8192 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
     r = W.make_round(n, 3000 + n, byzantine=True)
     bv = V.BatchVerifier(max_rows=65536)
     try:
