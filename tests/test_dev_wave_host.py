@@ -182,3 +182,16 @@ def test_row_per_signature_recover(wh, oracle):
         if want is not None:
             assert addr[16 * row].tobytes() == want, row
     assert [bool(ok[16 * r]) for r in range(4)] == [True, True, False, True]
+    # and a wavefront of four ordinary signatures of four keys, one of them with a high s
+    hs, sigs = [], []
+    for i in range(4):
+        ski = (int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1).to_bytes(32, "big")
+        hi = rng.bytes(32)
+        sg = bytearray(oracle.sign(ski, hi))
+        if i == 2:
+            sg[32:64] = (n - int.from_bytes(sg[32:64], "big")).to_bytes(32, "big")
+            sg[64] ^= 1
+        hs.append(hi); sigs.append(bytes(sg))
+    wh.wvh_recover4(b"".join(hs), b"".join(sigs), addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+    for row in range(4):
+        assert ok[16 * row] == 1 and addr[16 * row].tobytes() == oracle.recover_address(hs[row], sigs[row]), row
