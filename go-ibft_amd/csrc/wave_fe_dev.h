@@ -529,25 +529,29 @@ WVF void prefix_and_sqrt(uint32_t &X, uint32_t &Y, uint32_t &Z, uint32_t &root, 
 // parallel pass leaves limbs in [−4, 2^30 + 4) (top limb unmasked) — bounded, not canonical, which is
 // all the next batch needs (only f, g mod 2^30 and the sign of the top limbs of d, e are read).
 template <int WITH_MOD>
-WVF int32_t modinv_wave_apply(int32_t m1, int32_t a, int32_t m2, int32_t b, int32_t mod_limb, int32_t mm,
-                              const wk &k) {
+WVF int32_t modinv_wave_apply(int32_t m1, int32_t a, int32_t m2, int32_t b, int32_t mod_limb, int32_t mm, uint32_t li) {
   int64_t c = (int64_t)m1 * a + (int64_t)m2 * b;
   if (WITH_MOD) c += (int64_t)mod_limb * mm;
   const uint32_t lo = (uint32_t)c & (uint32_t)secp::M30;
   const int64_t n = (int64_t)row_shl<1>(lo) + (c >> 30);  // limb j = lo_{j+1} + hi_j  (exact: lo_0 = 0)
-  const bool top = k.li >= 8;
+  const bool top = li >= 8;
   const int32_t carry = top ? 0 : (int32_t)(n >> 30);
   const int32_t keep = top ? (int32_t)n : (int32_t)((uint32_t)n & (uint32_t)secp::M30);
   return keep + (int32_t)row_shr<1>((uint32_t)carry);
 }
-template <class MOD>
-WVF u256 modinv_wave(const u256 &x, const wk &k) {
+// One body for both moduli (is_p: the field prime, else the group order) so that the kernels carry ONE copy
+// of this code: the one-wavefront kernels sit right at the 64 KB of the instruction cache.
+WVF u256 modinv_wave_body(const u256 &x, bool is_p, uint32_t li) {
   const secp::s30 xs = secp::s30_from_u256(x);
-  int32_t f = 0, g = 0, d = 0, e = k.li == 0 ? 1 : 0;
+  int32_t mod[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) mod[i] = is_p ? secp::ModP::limb(i) : secp::ModN::limb(i);
+  const uint32_t inv30 = is_p ? secp::ModP::inv30() : secp::ModN::inv30();
+  int32_t f = 0, g = 0, d = 0, e = li == 0 ? 1 : 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
-    f = k.li == (uint32_t)i ? MOD::limb(i) : f;
-    g = k.li == (uint32_t)i ? xs.v[i] : g;
+    f = li == (uint32_t)i ? mod[i] : f;
+    g = li == (uint32_t)i ? xs.v[i] : g;
   }
   const int32_t mod_limb = f;
   int32_t zeta = -1;
@@ -561,12 +565,12 @@ WVF u256 modinv_wave(const u256 &x, const wk &k) {
     int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
     const uint32_t cd0 = (uint32_t)t.u * (uint32_t)d0 + (uint32_t)t.v * (uint32_t)e0;
     const uint32_t ce0 = (uint32_t)t.q * (uint32_t)d0 + (uint32_t)t.r * (uint32_t)e0;
-    md -= (int32_t)((MOD::inv30() * cd0 + (uint32_t)md) & (uint32_t)secp::M30);
-    me -= (int32_t)((MOD::inv30() * ce0 + (uint32_t)me) & (uint32_t)secp::M30);
-    const int32_t nd = modinv_wave_apply<1>(t.u, d, t.v, e, mod_limb, md, k);
-    const int32_t ne = modinv_wave_apply<1>(t.q, d, t.r, e, mod_limb, me, k);
-    const int32_t nf = modinv_wave_apply<0>(t.u, f, t.v, g, 0, 0, k);
-    const int32_t ng = modinv_wave_apply<0>(t.q, f, t.r, g, 0, 0, k);
+    md -= (int32_t)((inv30 * cd0 + (uint32_t)md) & (uint32_t)secp::M30);
+    me -= (int32_t)((inv30 * ce0 + (uint32_t)me) & (uint32_t)secp::M30);
+    const int32_t nd = modinv_wave_apply<1>(t.u, d, t.v, e, mod_limb, md, li);
+    const int32_t ne = modinv_wave_apply<1>(t.q, d, t.r, e, mod_limb, me, li);
+    const int32_t nf = modinv_wave_apply<0>(t.u, f, t.v, g, 0, 0, li);
+    const int32_t ng = modinv_wave_apply<0>(t.q, f, t.r, g, 0, 0, li);
     d = nd;
     e = ne;
     f = nf;
@@ -590,8 +594,48 @@ WVF u256 modinv_wave(const u256 &x, const wk &k) {
     D.v[i + 1] += D.v[i] >> 30;
     D.v[i] &= secp::M30;
   }
-  secp::normalize_30<MOD>(D, fneg);
+  // D in (−2M, M) → [0, M), negated first when f = −1 (secp::normalize_30 with the modulus at run time)
+  int32_t add = D.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; i++) D.v[i] += mod[i] & add;
+  const int32_t nm = fneg ? -1 : 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) D.v[i] = (D.v[i] ^ nm) - nm;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    D.v[i + 1] += D.v[i] >> 30;
+    D.v[i] &= secp::M30;
+  }
+  add = D.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; i++) D.v[i] += mod[i] & add;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    D.v[i + 1] += D.v[i] >> 30;
+    D.v[i] &= secp::M30;
+  }
   return secp::s30_to_u256(D);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __attribute__((noinline)) u256 modinv_wave_fn(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3,
+                                                               uint32_t x4, uint32_t x5, uint32_t x6, uint32_t x7,
+                                                               uint32_t is_p, uint32_t li) {
+  u256 x;
+  x.v[0] = x0; x.v[1] = x1; x.v[2] = x2; x.v[3] = x3;
+  x.v[4] = x4; x.v[5] = x5; x.v[6] = x6; x.v[7] = x7;
+  return modinv_wave_body(x, is_p != 0, li);
+}
+#endif
+template <class MOD> struct wave_mod_is_p;
+template <> struct wave_mod_is_p<secp::ModP> { static constexpr uint32_t value = 1; };
+template <> struct wave_mod_is_p<secp::ModN> { static constexpr uint32_t value = 0; };
+template <class MOD>
+WVF u256 modinv_wave(const u256 &x, const wk &k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return modinv_wave_fn(x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], wave_mod_is_p<MOD>::value, k.li);
+#else
+  return modinv_wave_body(x, wave_mod_is_p<MOD>::value != 0, k.li);
+#endif
 }
 // Jacobian (lane layout, the same in every lane) → affine; r.x / r.y canonical; false for infinity
 WVF bool jac_to_aff_wave(aff &r, const jac &p, const wk &k) {
@@ -707,7 +751,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
     waff pt;
     pt.x = e[ld] & k.act;
     pt.y = e[10 + ld] & k.act;
-    const wjac sum = wjac_add_aff(acc, pt, k);
+    const wjac sum = wjac_add_aff(acc, pt, k);  // (called multiply: four iterations do not pay for 6 KB of code)
     acc = wjac_select(dgt != 0, sum, acc);
   }
   acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
