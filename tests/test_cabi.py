@@ -53,3 +53,43 @@ def test_product_does_not_reference_oracle():
                     s = line.strip()
                     if s.startswith(("#include", "import ", "from ")):
                         assert "oracle" not in s, (f, s)
+
+
+def test_null_context_is_rejected_everywhere(lib):
+    """every entry point that takes a context answers IBFT_E_INVAL (-1) for NULL instead of touching the
+    device — checkable without a GPU"""
+    import ctypes as C
+    import go_ibft_amd.verifier as V
+    t = V.Tally()
+    m = (C.c_uint64 * 4)()
+    b = (C.c_uint8 * 256)()
+    off = (C.c_uint32 * 2)(0, 10)
+    null = C.c_void_p()
+    calls = [
+        lambda: lib.ibft_set_validators(null, 1, b, b, 1),
+        lambda: lib.ibft_verify_hashes(null, b, 8, 0, b, b, 1, m),
+        lambda: lib.ibft_proposal_hash(null, b, 8, 0, b),
+        lambda: lib.ibft_verify_seals(null, b, b, b, None, 1, m, C.byref(t)),
+        lambda: lib.ibft_verify_senders(null, b, off, b, b, None, 1, m, C.byref(t)),
+        lambda: lib.ibft_verify_senders_wire(null, b, off, 1, m, None, C.byref(t)),
+        lambda: lib.ibft_wire_stage_seals(null),
+        lambda: lib.ibft_tally(null, b, m, 1, C.byref(t)),
+        lambda: lib.ibft_seals_stage(null, b, b, b, None, 1),
+        lambda: lib.ibft_seals_launch(null, 1),
+        lambda: lib.ibft_seals_fetch(null, m, C.byref(t)),
+        lambda: lib.ibft_seals_export(null, None, None),
+        lambda: lib.ibft_seals_export_on(null, None, None, None),
+    ]
+    for i, call in enumerate(calls):
+        assert call() == -1, i
+
+
+def test_wire_row_struct_matches_the_header():
+    """ibft_wire_row_t: 80 bytes, field order as in include/ibftgpu.h (the numpy dtype the wrapper uses and
+    the Go struct in shim/go/ibftgpu/ibftgpu.go mirror it)"""
+    import go_ibft_amd.verifier as V
+    hdr = open(os.path.join(ROOT, "include", "ibftgpu.h")).read()
+    body = hdr[hdr.index("typedef struct {\n  uint64_t height, round;"):hdr.index("} ibft_wire_row_t;")]
+    names = re.findall(r"\b(height|round|status|type|payload_kind|has_view|hash_len|seal_len|from_len|sig_len|from|proposal_hash|pad)\b(?=[,;\[])", body)
+    assert names == list(V.WIRE_ROW.names)
+    assert V.WIRE_ROW.itemsize == 80 and V.WIRE_ROW.fields["from"][1] == 24 and V.WIRE_ROW.fields["proposal_hash"][1] == 44
