@@ -790,7 +790,8 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   const uint32_t one = k.li == 0 ? 1u : 0u;
   const uint32_t rhs = wfe_mul(wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u);  // magnitude 2
   const uint32_t yc = wfe_sqrt_candidate(rhs, k);
-  ok = ok && wfe_is_zero(wfe_sqr(yc, k) + wfe_neg2(rhs, k));
+  const bool on_curve = wfe_is_zero(wfe_sqr(yc, k) + wfe_neg2(rhs, k));  // cross-lane: every row evaluates it
+  ok = ok && on_curve;
   fe y = secp::fe_normalize(gather(yc));
   y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ

@@ -195,3 +195,37 @@ def test_row_per_signature_recover(wh, oracle):
     wh.wvh_recover4(b"".join(hs), b"".join(sigs), addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
     for row in range(4):
         assert ok[16 * row] == 1 and addr[16 * row].tobytes() == oracle.recover_address(hs[row], sigs[row]), row
+
+
+def test_byzantine_rows_through_both_emulated_recovers(wh, oracle):
+    """One row of every corruption kind of the synthetic workload (random bytes, r = 0, s ≥ n, v = 2, stolen
+    seal, …) plus honest rows through the one-wavefront recover and, four at a time, through the
+    row-per-signature recover: ok flag and address must be the oracle's for every row."""
+    from oracle import workload as W
+    wh.wvh_init_gtab()
+    r = W.make_round(64, 31337, byzantine=True)
+    picked, seen = [], set()
+    for i, kind in enumerate(r.kinds):
+        if kind not in seen and not r.pre_flags[i]:
+            seen.add(kind)
+            picked.append(i)
+    picked = picked[:12]
+    assert len(seen) >= 8
+    want = [oracle.recover_address(r.hash32[i].tobytes(), r.seal65[i].tobytes()) for i in picked]
+    addr = np.zeros((64, 20), dtype=np.uint8)
+    ok = np.zeros(64, dtype=np.int32)
+    for i, w in zip(picked, want):
+        wh.wvh_recover(r.hash32[i].tobytes(), r.seal65[i].tobytes(), 0, addr.ctypes.data_as(ctypes.c_void_p),
+                       ok.ctypes.data_as(ctypes.c_void_p))
+        assert (ok == ok[0]).all() and bool(ok[0]) == (w is not None), r.kinds[i]
+        if w is not None:
+            assert addr[0].tobytes() == w, r.kinds[i]
+    for g in range(0, len(picked) - 3, 4):
+        rows = picked[g:g + 4]
+        wh.wvh_recover4(b"".join(r.hash32[i].tobytes() for i in rows), b"".join(r.seal65[i].tobytes() for i in rows),
+                        addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+        for row, i in enumerate(rows):
+            w = want[picked.index(i)]
+            assert bool(ok[16 * row]) == (w is not None), r.kinds[i]
+            if w is not None:
+                assert addr[16 * row].tobytes() == w, r.kinds[i]
