@@ -1,17 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — committed-seal verifies/sec on MI355X (BASELINE.json metric).
+"""bench.py — committed-seal verifies/sec + quorum latency on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one resident batch: the COMMIT seals of a
-synthetic round (ECDSA recover + address compare + validator-set membership → verdict
-mask, then the weighted quorum tally), results copied back so the host sees the verdict
-mask and the quorum flag.  Inputs are resident in HBM when the timed region starts.
+One "step" = one pass of the hot path over one resident batch: the COMMIT seals of a synthetic
+round (ECDSA recover + address compare + validator-set membership → verdict mask, then the
+weighted quorum tally), results delivered so the host sees the verdict mask and the quorum flag.
+Inputs are resident in HBM when the timed region starts.
 
-  N=1 : BASELINE config #2 — "N=1024 validators, single round of COMMIT seals, 1×MI355X".
-  N>1 : weak scaling — every rank verifies its own 1024-row validator shard of a
-        1024·N-validator set, then the verdict-mask words and tally partials are
-        all-reduced over RCCL (disjoint shards: sum ≡ OR), as BASELINE configs #4/#5 do.
-        The exchange of pass k runs on its own stream behind a results-ready event and overlaps
-        with the kernels of pass k+1; the host consumes every merged result one pass later.
+  N=1 : BASELINE config #3 — "N=4096 validators, full PREPARE+COMMIT sequence with Keccak
+        proposal-hash check, 1×MI355X".  `value` = cold committed-seal verifies/s over the 4096
+        resident COMMIT seals (every row recovered, key cache off); `quorum_latency_ms_p50` = p50
+        over 1000 rounds of the WHOLE sequence of one height (IsValidValidator on 4095 PREPAREs +
+        4096 COMMITs, IsValidProposalHash over both sets, IsValidCommittedSeal + tally: 12 287
+        signature checks in five C-ABI calls, host columns → host-visible verdicts, H2D/D2H included).
+  N>1 : weak scaling, 4096 rows per GPU (N=4 is BASELINE config #4: 16 384 validators sharded 4
+        ways): every rank verifies its own validator shard, then the verdict-mask words and tally
+        partials are all-reduced over RCCL (disjoint shards: sum ≡ OR).  The exchange of pass k runs
+        on its own stream and overlaps with the kernels of pass k+1.  At N=8 the line also carries
+        `config5`: 65 536 validators, 8192 rows per GPU, 20 % Byzantine seals, checked against the
+        CPU oracle outside the timed region.
+  `python bench.py --gpus N` from a bare shell re-launches itself under torch.distributed.run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,8 +26,11 @@ from __future__ import annotations
 
 import argparse
 import gc
+import glob
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -32,29 +42,36 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_VERIFY = 118  # 32 hash + 65 sig + 20 signer in, 1 verdict out
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-ROWS_PER_GPU = 1024
+ROWS_PER_GPU = 4096          # BASELINE configs #3 (1 GPU) and #4 (4 GPUs × 4096)
+SEQ_ROUNDS = 1000            # latency p50 over ≥1000 rounds
+FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 
 
-def load_rows(n_total: int, lo: int, hi: int):
-    """Synthetic COMMIT round.  The default N=1024 case comes from the committed fixture;
-    other sizes are generated with the oracle's SIGNER (input generation only — nothing
-    of the oracle is on the timed path)."""
-    fx = os.path.join(ROOT, "tests", "golden", "bench_commit_n1024.npz")
-    if n_total == 1024 and os.path.exists(fx):
-        g = np.load(fx)
-        return g["addrs"], g["power"], g["hash32"][lo:hi], g["seal65"][lo:hi], g["signer20"][lo:hi], "fixture"
+def kernel_name(path: str, cold_lanes: int, warm_lanes: int) -> str:
+    if path == "cold":
+        return {1: "ecrecover_lane_kernel<0>", 64: "ecrecover_wave_kernel<0>",
+                16: "ecrecover_rows_kernel<0>"}.get(cold_lanes, f"ecrecover_group_kernel<0,{cold_lanes}>")
+    return {64: "verify_known_wave_kernel<0>", 1: "verify_known_lane_kernel<0>"}.get(
+        warm_lanes, f"verify_known_group_kernel<0,{warm_lanes}>")
+
+
+def load_round(n_total: int, lo: int, hi: int, byzantine: bool = False):
+    """Synthetic round.  N = 4096 comes from the committed fixture (no signing at bench
+    time); other sizes are generated with the oracle's SIGNER — input generation only, nothing of the
+    oracle is on the timed path."""
+    if n_total == 4096 and not byzantine and os.path.exists(FIXTURE):
+        g = np.load(FIXTURE)
+        return {"addrs": g["addrs"], "power": g["power"], "hash32": g["hash32"][lo:hi], "seal65": g["seal65"][lo:hi],
+                "signer20": g["signer20"][lo:hi], "pre": None, "src": "fixture", "fx": g}
     from oracle import workload as W
-    r = W.make_round(n_total, 1)
-    return r.addrs, r.power, r.hash32[lo:hi], r.seal65[lo:hi], r.signer20[lo:hi], "generated"
+    r = W.make_shard(n_total, 1, lo, hi, byzantine=byzantine)
+    return {"addrs": r.addrs, "power": r.power, "hash32": r.hash32, "seal65": r.seal65, "signer20": r.signer20,
+            "pre": r.pre_flags if byzantine else None, "src": "generated", "fx": None}
 
 
-def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0):
-    """The CPU oracle (a port — the reference has no implementation of this path and no
-    Go toolchain exists here) timed on this box's host cores over a bounded sample: the
-    same COMMIT rows tiled so that every pthread gets ≥64 rows per call."""
-    from oracle import binding as B
-    # usable cores: affinity mask ∧ cgroup CPU quota (the GPU box exposes 256 hardware threads but
-    # grants this container a 16-CPU quota), not the socket's thread count
+def usable_cores() -> int:
+    """affinity mask ∧ cgroup CPU quota (the GPU box exposes 256 hardware threads but grants this
+    container a 16-CPU quota), not the socket's thread count"""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -62,6 +79,15 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
             cores = max(1, min(cores, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0):
+    """The CPU oracle (a port — the reference has no implementation of this path and no Go toolchain
+    exists here) timed on this box's host cores over a bounded sample: the same COMMIT rows tiled so that
+    every pthread gets ≥512 rows per call."""
+    from oracle import binding as B
+    cores = usable_cores()
     vs = B.ValSet(addrs, power)
     n = len(seal65)
     reps = max(1, (512 * cores + n - 1) // n)   # ≥512 rows per thread so pthread spawn is amortised
@@ -82,7 +108,6 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
     ossl_rate = None
     try:
         import ctypes
-        import subprocess
         odir = os.path.join(ROOT, "oracle")
         subprocess.run(["make", "-C", odir, "libopenssl_xcheck.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         ol = ctypes.CDLL(os.path.join(odir, "libopenssl_xcheck.so"))
@@ -96,9 +121,99 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
     except (OSError, AssertionError, AttributeError):
         pass
     return {"value": done / el, "unit": "verifies/s", "cores": cores, "os_cpu_count": os.cpu_count(), "kind": "port",
+            "tuning": "untuned: plain C restatement (4x64 limbs, no GLV, no precomputed-window assembly); "
+                      "libsecp256k1-class code recovers in 25-50 us/core, i.e. 2-4x this per-core rate (SURVEY §6)",
             "openssl_ec_recover_1thread": ossl_rate,
             "sample": f"{done} seal verifies (the N={n} COMMIT batch tiled x{reps} per call, repeated for "
                       f"{el:.1f} s, {cores} pthreads); 1 thread: {single:.0f} verifies/s"}
+
+
+def profile_attachments(kname: str, rows: int, avg_kernel_s: float):
+    """PMC counters cannot be read from inside this process: the per-launch values measured with rocprofv3
+    (separate passes of this same command: tools/profile.sh → profiles/r*_traffic.json, tools/pmc_wave.sh →
+    profiles/r*_pmc_instruction_mix.txt) are attached when kernel and batch size match."""
+    traffic, valu = None, None
+    try:
+        needle = "ibftk::" + kname.replace(",", ", ")
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            ent = next((v for k, v in json.load(open(path)).items() if needle in k), None)
+            if ent and ent.get("rows") == rows:
+                traffic = ent["hbm_bytes_per_launch"]
+                break
+    except (OSError, ValueError):
+        pass
+    try:
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instruction_mix.txt")), reverse=True):
+            text = open(path).read()
+            m_rows = re.search(r"^# rows per launch: (\d+)", text, re.M)
+            file_rows = int(m_rows.group(1)) if m_rows else 1024
+            m = re.search(re.escape(kname.split("<")[0]) + r"<[^>]*>\s+SQ_INSTS_VALU\s+([0-9.]+) per launch", text)
+            if not (m and file_rows == rows):
+                continue
+            insts = float(m.group(1))
+            m_mad = re.search(r"^# v_mad_u64_u32 share of VALU \(static, hot loops\): ([0-9.]+)", text, re.M)
+            f_mad = float(m_mad.group(1)) if m_mad else 15.0 / 72.0  # wfe_mul: 15 mads of 72 VALU instructions
+            # peaks per SIMD: the guide's 2 cycles per wave64 VALU instruction; and the measured mix on this chip
+            # (profiles/r01_ubench_int.txt: v_mad_u64_u32 saturates at 4.75 cycles, plain/DPP VALU at 2.7)
+            peak_guide = 1024 * 2.4e9 / 2.0
+            peak_mix = 1024 * 2.4e9 / (f_mad * 4.75 + (1.0 - f_mad) * 2.7)
+            ach = insts / avg_kernel_s
+            valu = {"wave_insts_per_launch": insts, "achieved_ginst_s": ach / 1e9,
+                    "peak_ginst_s": peak_guide / 1e9, "frac": ach / peak_guide,
+                    "peak_measured_mix_ginst_s": peak_mix / 1e9, "frac_of_measured_mix": ach / peak_mix,
+                    "mad_share": f_mad, "source": os.path.relpath(path, ROOT)}
+            break
+    except (OSError, ValueError):
+        pass
+    return traffic, valu
+
+
+def sequence_latency(V, fx, flags: int, rounds: int):
+    """BASELINE config #3: the whole PREPARE + COMMIT sequence of one height through five C-ABI calls
+    (reference call sites: core/ibft.go:1128 ×2 sets, :858-861, :938, :943 + validator_manager.go:77-96),
+    host columns → host-visible verdicts.  Returns p50 / p10 / p90 in ms."""
+    n = len(fx["addrs"])
+    raw, rnd = fx["raw"].tobytes(), int(fx["round"])
+    ppayload, poff, psig = fx["prepare_payload"].tobytes(), fx["prepare_off"], fx["prepare_sig65"]
+    cpayload, coff, csig = fx["payload"].tobytes(), fx["off"], fx["msg_sig65"]
+    pfrom, phash = fx["addrs"][1:], fx["hash32"][1:]
+    plen, clen = np.full(n - 1, 32, np.uint8), np.full(n, 32, np.uint8)
+    bv = V.BatchVerifier(flags=flags, max_rows=n)
+    try:
+        bv.set_validators(int(fx["height"]), fx["addrs"], fx["power"])
+
+        def sequence():
+            a, _ = bv.is_valid_validator(ppayload, poff, psig, pfrom)                 # PREPARE ingest
+            b = bv.is_valid_proposal_hash(raw, rnd, phash, plen)                      # handlePrepare
+            c, _ = bv.is_valid_validator(cpayload, coff, csig, fx["signer20"])        # COMMIT ingest
+            d = bv.is_valid_proposal_hash(raw, rnd, fx["hash32"], clen)               # handleCommit a1
+            e, t = bv.is_valid_committed_seal(fx["hash32"], fx["seal65"], fx["signer20"])  # a2 + tally
+            return a, b, c, d, e, t
+        for _ in range(3):                                # warm path: the second pass builds the tables
+            a, b, c, d, e, t = sequence()
+        assert a.all() and b.all() and c.all() and d.all() and e.all() and t.has_quorum == 1
+        lat = np.empty(rounds)
+        for i in range(rounds):
+            t0 = time.perf_counter()
+            sequence()
+            lat[i] = time.perf_counter() - t0
+        dispatch = bv.last_dispatch()
+    finally:
+        bv.close()
+    q = np.percentile(lat * 1e3, [10, 50, 90])
+    return {"p50_ms": float(q[1]), "p10_ms": float(q[0]), "p90_ms": float(q[2]), "rounds": rounds,
+            "signatures_per_sequence": 3 * n - 1, "sig_verifies_per_s": (3 * n - 1) / float(np.median(lat)),
+            "dispatch_cold_warm_lanes": list(dispatch)}
+
+
+def relaunch(args) -> int:
+    """`python bench.py --gpus N` from a bare shell: become N ranks under torch.distributed.run."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -108,10 +223,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows (validators) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sequence", action="store_true", help="skip the config-#3 sequence latency legs")
+    ap.add_argument("--no-warm", action="store_true", help="skip the warm-path leg")
+    ap.add_argument("--seq-rounds", type=int, default=SEQ_ROUNDS)
     ap.add_argument("--path", choices=["cold", "warm"], default="cold",
                     help="cold = ECDSA recover+compare for every row (headline); warm = keys already learned, "
                          "rows verified against per-validator tables (IBFT_FLAG_PUBKEY_CACHE)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(args))
 
     import torch
     import go_ibft_amd.verifier as V
@@ -120,236 +241,217 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if args.gpus > 1 or world > 1 or os.environ.get("IBFT_BENCH_FORCE_DIST") == "1":
+    if world > 1 or os.environ.get("IBFT_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+        if world != args.gpus:
+            raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local)
 
-    rows = args.rows
-    n_total = rows * world
-    lo, hi = rank * rows, (rank + 1) * rows
-    addrs, power, hash32, seal65, signer20, src = load_rows(n_total, lo, hi)
-
-    def make_verifier(path):
-        v = V.BatchVerifier(device=local, max_rows=max(rows, 1024),   # raises without the HIP lib / GPU
-                            flags=V.FLAG_PUBKEY_CACHE if path == "warm" else 0)
-        v.set_validators(1, addrs, power)
-        v.seals_stage(hash32, seal65, signer20)                   # H2D once: inputs resident in HBM
-        if path == "warm":                                         # learn the keys, build the tables (untimed)
-            v.seals_launch(1); v.seals_fetch(); v.seals_launch(1); v.seals_fetch()
-            assert v.cache_stats()[0] == len(np.unique(signer20, axis=0))
-        return v
-
-    bv = make_verifier(args.path)
     import go_ibft_amd.shard as S
-    words = S.words_per_rank(n_total, world)
-    slots, tally_off = S.exchange_layout(n_total, world)
-    assert S.shard_range(n_total, rank, world) == (lo, hi)
-    # exchange buffer: [mask words of every shard | power_lo, power_hi, valid|distinct<<32] (+1 spare:
-    # the library exports 4 tally words, the 4th — has_quorum — is recomputed after the merge)
-    ar = [torch.zeros(slots + 1, dtype=torch.int64, device=dev) for _ in range(2)] if dist else None
-    evs = [torch.cuda.Event() for _ in range(2)] if dist else None
-    # the exchange (zero, copies, all-reduce) lives on its own stream: on torch's legacy default stream it
-    # serialised against the library's stream (0.361 vs 0.346 ms per pass with one rank)
-    xstream = torch.cuda.Stream(device=dev) if dist else None
 
-    def step():  # N = 1: one synchronous pass, results on the host when it returns
-        bv.seals_launch(1)
-        return bv.seals_fetch()
+    def run_config(rows: int, byzantine: bool, steps: int, warmup: int, path: str):
+        """one timed leg: `steps` passes over this rank's resident shard (+ the exchange when sharded)"""
+        n_total = rows * world
+        lo, hi = rank * rows, (rank + 1) * rows
+        rd = load_round(n_total, lo, hi, byzantine)
+        addrs, power = rd["addrs"], rd["power"]
+        bv = V.BatchVerifier(device=local, max_rows=max(rows, 1024),   # raises without the HIP lib / GPU
+                             flags=V.FLAG_PUBKEY_CACHE if path == "warm" else 0)
+        bv.set_validators(1, addrs, power)
+        bv.seals_stage(rd["hash32"], rd["seal65"], rd["signer20"], rd["pre"])  # H2D once: inputs resident in HBM
+        if path == "warm":                                             # learn the keys, build the tables (untimed)
+            bv.seals_launch(1); bv.seals_fetch(); bv.seals_launch(1); bv.seals_fetch()
+            assert bv.cache_stats()[0] == len(np.unique(rd["signer20"], axis=0)) or byzantine
+        words = S.words_per_rank(n_total, world)
+        slots, tally_off = S.exchange_layout(n_total, world)
+        assert S.shard_range(n_total, rank, world) == (lo, hi)
+        ar = [torch.zeros(slots + 1, dtype=torch.int64, device=dev) for _ in range(2)] if dist else None
+        evs = [torch.cuda.Event() for _ in range(2)] if dist else None
+        xstream = torch.cuda.Stream(device=dev) if dist else None
 
-    def exchange(k):
-        """hand shard k's verdict words + tally partials to the collective: copies and all-reduce run on
-        torch's stream behind a results-ready event, the library's own stream is free for the next batch"""
-        buf = ar[k & 1]
-        with torch.cuda.stream(xstream):
-            buf.zero_()
-            bv.seals_export_on(buf[rank * words:].data_ptr(), buf[tally_off:].data_ptr(), xstream.cuda_stream)
-            dist.all_reduce(buf)  # disjoint shards: sum == OR; tally partials add
-            evs[k & 1].record()
-
-    def run_sharded(k_steps):
-        """k_steps passes; the exchange of pass k overlaps with the kernels of pass k+1, and the host
-        consumes every merged result one pass later (bounded pipeline, depth 1)"""
-        bv.seals_launch(1)
-        for k in range(k_steps):
-            exchange(k)
-            if k + 1 < k_steps:
-                bv.seals_launch(1)
-            if k >= 1:
-                evs[(k - 1) & 1].synchronize()
-        evs[(k_steps - 1) & 1].synchronize()
-        return ar[(k_steps - 1) & 1]
-
-    def fence():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        bv.sync()
-
-    if dist is None:
-        for _ in range(args.warmup):
-            step()
-    elif args.warmup:
-        run_sharded(args.warmup)
-    fence()
-    # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed
-    # loop costs ≈40 ms (seen as one 43 ms step).  Collect now, keep the collector off while timing.
-    gc.collect()
-    gc.disable()
-    lat = []
-    kernel_ms, kernel_launches = 0.0, 0
-    t0 = time.perf_counter()
-    if dist is None:
-        for _ in range(args.steps):
-            s0 = time.perf_counter()
-            out = step()
-            lat.append(time.perf_counter() - s0)
-            ms, k = bv.last_kernel_ms()
-            kernel_ms += ms
-            kernel_launches += k
-    else:
-        out = run_sharded(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        kernel_ms, kernel_launches = bv.last_kernel_ms()  # the last pass's kernels (events are per launch)
-        for k in range(min(args.steps, 20)):              # latency of one synchronous pass incl. the exchange
-            s0 = time.perf_counter()
+        def step():  # N = 1: one synchronous pass, results on the host when it returns
             bv.seals_launch(1)
-            exchange(k)
-            evs[k & 1].synchronize()
-            lat.append(time.perf_counter() - s0)
+            return bv.seals_fetch()
 
-    # quorum latency including the host→device copies (SURVEY §8d: reported with and without H2D)
-    lat_h2d = []
-    if dist is None:
-        for _ in range(1000 if args.steps >= 200 else min(args.steps, 50)):  # SURVEY §8d: p50 over ≥1000 rounds
-            s0 = time.perf_counter()
-            bv.is_valid_committed_seal(hash32, seal65, signer20)
-            lat_h2d.append(time.perf_counter() - s0)
+        def exchange(k):
+            """hand shard k's verdict words + tally partials to the collective: copies and all-reduce run on
+            their own stream behind a results-ready event, the library's stream is free for the next batch"""
+            buf = ar[k & 1]
+            with torch.cuda.stream(xstream):
+                buf.zero_()
+                bv.seals_export_on(buf[rank * words:].data_ptr(), buf[tally_off:].data_ptr(), xstream.cuda_stream)
+                dist.all_reduce(buf)  # disjoint shards: sum == OR; tally partials add
+                evs[k & 1].record()
 
-    # correctness of what was timed (cheap, outside the timed region)
-    if dist is None:
-        verdict, tally = out
-        assert verdict.all() and tally.has_quorum == 1 and tally.power == int(power.sum())
-    else:
-        quorum = 2 * int(power.sum()) // 3 + 1
-        verdict, pw, valid, distinct, hq = S.merge(out.cpu().numpy()[:slots], n_total, world, quorum)
-        assert verdict.all() and valid == n_total and pw == int(power.sum()) and hq
+        def run_sharded(k_steps):
+            """the exchange of pass k overlaps with the kernels of pass k+1; the host consumes every merged
+            result one pass later (bounded pipeline, depth 1)"""
+            bv.seals_launch(1)
+            for k in range(k_steps):
+                exchange(k)
+                if k + 1 < k_steps:
+                    bv.seals_launch(1)
+                if k >= 1:
+                    evs[(k - 1) & 1].synchronize()
+            evs[(k_steps - 1) & 1].synchronize()
+            return ar[(k_steps - 1) & 1]
 
-    if rank == 0:
-        verifies = n_total * args.steps
-        value = verifies / elapsed
-        avg_kernel_s = (kernel_ms / 1e3) / max(kernel_launches, 1)
-        if args.path == "warm":
+        def fence():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            bv.sync()
+
+        if dist is None:
+            for _ in range(warmup):
+                step()
+        elif warmup:
+            run_sharded(warmup)
+        fence()
+        # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed
+        # loop costs ≈40 ms.  Collect now, keep the collector off while timing.
+        gc.collect()
+        gc.disable()
+        lat, kernel_ms, kernel_launches = [], 0.0, 0
+        t0 = time.perf_counter()
+        if dist is None:
+            for _ in range(steps):
+                s0 = time.perf_counter()
+                out = step()
+                lat.append(time.perf_counter() - s0)
+                ms, k = bv.last_kernel_ms()
+                kernel_ms += ms
+                kernel_launches += k
+        else:
+            out = run_sharded(steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+        gc.enable()
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            kernel_ms, kernel_launches = bv.last_kernel_ms()  # the last pass's kernels (events are per launch)
+            for k in range(min(steps, 20)):                   # latency of one synchronous pass incl. the exchange
+                s0 = time.perf_counter()
+                bv.seals_launch(1)
+                exchange(k)
+                evs[k & 1].synchronize()
+                lat.append(time.perf_counter() - s0)
+        # quorum latency of this one call including the host→device copies
+        lat_h2d = []
+        if dist is None:
+            for _ in range(min(steps, 200)):
+                s0 = time.perf_counter()
+                bv.is_valid_committed_seal(rd["hash32"], rd["seal65"], rd["signer20"], rd["pre"])
+                lat_h2d.append(time.perf_counter() - s0)
+        # correctness of what was timed (outside the timed region)
+        expect = None
+        if byzantine:
+            from oracle import binding as B
+            expect = B.verify_seals(B.ValSet(addrs, power), rd["hash32"], rd["seal65"], rd["signer20"], rd["pre"],
+                                    nthreads=usable_cores()).astype(bool)
+        if dist is None:
+            verdict, tally = out
+            if expect is None:
+                assert verdict.all() and tally.has_quorum == 1 and tally.power == int(power.sum())
+            else:
+                assert (verdict == expect).all()
+        else:
+            quorum = 2 * int(power.astype(object).sum()) // 3 + 1
+            verdict, pw, valid, distinct, hq = S.merge(out.cpu().numpy()[:slots], n_total, world, quorum)
+            if expect is None:
+                assert verdict.all() and valid == n_total and pw == int(power.sum()) and hq
+            else:
+                assert (verdict[lo:hi] == expect).all(), "merged verdicts differ from the oracle on this shard"
+                assert hq == (pw >= quorum)
+        cold_lanes, warm_lanes = bv.last_dispatch()
+        if path == "warm":
             bv.cache_stats()
-        cold_lanes = bv.last_dispatch()[0]
-        kname = ("ecrecover_lane_kernel<0>" if cold_lanes == 1 else "ecrecover_wave_kernel<0>" if cold_lanes == 64
-                 else "ecrecover_rows_kernel<0>" if cold_lanes == 16
-                 else f"ecrecover_group_kernel<0,{cold_lanes}>") \
-            if args.path == "cold" else (
-            "verify_known_wave_kernel<0>" if bv.lanes_per_signature == 64
-            else f"verify_known_group_kernel<0,{bv.lanes_per_signature}>" if bv.lanes_per_signature > 1
-            else "verify_known_lane_kernel<0>")
+            warm_lanes = bv.lanes_per_signature
+        res = {"n_total": n_total, "rows": rows, "elapsed": elapsed, "steps": steps, "lat": lat, "lat_h2d": lat_h2d,
+               "kernel_ms": kernel_ms, "kernel_launches": kernel_launches, "kname": kernel_name(path, cold_lanes, warm_lanes),
+               "src": rd["src"], "rd": rd, "tables": bv.cache_stats()[0] if path == "warm" else 0,
+               "valid_fraction": float(verdict.mean())}
+        bv.close()
+        return res
+
+    main_leg = run_config(args.rows, False, args.steps, args.warmup, args.path)
+
+    rec = None
+    if rank == 0:
+        m = main_leg
+        rows, n_total = m["rows"], m["n_total"]
+        value = n_total * m["steps"] / m["elapsed"]
+        avg_kernel_s = (m["kernel_ms"] / 1e3) / max(m["kernel_launches"], 1)
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so
-        # the per-launch value measured with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this
-        # same command by tools/profile.sh, newest profiles/r*_traffic.json) is attached when kernel and batch size match.
-        traffic = None
-        try:
-            import glob
-            needle = "ibftk::" + kname.replace(",", ", ")
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
-                ent = next((v for k, v in json.load(open(path)).items() if needle in k), None)
-                if ent and ent.get("rows") == rows:
-                    traffic = ent["hbm_bytes_per_launch"]
-                    break
-        except (OSError, ValueError):
-            pass
-        # the bound that matters for this kernel: VALU issue.  Wavefront-instructions per launch come from
-        # the PMC pass of the same command (tools/pmc_wave.sh → profiles/r*_pmc_instruction_mix.txt, rows =
-        # 1024), the time is the live kernel time; peak = 1024 SIMDs × one wave64 VALU instruction per 4 cycles
-        valu = None
-        try:
-            import glob
-            import re
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instruction_mix.txt")), reverse=True):
-                m = re.search(re.escape(kname.split("<")[0]) + r"<[^>]*>\s+SQ_INSTS_VALU\s+([0-9.]+) per launch",
-                              open(path).read())
-                if m and rows == 1024:
-                    insts = float(m.group(1))
-                    peak = 1024 * 2.4e9 / 4
-                    valu = {"wave_insts_per_launch": insts, "achieved_ginst_s": insts / avg_kernel_s / 1e9,
-                            "peak_ginst_s": peak / 1e9, "frac": insts / avg_kernel_s / peak,
-                            "source": os.path.relpath(path, ROOT)}
-                    break
-        except (OSError, ValueError):
-            pass
+        traffic, valu = profile_attachments(m["kname"], rows, avg_kernel_s)
+        workload = (f"BASELINE config #3: N={n_total} validators, 1xMI355X — value: one round of COMMIT seals per step "
+                    f"(ECDSA recover+compare+membership+quorum tally); quorum_latency_ms_p50: the full PREPARE+COMMIT "
+                    f"sequence with Keccak proposal-hash check") if world == 1 and rows == 4096 else \
+                   (f"N={n_total} validators sharded x{world} ({rows} rows/GPU), COMMIT seals per step + RCCL all-reduce of "
+                    f"the verdict-mask words and tally partials" + (" (BASELINE config #4)" if (world, rows) == (4, 4096) else ""))
         rec = {
             "metric": "committed_seal_verifies_per_sec", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": f"synthetic ({src})",
-            "config": {"workload": f"N={n_total} validators, single round of COMMIT seals "
-                                   f"(ECDSA recover+compare+membership+quorum tally), {rows} rows/GPU",
-                       "validators": n_total, "rows_per_gpu": rows, "path": args.path, "kernel": kname,
-                       "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU"},
-            "quorum_latency_ms_p50": float(np.median(lat) * 1e3),
-            "quorum_latency_ms_p50_incl_h2d": float(np.median(lat_h2d) * 1e3) if lat_h2d else None,
+            "ms_per_step": m["elapsed"] / m["steps"] * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": f"synthetic ({m['src']})",
+            "config": {"workload": workload, "validators": n_total, "rows_per_gpu": rows, "path": args.path,
+                       "kernel": m["kname"], "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU"},
+            "step_latency_ms_p50": float(np.median(m["lat"]) * 1e3),
+            "step_latency_ms_p50_incl_h2d": float(np.median(m["lat_h2d"]) * 1e3) if m["lat_h2d"] else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kname, "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": m["kname"], "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
                          "valu_issue": valu,
                          "note": "integer-VALU-bound path: HBM fraction is reported as required; valu_issue is "
                                  "the bound that applies (DESIGN.md §5)"},
         }
-        if world == 1 and args.path == "cold":
-            # extra, NOT the headline: the same batch once every validator's key is known (steady state)
-            bv.close()  # one context at a time: two live contexts slow each other's host-side sync
-            bv = None
-            wv = make_verifier("warm")
-            for _ in range(args.warmup):
-                wv.seals_launch(1); wv.seals_fetch()
-            wms, wk, wlat = 0.0, 0, []
-            w0 = time.perf_counter()
-            for _ in range(args.steps):
-                s0 = time.perf_counter()
-                wv.seals_launch(1)
-                wverdict, wtally = wv.seals_fetch()
-                wlat.append(time.perf_counter() - s0)
-                ms, k = wv.last_kernel_ms()  # same per-step sequence as the headline loop above
-                wms += ms
-                wk += k
-            wel = time.perf_counter() - w0
-            if os.environ.get("IBFT_BENCH_DEBUG"):
-                q = np.percentile(np.array(wlat) * 1e3, [10, 50, 90, 99, 100])
-                print("warm leg step ms p10/p50/p90/p99/max:", np.round(q, 3), file=sys.stderr)
-            assert wverdict.all() and wtally.has_quorum == 1
-            rec["warm_path"] = {"value": n_total * args.steps / wel, "unit": "verifies/s",
-                                "ms_per_step": wel / args.steps * 1e3, "kernel_ms": wms / max(wk, 1),
-                                "quorum_latency_ms_p50": float(np.median(wlat) * 1e3),
-                                "tables_bytes": int(wv.cache_stats()[0]) * 32 * 256 * 80,
-                                "lanes_per_signature": wv.lanes_per_signature,
-                                "kernel": ("verify_known_wave_kernel<0>" if wv.lanes_per_signature == 64
-                                           else f"verify_known_group_kernel<0,{wv.lanes_per_signature}>"
-                                           if wv.lanes_per_signature > 1 else "verify_known_lane_kernel<0>"),
-                                "note": "keys learned by an earlier cold pass; identical verdicts (csrc/verify_dev.h)"}
-            wv.close()
+        rec["quorum_latency_ms_p50"] = rec["step_latency_ms_p50"]   # replaced by the sequence below at N=1
+
+    if world == 1 and args.path == "cold" and not args.no_warm:
+        # extra, NOT the headline: the same batch once every validator's key is known (steady state)
+        w = run_config(args.rows, False, args.steps, args.warmup, "warm")
+        rec["warm_path"] = {"value": w["n_total"] * w["steps"] / w["elapsed"], "unit": "verifies/s",
+                            "ms_per_step": w["elapsed"] / w["steps"] * 1e3,
+                            "kernel_ms": w["kernel_ms"] / max(w["kernel_launches"], 1),
+                            "step_latency_ms_p50": float(np.median(w["lat"]) * 1e3),
+                            "tables_bytes": int(w["tables"]) * 32 * 256 * 80, "kernel": w["kname"],
+                            "note": "keys learned by an earlier cold pass; identical verdicts (csrc/verify_dev.h)"}
+    if world == 1 and not args.no_sequence and main_leg["rd"]["fx"] is not None:
+        fx = main_leg["rd"]["fx"]
+        cold = sequence_latency(V, fx, 0, args.seq_rounds)
+        warm = sequence_latency(V, fx, V.FLAG_PUBKEY_CACHE, args.seq_rounds)
+        rec["quorum_latency_ms_p50"] = cold["p50_ms"]
+        rec["quorum_latency"] = {"definition": "p50 over rounds of the config-#3 sequence: host SoA columns -> verdict masks + "
+                                               "quorum flag visible to the host, H2D + kernels + D2H included (SURVEY §8d)",
+                                 "cold": cold, "warm": warm}
+    if world == 8 and os.environ.get("IBFT_BENCH_SKIP_CONFIG5") != "1":
+        # BASELINE config #5: 65 536 validators, 8 × 8192 rows, 20 % Byzantine seals, parity vs the CPU oracle
+        try:
+            c5 = run_config(8192, True, max(10, args.steps // 4), 3, "cold")
+            if rank == 0:
+                rec["config5"] = {"validators": c5["n_total"], "rows_per_gpu": 8192, "byzantine_fraction": 0.2,
+                                  "value": c5["n_total"] * c5["steps"] / c5["elapsed"], "unit": "verifies/s",
+                                  "ms_per_step": c5["elapsed"] / c5["steps"] * 1e3, "kernel": c5["kname"],
+                                  "valid_fraction": c5["valid_fraction"],
+                                  "parity": "every rank's shard of the merged verdict mask equals the CPU oracle's verdicts; "
+                                            "merged quorum flag recomputed from the merged power"}
+        except Exception as e:  # noqa: BLE001 — the extra leg must never take the headline line down
+            if rank == 0:
+                rec["config5"] = {"error": repr(e)}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(addrs, power, hash32, seal65, signer20)
+            rd = main_leg["rd"]
+            rec["cpu_baseline"] = cpu_baseline(rd["addrs"], rd["power"], rd["hash32"], rd["seal65"], rd["signer20"])
         print(json.dumps(rec), flush=True)
-    if bv is not None:
-        bv.close()
     if dist is not None:
         dist.destroy_process_group()
 

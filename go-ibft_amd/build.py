@@ -7,27 +7,45 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libibftgpu.so")
-SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h",
-           os.path.join("..", "..", "include", "ibftgpu.h")]
+SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "modinv_dev.h",
+           "secp256k1_dev.h", "keccak_dev.h", os.path.join("..", "..", "include", "ibftgpu.h")]
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
 
 
-def _stale(target: str, deps: list[str]) -> bool:
-    if not os.path.exists(target):
+def _digest(deps: list[str], extra: str = "") -> str:
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for d in deps:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def _stale(target: str, deps: list[str], extra: str = "") -> bool:
+    """A target is current when the digest of its sources (+ the compile command) equals the one recorded
+    next to it when it was built — modification times say nothing after a checkout or a copy to another box."""
+    stamp = target + ".stamp"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != _digest(deps, extra)
+
+
+def _mark(target: str, deps: list[str], extra: str = "") -> None:
+    with open(target + ".stamp", "w") as f:
+        f.write(_digest(deps, extra) + "\n")
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
-    if force or _stale(LIB, SOURCES):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-o", LIB, os.path.join(CSRC, "ibftgpu.hip")]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB, os.path.join(CSRC, "ibftgpu.hip"), "-ldl"]
+    if force or _stale(LIB, SOURCES, " ".join(cmd[:-3])):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
+        _mark(LIB, SOURCES, " ".join(cmd[:-3]))
     return LIB
 
 
@@ -40,6 +58,7 @@ def build_devtest(force: bool = False) -> str:
     if force or _stale(DEVTEST, deps):
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-w",
                                "-o", DEVTEST, os.path.join(CSRC, "devtest.hip")], cwd=CSRC)
+        _mark(DEVTEST, deps)
     return DEVTEST
 
 
@@ -49,6 +68,7 @@ def build_host_harness(force: bool = False) -> str:
     if force or _stale(HOST_HARNESS, deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
                                "-o", HOST_HARNESS, os.path.join(CSRC, "host_arith_harness.hip")], cwd=CSRC)
+        _mark(HOST_HARNESS, deps)
     return HOST_HARNESS
 
 
@@ -59,6 +79,7 @@ def build_wave_harness(force: bool = False) -> str:
     if force or _stale(WAVE_HARNESS, deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
                                "-o", WAVE_HARNESS, os.path.join(CSRC, "host_wave_harness.hip")], cwd=CSRC)
+        _mark(WAVE_HARNESS, deps)
     return WAVE_HARNESS
 
 

@@ -263,3 +263,48 @@ extern "C" int devtest_wave_stage_ms(int n, const uint8_t *dig, const uint8_t *s
   (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
   return rc;
 }
+
+// ---- sixteen lanes per signature (recover_pubkey_row): stage timing at the product's launch shape ----
+template <int STOP>
+__global__ void __launch_bounds__(256) devtest_rows_recover_kernel(const uint32_t *gtab, const uint8_t *dig, const uint8_t *sig65,
+                                                                 uint32_t n, uint8_t *out) {
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (wave * 4u >= n) return;
+  const uint32_t row_raw = wave * 4u + (lane >> 4);
+  const uint32_t i = row_raw < n ? row_raw : n - 1;
+  uint32_t addr[5] = {0, 0, 0, 0, 0};
+  aff Q;
+  bool ok = wv::recover_pubkey_row<STOP>(gtab, from_be32(dig + 32 * i), from_be32(sig65 + 65 * i), from_be32(sig65 + 65 * i + 32),
+                                   sig65[65 * i + 64], 0, addr, Q);
+  if ((lane & 15u) == 0 && row_raw < n) {
+    uint8_t *o = out + (size_t)24 * i;
+    for (int k = 0; k < 5; k++) reinterpret_cast<uint32_t *>(o)[k] = addr[k];
+    o[20] = ok ? 1 : 0;
+  }
+}
+// ms per launch of n rows cut short after stage 1..6 and complete; out24 (n × 24 B) = addresses + ok of the complete run
+extern "C" int devtest_rows_stage_ms(int n, const uint8_t *dig, const uint8_t *sig65, float *ms7, uint8_t *out24) {
+  uint32_t *dg;
+  size_t gbytes = (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4;
+  if (hipMalloc(&dg, gbytes) != hipSuccess) return -1;
+  uint8_t *dd = dev_copy(dig, (size_t)32 * n), *ds = dev_copy(sig65, (size_t)65 * n), *dout;
+  if (!dd || !ds || hipMalloc(&dout, (size_t)24 * n) != hipSuccess) return -1;
+  devtest_gtab_kernel<<<(ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES + 63) / 64, 64>>>(dg);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int waves = (n + 3) / 4, blocks = (waves + 3) / 4;
+#define STAGE_RUN(idx, S)                                                              \
+  for (int rep = 0; rep < 3; rep++) {                                                  \
+    (void)hipEventRecord(e0, 0);                                                       \
+    devtest_rows_recover_kernel<S><<<blocks, 256>>>(dg, dd, ds, (uint32_t)n, dout);    \
+    (void)hipEventRecord(e1, 0);                                                       \
+    (void)hipEventSynchronize(e1);                                                     \
+    (void)hipEventElapsedTime(&ms7[idx], e0, e1);                                      \
+  }
+  STAGE_RUN(0, 1) STAGE_RUN(1, 2) STAGE_RUN(2, 3) STAGE_RUN(3, 4) STAGE_RUN(4, 5) STAGE_RUN(5, 6) STAGE_RUN(6, 99)
+#undef STAGE_RUN
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  if (out24) (void)hipMemcpy(out24, dout, (size_t)24 * n, hipMemcpyDeviceToHost);
+  (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
+  return rc;
+}

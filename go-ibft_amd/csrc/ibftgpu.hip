@@ -158,7 +158,7 @@ ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre) {
   a.vidx = (int32_t *)c->d_vidx.p;
   if (c->cache_on) {
     a.pub = (uint32_t *)c->d_pub.p;
-    a.pub_state = (uint8_t *)c->d_pub_state.p;
+    a.pub_state = (uint32_t *)c->d_pub_state.p;
     a.learned = (uint32_t *)((uint64_t *)c->d_tally.p + 4);
     a.qtab = (const uint32_t *)c->d_qtab.p;
     a.dummy_validator = c->dummy_validator;
@@ -320,10 +320,10 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator
   if (!c->cache_on || learned_total <= c->learned_seen) return IBFT_OK;
   const uint32_t nv = c->n_validators;
   hipLaunchKernelGGL(ibftk::qtab_build_kernel, dim3(((nv + 63) / 64) * ibftk::QTAB_WINDOWS), dim3(64), 0, c->stream,
-                     (const uint32_t *)c->d_pub.p, (const uint8_t *)c->d_pub_state.p, (uint32_t *)c->d_qtab.p, nv);
+                     (const uint32_t *)c->d_pub.p, (const uint32_t *)c->d_pub_state.p, (uint32_t *)c->d_qtab.p, nv);
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(ibftk::qtab_commit_kernel, dim3((nv + 255) / 256), dim3(256), 0, c->stream,
-                     (uint8_t *)c->d_pub_state.p, nv);
+                     (uint32_t *)c->d_pub_state.p, nv);
   HIPCHK(c, hipGetLastError());
   c->learned_seen = learned_total;
   c->dummy_validator = any_validator;
@@ -534,8 +534,8 @@ int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, co
     size_t budget = 64ull << 30;
     if (const char *e = getenv("IBFT_QTAB_BUDGET_GB")) budget = (size_t)strtoull(e, nullptr, 10) << 30;
     if (nv > 0 && qbytes <= budget && ensure(c, c->d_qtab, qbytes) == IBFT_OK &&
-        ensure(c, c->d_pub, nv * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK && ensure(c, c->d_pub_state, nv) == IBFT_OK) {
-      HIPCHK(c, hipMemsetAsync(c->d_pub_state.p, 0, nv, c->stream));
+        ensure(c, c->d_pub, nv * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK && ensure(c, c->d_pub_state, nv * 4) == IBFT_OK) {
+      HIPCHK(c, hipMemsetAsync(c->d_pub_state.p, 0, nv * 4, c->stream));
       HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_tally.p + 4, 0, 8, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       c->cache_on = true;

@@ -56,6 +56,12 @@ __device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, 
   return -1;
 }
 
+// ---- warm path: remember a recovered key, exactly once per validator ---------------------------
+// Several valid rows of the SAME validator in one cold batch are normal (PREPARE + COMMIT of one
+// sender, round-change envelopes + certificate messages): the 0→1 transition of pub_state is claimed
+// with a compare-and-swap and only the winner stores the key and counts it, so that `learned` is the
+// number of validators with a key — the host compares it with n_validators to drop the cold kernel
+// (learn_key, below recover_args).
 // ---- fixed-base table build (entries computed by recover_dev.h:gtab_entry) ----------
 __global__ void gtab_build_kernel(uint32_t *__restrict__ gtab) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,12 +117,21 @@ struct recover_args {
   int32_t *vidx;            // n: validator index of the row's sender (or -1)
   // warm path (null / 0 when the key cache is off)
   uint32_t *pub;            // n_validators × 20 dwords: recovered public keys (affine, 10×26 limbs)
-  uint8_t *pub_state;       // n_validators: 0 unknown, 1 key known, 2 table built
+  uint32_t *pub_state;      // n_validators: 0 unknown, 1 key known (claimed by CAS), 2 table built
   uint32_t *learned;        // counter of keys learned (host reads it with the tally)
   const uint32_t *qtab;     // n_validators × 32 × 256 × 20 dwords
   uint8_t *warm_done;       // n: 1 = the warm kernel already produced this row's verdict
   uint32_t dummy_validator; // a validator whose table is built (operand for lanes with no work)
 };
+
+__device__ __forceinline__ void learn_key(const recover_args &a, int vi, const aff &Qa) {
+  if (!a.pub_state || a.pub_state[vi] != 0) return;
+  if (atomicCAS(a.pub_state + vi, 0u, 1u) != 0u) return;  // another row of this validator won the claim
+  // state 1 is only read by qtab_build_kernel, a later launch on the same stream: no fence needed here
+  store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
+  atomicAdd(a.learned, 1u);
+  a.learned[1] = (uint32_t)vi;  // any learned validator: operand for idle lanes of the warm kernel
+}
 
 // Stage the block's rows through LDS (coalesced dword loads) and unpack this lane's row.
 struct row_regs {
@@ -191,13 +206,7 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_
   ok = ok && vi >= 0;
   if (need) a.vidx[q.row] = vi;
   // a key that hashes to a member's address is remembered for the warm path
-  if (ok && a.pub_state && a.pub_state[vi] == 0) {
-    store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
-    __threadfence();
-    a.pub_state[vi] = 1;
-    atomicAdd(a.learned, 1u);
-    a.learned[1] = (uint32_t)vi;  // any learned validator: operand for idle lanes of the warm kernel
-  }
+  if (ok) learn_key(a, vi, Qa);
   uint64_t bal = __ballot(ok);
   uint64_t keep = __ballot(done);
   if (lane == 0) {
@@ -497,13 +506,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
   ok = ok && vi >= 0;
   if (sub == 0 && need) {
     a.vidx[row] = vi;
-    if (ok && a.pub_state && a.pub_state[vi] == 0) {
-      store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
-      __threadfence();
-      a.pub_state[vi] = 1;
-      atomicAdd(a.learned, 1u);
-      a.learned[1] = (uint32_t)vi;
-    }
+    if (ok) learn_key(a, vi, Qa);
     if (ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
   }
 }
@@ -543,13 +546,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
   if (lane == 0 && ok) {
-    if (a.pub_state && a.pub_state[vi] == 0) {
-      store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
-      __threadfence();
-      a.pub_state[vi] = 1;
-      atomicAdd(a.learned, 1u);
-      a.learned[1] = (uint32_t)vi;
-    }
+    learn_key(a, vi, Qa);
     atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
   }
 }
@@ -592,13 +589,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_rows_kernel(
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
   if ((lane & 15u) == 0 && ok) {
-    if (a.pub_state && a.pub_state[vi] == 0) {
-      store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
-      __threadfence();
-      a.pub_state[vi] = 1;
-      atomicAdd(a.learned, 1u);
-      a.learned[1] = (uint32_t)vi;
-    }
+    learn_key(a, vi, Qa);
     atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
   }
 }
@@ -606,7 +597,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_rows_kernel(
 // ---- warm path table build -------------------------------------------------------------------
 // Lane ↔ (validator, window): a wavefront holds ONE window index for 64 consecutive validators so
 // that the doubling loop's trip count is wave-uniform.
-__global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restrict__ pub, const uint8_t *__restrict__ pub_state,
+__global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restrict__ pub, const uint32_t *__restrict__ pub_state,
                                                         uint32_t *__restrict__ qtab, uint32_t n_validators) {
   const uint32_t w = blockIdx.x % QTAB_WINDOWS;
   const uint32_t v = (blockIdx.x / QTAB_WINDOWS) * 64 + threadIdx.x;
@@ -616,7 +607,7 @@ __global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restri
   uint32_t *out = qtab + QTAB_DWORDS_PER_VALIDATOR * (work ? v : 0u) + (size_t)GTAB_ENTRY_DWORDS * QTAB_ENTRIES * w;
   qtab_build_window(Q, (int)w, out, work);
 }
-__global__ void qtab_commit_kernel(uint8_t *__restrict__ pub_state, uint32_t n_validators) {
+__global__ void qtab_commit_kernel(uint32_t *__restrict__ pub_state, uint32_t n_validators) {
   uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n_validators && pub_state[v] == 1) pub_state[v] = 2;
 }

@@ -781,8 +781,15 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
 // tables (the λ table is the first one with X·β), 33 digits each — then its sixteen G-table additions.
 // Lane-layout values (r, s, z, the scalars, the digits) simply differ from row to row; the only wave-wide
 // operations are the `any` votes, which merely make every row wait for the slowest one.
+// STOP < 99 cuts the function short after a stage (devtest timing breakdown only; addr then holds junk).
+template <int STOP = 99>
 WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
                            uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa) {
+#define WV_STAGE(n, keep)     \
+  if (STOP == (n)) {          \
+    addr[0] = (keep);         \
+    return ok;                \
+  }
   const wk k = wk_init();
   bool ok = ibftk::sig_in_range(r, s, v, flags);
   const fe rx = secp::fe_from_u256(r);
@@ -794,11 +801,13 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   ok = ok && on_curve;
   fe y = secp::fe_normalize(gather(yc));
   y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
+  WV_STAGE(1, y.n[0] ^ y.n[3])
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
   const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   const secp::glv_split sp = secp::sc_split_lambda(u2);
+  WV_STAGE(2, y.n[0] ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
   // signed radix-16 digits of |k1|, |k2|: k + 0x88…8 has nibbles d_j + 8, bit 128 is digit 32
   uint32_t w1[5], w2[5];
   {
@@ -826,6 +835,7 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   uint32_t TX[9];
 #pragma unroll
   for (int e = 1; e <= 8; e++) TX[e] = wfe_mul(T[e].x, beta, k);
+  WV_STAGE(3, T[3].x ^ T[5].y ^ T[6].z ^ T[7].x ^ T[8].y ^ TX[2] ^ TX[8] ^ u1.v[0] ^ w1[0] ^ w2[1])
   wjac acc = wjac_inf();
 #pragma unroll 1
   for (int jd = 32; jd >= 0; jd--) {
@@ -853,6 +863,7 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     const wjac s2 = wjac_add<true>(acc, q2, k);
     acc = wjac_select(m2 != 0, s2, acc);
   }
+  WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
   // u1·G: all the fixed-base windows in this row
 #pragma unroll 1
   for (int win = 0; win < ibftk::GTAB_WINDOWS; win++) {
@@ -862,10 +873,13 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     const wjac sum = wjac_add_aff<true>(acc, pt, k);
     acc = wjac_select(dgt != 0, sum, acc);
   }
+  WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
   ok = jac_to_aff_wave(Qa, wjac_gather(acc), k) && ok;
+  WV_STAGE(6, Qa.x.n[0] ^ Qa.y.n[1])
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
+#undef WV_STAGE
 }
 
 // ---- the warm path, one signature per wavefront --------------------------------------------------------

@@ -12,7 +12,7 @@ import os
 import struct
 import subprocess
 
-from .build import CSRC, HERE, build_lib
+from .build import CSRC, HERE, build_lib, _mark, _stale
 
 HOST_DIR = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HOST_DIR, "libibft_host.so")
@@ -22,13 +22,12 @@ HOST_DEPS = HOST_SRCS + ["proto.hpp", "messages.hpp", "backend.hpp"]
 
 def build_host(force: bool = False) -> str:
     build_lib()
-    stale = force or not os.path.exists(HOST_LIB) or any(
-        os.path.getmtime(os.path.join(HOST_DIR, d)) > os.path.getmtime(HOST_LIB) for d in HOST_DEPS)
-    inc = os.path.join(HERE, "..", "include", "ibft_host.h")
-    stale = stale or os.path.getmtime(inc) > os.path.getmtime(HOST_LIB)
-    if stale:
+    deps = [os.path.join("..", "host", d) for d in HOST_DEPS] + [os.path.join("..", "..", "include", "ibft_host.h"),
+                                                                  os.path.join("..", "..", "include", "ibftgpu.h")]
+    if force or _stale(HOST_LIB, deps):  # digest of the sources, not modification times (build.py)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB, *HOST_SRCS,
                                "-L" + CSRC, "-libftgpu", "-Wl,-rpath,$ORIGIN/../csrc"], cwd=HOST_DIR)
+        _mark(HOST_LIB, deps)
     return HOST_LIB
 
 

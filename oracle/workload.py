@@ -66,15 +66,34 @@ class Round:
     msg_sig65: np.ndarray  # n × 65
 
 
+def _addresses(sks):
+    """addresses of all validators (pubkey derivation dominates large sets: spread over host threads —
+    ctypes releases the GIL)"""
+    def one(sk):
+        return np.frombuffer(B.address(B.pubkey(sk)), dtype=np.uint8)
+    if len(sks) < 2048:
+        return np.array([one(sk) for sk in sks], dtype=np.uint8).reshape(len(sks), 20)
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        return np.array(list(ex.map(one, sks, chunksize=256)), dtype=np.uint8).reshape(len(sks), 20)
+
+
+def make_shard(n: int, seed: int, lo: int, hi: int, **kw) -> "Round":
+    """rows [lo, hi) of make_round(n, seed, **kw): the validator table covers all n validators, only the
+    shard's rows are signed (multi-GPU bench: every rank builds its own shard of one large round)"""
+    return make_round(n, seed, rows=(lo, hi), **kw)
+
+
 def make_round(n: int, seed: int = 1, *, height: int = 1, round_: int = 0, raw_len: int = 1024,
-               weighted: bool = False, byzantine: bool = False, with_envelopes: bool = False) -> Round:
+               weighted: bool = False, byzantine: bool = False, with_envelopes: bool = False,
+               rows: tuple | None = None) -> Round:
     sm = splitmix64(seed)
     raw = b"".join(next(sm).to_bytes(8, "little") for _ in range((raw_len + 7) // 8))[:raw_len]
     H = B.proposal_hash(raw, round_)
     sks = [validator_key(seed, i) for i in range(n)]
-    addrs = np.zeros((n, 20), dtype=np.uint8)
-    for i, sk in enumerate(sks):
-        addrs[i] = np.frombuffer(B.address(B.pubkey(sk)), dtype=np.uint8)
+    addrs = _addresses(sks)
+    lo, hi = rows if rows is not None else (0, n)
     if weighted:
         power = np.array([1 + B.keccak256(i.to_bytes(8, "little"))[0] % 16 for i in range(n)], dtype=np.uint64)
     else:
@@ -92,7 +111,8 @@ def make_round(n: int, seed: int = 1, *, height: int = 1, round_: int = 0, raw_l
     kind_ctr = 0
     for i in range(n):
         bad = byzantine and (next(bz) % 5 == 0)
-        sig = B.sign(sks[i], H)
+        mine = lo <= i < hi  # rows outside the shard only advance the corruption stream
+        sig = B.sign(sks[i], H) if mine else bytes(65)
         if bad:
             kind = CORRUPTIONS[kind_ctr % len(CORRUPTIONS)]
             kind_ctr += 1
@@ -101,11 +121,11 @@ def make_round(n: int, seed: int = 1, *, height: int = 1, round_: int = 0, raw_l
                 rb = b"".join(next(bz).to_bytes(8, "little") for _ in range(9))[:64]
                 sig = rb + bytes([next(bz) & 1])
             elif kind == "non_validator":
-                sig = B.sign(outsider, H)
+                sig = B.sign(outsider, H) if mine else sig
             elif kind == "other_hash":
-                sig = B.sign(sks[i], other_h)
+                sig = B.sign(sks[i], other_h) if mine else sig
             elif kind == "stolen_seal":
-                sig = B.sign(sks[(i + 1) % n], H)
+                sig = B.sign(sks[(i + 1) % n], H) if mine else sig
             elif kind == "r_zero":
                 sig = bytes(32) + sig[32:]
             elif kind == "s_zero":
@@ -135,7 +155,7 @@ def make_round(n: int, seed: int = 1, *, height: int = 1, round_: int = 0, raw_l
     if with_envelopes:
         chunks = []
         pos = 0
-        for i in range(n):
+        for i in range(lo, hi):
             body = wire.commit_body(hash32[i].tobytes()[: int(hash_len[i])], seal[i].tobytes())
             m = wire.IbftMessage(view=wire.View(height, round_), sender=addrs[i].tobytes(), type=wire.COMMIT,
                                  payload=body)
@@ -144,8 +164,12 @@ def make_round(n: int, seed: int = 1, *, height: int = 1, round_: int = 0, raw_l
             off[i] = pos
             pos += len(pns)
             msg_sig[i] = np.frombuffer(B.sign(sks[i], B.keccak256(pns)), dtype=np.uint8)
-        off[n] = pos
+        off[hi:] = pos
         payload = b"".join(chunks)
 
+    if rows is not None:  # the shard: row columns cut to [lo, hi), the validator table stays whole
+        sl = slice(lo, hi)
+        return Round(seed, hi - lo, height, round_, raw, H, sks, addrs, power, hash32[sl], hash_len[sl], seal[sl],
+                     signer[sl], pre[sl], kinds[lo:hi], payload, off[lo:hi + 1] - off[lo], msg_sig[sl])
     return Round(seed, n, height, round_, raw, H, sks, addrs, power, hash32, hash_len, seal, signer, pre,
                  kinds, payload, off, msg_sig)

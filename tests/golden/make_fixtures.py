@@ -62,6 +62,35 @@ def bench_fixture(name, n, seed):
     print(name, "rows", n)
 
 
+def bench_round_fixture(name, n, seed):
+    """BASELINE config #3 inputs: one whole height at N validators — the honest COMMIT round (seals +
+    message envelopes) and the PREPARE envelopes of everyone but the proposer (validator 0).  Inputs only
+    (so that bench.py signs nothing at run time); the expected verdict is all-true by construction and is
+    checked against the oracle here, once."""
+    from oracle import wire as WR
+    r = W.make_round(n, seed, with_envelopes=True)
+    vs = B.ValSet(r.addrs, r.power)
+    assert B.verify_seals(vs, r.hash32, r.seal65, r.signer20, nthreads=8).all()
+    assert B.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).all()
+    pp, poff, psig = [], [0], np.zeros((n - 1, 65), np.uint8)
+    for i in range(1, n):
+        m = WR.IbftMessage(view=WR.View(r.height, r.round), sender=r.addrs[i].tobytes(), type=WR.PREPARE,
+                           payload=WR.prepare_body(r.proposal_hash))
+        pns = m.payload_no_sig()
+        pp.append(pns)
+        poff.append(poff[-1] + len(pns))
+        psig[i - 1] = np.frombuffer(B.sign(r.sks[i], B.keccak256(pns)), np.uint8)
+    ppayload, poff = b"".join(pp), np.array(poff, np.uint32)
+    assert B.verify_senders(vs, ppayload, poff, psig, r.addrs[1:]).all()
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), seed=np.uint64(seed), raw=np.frombuffer(r.raw, dtype=np.uint8),
+        round=np.uint64(r.round), height=np.uint64(r.height), addrs=r.addrs, power=r.power, hash32=r.hash32,
+        seal65=r.seal65, signer20=r.signer20, payload=np.frombuffer(r.payload, dtype=np.uint8), off=r.off,
+        msg_sig65=r.msg_sig65, prepare_payload=np.frombuffer(ppayload, dtype=np.uint8), prepare_off=poff,
+        prepare_sig65=psig, proposal_hash=np.frombuffer(r.proposal_hash, dtype=np.uint8))
+    print(name, "rows", n)
+
+
 def kat_fixture():
     sk1 = (1).to_bytes(32, "big")
     d = B.keccak256(b"go-ibft golden")
@@ -84,3 +113,4 @@ if __name__ == "__main__":
     seals_fixture("round_n100_byz_weighted", 100, 2, byzantine=True, weighted=True)
     seals_fixture("round_n256_byz", 256, 3, byzantine=True)
     bench_fixture("bench_commit_n1024", 1024, 1)
+    bench_round_fixture("bench_round_n4096", 4096, 3)

@@ -152,3 +152,47 @@ def test_config5_n65536_byzantine_cold_and_warm(oracle):
         assert bv.last_dispatch() == (1, 1)
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("n_val,dups", [(64, 3), (300, 2), (1200, 4), (5000, 2), (40000, 2)])
+def test_duplicate_signers_in_a_cold_batch_do_not_lock_out_late_joiners(oracle, n_val, dups):
+    """several valid rows of ONE validator in the first (cold) batch — PREPARE + COMMIT
+    of the same sender are the normal case — must count that validator once.  An over-count made the host
+    believe every key was known and drop the cold kernel, so validators not yet learned got verdict 0 for
+    ever.  Here the first batch holds `dups` valid rows from each of the first half of the set (so the old
+    counter would reach n_val), then the second half joins late and must still be accepted; every kernel
+    shape the AUTO dispatch picks at these sizes goes through the same learn_key()."""
+    from oracle import workload as W
+    r = W.make_round(n_val, 900 + n_val)
+    r2 = W.make_round(n_val, 900 + n_val, round_=1)       # a second signature of every validator
+    vs = oracle.ValSet(r.addrs, r.power)
+    half = n_val // 2
+    bv = _mk(max_rows=max(1024, dups * half, n_val))
+    try:
+        bv.set_validators(1, r.addrs, r.power)
+        # batch 1: rows of validators [0, half) repeated `dups` times (two different valid signatures alternate)
+        idx = np.tile(np.arange(half), dups)
+        src = [r if k % 2 == 0 else r2 for k in range(dups) for _ in range(half)]
+        h = np.array([s.hash32[i] for s, i in zip(src, idx)]); sl = np.array([s.seal65[i] for s, i in zip(src, idx)])
+        f = r.signer20[idx]
+        got, t = bv.is_valid_committed_seal(h, sl, f)
+        assert got.all() and t.distinct_senders == half and t.valid_rows == dups * half
+        got, _ = bv.is_valid_committed_seal(h, sl, f)     # tables of the first half are built now
+        assert got.all()
+        tables, _, _ = bv.cache_stats()
+        assert tables == half, f"{tables} tables for {half} distinct validators"
+        # batch 2: everybody, the late half included — with some bad rows among the late ones
+        seal = r2.seal65.copy()
+        seal[half + 1, 40] ^= 0x55
+        seal[n_val - 1] = r2.seal65[0]
+        for _ in range(3):                                # late keys are learned, then served warm
+            got, t = bv.is_valid_committed_seal(r2.hash32, seal, r2.signer20)
+            exp = oracle.verify_seals(vs, r2.hash32, seal, r2.signer20, nthreads=8).astype(bool)
+            assert (got == exp).all(), np.nonzero(got != exp)[0][:8]
+            assert exp[half:].sum() == n_val - half - 2
+        assert bv.cache_stats()[0] == n_val - 2           # the two late validators with bad rows stay unlearned
+        got, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)   # and are still served (cold) when valid
+        assert got.all()
+        assert bv.cache_stats()[0] == n_val
+    finally:
+        bv.close()

@@ -1,0 +1,22 @@
+"""Timing breakdown of the row-per-signature recover (sixteen lanes per signature, devtest build) at the
+product's launch shape; run on the GPU box.  Usage: python tools/rows_stages.py [n_rows=4096]"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import go_ibft_amd.build as build
+from oracle import binding as B, workload as W
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+L = C.CDLL(os.environ.get("DEVTEST_SO") or build.build_devtest())
+r = W.make_round(n, 5)
+ms = (C.c_float * 7)()
+out = np.zeros((n, 24), np.uint8)
+rc = L.devtest_rows_stage_ms(n, r.hash32.tobytes(), r.seal65.tobytes(), ms, out.ctypes.data_as(C.c_void_p))
+assert rc == 0
+assert (out[:, 20] == 1).all() and (out[:, :20] == r.addrs).all(), "devtest rows kernel: wrong addresses"
+names = ["sqrt + y", "+scalars (r^-1, GLV)", "+tables (T, TX)", "+main loop (128 dbl, 66 add)", "+16 G additions", "+Z^-1",
+         "complete (+keccak)"]
+prev = 0.0
+print(f"# recover_pubkey_row, {n} rows = {(n + 3) // 4} wavefronts")
+for nm, m in zip(names, ms):
+    print(f"{nm:32s} {m:7.3f} ms   (+{m - prev:.3f})")
+    prev = m

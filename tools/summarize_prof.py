@@ -31,7 +31,7 @@ def per_kernel(path, counter):
     return {k: tot[k] / cnt[k] for k in tot}
 
 
-def main(out, summ, tag):
+def main(out, summ, tag, rows=4096):
     stats = find(os.path.join(out, "stats"), "*kernel_stats.csv")
     if stats:
         shutil.copy(stats, os.path.join(summ, f"{tag}_kernel_stats.csv"))
@@ -43,7 +43,7 @@ def main(out, summ, tag):
         for k in fe:
             if "recover" in k or "verify_known" in k:
                 traffic[k] = {
-                    "rows": 1024,
+                    "rows": int(rows),
                     "fetch_kb": fe[k],
                     "write_kb": wr.get(k, 0.0),
                     "hbm_bytes_per_launch": int((fe[k] + wr.get(k, 0.0)) * 1024),
@@ -56,4 +56,4 @@ def main(out, summ, tag):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
