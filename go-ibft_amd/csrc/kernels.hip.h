@@ -641,11 +641,26 @@ __global__ void wire_stage_seals_kernel(const wire::row_info *__restrict__ rows,
 }
 
 // ---- a8: weighted quorum tally ------------------------------------------------------------
-// One workgroup walks the verdict words; a validator's power is counted once (LDS
-// bitmap = the Go map's set semantics), lanes reduce with wave shuffles, waves through
-// LDS.  out[0..1] = power (128-bit), out[2] = valid_rows | distinct<<32, out[3] = has_quorum.
+// HasQuorum (core/validator_manager.go:77-96): Σ power over the DISTINCT member senders of the valid rows
+// ≥ ⌊2·total/3⌋+1.  Several workgroups (4 096 rows each) walk the verdict words: a validator's power is
+// counted once — a bitmap in HBM updated with device-scope atomicOr gives the Go map's set semantics across
+// workgroups —, lanes reduce with wave shuffles, waves through LDS, workgroups with one device-scope
+// atomicAdd per 32-bit piece; the workgroup that draws the last ticket recombines the pieces (carries),
+// compares with the quorum, delivers the result (also into mapped host memory) and leaves bitmap,
+// accumulators and ticket zeroed for the next launch.
+//   PW = 64-bit words per voting power: 1 (u64, ibft_set_validators) or 4 (256-bit, ibft_set_validators_u256:
+//   GetVotingPowers returns *big.Int, validator_manager.go:17-31).  Sums are TALLY_SUM_WORDS wide.
+// out[] (u64 words): [0..1] low 128 bits of the power, [2] valid_rows | distinct << 32, [3] has_quorum,
+//   [4] keys learned | a learned validator (written by the recover kernels), [5..9] the power in full,
+//   [16..16+2·PW) the raw 32-bit piece sums (what the multi-GPU exchange adds across ranks).
 constexpr int TALLY_THREADS = 1024;
-constexpr int TALLY_SEEN_WORDS = 32768;  // 1M validators in 128 KiB of LDS
+constexpr int TALLY_ROWS_PER_BLOCK = 4096;
+constexpr int TALLY_SUM_WORDS = 5;       // 256-bit powers × up to 2^20 validators < 2^276
+constexpr int TALLY_MAX_PIECES = 8;      // 2·PW 32-bit pieces
+constexpr int TALLY_OUT_WIDE = 5;        // out[5..10)
+constexpr int TALLY_OUT_PIECES = 16;     // out[16..24)
+constexpr int TALLY_OUT_WORDS = 24;
+constexpr int TALLY_ACC_WORDS = TALLY_MAX_PIECES + 3;  // pieces, valid, distinct, ticket
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -653,76 +668,195 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
   return v;
 }
 
-__global__ void __launch_bounds__(TALLY_THREADS)
-tally_kernel(uint64_t *__restrict__ work_mask, uint64_t *__restrict__ mask, const int32_t *__restrict__ vidx,
-             const uint64_t *__restrict__ vpower, uint32_t n, uint32_t n_validators,
-             uint64_t quorum_lo, uint64_t quorum_hi, uint64_t *__restrict__ out,
-             uint64_t *__restrict__ host_mask, uint64_t *__restrict__ host_tally) {
-  // The verdict kernels accumulate into work_mask (atomicOr / ballot words).  The tally CONSUMES it:
-  // the words move to `mask` (what fetch / export read), to host_mask when given — pinned host memory
-  // mapped into the device, like host_tally: the step then needs no device-to-host copy commands —
-  // and work_mask is left zeroed for the next launch, so no memset sits in front of the kernels.
-  for (uint32_t i = threadIdx.x; i < (n + 63) / 64; i += TALLY_THREADS) {
-    const uint64_t w = work_mask[i];
-    work_mask[i] = 0;
-    mask[i] = w;
-    if (host_mask) host_mask[i] = w;
+// Σ piece_k·2^(32k) → TALLY_SUM_WORDS little-endian u64 words (pieces are sums of 32-bit values, < 2^60)
+__device__ __forceinline__ void pieces_to_words(const uint64_t *piece, int n_pieces, uint64_t w[TALLY_SUM_WORDS]) {
+  uint64_t carry = 0;  // running value >> 32 at each 32-bit position
+  uint32_t half[2 * TALLY_SUM_WORDS];
+#pragma unroll
+  for (int k = 0; k < 2 * TALLY_SUM_WORDS; k++) {
+    const uint64_t t = carry + (k < n_pieces ? piece[k] : 0ull);  // < 2^61
+    half[k] = (uint32_t)t;
+    carry = t >> 32;
   }
-  __shared__ uint32_t seen[TALLY_SEEN_WORDS];
-  __shared__ uint64_t part[4][TALLY_THREADS / 64];
-  const uint32_t words = (n_validators + 31) / 32;
-  for (uint32_t i = threadIdx.x; i < words; i += TALLY_THREADS) seen[i] = 0;
+#pragma unroll
+  for (int i = 0; i < TALLY_SUM_WORDS; i++) w[i] = (uint64_t)half[2 * i] | ((uint64_t)half[2 * i + 1] << 32);
+}
+__device__ __forceinline__ bool words_ge(const uint64_t a[TALLY_SUM_WORDS], const uint64_t *b) {
+#pragma unroll
+  for (int i = TALLY_SUM_WORDS - 1; i >= 0; i--) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+
+struct tally_args {
+  uint64_t *work_mask;      // verdict words accumulated by the verdict kernels; consumed (zeroed) here
+  uint64_t *mask;           // verdict words as fetch / export / exchange read them
+  const int32_t *vidx;      // n: validator index of the row's sender (−1 = not a member)
+  const uint32_t *vpower32; // n_validators × 2·PW little-endian 32-bit pieces
+  uint32_t n, n_validators;
+  uint32_t *seen;           // ⌈n_validators/32⌉ words, zero between launches
+  uint64_t *acc;            // TALLY_ACC_WORDS, zero between launches
+  const uint64_t *quorum;   // TALLY_SUM_WORDS
+  uint64_t *out;            // TALLY_OUT_WORDS
+  uint64_t *host_mask, *host_tally;  // mapped pinned host memory (or null): no device-to-host copy commands
+};
+
+template <int PW>
+__global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
+  constexpr int NP = 2 * PW;
+  __shared__ uint64_t wds[TALLY_ROWS_PER_BLOCK / 64];
+  __shared__ uint64_t part[NP + 1][TALLY_THREADS / 64];
+  __shared__ uint32_t last_flag;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t row0 = blockIdx.x * (uint32_t)TALLY_ROWS_PER_BLOCK;
+  const uint32_t total_words = (a.n + 63) / 64;
+  // The verdict kernels accumulate into work_mask (atomicOr / ballot words).  The tally CONSUMES it: the words
+  // move to `mask`, to host_mask when given, and work_mask is left zeroed for the next launch.
+  if (tid < TALLY_ROWS_PER_BLOCK / 64) {
+    const uint32_t wi = row0 / 64 + tid;
+    uint64_t w = 0;
+    if (wi < total_words) {
+      w = a.work_mask[wi];
+      a.work_mask[wi] = 0;
+      a.mask[wi] = w;
+      if (a.host_mask) a.host_mask[wi] = w;
+    }
+    wds[tid] = w;
+  }
   __syncthreads();
-  uint64_t p_lo = 0, p_hi = 0, valid = 0, distinct = 0;
-  for (uint32_t row = threadIdx.x; row < n; row += TALLY_THREADS) {
-    bool bit = (mask[row >> 6] >> (row & 63)) & 1ull;
-    if (!bit) continue;
+  uint64_t p[NP];
+#pragma unroll
+  for (int k = 0; k < NP; k++) p[k] = 0;
+  uint64_t valid = 0, distinct = 0;
+#pragma unroll
+  for (int j = 0; j < TALLY_ROWS_PER_BLOCK / TALLY_THREADS; j++) {
+    const uint32_t lr = (uint32_t)j * TALLY_THREADS + tid, row = row0 + lr;
+    if (row >= a.n || !((wds[lr >> 6] >> (lr & 63)) & 1ull)) continue;
     valid++;
-    int vi = vidx[row];
+    const int vi = a.vidx[row];
     if (vi < 0) continue;  // unknown senders contribute 0 (validator_manager.go:88-92)
-    uint32_t m = 1u << (vi & 31);
-    uint32_t old = atomicOr(&seen[vi >> 5], m);
+    const uint32_t m = 1u << (vi & 31);
+    const uint32_t old = atomicOr(&a.seen[vi >> 5], m);  // device scope: the set is shared by all workgroups
     if (old & m) continue;  // distinct-sender set (validator_manager.go:147-155)
     distinct++;
-    uint64_t pw = vpower[vi];
-    uint64_t nl = p_lo + pw;
-    p_hi += nl < p_lo;
-    p_lo = nl;
+#pragma unroll
+    for (int k = 0; k < NP; k++) p[k] += a.vpower32[(size_t)vi * NP + k];
   }
-  // wave reduction of the 128-bit power: split into 32-bit pieces so lane sums cannot overflow
-  uint64_t a0 = wave_sum_u64(p_lo & 0xFFFFFFFFull), a1 = wave_sum_u64(p_lo >> 32);
-  uint64_t a2 = wave_sum_u64(p_hi);
-  uint64_t cnt = wave_sum_u64(valid | (distinct << 32));
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) {
-    part[0][wave] = a0;
-    part[1][wave] = a1;
-    part[2][wave] = a2;
-    part[3][wave] = cnt;
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const uint64_t sum = wave_sum_u64(p[k]);
+    if (lane == 0) part[k][wave] = sum;
+  }
+  {
+    const uint64_t cnt = wave_sum_u64(valid | (distinct << 32));
+    if (lane == 0) part[NP][wave] = cnt;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint64_t s0 = 0, s1 = 0, s2 = 0, c = 0;
-    for (int w = 0; w < TALLY_THREADS / 64; w++) {
-      s0 += part[0][w];
-      s1 += part[1][w];
-      s2 += part[2][w];
-      c += part[3][w];
+  if (tid <= NP) {  // thread k adds piece k (thread NP: the two counters) of this workgroup to the launch-wide sums
+    uint64_t sum = 0;
+    for (int w = 0; w < TALLY_THREADS / 64; w++) sum += part[tid][w];
+    if (tid < NP) {
+      if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + tid), (unsigned long long)sum);
+    } else {
+      if (sum & 0xFFFFFFFFull) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), (unsigned long long)(sum & 0xFFFFFFFFull));
+      if (sum >> 32) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), (unsigned long long)(sum >> 32));
     }
-    // power = s0 + s1*2^32 + s2*2^64
-    uint64_t lo = s0 + (s1 << 32);
-    uint64_t hi = s2 + (s1 >> 32) + (lo < s0 ? 1 : 0);
-    out[0] = lo;
-    out[1] = hi;
-    out[2] = c;
-    const uint64_t hq = (hi > quorum_hi || (hi == quorum_hi && lo >= quorum_lo)) ? 1 : 0;
-    out[3] = hq;
-    if (host_tally) {
-      host_tally[0] = lo;
-      host_tally[1] = hi;
-      host_tally[2] = c;
-      host_tally[3] = hq;
-      host_tally[4] = out[4];  // keys learned | a learned validator, written by the recover kernels
+    // the adds return nothing: wait until the memory side has acknowledged them before this workgroup's ticket
+    // can be drawn (device-scope read-modify-writes are performed where they are acknowledged)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();  // the bitmap atomics returned values (awaited by their users), the adds were awaited above
+  if (tid == 0) {
+    const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 2), 1ull);
+    last_flag = (t == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // ---- the last workgroup: every other one has added its pieces and set its bits ----
+  if (tid == 0) {
+    uint64_t piece[TALLY_MAX_PIECES];
+#pragma unroll
+    for (int k = 0; k < TALLY_MAX_PIECES; k++)
+      piece[k] = k < NP ? (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + k), 0ull) : 0ull;
+    const uint64_t v = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), 0ull);
+    const uint64_t d = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), 0ull);
+    uint64_t w[TALLY_SUM_WORDS];
+    pieces_to_words(piece, NP, w);
+    const uint64_t hq = words_ge(w, a.quorum) ? 1 : 0;
+    const uint64_t c = (v & 0xFFFFFFFFull) | (d << 32);
+    a.out[0] = w[0];
+    a.out[1] = w[1];
+    a.out[2] = c;
+    a.out[3] = hq;
+#pragma unroll
+    for (int i = 0; i < TALLY_SUM_WORDS; i++) a.out[TALLY_OUT_WIDE + i] = w[i];
+#pragma unroll
+    for (int k = 0; k < TALLY_MAX_PIECES; k++) a.out[TALLY_OUT_PIECES + k] = piece[k];
+    if (a.host_tally) {
+      a.host_tally[0] = w[0];
+      a.host_tally[1] = w[1];
+      a.host_tally[2] = c;
+      a.host_tally[3] = hq;
+      a.host_tally[4] = a.out[4];  // keys learned | a learned validator, written by the recover kernels
+#pragma unroll
+      for (int i = 0; i < TALLY_SUM_WORDS; i++) a.host_tally[TALLY_OUT_WIDE + i] = w[i];
+    }
+#pragma unroll
+    for (int k = 0; k < TALLY_ACC_WORDS; k++)
+      __hip_atomic_store(a.acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS)
+    __hip_atomic_store(a.seen + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- multi-GPU: the one exchange step -------------------------------------------------
+// Exchange buffer of a sharded batch (u64 slots): [ verdict words of rank 0 | … | rank W−1 | 2·PW piece sums |
+// valid rows | distinct senders ].  A rank fills its own word range and its partial tally, everything else is
+// zero: after ncclAllReduce(sum) the words are the global verdict mask (disjoint shards: sum ≡ OR) and the
+// pieces add without carries lost (32-bit pieces in 64-bit slots).  has_quorum is recomputed from the sum.
+__global__ void exchange_pack_kernel(const uint64_t *__restrict__ mask, const uint64_t *__restrict__ tally_out,
+                                     uint64_t *__restrict__ xbuf, uint32_t my_off, uint32_t my_words,
+                                     uint32_t total_words, uint32_t n_pieces) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total_words) {
+    xbuf[i] = (i >= my_off && i < my_off + my_words) ? mask[i - my_off] : 0ull;
+  } else if (i < total_words + n_pieces) {
+    xbuf[i] = tally_out[TALLY_OUT_PIECES + (i - total_words)];
+  } else if (i == total_words + n_pieces) {
+    xbuf[i] = tally_out[2] & 0xFFFFFFFFull;
+  } else if (i == total_words + n_pieces + 1) {
+    xbuf[i] = tally_out[2] >> 32;
+  }
+}
+// merged buffer → [ total_words verdict words | TALLY_OUT_WORDS-style tally ] in device memory and, when given,
+// mapped host memory
+__global__ void exchange_unpack_kernel(const uint64_t *__restrict__ xbuf, uint32_t total_words, uint32_t n_pieces,
+                                       const uint64_t *__restrict__ quorum, uint64_t *__restrict__ dst,
+                                       uint64_t *__restrict__ host_dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total_words) {
+    const uint64_t w = xbuf[i];
+    dst[i] = w;
+    if (host_dst) host_dst[i] = w;
+  } else if (i == total_words) {
+    uint64_t piece[TALLY_MAX_PIECES];
+#pragma unroll
+    for (int k = 0; k < TALLY_MAX_PIECES; k++) piece[k] = (uint32_t)k < n_pieces ? xbuf[total_words + k] : 0ull;
+    uint64_t w[TALLY_SUM_WORDS];
+    pieces_to_words(piece, TALLY_MAX_PIECES, w);
+    uint64_t t[2 + 2 + TALLY_SUM_WORDS];
+    t[0] = w[0];
+    t[1] = w[1];
+    t[2] = (xbuf[total_words + n_pieces] & 0xFFFFFFFFull) | (xbuf[total_words + n_pieces + 1] << 32);
+    t[3] = words_ge(w, quorum) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < TALLY_SUM_WORDS; k++) t[4 + k] = w[k];
+#pragma unroll
+    for (int k = 0; k < 4 + TALLY_SUM_WORDS; k++) {
+      dst[total_words + k] = t[k];
+      if (host_dst) host_dst[total_words + k] = t[k];
     }
   }
 }
