@@ -268,39 +268,30 @@ def main():
         if path == "warm":                                             # learn the keys, build the tables (untimed)
             bv.seals_launch(1); bv.seals_fetch(); bv.seals_launch(1); bv.seals_fetch()
             assert bv.cache_stats()[0] == len(np.unique(rd["signer20"], axis=0)) or byzantine
-        words = S.words_per_rank(n_total, world)
-        slots, tally_off = S.exchange_layout(n_total, world)
-        assert S.shard_range(n_total, rank, world) == (lo, hi)
-        ar = [torch.zeros(slots + 1, dtype=torch.int64, device=dev) for _ in range(2)] if dist else None
-        evs = [torch.cuda.Event() for _ in range(2)] if dist else None
-        xstream = torch.cuda.Stream(device=dev) if dist else None
+        assert V.shard_range(n_total, rank, world) == (lo, hi) == S.shard_range(n_total, rank, world)
+        if dist:
+            # the data-path collective lives in libibftgpu.so (RCCL all-reduce of verdict words + tally pieces);
+            # torch.distributed only carries the 128-byte communicator id and the timing fences
+            uid = [V.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, device=dev)
+            bv.comm_init(uid[0], rank, world)
 
         def step():  # N = 1: one synchronous pass, results on the host when it returns
             bv.seals_launch(1)
             return bv.seals_fetch()
 
-        def exchange(k):
-            """hand shard k's verdict words + tally partials to the collective: copies and all-reduce run on
-            their own stream behind a results-ready event, the library's stream is free for the next batch"""
-            buf = ar[k & 1]
-            with torch.cuda.stream(xstream):
-                buf.zero_()
-                bv.seals_export_on(buf[rank * words:].data_ptr(), buf[tally_off:].data_ptr(), xstream.cuda_stream)
-                dist.all_reduce(buf)  # disjoint shards: sum == OR; tally partials add
-                evs[k & 1].record()
-
         def run_sharded(k_steps):
-            """the exchange of pass k overlaps with the kernels of pass k+1; the host consumes every merged
-            result one pass later (bounded pipeline, depth 1)"""
+            """the exchange of pass k (own stream, behind the tally) overlaps with the kernels of pass k+1; the
+            host consumes every merged result one pass later (bounded pipeline, depth 1)"""
             bv.seals_launch(1)
+            res = None
             for k in range(k_steps):
-                exchange(k)
+                bv.seals_exchange(n_total)
                 if k + 1 < k_steps:
                     bv.seals_launch(1)
                 if k >= 1:
-                    evs[(k - 1) & 1].synchronize()
-            evs[(k_steps - 1) & 1].synchronize()
-            return ar[(k_steps - 1) & 1]
+                    res = bv.seals_fetch_merged()
+            return bv.seals_fetch_merged()
 
         def fence():
             if dist is not None:
@@ -341,8 +332,8 @@ def main():
             for k in range(min(steps, 20)):                   # latency of one synchronous pass incl. the exchange
                 s0 = time.perf_counter()
                 bv.seals_launch(1)
-                exchange(k)
-                evs[k & 1].synchronize()
+                bv.seals_exchange(n_total)
+                bv.seals_fetch_merged()
                 lat.append(time.perf_counter() - s0)
         # quorum latency of this one call including the host→device copies
         lat_h2d = []
@@ -364,13 +355,12 @@ def main():
             else:
                 assert (verdict == expect).all()
         else:
-            quorum = 2 * int(power.astype(object).sum()) // 3 + 1
-            verdict, pw, valid, distinct, hq = S.merge(out.cpu().numpy()[:slots], n_total, world, quorum)
+            verdict, tally = out                              # merged: global mask, summed tally
             if expect is None:
-                assert verdict.all() and valid == n_total and pw == int(power.sum()) and hq
+                assert verdict.all() and tally.valid_rows == n_total and tally.power == int(power.sum()) and tally.has_quorum
             else:
                 assert (verdict[lo:hi] == expect).all(), "merged verdicts differ from the oracle on this shard"
-                assert hq == (pw >= quorum)
+                assert bool(tally.has_quorum) == (tally.power >= tally.quorum) and tally.valid_rows == int(verdict.sum())
         cold_lanes, warm_lanes = bv.last_dispatch()
         if path == "warm":
             bv.cache_stats()
@@ -379,6 +369,8 @@ def main():
                "kernel_ms": kernel_ms, "kernel_launches": kernel_launches, "kname": kernel_name(path, cold_lanes, warm_lanes),
                "src": rd["src"], "rd": rd, "tables": bv.cache_stats()[0] if path == "warm" else 0,
                "valid_fraction": float(verdict.mean())}
+        if dist:
+            bv.comm_destroy()
         bv.close()
         return res
 

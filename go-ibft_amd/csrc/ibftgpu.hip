@@ -6,6 +6,8 @@
 #include "../../include/ibftgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen()ed on first use (ibft_comm_* / ibft_group_*)
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -54,8 +56,22 @@ struct ibft_ctx {
   uint32_t vslot_mask = 0;
   uint32_t n_validators = 0;
   bool have_valset = false;
-  unsigned __int128 quorum = 0;
+  uint32_t power_words = 1;                          // 64-bit words per voting power: 1 (u64) or 4 (256-bit)
+  uint64_t quorum_w[ibftk::TALLY_SUM_WORDS] = {0};   // ⌊2·total/3⌋+1, little-endian words
+  DevBuf d_seen, d_acc, d_quorum;                    // tally: distinct-sender bitmap, launch-wide sums + ticket, quorum words
+  uint64_t last_wide[ibftk::TALLY_SUM_WORDS] = {0};  // full-width power of the last fetched tally
   uint64_t height = 0;
+
+  // multi-GPU exchange (ibft_comm_*): rows of a batch sharded over `xworld` contexts, one all-reduce merges them
+  ncclComm_t comm = nullptr;
+  uint32_t xrank = 0, xworld = 1;
+  hipStream_t xstream = nullptr;
+  DevBuf d_xbuf[2], d_xres[2];
+  uint64_t *h_xres[2] = {nullptr, nullptr}, *dh_xres[2] = {nullptr, nullptr};
+  size_t h_xres_words = 0;
+  hipEvent_t ev_xdone[2] = {nullptr, nullptr};
+  uint64_t x_total[2] = {0, 0};   // n_total of the exchange in each slot
+  uint32_t x_issued = 0, x_fetched = 0;  // exchanges enqueued / consumed (at most 2 in flight)
 
   // warm path (IBFT_FLAG_PUBKEY_CACHE): recovered keys + per-validator fixed-base tables
   bool cache_on = false;       // flag set AND the tables fit the memory budget for this validator set
@@ -135,7 +151,9 @@ int alloc_rows(ibft_ctx *c) {
   if ((rc = ensure(c, c->d_mask_out, (size_t)mask_words(m) * 8))) return rc;
   c->mask_dirty_words = ~0u;
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
-  if ((rc = ensure(c, c->d_tally, 8 * 8))) return rc;
+  if ((rc = ensure(c, c->d_tally, (size_t)ibftk::TALLY_OUT_WORDS * 8))) return rc;
+  if ((rc = ensure(c, c->d_acc, (size_t)ibftk::TALLY_ACC_WORDS * 8))) return rc;
+  if ((rc = ensure(c, c->d_quorum, (size_t)ibftk::TALLY_SUM_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
   if ((rc = ensure(c, c->d_warm_done, m))) return rc;
   return IBFT_OK;
@@ -331,14 +349,28 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator
 }
 
 int enqueue_tally(ibft_ctx *c, uint32_t n) {
-  if (c->read_pending) {  // a consumer stream is still copying the previous results (ibft_seals_export_on)
+  if (c->read_pending) {  // a consumer stream is still copying the previous results (ibft_seals_export_on / exchange)
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_read, 0));
     c->read_pending = false;
   }
-  hipLaunchKernelGGL(ibftk::tally_kernel, dim3(1), dim3(ibftk::TALLY_THREADS), 0, c->stream,
-                     (uint64_t *)c->d_mask.p, (uint64_t *)c->d_mask_out.p, (const int32_t *)c->d_vidx.p,
-                     (const uint64_t *)c->d_vpower.p, n, c->n_validators, (uint64_t)c->quorum,
-                     (uint64_t)(c->quorum >> 64), (uint64_t *)c->d_tally.p, c->dh_mask, c->dh_tally);
+  ibftk::tally_args t{};
+  t.work_mask = (uint64_t *)c->d_mask.p;
+  t.mask = (uint64_t *)c->d_mask_out.p;
+  t.vidx = (const int32_t *)c->d_vidx.p;
+  t.vpower32 = (const uint32_t *)c->d_vpower.p;
+  t.n = n;
+  t.n_validators = c->n_validators;
+  t.seen = (uint32_t *)c->d_seen.p;
+  t.acc = (uint64_t *)c->d_acc.p;
+  t.quorum = (const uint64_t *)c->d_quorum.p;
+  t.out = (uint64_t *)c->d_tally.p;
+  t.host_mask = c->dh_mask;
+  t.host_tally = c->dh_tally;
+  const dim3 grid(std::max(1u, (n + ibftk::TALLY_ROWS_PER_BLOCK - 1) / ibftk::TALLY_ROWS_PER_BLOCK)), block(ibftk::TALLY_THREADS);
+  if (c->power_words == 1)
+    hipLaunchKernelGGL(ibftk::tally_kernel<1>, grid, block, 0, c->stream, t);
+  else
+    hipLaunchKernelGGL(ibftk::tally_kernel<4>, grid, block, 0, c->stream, t);
   HIPCHK(c, hipGetLastError());
   c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally
   if ((uint32_t)mask_words(n) >= c->mask_dirty_words) c->mask_dirty_words = 0;  // ... and it zeroed every word that held bits
@@ -353,9 +385,10 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
     if (out_mask && mw)
       HIPCHK(c, hipMemcpyAsync(c->h_mask, have_tally ? c->d_mask_out.p : c->d_mask.p, mw * 8, hipMemcpyDeviceToHost,
                                c->stream));
-    // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator}: one copy
+    // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator, power in full}: one copy
     if ((tally && have_tally) || c->cache_on)
-      HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, (size_t)(ibftk::TALLY_OUT_WIDE + ibftk::TALLY_SUM_WORDS) * 8,
+                               hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->cache_on) {
@@ -368,10 +401,12 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
     // clear the padding bits of the last word
     if (n & 63) out_mask[mw - 1] &= (~0ull) >> (64 - (n & 63));
   }
+  if (have_tally)
+    for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = c->h_tally[ibftk::TALLY_OUT_WIDE + i];
   if (tally) {
     memset(tally, 0, sizeof *tally);
-    tally->quorum_lo = (uint64_t)c->quorum;
-    tally->quorum_hi = (uint64_t)(c->quorum >> 64);
+    tally->quorum_lo = c->quorum_w[0];
+    tally->quorum_hi = c->quorum_w[1];
     if (have_tally) {
       tally->power_lo = c->h_tally[0];
       tally->power_hi = c->h_tally[1];
@@ -391,7 +426,191 @@ int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes) {
   return IBFT_OK;
 }
 
+
+// ---- RCCL, loaded on first use: a single-GPU deployment never needs the library ----------------------
+struct RcclApi {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+RcclApi *rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {getenv("IBFT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+      if (!nm || !*nm) continue;
+      if ((api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    }
+    if (!api.handle) return;
+#define IBFT_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, name))
+    IBFT_SYM(GetUniqueId, "ncclGetUniqueId");
+    IBFT_SYM(CommInitRank, "ncclCommInitRank");
+    IBFT_SYM(CommDestroy, "ncclCommDestroy");
+    IBFT_SYM(AllReduce, "ncclAllReduce");
+    IBFT_SYM(GroupStart, "ncclGroupStart");
+    IBFT_SYM(GroupEnd, "ncclGroupEnd");
+    IBFT_SYM(GetErrorString, "ncclGetErrorString");
+#undef IBFT_SYM
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllReduce && api.GroupStart && api.GroupEnd;
+  });
+  return api.ok ? &api : nullptr;
+}
+#define NCCLCHK(ctx, api, expr)                                                                              \
+  do {                                                                                                       \
+    ncclResult_t r_ = (expr);                                                                                \
+    if (r_ != ncclSuccess) {                                                                                 \
+      (ctx)->last_error = std::string(#expr) + ": " + ((api)->GetErrorString ? (api)->GetErrorString(r_) : "rccl error"); \
+      return IBFT_E_RCCL;                                                                                    \
+    }                                                                                                        \
+  } while (0)
+
+void comm_release(ibft_ctx *c) {
+  if (c->comm) {
+    if (RcclApi *a = rccl()) (void)a->CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
+  for (int i = 0; i < 2; i++) {
+    if (c->ev_xdone[i]) (void)hipEventDestroy(c->ev_xdone[i]);
+    c->ev_xdone[i] = nullptr;
+    if (c->h_xres[i]) (void)hipHostFree(c->h_xres[i]);
+    c->h_xres[i] = c->dh_xres[i] = nullptr;
+  }
+  c->h_xres_words = 0;
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
+  c->xstream = nullptr;
+  c->xrank = 0;
+  c->xworld = 1;
+  c->x_issued = c->x_fetched = 0;
+}
+
+// shard layout (pure): contiguous 64-aligned row ranges, the last rank takes the remainder
+uint64_t shard_rows_per_rank(uint64_t n_total, uint32_t world) {
+  return (((n_total + world - 1) / world) + 63) / 64 * 64;
+}
+
+int ensure_handoff_events(ibft_ctx *c) {
+  if (!c->ev_ready) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
+  }
+  return IBFT_OK;
+}
+
+struct xplan {
+  uint32_t slot, w, total_words, n_pieces, slots, my_words;
+};
+// before the collective: order behind the tally, pack this rank's words + partial tally into the exchange buffer
+int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x) {
+  if (!c->comm || !c->have_valset) return c->comm ? IBFT_E_NOVALSET : IBFT_E_INVAL;
+  if (c->x_issued - c->x_fetched >= 2) {
+    c->last_error = "two exchanges already in flight: call ibft_seals_fetch_merged first";
+    return IBFT_E_INVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint64_t per = shard_rows_per_rank(n_total, c->xworld);
+  x.slot = c->x_issued & 1u;
+  x.w = (uint32_t)(per / 64);
+  x.total_words = x.w * c->xworld;
+  x.n_pieces = 2 * c->power_words;
+  x.slots = x.total_words + x.n_pieces + 2;
+  x.my_words = (uint32_t)mask_words(c->staged_n);
+  const uint64_t lo = std::min<uint64_t>((uint64_t)c->xrank * per, n_total), hi = std::min<uint64_t>(lo + per, n_total);
+  if ((uint64_t)c->staged_n != hi - lo) {
+    c->last_error = "the resident batch is not this rank's shard of n_total rows (ibft_shard_range)";
+    return IBFT_E_INVAL;
+  }
+  int rc;
+  if ((rc = ensure(c, c->d_xbuf[x.slot], (size_t)x.slots * 8))) return rc;
+  const size_t res_words = (size_t)x.total_words + 16;
+  if ((rc = ensure(c, c->d_xres[x.slot], res_words * 8))) return rc;
+  if (res_words > c->h_xres_words) {  // (re)allocate the mapped result buffers; nothing is in flight on a fresh size
+    if (c->x_issued != c->x_fetched) HIPCHK(c, hipStreamSynchronize(c->xstream));
+    for (int i = 0; i < 2; i++) {
+      if (c->h_xres[i]) (void)hipHostFree(c->h_xres[i]);
+      c->h_xres[i] = c->dh_xres[i] = nullptr;
+      if (hipHostMalloc((void **)&c->h_xres[i], res_words * 8) != hipSuccess) return IBFT_E_NOMEM;
+      void *d = nullptr;
+      if (hipHostGetDevicePointer(&d, c->h_xres[i], 0) == hipSuccess) c->dh_xres[i] = (uint64_t *)d;
+    }
+    c->h_xres_words = res_words;
+  }
+  if ((rc = ensure_handoff_events(c))) return rc;
+  HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));  // everything launched so far, the tally included
+  HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
+  hipLaunchKernelGGL(ibftk::exchange_pack_kernel, dim3((x.slots + 255) / 256), dim3(256), 0, c->xstream,
+                     (const uint64_t *)c->d_mask_out.p, (const uint64_t *)c->d_tally.p, (uint64_t *)c->d_xbuf[x.slot].p,
+                     c->xrank * x.w, x.my_words, x.total_words, x.n_pieces);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev_read, c->xstream));
+  c->read_pending = true;  // the next tally overwrites d_mask_out / d_tally only after the pack has read them
+  return IBFT_OK;
+}
+int exchange_collective(ibft_ctx *c, RcclApi *api, const xplan &x) {
+  NCCLCHK(c, api, api->AllReduce(c->d_xbuf[x.slot].p, c->d_xbuf[x.slot].p, x.slots, ncclUint64, ncclSum, c->comm, c->xstream));
+  return IBFT_OK;
+}
+int exchange_post(ibft_ctx *c, uint64_t n_total, const xplan &x) {
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(ibftk::exchange_unpack_kernel, dim3((x.total_words + 1 + 255) / 256), dim3(256), 0, c->xstream,
+                     (const uint64_t *)c->d_xbuf[x.slot].p, x.total_words, x.n_pieces, (const uint64_t *)c->d_quorum.p,
+                     (uint64_t *)c->d_xres[x.slot].p, c->dh_xres[x.slot]);
+  HIPCHK(c, hipGetLastError());
+  if (!c->dh_xres[x.slot])
+    HIPCHK(c, hipMemcpyAsync(c->h_xres[x.slot], c->d_xres[x.slot].p, ((size_t)x.total_words + 16) * 8, hipMemcpyDeviceToHost,
+                             c->xstream));
+  HIPCHK(c, hipEventRecord(c->ev_xdone[x.slot], c->xstream));
+  c->x_total[x.slot] = n_total;
+  c->x_issued++;
+  return IBFT_OK;
+}
+int fetch_merged_locked(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (c->x_fetched == c->x_issued) return IBFT_E_INVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t slot = c->x_fetched & 1u;
+  HIPCHK(c, hipEventSynchronize(c->ev_xdone[slot]));
+  c->x_fetched++;
+  const uint64_t n_total = c->x_total[slot];
+  const uint64_t per = shard_rows_per_rank(n_total, c->xworld);
+  const size_t total_words = (size_t)(per / 64) * c->xworld, mw = (size_t)((n_total + 63) / 64);
+  const uint64_t *res = c->h_xres[slot];
+  if (out_mask && mw) memcpy(out_mask, res, mw * 8);
+  const uint64_t *t = res + total_words;
+  for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = t[4 + i];
+  if (tally) {
+    memset(tally, 0, sizeof *tally);
+    tally->quorum_lo = c->quorum_w[0];
+    tally->quorum_hi = c->quorum_w[1];
+    tally->power_lo = t[0];
+    tally->power_hi = t[1];
+    tally->valid_rows = (uint32_t)(t[2] & 0xFFFFFFFFull);
+    tally->distinct_senders = (uint32_t)(t[2] >> 32);
+    tally->has_quorum = (uint32_t)t[3];
+  }
+  return IBFT_OK;
+}
+int comm_attach(ibft_ctx *c, ncclComm_t comm, uint32_t rank, uint32_t world) {
+  HIPCHK(c, hipSetDevice(c->device));
+  c->comm = comm;
+  c->xrank = rank;
+  c->xworld = world;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_xdone[i], hipEventDisableTiming));
+  return IBFT_OK;
+}
+
 }  // namespace
+
+struct ibft_group {
+  std::mutex mu;
+  std::vector<ibft_ctx *> ctx;
+};
 
 extern "C" {
 
@@ -407,6 +626,7 @@ const char *ibft_strerror(int code) {
     case IBFT_E_NOVALSET: return "validator set not configured";
     case IBFT_E_POWER: return "total voting power is zero or less";
     case IBFT_E_TOOBIG: return "batch exceeds max_rows";
+    case IBFT_E_RCCL: return "RCCL unavailable or a collective failed";
     default: return "unknown error";
   }
 }
@@ -442,6 +662,8 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
     if ((rc = alloc_rows(c))) break;
+    if (hipMemsetAsync(c->d_acc.p, 0, c->d_acc.cap, c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_tally.p, 0, c->d_tally.cap, c->stream) != hipSuccess) { rc = IBFT_E_HIP; break; }
     if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_tally, 128) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     // zero-copy result delivery (tally_kernel writes the verdict words and its own result into the
@@ -474,8 +696,10 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
-                    &c->d_warm_done})
+                    &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
+                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1]})
     release(*b);
+  comm_release(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_read) (void)hipEventDestroy(c->ev_read);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
@@ -485,9 +709,9 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   delete c;
 }
 
-int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint64_t *power,
-                        size_t n) {
-  if (!c || (n && (!addrs20 || !power)) || n > (1u << 20)) return IBFT_E_INVAL;
+// powers: n × pw little-endian 64-bit words (pw = 1: ibft_set_validators, pw = 4: ibft_set_validators_u256)
+static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint64_t *power, uint32_t pw,
+                               size_t n) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   // Host-side build of the open-addressing table; a repeated address keeps the LAST
@@ -495,8 +719,8 @@ int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, co
   uint32_t slots = 64;
   while (slots < 2 * n + 2) slots <<= 1;
   std::vector<uint32_t> tab((size_t)slots * 6, 0);
-  std::vector<uint64_t> pw;
-  pw.reserve(n ? n : 1);
+  std::vector<uint64_t> pwv;  // distinct validators × pw words
+  pwv.reserve((n ? n : 1) * pw);
   for (size_t i = 0; i < n; i++) {
     uint32_t a[5];
     memcpy(a, addrs20 + 20 * i, 20);
@@ -505,31 +729,69 @@ int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, co
       uint32_t *e = &tab[(size_t)s * 6];
       if (e[5] == 0) {
         memcpy(e, a, 20);
-        pw.push_back(power[i]);
-        e[5] = (uint32_t)pw.size();
+        pwv.insert(pwv.end(), power + i * pw, power + (i + 1) * pw);
+        e[5] = (uint32_t)(pwv.size() / pw);
         break;
       }
       if (memcmp(e, a, 20) == 0) {
-        pw[e[5] - 1] = power[i];
+        memcpy(&pwv[(size_t)(e[5] - 1) * pw], power + i * pw, (size_t)pw * 8);
         break;
       }
       s = (s + 1) & (slots - 1);
     }
   }
-  unsigned __int128 total = 0;
-  for (uint64_t p : pw) total += p;
-  if (total == 0) return IBFT_E_POWER;  // validator_manager.go:68-70
-  if (pw.size() > (size_t)ibftk::TALLY_SEEN_WORDS * 32) return IBFT_E_TOOBIG;
+  const size_t nv = pwv.size() / pw;
+  // total voting power and quorum = ⌊2·total/3⌋ + 1 (calculateQuorum, validator_manager.go:130-135) in
+  // TALLY_SUM_WORDS × 64 bits, as 32-bit halves: total → ×2 → long division by 3 → +1
+  constexpr int H = 2 * ibftk::TALLY_SUM_WORDS;
+  uint64_t piece[H] = {0};
+  for (size_t v = 0; v < nv; v++)
+    for (uint32_t k = 0; k < 2 * pw; k++) piece[k] += (pwv[v * pw + k / 2] >> (32 * (k & 1))) & 0xFFFFFFFFull;
+  uint32_t half[H];
+  {
+    uint64_t carry = 0;
+    for (int k = 0; k < H; k++) {
+      const uint64_t t = carry + piece[k];
+      half[k] = (uint32_t)t;
+      carry = t >> 32;
+    }
+  }
+  bool zero = true;
+  for (int k = 0; k < H; k++) zero = zero && half[k] == 0;
+  if (zero) return IBFT_E_POWER;  // validator_manager.go:68-70
+  {
+    uint32_t carry = 0;  // × 2
+    for (int k = 0; k < H; k++) {
+      const uint32_t top = half[k] >> 31;
+      half[k] = (half[k] << 1) | carry;
+      carry = top;
+    }
+    uint64_t rem = 0;    // ÷ 3
+    for (int k = H - 1; k >= 0; k--) {
+      const uint64_t cur = (rem << 32) | half[k];
+      half[k] = (uint32_t)(cur / 3);
+      rem = cur % 3;
+    }
+    for (int k = 0; k < H; k++)  // + 1
+      if (++half[k] != 0) break;
+  }
+  uint64_t quorum_w[ibftk::TALLY_SUM_WORDS];
+  for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) quorum_w[i] = (uint64_t)half[2 * i] | ((uint64_t)half[2 * i + 1] << 32);
   int rc;
   if ((rc = upload(c, c->d_vtab, tab.data(), tab.size() * 4))) return rc;
-  if ((rc = upload(c, c->d_vpower, pw.data(), pw.size() * 8))) return rc;
+  if ((rc = upload(c, c->d_vpower, pwv.data(), pwv.size() * 8))) return rc;
+  if ((rc = upload(c, c->d_quorum, quorum_w, sizeof quorum_w))) return rc;
+  const size_t seen_bytes = ((nv + 31) / 32) * 4;
+  if (seen_bytes > c->d_seen.cap) {  // the tally keeps the bitmap zeroed between launches: zero it when it is (re)allocated
+    if ((rc = ensure(c, c->d_seen, seen_bytes))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_seen.p, 0, c->d_seen.cap, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // warm-path cache: kept when the address list is unchanged, rebuilt otherwise
   const bool same_set = c->valset_addrs.size() == n * 20 && (n == 0 || memcmp(c->valset_addrs.data(), addrs20, n * 20) == 0);
   if ((c->flags & IBFT_FLAG_PUBKEY_CACHE) && !(same_set && c->cache_on)) {
     c->cache_on = false;
     c->learned_seen = 0;
-    const size_t nv = pw.size();
     const size_t qbytes = nv * ibftk::QTAB_DWORDS_PER_VALIDATOR * 4;
     size_t budget = 64ull << 30;
     if (const char *e = getenv("IBFT_QTAB_BUDGET_GB")) budget = (size_t)strtoull(e, nullptr, 10) << 30;
@@ -543,10 +805,46 @@ int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, co
   }
   c->valset_addrs.assign(addrs20, addrs20 + n * 20);
   c->vslot_mask = slots - 1;
-  c->n_validators = (uint32_t)pw.size();
-  c->quorum = (total * 2) / 3 + 1;  // calculateQuorum, validator_manager.go:130-135
+  c->n_validators = (uint32_t)nv;
+  c->power_words = pw;
+  memcpy(c->quorum_w, quorum_w, sizeof quorum_w);
   c->height = height;
   c->have_valset = true;
+  return IBFT_OK;
+}
+
+int ibft_set_validators(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n) {
+  if (!c || (n && (!addrs20 || !power)) || n > (1u << 20)) return IBFT_E_INVAL;
+  return set_validators_impl(c, height, addrs20, power, 1, n);
+}
+
+int ibft_set_validators_u256(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint8_t *power_be32, size_t n) {
+  if (!c || (n && (!addrs20 || !power_be32)) || n > (1u << 20)) return IBFT_E_INVAL;
+  std::vector<uint64_t> words(n * 4);  // big.Int.FillBytes(32) → four little-endian words
+  for (size_t i = 0; i < n; i++)
+    for (int w = 0; w < 4; w++) {
+      uint64_t v = 0;
+      for (int b = 0; b < 8; b++) v = (v << 8) | power_be32[32 * i + 8 * (3 - w) + b];
+      words[4 * i + w] = v;
+    }
+  return set_validators_impl(c, height, addrs20, words.data(), 4, n);
+}
+
+int ibft_last_tally_wide(ibft_ctx *c, ibft_tally_wide_t *out) {
+  if (!c || !out) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  memset(out, 0, sizeof *out);
+  for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) {
+    out->quorum[i] = c->quorum_w[i];
+    out->power[i] = c->last_wide[i];
+  }
+  bool ge = true;
+  for (int i = ibftk::TALLY_SUM_WORDS - 1; i >= 0; i--)
+    if (out->power[i] != out->quorum[i]) {
+      ge = out->power[i] > out->quorum[i];
+      break;
+    }
+  out->has_quorum = ge ? 1 : 0;
   return IBFT_OK;
 }
 
@@ -672,9 +970,9 @@ int ibft_seals_export_on(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst, void 
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t cs = (hipStream_t)consumer_stream;
-  if (!c->ev_ready) {
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming));
+  {
+    int rce = ensure_handoff_events(c);
+    if (rce) return rce;
   }
   HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));  // everything launched so far, the tally included
   HIPCHK(c, hipStreamWaitEvent(cs, c->ev_ready, 0));
@@ -840,6 +1138,175 @@ int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_
   }
   if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
   return fetch_results(c, (uint32_t)n, nullptr, tally, true);
+}
+
+
+/* ---- multi-GPU: validator shards + one RCCL all-reduce of verdict words and tally partials ---- */
+int ibft_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) {
+  if (!world || rank >= world || !lo || !hi) return IBFT_E_INVAL;
+  const uint64_t per = shard_rows_per_rank(n_total, world);
+  *lo = std::min<uint64_t>((uint64_t)rank * per, n_total);
+  *hi = std::min<uint64_t>(*lo + per, n_total);
+  return IBFT_OK;
+}
+
+int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t power_words, uint32_t *words_per_rank, uint32_t *slots) {
+  if (!world || (power_words != 1 && power_words != 4)) return IBFT_E_INVAL;
+  const uint64_t w = shard_rows_per_rank(n_total, world) / 64;
+  if (words_per_rank) *words_per_rank = (uint32_t)w;
+  if (slots) *slots = (uint32_t)(w * world + 2 * power_words + 2);
+  return IBFT_OK;
+}
+
+int ibft_comm_unique_id(uint8_t id[IBFT_COMM_ID_BYTES]) {
+  static_assert(IBFT_COMM_ID_BYTES == sizeof(ncclUniqueId), "ABI");
+  if (!id) return IBFT_E_INVAL;
+  RcclApi *api = rccl();
+  if (!api) return IBFT_E_RCCL;
+  ncclUniqueId u;
+  if (api->GetUniqueId(&u) != ncclSuccess) return IBFT_E_RCCL;
+  memcpy(id, &u, sizeof u);
+  return IBFT_OK;
+}
+
+int ibft_comm_init(ibft_ctx *c, const uint8_t id[IBFT_COMM_ID_BYTES], uint32_t rank, uint32_t world) {
+  if (!c || !id || !world || rank >= world) return IBFT_E_INVAL;
+  RcclApi *api = rccl();
+  if (!api) return IBFT_E_RCCL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->comm) return IBFT_E_INVAL;
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t comm = nullptr;
+  NCCLCHK(c, api, api->CommInitRank(&comm, (int)world, u, (int)rank));  // collective: blocks until every rank has joined
+  return comm_attach(c, comm, rank, world);
+}
+
+int ibft_comm_destroy(ibft_ctx *c) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  (void)hipSetDevice(c->device);
+  if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+  comm_release(c);
+  return IBFT_OK;
+}
+
+int ibft_seals_exchange(ibft_ctx *c, uint64_t n_total) {
+  if (!c) return IBFT_E_INVAL;
+  RcclApi *api = rccl();
+  if (!api) return IBFT_E_RCCL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  xplan x{};
+  int rc;
+  if ((rc = exchange_pre(c, n_total, x))) return rc;
+  if ((rc = exchange_collective(c, api, x))) return rc;
+  return exchange_post(c, n_total, x);
+}
+
+int ibft_seals_fetch_merged(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return fetch_merged_locked(c, out_mask, tally);
+}
+
+int ibft_group_create(const int32_t *devices, uint32_t n_dev, uint32_t flags, uint32_t max_rows_total, ibft_group **out) {
+  if (!out || !devices || !n_dev || n_dev > 64) return IBFT_E_INVAL;
+  *out = nullptr;
+  RcclApi *api = rccl();
+  if (!api) return IBFT_E_RCCL;
+  ibft_group *g = new (std::nothrow) ibft_group();
+  if (!g) return IBFT_E_NOMEM;
+  const uint64_t total = max_rows_total ? max_rows_total : (uint64_t)DEFAULT_MAX_ROWS * n_dev;
+  int rc = IBFT_OK;
+  for (uint32_t i = 0; i < n_dev && rc == IBFT_OK; i++) {
+    ibft_cfg cfg{devices[i], flags, (uint32_t)shard_rows_per_rank(total, n_dev), IBFT_KERNEL_AUTO};
+    ibft_ctx *c = nullptr;
+    rc = ibft_ctx_create(&cfg, &c);
+    if (rc == IBFT_OK) g->ctx.push_back(c);
+  }
+  if (rc == IBFT_OK) {
+    ncclUniqueId u;
+    std::vector<ncclComm_t> comms(n_dev, nullptr);
+    // one thread initialises every rank: the calls only complete inside the group (ncclCommInitRank's contract)
+    bool ok = api->GetUniqueId(&u) == ncclSuccess && api->GroupStart() == ncclSuccess;
+    for (uint32_t i = 0; ok && i < n_dev; i++)
+      ok = hipSetDevice(devices[i]) == hipSuccess && api->CommInitRank(&comms[i], (int)n_dev, u, (int)i) == ncclSuccess;
+    ok = api->GroupEnd() == ncclSuccess && ok;
+    for (uint32_t i = 0; ok && i < n_dev; i++) ok = comm_attach(g->ctx[i], comms[i], i, n_dev) == IBFT_OK;
+    if (!ok) rc = IBFT_E_RCCL;
+  }
+  if (rc != IBFT_OK) {
+    ibft_group_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return IBFT_OK;
+}
+
+void ibft_group_destroy(ibft_group *g) {
+  if (!g) return;
+  for (ibft_ctx *c : g->ctx) ibft_ctx_destroy(c);
+  delete g;
+}
+
+uint32_t ibft_group_size(const ibft_group *g) { return g ? (uint32_t)g->ctx.size() : 0; }
+ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i) { return (g && i < g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+int ibft_group_set_validators(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n) {
+  if (!g) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (ibft_ctx *c : g->ctx) {  // the validator table is replicated on every device (28 B per validator)
+    const int rc = ibft_set_validators(c, height, addrs20, power, n);
+    if (rc) return rc;
+  }
+  return IBFT_OK;
+}
+
+int ibft_group_set_validators_u256(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint8_t *power_be32, size_t n) {
+  if (!g) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (ibft_ctx *c : g->ctx) {
+    const int rc = ibft_set_validators_u256(c, height, addrs20, power_be32, n);
+    if (rc) return rc;
+  }
+  return IBFT_OK;
+}
+
+int ibft_group_verify_seals(ibft_group *g, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                            const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (!g || (n && (!hash32 || !sig65 || !signer20 || !out_mask))) return IBFT_E_INVAL;
+  RcclApi *api = rccl();
+  if (!api) return IBFT_E_RCCL;
+  std::lock_guard<std::mutex> lk(g->mu);
+  const uint32_t world = (uint32_t)g->ctx.size();
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (ibft_ctx *c : g->ctx) locks.emplace_back(c->mu);
+  int rc;
+  // every device verifies its own 64-aligned row range: stage, verdict kernel, tally — all asynchronous past the upload
+  for (uint32_t i = 0; i < world; i++) {
+    ibft_ctx *c = g->ctx[i];
+    if (!c->have_valset) return IBFT_E_NOVALSET;
+    uint64_t lo, hi;
+    (void)ibft_shard_range(n, i, world, &lo, &hi);
+    if ((rc = seals_stage_locked(c, hash32 + 32 * lo, sig65 + 65 * lo, signer20 + 20 * lo, pre_flags ? pre_flags + lo : nullptr,
+                                 (size_t)(hi - lo))))
+      return rc;
+    if ((rc = seals_launch_locked(c, 1))) return rc;
+  }
+  // one all-reduce merges the verdict words and the tally partials (single thread: the calls go inside a group)
+  std::vector<xplan> plan(world);
+  for (uint32_t i = 0; i < world; i++)
+    if ((rc = exchange_pre(g->ctx[i], n, plan[i]))) return rc;
+  bool ok = api->GroupStart() == ncclSuccess;
+  for (uint32_t i = 0; ok && i < world; i++) ok = exchange_collective(g->ctx[i], api, plan[i]) == IBFT_OK;
+  ok = api->GroupEnd() == ncclSuccess && ok;
+  if (!ok) return IBFT_E_RCCL;
+  for (uint32_t i = 0; i < world; i++)
+    if ((rc = exchange_post(g->ctx[i], n, plan[i]))) return rc;
+  for (uint32_t i = world; i-- > 0;)  // every rank holds the merged result; device 0's copy is handed to the caller
+    if ((rc = fetch_merged_locked(g->ctx[i], i == 0 ? out_mask : nullptr, i == 0 ? tally : nullptr))) return rc;
+  return IBFT_OK;
 }
 
 }  // extern "C"

@@ -32,7 +32,14 @@ EXPORTS = [
     "ibft_verify_senders", "ibft_tally", "ibft_seals_stage", "ibft_seals_launch", "ibft_seals_fetch",
     "ibft_seals_device_ptrs", "ibft_seals_export", "ibft_last_kernel_ms", "ibft_cache_stats", "ibft_last_dispatch", "ibft_sync",
     "ibft_verify_senders_wire", "ibft_wire_stage_seals", "ibft_seals_export_on",
+    "ibft_set_validators_u256", "ibft_last_tally_wide",
+    "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
+    "ibft_seals_exchange", "ibft_seals_fetch_merged",
+    "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
+    "ibft_group_set_validators_u256", "ibft_group_verify_seals",
 ]
+COMM_ID_BYTES = 128
+E_RCCL = -8
 
 WIRE_OK, WIRE_NEEDS_HOST = 0, 1
 # ibft_wire_row_t (include/ibftgpu.h)
@@ -64,6 +71,25 @@ class Tally(C.Structure):
     @property
     def quorum(self) -> int:
         return self.quorum_lo | (self.quorum_hi << 64)
+
+
+class TallyWide(C.Structure):
+    """ibft_tally_wide_t: full-width (320-bit) power and quorum of the last tally."""
+    _fields_ = [("quorum_w", C.c_uint64 * 5), ("power_w", C.c_uint64 * 5), ("has_quorum", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+    @property
+    def power(self) -> int:
+        return sum(int(w) << (64 * i) for i, w in enumerate(self.power_w))
+
+    @property
+    def quorum(self) -> int:
+        return sum(int(w) << (64 * i) for i, w in enumerate(self.quorum_w))
+
+
+def powers_be32(powers) -> np.ndarray:
+    """list of Python ints → n × 32 big-endian bytes (what big.Int.FillBytes(make([]byte, 32)) produces)"""
+    return np.frombuffer(b"".join(int(p).to_bytes(32, "big") for p in powers), dtype=np.uint8).reshape(-1, 32).copy()
 
 
 _lib = None
@@ -101,6 +127,22 @@ def load_library() -> C.CDLL:
     L.ibft_sync.argtypes = [vp]
     L.ibft_verify_senders_wire.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(Tally)]
     L.ibft_wire_stage_seals.argtypes = [vp]
+    L.ibft_set_validators_u256.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
+    L.ibft_last_tally_wide.argtypes = [vp, C.POINTER(TallyWide)]
+    L.ibft_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ibft_exchange_layout.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ibft_comm_unique_id.argtypes = [vp]
+    L.ibft_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.ibft_comm_destroy.argtypes = [vp]
+    L.ibft_seals_exchange.argtypes = [vp, C.c_uint64]
+    L.ibft_seals_fetch_merged.argtypes = [vp, vp, C.POINTER(Tally)]
+    L.ibft_group_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    L.ibft_group_destroy.argtypes = [vp]; L.ibft_group_destroy.restype = None
+    L.ibft_group_size.argtypes = [vp]; L.ibft_group_size.restype = C.c_uint32
+    L.ibft_group_ctx.argtypes = [vp, C.c_uint32]; L.ibft_group_ctx.restype = vp
+    L.ibft_group_set_validators.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
+    L.ibft_group_set_validators_u256.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
+    L.ibft_group_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
     _lib = L
@@ -109,6 +151,34 @@ def load_library() -> C.CDLL:
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """ibft_shard_range (pure): rows [lo, hi) of rank `rank`"""
+    lo, hi = C.c_uint64(), C.c_uint64()
+    rc = load_library().ibft_shard_range(n_total, rank, world, C.byref(lo), C.byref(hi))
+    if rc:
+        raise ValueError(f"ibft_shard_range: {rc}")
+    return lo.value, hi.value
+
+
+def exchange_layout(n_total: int, world: int, power_words: int = 1) -> tuple[int, int]:
+    """ibft_exchange_layout (pure): (verdict words per rank, u64 slots of the exchange buffer)"""
+    w, s = C.c_uint32(), C.c_uint32()
+    rc = load_library().ibft_exchange_layout(n_total, world, power_words, C.byref(w), C.byref(s))
+    if rc:
+        raise ValueError(f"ibft_exchange_layout: {rc}")
+    return w.value, s.value
+
+
+def comm_unique_id() -> bytes:
+    """ibft_comm_unique_id: rank 0 creates it and hands it to the other ranks (loads librccl)"""
+    buf = np.zeros(COMM_ID_BYTES, dtype=np.uint8)
+    L = load_library()
+    rc = L.ibft_comm_unique_id(_p(buf))
+    if rc:
+        raise GpuUnavailable(f"ibft_comm_unique_id: {L.ibft_strerror(rc).decode()} ({rc})")
+    return buf.tobytes()
 
 
 def _u8(a, shape=None):
@@ -159,6 +229,17 @@ class BatchVerifier:
         a = _u8(addrs20, (-1, 20)); p = np.ascontiguousarray(power, dtype=np.uint64)
         assert len(a) == len(p)
         self._chk(self._L.ibft_set_validators(self._h, height, _p(a), _p(p), len(p)), "ibft_set_validators")
+
+    def set_validators_u256(self, height: int, addrs20, powers) -> None:
+        """powers: Python ints < 2^256 (GetVotingPowers' *big.Int values)"""
+        a = _u8(addrs20, (-1, 20)); p = powers_be32(powers)
+        assert len(a) == len(p)
+        self._chk(self._L.ibft_set_validators_u256(self._h, height, _p(a), _p(p), len(p)), "ibft_set_validators_u256")
+
+    def last_tally_wide(self) -> TallyWide:
+        t = TallyWide()
+        self._chk(self._L.ibft_last_tally_wide(self._h, C.byref(t)), "ibft_last_tally_wide")
+        return t
 
     def try_set_validators(self, height: int, addrs20, power) -> int:
         a = _u8(addrs20, (-1, 20)); p = np.ascontiguousarray(power, dtype=np.uint64)
@@ -262,6 +343,29 @@ class BatchVerifier:
         no host wait; the caller's collective overlaps with the next seals_launch"""
         self._chk(self._L.ibft_seals_export_on(self._h, d_mask_ptr, d_tally_ptr, stream), "ibft_seals_export_on")
 
+    # ---- multi-GPU: this context is one rank of a sharded batch (include/ibftgpu.h, ibft_comm_*) ----
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        assert len(uid) == COMM_ID_BYTES
+        self._chk(self._L.ibft_comm_init(self._h, _p(uid), rank, world), "ibft_comm_init")
+
+    def comm_destroy(self) -> None:
+        self._chk(self._L.ibft_comm_destroy(self._h), "ibft_comm_destroy")
+
+    def seals_exchange(self, n_total: int) -> None:
+        """enqueue pack + RCCL all-reduce + delivery of the merged result behind the last seals_launch"""
+        self._chk(self._L.ibft_seals_exchange(self._h, n_total), "ibft_seals_exchange")
+        self._xq = getattr(self, "_xq", [])
+        self._xq.append(n_total)
+
+    def seals_fetch_merged(self):
+        """oldest outstanding exchange → (global verdict bool[n_total], merged Tally)"""
+        n_total = self._xq.pop(0)
+        mask = np.zeros((n_total + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_seals_fetch_merged(self._h, _p(mask), C.byref(t)), "ibft_seals_fetch_merged")
+        return mask_to_bool(mask, n_total), t
+
     def last_kernel_ms(self):
         ms, k = C.c_float(), C.c_uint32()
         self._chk(self._L.ibft_last_kernel_ms(self._h, C.byref(ms), C.byref(k)), "ibft_last_kernel_ms")
@@ -282,3 +386,56 @@ class BatchVerifier:
 
     def sync(self):
         self._chk(self._L.ibft_sync(self._h), "ibft_sync")
+
+
+class DeviceGroup:
+    """ibft_group: one process, several MI355X — rows sharded over the devices, one RCCL all-reduce inside
+    the library merges verdict words and tally partials (what a Go Backend would call for N beyond one GPU)."""
+
+    def __init__(self, devices, flags: int = 0, max_rows_total: int = 0):
+        self._L = load_library()
+        self._g = C.c_void_p()
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self._L.ibft_group_create(_p(dv), len(dv), flags, max_rows_total, C.byref(self._g))
+        if rc != 0:
+            self._g = C.c_void_p()
+            raise GpuUnavailable(f"ibft_group_create: {self._L.ibft_strerror(rc).decode()} ({rc})")
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self._L.ibft_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._L.ibft_strerror(rc).decode()} ({rc})")
+
+    @property
+    def size(self) -> int:
+        return self._L.ibft_group_size(self._g)
+
+    def set_validators(self, height: int, addrs20, power) -> None:
+        a = _u8(addrs20, (-1, 20)); p = np.ascontiguousarray(power, dtype=np.uint64)
+        self._chk(self._L.ibft_group_set_validators(self._g, height, _p(a), _p(p), len(p)), "ibft_group_set_validators")
+
+    def set_validators_u256(self, height: int, addrs20, powers) -> None:
+        a = _u8(addrs20, (-1, 20)); p = powers_be32(powers)
+        self._chk(self._L.ibft_group_set_validators_u256(self._g, height, _p(a), _p(p), len(p)),
+                  "ibft_group_set_validators_u256")
+
+    def is_valid_committed_seal(self, hash32, sig65, signer20, pre_flags=None):
+        h = _u8(hash32, (-1, 32)); s = _u8(sig65, (-1, 65)); f = _u8(signer20, (-1, 20))
+        n = len(s)
+        pre = None if pre_flags is None else _u8(pre_flags)
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_group_verify_seals(self._g, _p(h), _p(s), _p(f), _p(pre), n, _p(mask), C.byref(t)),
+                  "ibft_group_verify_seals")
+        return mask_to_bool(mask, n), t
+
+    def last_tally_wide(self) -> TallyWide:
+        t = TallyWide()
+        self._chk(self._L.ibft_last_tally_wide(self._L.ibft_group_ctx(self._g, 0), C.byref(t)), "ibft_last_tally_wide")
+        return t

@@ -31,6 +31,11 @@
  *   proposalHash itself;  sender digest = keccak256(PayloadNoSig)
  *   (/root/reference/messages/proto/helper.go:12-27);  signature = 65 B r‖s‖v with
  *   r,s big-endian in [1,n-1] and v∈{0,1};  address = keccak256(X‖Y)[12:32].
+ *   Recovery-id policy: v is the parity of R.y and nothing else — R.x = r always.  The second candidate
+ *   of SEC 1 §4.1.6 (R.x = r + n, possible only for r < p − n ≈ 2^128.4, i.e. with probability ≈ 2^−127.6,
+ *   recovery ids 2 and 3) is NEVER tried: v ∈ {2,3} (and every other value) is rejected by every kernel
+ *   variant, cold and warm, exactly as go-ethereum's crypto.Ecrecover / the precompile reject it for a
+ *   65-byte [R‖S‖V] input with V > 1.  High-s signatures are accepted unless IBFT_FLAG_STRICT_LOW_S.
  *
  * Verdict masks: bit i of out_mask[i/64] is row i's verdict (1 = the reference
  * predicate would return true).  Rows the host already knows to be structurally
@@ -65,6 +70,7 @@ extern "C" {
 #define IBFT_E_NOVALSET (-5)  /* ibft_set_validators has not succeeded yet       */
 #define IBFT_E_POWER (-6)     /* total voting power is zero (errVotingPowerNotCorrect) */
 #define IBFT_E_TOOBIG (-7)    /* batch larger than cfg.max_rows                  */
+#define IBFT_E_RCCL (-8)      /* librccl could not be loaded, or a collective / communicator call failed */
 
 /* cfg.flags */
 #define IBFT_FLAG_STRICT_LOW_S 1u /* also reject s > n/2 (off: go-ethereum Ecrecover semantics) */
@@ -123,10 +129,26 @@ void ibft_ctx_destroy(ibft_ctx *ctx);
 
 /* Replace the validator table (addresses n×20, powers n×u64) for `height`.
  * Builds the device-side open-addressing table used for set membership and the
- * weighted tally.  Powers are u64 here; a set whose powers do not fit must keep
- * using the host big.Int path (validator_manager.go:19 uses *big.Int).            */
+ * weighted tally.  Powers are u64 here (128-bit sums); a set whose powers do not fit
+ * uses ibft_set_validators_u256 (validator_manager.go:19 uses *big.Int).           */
 int ibft_set_validators(ibft_ctx *ctx, uint64_t height, const uint8_t *addrs20,
                         const uint64_t *power, size_t n);
+
+/* The same with arbitrary-precision powers: ValidatorBackend.GetVotingPowers returns map[string]*big.Int
+ * (/root/reference/core/validator_manager.go:17-31) and a stake-weighted set (wei-denominated) exceeds 2^64
+ * with ~19 tokens.  power_be32 is n × 32 bytes, each a big-endian 256-bit integer (big.Int.FillBytes of a
+ * 32-byte slice); a power that does not fit 256 bits cannot be passed (keep such a set on the Go path).
+ * Sums and the quorum ⌊2·total/3⌋+1 are kept in 320 bits; ibft_tally_t then carries the LOW 128 bits of power
+ * and quorum and the exact has_quorum flag — ibft_last_tally_wide returns the full-width numbers.          */
+int ibft_set_validators_u256(ibft_ctx *ctx, uint64_t height, const uint8_t *addrs20,
+                             const uint8_t *power_be32, size_t n);
+typedef struct {
+  uint64_t quorum[5];        /* little-endian 64-bit words                                     */
+  uint64_t power[5];         /* Σ power over distinct valid member senders of the last tally    */
+  uint32_t has_quorum, reserved;
+} ibft_tally_wide_t;
+/* full-width result of the last tally this context delivered (verify / fetch / fetch_merged call)  */
+int ibft_last_tally_wide(ibft_ctx *ctx, ibft_tally_wide_t *out);
 
 /* a1.  raw/raw_len/round: the proposal all rows are checked against.  hash32 is
  * n×32 (zero-filled where absent), hash_len[i] the real byte length (0 = nil).    */
@@ -226,6 +248,52 @@ int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uin
 int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);
 /* Block the host until the context's stream is idle.                               */
 int ibft_sync(ibft_ctx *ctx);
+
+/* ---- multi-GPU (BASELINE configs #4 / #5) -------------------------------------------
+ * Rows are independent, so a batch of n_total rows is split into `world` contiguous row ranges whose
+ * length is a multiple of 64 (every 64-bit verdict word is owned by one rank; the last rank takes the
+ * remainder): rank k verifies rows [lo, hi) of ibft_shard_range on its own device, with the validator
+ * table replicated (ibft_set_validators on every context).  The one exchange step the north star names —
+ * "RCCL all-reduce over xGMI of the per-message valid-bitmask" — happens INSIDE this library:
+ * ncclAllReduce(sum, u64) over [verdict words of every shard | 32-bit pieces of the partial voting power |
+ * valid rows | distinct senders] (disjoint shards: sum ≡ OR; 32-bit pieces in 64-bit slots: no carry is
+ * lost), then has_quorum is recomputed from the merged power.  librccl is dlopen()ed on first use
+ * (IBFT_RCCL_LIB overrides the name), so single-GPU users never need it.  A sender is assumed to appear in
+ * one shard only (the store is keyed by sender, /root/reference/messages/messages.go:64).
+ *
+ * Two ways to drive it:
+ *  (1) one process, all GPUs — what a Go Backend would call: ibft_group_create + ibft_group_verify_seals;
+ *  (2) one process (or thread) per GPU: every rank creates its context, rank 0 calls ibft_comm_unique_id and
+ *      hands the 128 bytes to the others (any side channel), everybody calls ibft_comm_init (collective);
+ *      per batch: ibft_seals_stage + ibft_seals_launch on the rank's shard, ibft_seals_exchange (asynchronous:
+ *      runs on its own stream behind the tally, so it overlaps with the next ibft_seals_launch; at most two
+ *      exchanges in flight), ibft_seals_fetch_merged (oldest exchange first) → global mask + merged tally.  */
+#define IBFT_COMM_ID_BYTES 128
+int ibft_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi); /* pure */
+/* u64 slots of the exchange buffer and verdict words per rank (pure; power_words = 1 for u64 powers, 4 for u256) */
+int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t power_words, uint32_t *words_per_rank,
+                         uint32_t *slots);
+int ibft_comm_unique_id(uint8_t id[IBFT_COMM_ID_BYTES]);
+int ibft_comm_init(ibft_ctx *ctx, const uint8_t id[IBFT_COMM_ID_BYTES], uint32_t rank, uint32_t world);
+int ibft_comm_destroy(ibft_ctx *ctx);
+int ibft_seals_exchange(ibft_ctx *ctx, uint64_t n_total);
+/* out_mask: ⌈n_total/64⌉ words (bit g = verdict of global row g); either pointer may be NULL */
+int ibft_seals_fetch_merged(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
+
+typedef struct ibft_group ibft_group;
+/* one context per listed device + one communicator over them; max_rows_total = largest n (0 = 65536 per device) */
+int ibft_group_create(const int32_t *devices, uint32_t n_devices, uint32_t flags, uint32_t max_rows_total,
+                      ibft_group **out);
+void ibft_group_destroy(ibft_group *g);
+uint32_t ibft_group_size(const ibft_group *g);
+ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i); /* the i-th device's context (diagnostics, ibft_last_tally_wide) */
+int ibft_group_set_validators(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n);
+int ibft_group_set_validators_u256(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint8_t *power_be32,
+                                   size_t n);
+/* IsValidCommittedSeal + HasQuorum for n rows sharded over the group's devices: same arguments and results as
+ * ibft_verify_seals, out_mask / tally are the merged (global) ones.                                         */
+int ibft_group_verify_seals(ibft_group *g, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                            const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally);
 
 #ifdef __cplusplus
 }
