@@ -236,6 +236,8 @@ def main():
 
     import torch
     import go_ibft_amd.verifier as V
+    # one RCCL per process: the library dlopen()s librccl on first use — point it at the copy torch has loaded
+    os.environ.setdefault("IBFT_RCCL_LIB", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -439,13 +441,18 @@ def main():
         except Exception as e:  # noqa: BLE001 — the extra leg must never take the headline line down
             if rank == 0:
                 rec["config5"] = {"error": repr(e)}
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            rd = main_leg["rd"]
-            rec["cpu_baseline"] = cpu_baseline(rd["addrs"], rd["power"], rd["hash32"], rd["seal65"], rd["signer20"])
-        print(json.dumps(rec), flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        rd = main_leg["rd"]
+        rec["cpu_baseline"] = cpu_baseline(rd["addrs"], rd["power"], rd["hash32"], rd["seal65"], rd["signer20"])
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio (block-buffered on a pipe): push it out first so that
+        # the JSON line is the LAST thing on stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":

@@ -308,3 +308,51 @@ extern "C" int devtest_rows_stage_ms(int n, const uint8_t *dig, const uint8_t *s
   (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
   return rc;
 }
+
+// instruction-fetch experiment: the same wavefront runs the whole recover `reps` times (on different rows), so every
+// pass after the first finds the kernel's code in the instruction cache: t(2) − t(1) = one pass with warm code
+__global__ void __launch_bounds__(256) devtest_rows_repeat_kernel(const uint32_t *gtab, const uint8_t *dig, const uint8_t *sig65,
+                                                                uint32_t n, int reps, uint8_t *out) {
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (wave * 4u >= n) return;
+  uint32_t acc[5] = {0, 0, 0, 0, 0};
+  bool ok_all = true;
+#pragma unroll 1
+  for (int rep = 0; rep < reps; rep++) {
+    const uint32_t row_raw = (wave * 4u + (lane >> 4) + (uint32_t)rep * 64u) % n;
+    uint32_t addr[5] = {0, 0, 0, 0, 0};
+    aff Q;
+    const bool ok = wv::recover_pubkey_row<99>(gtab, from_be32(dig + 32 * row_raw), from_be32(sig65 + 65 * row_raw),
+                                           from_be32(sig65 + 65 * row_raw + 32), sig65[65 * row_raw + 64], 0, addr, Q);
+    ok_all = ok_all && ok;
+    for (int k = 0; k < 5; k++) acc[k] ^= addr[k];
+  }
+  const uint32_t i = wave * 4u + (lane >> 4);
+  if ((lane & 15u) == 0 && i < n) {
+    uint8_t *o = out + (size_t)24 * i;
+    for (int k = 0; k < 5; k++) reinterpret_cast<uint32_t *>(o)[k] = acc[k];
+    o[20] = ok_all ? 1 : 0;
+  }
+}
+extern "C" int devtest_rows_repeat_ms(int n, const uint8_t *dig, const uint8_t *sig65, int max_reps, float *ms) {
+  uint32_t *dg;
+  size_t gbytes = (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4;
+  if (hipMalloc(&dg, gbytes) != hipSuccess) return -1;
+  uint8_t *dd = dev_copy(dig, (size_t)32 * n), *ds = dev_copy(sig65, (size_t)65 * n), *dout;
+  if (!dd || !ds || hipMalloc(&dout, (size_t)24 * n) != hipSuccess) return -1;
+  devtest_gtab_kernel<<<(ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES + 63) / 64, 64>>>(dg);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int waves = (n + 3) / 4, blocks = (waves + 3) / 4;
+  for (int reps = 1; reps <= max_reps; reps++)
+    for (int t = 0; t < 3; t++) {
+      (void)hipEventRecord(e0, 0);
+      devtest_rows_repeat_kernel<<<blocks, 256>>>(dg, dd, ds, (uint32_t)n, reps, dout);
+      (void)hipEventRecord(e1, 0);
+      (void)hipEventSynchronize(e1);
+      (void)hipEventElapsedTime(&ms[reps - 1], e0, e1);
+    }
+  int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+  (void)hipFree(dd); (void)hipFree(ds); (void)hipFree(dout); (void)hipFree(dg);
+  return rc;
+}

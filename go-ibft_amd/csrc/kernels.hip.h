@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
 // (wave_fe_dev.h:recover_pubkey_row).  n = 4 096 is one wavefront per SIMD again; used for
 // 2 048 < n ≤ 8 192.  Rows beyond n recompute the last row and store nothing.
 template <int MODE>
-__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_rows_kernel(recover_args a) {
+__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) ecrecover_rows_kernel(recover_args a) {
   const uint32_t wave = blockIdx.x * WAVE_KERNEL_WAVES + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   if (wave * 4u >= a.n) return;  // whole wavefront

@@ -831,11 +831,37 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   T[6] = wjac_dbl(T[3], k);
   T[7] = wjac_add_aff(T[6], R1, k);
   T[8] = wjac_dbl(T[4], k);
+  // One common Z for the whole table ("effective affine"): with Zc = z2·z3·…·z8 and s_i = Zc / z_i, entry i is
+  // (x_i·s_i², y_i·s_i³, Zc) — the SAME Z everywhere, i.e. the affine point (x_i·s_i², y_i·s_i³) of the isomorphic
+  // curve y² = x³ + 7·Zc⁶.  The a = 0 formulas never look at the curve constant, so the main loop adds table
+  // entries with MIXED additions (11 multiplications instead of 16, 66 times) and Zc is multiplied into the
+  // accumulator's Z once, before the G additions bring it back among points of the real curve.  Prefix products
+  // forward, suffix products backward: 6 + 12 multiplications, then 4 per entry.
+  uint32_t AX[9], AY[9];
+  uint32_t Zc;
+  {
+    uint32_t pre[9];
+    pre[2] = T[2].z;
+#pragma unroll
+    for (int i = 3; i <= 7; i++) pre[i] = wfe_mul(pre[i - 1], T[i].z, k);
+    uint32_t suf = T[8].z;  // z_{i+1}·…·z8 while walking down
+#pragma unroll
+    for (int i = 8; i >= 1; i--) {
+      // s_i = (z2…z_{i-1})·(z_{i+1}…z8)
+      const uint32_t sc = i == 8 ? pre[7] : (i <= 2 ? suf : wfe_mul(pre[i - 1], suf, k));
+      const uint32_t s2 = wfe_sqr(sc, k);
+      AX[i] = wfe_mul(T[i].x, s2, k);
+      AY[i] = wfe_mul(T[i].y, wfe_mul(s2, sc, k), k);
+      if (i <= 7 && i >= 3) suf = wfe_mul(suf, T[i].z, k);  // after the step for i: suf = z_i·…·z8 (needed by i − 1)
+      if (i == 2) Zc = wfe_mul(suf, T[2].z, k);              // s_1 = z2·…·z8 = Zc: computed before the step for i = 1
+      if (i == 2) suf = Zc;
+    }
+  }
   const uint32_t beta = scatter(secp::GLV_CONST(1), k);
   uint32_t TX[9];
 #pragma unroll
-  for (int e = 1; e <= 8; e++) TX[e] = wfe_mul(T[e].x, beta, k);
-  WV_STAGE(3, T[3].x ^ T[5].y ^ T[6].z ^ T[7].x ^ T[8].y ^ TX[2] ^ TX[8] ^ u1.v[0] ^ w1[0] ^ w2[1])
+  for (int e = 1; e <= 8; e++) TX[e] = wfe_mul(AX[e], beta, k);
+  WV_STAGE(3, AX[3] ^ AY[5] ^ AX[6] ^ AX[7] ^ AY[8] ^ TX[2] ^ TX[8] ^ u1.v[0] ^ w1[0] ^ w2[1] ^ Zc)
   wjac acc = wjac_inf();
 #pragma unroll 1
   for (int jd = 32; jd >= 0; jd--) {
@@ -847,22 +873,22 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
     const int d1 = jd == 32 ? (int)(w1[4] & 1u) : n1 - 8, d2 = jd == 32 ? (int)(w2[4] & 1u) : n2 - 8;
     const uint32_t m1 = (uint32_t)(d1 < 0 ? -d1 : d1), m2 = (uint32_t)(d2 < 0 ? -d2 : d2);
-    wjac q1 = T[1], q2 = T[1];
-    uint32_t x2 = TX[1];
+    waff q1 = waff{AX[1], AY[1]}, q2 = waff{TX[1], AY[1]};
 #pragma unroll
     for (int e = 2; e <= 8; e++) {
-      q1 = wjac_select(m1 == (uint32_t)e, T[e], q1);
-      q2 = wjac_select(m2 == (uint32_t)e, T[e], q2);
-      x2 = m2 == (uint32_t)e ? TX[e] : x2;
+      q1.x = m1 == (uint32_t)e ? AX[e] : q1.x;
+      q1.y = m1 == (uint32_t)e ? AY[e] : q1.y;
+      q2.x = m2 == (uint32_t)e ? TX[e] : q2.x;
+      q2.y = m2 == (uint32_t)e ? AY[e] : q2.y;
     }
-    q2.x = x2;
     q1.y = ((d1 < 0) != sp.neg1) ? wfe_neg1(q1.y, k) : q1.y;  // magnitude ≤ 2
     q2.y = ((d2 < 0) != sp.neg2) ? wfe_neg1(q2.y, k) : q2.y;
-    const wjac s1 = wjac_add<true>(acc, q1, k);
+    const wjac s1 = wjac_add_aff<true>(acc, q1, k);
     acc = wjac_select(m1 != 0, s1, acc);
-    const wjac s2 = wjac_add<true>(acc, q2, k);
+    const wjac s2 = wjac_add_aff<true>(acc, q2, k);
     acc = wjac_select(m2 != 0, s2, acc);
   }
+  acc.z = wfe_mul(acc.z, Zc, k);  // back from the isomorphic curve (an accumulator at infinity keeps its flag)
   WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
   // u1·G: all the fixed-base windows in this row
 #pragma unroll 1

@@ -91,6 +91,6 @@ def test_bench_sharded_path_with_one_rank():
                           "--no-cpu-baseline", "--no-sequence", "--no-warm"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    rec = json.loads(out.stdout.strip().splitlines()[-1])   # the JSON line is the last thing on stdout
     assert rec["n_gpus"] == 1 and rec["config"]["validators"] == 4096 and rec["value"] > 1e5
     assert rec["roofline"]["kernel"].startswith("ecrecover_")

@@ -20,3 +20,10 @@ print(f"# recover_pubkey_row, {n} rows = {(n + 3) // 4} wavefronts")
 for nm, m in zip(names, ms):
     print(f"{nm:32s} {m:7.3f} ms   (+{m - prev:.3f})")
     prev = m
+
+# instruction-fetch share: the same wavefronts run the recover 1, 2, 3 times in ONE launch
+ms3 = (C.c_float * 3)()
+rc = L.devtest_rows_repeat_ms(n, r.hash32.tobytes(), r.seal65.tobytes(), 3, ms3)
+assert rc == 0
+print(f"# whole recover repeated inside one launch: 1x {ms3[0]:.3f} ms, 2x {ms3[1]:.3f} ms, 3x {ms3[2]:.3f} ms  ->  "
+      f"a pass with the code already in the instruction cache: {ms3[2] - ms3[1]:.3f} ms; first pass costs {ms3[0] - (ms3[2] - ms3[1]):+.3f} ms more")
