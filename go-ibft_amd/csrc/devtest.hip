@@ -274,8 +274,9 @@ __global__ void __launch_bounds__(256) devtest_rows_recover_kernel(const uint32_
   const uint32_t i = row_raw < n ? row_raw : n - 1;
   uint32_t addr[5] = {0, 0, 0, 0, 0};
   aff Q;
+  __shared__ uint32_t row_tab[4][wv::ROW_TAB_SLOTS * 64];
   bool ok = wv::recover_pubkey_row<STOP>(gtab, from_be32(dig + 32 * i), from_be32(sig65 + 65 * i), from_be32(sig65 + 65 * i + 32),
-                                   sig65[65 * i + 64], 0, addr, Q);
+                                   sig65[65 * i + 64], 0, addr, Q, row_tab[threadIdx.x >> 6]);
   if ((lane & 15u) == 0 && row_raw < n) {
     uint8_t *o = out + (size_t)24 * i;
     for (int k = 0; k < 5; k++) reinterpret_cast<uint32_t *>(o)[k] = addr[k];
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(256) devtest_rows_recover_kernel(const uint32_
   }
 }
 // ms per launch of n rows cut short after stage 1..6 and complete; out24 (n × 24 B) = addresses + ok of the complete run
+// ms7: 9 floats — stages 1, 2, 3, 4, 5, 6, complete, then the sub-stages 21 (r^-1 alone) and 22 (+ u1, u2)
 extern "C" int devtest_rows_stage_ms(int n, const uint8_t *dig, const uint8_t *sig65, float *ms7, uint8_t *out24) {
   uint32_t *dg;
   size_t gbytes = (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4;
@@ -301,7 +303,7 @@ extern "C" int devtest_rows_stage_ms(int n, const uint8_t *dig, const uint8_t *s
     (void)hipEventSynchronize(e1);                                                     \
     (void)hipEventElapsedTime(&ms7[idx], e0, e1);                                      \
   }
-  STAGE_RUN(0, 1) STAGE_RUN(1, 2) STAGE_RUN(2, 3) STAGE_RUN(3, 4) STAGE_RUN(4, 5) STAGE_RUN(5, 6) STAGE_RUN(6, 99)
+  STAGE_RUN(0, 1) STAGE_RUN(7, 21) STAGE_RUN(8, 22) STAGE_RUN(1, 2) STAGE_RUN(2, 3) STAGE_RUN(3, 4) STAGE_RUN(4, 5) STAGE_RUN(5, 6) STAGE_RUN(6, 99)
 #undef STAGE_RUN
   int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
   if (out24) (void)hipMemcpy(out24, dout, (size_t)24 * n, hipMemcpyDeviceToHost);
@@ -317,13 +319,15 @@ __global__ void __launch_bounds__(256) devtest_rows_repeat_kernel(const uint32_t
   if (wave * 4u >= n) return;
   uint32_t acc[5] = {0, 0, 0, 0, 0};
   bool ok_all = true;
+  __shared__ uint32_t row_tab[4][wv::ROW_TAB_SLOTS * 64];
 #pragma unroll 1
   for (int rep = 0; rep < reps; rep++) {
     const uint32_t row_raw = (wave * 4u + (lane >> 4) + (uint32_t)rep * 64u) % n;
     uint32_t addr[5] = {0, 0, 0, 0, 0};
     aff Q;
     const bool ok = wv::recover_pubkey_row<99>(gtab, from_be32(dig + 32 * row_raw), from_be32(sig65 + 65 * row_raw),
-                                           from_be32(sig65 + 65 * row_raw + 32), sig65[65 * row_raw + 64], 0, addr, Q);
+                                           from_be32(sig65 + 65 * row_raw + 32), sig65[65 * row_raw + 64], 0, addr, Q,
+                                           row_tab[threadIdx.x >> 6]);
     ok_all = ok_all && ok;
     for (int k = 0; k < 5; k++) acc[k] ^= addr[k];
   }

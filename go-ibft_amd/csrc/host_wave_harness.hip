@@ -124,7 +124,8 @@ void lane_rec4(void *vp) {
   u256 z = secp::from_be32(h), r = secp::from_be32(sg), s = secp::from_be32(sg + 32);
   uint32_t a[5];
   secp::aff Q;
-  bool ok = wv::recover_pubkey_row(g_gtab.data(), z, r, s, sg[64], 0, a, Q);
+  static uint32_t wtab[wv::ROW_TAB_SLOTS * 64];  // one emulated wavefront at a time; a lane touches only its own column
+  bool ok = wv::recover_pubkey_row(g_gtab.data(), z, r, s, sg[64], 0, a, Q, wtab);
   memcpy(j->addr20 + 20 * l, a, 20);
   j->ok[l] = ok ? 1 : 0;
 }

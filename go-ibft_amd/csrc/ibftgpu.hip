@@ -367,10 +367,21 @@ int enqueue_tally(ibft_ctx *c, uint32_t n) {
   t.host_mask = c->dh_mask;
   t.host_tally = c->dh_tally;
   const dim3 grid(std::max(1u, (n + ibftk::TALLY_ROWS_PER_BLOCK - 1) / ibftk::TALLY_ROWS_PER_BLOCK)), block(ibftk::TALLY_THREADS);
-  if (c->power_words == 1)
-    hipLaunchKernelGGL(ibftk::tally_kernel<1>, grid, block, 0, c->stream, t);
-  else
-    hipLaunchKernelGGL(ibftk::tally_kernel<4>, grid, block, 0, c->stream, t);
+  // one workgroup (n ≤ 4 096) keeps the distinct-sender bitmap in LDS — no global atomics on the latency-critical
+  // sizes; beyond (or when the bitmap does not fit 32 KiB of dynamic LDS) the device-scope bitmap + ticket form
+  const size_t lds = (size_t)((c->n_validators + 31) / 32) * 4;
+  const bool single = grid.x == 1 && lds <= 32768;
+  if (single) {
+    if (c->power_words == 1)
+      hipLaunchKernelGGL((ibftk::tally_kernel<1, false>), grid, block, lds, c->stream, t);
+    else
+      hipLaunchKernelGGL((ibftk::tally_kernel<4, false>), grid, block, lds, c->stream, t);
+  } else {
+    if (c->power_words == 1)
+      hipLaunchKernelGGL((ibftk::tally_kernel<1, true>), grid, block, 0, c->stream, t);
+    else
+      hipLaunchKernelGGL((ibftk::tally_kernel<4, true>), grid, block, 0, c->stream, t);
+  }
   HIPCHK(c, hipGetLastError());
   c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally
   if ((uint32_t)mask_words(n) >= c->mask_dirty_words) c->mask_dirty_words = 0;  // ... and it zeroed every word that held bits
@@ -921,7 +932,7 @@ int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, c
 static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
-  c->ev_used = 0;
+  if (c->ev_used >= 4096) c->ev_used = 0;  // event pairs accumulate until ibft_last_kernel_ms reads (and resets) them
   if (repeat == 0) repeat = 1;
   for (uint32_t k = 0; k < repeat; k++) {
     int rc;
@@ -941,6 +952,14 @@ int ibft_seals_fetch(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
+  return fetch_results(c, c->staged_n, out_mask, tally, true);
+}
+
+int ibft_seals_run(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  int rc = seals_launch_locked(c, 1);
+  if (rc) return rc;
   return fetch_results(c, c->staged_n, out_mask, tally, true);
 }
 
@@ -997,6 +1016,7 @@ int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
   }
   *ms = total;
   if (launches) *launches = c->ev_used;
+  c->ev_used = 0;
   return IBFT_OK;
 }
 

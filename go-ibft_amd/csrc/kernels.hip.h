@@ -554,8 +554,14 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
 // ---- cold path, SIXTEEN LANES PER SIGNATURE: every row of a wavefront recovers its own signature ------
 // (wave_fe_dev.h:recover_pubkey_row).  n = 4 096 is one wavefront per SIMD again; used for
 // 2 048 < n ≤ 8 192.  Rows beyond n recompute the last row and store nothing.
+// waves_per_eu(1, 2): the scheduler may spend registers (up to 256) on interleaving the independent
+// multiplications of a doubling — 42 → 9 s_nop per doubling in the main loop, 0.474 → 0.470 ms at 4 096 rows
+// (profiles/r02c_sweeps.txt) — while two wavefronts per SIMD (8 192 rows) still fit.
+#ifndef IBFT_ROWS_WAVES_PER_EU_ATTR
+#define IBFT_ROWS_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
+#endif
 template <int MODE>
-__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) ecrecover_rows_kernel(recover_args a) {
+__global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) IBFT_ROWS_WAVES_PER_EU_ATTR ecrecover_rows_kernel(recover_args a) {
   const uint32_t wave = blockIdx.x * WAVE_KERNEL_WAVES + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   if (wave * 4u >= a.n) return;  // whole wavefront
@@ -584,7 +590,8 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) __attribute__((amdgpu_
   }
   uint32_t got[5];
   aff Qa;
-  bool ok = wv::recover_pubkey_row(a.gtab, z, r, s, v, a.flags, got, Qa);
+  __shared__ uint32_t row_tab[WAVE_KERNEL_WAVES][wv::ROW_TAB_SLOTS * 64];  // the window tables: wave-private LDS
+  bool ok = wv::recover_pubkey_row(a.gtab, z, r, s, v, a.flags, got, Qa, row_tab[threadIdx.x >> 6]);
   ok = ok && need && !pre && vi >= 0;
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
@@ -702,15 +709,30 @@ struct tally_args {
   uint64_t *host_mask, *host_tally;  // mapped pinned host memory (or null): no device-to-host copy commands
 };
 
-template <int PW>
+// MULTI = false: ONE workgroup (n ≤ TALLY_ROWS_PER_BLOCK, the latency-critical sizes): the distinct-sender set is
+// a bitmap in LDS (dynamic: ⌈n_validators/32⌉ words) and nothing leaves the workgroup before the result — no
+// global atomics, no ticket.  MULTI = true: the bitmap lives in HBM (device-scope atomicOr), workgroups add their
+// 32-bit pieces with device-scope atomicAdd and the one that draws the last ticket finishes.
+template <int PW, bool MULTI>
 __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   constexpr int NP = 2 * PW;
+  constexpr int RPT = TALLY_ROWS_PER_BLOCK / TALLY_THREADS;
+  extern __shared__ uint32_t lseen[];  // MULTI = false only
   __shared__ uint64_t wds[TALLY_ROWS_PER_BLOCK / 64];
   __shared__ uint64_t part[NP + 1][TALLY_THREADS / 64];
   __shared__ uint32_t last_flag;
   const uint32_t tid = threadIdx.x;
   const uint32_t row0 = blockIdx.x * (uint32_t)TALLY_ROWS_PER_BLOCK;
   const uint32_t total_words = (a.n + 63) / 64;
+  // Two dependent memory round trips instead of four: the validator index of every row of this thread is loaded
+  // together with the verdict words, the voting powers right behind them — both speculatively (rows without a
+  // verdict bit and repeated senders simply do not use what was loaded).
+  int vi[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; j++) {
+    const uint32_t row = row0 + (uint32_t)j * TALLY_THREADS + tid;
+    vi[j] = row < a.n ? a.vidx[row] : -1;
+  }
   // The verdict kernels accumulate into work_mask (atomicOr / ballot words).  The tally CONSUMES it: the words
   // move to `mask`, to host_mask when given, and work_mask is left zeroed for the next launch.
   if (tid < TALLY_ROWS_PER_BLOCK / 64) {
@@ -724,24 +746,38 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     }
     wds[tid] = w;
   }
+  if (!MULTI)
+    for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS) lseen[i] = 0;
+  uint32_t pw[RPT][NP];
+#pragma unroll
+  for (int j = 0; j < RPT; j++)
+#pragma unroll
+    for (int k = 0; k < NP; k++) pw[j][k] = vi[j] >= 0 ? a.vpower32[(size_t)vi[j] * NP + k] : 0u;
   __syncthreads();
+  bool first[RPT];
+  uint64_t valid = 0, distinct = 0;
+#pragma unroll
+  for (int j = 0; j < RPT; j++) {
+    const uint32_t lr = (uint32_t)j * TALLY_THREADS + tid;
+    const bool bit = row0 + lr < a.n && ((wds[lr >> 6] >> (lr & 63)) & 1ull);
+    valid += bit;
+    first[j] = false;
+    if (bit && vi[j] >= 0) {  // unknown senders contribute 0 (validator_manager.go:88-92)
+      const uint32_t m = 1u << (vi[j] & 31);
+      const uint32_t old = MULTI ? atomicOr(&a.seen[vi[j] >> 5], m)    // device scope: one set for all workgroups
+                                 : atomicOr(&lseen[vi[j] >> 5], m);
+      first[j] = !(old & m);  // distinct-sender set (validator_manager.go:147-155)
+    }
+  }
   uint64_t p[NP];
 #pragma unroll
   for (int k = 0; k < NP; k++) p[k] = 0;
-  uint64_t valid = 0, distinct = 0;
 #pragma unroll
-  for (int j = 0; j < TALLY_ROWS_PER_BLOCK / TALLY_THREADS; j++) {
-    const uint32_t lr = (uint32_t)j * TALLY_THREADS + tid, row = row0 + lr;
-    if (row >= a.n || !((wds[lr >> 6] >> (lr & 63)) & 1ull)) continue;
-    valid++;
-    const int vi = a.vidx[row];
-    if (vi < 0) continue;  // unknown senders contribute 0 (validator_manager.go:88-92)
-    const uint32_t m = 1u << (vi & 31);
-    const uint32_t old = atomicOr(&a.seen[vi >> 5], m);  // device scope: the set is shared by all workgroups
-    if (old & m) continue;  // distinct-sender set (validator_manager.go:147-155)
+  for (int j = 0; j < RPT; j++) {
+    if (!first[j]) continue;
     distinct++;
 #pragma unroll
-    for (int k = 0; k < NP; k++) p[k] += a.vpower32[(size_t)vi * NP + k];
+    for (int k = 0; k < NP; k++) p[k] += pw[j][k];
   }
   const uint32_t wave = tid >> 6, lane = tid & 63;
 #pragma unroll
@@ -754,61 +790,75 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     if (lane == 0) part[NP][wave] = cnt;
   }
   __syncthreads();
-  if (tid <= NP) {  // thread k adds piece k (thread NP: the two counters) of this workgroup to the launch-wide sums
-    uint64_t sum = 0;
-    for (int w = 0; w < TALLY_THREADS / 64; w++) sum += part[tid][w];
-    if (tid < NP) {
-      if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + tid), (unsigned long long)sum);
-    } else {
-      if (sum & 0xFFFFFFFFull) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), (unsigned long long)(sum & 0xFFFFFFFFull));
-      if (sum >> 32) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), (unsigned long long)(sum >> 32));
+  uint64_t piece[TALLY_MAX_PIECES];
+  uint64_t v = 0, d = 0;
+  if (MULTI) {
+    if (tid <= NP) {  // thread k adds piece k (thread NP: the two counters) of this workgroup to the launch-wide sums
+      uint64_t sum = 0;
+      for (int w = 0; w < TALLY_THREADS / 64; w++) sum += part[tid][w];
+      if (tid < NP) {
+        if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + tid), (unsigned long long)sum);
+      } else {
+        if (sum & 0xFFFFFFFFull) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), (unsigned long long)(sum & 0xFFFFFFFFull));
+        if (sum >> 32) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), (unsigned long long)(sum >> 32));
+      }
+      // the adds return nothing: wait until the memory side has acknowledged them before this workgroup's ticket
+      // can be drawn (device-scope read-modify-writes are performed where they are acknowledged)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    // the adds return nothing: wait until the memory side has acknowledged them before this workgroup's ticket
-    // can be drawn (device-scope read-modify-writes are performed where they are acknowledged)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();  // the bitmap atomics returned values (awaited by their users), the adds were awaited above
-  if (tid == 0) {
-    const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 2), 1ull);
-    last_flag = (t == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  // ---- the last workgroup: every other one has added its pieces and set its bits ----
-  if (tid == 0) {
-    uint64_t piece[TALLY_MAX_PIECES];
+    __syncthreads();  // the bitmap atomics returned values (awaited by their users), the adds were awaited above
+    if (tid == 0) {
+      const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 2), 1ull);
+      last_flag = (t == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // ---- the last workgroup: every other one has added its pieces and set its bits ----
+    for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS)
+      __hip_atomic_store(a.seen + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid != 0) return;
 #pragma unroll
     for (int k = 0; k < TALLY_MAX_PIECES; k++)
       piece[k] = k < NP ? (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + k), 0ull) : 0ull;
-    const uint64_t v = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), 0ull);
-    const uint64_t d = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), 0ull);
-    uint64_t w[TALLY_SUM_WORDS];
-    pieces_to_words(piece, NP, w);
-    const uint64_t hq = words_ge(w, a.quorum) ? 1 : 0;
-    const uint64_t c = (v & 0xFFFFFFFFull) | (d << 32);
-    a.out[0] = w[0];
-    a.out[1] = w[1];
-    a.out[2] = c;
-    a.out[3] = hq;
-#pragma unroll
-    for (int i = 0; i < TALLY_SUM_WORDS; i++) a.out[TALLY_OUT_WIDE + i] = w[i];
-#pragma unroll
-    for (int k = 0; k < TALLY_MAX_PIECES; k++) a.out[TALLY_OUT_PIECES + k] = piece[k];
-    if (a.host_tally) {
-      a.host_tally[0] = w[0];
-      a.host_tally[1] = w[1];
-      a.host_tally[2] = c;
-      a.host_tally[3] = hq;
-      a.host_tally[4] = a.out[4];  // keys learned | a learned validator, written by the recover kernels
-#pragma unroll
-      for (int i = 0; i < TALLY_SUM_WORDS; i++) a.host_tally[TALLY_OUT_WIDE + i] = w[i];
-    }
+    v = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), 0ull);
+    d = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), 0ull);
 #pragma unroll
     for (int k = 0; k < TALLY_ACC_WORDS; k++)
       __hip_atomic_store(a.acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (tid != 0) return;
+#pragma unroll
+    for (int k = 0; k < TALLY_MAX_PIECES; k++) {
+      piece[k] = 0;
+      if (k < NP)
+        for (int w = 0; w < TALLY_THREADS / 64; w++) piece[k] += part[k][w];
+    }
+    uint64_t c = 0;
+    for (int w = 0; w < TALLY_THREADS / 64; w++) c += part[NP][w];
+    v = c & 0xFFFFFFFFull;
+    d = c >> 32;
   }
-  for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS)
-    __hip_atomic_store(a.seen + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t w[TALLY_SUM_WORDS];
+  pieces_to_words(piece, NP, w);
+  const uint64_t hq = words_ge(w, a.quorum) ? 1 : 0;
+  const uint64_t c = (v & 0xFFFFFFFFull) | (d << 32);
+  a.out[0] = w[0];
+  a.out[1] = w[1];
+  a.out[2] = c;
+  a.out[3] = hq;
+#pragma unroll
+  for (int i = 0; i < TALLY_SUM_WORDS; i++) a.out[TALLY_OUT_WIDE + i] = w[i];
+#pragma unroll
+  for (int k = 0; k < TALLY_MAX_PIECES; k++) a.out[TALLY_OUT_PIECES + k] = piece[k];
+  if (a.host_tally) {
+    a.host_tally[0] = w[0];
+    a.host_tally[1] = w[1];
+    a.host_tally[2] = c;
+    a.host_tally[3] = hq;
+    a.host_tally[4] = a.out[4];  // keys learned | a learned validator, written by the recover kernels
+#pragma unroll
+    for (int i = 0; i < TALLY_SUM_WORDS; i++) a.host_tally[TALLY_OUT_WIDE + i] = w[i];
+  }
 }
 
 // ---- multi-GPU: the one exchange step -------------------------------------------------

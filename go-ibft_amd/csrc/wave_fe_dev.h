@@ -415,6 +415,39 @@ WVF uint32_t wfe_sqrt_candidate(uint32_t a, const wk &k) {
   return wfe_sqr_n(t, 2, k);
 }
 
+// The same chain as ONE doubly nested loop around a single pasted multiplication: 14 segments of
+// "n squarings, then × a saved power" (the last one: two squarings).  The row-per-signature recover has no spare
+// row to hide the chain on, so it pays for every instruction of it: no call / return / argument moves per step
+// (≈15 of ≈90 instructions with the outlined multiply), and one 600-byte body instead of thirteen call sites.
+WVF uint32_t wfe_sqrt_candidate_rolled(uint32_t a, const wk &k) {
+  //                         x2 x3 x6 x9 x11 x22 x44 x88 x176 x220 x223  t   t  (2 squarings)
+  const uint8_t NSQ[14] = {1, 1, 3, 3, 2, 11, 22, 44, 88, 44, 3, 23, 6, 1};
+  uint32_t cur = a, x2 = 0, x3 = 0, x11 = 0, x22 = 0, x44 = 0, x88 = 0;
+#pragma unroll 1
+  for (int seg = 0; seg < 14; seg++) {
+    uint32_t opnd = a;                        // segments 0, 1
+    opnd = (seg == 2 || seg == 3 || seg == 10) ? x3 : opnd;
+    opnd = (seg == 4 || seg == 12) ? x2 : opnd;
+    opnd = seg == 5 ? x11 : opnd;
+    opnd = (seg == 6 || seg == 11) ? x22 : opnd;
+    opnd = (seg == 7 || seg == 9) ? x44 : opnd;
+    opnd = seg == 8 ? x88 : opnd;
+    const int nsq = NSQ[seg];
+#pragma unroll 1
+    for (int i = 0; i <= nsq; i++) {
+      const uint32_t b = (i < nsq || seg == 13) ? cur : opnd;  // wave-uniform choice
+      cur = wfe_mul<true>(cur, b, k);
+    }
+    x2 = seg == 0 ? cur : x2;
+    x3 = seg == 1 ? cur : x3;
+    x11 = seg == 4 ? cur : x11;
+    x22 = seg == 5 ? cur : x22;
+    x44 = seg == 6 ? cur : x44;
+    x88 = seg == 7 ? cur : x88;
+  }
+  return cur;
+}
+
 // ---- √ on a spare row ------------------------------------------------------------------------------
 // The a^((p+1)/4) chain (secp::fe_sqrt_candidate) is 266 dependent multiplications — but it needs
 // only ONE row.  While rows 0..2 run the 64 prefix doublings (three wfe_mul each, below), row 3
@@ -528,6 +561,42 @@ WVF void prefix_and_sqrt(uint32_t &X, uint32_t &Y, uint32_t &Z, uint32_t &root, 
 // Carries are not rippled: column c_i = lo30 + 2^30·hi gives limb_j = lo_{j+1} + hi_j, one more
 // parallel pass leaves limbs in [−4, 2^30 + 4) (top limb unmasked) — bounded, not canonical, which is
 // all the next batch needs (only f, g mod 2^30 and the sign of the top limbs of d, e are read).
+// 30 divsteps on the low words, variable time (zero runs stripped with one ctz), written so that the DPP rows of
+// a wavefront may hold DIFFERENT values (the row-per-signature recover): the add/subtract half has no branch —
+// with an if/else every row pays for both sides plus the EXEC-mask bookkeeping (r⁻¹ mod n took 0.034 ms of the
+// 0.47 ms row kernel that way) — and only the loop exit is a wave-wide vote; rows that are done idle through the
+// remaining rounds (z = 0, nothing selected).  ζ < 0: (ζ, f, g, u, v, q, r) ← (−ζ − 1, g, g − f, q, r, q − u, r − v);
+// otherwise g, q, r += f, u, v.  Same transition matrix and ζ as secp::divsteps_30 (tests/test_dev_wave_host.py).
+WVF int32_t divsteps_30_rows(int32_t zeta, uint32_t f0, uint32_t g0, secp::trans2x2 &t) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+  int i = 30;
+  for (;;) {
+    const uint32_t m = g | (1u << i);
+    const int z = __builtin_ctz(m);
+    g >>= z;
+    u <<= z;
+    v <<= z;
+    zeta -= z;
+    i -= z;
+    if (!any(i != 0)) break;
+    const uint32_t live = i != 0 ? 0xFFFFFFFFu : 0u;
+    const uint32_t c = (uint32_t)(zeta >> 31) & live;  // all ones: swap and subtract
+    const uint32_t og = g, oq = q, orr = r;
+    g += ((f ^ c) - c) & live;
+    q += ((u ^ c) - c) & live;
+    r += ((v ^ c) - c) & live;
+    f = (og & c) | (f & ~c);
+    u = (oq & c) | (u & ~c);
+    v = (orr & c) | (v & ~c);
+    zeta = (int32_t)((uint32_t)zeta ^ c);  // −ζ − 1 = ~ζ
+  }
+  t.u = (int32_t)u;
+  t.v = (int32_t)v;
+  t.q = (int32_t)q;
+  t.r = (int32_t)r;
+  return zeta;
+}
+
 template <int WITH_MOD>
 WVF int32_t modinv_wave_apply(int32_t m1, int32_t a, int32_t m2, int32_t b, int32_t mod_limb, int32_t mm, uint32_t li) {
   int64_t c = (int64_t)m1 * a + (int64_t)m2 * b;
@@ -558,7 +627,7 @@ WVF u256 modinv_wave_body(const u256 &x, bool is_p, uint32_t li) {
 #pragma unroll 1
   for (int b = 0; b < 20; b++) {
     secp::trans2x2 t;
-    zeta = secp::divsteps_30_var(zeta, row_bcast<0>((uint32_t)f), row_bcast<0>((uint32_t)g), t);
+    zeta = divsteps_30_rows(zeta, row_bcast<0>((uint32_t)f), row_bcast<0>((uint32_t)g), t);
     // (d, e) ← t·(d, e)/2^30 mod M: the multiple of M that makes it divisible (modinv_dev.h:update_de_30)
     const int32_t d0 = (int32_t)row_bcast<0>((uint32_t)d), e0 = (int32_t)row_bcast<0>((uint32_t)e);
     const int32_t sd = (int32_t)row_bcast<8>((uint32_t)d) >> 31, se = (int32_t)row_bcast<8>((uint32_t)e) >> 31;
@@ -644,6 +713,18 @@ WVF bool jac_to_aff_wave(aff &r, const jac &p, const wk &k) {
   r.x = secp::fe_normalize(secp::fe_mul(p.x, zi2));
   r.y = secp::fe_normalize(secp::fe_mul(p.y, secp::fe_mul(zi2, zi)));
   return !(p.inf || secp::fe_is_zero(p.z));
+}
+
+// The same from the row layout, multiplications included: Z⁻¹ goes back into the row and X·Z⁻², Y·Z⁻³ are four
+// wfe_mul (≈90 instructions each, and code that is hot anyway) instead of four lane-layout multiplications
+// (≈224 each, fetched for this one use).
+WVF bool wjac_to_aff(aff &r, const wjac &p, const wk &k) {
+  const fe zf = gather(p.z);
+  const uint32_t zi = scatter(secp::fe_from_u256(modinv_wave<secp::ModP>(secp::fe_to_u256(zf), k)), k);
+  const uint32_t zi2 = wfe_sqr(zi, k);
+  r.x = secp::fe_normalize(gather(wfe_mul(p.x, zi2, k)));
+  r.y = secp::fe_normalize(gather(wfe_mul(p.y, wfe_mul(zi2, zi, k), k)));
+  return !(p.inf || secp::fe_is_zero(zf));
 }
 
 // ---- the recover, one signature per wavefront -------------------------------------------------------
@@ -782,9 +863,15 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
 // Lane-layout values (r, s, z, the scalars, the digits) simply differ from row to row; the only wave-wide
 // operations are the `any` votes, which merely make every row wait for the slowest one.
 // STOP < 99 cuts the function short after a stage (devtest timing breakdown only; addr then holds junk).
+// wtab: ROW_TAB_SLOTS × 64 dwords of wave-private scratch (LDS in the kernels): element (slot, lane) at
+// wtab[slot·64 + lane]; a lane only ever touches its own column, so no barrier is involved.
+#ifndef IBFT_ROWS_VARIANT
+#define IBFT_ROWS_VARIANT 2  // 1: table in registers, straight-line build (kept for A/B timing); 2: table in LDS, rolled loops
+#endif
+constexpr int ROW_TAB_SLOTS = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products
 template <int STOP = 99>
 WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
-                           uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa) {
+                           uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa, uint32_t *wtab) {
 #define WV_STAGE(n, keep)     \
   if (STOP == (n)) {          \
     addr[0] = (keep);         \
@@ -796,7 +883,7 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   const uint32_t x = scatter(rx, k);
   const uint32_t one = k.li == 0 ? 1u : 0u;
   const uint32_t rhs = wfe_mul(wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u);  // magnitude 2
-  const uint32_t yc = wfe_sqrt_candidate(rhs, k);
+  const uint32_t yc = wfe_sqrt_candidate_rolled(rhs, k);
   const bool on_curve = wfe_is_zero(wfe_sqr(yc, k) + wfe_neg2(rhs, k));  // cross-lane: every row evaluates it
   ok = ok && on_curve;
   fe y = secp::fe_normalize(gather(yc));
@@ -804,8 +891,10 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   WV_STAGE(1, y.n[0] ^ y.n[3])
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
   const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
+  WV_STAGE(21, y.n[0] ^ rinv.n[0] ^ rinv.n[9])
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+  WV_STAGE(22, y.n[0] ^ u1.v[0] ^ u2.v[3])
   const secp::glv_split sp = secp::sc_split_lambda(u2);
   WV_STAGE(2, y.n[0] ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
   // signed radix-16 digits of |k1|, |k2|: k + 0x88…8 has nibbles d_j + 8, bit 128 is digit 32
@@ -820,6 +909,7 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     w1[4] = c1;
     w2[4] = c2;
   }
+#if IBFT_ROWS_VARIANT == 1
   // tables 1..8 of R (affine start: mixed additions) and, through X·β, of λR
   const waff R1 = waff{x, scatter(y, k)};
   wjac T[9];
@@ -888,6 +978,89 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     const wjac s2 = wjac_add_aff<true>(acc, q2, k);
     acc = wjac_select(m2 != 0, s2, acc);
   }
+#else
+  // Tables 1..8 of R (affine start: mixed additions) and, through X·β, of λR — in wave-private LDS, built and
+  // brought to ONE common Z by rolled loops: code that runs once per signature is fetched, not executed
+  // (profiles/r02c_rows_stage_ms.txt: the same arithmetic written straight-line cost 0.05 ms of instruction-cache
+  // misses per launch), so every loop body below appears once.
+  //   "Effective affine": with Zc = z2·z3·…·z8 and s_i = Zc / z_i, entry i is (x_i·s_i², y_i·s_i³, Zc) — the affine
+  //   point (x_i·s_i², y_i·s_i³) of the isomorphic curve y² = x³ + 7·Zc⁶.  The a = 0 formulas never look at the
+  //   curve constant, so the main loop adds table entries with MIXED additions (11 multiplications instead of 16,
+  //   66 times) and Zc is multiplied into the accumulator's Z once, before the G additions.
+  const uint32_t lane_ = lane_id();
+#define WT(slot) wtab[(slot) * 64 + lane_]
+  const waff R1 = waff{x, scatter(y, k)};
+  {
+    wjac cur = wjac_from_aff(R1, k);
+    WT(0) = cur.x;
+    WT(1) = cur.y;
+    WT(2) = cur.z;
+#pragma unroll 1
+    for (int i = 2; i <= 8; i++) {  // T[i] = i odd ? T[i−1] + R : 2·T[i/2]   (cur = T[i−1] on entry)
+      if (i & 1) {
+        cur = wjac_add_aff(cur, R1, k);
+      } else {
+        const int h = 3 * ((i >> 1) - 1);
+        const wjac half = wjac{WT(h), WT(h + 1), WT(h + 2), false};
+        cur = wjac_dbl(half, k);
+      }
+      WT(3 * (i - 1)) = cur.x;
+      WT(3 * (i - 1) + 1) = cur.y;
+      WT(3 * (i - 1) + 2) = cur.z;
+    }
+  }
+  uint32_t Zc;
+  {
+    // prefix products pre[i] = z2·…·z_i (pre[0] = pre[1] = 1), then walking down with the suffix product
+    // suf = z_{i+1}·…·z8:  s_i = pre[i−1]·suf.  Uniform body (z1 = 1 costs a few multiplications by one).
+    WT(24) = one;
+    WT(25) = one;
+    uint32_t run = one;
+#pragma unroll 1
+    for (int i = 2; i <= 7; i++) {
+      run = wfe_mul(run, WT(3 * (i - 1) + 2), k);
+      WT(24 + i) = run;
+    }
+    const uint32_t beta = scatter(secp::GLV_CONST(1), k);
+    uint32_t suf = one;
+#pragma unroll 1
+    for (int i = 8; i >= 1; i--) {
+      const int b = 3 * (i - 1);
+      const uint32_t xi = WT(b), yi = WT(b + 1), zi = WT(b + 2), pr = WT(24 + i - 1);
+      const uint32_t sc = wfe_mul(pr, suf, k);
+      const uint32_t s2 = wfe_sqr(sc, k);
+      const uint32_t ax = wfe_mul(xi, s2, k);
+      WT(b) = ax;
+      WT(b + 1) = wfe_mul(yi, wfe_mul(s2, sc, k), k);
+      WT(b + 2) = wfe_mul(ax, beta, k);  // the λ table: X·β
+      suf = wfe_mul(suf, zi, k);
+    }
+    Zc = suf;
+  }
+  WV_STAGE(3, WT(0) ^ WT(7) ^ WT(23) ^ u1.v[0] ^ w1[0] ^ w2[1] ^ Zc)
+  wjac acc = wjac_inf();
+#pragma unroll 1
+  for (int jd = 32; jd >= 0; jd--) {
+    // digit jd of both scalars (digit 32 is the carry bit, never negative); the table reads are issued before the
+    // doublings that hide their latency
+    const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
+    const int d1 = jd == 32 ? (int)(w1[4] & 1u) : n1 - 8, d2 = jd == 32 ? (int)(w2[4] & 1u) : n2 - 8;
+    const uint32_t m1 = (uint32_t)(d1 < 0 ? -d1 : d1), m2 = (uint32_t)(d2 < 0 ? -d2 : d2);
+    const int e1 = 3 * (int)((m1 ? m1 : 1u) - 1u), e2 = 3 * (int)((m2 ? m2 : 1u) - 1u);
+    waff q1 = waff{WT(e1), WT(e1 + 1)}, q2 = waff{WT(e2 + 2), WT(e2 + 1)};
+    if (jd < 32) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) acc = wjac_dbl<true>(acc, k);
+    }
+    q1.y = ((d1 < 0) != sp.neg1) ? wfe_neg1(q1.y, k) : q1.y;  // magnitude ≤ 2
+    q2.y = ((d2 < 0) != sp.neg2) ? wfe_neg1(q2.y, k) : q2.y;
+    const wjac s1 = wjac_add_aff<true>(acc, q1, k);
+    acc = wjac_select(m1 != 0, s1, acc);
+    const wjac s2 = wjac_add_aff<true>(acc, q2, k);
+    acc = wjac_select(m2 != 0, s2, acc);
+  }
+#undef WT
+#endif
   acc.z = wfe_mul(acc.z, Zc, k);  // back from the isomorphic curve (an accumulator at infinity keeps its flag)
   WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
   // u1·G: all the fixed-base windows in this row
@@ -900,7 +1073,7 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     acc = wjac_select(dgt != 0, sum, acc);
   }
   WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
-  ok = jac_to_aff_wave(Qa, wjac_gather(acc), k) && ok;
+  ok = wjac_to_aff(Qa, acc, k) && ok;
   WV_STAGE(6, Qa.x.n[0] ^ Qa.y.n[1])
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);

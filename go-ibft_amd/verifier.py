@@ -34,7 +34,7 @@ EXPORTS = [
     "ibft_verify_senders_wire", "ibft_wire_stage_seals", "ibft_seals_export_on",
     "ibft_set_validators_u256", "ibft_last_tally_wide",
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
-    "ibft_seals_exchange", "ibft_seals_fetch_merged",
+    "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals",
 ]
@@ -100,9 +100,10 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
-        raise GpuUnavailable(f"{LIB} is not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
-    L = C.CDLL(LIB)
+    lib_path = os.environ.get("IBFT_GPU_LIB") or LIB   # IBFT_GPU_LIB: A/B experiments with another build of the library
+    if not os.path.exists(lib_path):
+        raise GpuUnavailable(f"{lib_path} is not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(lib_path)
     vp = C.c_void_p
     L.ibft_version.restype = C.c_int
     L.ibft_strerror.argtypes = [C.c_int]; L.ibft_strerror.restype = C.c_char_p
@@ -118,6 +119,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_stage.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.ibft_seals_launch.argtypes = [vp, C.c_uint32]
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
+    L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_seals_export_on.argtypes = [vp, vp, vp, vp]
@@ -328,6 +330,15 @@ class BatchVerifier:
         t = Tally()
         self._chk(self._L.ibft_seals_fetch(self._h, _p(mask), C.byref(t)), "ibft_seals_fetch")
         return mask_to_bool(mask, n), t
+
+    def seals_run(self):
+        """one more pass over the resident batch (launch + fetch in one C call) → (verdict bool[n], Tally)"""
+        n = self._staged
+        if getattr(self, "_run_mask", None) is None or len(self._run_mask) != ((n + 63) // 64 or 1):
+            self._run_mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_seals_run(self._h, _p(self._run_mask), C.byref(t)), "ibft_seals_run")
+        return mask_to_bool(self._run_mask, n), t
 
     def seals_device_ptrs(self):
         dm, dt, w = C.c_void_p(), C.c_void_p(), C.c_size_t()

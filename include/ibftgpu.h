@@ -220,6 +220,8 @@ int ibft_seals_stage(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
                      const uint8_t *signer20, const uint8_t *pre_flags, size_t n);
 int ibft_seals_launch(ibft_ctx *ctx, uint32_t repeat);
 int ibft_seals_fetch(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
+/* launch(1) + fetch in one call: one more pass over the resident batch, results on return.      */
+int ibft_seals_run(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
 /* Device address of the resident verdict mask (⌈n/64⌉ u64 words) and of the two
  * u64 tally accumulators {power, valid_rows|distinct<<32}: lets the caller run an
  * RCCL all-reduce over validator shards without a host round trip.                 */
@@ -235,8 +237,8 @@ int ibft_seals_export(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst);
  * (on the device) until they have been read.  The caller's collective then overlaps with the next
  * ibft_seals_launch on the context's own stream.                                                  */
 int ibft_seals_export_on(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst, void *consumer_stream);
-/* HIP-event time (ms) of the dominant kernel summed over the last launch, and its
- * launch count; measured on the context's own stream.                              */
+/* HIP-event time (ms) of the verdict kernels, measured on the context's own stream, summed over the
+ * launches since the previous call of this function (which resets the sum), and their count.      */
 int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
 /* Warm-path statistics: validators whose table is built, how many verdict passes ran with /
  * without the warm kernel since the context was created, and the lanes-per-signature (64 = one

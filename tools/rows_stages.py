@@ -8,7 +8,7 @@ from oracle import binding as B, workload as W
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 L = C.CDLL(os.environ.get("DEVTEST_SO") or build.build_devtest())
 r = W.make_round(n, 5)
-ms = (C.c_float * 7)()
+ms = (C.c_float * 9)()
 out = np.zeros((n, 24), np.uint8)
 rc = L.devtest_rows_stage_ms(n, r.hash32.tobytes(), r.seal65.tobytes(), ms, out.ctypes.data_as(C.c_void_p))
 assert rc == 0
@@ -17,7 +17,8 @@ names = ["sqrt + y", "+scalars (r^-1, GLV)", "+tables (T, TX)", "+main loop (128
          "complete (+keccak)"]
 prev = 0.0
 print(f"# recover_pubkey_row, {n} rows = {(n + 3) // 4} wavefronts")
-for nm, m in zip(names, ms):
+print(f"#   inside the scalar stage: after r^-1 mod n {ms[7]:.3f} ms, after u1 = -z/r, u2 = s/r {ms[8]:.3f} ms, after the GLV split {ms[1]:.3f} ms")
+for nm, m in zip(names, list(ms)[:7]):
     print(f"{nm:32s} {m:7.3f} ms   (+{m - prev:.3f})")
     prev = m
 
