@@ -881,8 +881,8 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
                        const uint8_t *hash32, const uint8_t *hash_len, size_t n, uint64_t *out_mask) {
   if (!c || (raw_len && !raw) || (n && (!hash32 || !hash_len || !out_mask)) || raw_len > (1ull << 31))
     return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);  // context state is only read inside the critical section
   if (n > c->max_rows) return IBFT_E_TOOBIG;
-  std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<uint8_t> msg(raw_len + 8);
   if (raw_len) memcpy(msg.data(), raw, raw_len);
@@ -965,6 +965,7 @@ int ibft_seals_run(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
 
 int ibft_seals_device_ptrs(ibft_ctx *c, void **d_mask, size_t *mask_words_out, void **d_tally) {
   if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (d_mask) *d_mask = c->d_mask_out.p;
   if (mask_words_out) *mask_words_out = (size_t)mask_words(c->staged_n);
   if (d_tally) *d_tally = c->d_tally.p;
@@ -1023,6 +1024,7 @@ int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
 int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes,
                      uint32_t *lanes_per_signature) {
   if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (tables) *tables = c->cache_on ? c->learned_seen : 0;
   if (warm_passes) *warm_passes = c->warm_passes;
   if (cold_passes) *cold_passes = c->cold_passes;
@@ -1032,6 +1034,7 @@ int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint3
 
 int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) {
   if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (cold_lanes) *cold_lanes = c->last_cold_group;
   if (warm_lanes) *warm_lanes = c->last_group;
   return IBFT_OK;
@@ -1060,12 +1063,12 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
                         const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
                         ibft_tally_t *tally) {
   if (!c || (n && (!off || !sig65 || !from20 || !out_mask))) return IBFT_E_INVAL;
-  if (n > c->max_rows) return IBFT_E_TOOBIG;
-  if (!c->have_valset) return IBFT_E_NOVALSET;
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !payload) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   c->wire_valid = false;
@@ -1088,12 +1091,12 @@ int ibft_verify_senders_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint3
                              ibft_wire_row_t *out_rows, ibft_tally_t *tally) {
   static_assert(sizeof(ibft_wire_row_t) == sizeof(wire::row_info), "ABI");
   if (!c || (n && (!off || !out_mask))) return IBFT_E_INVAL;
-  if (n > c->max_rows) return IBFT_E_TOOBIG;
-  if (!c->have_valset) return IBFT_E_NOVALSET;
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   const size_t wbytes = n ? off[n] : 0;
@@ -1140,9 +1143,9 @@ int ibft_wire_stage_seals(ibft_ctx *c) {
 
 int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, ibft_tally_t *tally) {
   if (!c || !tally || (n && (!sender20 || !mask))) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
-  std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   // resolve sender -> validator index with a small lookup pass over the table in HBM
   int rc;

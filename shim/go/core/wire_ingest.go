@@ -14,8 +14,8 @@ package core
 import (
 	goproto "google.golang.org/protobuf/proto"
 
+	"github.com/0xPolygon/go-ibft/ibftgpu"
 	"github.com/0xPolygon/go-ibft/messages/proto"
-	"github.com/0xPolygon/go-ibft/shim/ibftgpu"
 )
 
 // WireVerifier is the optional interface a Backend offers next to BatchVerifier.
@@ -54,6 +54,39 @@ func (i *IBFT) AddWireMessages(raw [][]byte) {
 		}
 	}
 	i.addWireStock(stock, nil)
+}
+
+// addVerifiedMessage is AddMessage (core/ibft.go:1101-1123) for a message whose sender the device has already
+// vouched for: isAcceptableMessage (core/ibft.go:1126-1149) minus its first check, then the same store +
+// quorum probe + signal.
+func (i *IBFT) addVerifiedMessage(message *proto.IbftMessage) {
+	if message == nil || !i.isAcceptableView(message) {
+		return
+	}
+	i.messages.AddMessage(message)
+	if message.View.Height == i.state.getHeight() {
+		msgs := i.messages.GetValidMessages(
+			message.View,
+			message.Type,
+			func(_ *proto.IbftMessage) bool { return true })
+		if i.hasQuorumByMsgType(msgs, message.Type) {
+			i.messages.SignalEvent(message.Type, message.View)
+		}
+	}
+}
+
+// isAcceptableView is the part of isAcceptableMessage (core/ibft.go:1132-1148) that follows the sender check.
+func (i *IBFT) isAcceptableView(message *proto.IbftMessage) bool {
+	if message.View == nil {
+		return false
+	}
+	if i.state.getHeight() > message.View.Height {
+		return false
+	}
+	if i.state.getHeight() == message.View.Height {
+		return message.View.Round >= i.state.getRound()
+	}
+	return true
 }
 
 // addWireStock is the unchanged path: unmarshal, then AddMessage (which calls IsValidValidator itself).

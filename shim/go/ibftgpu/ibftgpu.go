@@ -4,15 +4,21 @@
 //
 // NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain.  It is the
 // reference-side stub a go-ibft maintainer adds; the C side it binds is exercised through the
-// same C ABI by tests/ (ctypes) and by go-ibft_amd/host (C++).
+// same C ABI by tests/ (ctypes) and by go-ibft_amd/host (C++).  tools/check_go_shim.py checks that
+// every identifier these files use exists — in this tree, in include/ibftgpu.h or in the reference.
+//
+// Placement: shim/go/ is an OVERLAY on the go-ibft module root — shim/go/ibftgpu → <module>/ibftgpu
+// (import path github.com/0xPolygon/go-ibft/ibftgpu), shim/go/core/*.go → core/, shim/go/messages/*.go →
+// messages/ — with include/ibftgpu.h copied next to this file and libibftgpu.so on the linker /
+// loader path (CGO_LDFLAGS=-L…, LD_LIBRARY_PATH).
 //
 // cgo rules honoured: every slice handed to C is a flat []byte/[]uint32/[]uint64 without Go
 // pointers inside; C copies it to HBM before returning and retains nothing.
 package ibftgpu
 
 /*
-#cgo CFLAGS: -I${SRCDIR}/../../../include
-#cgo LDFLAGS: -L${SRCDIR}/../../../go-ibft_amd/csrc -libftgpu -Wl,-rpath,${SRCDIR}/../../../go-ibft_amd/csrc
+#cgo CFLAGS: -I${SRCDIR}
+#cgo LDFLAGS: -libftgpu
 #include <stdlib.h>
 #include "ibftgpu.h"
 */
@@ -21,6 +27,7 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"math/big"
 	"runtime"
 	"unsafe"
 )
@@ -46,8 +53,10 @@ type Tally struct {
 }
 
 // Ctx owns one ibft_ctx (one HIP stream, resident columns on one GPU).  Use one Ctx per
-// concurrent caller: AddMessage goroutines, the round goroutine and the two watcher
-// goroutines of core/ibft.go:335-347 each hold their own (a sync.Pool works well).
+// concurrent caller — AddMessage goroutines, the round goroutine and the two watcher goroutines of
+// core/ibft.go:335-347 — from a FIXED set (a buffered channel of contexts, not a sync.Pool: the validator
+// table and the key cache live in the context, so SetValidators must reach every one of them and none
+// may be dropped by the garbage collector; INTEGRATION.md §2).
 type Ctx struct{ h *C.ibft_ctx }
 
 // Options mirrors ibft_cfg.  KeyCache turns on the warm path (IBFT_FLAG_PUBKEY_CACHE): the
@@ -99,7 +108,7 @@ func (c *Ctx) check(rc C.int) error {
 }
 
 // SetValidators uploads the table GetVotingPowers(height) returned (20-byte addresses, u64
-// powers; callers whose powers exceed u64 must stay on the *big.Int path).
+// powers; SetValidatorsBig takes the *big.Int values as they are).
 func (c *Ctx) SetValidators(height uint64, addrs20 []byte, power []uint64) error {
 	n := len(power)
 	var pp *C.uint64_t
@@ -107,6 +116,37 @@ func (c *Ctx) SetValidators(height uint64, addrs20 []byte, power []uint64) error
 		pp = (*C.uint64_t)(unsafe.Pointer(&power[0]))
 	}
 	return c.check(C.ibft_set_validators(c.h, C.uint64_t(height), ptr8(addrs20), pp, C.size_t(n)))
+}
+
+// SetValidatorsBig is SetValidators for map[string]*big.Int as ValidatorBackend.GetVotingPowers returns it
+// (core/validator_manager.go:17-31): every power must fit 256 bits (a larger one returns ErrFallback and the
+// set stays on the Go path).  Sums and the quorum are kept in 320 bits on the device.
+func (c *Ctx) SetValidatorsBig(height uint64, addrs20 []byte, power []*big.Int) error {
+	be := make([]byte, 32*len(power))
+	for i, p := range power {
+		if p.Sign() < 0 || p.BitLen() > 256 {
+			return fmt.Errorf("%w: voting power %d does not fit 256 bits", ErrFallback, i)
+		}
+		p.FillBytes(be[32*i : 32*i+32])
+	}
+	return c.check(C.ibft_set_validators_u256(c.h, C.uint64_t(height), ptr8(addrs20), ptr8(be), C.size_t(len(power))))
+}
+
+// TallyWide is the full-width result of the last tally (ibft_last_tally_wide).
+func (c *Ctx) TallyWide() (power, quorum *big.Int, hasQuorum bool, err error) {
+	var t C.ibft_tally_wide_t
+	if err = c.check(C.ibft_last_tally_wide(c.h, &t)); err != nil {
+		return nil, nil, false, err
+	}
+	return words(t.power[:]), words(t.quorum[:]), t.has_quorum != 0, nil
+}
+
+func words(w []C.uint64_t) *big.Int {
+	v := new(big.Int)
+	for i := len(w) - 1; i >= 0; i-- {
+		v.Lsh(v, 64).Or(v, new(big.Int).SetUint64(uint64(w[i])))
+	}
+	return v
 }
 
 // VerifyHashes = IsValidProposalHash over a batch (core/ibft.go:858-861, 938).
@@ -167,8 +207,73 @@ func (c *Ctx) VerifySendersWire(wire []byte, off []uint32) ([]uint64, []WireRow,
 }
 
 // StageWireSeals makes the COMMIT seals found by the last VerifySendersWire the resident seal batch;
-// follow with SealsLaunch + SealsFetch (IsValidCommittedSeal without a second upload).
+// follow with SealsRun (IsValidCommittedSeal without a second upload).
 func (c *Ctx) StageWireSeals() error { return c.check(C.ibft_wire_stage_seals(c.h)) }
+
+// SealsRun = one pass of IsValidCommittedSeal + HasQuorum over the RESIDENT seal batch of n rows
+// (ibft_seals_run: launch + fetch).
+func (c *Ctx) SealsRun(n int) ([]uint64, Tally, error) {
+	mask := make([]uint64, (n+63)/64+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_seals_run(c.h, (*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
+	return mask, tally(t), c.check(rc)
+}
+
+// Group is one process driving several MI355X (ibft_group_*): the rows of a batch are sharded over the
+// devices in 64-aligned ranges and ONE RCCL all-reduce inside the library merges the verdict words and the
+// tally partials — for validator sets beyond a single GPU's batch (BASELINE configs #4 / #5).
+type Group struct{ g *C.ibft_group }
+
+func NewGroup(devices []int32, o Options) (*Group, error) {
+	var flags C.uint32_t
+	if o.StrictLowS {
+		flags |= C.IBFT_FLAG_STRICT_LOW_S
+	}
+	if o.KeyCache {
+		flags |= C.IBFT_FLAG_PUBKEY_CACHE
+	}
+	var g *C.ibft_group
+	rc := C.ibft_group_create((*C.int32_t)(unsafe.Pointer(&devices[0])), C.uint32_t(len(devices)), flags,
+		C.uint32_t(o.MaxRows), &g)
+	if rc != C.IBFT_OK {
+		return nil, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	gr := &Group{g: g}
+	runtime.SetFinalizer(gr, (*Group).Close)
+	return gr, nil
+}
+
+func (g *Group) Close() {
+	if g.g != nil {
+		C.ibft_group_destroy(g.g)
+		g.g = nil
+	}
+}
+
+func (g *Group) SetValidators(height uint64, addrs20 []byte, power []uint64) error {
+	var pp *C.uint64_t
+	if len(power) > 0 {
+		pp = (*C.uint64_t)(unsafe.Pointer(&power[0]))
+	}
+	if rc := C.ibft_group_set_validators(g.g, C.uint64_t(height), ptr8(addrs20), pp, C.size_t(len(power))); rc != C.IBFT_OK {
+		return fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	return nil
+}
+
+// VerifySeals = IsValidCommittedSeal + HasQuorum over n rows sharded across the group's devices; mask and
+// tally are the merged (global) ones.
+func (g *Group) VerifySeals(hash32, sig65, signer20, preFlags []byte) ([]uint64, Tally, error) {
+	n := len(sig65) / 65
+	mask := make([]uint64, (n+63)/64+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_group_verify_seals(g.g, ptr8(hash32), ptr8(sig65), ptr8(signer20), ptr8(preFlags), C.size_t(n),
+		(*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
+	if rc != C.IBFT_OK {
+		return nil, Tally{}, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	return mask, tally(t), nil
+}
 
 func tally(t C.ibft_tally_t) Tally {
 	return Tally{uint64(t.quorum_lo), uint64(t.quorum_hi), uint64(t.power_lo), uint64(t.power_hi),

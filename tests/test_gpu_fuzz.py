@@ -108,3 +108,67 @@ def test_crafted_scalars_all_variants(oracle, lanes, monkeypatch):
         assert bv.cache_stats()[0] == len(addrs)
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
+def test_recovery_id_policy_r_plus_n_candidate_is_never_tried(oracle, lanes, monkeypatch):
+    """include/ibftgpu.h, conventions: v is the parity of R.y and nothing else — R.x = r always.  SEC 1 §4.1.6's
+    second candidate R.x = r + n exists only for r < p − n (≈ 2^128.4); a signature whose TRUE nonce point has
+    x = r + n is 'recoverable' only with recovery id 2 / 3, which this interface (like go-ethereum's 65-byte
+    [R‖S‖V], V ∈ {0, 1}) does not have.  Such signatures are constructed here on purpose: every kernel variant,
+    cold and warm, must (a) reject v = 2 and v = 3, (b) with v = 0 / 1 name whatever signer x = r gives (never the
+    x = r + n one) — i.e. agree with the oracle row by row."""
+    import go_ibft_amd.verifier as V
+    from oracle import pyref
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    n, p = pyref.N, pyref.P
+    rng = np.random.default_rng(77)
+    hs, sigs, want, true_signer = [], [], [], []
+    r = 5
+    while len(hs) < 4 * 12:
+        r += int(rng.integers(1, 1 << 60))
+        assert r < p - n
+        x = r + n                                   # the nonce point really has x = r + n ≥ n
+        y2 = (pow(x, 3, p) + 7) % p
+        y = pow(y2, (p + 1) // 4, p)
+        if y * y % p != y2:
+            continue
+        s = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        z = int.from_bytes(rng.bytes(32), "big")
+        # the key this signature was "made with": Q = r^-1 (s·R − z·G) with R = (r + n, y)
+        R = (x, y)
+        rinv = pow(r, -1, n)
+        Q = pyref.pt_add(pyref.pt_mul(s * rinv % n, R), pyref.pt_mul((-z * rinv) % n, pyref.G))
+        signer_true = pyref.address(Q)
+        for v in (0, 1, 2, 3):
+            sig = r.to_bytes(32, "big") + s.to_bytes(32, "big") + bytes([v])
+            h = z.to_bytes(32, "big")
+            a = oracle.recover_address(h, sig)
+            assert a == pyref.recover_address(h, sig)
+            if v >= 2:
+                assert a is None
+            hs.append(np.frombuffer(h, np.uint8)); sigs.append(np.frombuffer(sig, np.uint8))
+            want.append(a); true_signer.append(signer_true)
+    hs, sigs = np.array(hs), np.array(sigs)
+    # members: the x = r signers (where one exists) and the "true" x = r + n signers
+    named = [np.frombuffer(a, np.uint8) for a in want if a is not None]
+    valset = np.unique(np.array(named + [np.frombuffer(a, np.uint8) for a in true_signer]), axis=0)
+    vs = oracle.ValSet(valset, np.ones(len(valset), np.uint64))
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=1024)
+    try:
+        bv.set_validators(1, valset, np.ones(len(valset), np.uint64))
+        for claim in ("x=r signer", "x=r+n signer"):
+            signer = np.array([np.frombuffer((w if (claim == "x=r signer" and w is not None) else t), np.uint8)
+                               for w, t in zip(want, true_signer)])
+            exp = oracle.verify_seals(vs, hs, sigs, signer).astype(bool)
+            for _ in range(2):                      # cold, then warm for the keys learned
+                got, _ = bv.is_valid_committed_seal(hs, sigs, signer)
+                assert (got == exp).all(), (claim, np.nonzero(got != exp)[0][:8])
+            v_col = sigs[:, 64]
+            assert not got[v_col >= 2].any()        # recovery ids 2, 3: rejected whoever is claimed
+            if claim == "x=r+n signer":
+                assert not got.any()                # the r + n candidate is never the one recovered
+            else:
+                assert got[v_col < 2].sum() >= 10   # x = r on the curve: those rows DO verify as the x = r signer
+    finally:
+        bv.close()

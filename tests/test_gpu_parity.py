@@ -233,11 +233,12 @@ def test_large_n_properties(gpu_verifier, oracle):
     assert (again == got).all() and t3.power == t.power
 
 
-@pytest.mark.parametrize("lanes", [1, 8, 64])
+@pytest.mark.parametrize("lanes", [1, 8, 16, 64])
 def test_public_recover_vectors_on_gpu(lanes, monkeypatch):
-    """go-ethereum's signature test vector and the ecrecover-precompile example (tests/golden/kats.json)
-    through the cold kernels (lane, 8-lane, one wavefront) and then the warm path: the signer must
-    verify as the published address and as no other."""
+    """The third-party recover vectors of tests/golden/kats.json (go-ethereum's signature test triple, the
+    ecrecover-precompile example, five RFC 6979 secp256k1 vectors of the bitcoin test suites) through the cold
+    kernels (lane, 8-lane, a DPP row per signature, one wavefront) and then the warm path: the signer must verify
+    as the published address and as no other."""
     import json
     import go_ibft_amd.verifier as V
     monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))

@@ -68,6 +68,30 @@ def test_public_recover_vectors(oracle):
         assert pyref.recover_address(d, sig).hex() == v["address"]
 
 
+def test_public_key_point_and_keccak_vectors(oracle):
+    """More third-party known answers (tests/golden/kats.json names each source): well-known private key →
+    address pairs, small multiples of G, Keccak-256 strings — through the C oracle and the pure-Python derivation."""
+    from oracle import pyref
+    k = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+    for v in k["public_key_address_vectors"]:
+        sk = bytes.fromhex(v["private_key"])
+        assert oracle.address(oracle.pubkey(sk)).hex() == v["address"], v["source"]
+        assert pyref.address(pyref.pubkey(int.from_bytes(sk, "big"))).hex() == v["address"]
+    for v in k["public_point_vectors"]:
+        assert oracle.pubkey(v["k"].to_bytes(32, "big")).hex() == v["x"] + v["y"]
+    for v in k["public_keccak_vectors"]:
+        assert oracle.keccak256(v["message"].encode()).hex() == v["digest"], v["source"]
+        assert pyref.keccak256(v["message"].encode()).hex() == v["digest"]
+    # the RFC 6979 vectors carry their message: the digest in the file is its SHA-256
+    import hashlib
+    for v in k["public_recover_vectors"]:
+        if "message" in v:
+            assert hashlib.sha256(v["message"].encode()).hexdigest() == v["digest"]
+            assert oracle.pubkey(bytes.fromhex(v["private_key"])).hex() == v["pub64"]
+            flipped = bytes.fromhex(v["sig65"])[:64] + bytes([bytes.fromhex(v["sig65"])[64] ^ 1])
+            assert oracle.ecrecover(bytes.fromhex(v["digest"]), flipped) != bytes.fromhex(v["pub64"])
+
+
 def test_sign_recover_roundtrip_and_rejections(oracle):
     n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
     rng = np.random.default_rng(5)
