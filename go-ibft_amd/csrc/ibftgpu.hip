@@ -87,6 +87,11 @@ struct ibft_ctx {
   uint32_t wave_rows_max = 2048;  // AUTO: one wavefront per signature up to this many rows (two per SIMD: 0.45 ms); the
                                   // row-per-signature kernel (0.55 ms up to 4 096 rows) wins from there
 
+  // a1: the proposal whose Keccak the device holds in d_H (raw ‖ BE64(round)); the same proposal is checked
+  // against every PREPARE and COMMIT set of a round and on every wake-up, so it is hashed once
+  std::vector<uint8_t> hashed_proposal;
+  bool have_H = false;
+
   // staged batch
   uint32_t staged_n = 0;
   bool staged_pre = false;
@@ -94,6 +99,7 @@ struct ibft_ctx {
   // pinned host mirrors for results
   uint64_t *h_mask = nullptr;
   uint64_t *h_tally = nullptr;
+  uint64_t *h_digest = nullptr;  // 32-byte staging for a1 digests (never shared with results a kernel may still deliver)
   uint64_t *dh_mask = nullptr, *dh_tally = nullptr;  // the same pinned buffers as the device sees them
   bool host_direct = false;                          // the last tally kernel delivered its results there
   hipEvent_t ev_ready = nullptr, ev_read = nullptr;  // ibft_seals_export_on: results ready / results read
@@ -429,6 +435,28 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
   return IBFT_OK;
 }
 
+int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes);
+
+// d_H ← keccak256(raw ‖ BE64(round)) unless it already holds exactly that (enqueued on the context's stream)
+int ensure_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round) {
+  uint8_t be[8];
+  for (int i = 0; i < 8; i++) be[i] = (uint8_t)(round >> (8 * (7 - i)));
+  if (c->have_H && c->hashed_proposal.size() == raw_len + 8 && (raw_len == 0 || memcmp(c->hashed_proposal.data(), raw, raw_len) == 0) &&
+      memcmp(c->hashed_proposal.data() + raw_len, be, 8) == 0)
+    return IBFT_OK;
+  c->have_H = false;
+  c->hashed_proposal.resize(raw_len + 8);
+  if (raw_len) memcpy(c->hashed_proposal.data(), raw, raw_len);
+  memcpy(c->hashed_proposal.data() + raw_len, be, 8);
+  int rc = upload(c, c->d_raw, c->hashed_proposal.data(), c->hashed_proposal.size());
+  if (rc) return rc;
+  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)c->d_raw.p,
+                     (uint32_t)c->hashed_proposal.size(), (uint64_t *)c->d_H.p);
+  HIPCHK(c, hipGetLastError());
+  c->have_H = true;  // valid once the stream reaches this point; every reader is stream-ordered behind it
+  return IBFT_OK;
+}
+
 int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes) {
   if (!bytes) return IBFT_OK;
   int rc = ensure(c, b, bytes);
@@ -677,6 +705,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
         hipMemsetAsync(c->d_tally.p, 0, c->d_tally.cap, c->stream) != hipSuccess) { rc = IBFT_E_HIP; break; }
     if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_tally, 128) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if (hipHostMalloc((void **)&c->h_digest, 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     // zero-copy result delivery (tally_kernel writes the verdict words and its own result into the
     // pinned buffers); IBFT_NO_HOST_DIRECT=1 keeps the two device-to-host copies instead
     if (!getenv("IBFT_NO_HOST_DIRECT")) {
@@ -715,6 +744,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->ev_read) (void)hipEventDestroy(c->ev_read);
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_tally) (void)hipHostFree(c->h_tally);
+  if (c->h_digest) (void)hipHostFree(c->h_digest);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -863,18 +893,33 @@ int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
   if (!c || (raw_len && !raw) || !out32 || raw_len > (1ull << 31)) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  std::vector<uint8_t> msg(raw_len + 8);
-  if (raw_len) memcpy(msg.data(), raw, raw_len);
-  for (int i = 0; i < 8; i++) msg[raw_len + i] = (uint8_t)(round >> (8 * (7 - i)));
   int rc;
-  if ((rc = upload(c, c->d_raw, msg.data(), msg.size()))) return rc;
-  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->stream,
-                     (const uint8_t *)c->d_raw.p, (uint32_t)msg.size(), (uint64_t *)c->d_H.p);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_H.p, 32, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  memcpy(out32, c->h_tally, 32);
+  if ((rc = ensure_proposal_hash(c, raw, raw_len, round))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->h_digest, c->d_H.p, 32, hipMemcpyDeviceToHost, c->stream));
+  if (hipStreamSynchronize(c->stream) != hipSuccess) {
+    c->have_H = false;
+    c->last_error = "hipStreamSynchronize failed";
+    return IBFT_E_HIP;
+  }
+  memcpy(out32, c->h_digest, 32);
   return IBFT_OK;
+}
+
+static int hash_eq_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *hash_len, size_t n, uint64_t *out_mask) {
+  int rc;
+  c->wire_valid = false;
+  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
+  if ((rc = upload(c, c->d_hash_len, hash_len, n))) return rc;
+  if (n) {
+    hipLaunchKernelGGL(ibftk::hash_eq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint8_t *)c->d_hash.p, (const uint8_t *)c->d_hash_len.p,
+                       (const uint64_t *)c->d_H.p, (uint32_t)n, (uint64_t *)c->d_mask.p);
+    HIPCHK(c, hipGetLastError());
+    c->mask_dirty_words = std::max(c->mask_dirty_words, (uint32_t)mask_words(n));  // ballot words, no tally follows
+  }
+  rc = fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
+  if (rc) c->have_H = false;  // a failed stream leaves nothing to trust
+  return rc;
 }
 
 int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round,
@@ -884,25 +929,22 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
   std::lock_guard<std::mutex> lk(c->mu);  // context state is only read inside the critical section
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
-  std::vector<uint8_t> msg(raw_len + 8);
-  if (raw_len) memcpy(msg.data(), raw, raw_len);
-  for (int i = 0; i < 8; i++) msg[raw_len + i] = (uint8_t)(round >> (8 * (7 - i)));
   int rc;
-  c->wire_valid = false;
-  if ((rc = upload(c, c->d_raw, msg.data(), msg.size()))) return rc;
-  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
-  if ((rc = upload(c, c->d_hash_len, hash_len, n))) return rc;
-  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->stream,
-                     (const uint8_t *)c->d_raw.p, (uint32_t)msg.size(), (uint64_t *)c->d_H.p);
-  HIPCHK(c, hipGetLastError());
-  if (n) {
-    hipLaunchKernelGGL(ibftk::hash_eq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                       (const uint8_t *)c->d_hash.p, (const uint8_t *)c->d_hash_len.p,
-                       (const uint64_t *)c->d_H.p, (uint32_t)n, (uint64_t *)c->d_mask.p);
-    HIPCHK(c, hipGetLastError());
-    c->mask_dirty_words = std::max(c->mask_dirty_words, (uint32_t)mask_words(n));  // ballot words, no tally follows
-  }
-  return fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
+  if ((rc = ensure_proposal_hash(c, raw, raw_len, round))) return rc;
+  return hash_eq_locked(c, hash32, hash_len, n, out_mask);
+}
+
+int ibft_verify_hashes_digest(ibft_ctx *c, const uint8_t digest32[32], const uint8_t *hash32, const uint8_t *hash_len,
+                              size_t n, uint64_t *out_mask) {
+  if (!c || !digest32 || (n && (!hash32 || !hash_len || !out_mask))) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->have_H = false;  // d_H now holds the caller's digest, not the hash of the remembered proposal
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
+  memcpy(c->h_digest, digest32, 32);
+  HIPCHK(c, hipMemcpyAsync(c->d_H.p, c->h_digest, 32, hipMemcpyHostToDevice, c->stream));
+  return hash_eq_locked(c, hash32, hash_len, n, out_mask);
 }
 
 static int seals_stage_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,

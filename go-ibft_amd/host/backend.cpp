@@ -148,6 +148,32 @@ bool GpuBackend::VerifySendersWire(const uint8_t *wire, const uint32_t *off, siz
   return true;
 }
 
+bool LoopBatch::VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
+  if (fail_hashes) return false;
+  calls++;
+  v.assign(msgs.size(), 0);
+  for (size_t i = 0; i < msgs.size(); i++) v[i] = v_->IsValidProposalHash(proposal, extract_prepare_hash(*msgs[i]));
+  return true;
+}
+bool LoopBatch::VerifyCommitBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
+  if (fail_hashes || fail_seals) return false;
+  calls++;
+  v.assign(msgs.size(), 0);
+  for (size_t i = 0; i < msgs.size(); i++) {
+    const bytes *h = extract_commit_hash(*msgs[i]);
+    std::optional<CommittedSeal> seal = extract_committed_seal(*msgs[i]);
+    v[i] = v_->IsValidProposalHash(proposal, h) && v_->IsValidCommittedSeal(h, seal ? &*seal : nullptr);
+  }
+  return true;
+}
+bool LoopBatch::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
+  if (fail_senders) return false;
+  calls++;
+  v.assign(msgs.size(), 0);
+  for (size_t i = 0; i < msgs.size(); i++) v[i] = v_->IsValidValidator(*msgs[i]);
+  return true;
+}
+
 bool HotPath::isAcceptableMessage(const IbftMessage &m) {
   if (!verifier || !verifier->IsValidValidator(m)) return false;  // ibft.go:1128
   if (!m.view) return false;                                       // :1133
@@ -180,12 +206,103 @@ int HotPath::AddMessage(MsgPtr m) {
 }
 
 void HotPath::EnableQuorumIndex() {
+  index_enabled_ = true;
   messages.SetHooks(
       [this](uint32_t type, uint64_t h, uint64_t r, const bytes &from, int delta) {
         quorumIndex.OnSender(type, h, r, from, delta, validatorManager);
       },
-      [this](uint64_t below) { quorumIndex.OnPrune(below); });
+      [this](uint64_t below) {
+        quorumIndex.OnPrune(below);
+        PruneVerdictCache(below);
+      });
 }
+
+void HotPath::PruneVerdictCache(uint64_t below_height) {
+  for (auto it = verdict_cache_.begin(); it != verdict_cache_.end();)
+    it = it->second.height < below_height ? verdict_cache_.erase(it) : std::next(it);
+}
+
+// IBFT.AddMessage with IsValidValidator already answered (by the device batch or the cache)
+int HotPath::addWithVerdict(MsgPtr m, bool sender_ok) {
+  struct TableVerifier : Verifier {
+    Verifier *inner;
+    bool verdict;
+    bool IsValidProposalHash(const Proposal *p, const bytes *h) override { return inner->IsValidProposalHash(p, h); }
+    bool IsValidCommittedSeal(const bytes *h, const CommittedSeal *s) override { return inner->IsValidCommittedSeal(h, s); }
+    bool IsValidValidator(const IbftMessage &) override { return verdict; }
+    bool IsProposer(const bytes &id, uint64_t hh, uint64_t rr) override { return inner->IsProposer(id, hh, rr); }
+    bool IsValidProposal(const bytes &raw) override { return inner->IsValidProposal(raw); }
+    bytes ID() override { return inner->ID(); }
+  } tv;
+  tv.inner = verifier;
+  tv.verdict = sender_ok;
+  Verifier *saved = verifier;
+  verifier = &tv;
+  const int rc = index_enabled_ ? AddMessageFast(std::move(m)) : AddMessage(std::move(m));
+  verifier = saved;
+  return rc;
+}
+
+bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats) {
+  results.assign(raw.size(), -1);
+  IngestStats st;
+  std::vector<MsgPtr> msgs(raw.size());
+  std::vector<int> verdict(raw.size(), -1);  // −1 unknown, 0 / 1 decided
+  std::vector<size_t> ask;                   // rows the device has to judge: first occurrence of each distinct message
+  std::map<bytes, size_t> first_in_batch;
+  for (size_t i = 0; i < raw.size(); i++) {
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode((const uint8_t *)raw[i].data(), raw[i].size(), *m)) continue;  // proto.Unmarshal error: dropped
+    msgs[i] = std::move(m);
+    auto hit = verdict_cache_.find(raw[i]);
+    if (hit != verdict_cache_.end()) {
+      verdict[i] = hit->second.ok ? 1 : 0;
+      st.cache_hits++;
+    } else if (first_in_batch.emplace(raw[i], i).second) {
+      ask.push_back(i);
+    }
+  }
+  if (!ask.empty()) {
+    std::vector<uint8_t> v;
+    bool ok = false;
+    if (use_batch && batch) {
+      st.device_calls++;
+      if (auto *gpu = dynamic_cast<GpuBackend *>(batch)) {  // the device walks the bytes themselves (§8f rank 3)
+        bytes wire;
+        std::vector<uint32_t> off{0};
+        for (size_t i : ask) {
+          wire += raw[i];
+          off.push_back((uint32_t)wire.size());
+        }
+        ok = gpu->VerifySendersWire((const uint8_t *)wire.data(), off.data(), ask.size(), v);
+      } else {
+        std::vector<MsgPtr> sub;
+        for (size_t i : ask) sub.push_back(msgs[i]);
+        ok = batch->VerifySenderBatch(sub, v);
+      }
+      ok = ok && v.size() == ask.size();
+    }
+    if (!ok) {  // no batch backend, or the device call failed: the per-message verifier
+      if (use_batch && batch) fallbacks++;
+      v.assign(ask.size(), 0);
+      for (size_t j = 0; j < ask.size(); j++) v[j] = verifier && verifier->IsValidValidator(*msgs[ask[j]]);
+    }
+    st.device_rows = ask.size();
+    for (size_t j = 0; j < ask.size(); j++) {
+      const size_t i = ask[j];
+      verdict[i] = v[j] ? 1 : 0;
+      verdict_cache_[raw[i]] = CachedVerdict{v[j] != 0, msgs[i]->view ? msgs[i]->view->height : 0};
+    }
+  }
+  for (size_t i = 0; i < raw.size(); i++) {
+    if (!msgs[i]) continue;
+    if (verdict[i] < 0) verdict[i] = verdict[first_in_batch[raw[i]]];  // a repeat inside this batch
+    results[i] = addWithVerdict(msgs[i], verdict[i] == 1);
+  }
+  if (stats) *stats = st;
+  return true;
+}
+
 
 int HotPath::AddMessageFast(MsgPtr m) {
   if (!m) return 0;
@@ -226,7 +343,13 @@ bool HotPath::handlePrepare(const View &view) {
   if (use_batch && batch) {
     prepareMessages = messages.GetValidMessagesBatch(view, PREPARE, [&](const std::vector<MsgPtr> &all) {
       std::vector<uint8_t> v;
-      if (!batch->VerifyPrepareBatch(proposal, all, v)) v.clear();
+      if (!batch->VerifyPrepareBatch(proposal, all, v) || v.size() != all.size()) {
+        // device unavailable: the per-message closure, same lock held — never "nothing"
+        fallbacks++;
+        v.assign(all.size(), 0);
+        for (size_t k = 0; k < all.size(); k++)
+          v[k] = verifier->IsValidProposalHash(proposal, extract_prepare_hash(*all[k]));
+      }
       return v;
     });
   } else {
@@ -247,7 +370,16 @@ bool HotPath::handleCommit(const View &view) {
   if (use_batch && batch) {
     commitMessages = messages.GetValidMessagesBatch(view, COMMIT, [&](const std::vector<MsgPtr> &all) {
       std::vector<uint8_t> v;
-      if (!batch->VerifyCommitBatch(proposal, all, v)) v.clear();
+      if (!batch->VerifyCommitBatch(proposal, all, v) || v.size() != all.size()) {
+        fallbacks++;  // device unavailable: answer with the per-message verifier, same lock held
+        v.assign(all.size(), 0);
+        for (size_t k = 0; k < all.size(); k++) {
+          const bytes *proposalHash = extract_commit_hash(*all[k]);
+          std::optional<CommittedSeal> seal = extract_committed_seal(*all[k]);
+          v[k] = verifier->IsValidProposalHash(proposal, proposalHash) &&
+                 verifier->IsValidCommittedSeal(proposalHash, seal ? &*seal : nullptr);
+        }
+      }
       return v;
     });
   } else {
@@ -336,6 +468,15 @@ bool HotPath::proposalMatchesCertificate(const Proposal *proposal, const Prepare
   // ExtractProposalHash on a nil message would panic in the reference; treat as a nil hash
   hashes.push_back(certificate->proposal_message ? extract_proposal_hash(*certificate->proposal_message) : nullptr);
   for (auto &m : certificate->prepare_messages) hashes.push_back(m ? extract_prepare_hash(*m) : nullptr);
+  if (!hash_verdict_.empty()) {  // answered by handleRoundChangeMessage's pre-pass
+    bool all_known = true;
+    for (const bytes *h : hashes) all_known = all_known && hash_verdict_.count({proposal, h}) != 0;
+    if (all_known) {
+      for (const bytes *h : hashes)
+        if (!hash_verdict_[{proposal, h}]) return false;
+      return true;
+    }
+  }
   last_cert_hashes = 0;
   if (use_batch && batch && proposal) {
     // one hash batch: reuse VerifyPrepareBatch's column path through synthetic PREPARE messages
@@ -431,6 +572,92 @@ bool HotPath::validateProposal(const IbftMessage &msg, const View &view) {
   p2.raw_proposal = proposal->raw_proposal;
   p2.round = maxRound;
   return verifier->IsValidProposalHash(&p2, expected);
+}
+
+}  // namespace ibft
+
+// ---- handleRoundChangeMessage (core/ibft.go:470-512) ------------------------------------------------
+namespace ibft {
+
+bool HotPath::isValidProposalHashCached(const Proposal *proposal, const bytes *hash) {
+  auto it = hash_verdict_.find({proposal, hash});
+  if (it != hash_verdict_.end()) return it->second;
+  return verifier->IsValidProposalHash(proposal, hash);
+}
+
+// One hash batch per DISTINCT (raw proposal, round) referenced by the ROUND-CHANGE messages: in a round change
+// every honest node carries the same last prepared proposal, so this is normally a single device call for all
+// the N·(Q+1) hashes of all certificates.
+void HotPath::prefetchCertificateHashes(const std::vector<MsgPtr> &rcs) {
+  hash_verdict_.clear();
+  last_cert_hashes = 0;
+  if (!(use_batch && batch)) return;
+  struct Group {
+    const Proposal *rep;
+    std::vector<std::pair<const Proposal *, const bytes *>> keys;
+    std::vector<MsgPtr> synth;
+  };
+  std::map<std::pair<bytes, uint64_t>, Group> groups;
+  for (auto &rc : rcs) {
+    const Proposal *proposal = extract_last_prepared_proposal(*rc);
+    const PreparedCertificate *cert = extract_latest_pc(*rc);
+    if (!proposal || !cert) continue;  // proposalMatchesCertificate decides these without the backend
+    Group &g = groups[{proposal->raw_proposal, proposal->round}];
+    if (g.keys.empty()) g.rep = proposal;
+    auto push = [&](const bytes *h) {
+      auto m = std::make_shared<IbftMessage>();
+      m->type = PREPARE;
+      if (h) {
+        m->kind = PayloadKind::PREPARE;
+        m->prepare.proposal_hash = *h;
+      }
+      g.synth.push_back(std::move(m));
+      g.keys.push_back({proposal, h});
+    };
+    push(cert->proposal_message ? extract_proposal_hash(*cert->proposal_message) : nullptr);
+    for (auto &m : cert->prepare_messages) push(m ? extract_prepare_hash(*m) : nullptr);
+  }
+  for (auto &kv : groups) {
+    Group &g = kv.second;
+    std::vector<uint8_t> v;
+    if (!batch->VerifyPrepareBatch(g.rep, g.synth, v) || v.size() != g.synth.size()) {
+      fallbacks++;  // this group stays on the per-message path (the table simply has no entry)
+      continue;
+    }
+    for (size_t i = 0; i < g.keys.size(); i++) hash_verdict_[g.keys[i]] = v[i] != 0;
+    last_cert_hashes += g.keys.size();
+  }
+}
+
+std::vector<MsgPtr> HotPath::handleRoundChangeMessage(const View &view) {
+  const uint64_t h = view.height;
+  const bool hasAcceptedProposal = getProposal() != nullptr;
+  auto isValidMsgFn = [&](const IbftMessage &msg) {
+    const Proposal *proposal = extract_last_prepared_proposal(msg);
+    const PreparedCertificate *certificate = extract_latest_pc(msg);
+    if (!msg.view) return false;  // the reference dereferences msg.View; a stored message always has one
+    if (!validPCImpl(certificate, msg.view->round, h)) return false;
+    return proposalMatchesCertificate(proposal, certificate);
+  };
+  auto isValidRCCFn = [&](uint64_t round, const std::vector<MsgPtr> &msgs) {
+    if (round == view.round && hasAcceptedProposal) return false;
+    return hasQuorumByMsgType(msgs, ROUND_CHANGE);
+  };
+  std::function<void(const std::vector<MsgPtr> &)> prepass;
+  if (use_batch && batch)
+    prepass = [&](const std::vector<MsgPtr> &all) {
+      std::vector<const IbftMessage *> need;
+      for (auto &rc : all) collect_pc(extract_latest_pc(*rc), need);
+      prefetchSenders(need);
+      if (!need.empty() && sender_verdict_.empty()) fallbacks++;
+      prefetchCertificateHashes(all);
+    };
+  else
+    sender_verdict_.clear();
+  std::vector<MsgPtr> out = messages.GetExtendedRCC(h, isValidMsgFn, isValidRCCFn, prepass);
+  sender_verdict_.clear();
+  hash_verdict_.clear();
+  return out;
 }
 
 }  // namespace ibft

@@ -82,6 +82,22 @@ class GpuBackend : public BatchVerifier {
   ibft_ctx *ctx_;
 };
 
+// BatchVerifier that answers every batch by looping over a per-message Verifier: the batch control flow of the
+// hot path (one callback per walk, verdict tables, device-failure fallback) without a device — what the
+// CPU-side tests drive.  fail_* make the corresponding batch call report "device unavailable".
+class LoopBatch : public BatchVerifier {
+ public:
+  explicit LoopBatch(Verifier *v) : v_(v) {}
+  bool VerifyPrepareBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  bool VerifyCommitBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  bool fail_hashes = false, fail_seals = false, fail_senders = false;
+  size_t calls = 0;  // batch calls answered
+
+ private:
+  Verifier *v_;
+};
+
 enum class StateName { newRound, prepare, commit, fin };
 
 class HotPath {
@@ -107,12 +123,36 @@ class HotPath {
   // call EnableQuorumIndex() once, and NotifyValidatorSetChanged() after validatorManager.Init.
   int AddMessageFast(MsgPtr m);
   void EnableQuorumIndex();
-  void NotifyValidatorSetChanged() { quorumIndex.Invalidate(); }
+  void NotifyValidatorSetChanged() {
+    quorumIndex.Invalidate();
+    verdict_cache_.clear();
+  }
   QuorumIndex quorumIndex;
   bool isAcceptableMessage(const IbftMessage &m);
   bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
   bool handlePrepare(const View &view);
   bool handleCommit(const View &view);
+  // handleRoundChangeMessage (core/ibft.go:470-512): the extended RCC for `view`, empty = nil.  With use_batch the
+  // signatures of every prepared certificate carried by every stored ROUND-CHANGE message of the height and all
+  // their proposal-hash checks (grouped by the proposal they refer to) are answered from ONE sender batch and one
+  // hash batch per distinct proposal, gathered by a pre-pass under the store's lock; the walk is the reference's.
+  std::vector<MsgPtr> handleRoundChangeMessage(const View &view);
+  // device batches of the last handle* / certificate call that fell back to the per-message verifier
+  size_t fallbacks = 0;
+
+  // ---- §8f rank 1: the receive side.  Messages arrive as wire bytes; IngestWire answers IsValidValidator for a
+  // whole micro-batch with one device call (verdicts of byte-identical messages — gossip re-deliveries — come
+  // from a cache keyed by the full wire bytes: the verdict is a pure function of them and of the validator set,
+  // so NotifyValidatorSetChanged clears it, and a height prune drops what can no longer be accepted), then runs
+  // AddMessage (AddMessageFast when the quorum index is enabled) per message with the verdict attached.
+  // results[i]: −1 undecodable, else AddMessage's 0 / 1 / 2.
+  struct IngestStats {
+    size_t device_rows = 0, cache_hits = 0, device_calls = 0;
+  };
+  bool IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats = nullptr);
+  // IBFT.AddMessage with IsValidValidator already answered (AddMessageFast when the quorum index is enabled)
+  int addWithVerdict(MsgPtr m, bool sender_ok);
+  void PruneVerdictCache(uint64_t below_height);
   // Certificate checks (§8f rank 2), restated from core/ibft.go: validPC :1162-1231,
   // proposalMatchesCertificate :516-551, validateProposalCommon :629-655, validateProposal0
   // :658-680, validateProposal :683-788.  With use_batch, every IsValidValidator /
@@ -130,7 +170,16 @@ class HotPath {
  private:
   // verdict tables filled by the batch pre-pass; empty = ask the per-message verifier
   std::map<const IbftMessage *, bool> sender_verdict_;
+  std::map<std::pair<const Proposal *, const bytes *>, bool> hash_verdict_;  // (proposal, hash) by identity
   bool isValidValidatorCached(const IbftMessage &m);
+  bool isValidProposalHashCached(const Proposal *proposal, const bytes *hash);
+  void prefetchCertificateHashes(const std::vector<MsgPtr> &rcs);
+  bool index_enabled_ = false;
+  struct CachedVerdict {
+    bool ok;
+    uint64_t height;
+  };
+  std::map<bytes, CachedVerdict> verdict_cache_;
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);
 

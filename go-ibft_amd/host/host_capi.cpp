@@ -101,6 +101,7 @@ struct ibft_host {
   HotPath hp;
   CallbackVerifier cbv;
   std::unique_ptr<GpuBackend> gpu;
+  std::unique_ptr<LoopBatch> loop;
 };
 
 extern "C" {
@@ -298,26 +299,40 @@ int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len
   if (!h->hp.batch) return -2;
   std::vector<uint8_t> ok;
   if (!h->hp.batch->VerifySenderBatch(msgs, ok)) return -3;
-  // Replay IBFT.AddMessage per message with IsValidValidator answered from the verdict table
-  struct TableVerifier : Verifier {
-    Verifier *inner;
-    bool verdict = false;
-    bool IsValidProposalHash(const Proposal *p, const bytes *hsh) override { return inner->IsValidProposalHash(p, hsh); }
-    bool IsValidCommittedSeal(const bytes *hsh, const CommittedSeal *s) override { return inner->IsValidCommittedSeal(hsh, s); }
-    bool IsValidValidator(const IbftMessage &) override { return verdict; }
-    bool IsProposer(const bytes &id, uint64_t hh, uint64_t rr) override { return inner->IsProposer(id, hh, rr); }
-    bool IsValidProposal(const bytes &raw) override { return inner->IsValidProposal(raw); }
-    bytes ID() override { return inner->ID(); }
-  } tv;
-  tv.inner = h->hp.verifier;
-  Verifier *saved = h->hp.verifier;
-  h->hp.verifier = &tv;
-  for (size_t i = 0; i < n; i++) {
-    tv.verdict = ok[i] != 0;
-    results[i] = (uint8_t)h->hp.AddMessage(msgs[i]);
-  }
-  h->hp.verifier = saved;
+  // IBFT.AddMessage per message with IsValidValidator answered from the verdict table; the O(1) quorum probe
+  // (AddMessageFast) when the quorum index is enabled
+  for (size_t i = 0; i < n; i++) results[i] = (uint8_t)h->hp.addWithVerdict(msgs[i], ok[i] != 0);
   return 0;
+}
+
+int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_t *results, size_t n, size_t *device_rows,
+                          size_t *cache_hits, size_t *device_calls) {
+  std::vector<bytes> raw;
+  if (!unpack_list(packed, len, raw) || raw.size() != n) return -1;
+  std::vector<int> res;
+  HotPath::IngestStats st;
+  if (!h->hp.IngestWire(raw, res, &st)) return -3;
+  for (size_t i = 0; i < n; i++) results[i] = (int8_t)res[i];
+  if (device_rows) *device_rows = st.device_rows;
+  if (cache_hits) *cache_hits = st.cache_hits;
+  if (device_calls) *device_calls = st.device_calls;
+  return 0;
+}
+
+void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
+  h->loop.reset(new LoopBatch(&h->cbv));
+  h->loop->fail_hashes = (fail_mask & 1) != 0;
+  h->loop->fail_seals = (fail_mask & 2) != 0;
+  h->loop->fail_senders = (fail_mask & 4) != 0;
+  h->hp.batch = h->loop.get();
+}
+size_t ibft_host_loop_batch_calls(ibft_host *h) { return h->loop ? h->loop->calls : 0; }
+size_t ibft_host_fallbacks(ibft_host *h) { return h->hp.fallbacks; }
+
+int ibft_host_handle_round_change(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *rcc) {
+  std::vector<MsgPtr> out = h->hp.handleRoundChangeMessage(View{height, round, {}});
+  if (rcc) msgs_to_buf(out, rcc);
+  return out.empty() ? 0 : 1;
 }
 
 void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len) { h->cbv.id.assign((const char *)id, len); }

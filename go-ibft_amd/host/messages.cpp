@@ -99,11 +99,18 @@ std::vector<MsgPtr> Messages::GetValidMessagesBatch(const View &view, MessageTyp
 
 std::vector<MsgPtr> Messages::GetExtendedRCC(
     uint64_t height, const Predicate &isValidMessage,
-    const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC) {
+    const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC,
+    const std::function<void(const std::vector<MsgPtr> &)> &prepass) {
   std::unique_lock lk(mux_[ROUND_CHANGE]);
   std::vector<MsgPtr> extended;
   auto h = maps_[ROUND_CHANGE].find(height);
   if (h == maps_[ROUND_CHANGE].end()) return extended;
+  if (prepass) {
+    std::vector<MsgPtr> all;
+    for (auto &rm : h->second)
+      for (auto &kv : rm.second) all.push_back(kv.second);
+    prepass(all);
+  }
   uint64_t highest = 0;
   for (auto &rm : h->second) {
     const uint64_t round = rm.first;

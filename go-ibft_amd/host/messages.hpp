@@ -45,8 +45,12 @@ class Messages {
   // callback loop) and returns one verdict per message; rejected ones are deleted.
   using BatchPredicate = std::function<std::vector<uint8_t>(const std::vector<MsgPtr> &)>;
   std::vector<MsgPtr> GetValidMessagesBatch(const View &view, MessageType type, const BatchPredicate &verdicts);
+  // prepass (optional): called ONCE, under the same lock, with every ROUND-CHANGE message stored for `height`
+  // before the walk — lets a batch backend answer all the nested signature / hash questions of the walk with one
+  // device call; the walk itself and what it returns are untouched.
   std::vector<MsgPtr> GetExtendedRCC(uint64_t height, const Predicate &isValidMessage,
-                                     const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC);
+                                     const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC,
+                                     const std::function<void(const std::vector<MsgPtr> &)> &prepass = nullptr);
   std::vector<MsgPtr> GetMostRoundChangeMessages(uint64_t minRound, uint64_t height);
 
  private:

@@ -98,6 +98,12 @@ def lib() -> C.CDLL:
         L.ibft_host_last_cert_batch.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.ibft_host_handle_prepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         L.ibft_host_handle_commit.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
+        L.ibft_host_handle_round_change.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
+        L.ibft_host_ingest_wire.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ibft_host_use_loop_batch.argtypes = [vp, C.c_int]
+        L.ibft_host_loop_batch_calls.argtypes = [vp]; L.ibft_host_loop_batch_calls.restype = C.c_size_t
+        L.ibft_host_fallbacks.argtypes = [vp]; L.ibft_host_fallbacks.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -326,3 +332,28 @@ class Host:
         b = Buf()
         q = self.L.ibft_host_handle_commit(self.h, height, round_, C.byref(b))
         return bool(q), unpack_seals(_take(b))
+
+    def handle_round_change(self, height, round_):
+        """handleRoundChangeMessage → the extended RCC's messages (wire), [] = nil"""
+        b = Buf()
+        self.L.ibft_host_handle_round_change(self.h, height, round_, C.byref(b))
+        return unpack(_take(b))
+
+    def ingest_wire(self, wires):
+        """receive side: (results per message: -1 undecodable / 0 / 1 / 2, device rows, cache hits, device calls)"""
+        p = pack(wires)
+        res = C.create_string_buffer(max(len(wires), 1))
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        rc = self.L.ibft_host_ingest_wire(self.h, p, len(p), res, len(wires), C.byref(a), C.byref(b), C.byref(c))
+        if rc != 0:
+            raise RuntimeError(f"ibft_host_ingest_wire rc={rc}")
+        return [x - 256 if x > 127 else x for x in res.raw[:len(wires)]], a.value, b.value, c.value
+
+    def use_loop_batch(self, fail_mask: int = 0):
+        self.L.ibft_host_use_loop_batch(self.h, fail_mask)
+
+    def loop_batch_calls(self) -> int:
+        return self.L.ibft_host_loop_batch_calls(self.h)
+
+    def fallbacks(self) -> int:
+        return self.L.ibft_host_fallbacks(self.h)

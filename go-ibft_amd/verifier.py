@@ -34,7 +34,7 @@ EXPORTS = [
     "ibft_verify_senders_wire", "ibft_wire_stage_seals", "ibft_seals_export_on",
     "ibft_set_validators_u256", "ibft_last_tally_wide",
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
-    "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run",
+    "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals",
 ]
@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
     L.ibft_set_validators.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.ibft_verify_hashes.argtypes = [vp, vp, C.c_size_t, C.c_uint64, vp, vp, C.c_size_t, vp]
     L.ibft_proposal_hash.argtypes = [vp, vp, C.c_size_t, C.c_uint64, vp]
+    L.ibft_verify_hashes_digest.argtypes = [vp, vp, vp, vp, C.c_size_t, vp]
     L.ibft_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_tally.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(Tally)]
@@ -261,6 +262,16 @@ class BatchVerifier:
         r = np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
         self._chk(self._L.ibft_verify_hashes(self._h, _p(r), len(raw), round_, _p(h), _p(hl), n, _p(mask)),
                   "ibft_verify_hashes")
+        return mask_to_bool(mask, n)
+
+    def is_valid_proposal_hash_digest(self, digest32: bytes, hash32, hash_len) -> np.ndarray:
+        """IsValidProposalHash with keccak(proposal) already known to the caller: a compare per row"""
+        h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
+        n = len(hl)
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        d = np.frombuffer(bytes(digest32), dtype=np.uint8).copy()
+        assert len(d) == 32
+        self._chk(self._L.ibft_verify_hashes_digest(self._h, _p(d), _p(h), _p(hl), n, _p(mask)), "ibft_verify_hashes_digest")
         return mask_to_bool(mask, n)
 
     # Verifier.IsValidCommittedSeal, batched

@@ -109,6 +109,21 @@ int ibft_host_add_message_fast(ibft_host *h, const uint8_t *wire, size_t len);
 /* Batched ingest: IsValidValidator for many messages in one device call,
  * then the same store/probe logic per accepted message; results[i] as above. */
 int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n);
+/* The receive side: n messages as the transport delivered them (packed wire bytes).  ONE
+ * device call answers IsValidValidator for the messages not seen before — byte-identical re-deliveries come
+ * from a verdict cache keyed by the full wire bytes (cleared when the validator set changes, pruned with the
+ * store) — then IBFT.AddMessage runs per message with the verdict attached (the O(1) quorum probe when
+ * ibft_host_enable_quorum_index was called).  results[i]: -1 undecodable, else 0 / 1 / 2 as above.  With no
+ * batch backend, or when the device call fails, the per-message verifier answers (ibft_host_fallbacks).   */
+int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_t *results, size_t n,
+                          size_t *device_rows, size_t *cache_hits, size_t *device_calls);
+/* A batch backend that loops over the callback Verifier (no device): the batch control flow — one call per walk,
+ * verdict tables, fallback — for CPU-side tests.  fail_mask bits: 1 hash batches, 2 seal batches, 4 sender
+ * batches report "device unavailable".                                                                      */
+void ibft_host_use_loop_batch(ibft_host *h, int fail_mask);
+size_t ibft_host_loop_batch_calls(ibft_host *h);
+/* batches that fell back to the per-message verifier because the batch backend reported failure            */
+size_t ibft_host_fallbacks(ibft_host *h);
 /* Certificate checks (core/ibft.go: validPC :1162-1231, proposalMatchesCertificate :516-551,
  * validateProposal0 :658-680, validateProposal :683-788).  NULL wire pointers are Go nils.  With
  * ibft_host_use_batch(1) and a GPU attached, all sender signatures / hashes of the certificate go
@@ -123,6 +138,11 @@ void ibft_host_last_cert_batch(ibft_host *h, size_t *senders, size_t *hashes);
 /* handlePrepare / handleCommit (core/ibft.go:855-889, 931-967): 1 = quorum reached */
 int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared);
 int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals);
+/* handleRoundChangeMessage (core/ibft.go:470-512): 1 = an extended RCC exists for (height, round), its messages in
+ * rcc.  In batch mode every nested signature of every stored ROUND-CHANGE message's prepared certificate goes to
+ * the device in one sender batch and the certificate hashes in one hash batch per distinct proposal
+ * (ibft_host_last_cert_batch reports both counts).                                                          */
+int ibft_host_handle_round_change(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *rcc);
 
 #ifdef __cplusplus
 }

@@ -155,8 +155,15 @@ int ibft_last_tally_wide(ibft_ctx *ctx, ibft_tally_wide_t *out);
 int ibft_verify_hashes(ibft_ctx *ctx, const uint8_t *raw, size_t raw_len, uint64_t round,
                        const uint8_t *hash32, const uint8_t *hash_len, size_t n,
                        uint64_t *out_mask);
+/* The same with the proposal's Keccak already in hand (an application Backend computes it when it builds or
+ * validates the proposal): a pure 32-byte compare per row.  Recommended for proposals beyond ~64 KiB — Keccak is
+ * a sequential sponge, one lane walks it at ≈13 µs per 136-byte block (profiles/r02_a1_sizes.json).         */
+int ibft_verify_hashes_digest(ibft_ctx *ctx, const uint8_t digest32[32], const uint8_t *hash32,
+                              const uint8_t *hash_len, size_t n, uint64_t *out_mask);
 /* keccak256(raw ‖ BE64(round)) computed on the device (what BuildPrepareMessage's
- * caller would sign).                                                              */
+ * caller would sign).  The context remembers the last proposal it hashed: ibft_verify_hashes /
+ * ibft_proposal_hash with the same (raw, round) — every PREPARE and COMMIT set of a round, every wake-up —
+ * skip the upload and the hash.                                                    */
 int ibft_proposal_hash(ibft_ctx *ctx, const uint8_t *raw, size_t raw_len, uint64_t round,
                        uint8_t out32[32]);
 

@@ -204,3 +204,91 @@ def test_round_change_certificate_batch_equals_stock(gpu_verifier, oracle):
                 assert senders == quorum + quorum * (1 + len(prepares0))      # every nested signature, one batch
             h.close()
         assert out[0] == out[1] == expect, (corrupt, out)
+
+
+def test_extended_rcc_with_quorum_sized_certificates_batch_equals_stock(gpu_verifier, oracle):
+    """§8f rank 2, handleRoundChangeMessage (core/ibft.go:470-512) at N = 256: the store holds ROUND-CHANGE
+    messages of round 1 from more than a quorum of validators, each carrying a PreparedCertificate with a PREPREPARE
+    and Q − 1 PREPAREs — ≈ Q² nested signatures and as many proposal-hash checks.  Batch mode answers all of them
+    from ONE device sender batch and one hash batch (all carry the same last prepared proposal) and must build the
+    same extended RCC as the per-message walk backed by the CPU oracle: the message whose certificate holds a bad
+    PREPARE signature and the one whose certificate belongs to another proposal are left out by both."""
+    import go_ibft_amd.hostlib as H
+    from oracle import wire as W, workload as WL
+    n = 256
+    r = WL.make_round(n, 4096)
+    addrs = [r.addrs[i].tobytes() for i in range(n)]
+    idx = {a: i for i, a in enumerate(addrs)}
+    quorum = 2 * n // 3 + 1
+    raw = r.raw
+    proposer = lambda hh, rr: addrs[(hh + rr) % n]
+
+    def signed(m):
+        m.signature = oracle.sign(r.sks[idx[m.sender]], oracle.keccak256(m.payload_no_sig()))
+        return m
+
+    def certificate(raw_block, bad_prepare=False):
+        h0 = oracle.proposal_hash(raw_block, 0)
+        pp = signed(W.IbftMessage(view=W.View(1, 0), sender=proposer(1, 0), type=W.PREPREPARE,
+                                  payload=W.preprepare_body(W.Proposal(raw_block, 0), h0, None)))
+        prs = [signed(W.IbftMessage(view=W.View(1, 0), sender=a, type=W.PREPARE, payload=W.prepare_body(h0)))
+               for a in addrs if a != pp.sender][: quorum - 1]
+        if bad_prepare:
+            prs[17].signature = prs[18].signature
+        return pp, prs
+    good, bad_sig, other = certificate(raw), certificate(raw, bad_prepare=True), certificate(b"another block")
+    senders = addrs[5: 5 + quorum + 4]
+    rcs = []
+    for k, a in enumerate(senders):
+        cert = bad_sig if k == 3 else other if k == 9 else good
+        rcs.append(signed(W.IbftMessage(view=W.View(1, 1), sender=a, type=W.ROUND_CHANGE,
+                                        payload=W.round_change_body(W.Proposal(raw, 0), W.prepared_certificate(*cert)))))
+    wires = [m.encode() for m in rcs]
+    gpu_verifier.set_validators(1, r.addrs, r.power)
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    out = {}
+    for batch in (False, True):
+        h = H.Host()
+        assert h.vm_init({a: 1 for a in addrs})
+        h.set_verifier(f1, f2, f3, is_proposer=lambda who, hh, rr: who == proposer(hh, rr))
+        h.set_state(1, 1, None)
+        h.attach_gpu(gpu_verifier)
+        h.use_batch(batch)
+        for wv in wires:
+            assert h.store_add(wv) == 0
+        out[batch] = sorted(h.handle_round_change(1, 1))
+        if batch:
+            nsend, nhash = h.last_cert_batch()
+            assert nsend == len(rcs) * quorum and nhash == len(rcs) * quorum     # every nested signature and hash
+            assert h.fallbacks() == 0
+        h.close()
+    assert out[False] == out[True]
+    assert len(out[True]) == len(rcs) - 2 and wires[3] not in out[True] and wires[9] not in out[True]
+
+
+def test_ingest_wire_through_the_device(gpu_verifier, oracle):
+    """§8f rank 1 with the real backend: a micro-batch of raw COMMIT messages → one ibft_verify_senders_wire call;
+    re-delivery → the verdict cache; results equal per-message IBFT.AddMessage with the oracle-backed verifier."""
+    import go_ibft_amd.hostlib as H
+    r, proposal, prepares, commits = _build_round(oracle, 300, 77, byzantine=True)
+    gpu_verifier.set_validators(r.height, r.addrs, r.power)
+    powers = {r.addrs[i].tobytes(): int(r.power[i]) for i in range(r.n)}
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    wires = [m.encode() for m in prepares + commits]
+    ref, ing = H.Host(), H.Host()
+    for h in (ref, ing):
+        assert h.vm_init(powers)
+        h.set_state(r.height, r.round, proposal.encode())
+        h.set_verifier(f1, f2, f3)
+    ing.attach_gpu(gpu_verifier)
+    ing.use_batch(True)
+    ing.enable_quorum_index()
+    expect = [ref.add_message(x) for x in wires]
+    got, rows, hits, calls = ing.ingest_wire(wires)
+    assert got == expect and (rows, hits, calls) == (len(wires), 0, 1)
+    assert 0 in got and 2 in got
+    again, rows, hits, calls = ing.ingest_wire(wires)
+    assert (rows, hits, calls) == (0, len(wires), 0) and [x != 0 for x in again] == [x != 0 for x in expect]
+    for t in (1, 2):
+        assert ref.store_num(r.height, r.round, t) == ing.store_num(r.height, r.round, t)
+    ref.close(); ing.close()

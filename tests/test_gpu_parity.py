@@ -281,3 +281,34 @@ def test_stale_work_mask_bits_do_not_leak(oracle):
             assert (~exp).sum() > 100
     finally:
         bv.close()
+
+
+def test_proposal_hash_is_remembered_and_digest_form_agrees(oracle):
+    """a1: the context hashes a proposal once (same (raw, round) → only the compares run), notices a changed
+    byte or round, and the digest-supplied form gives the same verdicts; nil / short / wrong hashes stay false."""
+    import go_ibft_amd.verifier as V
+    rng = np.random.default_rng(99)
+    bv = V.BatchVerifier(max_rows=4096)
+    try:
+        for L in (0, 1, 135, 136, 137, 1024, 70000):
+            raw = rng.bytes(L)
+            for rnd in (0, 5):
+                H = oracle.proposal_hash(raw, rnd)
+                n = 300
+                hashes = np.tile(np.frombuffer(H, np.uint8), (n, 1)).copy()
+                hl = np.full(n, 32, np.uint8)
+                hashes[::3, 31] ^= 0x80
+                hl[5] = 0; hashes[5] = 0
+                hl[6] = 31
+                exp = oracle.verify_hashes(raw, rnd, hashes, hl).astype(bool)
+                assert exp.sum() > 100 and (~exp).sum() > 100
+                for _ in range(3):
+                    assert (bv.is_valid_proposal_hash(raw, rnd, hashes, hl) == exp).all()
+                assert (bv.is_valid_proposal_hash_digest(H, hashes, hl) == exp).all()
+                assert bv.proposal_hash(raw, rnd) == H
+                if L:                                   # one byte of the proposal changes: nothing may be reused
+                    raw2 = bytes([raw[0] ^ 1]) + raw[1:]
+                    assert not bv.is_valid_proposal_hash(raw2, rnd, hashes, hl).any()
+                    assert (bv.is_valid_proposal_hash(raw, rnd, hashes, hl) == exp).all()
+    finally:
+        bv.close()

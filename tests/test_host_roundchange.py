@@ -1,0 +1,221 @@
+"""SURVEY.md §8f ranks 1 and 2, host side, WITHOUT a device: the batch control flow of the C++ mirror is driven
+through a batch backend that loops over the callback Verifier (ibft_host_use_loop_batch), so that
+
+  * handleRoundChangeMessage (core/ibft.go:470-512 → messages.GetExtendedRCC, messages/messages.go:202-245) with
+    one sender batch + one hash batch per distinct proposal decides exactly like the per-message walk;
+  * a batch backend that reports failure makes handlePrepare / handleCommit / handleRoundChangeMessage answer
+    with the per-message verifier under the same lock (the mirror used to return "nothing");
+  * the receive side (IngestWire): one batch per micro-batch, a verdict cache keyed by the full wire bytes —
+    re-deliveries hit it, a replayed (from, signature) under a different payload does not.
+"""
+import random
+
+import pytest
+
+import go_ibft_amd.hostlib as H
+from oracle import wire as W
+
+PP, PR, CM, RC = W.PREPREPARE, W.PREPARE, W.COMMIT, W.ROUND_CHANGE
+
+
+def nodes(n):
+    return [f"node {i:02d}".encode() for i in range(n)]
+
+
+def fake_hash(raw: bytes, rnd: int) -> bytes:
+    return (b"H|" + raw[:8] + b"|%d" % rnd).ljust(32, b".")[:32]
+
+
+class World:
+    """a validator set, a round-robin proposer, and a mock backend whose verdicts are looked up in sets"""
+
+    def __init__(self, n, seed):
+        self.rng = random.Random(seed)
+        self.addrs = nodes(n)
+        self.n = n
+        self.bad_wires = set()        # IsValidValidator == false for exactly these message bytes
+        self.calls = {"validator": 0, "hash": 0}
+
+    def proposer(self, h, r):
+        return self.addrs[(h + r) % self.n]
+
+    def verifier(self):
+        def vv(wire):
+            self.calls["validator"] += 1
+            return wire not in self.bad_wires
+
+        def ph(prop, hsh):
+            self.calls["hash"] += 1
+            return prop is not None and hsh == fake_hash(prop[0], prop[1])
+        return dict(is_valid_validator=vv, is_valid_proposal_hash=ph,
+                    is_proposer=lambda who, hh, rr: who == self.proposer(hh, rr))
+
+    def host(self):
+        h = H.Host()
+        assert h.vm_init({a: 1 for a in self.addrs})
+        h.set_verifier(**self.verifier())
+        return h
+
+    def certificate(self, height, round_, raw, corrupt=None):
+        """PREPREPARE of `round_` by its proposer + a quorum of PREPAREs by others; signatures are opaque tags"""
+        hsh = fake_hash(raw, round_)
+        prop = self.proposer(height, round_)
+        pp = W.IbftMessage(view=W.View(height, round_), sender=prop, type=PP, signature=b"sig-pp-" + prop,
+                           payload=W.preprepare_body(W.Proposal(raw, round_), hsh, None))
+        others = [a for a in self.addrs if a != prop]
+        self.rng.shuffle(others)
+        q = 2 * self.n // 3 + 1
+        prs = [W.IbftMessage(view=W.View(height, round_), sender=a, type=PR, signature=b"sig-pr-" + a,
+                             payload=W.prepare_body(hsh)) for a in others[:q - 1]]
+        if corrupt == "bad_prepare_signature":
+            self.bad_wires.add(prs[self.rng.randrange(len(prs))].encode())
+        elif corrupt == "bad_proposal_signature":
+            self.bad_wires.add(pp.encode())
+        elif corrupt == "wrong_hash_in_prepare":
+            k = self.rng.randrange(len(prs))
+            prs[k] = W.IbftMessage(view=W.View(height, round_), sender=prs[k].sender, type=PR, signature=prs[k].signature,
+                                   payload=W.prepare_body(fake_hash(b"other", round_)))
+        elif corrupt == "too_few_prepares":
+            prs = prs[: q // 2]
+        return pp, prs
+
+
+def rc_message(w, height, round_, sender, raw=None, cert=None, cert_round=0):
+    body = W.round_change_body(W.Proposal(raw, cert_round) if raw is not None else None,
+                               W.prepared_certificate(*cert) if cert is not None else None)
+    return W.IbftMessage(view=W.View(height, round_), sender=sender, type=RC, signature=b"sig-rc-" + sender, payload=body)
+
+
+KINDS = [None, None, None, "bad_prepare_signature", "bad_proposal_signature", "wrong_hash_in_prepare", "too_few_prepares",
+         "no_certificate", "proposal_without_certificate", "other_proposal"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_round_change_batch_equals_stock(seed):
+    w = World(n=7 + seed % 4, seed=seed)
+    height = 3
+    raw = b"block-%d" % seed
+    stock, batch = w.host(), w.host()
+    batch.use_loop_batch(0)
+    batch.use_batch(True)
+    for rnd in (1, 2, 3):
+        senders = list(w.addrs)
+        w.rng.shuffle(senders)
+        for a in senders[: w.rng.randrange(2, w.n + 1)]:
+            kind = w.rng.choice(KINDS)
+            cert_round = w.rng.randrange(0, rnd)
+            if kind == "no_certificate":
+                m = rc_message(w, height, rnd, a)
+            elif kind == "proposal_without_certificate":
+                m = rc_message(w, height, rnd, a, raw=raw, cert=None, cert_round=cert_round)
+            elif kind == "other_proposal":      # certificate for another block than the carried proposal
+                m = rc_message(w, height, rnd, a, raw=raw, cert=w.certificate(height, cert_round, b"another"), cert_round=cert_round)
+            else:
+                m = rc_message(w, height, rnd, a, raw=raw, cert=w.certificate(height, cert_round, raw, kind), cert_round=cert_round)
+            for h in (stock, batch):
+                assert h.store_add(m.encode()) == 0
+    for view_round in (1, 2, 3):
+        for accepted in (None, W.IbftMessage(view=W.View(height, view_round), sender=w.proposer(height, view_round), type=PP,
+                                             payload=W.preprepare_body(W.Proposal(raw, view_round), fake_hash(raw, view_round), None))):
+            for h in (stock, batch):
+                h.set_state(height, view_round, accepted.encode() if accepted else None)
+            w.calls = {"validator": 0, "hash": 0}
+            a = stock.handle_round_change(height, view_round)
+            stock_calls = dict(w.calls)
+            before = batch.loop_batch_calls()
+            b = batch.handle_round_change(height, view_round)
+            assert sorted(a) == sorted(b), (seed, view_round, accepted is not None)
+            # one sender batch + one hash batch per distinct carried proposal (raw, round): rounds 0, 1, 2 here
+            assert batch.loop_batch_calls() - before <= 1 + 3
+            assert batch.fallbacks() == 0
+            if stock_calls["validator"] > 20:
+                senders_batched, hashes_batched = batch.last_cert_batch()
+                assert senders_batched >= 1 and hashes_batched >= 1
+    stock.close(); batch.close()
+
+
+def _commit_world(n=9, bad=(2, 5)):
+    w = World(n, 1)
+    raw = b"the block"
+    hsh = fake_hash(raw, 0)
+    proposal = W.IbftMessage(view=W.View(1, 0), sender=w.proposer(1, 0), type=PP,
+                             payload=W.preprepare_body(W.Proposal(raw, 0), hsh, None))
+    prepares = [W.IbftMessage(view=W.View(1, 0), sender=a, type=PR, payload=W.prepare_body(hsh if i not in bad else b"x" * 32))
+                for i, a in enumerate(w.addrs) if a != proposal.sender]
+    commits = [W.IbftMessage(view=W.View(1, 0), sender=a, type=CM,
+                             payload=W.commit_body(hsh if i not in bad else b"y" * 32, b"seal-" + a)) for i, a in enumerate(w.addrs)]
+    return w, proposal, prepares, commits
+
+
+@pytest.mark.parametrize("fail_mask", [1, 2, 4, 7])
+def test_failing_batch_backend_falls_back_to_the_per_message_verifier(fail_mask):
+    w, proposal, prepares, commits = _commit_world()
+    ver = w.verifier()
+    ver["is_valid_committed_seal"] = lambda hsh, seal: seal is not None and not seal[1].endswith(b"03")
+    hosts = []
+    for mode in ("stock", "failing-batch"):
+        h = H.Host()
+        assert h.vm_init({a: 1 for a in w.addrs})
+        h.set_verifier(**ver)
+        h.set_state(1, 0, proposal.encode())
+        if mode != "stock":
+            h.use_loop_batch(fail_mask)
+            h.use_batch(True)
+        for m in prepares + commits:
+            h.store_add(m.encode())
+        hosts.append(h)
+    stock, failing = hosts
+    assert stock.handle_prepare(1, 0) == failing.handle_prepare(1, 0)
+    qs, seals_s = stock.handle_commit(1, 0)
+    qf, seals_f = failing.handle_commit(1, 0)
+    assert qs == qf and sorted(seals_s) == sorted(seals_f)
+    for t in (PR, CM):                                  # and the same messages were pruned from the store
+        assert stock.store_num(1, 0, t) == failing.store_num(1, 0, t)
+    if fail_mask & 3:
+        assert failing.fallbacks() >= 1
+    for h in hosts:
+        h.close()
+
+
+def test_ingest_micro_batches_and_the_verdict_cache():
+    w, proposal, prepares, commits = _commit_world(n=10, bad=())
+    forged = W.IbftMessage(view=W.View(1, 0), sender=commits[3].sender, type=CM, signature=b"sig",
+                           payload=W.commit_body(b"z" * 32, b"another seal"))
+    genuine = W.IbftMessage(view=W.View(1, 0), sender=commits[3].sender, type=CM, signature=b"sig",
+                            payload=W.commit_body(fake_hash(b"the block", 0), b"seal-" + commits[3].sender))
+    commits[3] = genuine
+    w.bad_wires.add(forged.encode())                      # same From and Signature, different payload: invalid
+    w.bad_wires.add(commits[7].encode())
+    wires = [m.encode() for m in commits]
+    ref, ing = w.host(), w.host()
+    for h in (ref, ing):
+        h.set_state(1, 0, proposal.encode())
+    ing.use_loop_batch(0)
+    ing.use_batch(True)
+    ing.enable_quorum_index()
+    expect = [ref.add_message(x) for x in wires]
+    got, rows, hits, calls = ing.ingest_wire(wires + [b"\xff\xff"])
+    assert got == expect + [-1] and (rows, hits, calls) == (len(wires), 0, 1)
+    assert 0 in expect and 2 in expect                   # a rejected sender, and the quorum signal
+    # gossip re-delivery: answered from the cache, no batch call; the store decisions repeat (same sender overwrites)
+    again, rows, hits, calls = ing.ingest_wire(wires)
+    assert (rows, hits, calls) == (0, len(wires), 0)
+    assert [r != 0 for r in again] == [r != 0 for r in expect]
+    # a replay of (From, Signature) under another payload is a different message: not a cache hit, judged, rejected
+    got, rows, hits, calls = ing.ingest_wire([forged.encode(), wires[0], forged.encode()])
+    assert got[0] == 0 and got[2] == 0 and got[1] != 0 and (rows, hits, calls) == (1, 1, 1)
+    # validator set change: every cached verdict is dropped
+    assert ing.vm_init({a: 1 for a in w.addrs})
+    _, rows, hits, _ = ing.ingest_wire(wires[:4])
+    assert (rows, hits) == (4, 0)
+    # pruning the store below a height drops the cached verdicts of older messages
+    ing.store_prune(2)
+    _, rows, hits, _ = ing.ingest_wire(wires[:4])
+    assert (rows, hits) == (4, 0)
+    # no batch backend at all: the per-message verifier answers, results unchanged
+    plain = w.host()
+    plain.set_state(1, 0, proposal.encode())
+    got, rows, hits, calls = plain.ingest_wire(wires)
+    assert got == expect and calls == 0
+    for h in (ref, ing, plain):
+        h.close()
