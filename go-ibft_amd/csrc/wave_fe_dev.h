@@ -184,9 +184,8 @@ HD void wfe_mul_step(uint32_t a, uint32_t b, uint64_t &lo, uint64_t &hi) {
   if (I >= 7) hi = mad64(ai, row_shl<16 - (I >= 7 ? I : 7)>(b), hi);  // columns 16..18 in lanes 0..2
 }
 
-// both inputs of magnitude ≤ 15 with zero idle lanes; result magnitude 1 (< 2^26 + 2^16), idle lanes zero
-HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint32_t lt3) {
-  uint64_t lo = 0, hi = 0;
+// column sums of a·b added to (lo, hi): lane k of lo = column k (k = 0..15), lane k of hi = column 16 + k (k = 0..2)
+HD void wfe_prod(uint32_t a, uint32_t b, uint64_t &lo, uint64_t &hi) {
   {
     const uint32_t a0 = row_bcast<0>(a);
     lo = mad64(a0, b, lo);
@@ -200,7 +199,10 @@ HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint
   wfe_mul_step<7>(a, b, lo, hi);
   wfe_mul_step<8>(a, b, lo, hi);
   wfe_mul_step<9>(a, b, lo, hi);
-  // lane k of lo = column k (k = 0..15), lane k of hi = column 16 + k (k = 0..2): cut into 26-bit chunks
+}
+// 64-bit column sums (each < 2^64) → magnitude 1 (< 2^26 + 2^16), idle lanes zero
+HD uint32_t wfe_reduce(uint64_t lo, uint64_t hi, uint32_t act, uint32_t m3, uint32_t lt3) {
+  // cut into 26-bit chunks
   const uint32_t c0 = (uint32_t)lo & M26, c1 = (uint32_t)(lo >> 26) & M26, c2 = (uint32_t)(lo >> 52);
   const uint32_t h0 = (uint32_t)hi & M26, h1 = (uint32_t)(hi >> 26) & M26, h2 = (uint32_t)(hi >> 52);
   // S: positions 0..15, T: positions 16..20 (lane j = position 16 + j)
@@ -217,6 +219,21 @@ HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint
   V2 = mad64(row_shr<1>(H2), 0x400u, V2);  // lanes 0..2 < 2^41, lanes 3..9 = U
   return ((uint32_t)V2 & m3) + row_shr<1>((uint32_t)(V2 >> 26) & lt3);
 }
+// both inputs of magnitude ≤ 15 with zero idle lanes; result magnitude 1 (< 2^26 + 2^16), idle lanes zero
+HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint32_t lt3) {
+  uint64_t lo = 0, hi = 0;
+  wfe_prod(a, b, lo, hi);
+  return wfe_reduce(lo, hi, act, m3, lt3);
+}
+// a·b + c·d with ONE reduction (107 VALU instructions instead of 2 × 72 + the carry pass of the sum): the point
+// formulas end in "product − product" (Y3 = E·(D − X3) − 8·B², Y3 = r·(V − X3) − 2·Y1·J), and the subtrahend enters
+// as a negated factor.  Magnitudes: ma·mb + mc·md ≤ 225 (10·225·U² < 2^64).
+HD uint32_t wfe_mul2_body(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t act, uint32_t m3, uint32_t lt3) {
+  uint64_t lo = 0, hi = 0;
+  wfe_prod(a, b, lo, hi);
+  wfe_prod(c, d, lo, hi);
+  return wfe_reduce(lo, hi, act, m3, lt3);
+}
 // INL = true pastes the 72 VALU instructions in place (hot loops: no call/return, no argument moves,
 // and the scheduler can fill the DPP wait states across neighbouring multiplications); INL = false
 // calls one outlined copy (straight-line code that runs once — table, G additions, joins — where
@@ -226,18 +243,34 @@ static __device__ __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint
                                                                uint32_t lt3) {
   return wfe_mul_body(a, b, act, m3, lt3);
 }
+static __device__ __attribute__((noinline)) uint32_t wfe_mul2_fn(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t act,
+                                                                uint32_t m3, uint32_t lt3) {
+  return wfe_mul2_body(a, b, c, d, act, m3, lt3);
+}
 template <bool INL = false>
 HD uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) {
   return INL ? wfe_mul_body(a, b, k.act, k.m3, k.lt3) : wfe_mul_fn(a, b, k.act, k.m3, k.lt3);
+}
+template <bool INL = false>
+HD uint32_t wfe_mul2(uint32_t a, uint32_t b, uint32_t c, uint32_t d, const wk &k) {
+  return INL ? wfe_mul2_body(a, b, c, d, k.act, k.m3, k.lt3) : wfe_mul2_fn(a, b, c, d, k.act, k.m3, k.lt3);
 }
 #else
 static __host__ __device__ __attribute__((noinline)) uint32_t wfe_mul_fn(uint32_t a, uint32_t b, uint32_t act,
                                                                         uint32_t m3, uint32_t lt3) {
   return wfe_mul_body(a, b, act, m3, lt3);
 }
+static __host__ __device__ __attribute__((noinline)) uint32_t wfe_mul2_fn(uint32_t a, uint32_t b, uint32_t c, uint32_t d,
+                                                                         uint32_t act, uint32_t m3, uint32_t lt3) {
+  return wfe_mul2_body(a, b, c, d, act, m3, lt3);
+}
 template <bool INL = false>
 __host__ __device__ inline uint32_t wfe_mul(uint32_t a, uint32_t b, const wk &k) {
   return wfe_mul_fn(a, b, k.act, k.m3, k.lt3);
+}
+template <bool INL = false>
+__host__ __device__ inline uint32_t wfe_mul2(uint32_t a, uint32_t b, uint32_t c, uint32_t d, const wk &k) {
+  return wfe_mul2_fn(a, b, c, d, k.act, k.m3, k.lt3);
 }
 #endif
 template <bool INL = false>
@@ -302,21 +335,21 @@ HD wjac wjac_select(bool c, const wjac &a, const wjac &b) {
 }
 HD wjac wjac_from_aff(const waff &a, const wk &k) { return wjac{a.x, a.y, k.li == 0 ? 1u : 0u, false}; }
 
-// dbl-2009-l (same formula and magnitude bookkeeping as secp::jac_dbl)
+// dbl-2009-l with S = M (a squaring costs what a multiplication costs here): D = 2·((X + B)² − A − C) is 4·X·B —
+// one multiplication that waits for B only —, and Y3 = E·(D − X3) − 8·B² is ONE fused multiply-add, so C = B² is never
+// formed: five multiplications and a fused pair (≈ 6.5) instead of seven, the linear work of t and D gone.
 template <bool INL = false>
 WVF wjac wjac_dbl(const wjac &p, const wk &k) {
   const uint32_t A = wfe_sqr<INL>(p.x, k);
   const uint32_t B = wfe_sqr<INL>(p.y, k);
-  const uint32_t C = wfe_sqr<INL>(B, k);
-  uint32_t t = wfe_sqr<INL>(p.x + B, k);                      // in 2
-  t = t + wfe_neg1(A, k) + wfe_neg1(C, k);               // 5
-  const uint32_t D = wfe_weak(2u * t, k);                // 10 → 1
+  const uint32_t XB = wfe_mul<INL>(p.x, B, k);
+  wjac r;
+  r.z = wfe_mul<INL>(2u * p.y, p.z, k);
   const uint32_t E = 3u * A;                             // 3
   const uint32_t F = wfe_sqr<INL>(E, k);
-  wjac r;
-  r.x = wfe_weak(F + wfe_neg2(2u * D, k), k);            // 4 → 1
-  r.y = wfe_weak(wfe_mul<INL>(E, D + wfe_neg1(r.x, k), k) + wfe_neg8(8u * C, k), k);  // in 3,3; 10 → 1
-  r.z = wfe_mul<INL>(2u * p.y, p.z, k);
+  r.x = wfe_weak(F + wfe_neg8(8u * XB, k), k);           // X3 = F − 2D, 2D = 8·X·B: 1 + 9 → 1
+  // Y3 = E·(D − X3) + (−8B)·B: magnitudes 3·(4 + 2) + 9·1 = 27
+  r.y = wfe_mul2<INL>(E, 4u * XB + wfe_neg1(r.x, k), wfe_neg8(8u * B, k), B, k);
   r.inf = p.inf;
   return r;
 }
@@ -351,7 +384,8 @@ WVF wjac wjac_add(const wjac &p, const wjac &q, const wk &k) {
   r = wjac_select(p.inf, q, r);
   return r;
 }
-// madd-2007-bl (q affine, never infinity)
+// madd-2007-bl (q affine, never infinity) with Z3 = (Z1 + H)² − Z1Z1 − HH written as 2·Z1·H (S = M here) and
+// Y3 = r·(V − X3) − 2·Y1·J as ONE fused multiply-add: nine multiplications and a fused pair instead of eleven.
 template <bool INL = false>
 WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
   const uint32_t z1z1 = wfe_sqr<INL>(p.z, k);
@@ -365,10 +399,10 @@ WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
   const uint32_t r2 = 2u * rr;                // 8
   const uint32_t v = wfe_mul<INL>(p.x, i, k);
   wjac r;
+  r.z = wfe_mul<INL>(2u * p.z, h, k);         // 2 · 3
   r.x = wfe_weak(wfe_sqr<INL>(r2, k) + wfe_neg1(j, k) + wfe_neg2(2u * v, k), k);
-  const uint32_t y1j2 = 2u * wfe_mul<INL>(p.y, j, k);
-  r.y = wfe_weak(wfe_mul<INL>(r2, v + wfe_neg1(r.x, k), k) + wfe_neg2(y1j2, k), k);
-  r.z = wfe_weak(wfe_sqr<INL>(p.z + h, k) + wfe_neg1(z1z1, k) + wfe_neg1(hh, k), k);  // in 4; 5 → 1
+  // Y3 = r2·(V − X3) + (−2·Y1)·J: magnitudes 8·3 + 9·1 = 33
+  r.y = wfe_mul2<INL>(r2, v + wfe_neg1(r.x, k), wfe_neg8(2u * p.y, k), j, k);
   r.inf = false;
   const bool hz = wfe_is_zero(h);
   bool rz = false;
