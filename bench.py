@@ -44,6 +44,7 @@ ALGO_BYTES_PER_VERIFY = 118  # 32 hash + 65 sig + 20 signer in, 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 ROWS_PER_GPU = 4096          # BASELINE configs #3 (1 GPU) and #4 (4 GPUs × 4096)
 SEQ_ROUNDS = 1000            # latency p50 over ≥1000 rounds
+KERNEL_TIMING_EVERY = 4      # HIP-event pair around the verdict kernel of every 4th timed pass (≥ 50 samples at --steps 200)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 
 
@@ -313,6 +314,7 @@ def main():
         lat, kernel_ms, kernel_launches = [], 0.0, 0
         t0 = time.perf_counter()
         if dist is None:
+            bv.set_kernel_timing(KERNEL_TIMING_EVERY)         # an event pair costs ≈5 µs of a step: sample the passes
             bv.last_kernel_ms()                               # reset: the HIP-event pairs of the timed passes accumulate
             for _ in range(steps):
                 s0 = time.perf_counter()
@@ -402,6 +404,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": m["kname"], "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel_timing": f"HIP events on the library's stream around the verdict kernel of every "
+                                          f"{KERNEL_TIMING_EVERY if world == 1 else 1}th timed pass ({m['kernel_launches']} samples)",
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
                          "valu_issue": valu,
                          "note": "integer-VALU-bound path: HBM fraction is reported as required; valu_issue is "

@@ -106,6 +106,8 @@ struct ibft_ctx {
   bool read_pending = false;                         // the next tally must wait for ev_read
 
   // dominant-kernel timing
+  uint32_t time_every = 1;     // HIP-event pair around the verdict kernels of every n-th staged pass (0 = never)
+  uint32_t pass_counter = 0;
   std::vector<hipEvent_t> ev;  // pairs
   uint32_t ev_used = 0;
 };
@@ -680,6 +682,9 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   int dev = cfg ? cfg->device : 0;
   if (dev < 0 || dev >= ndev) return IBFT_E_NODEVICE;
   if (hipSetDevice(dev) != hipSuccess) return IBFT_E_NODEVICE;
+  // experiment: how much of a step is the host waking up?  IBFT_SPIN=1 asks the runtime to spin in synchronize calls
+  if (const char *e = getenv("IBFT_SPIN"))
+    if (atoi(e) == 1) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return IBFT_E_NODEVICE;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return IBFT_E_NODEVICE;  // gfx950-only code object
@@ -695,6 +700,8 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
     const int g = atoi(e);
     if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64) c->cold_group_force = (uint32_t)g;
   }
+  if (const char *e = getenv("IBFT_NO_EVENTS"))
+    if (atoi(e) == 1) c->time_every = 0;
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("IBFT_ROWS_KERNEL_MAX")) c->rows_kernel_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;
@@ -978,7 +985,8 @@ static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
   if (repeat == 0) repeat = 1;
   for (uint32_t k = 0; k < repeat; k++) {
     int rc;
-    if ((rc = enqueue_recover(c, c->staged_n, c->staged_pre, 0, true))) return rc;
+    const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
+    if ((rc = enqueue_recover(c, c->staged_n, c->staged_pre, 0, time_it))) return rc;
     if ((rc = enqueue_tally(c, c->staged_n))) return rc;
   }
   return IBFT_OK;
@@ -1060,6 +1068,14 @@ int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
   *ms = total;
   if (launches) *launches = c->ev_used;
   c->ev_used = 0;
+  return IBFT_OK;
+}
+
+int ibft_set_kernel_timing(ibft_ctx *c, uint32_t every_n) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->time_every = every_n;
+  c->pass_counter = 0;
   return IBFT_OK;
 }
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "ibft_verify_senders_wire", "ibft_wire_stage_seals", "ibft_seals_export_on",
     "ibft_set_validators_u256", "ibft_last_tally_wide",
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
-    "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest",
+    "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals",
 ]
@@ -125,6 +125,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_seals_export_on.argtypes = [vp, vp, vp, vp]
     L.ibft_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.ibft_set_kernel_timing.argtypes = [vp, C.c_uint32]
     L.ibft_cache_stats.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.ibft_last_dispatch.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_sync.argtypes = [vp]
@@ -387,6 +388,10 @@ class BatchVerifier:
         t = Tally()
         self._chk(self._L.ibft_seals_fetch_merged(self._h, _p(mask), C.byref(t)), "ibft_seals_fetch_merged")
         return mask_to_bool(mask, n_total), t
+
+    def set_kernel_timing(self, every_n: int) -> None:
+        """HIP-event pair around the verdict kernels of every n-th staged pass (1 = all, 0 = none)"""
+        self._chk(self._L.ibft_set_kernel_timing(self._h, every_n), "ibft_set_kernel_timing")
 
     def last_kernel_ms(self):
         ms, k = C.c_float(), C.c_uint32()

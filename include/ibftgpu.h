@@ -247,6 +247,9 @@ int ibft_seals_export_on(ibft_ctx *ctx, void *d_mask_dst, void *d_tally_dst, voi
 /* HIP-event time (ms) of the verdict kernels, measured on the context's own stream, summed over the
  * launches since the previous call of this function (which resets the sum), and their count.      */
 int ibft_last_kernel_ms(ibft_ctx *ctx, float *ms, uint32_t *launches);
+/* Time the verdict kernels of every n-th staged pass only (default 1 = every pass, 0 = never): an event pair
+ * costs ≈5 µs of a 0.45 ms step (profiles/r02_launch_gap.txt).                                            */
+int ibft_set_kernel_timing(ibft_ctx *ctx, uint32_t every_n);
 /* Warm-path statistics: validators whose table is built, how many verdict passes ran with /
  * without the warm kernel since the context was created, and the lanes-per-signature (64 = one
  * wavefront per signature … 1 = lane kernel) the last warm pass used.                         */
