@@ -148,23 +148,41 @@ def profile_attachments(kname: str, rows: int, avg_kernel_s: float):
             text = open(path).read()
             m_rows = re.search(r"^# rows per launch: (\d+)", text, re.M)
             file_rows = int(m_rows.group(1)) if m_rows else 1024
-            m = re.search(re.escape(kname.split("<")[0]) + r"<[^>]*>\s+SQ_INSTS_VALU\s+([0-9.]+) per launch", text)
+            kshort = re.escape(kname.split("<")[0]) + r"<[^>]*>"
+            m = re.search(kshort + r"\s+SQ_INSTS_VALU\s+([0-9.]+) per launch", text)
             if not (m and file_rows == rows):
                 continue
             insts = float(m.group(1))
-            m_mad = re.search(r"^# v_mad_u64_u32 share of VALU \(static, hot loops\): ([0-9.]+)", text, re.M)
-            f_mad = float(m_mad.group(1)) if m_mad else 15.0 / 72.0  # wfe_mul: 15 mads of 72 VALU instructions
-            # peaks per SIMD: the guide's 2 cycles per wave64 VALU instruction; and the measured mix on this chip
-            # (profiles/r01_ubench_int.txt: v_mad_u64_u32 saturates at 4.75 cycles, plain/DPP VALU at 2.7)
-            peak_guide = 1024 * 2.4e9 / 2.0
-            peak_mix = 1024 * 2.4e9 / (f_mad * 4.75 + (1.0 - f_mad) * 2.7)
+            ms = re.search(kshort + r"\s+SQ_INSTS_SALU\s+([0-9.]+) per launch", text)
+            salu = float(ms.group(1)) if ms else 0.0
+            # static mix of the hot loops (tools/static_mix.py) and the measured issue time of each class
+            # (tools/ubench_wave.hip → profiles/r02a_ubench_wave.txt, wall ns per wave-instruction per SIMD)
+            f_mad, f_dpp, nop_per_valu = 15.0 / 72.0, 0.38, 0.065
+            for sp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_static_mix.txt")), reverse=True):
+                st = open(sp).read()
+                if kname.split("<")[0] in st:
+                    f_mad = float(re.search(r"v_mad_u64_u32 share of VALU[^:]*: ([0-9.]+)", st).group(1))
+                    f_dpp = float(re.search(r"DPP share of VALU[^:]*: ([0-9.]+)", st).group(1))
+                    nop_per_valu = float(re.search(r"s_nop per VALU instruction[^:]*: ([0-9.]+)", st).group(1))
+                    break
+            waves_per_simd = max(1.0, rows * 16 / 64 / 1024) if "rows_kernel" in kname else 1.0
+            # ns per wave-instruction per SIMD: plain VALU / DPP / v_mad_u64_u32 at 1 and at 2 wavefronts per SIMD
+            t_plain, t_dpp, t_mad = (2.07, 2.22, 2.50) if waves_per_simd < 1.5 else (1.11, 1.93, 2.19)
+            ns_per_valu = f_mad * t_mad + (f_dpp - 0.0) * t_dpp + (1.0 - f_mad - f_dpp) * t_plain
+            peak_measured = 1024 / (ns_per_valu * 1e-9)            # VALU wave-instructions per second, whole chip
+            peak_guide = 1024 * 2.4e9 / 2.0                        # the guide: a wave64 VALU instruction issues over 2 cycles
             ach = insts / avg_kernel_s
-            valu = {"wave_insts_per_launch": insts, "achieved_ginst_s": ach / 1e9,
+            valu = {"wave_insts_per_launch": insts, "salu_insts_per_launch": salu, "achieved_ginst_s": ach / 1e9,
                     "peak_ginst_s": peak_guide / 1e9, "frac": ach / peak_guide,
-                    "peak_measured_mix_ginst_s": peak_mix / 1e9, "frac_of_measured_mix": ach / peak_mix,
-                    "mad_share": f_mad, "source": os.path.relpath(path, ROOT)}
+                    "peak_at_this_occupancy_ginst_s": peak_measured / 1e9, "frac_of_peak_at_this_occupancy": ach / peak_measured,
+                    "waves_per_simd": waves_per_simd, "mad_share": f_mad, "dpp_share": f_dpp, "s_nop_per_valu": nop_per_valu,
+                    "note": "peak_ginst_s = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (the guide); "
+                            "peak_at_this_occupancy = 1024 SIMDs / (mix-weighted issue time of ONE resident wavefront per SIMD: "
+                            "2.07 ns plain, 2.22 ns DPP, 2.50 ns v_mad_u64_u32 — profiles/r02a_ubench_wave.txt): this batch size "
+                            "gives the row-per-signature kernel exactly one wavefront per SIMD, so that is its ceiling",
+                    "source": os.path.relpath(path, ROOT)}
             break
-    except (OSError, ValueError):
+    except (OSError, ValueError, AttributeError):
         pass
     return traffic, valu
 
