@@ -375,20 +375,23 @@ int enqueue_tally(ibft_ctx *c, uint32_t n) {
   t.host_mask = c->dh_mask;
   t.host_tally = c->dh_tally;
   const dim3 grid(std::max(1u, (n + ibftk::TALLY_ROWS_PER_BLOCK - 1) / ibftk::TALLY_ROWS_PER_BLOCK)), block(ibftk::TALLY_THREADS);
-  // one workgroup (n ≤ 4 096) keeps the distinct-sender bitmap in LDS — no global atomics on the latency-critical
-  // sizes; beyond (or when the bitmap does not fit 32 KiB of dynamic LDS) the device-scope bitmap + ticket form
+  // one workgroup (n ≤ 4 096): everything stays in the workgroup — no global atomics on the latency-critical sizes;
+  // beyond: ticket form, each workgroup merging its LDS bitmap into the HBM one word by word.  A validator set whose
+  // bitmap does not fit 48 KiB of dynamic LDS (> 393 216 validators) sends every row's bit to HBM directly.
   const size_t lds = (size_t)((c->n_validators + 31) / 32) * 4;
-  const bool single = grid.x == 1 && lds <= 32768;
+  t.lds_bitmap = lds <= 49152 ? 1u : 0u;
+  const size_t dyn = t.lds_bitmap ? lds : 0;
+  const bool single = grid.x == 1 && t.lds_bitmap;
   if (single) {
     if (c->power_words == 1)
-      hipLaunchKernelGGL((ibftk::tally_kernel<1, false>), grid, block, lds, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<1, false>), grid, block, dyn, c->stream, t);
     else
-      hipLaunchKernelGGL((ibftk::tally_kernel<4, false>), grid, block, lds, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<4, false>), grid, block, dyn, c->stream, t);
   } else {
     if (c->power_words == 1)
-      hipLaunchKernelGGL((ibftk::tally_kernel<1, true>), grid, block, 0, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<1, true>), grid, block, dyn, c->stream, t);
     else
-      hipLaunchKernelGGL((ibftk::tally_kernel<4, true>), grid, block, 0, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<4, true>), grid, block, dyn, c->stream, t);
   }
   HIPCHK(c, hipGetLastError());
   c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally

@@ -707,6 +707,7 @@ struct tally_args {
   const uint64_t *quorum;   // TALLY_SUM_WORDS
   uint64_t *out;            // TALLY_OUT_WORDS
   uint64_t *host_mask, *host_tally;  // mapped pinned host memory (or null): no device-to-host copy commands
+  uint32_t lds_bitmap;      // the launch carries ⌈n_validators/32⌉ words of dynamic LDS for the workgroup's bitmap
 };
 
 // MULTI = false: ONE workgroup (n ≤ TALLY_ROWS_PER_BLOCK, the latency-critical sizes): the distinct-sender set is
@@ -717,7 +718,7 @@ template <int PW, bool MULTI>
 __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   constexpr int NP = 2 * PW;
   constexpr int RPT = TALLY_ROWS_PER_BLOCK / TALLY_THREADS;
-  extern __shared__ uint32_t lseen[];  // MULTI = false only
+  extern __shared__ uint32_t lseen[];  // ⌈n_validators/32⌉ words when a.lds_bitmap
   __shared__ uint64_t wds[TALLY_ROWS_PER_BLOCK / 64];
   __shared__ uint64_t part[NP + 1][TALLY_THREADS / 64];
   __shared__ uint32_t last_flag;
@@ -746,8 +747,11 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     }
     wds[tid] = w;
   }
-  if (!MULTI)
-    for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS) lseen[i] = 0;
+  // the workgroup's own distinct-sender bitmap is always in LDS (a.lds_bitmap = 0 only when a huge validator set
+  // does not fit: MULTI then sends every row's bit to the HBM bitmap directly)
+  const uint32_t seen_words = (a.n_validators + 31) / 32;
+  if (a.lds_bitmap)
+    for (uint32_t i = tid; i < seen_words; i += TALLY_THREADS) lseen[i] = 0;
   uint32_t pw[RPT][NP];
 #pragma unroll
   for (int j = 0; j < RPT; j++)
@@ -764,9 +768,27 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     first[j] = false;
     if (bit && vi[j] >= 0) {  // unknown senders contribute 0 (validator_manager.go:88-92)
       const uint32_t m = 1u << (vi[j] & 31);
-      const uint32_t old = MULTI ? atomicOr(&a.seen[vi[j] >> 5], m)    // device scope: one set for all workgroups
-                                 : atomicOr(&lseen[vi[j] >> 5], m);
+      const uint32_t old = a.lds_bitmap ? atomicOr(&lseen[vi[j] >> 5], m)
+                                        : atomicOr(&a.seen[vi[j] >> 5], m);  // device scope (huge sets only)
       first[j] = !(old & m);  // distinct-sender set (validator_manager.go:147-155)
+    }
+  }
+  if (MULTI && a.lds_bitmap) {
+    // Several workgroups: the set is shared through a bitmap in HBM, but device-scope atomics on one cache line
+    // retire at ≈12 ns each — one per ROW made this kernel 52 µs at 4 096 rows.  So the workgroup merges its LDS
+    // bitmap WORD by word (one returning atomicOr per non-empty word) and keeps, per word, the bits it was the
+    // first to set: a row counts iff it was first inside its workgroup AND its workgroup was first for the validator.
+    __syncthreads();
+    for (uint32_t i = tid; i < seen_words; i += TALLY_THREADS) {
+      const uint32_t mine = lseen[i];
+      if (mine) lseen[i] = mine & ~atomicOr(&a.seen[i], mine);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RPT; j++)
+    {
+      const uint32_t v = first[j] ? (uint32_t)vi[j] : 0u;  // (first[j] implies vi[j] ≥ 0)
+      first[j] = first[j] && ((lseen[v >> 5] >> (v & 31)) & 1u);
     }
   }
   uint64_t p[NP];
