@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libibftgpu.so")
 SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "modinv_dev.h",
-           "secp256k1_dev.h", "keccak_dev.h", os.path.join("..", "..", "include", "ibftgpu.h")]
+           "sign_dev.h", "secp256k1_dev.h", "keccak_dev.h", os.path.join("..", "..", "include", "ibftgpu.h")]
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
 
@@ -64,7 +64,7 @@ def build_devtest(force: bool = False) -> str:
 
 def build_host_harness(force: bool = False) -> str:
     """TEST-ONLY: the device arithmetic headers compiled for the CPU (hipcc host pass)."""
-    deps = ["host_arith_harness.hip", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h", "wire_dev.h", "verify_dev.h"]
+    deps = ["host_arith_harness.hip", "sign_dev.h", "recover_dev.h", "modinv_dev.h", "secp256k1_dev.h", "keccak_dev.h", "wire_dev.h", "verify_dev.h"]
     if force or _stale(HOST_HARNESS, deps):
         subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
                                "-o", HOST_HARNESS, os.path.join(CSRC, "host_arith_harness.hip")], cwd=CSRC)

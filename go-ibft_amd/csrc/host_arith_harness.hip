@@ -12,6 +12,7 @@
 
 #include "recover_dev.h"
 #include "verify_dev.h"
+#include "sign_dev.h"
 #include "modinv_dev.h"
 #include "wire_dev.h"
 
@@ -140,6 +141,19 @@ int dev_recover_address(const uint8_t *digest32, const uint8_t *sig65, uint32_t 
   uint32_t a[5];
   bool ok = ibftk::recover_address(g_gtab.data(), secp::from_be32(digest32), secp::from_be32(sig65),
                                    secp::from_be32(sig65 + 32), sig65[64], flags, a);
+  memcpy(addr20, a, 20);
+  return ok ? 1 : 0;
+}
+
+// the signing row (sign_dev.h): sig65 = r ‖ s ‖ v and the signer's address; returns 0 for an unusable key
+int dev_sign(const uint8_t *sk32, const uint8_t *digest32, uint8_t *sig65, uint8_t *addr20) {
+  dev_gtab_init();
+  u256 r, s;
+  uint32_t v, a[5];
+  bool ok = ibftk::sign_row(g_gtab.data(), sk32, digest32, r, s, v, a);
+  secp::to_be32(sig65, r);
+  secp::to_be32(sig65 + 32, s);
+  sig65[64] = (uint8_t)v;
   memcpy(addr20, a, 20);
   return ok ? 1 : 0;
 }

@@ -1101,6 +1101,42 @@ int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) 
   return IBFT_OK;
 }
 
+// f4: the committed seals of a simulated validator set, one per row.
+int ibft_sign_seals(ibft_ctx *c, const uint8_t *sk32, const uint8_t *hash32, size_t n, uint8_t *out_sig65,
+                    uint8_t *out_signer20, uint8_t *out_ok) {
+  if (!c || (n && (!sk32 || !hash32 || !out_sig65))) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  HIPCHK(c, hipSetDevice(c->device));
+  c->wire_valid = false;
+  c->staged_n = 0;
+  if (n == 0) return IBFT_OK;
+  int rc;
+  if ((rc = upload(c, c->d_payload, sk32, n * 32))) return rc;  // the sender-payload column is free during a seal batch
+  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
+  ibftk::sign_args a;
+  a.gtab = (const uint32_t *)c->d_gtab.p;
+  a.sk32 = (const uint8_t *)c->d_payload.p;
+  a.hash32 = (const uint8_t *)c->d_hash.p;
+  a.sig65 = (uint8_t *)c->d_sig.p;
+  a.signer20 = (uint8_t *)c->d_signer.p;
+  a.ok = (uint8_t *)c->d_pre.p;
+  a.n = (uint32_t)n;
+  const uint32_t blocks = (uint32_t)((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(ibftk::sign_lane_kernel, dim3(blocks), dim3(ibftk::ROWS_PER_BLOCK), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemsetAsync(c->d_payload.p, 0, n * 32, c->stream));  // the keys do not outlive the call in HBM
+  HIPCHK(c, hipMemcpyAsync(out_sig65, c->d_sig.p, n * 65, hipMemcpyDeviceToHost, c->stream));
+  if (out_signer20) HIPCHK(c, hipMemcpyAsync(out_signer20, c->d_signer.p, n * 20, hipMemcpyDeviceToHost, c->stream));
+  if (out_ok) HIPCHK(c, hipMemcpyAsync(out_ok, c->d_pre.p, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // hash32 / sig65 / signer20 now hold exactly what ibft_seals_stage would have uploaded for these seals:
+  // the batch is staged (rows whose key was refused carry a zero signature, which every verifier rejects)
+  c->staged_n = (uint32_t)n;
+  c->staged_pre = false;
+  return IBFT_OK;
+}
+
 int ibft_sync(ibft_ctx *c) {
   if (!c) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);

@@ -30,6 +30,7 @@
 
 #include "recover_dev.h"
 #include "verify_dev.h"
+#include "sign_dev.h"
 #include "wave_fe_dev.h"
 #include "wire_dev.h"
 
@@ -67,6 +68,54 @@ __global__ void gtab_build_kernel(uint32_t *__restrict__ gtab) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= GTAB_WINDOWS * GTAB_ENTRIES) return;
   gtab_entry(tid / GTAB_ENTRIES, tid % GTAB_ENTRIES, gtab + (size_t)GTAB_ENTRY_DWORDS * tid);
+}
+
+// ---- f4: signing side, one lane per seal (sign_dev.h) ------------------------------------------------
+// Writes the same columns ibft_seals_stage fills (hash32 is already there; sig65 and signer20 are produced
+// here), so the batch it signed is a staged batch: ibft_seals_run verifies it without another upload.
+struct sign_args {
+  const uint32_t *gtab;
+  const uint8_t *sk32;     // n × 32, big-endian secret keys
+  const uint8_t *hash32;   // n × 32, the proposal hash each row seals
+  uint8_t *sig65;          // n × 65 out
+  uint8_t *signer20;       // n × 20 out
+  uint8_t *ok;             // n out: 1 = signed, 0 = key outside [1, n)
+  uint32_t n;
+};
+__global__ void __launch_bounds__(ROWS_PER_BLOCK) sign_lane_kernel(sign_args a) {
+  const uint32_t row = blockIdx.x * (uint32_t)ROWS_PER_BLOCK + threadIdx.x;
+  const bool live = row < a.n;
+  const uint32_t src = live ? row : a.n - 1;  // idle lanes sign the last row again and store nothing
+  uint8_t sk[32], dg[32];
+  const uint32_t *ks = reinterpret_cast<const uint32_t *>(a.sk32 + 32ull * src);
+  const uint32_t *ds = reinterpret_cast<const uint32_t *>(a.hash32 + 32ull * src);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint32_t kw = ks[i], dw = ds[i];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      sk[4 * i + b] = (uint8_t)(kw >> (8 * b));
+      dg[4 * i + b] = (uint8_t)(dw >> (8 * b));
+    }
+  }
+  u256 r, s;
+  uint32_t v, addr[5];
+  const bool ok = sign_row(a.gtab, sk, dg, r, s, v, addr);
+  if (!live) return;
+  uint8_t *o = a.sig65 + 65ull * row;  // 65-byte rows are not dword aligned: byte stores
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      o[4 * (7 - i) + b] = (uint8_t)(r.v[i] >> (8 * (3 - b)));
+      o[32 + 4 * (7 - i) + b] = (uint8_t)(s.v[i] >> (8 * (3 - b)));
+    }
+  }
+  o[64] = (uint8_t)v;
+  uint32_t *ad = reinterpret_cast<uint32_t *>(a.signer20 + 20ull * row);
+#pragma unroll
+  for (int i = 0; i < 5; i++) ad[i] = addr[i];
+  a.ok[row] = ok ? 1 : 0;
 }
 
 // ---- proposal hash + a1 ---------------------------------------------------------------

@@ -36,7 +36,7 @@ EXPORTS = [
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
-    "ibft_group_set_validators_u256", "ibft_group_verify_seals",
+    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -121,6 +121,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_launch.argtypes = [vp, C.c_uint32]
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
+    L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_seals_export_on.argtypes = [vp, vp, vp, vp]
@@ -351,6 +352,20 @@ class BatchVerifier:
         t = Tally()
         self._chk(self._L.ibft_seals_run(self._h, _p(self._run_mask), C.byref(t)), "ibft_seals_run")
         return mask_to_bool(self._run_mask, n), t
+
+    def sign_seals(self, sk32, hash32):
+        """ibft_sign_seals (simulators only): (sig65 u8[n,65], signer20 u8[n,20], ok bool[n]); leaves the batch staged"""
+        sk = np.ascontiguousarray(sk32, dtype=np.uint8).reshape(-1, 32)
+        hs = np.ascontiguousarray(hash32, dtype=np.uint8).reshape(-1, 32)
+        n = len(sk)
+        if len(hs) != n:
+            raise ValueError("one hash per key")
+        sig = np.zeros((n, 65), dtype=np.uint8)
+        signer = np.zeros((n, 20), dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.uint8)
+        self._chk(self._L.ibft_sign_seals(self._h, _p(sk), _p(hs), n, _p(sig), _p(signer), _p(ok)), "ibft_sign_seals")
+        self._staged = n
+        return sig, signer, ok.astype(bool)
 
     def seals_device_ptrs(self):
         dm, dt, w = C.c_void_p(), C.c_void_p(), C.c_size_t()

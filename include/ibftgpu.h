@@ -258,6 +258,21 @@ int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uin
 /* Lanes per signature used by the last verdict pass: cold kernel (1 = ecrecover_lane_kernel,
  * 2/4/8 = ecrecover_group_kernel) and warm kernel (0 = none ran, 1 = lane, 2..64 = group).     */
 int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);
+/* ---- f4: the signing side, for SIMULATORS ----------------------------------
+ * Replaces, for a process that plays n validators at once, the n calls of Backend.BuildCommitMessage
+ * (/root/reference/core/backend.go:12-34; sendCommitMessage, core/ibft.go:898-909) that each produce one
+ * committed seal: row i gets the 65-byte seal r ‖ s ‖ v of hash32[i] under the secp256k1 key sk32[i]
+ * (32 bytes big-endian, must lie in [1, n)), always low-s, v = parity of R.y after the low-s flip — i.e. a
+ * seal ibft_verify_seals accepts under every flag — and the signer address keccak256(X‖Y)[12..32) of that
+ * key.  out_signer20 and out_ok may be NULL; out_ok[i] = 0 (zero signature, zero address) for a refused key.
+ * The nonce is deterministic: k = keccak256(sk ‖ hash ‖ LE32(ctr)) mod n with the first usable ctr
+ * (go-ibft_amd/csrc/sign_dev.h) — the CPU oracle's rule, so device seals are byte-identical to the
+ * oracle's; it is not RFC 6979.  NOT for a production validator's key: keys cross PCIe in the clear and sit
+ * in HBM for the duration of the call (the column is zeroed before the call returns), and the kernel is not
+ * written to be constant-time.  On return the batch is STAGED (hash32 / sig65 / signer20 columns are resident
+ * exactly as after ibft_seals_stage): ibft_seals_run verifies what was just signed without another upload.  */
+int ibft_sign_seals(ibft_ctx *ctx, const uint8_t *sk32, const uint8_t *hash32, size_t n, uint8_t *out_sig65,
+                    uint8_t *out_signer20, uint8_t *out_ok);
 /* Block the host until the context's stream is idle.                               */
 int ibft_sync(ibft_ctx *ctx);
 

@@ -223,3 +223,28 @@ def test_variable_time_divsteps_match_constant_time(dev):
         cases.append((int(rng.integers(-40, 40)), int(rng.integers(0, 2**32)) | 1, int(rng.integers(0, 2**32))))
     for zeta, f0, g0 in cases:
         assert dev.dev_divsteps_agree(zeta, f0, g0) == 1, (zeta, f0, g0)
+
+
+def test_sign_row_matches_oracle_byte_for_byte(dev):
+    """sign_dev.h on the CPU against oracle/secp256k1.c:orc_sign — same deterministic nonce, so the 65 bytes
+    are identical; the address is the oracle's address of the oracle's public key; keys outside [1, n) fail."""
+    from oracle import binding as O
+    rng = np.random.default_rng(41)
+    keys = [1, 2, N - 1, N - 2, (N - 1) // 2, (N + 1) // 2, 2**255 % N] + \
+           [int.from_bytes(rng.bytes(32), "big") % (N - 1) + 1 for _ in range(40)]
+    digests = [bytes(32), b"\xff" * 32, b32(N), b32(N - 1), b32(N + 1)] + [rng.bytes(32) for _ in range(6)]
+    high = 0
+    for i, sk in enumerate(keys):
+        for dg in (digests if i < 8 else digests[5 + i % 6:6 + i % 6]):
+            sig, addr = C.create_string_buffer(65), C.create_string_buffer(20)
+            assert dev.dev_sign(b32(sk), dg, sig, addr) == 1
+            assert sig.raw == O.sign(b32(sk), dg)
+            assert addr.raw == O.address(O.pubkey(b32(sk)))
+            assert int.from_bytes(sig.raw[32:64], "big") <= (N - 1) // 2          # low-s, always
+            assert O.ecrecover(dg, sig.raw, 1) == O.pubkey(b32(sk))               # strict-low-s recover agrees
+            high += sig.raw[64]
+    assert high > 0                                                               # both parities seen
+    for bad in (0, N, N + 1, 2**256 - 1):
+        sig, addr = C.create_string_buffer(65), C.create_string_buffer(20)
+        assert dev.dev_sign(b32(bad), digests[5], sig, addr) == 0
+        assert sig.raw == bytes(65) and addr.raw == bytes(20)
