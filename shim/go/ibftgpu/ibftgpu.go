@@ -219,6 +219,22 @@ func (c *Ctx) SealsRun(n int) ([]uint64, Tally, error) {
 	return mask, tally(t), c.check(rc)
 }
 
+// SignSeals = n × Backend.BuildCommitMessage's committed seal (core/backend.go:12-34) for a SIMULATOR that plays
+// n validators in one process: sk and hashes are n×32 bytes; returns the n×65 seals, the n×20 signer addresses
+// and ok[i] == 0 for a key outside [1, n).  Leaves the batch resident: SealsRun(n) verifies it without an upload.
+// Not for a production validator's key (include/ibftgpu.h, ibft_sign_seals).
+func (c *Ctx) SignSeals(sk, hashes []byte) (seals, signers, ok []byte, err error) {
+	n := len(sk) / 32
+	if n == 0 || len(hashes) != 32*n {
+		return nil, nil, nil, ErrFallback
+	}
+	seals, signers, ok = make([]byte, 65*n), make([]byte, 20*n), make([]byte, n)
+	rc := C.ibft_sign_seals(c.h, (*C.uint8_t)(unsafe.Pointer(&sk[0])), (*C.uint8_t)(unsafe.Pointer(&hashes[0])),
+		C.size_t(n), (*C.uint8_t)(unsafe.Pointer(&seals[0])), (*C.uint8_t)(unsafe.Pointer(&signers[0])),
+		(*C.uint8_t)(unsafe.Pointer(&ok[0])))
+	return seals, signers, ok, c.check(rc)
+}
+
 // Group is one process driving several MI355X (ibft_group_*): the rows of a batch are sharded over the
 // devices in 64-aligned ranges and ONE RCCL all-reduce inside the library merges the verdict words and the
 // tally partials — for validator sets beyond a single GPU's batch (BASELINE configs #4 / #5).
