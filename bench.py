@@ -61,7 +61,8 @@ def load_round(n_total: int, lo: int, hi: int, byzantine: bool = False):
     time); other sizes are generated with the oracle's SIGNER — input generation only, nothing of the
     oracle is on the timed path."""
     if n_total == 4096 and not byzantine and os.path.exists(FIXTURE):
-        g = np.load(FIXTURE)
+        with np.load(FIXTURE) as z:
+            g = {k: z[k] for k in z.files}   # materialised once: an NpzFile re-reads the archive on every g[k]
         return {"addrs": g["addrs"], "power": g["power"], "hash32": g["hash32"][lo:hi], "seal65": g["seal65"][lo:hi],
                 "signer20": g["signer20"][lo:hi], "pre": None, "src": "fixture", "fx": g}
     from oracle import workload as W

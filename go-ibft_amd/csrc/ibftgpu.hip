@@ -35,6 +35,7 @@ struct ibft_ctx {
   int device = 0;
   uint32_t flags = 0;
   uint32_t max_rows = DEFAULT_MAX_ROWS;
+  uint32_t row_cap = 0;  // rows the columns can hold: max_rows, or 2·⌈max_rows/64⌉·64 once a message set was verified
   uint32_t kernel = IBFT_KERNEL_AUTO;
   hipStream_t stream = nullptr;
   std::string last_error;
@@ -101,6 +102,9 @@ struct ibft_ctx {
   uint64_t *h_tally = nullptr;
   uint64_t *h_digest = nullptr;  // 32-byte staging for a1 digests (never shared with results a kernel may still deliver)
   uint64_t *dh_mask = nullptr, *dh_tally = nullptr;  // the same pinned buffers as the device sees them
+  // message sets (ibft_verify_messages): sender words then valid words, ⌈max_rows/64⌉ each
+  uint64_t *h_set = nullptr, *dh_set = nullptr;
+  DevBuf d_set;
   bool host_direct = false;                          // the last tally kernel delivered its results there
   hipEvent_t ev_ready = nullptr, ev_read = nullptr;  // ibft_seals_export_on: results ready / results read
   bool read_pending = false;                         // the next tally must wait for ev_read
@@ -146,9 +150,10 @@ void release(DevBuf &b) {
 
 int mask_words(size_t n) { return (int)((n + 63) / 64); }
 
-int alloc_rows(ibft_ctx *c) {
-  size_t m = c->max_rows;
+int alloc_rows(ibft_ctx *c, uint32_t rows) {
+  size_t m = rows;
   int rc;
+  const void *old_mask = c->d_mask.p;
   if ((rc = ensure(c, c->d_hash, m * 32))) return rc;
   if ((rc = ensure(c, c->d_sig, m * 65 + 64))) return rc;
   if ((rc = ensure(c, c->d_signer, m * 20))) return rc;
@@ -157,13 +162,14 @@ int alloc_rows(ibft_ctx *c) {
   if ((rc = ensure(c, c->d_off, (m + 1) * 4))) return rc;
   if ((rc = ensure(c, c->d_mask, (size_t)mask_words(m) * 8))) return rc;
   if ((rc = ensure(c, c->d_mask_out, (size_t)mask_words(m) * 8))) return rc;
-  c->mask_dirty_words = ~0u;
+  if (c->d_mask.p != old_mask) c->mask_dirty_words = ~0u;  // fresh memory: the next verdict launch zeroes it first
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
   if ((rc = ensure(c, c->d_tally, (size_t)ibftk::TALLY_OUT_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_acc, (size_t)ibftk::TALLY_ACC_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_quorum, (size_t)ibftk::TALLY_SUM_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_H, 4 * 8))) return rc;
   if ((rc = ensure(c, c->d_warm_done, m))) return rc;
+  c->row_cap = std::max(c->row_cap, rows);
   return IBFT_OK;
 }
 
@@ -209,7 +215,7 @@ int next_events(ibft_ctx *c, hipEvent_t *start, hipEvent_t *stop) {
 // zero the work mask unless the last tally already left it zero
 int clean_mask(ibft_ctx *c) {
   if (c->mask_dirty_words == 0) return IBFT_OK;
-  HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->max_rows) * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_mask.p, 0, (size_t)mask_words(c->row_cap) * 8, c->stream));
   c->mask_dirty_words = 0;
   return IBFT_OK;
 }
@@ -710,12 +716,14 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   int rc = IBFT_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
-    if ((rc = alloc_rows(c))) break;
+    if ((rc = alloc_rows(c, c->max_rows))) break;
     if (hipMemsetAsync(c->d_acc.p, 0, c->d_acc.cap, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_tally.p, 0, c->d_tally.cap, c->stream) != hipSuccess) { rc = IBFT_E_HIP; break; }
     if (hipHostMalloc((void **)&c->h_mask, (size_t)mask_words(c->max_rows) * 8 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_tally, 128) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_digest, 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if (hipHostMalloc((void **)&c->h_set, (size_t)mask_words(c->max_rows) * 16 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if ((rc = ensure(c, c->d_set, (size_t)mask_words(c->max_rows) * 16))) break;
     // zero-copy result delivery (tally_kernel writes the verdict words and its own result into the
     // pinned buffers); IBFT_NO_HOST_DIRECT=1 keeps the two device-to-host copies instead
     if (!getenv("IBFT_NO_HOST_DIRECT")) {
@@ -723,6 +731,8 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
       if (hipHostGetDevicePointer(&dm, c->h_mask, 0) == hipSuccess && hipHostGetDevicePointer(&dt, c->h_tally, 0) == hipSuccess) {
         c->dh_mask = (uint64_t *)dm;
         c->dh_tally = (uint64_t *)dt;
+        void *ds = nullptr;
+        if (hipHostGetDevicePointer(&ds, c->h_set, 0) == hipSuccess) c->dh_set = (uint64_t *)ds;
       }
     }
     if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
@@ -747,7 +757,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
-                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1]})
+                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set})
     release(*b);
   comm_release(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -755,6 +765,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_tally) (void)hipHostFree(c->h_tally);
   if (c->h_digest) (void)hipHostFree(c->h_digest);
+  if (c->h_set) (void)hipHostFree(c->h_set);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1098,6 +1109,101 @@ int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) 
   std::lock_guard<std::mutex> lk(c->mu);
   if (cold_lanes) *cold_lanes = c->last_cold_group;
   if (warm_lanes) *warm_lanes = c->last_group;
+  return IBFT_OK;
+}
+
+// A whole PREPARE or COMMIT set in one call (kernels.hip.h: "a message set in one pass").
+int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
+                         const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
+                         const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw, size_t raw_len,
+                         uint64_t round,
+                         const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally) {
+  if (!c || (n && (!off || !msg_sig65 || !from20 || !hash32 || !hash_len || !out_sender_mask || !out_valid_mask)))
+    return IBFT_E_INVAL;
+  if ((raw_len && !raw) || raw_len > (1ull << 31)) return IBFT_E_INVAL;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  if (n && off[n] && !payload) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  c->wire_valid = false;
+  c->staged_n = 0;
+  const uint32_t half = ((uint32_t)n + 63u) & ~63u;
+  const uint32_t rows = seal65 ? half + (uint32_t)n : (uint32_t)n;  // verdict rows of the one launch
+  if ((rc = alloc_rows(c, 2 * (((uint32_t)c->max_rows + 63u) & ~63u)))) return rc;
+  // the proposal the set is checked against: its digest, or raw ‖ BE64(round) hashed once and remembered
+  if (digest32) {
+    c->have_H = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
+    memcpy(c->h_digest, digest32, 32);
+    HIPCHK(c, hipMemcpyAsync(c->d_H.p, c->h_digest, 32, hipMemcpyHostToDevice, c->stream));
+  } else if ((rc = ensure_proposal_hash(c, raw, raw_len, round))) {
+    return rc;
+  }
+  if (n == 0) {
+    if (tally) {
+      memset(tally, 0, sizeof *tally);
+      tally->quorum_lo = c->quorum_w[0];
+      tally->quorum_hi = c->quorum_w[1];
+    }
+    for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = 0;
+    return IBFT_OK;
+  }
+  uint8_t *d_hash = (uint8_t *)c->d_hash.p, *d_sig = (uint8_t *)c->d_sig.p, *d_signer = (uint8_t *)c->d_signer.p,
+          *d_pre = (uint8_t *)c->d_pre.p;
+  const size_t pbytes = off[n];
+  if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
+  if (pbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, payload, pbytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_sig, msg_sig65, n * 65, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_signer, from20, n * 20, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_hash + 32ull * half, hash32, n * 32, hipMemcpyHostToDevice, c->stream));  // carried hashes
+  HIPCHK(c, hipMemcpyAsync(c->d_hash_len.p, hash_len, n, hipMemcpyHostToDevice, c->stream));
+  // rows the host rejected before any crypto: applied to the verdict words afterwards (the verdict launch runs them
+  // like any other row — skipping work inside a lock-step wavefront saves nothing)
+  if (sender_pre) HIPCHK(c, hipMemcpyAsync(d_pre, sender_pre, n, hipMemcpyHostToDevice, c->stream));
+  if (valid_pre) HIPCHK(c, hipMemcpyAsync(d_pre + half, valid_pre, n, hipMemcpyHostToDevice, c->stream));
+  if (seal65) {
+    HIPCHK(c, hipMemcpyAsync(d_sig + 65ull * half, seal65, n * 65, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_signer + 20ull * half, d_signer, n * 20, hipMemcpyDeviceToDevice, c->stream));
+    if (half != n)  // rows n..half−1 sit between the two groups: a zero signature is rejected by every kernel
+      HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
+  }
+  hipLaunchKernelGGL(ibftk::payload_digest_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
+                     (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n, d_hash);
+  HIPCHK(c, hipGetLastError());
+  c->ev_used = 0;
+  const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
+  if ((rc = enqueue_recover(c, rows, false, 0, time_it))) return rc;
+  ibftk::set_args sa{};
+  sa.sender_pre = sender_pre ? d_pre : nullptr;
+  sa.valid_pre = valid_pre ? d_pre + half : nullptr;
+  sa.work_mask = (uint64_t *)c->d_mask.p;
+  sa.hash32 = d_hash + 32ull * half;
+  sa.hash_len = (const uint8_t *)c->d_hash_len.p;
+  sa.H4 = (const uint64_t *)c->d_H.p;
+  sa.n = (uint32_t)n;
+  sa.half_words = seal65 ? half / 64 : 0;
+  const size_t mw = (size_t)mask_words(n);
+  sa.sender_out = (uint64_t *)c->d_set.p;
+  sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
+  sa.host_sender = c->dh_set;
+  sa.host_valid = c->dh_set ? c->dh_set + mask_words(c->max_rows) : nullptr;
+  hipLaunchKernelGGL(ibftk::message_set_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sa);
+  HIPCHK(c, hipGetLastError());
+  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  c->mask_dirty_words = 0;  // the combine kernel zeroed the seal words, the tally the sender words
+  if (!c->dh_set)
+    HIPCHK(c, hipMemcpyAsync(c->h_set, c->d_set.p, (size_t)mask_words(c->max_rows) * 16, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = fetch_results(c, (uint32_t)n, nullptr, tally, true))) {
+    c->have_H = false;
+    return rc;
+  }
+  memcpy(out_sender_mask, c->h_set, mw * 8);
+  memcpy(out_valid_mask, c->h_set + mask_words(c->max_rows), mw * 8);
   return IBFT_OK;
 }
 

@@ -696,6 +696,73 @@ __global__ void wire_stage_seals_kernel(const wire::row_info *__restrict__ rows,
   pre_flags[row] = ok ? 0 : 1;
 }
 
+// ---- a message set in one pass: both signatures of every message in ONE verdict launch ------------------------
+// A PREPARE / COMMIT message is checked three times by the reference, at different moments: IsValidValidator when it
+// arrives (core/ibft.go:1128), IsValidProposalHash and — COMMIT only — IsValidCommittedSeal when the view is
+// handled (:856-862, :932-944).  All three are pure functions of the message bytes and of the validator set, so a
+// whole set can be judged at once: the envelope signatures are rows [0, n) of the batch (their digests, Keccak of
+// PayloadNoSig, come from payload_digest_kernel), the committed seals are rows [half, half + n) with the hash each
+// message carries as digest, half = ⌈n/64⌉·64 — 2n signatures in one launch fill the chip where n alone left
+// every SIMD with a single wavefront (n = 4 096: 8 192 rows, two wavefronts per SIMD).
+__global__ void payload_digest_kernel(const uint8_t *__restrict__ payload, const uint32_t *__restrict__ off, uint32_t n,
+                                      uint8_t *__restrict__ digest32) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = row < n;
+  const uint32_t o0 = live ? off[row] : 0u, o1 = live ? off[row + 1] : 0u;
+  uint64_t d[4];
+  keccak::hash_bytes(payload + o0, o1 - o0, d);
+  if (live) {
+    uint4 *o = reinterpret_cast<uint4 *>(digest32 + 32ull * row);
+    o[0] = make_uint4((uint32_t)d[0], (uint32_t)(d[0] >> 32), (uint32_t)d[1], (uint32_t)(d[1] >> 32));
+    o[1] = make_uint4((uint32_t)d[2], (uint32_t)(d[2] >> 32), (uint32_t)d[3], (uint32_t)(d[3] >> 32));
+  }
+}
+// After the verdict launch: word w of the work mask holds the envelope verdicts of rows 64w.., word half/64 + w the
+// seal verdicts of the same messages.  a1 is evaluated here (hash_eq_kernel's compare).  Delivered: sender words
+// (IsValidValidator), valid words (a1 ∧ a2 — handlePrepare's / handleCommit's closure; a1 alone without seals);
+// the work mask keeps sender ∧ valid for the tally, which then answers hasQuorumByMsgType for the set.
+struct set_args {
+  uint64_t *work_mask;
+  const uint8_t *hash32;    // n × 32: the proposal hash each message carries
+  const uint8_t *hash_len;  // n
+  const uint64_t *H4;       // keccak256(raw proposal ‖ BE64(round))
+  const uint8_t *sender_pre, *valid_pre;  // n each or null: rows the host rejected before any crypto
+  uint32_t n, half_words;   // half_words = 0: no seals (PREPARE)
+  uint64_t *sender_out, *valid_out;    // device copies (⌈n/64⌉ words each)
+  uint64_t *host_sender, *host_valid;  // mapped pinned host memory or null
+};
+__global__ void message_set_combine_kernel(set_args a) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  bool a1 = false, spre = false;
+  if (row < a.n) {
+    spre = a.sender_pre && a.sender_pre[row] != 0;
+    const uint4 *p = reinterpret_cast<const uint4 *>(a.hash32 + 32ull * row);
+    const uint4 x = p[0], y = p[1];
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(a.H4);
+    const uint32_t diff = (x.x ^ h[0]) | (x.y ^ h[1]) | (x.z ^ h[2]) | (x.w ^ h[3]) | (y.x ^ h[4]) | (y.y ^ h[5]) |
+                          (y.z ^ h[6]) | (y.w ^ h[7]);
+    a1 = diff == 0 && a.hash_len[row] == 32 && !(a.valid_pre && a.valid_pre[row] != 0);
+  }
+  const uint64_t bal = __ballot(a1), sbad = __ballot(spre);
+  if ((threadIdx.x & 63) != 0 || row >= a.n) return;
+  const uint32_t w = row >> 6;
+  const uint32_t left = a.n - row;  // ≥ 1
+  const uint64_t tail = left >= 64 ? ~0ull : (~0ull >> (64 - left));
+  const uint64_t S = a.work_mask[w] & tail & ~sbad;
+  uint64_t V = bal;
+  if (a.half_words) {
+    V &= a.work_mask[a.half_words + w];
+    a.work_mask[a.half_words + w] = 0;
+  }
+  a.sender_out[w] = S;
+  a.valid_out[w] = V;
+  if (a.host_sender) {
+    a.host_sender[w] = S;
+    a.host_valid[w] = V;
+  }
+  a.work_mask[w] = S & V;
+}
+
 // ---- a8: weighted quorum tally ------------------------------------------------------------
 // HasQuorum (core/validator_manager.go:77-96): Σ power over the DISTINCT member senders of the valid rows
 // ≥ ⌊2·total/3⌋+1.  Several workgroups (4 096 rows each) walk the verdict words: a validator's power is

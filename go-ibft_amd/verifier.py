@@ -36,7 +36,7 @@ EXPORTS = [
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
-    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals",
+    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -122,6 +122,8 @@ def load_library() -> C.CDLL:
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.ibft_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp, vp, vp,
+                                       C.POINTER(Tally)]
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
     L.ibft_seals_export_on.argtypes = [vp, vp, vp, vp]
@@ -299,6 +301,27 @@ class BatchVerifier:
         self._chk(self._L.ibft_verify_senders(self._h, _p(pl), _p(off), _p(s), _p(f), _p(pre), n, _p(mask),
                                               C.byref(t)), "ibft_verify_senders")
         return mask_to_bool(mask, n), t
+
+    # a whole PREPARE / COMMIT set in one call: IsValidValidator ∧ IsValidProposalHash (∧ IsValidCommittedSeal)
+    def verify_messages(self, payload: bytes, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None, valid_pre=None,
+                        raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
+        """→ (sender bool[n], valid bool[n], Tally over sender ∧ valid); seal65=None for a PREPARE set"""
+        pl = np.frombuffer(bytes(payload) or b"\0", dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        s = _u8(msg_sig65, (-1, 65)); f = _u8(from20, (-1, 20)); h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
+        n = len(s)
+        sl = None if seal65 is None else _u8(seal65, (-1, 65))
+        spre = None if sender_pre is None else _u8(sender_pre)
+        vpre = None if valid_pre is None else _u8(valid_pre)
+        rawb = None if raw is None else np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
+        dg = None if digest32 is None else np.frombuffer(bytes(digest32), dtype=np.uint8)
+        ms = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_verify_messages(self._h, _p(pl), _p(off), _p(s), _p(f), _p(h), _p(hl), _p(sl), _p(spre), _p(vpre), n,
+                                               _p(rawb), 0 if raw is None else len(raw), round_, _p(dg), _p(ms), _p(mv),
+                                               C.byref(t)), "ibft_verify_messages")
+        return mask_to_bool(ms, n), mask_to_bool(mv, n), t
 
     # §8f rank 3: a3 straight from the wire bytes (PREPARE / COMMIT); rows["status"] == WIRE_NEEDS_HOST
     # are not judged (verdict 0) and go through the protobuf runtime + is_valid_validator

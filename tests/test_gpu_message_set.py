@@ -1,0 +1,114 @@
+"""GPU: a whole PREPARE / COMMIT set in one call (ibft_verify_messages) ≡ the three separate Verifier batches
+(IsValidValidator core/backend.go:41-45, IsValidProposalHash :50-51, IsValidCommittedSeal :53-55) and ≡ the CPU
+oracle, bit for bit; its tally ≡ HasQuorum over the rows both verdicts accept (core/ibft.go:1273-1284 on what
+handleCommit's GetValidMessages returns, :932-944)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_expect(oracle, r, with_seals):
+    vs = oracle.ValSet(r.addrs, r.power)
+    senders = oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)
+    hashes = oracle.verify_hashes(r.raw, r.round, r.hash32, r.hash_len).astype(bool)
+    valid = hashes
+    if with_seals:
+        seals = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=8).astype(bool)
+        valid = hashes & seals
+    return vs, senders, valid
+
+
+def _tally_expect(oracle, vs, r, both):
+    return oracle.tally(vs, r.signer20, both.astype(np.uint8))
+
+
+@pytest.mark.parametrize("n,flags", [(1, 0), (63, 0), (64, 0), (65, 0), (333, 0), (1000, 2), (4096, 0), (4096, 2), (5000, 0)])
+def test_commit_set_equals_separate_calls_and_oracle(oracle, n, flags):
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    r = W.make_round(n, 100 + n, byzantine=True, with_envelopes=True, weighted=True)
+    # some envelopes are forged too: a foreign signature, a flipped byte, a non-member sender
+    sig = r.msg_sig65.copy()
+    rng = np.random.default_rng(n)
+    forged = rng.choice(n, size=max(1, n // 9), replace=False)
+    for j, i in enumerate(forged):
+        if j % 3 == 0:
+            sig[i] = r.msg_sig65[(i + 1) % n]
+        elif j % 3 == 1:
+            sig[i, j % 64] ^= 0x10
+        else:
+            sig[i, 64] ^= 1
+    r.msg_sig65 = sig
+    vs, senders, valid = _oracle_expect(oracle, r, True)
+    bv = V.BatchVerifier(max_rows=max(n, 256), flags=flags)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        for rep in range(3 if flags else 1):    # with the key cache: cold pass, table build, warm passes
+            s, v, t = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                         valid_pre=r.pre_flags, raw=r.raw, round_=r.round)
+            assert (s == senders).all(), np.flatnonzero(s != senders)[:8]
+            assert (v == valid).all(), [(i, r.kinds[i]) for i in np.flatnonzero(v != valid)[:8]]
+            et = _tally_expect(oracle, vs, r, senders & valid)
+            assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == \
+                   (et.power, et.valid_rows, et.distinct_senders, et.has_quorum)
+        # the separate calls on the same context agree (and the digest form of the proposal)
+        s2, _ = bv.is_valid_validator(r.payload, r.off, r.msg_sig65, r.signer20)
+        h2 = bv.is_valid_proposal_hash(r.raw, r.round, r.hash32, r.hash_len)
+        a2, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+        assert (s2 == senders).all() and ((h2 & a2) == valid).all()
+        s3, v3, t3 = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                        valid_pre=r.pre_flags, digest32=r.proposal_hash)
+        assert (s3 == senders).all() and (v3 == valid).all() and t3.power == et.power
+    finally:
+        bv.close()
+
+
+@pytest.mark.parametrize("n", [7, 200, 4095])
+def test_prepare_set_has_no_seals(oracle, n):
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    r = W.make_round(n, 900 + n, byzantine=True, with_envelopes=True)
+    vs, senders, valid = _oracle_expect(oracle, r, False)
+    bv = V.BatchVerifier(max_rows=4096)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        s, v, t = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len,
+                                     raw=r.raw, round_=r.round)
+        assert (s == senders).all() and (v == valid).all()
+        et = _tally_expect(oracle, vs, r, senders & valid)
+        assert (t.power, t.valid_rows, t.has_quorum) == (et.power, et.valid_rows, et.has_quorum)
+        # a wrong round changes the proposal hash: nothing is valid, every sender still is
+        s, v, t = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len,
+                                     raw=r.raw, round_=r.round + 1)
+        assert (s == senders).all() and not v.any() and t.valid_rows == 0 and t.has_quorum == 0
+    finally:
+        bv.close()
+
+
+def test_pre_columns_empty_set_and_interleaving_with_other_calls(oracle):
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    r = W.make_round(300, 77, with_envelopes=True)
+    bv = V.BatchVerifier(max_rows=1024)
+    try:
+        with pytest.raises(Exception):
+            bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len, r.seal65, raw=r.raw)
+        bv.set_validators(r.height, r.addrs, r.power)
+        spre = np.zeros(300, np.uint8); spre[[0, 64, 299]] = 1
+        vpre = np.zeros(300, np.uint8); vpre[[1, 64, 128]] = 4
+        s, v, t = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                     sender_pre=spre, valid_pre=vpre, raw=r.raw, round_=r.round)
+        assert (s == (spre == 0)).all() and (v == (vpre == 0)).all() and t.valid_rows == 300 - 5
+        # a seal batch right after (the work mask must be clean), then the set again, then an empty set
+        got, t2 = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)
+        assert got.all() and t2.valid_rows == 300
+        s, v, t = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                     raw=r.raw, round_=r.round)
+        assert s.all() and v.all() and t.has_quorum == 1 and t.power == 300
+        z = np.zeros((0, 65), np.uint8)
+        s, v, t = bv.verify_messages(b"", np.zeros(1, np.uint32), z, np.zeros((0, 20), np.uint8), np.zeros((0, 32), np.uint8),
+                                     np.zeros(0, np.uint8), z, raw=r.raw, round_=r.round)
+        assert len(s) == 0 and len(v) == 0 and t.has_quorum == 0 and t.quorum == 201
+    finally:
+        bv.close()
