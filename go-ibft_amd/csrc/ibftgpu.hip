@@ -1112,6 +1112,15 @@ int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) 
   return IBFT_OK;
 }
 
+void *ibft_pinned_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+  return p;
+}
+void ibft_pinned_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 // A whole PREPARE or COMMIT set in one call (kernels.hip.h: "a message set in one pass").
 int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
                          const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,

@@ -63,6 +63,45 @@ __device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, 
 // with a compare-and-swap and only the winner stores the key and counts it, so that `learned` is the
 // number of validators with a key — the host compares it with n_validators to drop the cold kernel
 // (learn_key, below recover_args).
+// ---- Keccak-256 of a byte range in HBM, one lane, dword loads ------------------------------------------
+// keccak::hash_bytes reads the message a byte at a time (it also runs on the CPU test harness): 136 dependent-
+// looking byte loads per block cost more than the permutation itself (payload_digest_kernel: 41 µs for one block
+// per lane, profiles/r02g_seq_kernel_stats.csv).  Here a block is 35 aligned dword loads issued together and
+// realigned with funnel shifts.  Reads up to 7 bytes past the end of the range: the payload buffers carry 256
+// bytes of slack (ibftgpu.hip).
+__device__ __forceinline__ void hash_range_dwords(const uint8_t *__restrict__ in, uint32_t len, uint64_t out4[4]) {
+  uint64_t s[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) s[i] = 0;
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(in) & 3u), sh = 8u * mis;
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(in - mis);
+  for (;;) {
+    const uint32_t take = len < 136u ? len : 136u;  // message bytes in this block
+    const uint32_t nd = (take + 3u) >> 2;           // dwords that hold them
+    uint32_t raw[35];
+#pragma unroll
+    for (int j = 0; j < 35; j++) raw[j] = (uint32_t)j <= nd ? p[j] : 0u;
+    uint32_t w[34];
+#pragma unroll
+    for (int j = 0; j < 34; j++) {
+      const uint32_t v = (uint32_t)(((uint64_t)raw[j + 1] << 32 | raw[j]) >> sh);  // bytes 4j..4j+3 of the block
+      const uint32_t have = take > 4u * (uint32_t)j ? take - 4u * (uint32_t)j : 0u;  // how many of them are message bytes
+      w[j] = have >= 4u ? v : (have ? (v & ((1u << (8u * have)) - 1u)) : 0u);
+      // pad10*1: first bit right after the message … (static register index: no scratch)
+      w[j] |= (take < 136u && (take >> 2) == (uint32_t)j) ? 0x01u << (8u * (take & 3u)) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 17; i++) s[i] ^= (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    if (take < 136u) s[16] ^= 0x8000000000000000ULL;               // … last bit at byte 135
+    keccak::f1600(s);
+    if (take < 136u) break;
+    p += 34;
+    len -= 136u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out4[i] = s[i];
+}
+
 // ---- fixed-base table build (entries computed by recover_dev.h:gtab_entry) ----------
 __global__ void gtab_build_kernel(uint32_t *__restrict__ gtab) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,7 +264,7 @@ __device__ __forceinline__ row_regs stage_rows(const recover_args &a, uint8_t *l
   } else {
     uint64_t d[4];
     uint32_t o0 = q.live ? a.off[q.row] : 0u, o1 = q.live ? a.off[q.row + 1] : 0u;
-    keccak::hash_bytes(a.payload + o0, o1 - o0, d);
+    hash_range_dwords(a.payload + o0, o1 - o0, d);
     keccak::digest_to_limbs(d, q.z.v);
   }
 #pragma unroll
@@ -325,7 +364,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
     z = secp::from_be32(a.hash32 + 32ull * row);
   } else {
     uint64_t d[4];
-    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    hash_range_dwords(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
     keccak::digest_to_limbs(d, z.v);
   }
   uint32_t want[5];
@@ -394,7 +433,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) verify_known_wave_kern
     z = secp::from_be32(a.hash32 + 32ull * row);
   } else {
     uint64_t d[4];
-    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    hash_range_dwords(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
     keccak::digest_to_limbs(d, z.v);
   }
   uint32_t want[5];
@@ -446,7 +485,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
     z = secp::from_be32(a.hash32 + 32ull * row);
   } else {
     uint64_t d[4];
-    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    hash_range_dwords(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
     keccak::digest_to_limbs(d, z.v);
   }
   uint32_t want[5];
@@ -586,7 +625,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
     z = secp::from_be32(a.hash32 + 32ull * row);
   } else {
     uint64_t d[4];
-    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    hash_range_dwords(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
     keccak::digest_to_limbs(d, z.v);
   }
   uint32_t got[5];
@@ -634,7 +673,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) IBFT_ROWS_WAVES_PER_EU
     z = secp::from_be32(a.hash32 + 32ull * row);
   } else {
     uint64_t d[4];
-    keccak::hash_bytes(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    hash_range_dwords(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
     keccak::digest_to_limbs(d, z.v);
   }
   uint32_t got[5];
@@ -710,7 +749,7 @@ __global__ void payload_digest_kernel(const uint8_t *__restrict__ payload, const
   const bool live = row < n;
   const uint32_t o0 = live ? off[row] : 0u, o1 = live ? off[row + 1] : 0u;
   uint64_t d[4];
-  keccak::hash_bytes(payload + o0, o1 - o0, d);
+  hash_range_dwords(payload + o0, o1 - o0, d);
   if (live) {
     uint4 *o = reinterpret_cast<uint4 *>(digest32 + 32ull * row);
     o[0] = make_uint4((uint32_t)d[0], (uint32_t)(d[0] >> 32), (uint32_t)d[1], (uint32_t)(d[1] >> 32));

@@ -36,7 +36,7 @@ EXPORTS = [
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
-    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages",
+    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -122,6 +122,8 @@ def load_library() -> C.CDLL:
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.ibft_pinned_alloc.argtypes = [C.c_size_t]; L.ibft_pinned_alloc.restype = vp
+    L.ibft_pinned_free.argtypes = [vp]; L.ibft_pinned_free.restype = None
     L.ibft_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp, vp, vp,
                                        C.POINTER(Tally)]
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
@@ -158,6 +160,42 @@ def load_library() -> C.CDLL:
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _PinnedOwner:
+    """keeps one ibft_pinned_alloc block alive for as long as a numpy view of it exists"""
+
+    def __init__(self, nbytes: int):
+        self._L = load_library()
+        self.ptr = self._L.ibft_pinned_alloc(nbytes)
+        if not self.ptr:
+            raise GpuUnavailable("ibft_pinned_alloc failed")
+        self.buf = (C.c_uint8 * max(nbytes, 1)).from_address(self.ptr)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._L.ibft_pinned_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_copy(a) -> np.ndarray:
+    """a copy of `a` (array or bytes) in page-locked memory from ibft_pinned_alloc: what a caller's flatten step
+    should write its columns into (include/ibftgpu.h, "pinned column buffers")"""
+    if isinstance(a, (bytes, bytearray, memoryview)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    a = np.ascontiguousarray(a)
+    own = _PinnedOwner(a.nbytes)
+    out = np.frombuffer(own.buf, dtype=a.dtype, count=a.size).reshape(a.shape)  # .base chain keeps `own.buf` alive
+    out[...] = a
+    own.buf._owner = own  # the view's base chain reaches the ctypes array, which now keeps the block's owner alive
+    return out
+
+
+def _bytes_col(x) -> np.ndarray:
+    """a byte column as the C ABI wants it, without copying arrays that already are one (pinned buffers stay pinned)"""
+    if isinstance(x, np.ndarray) and x.dtype == np.uint8 and x.flags["C_CONTIGUOUS"] and x.size:
+        return x.reshape(-1)
+    return np.frombuffer(bytes(x) or b"\0", dtype=np.uint8)
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -291,7 +329,7 @@ class BatchVerifier:
 
     # Verifier.IsValidValidator, batched
     def is_valid_validator(self, payload: bytes, off, sig65, from20, pre_flags=None):
-        pl = np.frombuffer(bytes(payload) or b"\0", dtype=np.uint8)
+        pl = _bytes_col(payload)
         off = np.ascontiguousarray(off, dtype=np.uint32)
         s = _u8(sig65, (-1, 65)); f = _u8(from20, (-1, 20))
         n = len(s)
@@ -306,7 +344,7 @@ class BatchVerifier:
     def verify_messages(self, payload: bytes, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None, valid_pre=None,
                         raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
         """→ (sender bool[n], valid bool[n], Tally over sender ∧ valid); seal65=None for a PREPARE set"""
-        pl = np.frombuffer(bytes(payload) or b"\0", dtype=np.uint8)
+        pl = _bytes_col(payload)
         off = np.ascontiguousarray(off, dtype=np.uint32)
         s = _u8(msg_sig65, (-1, 65)); f = _u8(from20, (-1, 20)); h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
         n = len(s)

@@ -112,3 +112,43 @@ def test_pre_columns_empty_set_and_interleaving_with_other_calls(oracle):
         assert len(s) == 0 and len(v) == 0 and t.has_quorum == 0 and t.quorum == 201
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
+def test_payload_lengths_around_the_keccak_rate_at_every_alignment(oracle, lanes, monkeypatch):
+    """PayloadNoSig rows of every length around the 136-byte Keccak rate (empty, one block exactly, one byte over,
+    several blocks), packed back to back so that rows start at every byte alignment: the kernels hash them with
+    aligned dword loads + funnel shifts (kernels.hip.h:hash_range_dwords), the oracle byte by byte."""
+    import go_ibft_amd.verifier as V
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    rng = np.random.default_rng(1360 + lanes)
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 9, 55, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 271, 272, 273, 407, 408, 409,
+            1000, 4093] + [int(x) for x in rng.integers(0, 300, size=100)]
+    n = len(lens)
+    from oracle import workload as W
+    sks = [W.validator_key(99, i) for i in range(n)]
+    addrs = np.array([np.frombuffer(oracle.address(oracle.pubkey(sk)), np.uint8) for sk in sks])
+    rows = [rng.bytes(L) for L in lens]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(lens)
+    sig = np.array([np.frombuffer(oracle.sign(sks[i], oracle.keccak256(rows[i])), np.uint8) for i in range(n)])
+    sig[5, 3] ^= 1      # one forged row: the verdict is not trivially all-ones
+    payload = b"".join(rows)
+    vs = oracle.ValSet(addrs, np.ones(n, np.uint64))
+    exp = oracle.verify_senders(vs, payload, off, sig, addrs).astype(bool)
+    assert exp.sum() == n - 1
+    bv = V.BatchVerifier(max_rows=256)
+    try:
+        bv.set_validators(1, addrs, np.ones(n, np.uint64))
+        got, _ = bv.is_valid_validator(payload, off, sig, addrs)
+        assert bv.last_dispatch() == (lanes, 0)
+        assert (got == exp).all(), [lens[i] for i in np.flatnonzero(got != exp)]
+        h = np.zeros((n, 32), np.uint8)
+        s, v, _ = bv.verify_messages(payload, off, sig, addrs, h, np.full(n, 32, np.uint8), raw=b"x", round_=0)
+        assert (s == exp).all() and not v.any()
+        # pinned columns (ibft_pinned_alloc) give the same answer
+        s, v, _ = bv.verify_messages(V.pinned_copy(payload), V.pinned_copy(off), V.pinned_copy(sig), V.pinned_copy(addrs),
+                                     V.pinned_copy(h), V.pinned_copy(np.full(n, 32, np.uint8)), raw=b"x", round_=0)
+        assert (s == exp).all() and not v.any()
+    finally:
+        bv.close()
