@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -105,6 +106,8 @@ struct ibft_ctx {
   // message sets (ibft_verify_messages): sender words then valid words, ⌈max_rows/64⌉ each
   uint64_t *h_set = nullptr, *dh_set = nullptr;
   DevBuf d_set;
+  bool gather_pinned = true;  // columns in ibft_pinned_alloc buffers are read by one gather launch (IBFT_NO_GATHER=1: never)
+  uint32_t gathers = 0;       // batches whose columns came in through the gather launch
   bool host_direct = false;                          // the last tally kernel delivered its results there
   hipEvent_t ev_ready = nullptr, ev_read = nullptr;  // ibft_seals_export_on: results ready / results read
   bool read_pending = false;                         // the next tally must wait for ev_read
@@ -476,6 +479,65 @@ int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes) {
   return IBFT_OK;
 }
 
+// Blocks handed out by ibft_pinned_alloc: a column that lies inside one can be read by the device directly.
+struct PinnedRegistry {
+  std::mutex mu;
+  std::map<uintptr_t, size_t> blocks;
+  bool covers(const void *p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = blocks.upper_bound(a);
+    if (it == blocks.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+  }
+};
+PinnedRegistry &pinned_registry() {
+  static PinnedRegistry r;
+  return r;
+}
+
+// The host→HBM column copies of one batch.  flush(): ONE gather launch when every source is pinned (the device
+// reads the columns itself), otherwise one hipMemcpyAsync per column as before.
+struct ColumnCopies {
+  struct Seg {
+    void *dst;
+    const void *src;
+    size_t bytes;
+  };
+  Seg seg[ibftk::GATHER_MAX];
+  int n = 0;
+  void add(void *dst, const void *src, size_t bytes) {
+    if (bytes && n < ibftk::GATHER_MAX) seg[n++] = Seg{dst, src, bytes};
+  }
+  int flush(ibft_ctx *c) {
+    if (n == 0) return IBFT_OK;
+    bool pinned = c->gather_pinned;
+    for (int i = 0; i < n && pinned; i++) pinned = seg[i].bytes < (1ull << 31) && pinned_registry().covers(seg[i].src, seg[i].bytes);
+    if (!pinned) {
+      for (int i = 0; i < n; i++) HIPCHK(c, hipMemcpyAsync(seg[i].dst, seg[i].src, seg[i].bytes, hipMemcpyHostToDevice, c->stream));
+      n = 0;
+      return IBFT_OK;
+    }
+    ibftk::gather_args a{};
+    uint32_t blocks = 0;
+    for (int i = 0; i < n; i++) {
+      a.src[i] = (const uint8_t *)seg[i].src;
+      a.dst[i] = (uint8_t *)seg[i].dst;
+      a.bytes[i] = (uint32_t)seg[i].bytes;
+      a.first_block[i] = blocks;
+      blocks += (uint32_t)((seg[i].bytes + ibftk::GATHER_BLOCK_BYTES - 1) / ibftk::GATHER_BLOCK_BYTES);
+    }
+    a.first_block[n] = blocks;
+    a.n = (uint32_t)n;
+    hipLaunchKernelGGL(ibftk::gather_columns_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    c->gathers++;
+    n = 0;
+    return IBFT_OK;
+  }
+};
+
 
 // ---- RCCL, loaded on first use: a single-GPU deployment never needs the library ----------------------
 struct RcclApi {
@@ -711,6 +773,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   }
   if (const char *e = getenv("IBFT_NO_EVENTS"))
     if (atoi(e) == 1) c->time_every = 0;
+  if (getenv("IBFT_NO_GATHER")) c->gather_pinned = false;
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("IBFT_ROWS_KERNEL_MAX")) c->rows_kernel_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;
@@ -929,8 +992,10 @@ int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
 static int hash_eq_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *hash_len, size_t n, uint64_t *out_mask) {
   int rc;
   c->wire_valid = false;
-  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
-  if ((rc = upload(c, c->d_hash_len, hash_len, n))) return rc;
+  ColumnCopies cc;
+  cc.add(c->d_hash.p, hash32, n * 32);
+  cc.add(c->d_hash_len.p, hash_len, n);
+  if ((rc = cc.flush(c))) return rc;
   if (n) {
     hipLaunchKernelGGL(ibftk::hash_eq_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                        (const uint8_t *)c->d_hash.p, (const uint8_t *)c->d_hash_len.p,
@@ -969,17 +1034,20 @@ int ibft_verify_hashes_digest(ibft_ctx *c, const uint8_t digest32[32], const uin
 }
 
 static int seals_stage_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
-                              const uint8_t *pre_flags, size_t n) {
+                              const uint8_t *pre_flags, size_t n, bool wait) {
   if (n && (!hash32 || !sig65 || !signer20)) return IBFT_E_INVAL;
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   c->wire_valid = false;
-  if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
-  if ((rc = upload(c, c->d_sig, sig65, n * 65))) return rc;
-  if ((rc = upload(c, c->d_signer, signer20, n * 20))) return rc;
-  if (pre_flags && (rc = upload(c, c->d_pre, pre_flags, n))) return rc;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ColumnCopies cc;
+  cc.add(c->d_hash.p, hash32, n * 32);
+  cc.add(c->d_sig.p, sig65, n * 65);
+  cc.add(c->d_signer.p, signer20, n * 20);
+  if (pre_flags) cc.add(c->d_pre.p, pre_flags, n);
+  if ((rc = cc.flush(c))) return rc;
+  // ibft_seals_stage promises the caller its buffers back; the one-shot call waits once, at the end
+  if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));
   c->staged_n = (uint32_t)n;
   c->staged_pre = pre_flags != nullptr;
   return IBFT_OK;
@@ -989,7 +1057,7 @@ int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, c
                      const uint8_t *pre_flags, size_t n) {
   if (!c) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
-  return seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n);
+  return seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n, true);
 }
 
 static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
@@ -1112,13 +1180,31 @@ int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) 
   return IBFT_OK;
 }
 
+int ibft_column_stats(ibft_ctx *c, uint32_t *gather_batches) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (gather_batches) *gather_batches = c->gathers;
+  return IBFT_OK;
+}
+
 void *ibft_pinned_alloc(size_t bytes) {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
+  void *dp = nullptr;
+  // the gather launch dereferences the host address itself: only register blocks the device sees at that address
+  if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess && dp == p) {
+    std::lock_guard<std::mutex> lk(pinned_registry().mu);
+    pinned_registry().blocks[(uintptr_t)p] = bytes ? bytes : 1;
+  }
   return p;
 }
 void ibft_pinned_free(void *p) {
-  if (p) (void)hipHostFree(p);
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(pinned_registry().mu);
+    pinned_registry().blocks.erase((uintptr_t)p);
+  }
+  (void)hipHostFree(p);
 }
 
 // A whole PREPARE or COMMIT set in one call (kernels.hip.h: "a message set in one pass").
@@ -1165,22 +1251,24 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
           *d_pre = (uint8_t *)c->d_pre.p;
   const size_t pbytes = off[n];
   if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
-  if (pbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, payload, pbytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_off.p, off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_sig, msg_sig65, n * 65, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_signer, from20, n * 20, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_hash + 32ull * half, hash32, n * 32, hipMemcpyHostToDevice, c->stream));  // carried hashes
-  HIPCHK(c, hipMemcpyAsync(c->d_hash_len.p, hash_len, n, hipMemcpyHostToDevice, c->stream));
+  ColumnCopies cc;
+  cc.add(c->d_payload.p, payload, pbytes);
+  cc.add(c->d_off.p, off, (n + 1) * 4);
+  cc.add(d_sig, msg_sig65, n * 65);
+  cc.add(d_signer, from20, n * 20);
+  cc.add(d_hash + 32ull * half, hash32, n * 32);  // the hashes the messages carry
+  cc.add(c->d_hash_len.p, hash_len, n);
   // rows the host rejected before any crypto: applied to the verdict words afterwards (the verdict launch runs them
   // like any other row — skipping work inside a lock-step wavefront saves nothing)
-  if (sender_pre) HIPCHK(c, hipMemcpyAsync(d_pre, sender_pre, n, hipMemcpyHostToDevice, c->stream));
-  if (valid_pre) HIPCHK(c, hipMemcpyAsync(d_pre + half, valid_pre, n, hipMemcpyHostToDevice, c->stream));
+  if (sender_pre) cc.add(d_pre, sender_pre, n);
+  if (valid_pre) cc.add(d_pre + half, valid_pre, n);
   if (seal65) {
-    HIPCHK(c, hipMemcpyAsync(d_sig + 65ull * half, seal65, n * 65, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_signer + 20ull * half, d_signer, n * 20, hipMemcpyDeviceToDevice, c->stream));
+    cc.add(d_sig + 65ull * half, seal65, n * 65);
+    cc.add(d_signer + 20ull * half, from20, n * 20);  // the seal's signer is the message's From
     if (half != n)  // rows n..half−1 sit between the two groups: a zero signature is rejected by every kernel
       HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
   }
+  if ((rc = cc.flush(c))) return rc;
   hipLaunchKernelGGL(ibftk::payload_digest_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
                      (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n, d_hash);
   HIPCHK(c, hipGetLastError());
@@ -1266,7 +1354,7 @@ int ibft_verify_seals(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, 
   std::lock_guard<std::mutex> lk(c->mu);  // one critical section: stage + launch + fetch
   if (!c->have_valset) return IBFT_E_NOVALSET;
   int rc;
-  if ((rc = seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n))) return rc;
+  if ((rc = seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n, false))) return rc;
   if ((rc = seals_launch_locked(c, 1))) return rc;
   return fetch_results(c, c->staged_n, out_mask, tally, true);
 }
@@ -1286,11 +1374,13 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
   c->wire_valid = false;
   size_t pbytes = n ? off[n] : 0;
   if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
-  if (pbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, payload, pbytes, hipMemcpyHostToDevice, c->stream));
-  if ((rc = upload(c, c->d_off, off, (n + 1) * 4))) return rc;
-  if ((rc = upload(c, c->d_sig, sig65, n * 65))) return rc;
-  if ((rc = upload(c, c->d_signer, from20, n * 20))) return rc;
-  if (pre_flags && (rc = upload(c, c->d_pre, pre_flags, n))) return rc;
+  ColumnCopies cc;
+  cc.add(c->d_payload.p, payload, pbytes);
+  cc.add(c->d_off.p, off, (n + 1) * 4);
+  cc.add(c->d_sig.p, sig65, n * 65);
+  cc.add(c->d_signer.p, from20, n * 20);
+  if (pre_flags) cc.add(c->d_pre.p, pre_flags, n);
+  if ((rc = cc.flush(c))) return rc;
   c->staged_n = (uint32_t)n;
   c->staged_pre = pre_flags != nullptr;
   c->ev_used = 0;
@@ -1525,7 +1615,7 @@ int ibft_group_verify_seals(ibft_group *g, const uint8_t *hash32, const uint8_t 
     uint64_t lo, hi;
     (void)ibft_shard_range(n, i, world, &lo, &hi);
     if ((rc = seals_stage_locked(c, hash32 + 32 * lo, sig65 + 65 * lo, signer20 + 20 * lo, pre_flags ? pre_flags + lo : nullptr,
-                                 (size_t)(hi - lo))))
+                                 (size_t)(hi - lo), false)))
       return rc;
     if ((rc = seals_launch_locked(c, 1))) return rc;
   }

@@ -63,6 +63,42 @@ __device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, 
 // with a compare-and-swap and only the winner stores the key and counts it, so that `learned` is the
 // number of validators with a key — the host compares it with n_validators to drop the cold kernel
 // (learn_key, below recover_args).
+// ---- host columns → HBM in one launch --------------------------------------------------------------------
+// A batch arrives as 4–9 separate byte columns.  One hipMemcpyAsync per column costs ≈8 µs of host time each and the
+// copies run one behind the other (profiles/r02h_seq_*: 134 µs before the first kernel of a COMMIT set).  When the
+// caller keeps its columns in ibft_pinned_alloc buffers the device can read them itself: one launch, every segment
+// read with 16-byte loads straight over PCIe (≈1.3 MB: ≈25 µs).  Pageable columns keep the per-column copies.
+constexpr int GATHER_MAX = 12;
+constexpr int GATHER_BLOCK_BYTES = 256 * 16;
+struct gather_args {
+  const uint8_t *src[GATHER_MAX];
+  uint8_t *dst[GATHER_MAX];
+  uint32_t bytes[GATHER_MAX];
+  uint32_t first_block[GATHER_MAX + 1];  // segment s owns blocks [first_block[s], first_block[s+1])
+  uint32_t n;
+};
+__global__ void __launch_bounds__(256) gather_columns_kernel(gather_args a) {
+  uint32_t s = 0;
+#pragma unroll 1
+  while (s + 1 < a.n && blockIdx.x >= a.first_block[s + 1]) s++;
+  const uint32_t off = (blockIdx.x - a.first_block[s]) * (uint32_t)GATHER_BLOCK_BYTES + threadIdx.x * 16u;
+  const uint32_t len = a.bytes[s];
+  if (off >= len) return;
+  const uint8_t *src = a.src[s] + off;
+  uint8_t *dst = a.dst[s] + off;
+  const uint32_t take = len - off < 16u ? len - off : 16u;
+  if (take == 16u && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+  } else if (take == 16u && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) == 0) {
+    const uint32_t *sp = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *dp = reinterpret_cast<uint32_t *>(dst);
+    const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3];
+    dp[0] = w0; dp[1] = w1; dp[2] = w2; dp[3] = w3;
+  } else {
+    for (uint32_t i = 0; i < take; i++) dst[i] = src[i];
+  }
+}
+
 // ---- Keccak-256 of a byte range in HBM, one lane, dword loads ------------------------------------------
 // keccak::hash_bytes reads the message a byte at a time (it also runs on the CPU test harness): 136 dependent-
 // looking byte loads per block cost more than the permutation itself (payload_digest_kernel: 41 µs for one block

@@ -263,10 +263,16 @@ int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes
  * column through its own bounce buffer — measured at ≈8.5 GB/s, 0.15 ms for the 1.3 MB of a 4 096-message
  * COMMIT set (profiles/r02g_seq_*).  A caller that flattens messages into columns anyway (the cgo shim's
  * SoA batcher) should write them into buffers from ibft_pinned_alloc instead: page-locked
- * memory the copy engines read directly.  Plain memory otherwise: valid until ibft_pinned_free, usable with
+ * memory the device reads directly — when every column of a call lies in such buffers the library replaces
+ * the per-column copy commands by ONE gather launch (≈8 µs of host time per column saved, the copies no
+ * longer queue one behind the other).  Plain memory otherwise: valid until ibft_pinned_free, usable with
  * any context, any thread.  Returns NULL when the runtime refuses (no device, out of lockable memory).     */
 void *ibft_pinned_alloc(size_t bytes);
 void ibft_pinned_free(void *p);
+/* Batches of this context whose columns ALL lay in ibft_pinned_alloc blocks and were therefore read by the
+ * device in one gather launch instead of one copy command per column (environment IBFT_NO_GATHER=1 turns
+ * the gather off: pinned columns then take the copy commands, still faster to issue than pageable ones).  */
+int ibft_column_stats(ibft_ctx *ctx, uint32_t *gather_batches);
 
 /* ---- a whole PREPARE / COMMIT set in one call --------------------------------------------------------
  * The reference judges a stored PREPARE / COMMIT message three times, at different moments: IsValidValidator

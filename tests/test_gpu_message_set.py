@@ -150,5 +150,18 @@ def test_payload_lengths_around_the_keccak_rate_at_every_alignment(oracle, lanes
         s, v, _ = bv.verify_messages(V.pinned_copy(payload), V.pinned_copy(off), V.pinned_copy(sig), V.pinned_copy(addrs),
                                      V.pinned_copy(h), V.pinned_copy(np.full(n, 32, np.uint8)), raw=b"x", round_=0)
         assert (s == exp).all() and not v.any()
+        assert bv.gather_batches() == 1     # only that last batch had every column in pinned blocks
+        pin = [V.pinned_copy(x) for x in (payload, off, sig, addrs)]
+        got, _ = bv.is_valid_validator(*pin)
+        assert (got == exp).all() and bv.gather_batches() == 2
+        got, _ = bv.is_valid_validator(pin[0], pin[1], sig, pin[3])   # one pageable column: copy commands for all
+        assert (got == exp).all() and bv.gather_batches() == 2
+        # odd source alignments inside a pinned block take the gather's dword / byte paths
+        big = V.pinned_copy(np.zeros(len(payload) + 64, np.uint8))
+        for shift in (1, 2, 4, 7):
+            big[shift:shift + len(payload)] = np.frombuffer(payload, np.uint8)
+            got, _ = bv.is_valid_validator(big[shift:shift + len(payload)], pin[1], pin[2], pin[3])
+            assert (got == exp).all()
+        assert bv.gather_batches() == 6
     finally:
         bv.close()

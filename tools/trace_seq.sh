@@ -10,7 +10,7 @@ mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 cd /tmp
 timeout 600 rocprofv3 --hip-runtime-trace --kernel-trace --memory-copy-trace --stats -d "$OUT" -o q --output-format csv -- \
-  python $ROOT/tools/seq_breakdown.py 100 > "$OUT/run.log" 2>&1
+  python $ROOT/tools/seq_breakdown.py 100 ${2:-} > "$OUT/run.log" 2>&1
 echo "rc=$?"
 cd "$ROOT"
 find "$OUT" -name '*stats*.csv' | while read f; do b=$(basename "$f"); cp "$f" "$SUM/${TAG}_seq_${b#q_}"; done
