@@ -1,6 +1,8 @@
 // backend.cpp — see backend.hpp.
 #include "backend.hpp"
 
+#include <algorithm>
+
 #include <chrono>
 
 #include <cstring>
@@ -117,6 +119,28 @@ bool GpuBackend::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<
   return true;
 }
 
+bool GpuBackend::VerifyMessageSet(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &msgs,
+                                  std::vector<uint8_t> &sender, std::vector<uint8_t> &closure) {
+  sender.assign(msgs.size(), 0);
+  closure.assign(msgs.size(), 0);
+  if ((type != PREPARE && type != COMMIT) || !proposal) return false;  // nothing to check the hashes against
+  if (msgs.empty()) return true;
+  SenderColumns sc;
+  flatten_senders(msgs, sc);
+  SealColumns cc;
+  if (type == COMMIT) flatten_commits(msgs, cc); else flatten_prepares(msgs, cc);
+  std::vector<uint64_t> ms((sc.n + 63) / 64, 0), mv((sc.n + 63) / 64, 0);
+  last_rc = ibft_verify_messages(ctx_, sc.payload.data(), sc.off.data(), sc.sig65.data(), sc.from20.data(), cc.hash32.data(),
+                                 cc.hash_len.data(), type == COMMIT ? cc.sig65.data() : nullptr, sc.pre_flags.data(),
+                                 type == COMMIT ? cc.pre_flags.data() : nullptr, sc.n,
+                                 (const uint8_t *)proposal->raw_proposal.data(), proposal->raw_proposal.size(),
+                                 proposal->round, nullptr, ms.data(), mv.data(), nullptr);
+  if (last_rc != IBFT_OK) return false;
+  unpack_mask(ms, sc.n, sender);
+  unpack_mask(mv, sc.n, closure);
+  return true;
+}
+
 bool GpuBackend::VerifySendersWire(const uint8_t *wire, const uint32_t *off, size_t n, std::vector<uint8_t> &verdict,
                                    WireStats *stats) {
   verdict.assign(n, 0);
@@ -174,6 +198,26 @@ bool LoopBatch::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<u
   return true;
 }
 
+bool LoopBatch::VerifyMessageSet(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &msgs,
+                                 std::vector<uint8_t> &sender, std::vector<uint8_t> &closure) {
+  if (fail_sets || !proposal || (type != PREPARE && type != COMMIT)) return false;
+  calls++;
+  set_calls++;
+  sender.assign(msgs.size(), 0);
+  closure.assign(msgs.size(), 0);
+  for (size_t i = 0; i < msgs.size(); i++) {
+    sender[i] = v_->IsValidValidator(*msgs[i]);
+    if (type == PREPARE) {
+      closure[i] = v_->IsValidProposalHash(proposal, extract_prepare_hash(*msgs[i]));
+    } else {
+      const bytes *h = extract_commit_hash(*msgs[i]);
+      std::optional<CommittedSeal> seal = extract_committed_seal(*msgs[i]);
+      closure[i] = v_->IsValidProposalHash(proposal, h) && v_->IsValidCommittedSeal(h, seal ? &*seal : nullptr);
+    }
+  }
+  return true;
+}
+
 bool HotPath::isAcceptableMessage(const IbftMessage &m) {
   if (!verifier || !verifier->IsValidValidator(m)) return false;  // ibft.go:1128
   if (!m.view) return false;                                       // :1133
@@ -220,6 +264,10 @@ void HotPath::EnableQuorumIndex() {
 void HotPath::PruneVerdictCache(uint64_t below_height) {
   for (auto it = verdict_cache_.begin(); it != verdict_cache_.end();)
     it = it->second.height < below_height ? verdict_cache_.erase(it) : std::next(it);
+  for (auto it = closure_cache_.begin(); it != closure_cache_.end();) {
+    const IbftMessage &m = *it->second.keep;
+    it = (!m.view || m.view->height < below_height) ? closure_cache_.erase(it) : std::next(it);
+  }
 }
 
 // IBFT.AddMessage with IsValidValidator already answered (by the device batch or the cache)
@@ -243,11 +291,27 @@ int HotPath::addWithVerdict(MsgPtr m, bool sender_ok) {
   return rc;
 }
 
+void HotPath::syncClosureKey(const Proposal *proposal) {
+  bytes key;
+  if (proposal) {
+    key = proposal->raw_proposal;
+    for (int i = 7; i >= 0; i--) key.push_back((char)(proposal->round >> (8 * i)));
+  }
+  if (key != closure_key_) {  // another proposal (or none): what the table says no longer applies
+    closure_key_ = std::move(key);
+    closure_cache_.clear();
+    closure_epoch_++;
+  }
+}
+
 bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats) {
   results.assign(raw.size(), -1);
   IngestStats st;
+  const Proposal *proposal = getProposal();
+  syncClosureKey(proposal);
   std::vector<MsgPtr> msgs(raw.size());
   std::vector<int> verdict(raw.size(), -1);  // −1 unknown, 0 / 1 decided
+  std::vector<int> closure(raw.size(), -1);  // the handle* closure where it is already known
   std::vector<size_t> ask;                   // rows the device has to judge: first occurrence of each distinct message
   std::map<bytes, size_t> first_in_batch;
   for (size_t i = 0; i < raw.size(); i++) {
@@ -257,12 +321,47 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
     auto hit = verdict_cache_.find(raw[i]);
     if (hit != verdict_cache_.end()) {
       verdict[i] = hit->second.ok ? 1 : 0;
+      if (hit->second.closure >= 0 && hit->second.closure_epoch == closure_epoch_) closure[i] = hit->second.closure;
       st.cache_hits++;
     } else if (first_in_batch.emplace(raw[i], i).second) {
       ask.push_back(i);
     }
   }
-  if (!ask.empty()) {
+  // (1) messages of the current view with the proposal at hand: judged completely, one set call per type
+  std::vector<size_t> rest;
+  if (use_batch && batch && use_sets && proposal) {
+    std::vector<size_t> of_type[2];
+    for (size_t i : ask) {
+      const IbftMessage &m = *msgs[i];
+      const bool here = m.view && m.view->height == height && m.view->round == round;
+      if (here && (m.type == PREPARE || m.type == COMMIT))
+        of_type[m.type == COMMIT].push_back(i);
+      else
+        rest.push_back(i);
+    }
+    for (int t = 0; t < 2; t++) {
+      if (of_type[t].empty()) continue;
+      std::vector<MsgPtr> sub;
+      for (size_t i : of_type[t]) sub.push_back(msgs[i]);
+      std::vector<uint8_t> vs, vc;
+      if (batch->VerifyMessageSet(proposal, t ? COMMIT : PREPARE, sub, vs, vc) && vs.size() == sub.size() &&
+          vc.size() == sub.size()) {
+        st.device_calls++;
+        st.set_rows += sub.size();
+        for (size_t k = 0; k < sub.size(); k++) {
+          verdict[of_type[t][k]] = vs[k] ? 1 : 0;
+          closure[of_type[t][k]] = vc[k] ? 1 : 0;
+        }
+      } else {  // not offered, or the device call failed: these rows take the sender route below
+        rest.insert(rest.end(), of_type[t].begin(), of_type[t].end());
+      }
+    }
+    std::sort(rest.begin(), rest.end());
+  } else {
+    rest = ask;
+  }
+  // (2) everything else: IsValidValidator only
+  if (!rest.empty()) {
     std::vector<uint8_t> v;
     bool ok = false;
     if (use_batch && batch) {
@@ -270,33 +369,39 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
       if (auto *gpu = dynamic_cast<GpuBackend *>(batch)) {  // the device walks the bytes themselves (§8f rank 3)
         bytes wire;
         std::vector<uint32_t> off{0};
-        for (size_t i : ask) {
+        for (size_t i : rest) {
           wire += raw[i];
           off.push_back((uint32_t)wire.size());
         }
-        ok = gpu->VerifySendersWire((const uint8_t *)wire.data(), off.data(), ask.size(), v);
+        ok = gpu->VerifySendersWire((const uint8_t *)wire.data(), off.data(), rest.size(), v);
       } else {
         std::vector<MsgPtr> sub;
-        for (size_t i : ask) sub.push_back(msgs[i]);
+        for (size_t i : rest) sub.push_back(msgs[i]);
         ok = batch->VerifySenderBatch(sub, v);
       }
-      ok = ok && v.size() == ask.size();
+      ok = ok && v.size() == rest.size();
     }
     if (!ok) {  // no batch backend, or the device call failed: the per-message verifier
       if (use_batch && batch) fallbacks++;
-      v.assign(ask.size(), 0);
-      for (size_t j = 0; j < ask.size(); j++) v[j] = verifier && verifier->IsValidValidator(*msgs[ask[j]]);
+      v.assign(rest.size(), 0);
+      for (size_t j = 0; j < rest.size(); j++) v[j] = verifier && verifier->IsValidValidator(*msgs[rest[j]]);
     }
-    st.device_rows = ask.size();
-    for (size_t j = 0; j < ask.size(); j++) {
-      const size_t i = ask[j];
-      verdict[i] = v[j] ? 1 : 0;
-      verdict_cache_[raw[i]] = CachedVerdict{v[j] != 0, msgs[i]->view ? msgs[i]->view->height : 0};
-    }
+    for (size_t j = 0; j < rest.size(); j++) verdict[rest[j]] = v[j] ? 1 : 0;
+  }
+  st.device_rows = ask.size();
+  for (size_t i : ask) {
+    CachedVerdict cv{verdict[i] == 1, msgs[i]->view ? msgs[i]->view->height : 0};
+    cv.closure = closure[i];
+    cv.closure_epoch = closure_epoch_;
+    verdict_cache_[raw[i]] = cv;
   }
   for (size_t i = 0; i < raw.size(); i++) {
     if (!msgs[i]) continue;
-    if (verdict[i] < 0) verdict[i] = verdict[first_in_batch[raw[i]]];  // a repeat inside this batch
+    if (verdict[i] < 0) {  // a repeat inside this batch
+      verdict[i] = verdict[first_in_batch[raw[i]]];
+      closure[i] = closure[first_in_batch[raw[i]]];
+    }
+    if (closure[i] >= 0 && verdict[i] == 1) closure_cache_[msgs[i].get()] = ClosureVerdict{msgs[i], closure[i] == 1};
     results[i] = addWithVerdict(msgs[i], verdict[i] == 1);
   }
   if (stats) *stats = st;
@@ -337,21 +442,53 @@ int HotPath::AddMessageFast(MsgPtr m) {
   return q ? 2 : 1;
 }
 
+// The verdicts of a handle* walk in batch mode: what arrived through IngestWire's set calls is already in the table;
+// the rest goes to the device in one batch; if that fails, the per-message closure answers, same lock held
+//  — never "nothing".
+std::vector<uint8_t> HotPath::closureVerdicts(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &all) {
+  syncClosureKey(proposal);
+  std::vector<uint8_t> v(all.size(), 0);
+  std::vector<MsgPtr> rest;
+  std::vector<size_t> rest_idx;
+  for (size_t k = 0; k < all.size(); k++) {
+    auto it = use_sets ? closure_cache_.find(all[k].get()) : closure_cache_.end();
+    if (it != closure_cache_.end()) {
+      v[k] = it->second.ok;
+      closure_hits++;
+    } else {
+      rest.push_back(all[k]);
+      rest_idx.push_back(k);
+    }
+  }
+  if (rest.empty()) return v;
+  std::vector<uint8_t> vr;
+  const bool ok = (type == PREPARE ? batch->VerifyPrepareBatch(proposal, rest, vr) : batch->VerifyCommitBatch(proposal, rest, vr)) &&
+                  vr.size() == rest.size();
+  if (!ok) {
+    fallbacks++;
+    vr.assign(rest.size(), 0);
+    for (size_t k = 0; k < rest.size(); k++) {
+      if (type == PREPARE) {
+        vr[k] = verifier->IsValidProposalHash(proposal, extract_prepare_hash(*rest[k]));
+      } else {
+        const bytes *proposalHash = extract_commit_hash(*rest[k]);
+        std::optional<CommittedSeal> seal = extract_committed_seal(*rest[k]);
+        vr[k] = verifier->IsValidProposalHash(proposal, proposalHash) &&
+                verifier->IsValidCommittedSeal(proposalHash, seal ? &*seal : nullptr);
+      }
+    }
+  }
+  for (size_t k = 0; k < rest.size(); k++) v[rest_idx[k]] = vr[k];
+  return v;
+}
+
 bool HotPath::handlePrepare(const View &view) {
   std::vector<MsgPtr> prepareMessages;
   const Proposal *proposal = getProposal();
+  closure_hits = 0;
   if (use_batch && batch) {
-    prepareMessages = messages.GetValidMessagesBatch(view, PREPARE, [&](const std::vector<MsgPtr> &all) {
-      std::vector<uint8_t> v;
-      if (!batch->VerifyPrepareBatch(proposal, all, v) || v.size() != all.size()) {
-        // device unavailable: the per-message closure, same lock held — never "nothing"
-        fallbacks++;
-        v.assign(all.size(), 0);
-        for (size_t k = 0; k < all.size(); k++)
-          v[k] = verifier->IsValidProposalHash(proposal, extract_prepare_hash(*all[k]));
-      }
-      return v;
-    });
+    prepareMessages = messages.GetValidMessagesBatch(
+        view, PREPARE, [&](const std::vector<MsgPtr> &all) { return closureVerdicts(proposal, PREPARE, all); });
   } else {
     prepareMessages = messages.GetValidMessages(view, PREPARE, [&](const IbftMessage &m) {
       return verifier->IsValidProposalHash(proposal, extract_prepare_hash(m));
@@ -367,21 +504,10 @@ bool HotPath::handlePrepare(const View &view) {
 bool HotPath::handleCommit(const View &view) {
   std::vector<MsgPtr> commitMessages;
   const Proposal *proposal = getProposal();
+  closure_hits = 0;
   if (use_batch && batch) {
-    commitMessages = messages.GetValidMessagesBatch(view, COMMIT, [&](const std::vector<MsgPtr> &all) {
-      std::vector<uint8_t> v;
-      if (!batch->VerifyCommitBatch(proposal, all, v) || v.size() != all.size()) {
-        fallbacks++;  // device unavailable: answer with the per-message verifier, same lock held
-        v.assign(all.size(), 0);
-        for (size_t k = 0; k < all.size(); k++) {
-          const bytes *proposalHash = extract_commit_hash(*all[k]);
-          std::optional<CommittedSeal> seal = extract_committed_seal(*all[k]);
-          v[k] = verifier->IsValidProposalHash(proposal, proposalHash) &&
-                 verifier->IsValidCommittedSeal(proposalHash, seal ? &*seal : nullptr);
-        }
-      }
-      return v;
-    });
+    commitMessages = messages.GetValidMessagesBatch(
+        view, COMMIT, [&](const std::vector<MsgPtr> &all) { return closureVerdicts(proposal, COMMIT, all); });
   } else {
     commitMessages = messages.GetValidMessages(view, COMMIT, [&](const IbftMessage &m) {
       const bytes *proposalHash = extract_commit_hash(m);

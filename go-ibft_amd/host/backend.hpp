@@ -40,6 +40,13 @@ struct BatchVerifier {
                                  std::vector<uint8_t> &verdict) = 0;
   // verdict[i] == IsValidValidator(msgs[i]) (ibft.go:1128)
   virtual bool VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &verdict) = 0;
+  // A whole PREPARE or COMMIT set at once (include/ibftgpu.h: ibft_verify_messages): sender[i] == IsValidValidator(msgs[i])
+  // and closure[i] == what handlePrepare's / handleCommit's closure returns for msgs[i] against `proposal` — all three
+  // predicates are pure, so a message can be judged completely when it arrives.  false = not offered / device unavailable.
+  virtual bool VerifyMessageSet(const Proposal * /*proposal*/, MessageType /*type*/, const std::vector<MsgPtr> & /*msgs*/,
+                                std::vector<uint8_t> & /*sender*/, std::vector<uint8_t> & /*closure*/) {
+    return false;
+  }
 };
 
 // SoA columns handed to the C ABI (plain bytes, no pointers inside: cgo-safe layout)
@@ -64,6 +71,8 @@ class GpuBackend : public BatchVerifier {
   bool VerifyPrepareBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifyCommitBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
+  bool VerifyMessageSet(const Proposal *, MessageType, const std::vector<MsgPtr> &, std::vector<uint8_t> &,
+                        std::vector<uint8_t> &) override;
   // §8f rank 3: IsValidValidator for n messages straight from their wire bytes.  The device walks,
   // hashes and verifies the PREPARE/COMMIT rows it can vouch for (ibft_verify_senders_wire); rows
   // it flags (other payload kinds, unknown fields, non-canonical encodings) take the stock route —
@@ -91,8 +100,11 @@ class LoopBatch : public BatchVerifier {
   bool VerifyPrepareBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifyCommitBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
-  bool fail_hashes = false, fail_seals = false, fail_senders = false;
-  size_t calls = 0;  // batch calls answered
+  bool VerifyMessageSet(const Proposal *, MessageType, const std::vector<MsgPtr> &, std::vector<uint8_t> &,
+                        std::vector<uint8_t> &) override;
+  bool fail_hashes = false, fail_seals = false, fail_senders = false, fail_sets = false;
+  size_t calls = 0;      // batch calls answered
+  size_t set_calls = 0;  // of which message-set calls
 
  private:
   Verifier *v_;
@@ -126,6 +138,7 @@ class HotPath {
   void NotifyValidatorSetChanged() {
     quorumIndex.Invalidate();
     verdict_cache_.clear();
+    closure_cache_.clear();
   }
   QuorumIndex quorumIndex;
   bool isAcceptableMessage(const IbftMessage &m);
@@ -146,9 +159,15 @@ class HotPath {
   // so NotifyValidatorSetChanged clears it, and a height prune drops what can no longer be accepted), then runs
   // AddMessage (AddMessageFast when the quorum index is enabled) per message with the verdict attached.
   // results[i]: −1 undecodable, else AddMessage's 0 / 1 / 2.
+  // With use_sets (default) the PREPARE / COMMIT messages of the CURRENT view are judged completely on arrival when the
+  // proposal is already accepted: one VerifyMessageSet call per type answers IsValidValidator and the handlePrepare /
+  // handleCommit closure together (both signatures of a COMMIT in one verdict launch); the closure verdicts wait in a
+  // table keyed by the stored message and handlePrepare / handleCommit only send the device what the table cannot answer.
   struct IngestStats {
-    size_t device_rows = 0, cache_hits = 0, device_calls = 0;
+    size_t device_rows = 0, cache_hits = 0, device_calls = 0, set_rows = 0;
   };
+  bool use_sets = true;
+  size_t closure_hits = 0;  // messages of the last handlePrepare / handleCommit whose closure verdict was already known
   bool IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats = nullptr);
   // IBFT.AddMessage with IsValidValidator already answered (AddMessageFast when the quorum index is enabled)
   int addWithVerdict(MsgPtr m, bool sender_ok);
@@ -178,7 +197,20 @@ class HotPath {
   struct CachedVerdict {
     bool ok;
     uint64_t height;
+    int closure = -1;            // −1 unknown, else the handle* closure's verdict …
+    uint64_t closure_epoch = 0;  // … against the proposal of this epoch
   };
+  // closure verdicts by stored message (the entry keeps the message alive, so its address cannot be reused)
+  struct ClosureVerdict {
+    MsgPtr keep;
+    bool ok;
+  };
+  std::map<const IbftMessage *, ClosureVerdict> closure_cache_;
+  bytes closure_key_;          // raw proposal ‖ BE64(round) the table refers to
+  uint64_t closure_epoch_ = 1;
+  void syncClosureKey(const Proposal *proposal);
+  // the handle* walks: table hits first, one batch call for the rest, per-message closure when that fails
+  std::vector<uint8_t> closureVerdicts(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &all);
   std::map<bytes, CachedVerdict> verdict_cache_;
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);

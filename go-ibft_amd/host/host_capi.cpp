@@ -102,6 +102,7 @@ struct ibft_host {
   CallbackVerifier cbv;
   std::unique_ptr<GpuBackend> gpu;
   std::unique_ptr<LoopBatch> loop;
+  size_t last_set_rows = 0;
 };
 
 extern "C" {
@@ -316,14 +317,20 @@ int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_
   if (device_rows) *device_rows = st.device_rows;
   if (cache_hits) *cache_hits = st.cache_hits;
   if (device_calls) *device_calls = st.device_calls;
+  h->last_set_rows = st.set_rows;
   return 0;
 }
+void ibft_host_use_sets(ibft_host *h, int on) { h->hp.use_sets = on != 0; }
+size_t ibft_host_last_set_rows(ibft_host *h) { return h->last_set_rows; }
+size_t ibft_host_closure_hits(ibft_host *h) { return h->hp.closure_hits; }
+size_t ibft_host_loop_batch_set_calls(ibft_host *h) { return h->loop ? h->loop->set_calls : 0; }
 
 void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
   h->loop.reset(new LoopBatch(&h->cbv));
   h->loop->fail_hashes = (fail_mask & 1) != 0;
   h->loop->fail_seals = (fail_mask & 2) != 0;
   h->loop->fail_senders = (fail_mask & 4) != 0;
+  h->loop->fail_sets = (fail_mask & 8) != 0;
   h->hp.batch = h->loop.get();
 }
 size_t ibft_host_loop_batch_calls(ibft_host *h) { return h->loop ? h->loop->calls : 0; }

@@ -104,6 +104,9 @@ def lib() -> C.CDLL:
         L.ibft_host_use_loop_batch.argtypes = [vp, C.c_int]
         L.ibft_host_loop_batch_calls.argtypes = [vp]; L.ibft_host_loop_batch_calls.restype = C.c_size_t
         L.ibft_host_fallbacks.argtypes = [vp]; L.ibft_host_fallbacks.restype = C.c_size_t
+        L.ibft_host_use_sets.argtypes = [vp, C.c_int]; L.ibft_host_use_sets.restype = None
+        for nm in ('ibft_host_last_set_rows', 'ibft_host_closure_hits', 'ibft_host_loop_batch_set_calls'):
+            getattr(L, nm).argtypes = [vp]; getattr(L, nm).restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -348,6 +351,18 @@ class Host:
         if rc != 0:
             raise RuntimeError(f"ibft_host_ingest_wire rc={rc}")
         return [x - 256 if x > 127 else x for x in res.raw[:len(wires)]], a.value, b.value, c.value
+
+    def use_sets(self, on: bool):
+        self.L.ibft_host_use_sets(self.h, 1 if on else 0)
+
+    def last_set_rows(self) -> int:
+        return self.L.ibft_host_last_set_rows(self.h)
+
+    def closure_hits(self) -> int:
+        return self.L.ibft_host_closure_hits(self.h)
+
+    def loop_batch_set_calls(self) -> int:
+        return self.L.ibft_host_loop_batch_set_calls(self.h)
 
     def use_loop_batch(self, fail_mask: int = 0):
         self.L.ibft_host_use_loop_batch(self.h, fail_mask)

@@ -117,9 +117,20 @@ int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len
  * batch backend, or when the device call fails, the per-message verifier answers (ibft_host_fallbacks).   */
 int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_t *results, size_t n,
                           size_t *device_rows, size_t *cache_hits, size_t *device_calls);
+/* Message sets (include/ibftgpu.h: ibft_verify_messages).  When the proposal of the current view is already
+ * accepted, ibft_host_ingest_wire sends the PREPARE / COMMIT messages of that view through ONE set call per
+ * type: IsValidValidator and the handlePrepare / handleCommit closure (core/ibft.go:856-862, :932-944) are
+ * answered together, the closure verdicts wait in a table keyed by the stored message, and
+ * ibft_host_handle_prepare / _commit only send the device what the table cannot answer
+ * (ibft_host_closure_hits = messages of the last handle call answered from it).  The table is dropped when
+ * the proposal, the round or the validator set changes and pruned with the store.  use_sets(0) = off.      */
+void ibft_host_use_sets(ibft_host *h, int on);
+size_t ibft_host_last_set_rows(ibft_host *h);   /* rows of the last ingest that went through set calls */
+size_t ibft_host_closure_hits(ibft_host *h);
+size_t ibft_host_loop_batch_set_calls(ibft_host *h);
 /* A batch backend that loops over the callback Verifier (no device): the batch control flow — one call per walk,
  * verdict tables, fallback — for CPU-side tests.  fail_mask bits: 1 hash batches, 2 seal batches, 4 sender
- * batches report "device unavailable".                                                                      */
+ * batches, 8 message-set calls report "device unavailable".                                                                      */
 void ibft_host_use_loop_batch(ibft_host *h, int fail_mask);
 size_t ibft_host_loop_batch_calls(ibft_host *h);
 /* batches that fell back to the per-message verifier because the batch backend reported failure            */

@@ -52,13 +52,21 @@ func (i *IBFT) commitMessagesFor(view *proto.View) []*proto.IbftMessage {
 		fellBack := false
 		msgs := store.GetValidMessagesBatch(view, proto.MessageType_COMMIT,
 			func(all []*proto.IbftMessage) []bool {
-				verdicts, ok := bv.VerifyCommitBatch(i.state.getProposal(), all)
-				if !ok { // device unavailable: answer with the per-message verifier, same lock held
+				// what AddMessages already judged against this proposal (message_sets.go) is not asked again
+				verdicts, rest, restIdx := i.lookupClosures(all)
+				if len(rest) == 0 {
+					return verdicts
+				}
+				vr, ok := bv.VerifyCommitBatch(i.state.getProposal(), rest)
+				if !ok || len(vr) != len(rest) { // device unavailable: the per-message verifier, same lock held
 					fellBack = true
-					verdicts = make([]bool, len(all))
-					for k, m := range all {
-						verdicts[k] = isValidCommit(m)
+					vr = make([]bool, len(rest))
+					for k, m := range rest {
+						vr[k] = isValidCommit(m)
 					}
+				}
+				for k, v := range vr {
+					verdicts[restIdx[k]] = v
 				}
 				return verdicts
 			})
@@ -78,12 +86,19 @@ func (i *IBFT) prepareMessagesFor(view *proto.View) []*proto.IbftMessage {
 	if hasBatch && storeOK {
 		return store.GetValidMessagesBatch(view, proto.MessageType_PREPARE,
 			func(all []*proto.IbftMessage) []bool {
-				verdicts, ok := bv.VerifyPrepareBatch(i.state.getProposal(), all)
-				if !ok {
-					verdicts = make([]bool, len(all))
-					for k, m := range all {
-						verdicts[k] = isValidPrepare(m)
+				verdicts, rest, restIdx := i.lookupClosures(all)
+				if len(rest) == 0 {
+					return verdicts
+				}
+				vr, ok := bv.VerifyPrepareBatch(i.state.getProposal(), rest)
+				if !ok || len(vr) != len(rest) {
+					vr = make([]bool, len(rest))
+					for k, m := range rest {
+						vr[k] = isValidPrepare(m)
 					}
+				}
+				for k, v := range vr {
+					verdicts[restIdx[k]] = v
 				}
 				return verdicts
 			})

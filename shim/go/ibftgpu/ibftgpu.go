@@ -179,6 +179,40 @@ func (c *Ctx) VerifySenders(payload []byte, off []uint32, sig65, from20, preFlag
 	return mask, tally(t), c.check(rc)
 }
 
+// VerifyMessages = a whole PREPARE / COMMIT set in one call (ibft_verify_messages): senderMask bit i is
+// IsValidValidator(message i), validMask bit i the handlePrepare / handleCommit closure for it, the tally is
+// HasQuorum over the rows with both bits.  seal65 == nil for a PREPARE set; senderPre / validPre may be nil.
+func (c *Ctx) VerifyMessages(payload []byte, off []uint32, msgSig65, from20, hash32, hashLen, seal65, senderPre, validPre,
+	raw []byte, round uint64) (senderMask, validMask []uint64, t Tally, err error) {
+	n := len(off) - 1
+	senderMask, validMask = make([]uint64, (n+63)/64+1), make([]uint64, (n+63)/64+1)
+	var ct C.ibft_tally_t
+	rc := C.ibft_verify_messages(c.h, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0])), ptr8(msgSig65), ptr8(from20),
+		ptr8(hash32), ptr8(hashLen), ptr8(seal65), ptr8(senderPre), ptr8(validPre), C.size_t(n), ptr8(raw),
+		C.size_t(len(raw)), C.uint64_t(round), nil, (*C.uint64_t)(unsafe.Pointer(&senderMask[0])),
+		(*C.uint64_t)(unsafe.Pointer(&validMask[0])), &ct)
+	return senderMask, validMask, tally(ct), c.check(rc)
+}
+
+// PinnedBytes returns n bytes of page-locked memory (ibft_pinned_alloc) as a Go slice: column buffers the
+// flatten step writes into once and reuses every round.  When every column of a call lies in such buffers the
+// library reads them with one gather launch instead of one copy command per column.  C memory: invisible to
+// the garbage collector, release with FreePinned.
+func PinnedBytes(n int) []byte {
+	p := C.ibft_pinned_alloc(C.size_t(n))
+	if p == nil {
+		return make([]byte, n) // ordinary memory works everywhere, only slower
+	}
+	return unsafe.Slice((*byte)(p), n)
+}
+
+// FreePinned releases a slice obtained from PinnedBytes (and only such a slice).
+func FreePinned(b []byte) {
+	if len(b) > 0 {
+		C.ibft_pinned_free(unsafe.Pointer(&b[0]))
+	}
+}
+
 // WireRow is what the device found in one IbftMessage (ibft_wire_row_t).
 type WireRow struct {
 	Height, Round                            uint64

@@ -266,9 +266,13 @@ def test_extended_rcc_with_quorum_sized_certificates_batch_equals_stock(gpu_veri
     assert len(out[True]) == len(rcs) - 2 and wires[3] not in out[True] and wires[9] not in out[True]
 
 
-def test_ingest_wire_through_the_device(gpu_verifier, oracle):
-    """§8f rank 1 with the real backend: a micro-batch of raw COMMIT messages → one ibft_verify_senders_wire call;
-    re-delivery → the verdict cache; results equal per-message IBFT.AddMessage with the oracle-backed verifier."""
+@pytest.mark.parametrize("sets", [False, True])
+def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets):
+    """§8f rank 1 with the real backend.  sets off: a micro-batch of raw messages → one ibft_verify_senders_wire call.
+    sets on (default): the PREPARE and COMMIT messages of the current view → one ibft_verify_messages call per type,
+    both signatures of every COMMIT in one verdict launch, and handlePrepare / handleCommit then decide without
+    another device call.  Re-delivery → the verdict cache.  Everything equals per-message IBFT.AddMessage and the
+    stock walks with the oracle-backed verifier."""
     import go_ibft_amd.hostlib as H
     r, proposal, prepares, commits = _build_round(oracle, 300, 77, byzantine=True)
     gpu_verifier.set_validators(r.height, r.addrs, r.power)
@@ -282,13 +286,29 @@ def test_ingest_wire_through_the_device(gpu_verifier, oracle):
         h.set_verifier(f1, f2, f3)
     ing.attach_gpu(gpu_verifier)
     ing.use_batch(True)
+    ing.use_sets(sets)
     ing.enable_quorum_index()
     expect = [ref.add_message(x) for x in wires]
     got, rows, hits, calls = ing.ingest_wire(wires)
-    assert got == expect and (rows, hits, calls) == (len(wires), 0, 1)
+    assert got == expect and (rows, hits, calls) == (len(wires), 0, 2 if sets else 1)
+    assert ing.last_set_rows() == (len(wires) if sets else 0)
     assert 0 in got and 2 in got
     again, rows, hits, calls = ing.ingest_wire(wires)
     assert (rows, hits, calls) == (0, len(wires), 0) and [x != 0 for x in again] == [x != 0 for x in expect]
     for t in (1, 2):
         assert ref.store_num(r.height, r.round, t) == ing.store_num(r.height, r.round, t)
+    okp, prepared = ref.handle_prepare(r.height, r.round)
+    okp2, prepared2 = ing.handle_prepare(r.height, r.round)
+    assert (okp, sorted(prepared)) == (okp2, sorted(prepared2))
+    hits_p = ing.closure_hits()
+    okc, seals = ref.handle_commit(r.height, r.round)
+    okc2, seals2 = ing.handle_commit(r.height, r.round)
+    assert okc and (okc, sorted(seals)) == (okc2, sorted(seals2))
+    for t in (1, 2):
+        assert ref.store_num(r.height, r.round, t) == ing.store_num(r.height, r.round, t)
+    if sets:    # every stored message had its closure verdict waiting
+        assert hits_p >= len(prepared2) and ing.closure_hits() >= len(seals2)
+    else:
+        assert hits_p == 0 and ing.closure_hits() == 0
+    assert ing.fallbacks() == 0
     ref.close(); ing.close()

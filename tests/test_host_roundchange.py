@@ -219,3 +219,64 @@ def test_ingest_micro_batches_and_the_verdict_cache():
     assert got == expect and calls == 0
     for h in (ref, ing, plain):
         h.close()
+
+
+@pytest.mark.parametrize("mode", ["sets", "sets-fail", "sets-off"])
+def test_messages_judged_completely_on_arrival(mode):
+    """Message sets (ibft_verify_messages behind BatchVerifier::VerifyMessageSet): with the proposal of the view accepted,
+    a PREPARE / COMMIT that arrives is judged completely — IsValidValidator AND the handlePrepare / handleCommit closure —
+    by one set call per type and micro-batch; handlePrepare / handleCommit then decide like the stock walk WITHOUT another
+    batch call.  A failing set call, or sets switched off, gives the same decisions through the older batches."""
+    w, proposal, prepares, commits = _commit_world(n=13, bad=(2, 5))
+    ver = w.verifier()
+    ver["is_valid_committed_seal"] = lambda hsh, seal: seal is not None and not seal[1].endswith(b"03")
+    w.bad_wires.add(commits[7].encode())                # a forged envelope: never stored
+    w.bad_wires.add(prepares[4].encode())
+    future = [W.IbftMessage(view=W.View(1, 1), sender=a, type=CM, payload=W.commit_body(b"f" * 32, b"seal-" + a))
+              for a in w.addrs[:3]]                     # another round: sender check only
+    ref, ing = H.Host(), H.Host()
+    for h in (ref, ing):
+        assert h.vm_init({a: 1 for a in w.addrs})
+        h.set_verifier(**ver)
+        h.set_state(1, 0, proposal.encode())
+    ing.use_loop_batch(8 if mode == "sets-fail" else 0)
+    ing.use_batch(True)
+    ing.use_sets(mode != "sets-off")
+    wires = [m.encode() for m in prepares + commits + future]
+    random.Random(5).shuffle(wires)
+    expect = [ref.add_message(x) for x in wires]
+    got = []
+    for k in range(0, len(wires), 7):                   # micro-batches, as the transport would hand them over
+        res, rows, hits, calls = ing.ingest_wire(wires[k:k + 7])
+        got += res
+        if mode == "sets":
+            assert calls <= 3 and ing.last_set_rows() + 3 >= rows       # ≤ one call per type + one for other views
+        else:
+            assert ing.last_set_rows() == 0
+    assert [g != 0 for g in got] == [e != 0 for e in expect]
+    assert ing.loop_batch_set_calls() > 0 if mode == "sets" else ing.loop_batch_set_calls() == 0
+    # gossip re-delivery of everything: verdicts (both kinds) come from the cache, no batch call at all
+    before = ing.loop_batch_calls()
+    res, rows, hits, calls = ing.ingest_wire(wires)
+    assert (rows, calls) == (0, 0) and ing.loop_batch_calls() == before
+    for handle in ("handle_prepare", "handle_commit"):
+        before = ing.loop_batch_calls()
+        a, b = getattr(ref, handle)(1, 0), getattr(ing, handle)(1, 0)
+        assert (a[0], sorted(a[1])) == (b[0], sorted(b[1])) if isinstance(a, tuple) else a == b
+        stored = ing.store_num(1, 0, PR if handle == "handle_prepare" else CM)
+        assert ref.store_num(1, 0, PR if handle == "handle_prepare" else CM) == stored   # same messages pruned
+        if mode == "sets":
+            assert ing.loop_batch_calls() == before and ing.closure_hits() >= stored
+        else:
+            assert ing.loop_batch_calls() == before + 1 and ing.closure_hits() == 0
+    assert ing.fallbacks() == 0
+    # a new round with another proposal: what the table said no longer applies — the walk asks the batch backend again
+    raw2 = b"block two"
+    proposal2 = W.IbftMessage(view=W.View(1, 1), sender=w.proposer(1, 1), type=PP,
+                              payload=W.preprepare_body(W.Proposal(raw2, 1), fake_hash(raw2, 1), None))
+    for h in (ref, ing):
+        h.set_state(1, 1, proposal2.encode())
+    before = ing.loop_batch_calls()
+    a, b = ref.handle_commit(1, 1), ing.handle_commit(1, 1)
+    assert a[0] == b[0] and ing.closure_hits() == 0 and ing.loop_batch_calls() == before + 1
+    ref.close(); ing.close()
