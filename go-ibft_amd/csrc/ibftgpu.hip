@@ -49,6 +49,7 @@ struct ibft_ctx {
   // and no memset is needed in front of the atomicOr kernels
   uint32_t mask_dirty_words = ~0u;
   DevBuf d_wire_rows, d_seal;  // §8f rank 3: per-row parse results and the COMMIT seals found in the wire bytes
+  DevBuf d_noseal;             // message sets from wire bytes: rows (PREPAREs) whose closure has no seal
   uint32_t wire_n = 0;         // rows of the last ibft_verify_senders_wire
   bool wire_valid = false;     // its columns are still the resident ones
   // fixed-base table for G
@@ -820,7 +821,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
-                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set})
+                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal})
     release(*b);
   comm_release(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -1425,6 +1426,98 @@ int ibft_verify_senders_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint3
   if (out_rows && n)
     HIPCHK(c, hipMemcpyAsync(out_rows, c->d_wire_rows.p, n * sizeof(ibft_wire_row_t), hipMemcpyDeviceToHost, c->stream));
   return fetch_results(c, (uint32_t)n, out_mask, tally, true);
+}
+
+// A batch of raw IbftMessages judged completely: the wire walk, then BOTH signatures of every message in one verdict
+// launch (sender rows [0, n), seal rows [half, half + n)), the closure's hash compare folded into the combine step.
+int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint32_t *off, size_t n, uint64_t height,
+                              uint64_t round, const uint8_t *raw, size_t raw_len, uint64_t proposal_round,
+                              const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask,
+                              ibft_wire_row_t *out_rows, ibft_tally_t *tally) {
+  if (!c || (n && (!off || !out_sender_mask || !out_valid_mask))) return IBFT_E_INVAL;
+  if ((raw_len && !raw) || raw_len > (1ull << 31)) return IBFT_E_INVAL;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  c->wire_valid = false;
+  c->staged_n = 0;
+  const uint32_t half = ((uint32_t)n + 63u) & ~63u;
+  if ((rc = alloc_rows(c, 2 * (((uint32_t)c->max_rows + 63u) & ~63u)))) return rc;
+  if (digest32) {
+    c->have_H = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
+    memcpy(c->h_digest, digest32, 32);
+    HIPCHK(c, hipMemcpyAsync(c->d_H.p, c->h_digest, 32, hipMemcpyHostToDevice, c->stream));
+  } else if ((rc = ensure_proposal_hash(c, raw, raw_len, proposal_round))) {
+    return rc;
+  }
+  if (n == 0) {
+    if (tally) {
+      memset(tally, 0, sizeof *tally);
+      tally->quorum_lo = c->quorum_w[0];
+      tally->quorum_hi = c->quorum_w[1];
+    }
+    for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = 0;
+    return IBFT_OK;
+  }
+  const size_t wbytes = off[n];
+  if ((rc = ensure(c, c->d_payload, wbytes + 256))) return rc;
+  if ((rc = ensure(c, c->d_wire_rows, (size_t)c->max_rows * sizeof(wire::row_info)))) return rc;
+  if ((rc = ensure(c, c->d_seal, (size_t)c->max_rows * 65 + 64))) return rc;
+  if ((rc = ensure(c, c->d_noseal, c->max_rows))) return rc;
+  ColumnCopies cc;
+  cc.add(c->d_payload.p, wire_bytes, wbytes);
+  cc.add(c->d_off.p, off, (n + 1) * 4);
+  if ((rc = cc.flush(c))) return rc;
+  uint8_t *d_hash = (uint8_t *)c->d_hash.p, *d_sig = (uint8_t *)c->d_sig.p, *d_signer = (uint8_t *)c->d_signer.p,
+          *d_pre = (uint8_t *)c->d_pre.p;
+  hipLaunchKernelGGL(ibftk::wire_parse_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
+                     (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n,
+                     (wire::row_info *)c->d_wire_rows.p, d_hash, d_sig, d_signer, (uint8_t *)c->d_seal.p, d_pre);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(ibftk::wire_set_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     (const wire::row_info *)c->d_wire_rows.p, (const uint8_t *)c->d_seal.p, (uint32_t)n, half, height, round,
+                     d_hash, (uint8_t *)c->d_hash_len.p, d_sig, d_signer, d_pre, (uint8_t *)c->d_noseal.p);
+  HIPCHK(c, hipGetLastError());
+  if (half != n) HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
+  c->ev_used = 0;
+  const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
+  if ((rc = enqueue_recover(c, half + (uint32_t)n, false, 0, time_it))) return rc;
+  ibftk::set_args sa{};
+  sa.work_mask = (uint64_t *)c->d_mask.p;
+  sa.hash32 = d_hash + 32ull * half;
+  sa.hash_len = (const uint8_t *)c->d_hash_len.p;
+  sa.H4 = (const uint64_t *)c->d_H.p;
+  sa.sender_pre = d_pre;  // not canonical here, or From / Signature of a length no signature check can pass
+  sa.valid_pre = d_pre + half;
+  sa.no_seal = (const uint8_t *)c->d_noseal.p;
+  sa.n = (uint32_t)n;
+  sa.half_words = half / 64;
+  const size_t mw = (size_t)mask_words(n);
+  sa.sender_out = (uint64_t *)c->d_set.p;
+  sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
+  sa.host_sender = c->dh_set;
+  sa.host_valid = c->dh_set ? c->dh_set + mask_words(c->max_rows) : nullptr;
+  hipLaunchKernelGGL(ibftk::message_set_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sa);
+  HIPCHK(c, hipGetLastError());
+  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  c->mask_dirty_words = 0;
+  if (!c->dh_set)
+    HIPCHK(c, hipMemcpyAsync(c->h_set, c->d_set.p, (size_t)mask_words(c->max_rows) * 16, hipMemcpyDeviceToHost, c->stream));
+  if (out_rows)
+    HIPCHK(c, hipMemcpyAsync(out_rows, c->d_wire_rows.p, n * sizeof(ibft_wire_row_t), hipMemcpyDeviceToHost, c->stream));
+  if ((rc = fetch_results(c, (uint32_t)n, nullptr, tally, true))) {
+    c->have_H = false;
+    return rc;
+  }
+  memcpy(out_sender_mask, c->h_set, mw * 8);
+  memcpy(out_valid_mask, c->h_set + mask_words(c->max_rows), mw * 8);
+  return IBFT_OK;
 }
 
 int ibft_wire_stage_seals(ibft_ctx *c) {

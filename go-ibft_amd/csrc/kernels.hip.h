@@ -802,6 +802,7 @@ struct set_args {
   const uint8_t *hash_len;  // n
   const uint64_t *H4;       // keccak256(raw proposal ‖ BE64(round))
   const uint8_t *sender_pre, *valid_pre;  // n each or null: rows the host rejected before any crypto
+  const uint8_t *no_seal;   // n or null: rows (PREPAREs of a mixed wire batch) whose valid bit is a1 alone
   uint32_t n, half_words;   // half_words = 0: no seals (PREPARE)
   uint64_t *sender_out, *valid_out;    // device copies (⌈n/64⌉ words each)
   uint64_t *host_sender, *host_valid;  // mapped pinned host memory or null
@@ -819,6 +820,7 @@ __global__ void message_set_combine_kernel(set_args a) {
     a1 = diff == 0 && a.hash_len[row] == 32 && !(a.valid_pre && a.valid_pre[row] != 0);
   }
   const uint64_t bal = __ballot(a1), sbad = __ballot(spre);
+  const uint64_t skip_seal = __ballot(row < a.n && a.no_seal && a.no_seal[row] != 0);
   if ((threadIdx.x & 63) != 0 || row >= a.n) return;
   const uint32_t w = row >> 6;
   const uint32_t left = a.n - row;  // ≥ 1
@@ -826,7 +828,7 @@ __global__ void message_set_combine_kernel(set_args a) {
   const uint64_t S = a.work_mask[w] & tail & ~sbad;
   uint64_t V = bal;
   if (a.half_words) {
-    V &= a.work_mask[a.half_words + w];
+    V &= a.work_mask[a.half_words + w] | skip_seal;
     a.work_mask[a.half_words + w] = 0;
   }
   a.sender_out[w] = S;
@@ -836,6 +838,33 @@ __global__ void message_set_combine_kernel(set_args a) {
     a.host_valid[w] = V;
   }
   a.work_mask[w] = S & V;
+}
+
+// The same set judged straight from the transport's bytes: wire_parse_kernel has filled the sender rows [0, n)
+// (digest of PayloadNoSig, Signature, From) and the seal column; this kernel lays the second group of verdict rows
+// [half, half + n) — the hash each message carries as digest, its committed seal as signature, From as signer — and
+// decides, per row, everything about the closure that needs no arithmetic: valid_pre ≠ 0 unless the message is a
+// canonical PREPARE (type 1, PrepareMessage) or COMMIT (type 2, CommitMessage, 65-byte seal) of the view
+// (height, round) with a 20-byte From (ExtractPrepareHash / ExtractCommitHash / ExtractCommittedSeal return nil
+// otherwise, messages/helpers.go).  A PREPARE row's seal row is a zero signature: its verdict is forced below.
+__global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, const uint8_t *__restrict__ seal65, uint32_t n,
+                                      uint32_t half, uint64_t height, uint64_t round, uint8_t *__restrict__ hash32,
+                                      uint8_t *__restrict__ hash_len, uint8_t *__restrict__ sig65,
+                                      uint8_t *__restrict__ signer20, uint8_t *__restrict__ pre_flags,
+                                      uint8_t *__restrict__ is_prepare) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const wire::row_info &ri = rows[row];
+  const bool here = ri.status == wire::STATUS_OK && ri.has_view && ri.height == height && ri.round == round && ri.from_len == 20;
+  const bool prepare = here && ri.type == 1 && ri.payload_kind == wire::KIND_PREPARE;
+  const bool commit = here && ri.type == 2 && ri.payload_kind == wire::KIND_COMMIT && ri.seal_len == 65;
+  const uint32_t dst = half + row;
+  for (int i = 0; i < 32; i++) hash32[32ull * dst + i] = ri.proposal_hash[i];
+  for (int i = 0; i < 65; i++) sig65[65ull * dst + i] = commit ? seal65[65ull * row + i] : 0;
+  for (int i = 0; i < 20; i++) signer20[20ull * dst + i] = ri.from[i];
+  hash_len[row] = ri.hash_len;
+  pre_flags[dst] = (prepare || commit) ? 0 : 1;
+  is_prepare[row] = prepare ? 1 : 0;
 }
 
 // ---- a8: weighted quorum tally ------------------------------------------------------------

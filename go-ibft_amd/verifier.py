@@ -37,6 +37,7 @@ EXPORTS = [
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
+    "ibft_verify_messages_wire",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -122,6 +123,8 @@ def load_library() -> C.CDLL:
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp,
+                                            C.POINTER(Tally)]
     L.ibft_pinned_alloc.argtypes = [C.c_size_t]; L.ibft_pinned_alloc.restype = vp
     L.ibft_pinned_free.argtypes = [vp]; L.ibft_pinned_free.restype = None
     L.ibft_column_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -375,6 +378,24 @@ class BatchVerifier:
                                                    C.byref(t)), "ibft_verify_senders_wire")
         self._staged = n
         return mask_to_bool(mask, n), rows, t
+
+    def verify_messages_wire(self, wire, off, height: int, round_: int, raw: bytes | None = None, proposal_round: int | None = None,
+                             digest32: bytes | None = None):
+        """raw messages judged completely → (sender bool[n], valid bool[n], rows, Tally); see include/ibftgpu.h"""
+        wb = _bytes_col(wire)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = len(off) - 1
+        ms = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        rows = np.zeros(n, dtype=WIRE_ROW)
+        rawb = None if raw is None else np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
+        dg = None if digest32 is None else np.frombuffer(bytes(digest32), dtype=np.uint8)
+        t = Tally()
+        self._chk(self._L.ibft_verify_messages_wire(self._h, _p(wb), _p(off), n, height, round_, _p(rawb),
+                                                    0 if raw is None else len(raw),
+                                                    round_ if proposal_round is None else proposal_round, _p(dg), _p(ms), _p(mv),
+                                                    _p(rows) if n else None, C.byref(t)), "ibft_verify_messages_wire")
+        return mask_to_bool(ms, n), mask_to_bool(mv, n), rows, t
 
     def wire_stage_seals(self):
         """the COMMIT seals of the last is_valid_validator_wire batch become the resident seal batch"""

@@ -300,6 +300,24 @@ int ibft_verify_messages(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *
                          const uint8_t *raw, size_t raw_len, uint64_t round, const uint8_t *digest32,
                          uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally);
 
+/* The same for a batch of messages AS THE TRANSPORT DELIVERED THEM (ibft_verify_senders_wire's input): the
+ * device walks the bytes, and every canonical PREPARE / COMMIT message of the view (height, round) is judged
+ * completely in one verdict launch — no proto.Unmarshal, no PayloadNoSig re-marshal, no flattening on the host.
+ *   out_sender_mask bit i = IsValidValidator(message i)        (0 for rows with out_rows[i].status ==
+ *                           IBFT_WIRE_NEEDS_HOST: those take the stock route, exactly as after
+ *                           ibft_verify_senders_wire);
+ *   out_valid_mask  bit i = message i is a PREPARE or COMMIT of (height, round) — type and payload agree, 20-byte
+ *                           From, 65-byte seal for a COMMIT — whose 32-byte proposal hash equals the proposal's
+ *                           and, for a COMMIT, whose committed seal verifies for From: the handlePrepare /
+ *                           handleCommit closure (core/ibft.go:856-862, :932-944).  Messages of other views or
+ *                           kinds have bit 0 here and are judged when their view is handled;
+ *   tally                 = HasQuorum over the rows with both bits (meaningful for a batch of one type).
+ * The proposal: raw + proposal_round (hashed once and remembered) or digest32, as in ibft_verify_messages.   */
+int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const uint32_t *off, size_t n,
+                              uint64_t height, uint64_t round, const uint8_t *raw, size_t raw_len,
+                              uint64_t proposal_round, const uint8_t *digest32, uint64_t *out_sender_mask,
+                              uint64_t *out_valid_mask, ibft_wire_row_t *out_rows, ibft_tally_t *tally);
+
 /* ---- f4: the signing side, for SIMULATORS ----------------------------------
  * Replaces, for a process that plays n validators at once, the n calls of Backend.BuildCommitMessage
  * (/root/reference/core/backend.go:12-34; sendCommitMessage, core/ibft.go:898-909) that each produce one

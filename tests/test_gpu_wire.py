@@ -146,3 +146,51 @@ def test_golden_wire_rows_on_gpu(oracle):
         bv.close()
     assert [int(s) for s in info["status"]] == [o["status"] for o in rows]
     assert (got == want).all() and want.sum() >= 10
+
+
+@pytest.mark.parametrize("cache", [False, True])
+def test_messages_judged_completely_from_wire_bytes(oracle, cache):
+    """ibft_verify_messages_wire: sender bits ≡ ibft_verify_senders_wire; valid bits ≡ the handlePrepare / handleCommit
+    closure evaluated by the oracle on the decoded message — for canonical PREPARE / COMMIT messages of the asked view
+    only; other views, other kinds, odd encodings and fuzzed bytes have valid bit 0."""
+    import go_ibft_amd.verifier as V
+    height, rnd = 9, 1
+    r = W.make_round(300, 611, height=height, round_=rnd, byzantine=True, weighted=True)
+    other = W.make_round(40, 612, height=height, round_=rnd + 1)               # same height, another round
+    rows_bytes = WCASE.canonical_round(r, ("commit", "prepare", "commit", "prepare", "preprepare", "roundchange")) + \
+        WCASE.canonical_round(other) + [m for _, m in WCASE.handmade(r)] + WCASE.fuzz(WCASE.canonical_round(r)[:40], 400, 23)
+    wire, off = WCASE.pack(rows_bytes)
+    vs = oracle.ValSet(r.addrs, r.power)
+    exps, want_sender = _expected(oracle, vs, rows_bytes)
+    H = oracle.proposal_hash(r.raw, rnd)
+    want_valid = np.zeros(len(exps), dtype=bool)
+    for i, e in enumerate(exps):
+        if e.status != WP.OK or (e.height, e.round) != (height, rnd) or len(e.sender) != 20 or e.proposal_hash != H:
+            continue
+        if e.type == 1 and e.payload_kind == 6:
+            want_valid[i] = True
+        elif e.type == 2 and e.payload_kind == 7 and len(e.committed_seal) == 65:
+            got = oracle.recover_address(e.proposal_hash, e.committed_seal)
+            want_valid[i] = got is not None and got == e.sender and vs.index(e.sender) >= 0
+    assert want_valid.sum() > 100 and (want_sender & ~want_valid).sum() > 20
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE if cache else 0, max_rows=4096)
+    try:
+        bv.set_validators(1, r.addrs, r.power)
+        for _ in range(3 if cache else 1):
+            s, v, rows, t = bv.verify_messages_wire(wire, off, height, rnd, raw=r.raw)
+            assert (s == want_sender).all(), np.nonzero(s != want_sender)[0][:10]
+            assert (v == want_valid).all(), np.nonzero(v != want_valid)[0][:10]
+            assert [int(x) for x in rows["status"]] == [e.status for e in exps]
+        # the digest form of the proposal, and a pinned buffer for the bytes
+        s, v, _, _ = bv.verify_messages_wire(V.pinned_copy(wire), V.pinned_copy(off), height, rnd, digest32=H)
+        assert (s == want_sender).all() and (v == want_valid).all() and bv.gather_batches() >= 1
+        # asked about another view: the same sender bits, the other round's messages do not match THIS proposal
+        s, v, _, _ = bv.verify_messages_wire(wire, off, height, rnd + 1, raw=r.raw, proposal_round=rnd)
+        assert (s == want_sender).all() and not v.any()
+        # the older two-step route still answers the same afterwards (columns restaged cleanly)
+        got, _, _ = bv.is_valid_validator_wire(wire, off)
+        assert (got == want_sender).all()
+        s, v, rows, t = bv.verify_messages_wire(*WCASE.pack([]), height, rnd, raw=r.raw)
+        assert len(s) == 0 and len(v) == 0 and t.has_quorum == 0
+    finally:
+        bv.close()
