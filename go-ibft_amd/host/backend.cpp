@@ -172,6 +172,42 @@ bool GpuBackend::VerifySendersWire(const uint8_t *wire, const uint32_t *off, siz
   return true;
 }
 
+bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
+                                    const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
+                                    std::vector<uint8_t> &judged) {
+  sender.assign(n, 0);
+  closure.assign(n, 0);
+  judged.assign(n, 0);
+  if (n == 0) return true;
+  std::vector<uint64_t> ms((n + 63) / 64, 0), mv((n + 63) / 64, 0);
+  std::vector<ibft_wire_row_t> rows(n);
+  last_rc = ibft_verify_messages_wire(ctx_, wire, off, n, height, round, (const uint8_t *)proposal.raw_proposal.data(),
+                                      proposal.raw_proposal.size(), proposal.round, nullptr, ms.data(), mv.data(), rows.data(),
+                                      nullptr);
+  if (last_rc != IBFT_OK) return false;
+  unpack_mask(ms, n, sender);
+  unpack_mask(mv, n, closure);
+  std::vector<size_t> idx;
+  std::vector<MsgPtr> msgs;
+  for (size_t i = 0; i < n; i++) {
+    const ibft_wire_row_t &ri = rows[i];
+    if (ri.status == IBFT_WIRE_OK) {
+      // the closure of a PREPARE / COMMIT of this view is settled by the device, whatever the verdict
+      judged[i] = ri.has_view && ri.height == height && ri.round == round && (ri.type == PREPARE || ri.type == COMMIT);
+      continue;
+    }
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode(wire + off[i], off[i + 1] - off[i], *m)) continue;  // proto.Unmarshal error: dropped
+    idx.push_back(i);
+    msgs.push_back(std::move(m));
+  }
+  if (msgs.empty()) return true;
+  std::vector<uint8_t> v2;
+  if (!VerifySenderBatch(msgs, v2)) return false;
+  for (size_t j = 0; j < idx.size(); j++) sender[idx[j]] = v2[j];
+  return true;
+}
+
 bool LoopBatch::VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
   if (fail_hashes) return false;
   calls++;
@@ -329,7 +365,33 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
   }
   // (1) messages of the current view with the proposal at hand: judged completely, one set call per type
   std::vector<size_t> rest;
-  if (use_batch && batch && use_sets && proposal) {
+  GpuBackend *gpu_sets = (use_batch && use_sets && proposal) ? dynamic_cast<GpuBackend *>(batch) : nullptr;
+  bool wire_sets_done = false;
+  if (gpu_sets && !ask.empty()) {
+    // the device walks the bytes AND judges every PREPARE / COMMIT of this view completely: one call for the micro-batch
+    bytes wire;
+    std::vector<uint32_t> off{0};
+    for (size_t i : ask) {
+      wire += raw[i];
+      off.push_back((uint32_t)wire.size());
+    }
+    std::vector<uint8_t> vs, vc, judged;
+    if (gpu_sets->VerifyMessagesWire((const uint8_t *)wire.data(), off.data(), ask.size(), height, round, *proposal, vs, vc,
+                                     judged)) {
+      st.device_calls++;
+      for (size_t j = 0; j < ask.size(); j++) {
+        verdict[ask[j]] = vs[j] ? 1 : 0;
+        if (judged[j]) {
+          closure[ask[j]] = vc[j] ? 1 : 0;
+          st.set_rows++;
+        }
+      }
+      wire_sets_done = true;
+    }
+  }
+  if (wire_sets_done) {
+    // nothing left
+  } else if (use_batch && batch && use_sets && proposal && !gpu_sets) {
     std::vector<size_t> of_type[2];
     for (size_t i : ask) {
       const IbftMessage &m = *msgs[i];

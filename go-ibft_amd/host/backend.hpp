@@ -85,6 +85,12 @@ class GpuBackend : public BatchVerifier {
   };
   bool VerifySendersWire(const uint8_t *wire, const uint32_t *off, size_t n, std::vector<uint8_t> &verdict,
                          WireStats *stats = nullptr);
+  // The same batch judged completely (ibft_verify_messages_wire): sender[i] as above; for the canonical PREPARE / COMMIT
+  // messages of the view (height, round) — judged[i] != 0 — closure[i] is the handlePrepare / handleCommit closure against
+  // `proposal`, both signatures of a COMMIT verified in the same launch.  Rows the device flags take the stock sender route.
+  bool VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
+                          const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
+                          std::vector<uint8_t> &judged);
   int last_rc = 0;
 
  private:
