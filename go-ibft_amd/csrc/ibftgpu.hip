@@ -107,6 +107,8 @@ struct ibft_ctx {
   // message sets (ibft_verify_messages): sender words then valid words, ⌈max_rows/64⌉ each
   uint64_t *h_set = nullptr, *dh_set = nullptr;
   DevBuf d_set;
+  uint8_t *h_class = nullptr, *dh_class = nullptr;  // one routing byte per wire row (ibft_verify_messages_wire)
+  DevBuf d_class;
   bool gather_pinned = true;  // columns in ibft_pinned_alloc buffers are read by one gather launch (IBFT_NO_GATHER=1: never)
   uint32_t gathers = 0;       // batches whose columns came in through the gather launch
   bool host_direct = false;                          // the last tally kernel delivered its results there
@@ -788,6 +790,8 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
     if (hipHostMalloc((void **)&c->h_digest, 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if (hipHostMalloc((void **)&c->h_set, (size_t)mask_words(c->max_rows) * 16 + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
     if ((rc = ensure(c, c->d_set, (size_t)mask_words(c->max_rows) * 16))) break;
+    if (hipHostMalloc((void **)&c->h_class, (size_t)c->max_rows + 64) != hipSuccess) { rc = IBFT_E_NOMEM; break; }
+    if ((rc = ensure(c, c->d_class, (size_t)c->max_rows + 64))) break;
     // zero-copy result delivery (tally_kernel writes the verdict words and its own result into the
     // pinned buffers); IBFT_NO_HOST_DIRECT=1 keeps the two device-to-host copies instead
     if (!getenv("IBFT_NO_HOST_DIRECT")) {
@@ -797,6 +801,8 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
         c->dh_tally = (uint64_t *)dt;
         void *ds = nullptr;
         if (hipHostGetDevicePointer(&ds, c->h_set, 0) == hipSuccess) c->dh_set = (uint64_t *)ds;
+        void *dc = nullptr;
+        if (hipHostGetDevicePointer(&dc, c->h_class, 0) == hipSuccess) c->dh_class = (uint8_t *)dc;
       }
     }
     if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
@@ -821,7 +827,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
-                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal})
+                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class})
     release(*b);
   comm_release(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -830,6 +836,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->h_tally) (void)hipHostFree(c->h_tally);
   if (c->h_digest) (void)hipHostFree(c->h_digest);
   if (c->h_set) (void)hipHostFree(c->h_set);
+  if (c->h_class) (void)hipHostFree(c->h_class);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1433,7 +1440,7 @@ int ibft_verify_senders_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint3
 int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint32_t *off, size_t n, uint64_t height,
                               uint64_t round, const uint8_t *raw, size_t raw_len, uint64_t proposal_round,
                               const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask,
-                              ibft_wire_row_t *out_rows, ibft_tally_t *tally) {
+                              uint8_t *out_class, ibft_wire_row_t *out_rows, ibft_tally_t *tally) {
   if (!c || (n && (!off || !out_sender_mask || !out_valid_mask))) return IBFT_E_INVAL;
   if ((raw_len && !raw) || raw_len > (1ull << 31)) return IBFT_E_INVAL;
   for (size_t i = 0; i < n; i++)
@@ -1482,7 +1489,8 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(ibftk::wire_set_stage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                      (const wire::row_info *)c->d_wire_rows.p, (const uint8_t *)c->d_seal.p, (uint32_t)n, half, height, round,
-                     d_hash, (uint8_t *)c->d_hash_len.p, d_sig, d_signer, d_pre, (uint8_t *)c->d_noseal.p);
+                     d_hash, (uint8_t *)c->d_hash_len.p, d_sig, d_signer, d_pre, (uint8_t *)c->d_noseal.p,
+                     (uint8_t *)c->d_class.p, c->dh_class);
   HIPCHK(c, hipGetLastError());
   if (half != n) HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
   c->ev_used = 0;
@@ -1509,7 +1517,9 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   c->mask_dirty_words = 0;
   if (!c->dh_set)
     HIPCHK(c, hipMemcpyAsync(c->h_set, c->d_set.p, (size_t)mask_words(c->max_rows) * 16, hipMemcpyDeviceToHost, c->stream));
-  if (out_rows)
+  if (out_class && !c->dh_class)
+    HIPCHK(c, hipMemcpyAsync(c->h_class, c->d_class.p, n, hipMemcpyDeviceToHost, c->stream));
+  if (out_rows)  // 80 B per row through a copy command: ask for it only when the fields are needed (out_class routes)
     HIPCHK(c, hipMemcpyAsync(out_rows, c->d_wire_rows.p, n * sizeof(ibft_wire_row_t), hipMemcpyDeviceToHost, c->stream));
   if ((rc = fetch_results(c, (uint32_t)n, nullptr, tally, true))) {
     c->have_H = false;
@@ -1517,6 +1527,7 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   }
   memcpy(out_sender_mask, c->h_set, mw * 8);
   memcpy(out_valid_mask, c->h_set + mask_words(c->max_rows), mw * 8);
+  if (out_class) memcpy(out_class, c->h_class, n);
   return IBFT_OK;
 }
 

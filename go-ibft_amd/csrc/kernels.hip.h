@@ -745,15 +745,32 @@ __global__ void qtab_commit_kernel(uint32_t *__restrict__ pub_state, uint32_t n_
 
 // ---- §8f rank 3: IbftMessage wire bytes → verifier columns (wire_dev.h) -----------------------------
 // One lane per message: canonical-form walk, Keccak of PayloadNoSig, scatter into the columns.
-__global__ void wire_parse_kernel(const uint8_t *__restrict__ wire_bytes, const uint32_t *__restrict__ off, uint32_t n,
-                                  wire::row_info *__restrict__ rows, uint8_t *__restrict__ digest32,
-                                  uint8_t *__restrict__ sig65, uint8_t *__restrict__ from20,
-                                  uint8_t *__restrict__ seal65, uint8_t *__restrict__ pre_flags) {
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+// The 64 messages of a wavefront are contiguous in the batch: they are brought into LDS with coalesced dword loads
+// first (a lane walking ≈200 bytes of HBM one dependent byte load at a time made this kernel 75 µs), and every lane
+// walks and hashes its message from there.  A wavefront whose messages exceed the buffer reads HBM directly.
+constexpr uint32_t WIRE_LDS_BYTES = 32 * 1024;
+__global__ void __launch_bounds__(64) wire_parse_kernel(const uint8_t *__restrict__ wire_bytes, const uint32_t *__restrict__ off,
+                                                        uint32_t n, wire::row_info *__restrict__ rows,
+                                                        uint8_t *__restrict__ digest32, uint8_t *__restrict__ sig65,
+                                                        uint8_t *__restrict__ from20, uint8_t *__restrict__ seal65,
+                                                        uint8_t *__restrict__ pre_flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t lbuf[WIRE_LDS_BYTES + 16];
+  const uint32_t row0 = blockIdx.x * 64u, lane = threadIdx.x;
+  const uint32_t cnt = n - row0 < 64u ? n - row0 : 64u;
+  const uint32_t b0 = off[row0] & ~3u, b1 = off[row0 + cnt];
+  const bool staged = b1 - b0 <= WIRE_LDS_BYTES;  // wave-uniform
+  if (staged) {
+    // aligned dwords of [b0, b1): reads up to 3 bytes past the batch — the buffer carries 256 bytes of slack
+    for (uint32_t i = 4u * lane; b0 + i < b1; i += 256u)
+      *reinterpret_cast<uint32_t *>(lbuf + i) = *reinterpret_cast<const uint32_t *>(wire_bytes + b0 + i);
+    __syncthreads();
+  }
+  const uint32_t row = row0 + lane;
   if (row >= n) return;
   const uint32_t o0 = off[row], o1 = off[row + 1];
-  wire::process_row(wire_bytes + o0, o1 - o0, rows + row, digest32 + 32ull * row, sig65 + 65ull * row,
-                    from20 + 20ull * row, seal65 + 65ull * row, pre_flags + row);
+  const uint8_t *m = staged ? lbuf + (o0 - b0) : wire_bytes + o0;
+  wire::process_row(m, o1 - o0, rows + row, digest32 + 32ull * row, sig65 + 65ull * row, from20 + 20ull * row,
+                    seal65 + 65ull * row, pre_flags + row);
 }
 // After the sender pass: make the COMMIT seals found by wire_parse_kernel the resident seal batch
 // (hash column ← proposal hash, signature column ← committed seal, From stays).  Rows that are not
@@ -851,7 +868,8 @@ __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, c
                                       uint32_t half, uint64_t height, uint64_t round, uint8_t *__restrict__ hash32,
                                       uint8_t *__restrict__ hash_len, uint8_t *__restrict__ sig65,
                                       uint8_t *__restrict__ signer20, uint8_t *__restrict__ pre_flags,
-                                      uint8_t *__restrict__ is_prepare) {
+                                      uint8_t *__restrict__ is_prepare, uint8_t *__restrict__ row_class,
+                                      uint8_t *__restrict__ host_row_class) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   const wire::row_info &ri = rows[row];
@@ -865,6 +883,13 @@ __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, c
   hash_len[row] = ri.hash_len;
   pre_flags[dst] = (prepare || commit) ? 0 : 1;
   is_prepare[row] = prepare ? 1 : 0;
+  // what the host needs to route the row, in one byte (include/ibftgpu.h: IBFT_WIRE_CLASS_*): bit 0 = not judged here
+  // (stock route), bit 1 = a PREPARE / COMMIT of the asked view, i.e. its valid bit IS the closure's verdict, bits 4.. = type
+  const bool in_view = ri.status == wire::STATUS_OK && ri.has_view && ri.height == height && ri.round == round;
+  const uint8_t cls = (uint8_t)((ri.status == wire::STATUS_OK ? 0 : 1) | ((in_view && (ri.type == 1 || ri.type == 2)) ? 2 : 0) |
+                                ((ri.type & 15u) << 4));
+  row_class[row] = cls;
+  if (host_row_class) host_row_class[row] = cls;
 }
 
 // ---- a8: weighted quorum tally ------------------------------------------------------------

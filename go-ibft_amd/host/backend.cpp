@@ -180,20 +180,19 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
   judged.assign(n, 0);
   if (n == 0) return true;
   std::vector<uint64_t> ms((n + 63) / 64, 0), mv((n + 63) / 64, 0);
-  std::vector<ibft_wire_row_t> rows(n);
+  std::vector<uint8_t> cls(n, 0);
   last_rc = ibft_verify_messages_wire(ctx_, wire, off, n, height, round, (const uint8_t *)proposal.raw_proposal.data(),
-                                      proposal.raw_proposal.size(), proposal.round, nullptr, ms.data(), mv.data(), rows.data(),
-                                      nullptr);
+                                      proposal.raw_proposal.size(), proposal.round, nullptr, ms.data(), mv.data(), cls.data(),
+                                      nullptr, nullptr);
   if (last_rc != IBFT_OK) return false;
   unpack_mask(ms, n, sender);
   unpack_mask(mv, n, closure);
   std::vector<size_t> idx;
   std::vector<MsgPtr> msgs;
   for (size_t i = 0; i < n; i++) {
-    const ibft_wire_row_t &ri = rows[i];
-    if (ri.status == IBFT_WIRE_OK) {
+    if (!(cls[i] & IBFT_WIRE_CLASS_NEEDS_HOST)) {
       // the closure of a PREPARE / COMMIT of this view is settled by the device, whatever the verdict
-      judged[i] = ri.has_view && ri.height == height && ri.round == round && (ri.type == PREPARE || ri.type == COMMIT);
+      judged[i] = (cls[i] & IBFT_WIRE_CLASS_CLOSURE) != 0;
       continue;
     }
     auto m = std::make_shared<IbftMessage>();

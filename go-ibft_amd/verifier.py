@@ -43,6 +43,7 @@ COMM_ID_BYTES = 128
 E_RCCL = -8
 
 WIRE_OK, WIRE_NEEDS_HOST = 0, 1
+WIRE_CLASS_NEEDS_HOST, WIRE_CLASS_CLOSURE = 1, 2
 # ibft_wire_row_t (include/ibftgpu.h)
 WIRE_ROW = np.dtype([("height", "<u8"), ("round", "<u8"), ("status", "u1"), ("type", "u1"), ("payload_kind", "u1"),
                      ("has_view", "u1"), ("hash_len", "u1"), ("seal_len", "u1"), ("from_len", "u1"), ("sig_len", "u1"),
@@ -123,7 +124,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
-    L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp,
+    L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp,
                                             C.POINTER(Tally)]
     L.ibft_pinned_alloc.argtypes = [C.c_size_t]; L.ibft_pinned_alloc.restype = vp
     L.ibft_pinned_free.argtypes = [vp]; L.ibft_pinned_free.restype = None
@@ -380,22 +381,26 @@ class BatchVerifier:
         return mask_to_bool(mask, n), rows, t
 
     def verify_messages_wire(self, wire, off, height: int, round_: int, raw: bytes | None = None, proposal_round: int | None = None,
-                             digest32: bytes | None = None):
-        """raw messages judged completely → (sender bool[n], valid bool[n], rows, Tally); see include/ibftgpu.h"""
+                             digest32: bytes | None = None, want_rows: bool = True):
+        """raw messages judged completely → (sender bool[n], valid bool[n], rows or class bytes, Tally): rows = the full
+        parse results (want_rows) or the one routing byte per row (CLASS_* bits); see include/ibftgpu.h"""
         wb = _bytes_col(wire)
         off = np.ascontiguousarray(off, dtype=np.uint32)
         n = len(off) - 1
         ms = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
         mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
-        rows = np.zeros(n, dtype=WIRE_ROW)
+        rows = np.zeros(n, dtype=WIRE_ROW) if want_rows else None
+        cls = np.zeros(max(n, 1), dtype=np.uint8)
         rawb = None if raw is None else np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
         dg = None if digest32 is None else np.frombuffer(bytes(digest32), dtype=np.uint8)
         t = Tally()
         self._chk(self._L.ibft_verify_messages_wire(self._h, _p(wb), _p(off), n, height, round_, _p(rawb),
                                                     0 if raw is None else len(raw),
                                                     round_ if proposal_round is None else proposal_round, _p(dg), _p(ms), _p(mv),
-                                                    _p(rows) if n else None, C.byref(t)), "ibft_verify_messages_wire")
-        return mask_to_bool(ms, n), mask_to_bool(mv, n), rows, t
+                                                    _p(cls), _p(rows) if (n and want_rows) else None, C.byref(t)),
+                  "ibft_verify_messages_wire")
+        self._last_class = cls[:n]
+        return mask_to_bool(ms, n), mask_to_bool(mv, n), (rows if want_rows else cls[:n]), t
 
     def wire_stage_seals(self):
         """the COMMIT seals of the last is_valid_validator_wire batch become the resident seal batch"""

@@ -311,12 +311,21 @@ int ibft_verify_messages(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *
  *                           and, for a COMMIT, whose committed seal verifies for From: the handlePrepare /
  *                           handleCommit closure (core/ibft.go:856-862, :932-944).  Messages of other views or
  *                           kinds have bit 0 here and are judged when their view is handled;
- *   tally                 = HasQuorum over the rows with both bits (meaningful for a batch of one type).
+ *   tally                 = HasQuorum over the rows with both bits (meaningful for a batch of one type);
+ *   out_class[i] (n bytes, may be NULL) = what the caller needs to route row i: IBFT_WIRE_CLASS_NEEDS_HOST — not
+ *                           judged here, stock route; IBFT_WIRE_CLASS_CLOSURE — a PREPARE / COMMIT of the asked
+ *                           view: its valid bit IS the closure's verdict; bits 4..7 = IbftMessage.type.  One byte
+ *                           per row, delivered with the masks;
+ *   out_rows (may be NULL) = the full parse results, 80 B per row through a copy command — only when the
+ *                           fields themselves are wanted.
  * The proposal: raw + proposal_round (hashed once and remembered) or digest32, as in ibft_verify_messages.   */
+#define IBFT_WIRE_CLASS_NEEDS_HOST 0x01u
+#define IBFT_WIRE_CLASS_CLOSURE 0x02u
 int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const uint32_t *off, size_t n,
                               uint64_t height, uint64_t round, const uint8_t *raw, size_t raw_len,
                               uint64_t proposal_round, const uint8_t *digest32, uint64_t *out_sender_mask,
-                              uint64_t *out_valid_mask, ibft_wire_row_t *out_rows, ibft_tally_t *tally);
+                              uint64_t *out_valid_mask, uint8_t *out_class, ibft_wire_row_t *out_rows,
+                              ibft_tally_t *tally);
 
 /* ---- f4: the signing side, for SIMULATORS ----------------------------------
  * Replaces, for a process that plays n validators at once, the n calls of Backend.BuildCommitMessage

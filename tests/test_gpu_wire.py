@@ -181,6 +181,15 @@ def test_messages_judged_completely_from_wire_bytes(oracle, cache):
             assert (s == want_sender).all(), np.nonzero(s != want_sender)[0][:10]
             assert (v == want_valid).all(), np.nonzero(v != want_valid)[0][:10]
             assert [int(x) for x in rows["status"]] == [e.status for e in exps]
+        # the one routing byte per row instead of the 80-byte parse results
+        s, v, cls, _ = bv.verify_messages_wire(wire, off, height, rnd, raw=r.raw, want_rows=False)
+        assert (s == want_sender).all() and (v == want_valid).all()
+        for c, e in zip(cls, exps):
+            assert bool(c & V.WIRE_CLASS_NEEDS_HOST) == (e.status != WP.OK)
+            in_view = e.status == WP.OK and (e.height, e.round) == (height, rnd) and e.type in (1, 2)
+            assert bool(c & V.WIRE_CLASS_CLOSURE) == in_view
+            if e.status == WP.OK:
+                assert c >> 4 == (e.type & 15)
         # the digest form of the proposal, and a pinned buffer for the bytes
         s, v, _, _ = bv.verify_messages_wire(V.pinned_copy(wire), V.pinned_copy(off), height, rnd, digest32=H)
         assert (s == want_sender).all() and (v == want_valid).all() and bv.gather_batches() >= 1

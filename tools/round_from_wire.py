@@ -45,8 +45,8 @@ for name, flags in (("cold", 0), ("warm", V.FLAG_PUBKEY_CACHE)):
         return s1.all() and h1.all() and s2.all() and a2.all() and h2.all(), t
 
     def sets():
-        s1, v1, _, _ = bv.verify_messages_wire(pw, poff, r.height, r.round, raw=r.raw)
-        s2, v2, _, t = bv.verify_messages_wire(cw, coff, r.height, r.round, raw=r.raw)
+        s1, v1, _, _ = bv.verify_messages_wire(pw, poff, r.height, r.round, raw=r.raw, want_rows=False)
+        s2, v2, _, t = bv.verify_messages_wire(cw, coff, r.height, r.round, raw=r.raw, want_rows=False)
         return s1.all() and v1.all() and s2.all() and v2.all(), t
     res = {}
     for form, fn in (("two_step", two_step), ("sets", sets)):
