@@ -1492,10 +1492,14 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
                      d_hash, (uint8_t *)c->d_hash_len.p, d_sig, d_signer, d_pre, (uint8_t *)c->d_noseal.p,
                      (uint8_t *)c->d_class.p, c->dh_class);
   HIPCHK(c, hipGetLastError());
-  if (half != n) HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
+  if (half != n) {
+    HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
+    HIPCHK(c, hipMemsetAsync(d_pre + n, 1, half - n, c->stream));
+  }
   c->ev_used = 0;
   const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
-  if ((rc = enqueue_recover(c, half + (uint32_t)n, false, 0, time_it))) return rc;
+  // with the pre column: wavefronts whose rows are all dead (the seal rows of PREPAREs, other views, odd encodings) exit at once
+  if ((rc = enqueue_recover(c, half + (uint32_t)n, true, 0, time_it))) return rc;
   ibftk::set_args sa{};
   sa.work_mask = (uint64_t *)c->d_mask.p;
   sa.hash32 = d_hash + 32ull * half;

@@ -834,7 +834,9 @@ __global__ void message_set_combine_kernel(set_args a) {
     const uint32_t *h = reinterpret_cast<const uint32_t *>(a.H4);
     const uint32_t diff = (x.x ^ h[0]) | (x.y ^ h[1]) | (x.z ^ h[2]) | (x.w ^ h[3]) | (y.x ^ h[4]) | (y.y ^ h[5]) |
                           (y.z ^ h[6]) | (y.w ^ h[7]);
-    a1 = diff == 0 && a.hash_len[row] == 32 && !(a.valid_pre && a.valid_pre[row] != 0);
+    // valid_pre marks a dead seal side; a row flagged no_seal (a PREPARE among raw messages) has no seal side to be dead
+    const bool dead = a.valid_pre && a.valid_pre[row] != 0 && !(a.no_seal && a.no_seal[row] != 0);
+    a1 = diff == 0 && a.hash_len[row] == 32 && !dead;
   }
   const uint64_t bal = __ballot(a1), sbad = __ballot(spre);
   const uint64_t skip_seal = __ballot(row < a.n && a.no_seal && a.no_seal[row] != 0);
@@ -861,8 +863,8 @@ __global__ void message_set_combine_kernel(set_args a) {
 // (digest of PayloadNoSig, Signature, From) and the seal column; this kernel lays the second group of verdict rows
 // [half, half + n) — the hash each message carries as digest, its committed seal as signature, From as signer — and
 // decides, per row, everything about the closure that needs no arithmetic: valid_pre ≠ 0 unless the message is a
-// canonical PREPARE (type 1, PrepareMessage) or COMMIT (type 2, CommitMessage, 65-byte seal) of the view
-// (height, round) with a 20-byte From (ExtractPrepareHash / ExtractCommitHash / ExtractCommittedSeal return nil
+// canonical COMMIT (type 2, CommitMessage, 65-byte seal) of the view (height, round) with a 20-byte From — a canonical
+// PREPARE of the view (type 1, PrepareMessage) is flagged in is_prepare instead: its closure is the hash compare alone (ExtractPrepareHash / ExtractCommitHash / ExtractCommittedSeal return nil
 // otherwise, messages/helpers.go).  A PREPARE row's seal row is a zero signature: its verdict is forced below.
 __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, const uint8_t *__restrict__ seal65, uint32_t n,
                                       uint32_t half, uint64_t height, uint64_t round, uint8_t *__restrict__ hash32,
@@ -881,7 +883,7 @@ __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, c
   for (int i = 0; i < 65; i++) sig65[65ull * dst + i] = commit ? seal65[65ull * row + i] : 0;
   for (int i = 0; i < 20; i++) signer20[20ull * dst + i] = ri.from[i];
   hash_len[row] = ri.hash_len;
-  pre_flags[dst] = (prepare || commit) ? 0 : 1;
+  pre_flags[dst] = commit ? 0 : 1;  // the verdict launch skips every seal row that is not a COMMIT's (whole wavefronts exit)
   is_prepare[row] = prepare ? 1 : 0;
   // what the host needs to route the row, in one byte (include/ibftgpu.h: IBFT_WIRE_CLASS_*): bit 0 = not judged here
   // (stock route), bit 1 = a PREPARE / COMMIT of the asked view, i.e. its valid bit IS the closure's verdict, bits 4.. = type
