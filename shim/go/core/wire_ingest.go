@@ -25,11 +25,27 @@ type WireVerifier interface {
 	VerifySendersWire(wire []byte, off []uint32) (mask []uint64, rows []ibftgpu.WireRow, ok bool)
 }
 
+// WireSetVerifier judges raw messages COMPLETELY (libibftgpu: ibft_verify_messages_wire): sender bit i is
+// IsValidValidator(message i); for the canonical PREPARE / COMMIT messages of the view (height, round) — class[i] has
+// ibftgpu.WireClassClosure — valid bit i is the handlePrepare / handleCommit closure against proposal, both
+// signatures of a COMMIT verified in the same launch.  class[i] with ibftgpu.WireClassNeedsHost: not judged, stock route.
+type WireSetVerifier interface {
+	VerifyMessagesWire(wire []byte, off []uint32, height, round uint64, proposal *proto.Proposal) (sender, valid []uint64, class []byte, ok bool)
+}
+
 // AddWireMessages is what the transport calls instead of unmarshalling and calling AddMessage once per
 // message.  raw[i] is one message exactly as received.
 func (i *IBFT) AddWireMessages(raw [][]byte) {
+	if len(raw) == 0 {
+		return
+	}
+	if ws, hasSets := i.backend.(WireSetVerifier); hasSets && i.state.getProposal() != nil {
+		if i.addWireSets(ws, raw) {
+			return
+		}
+	}
 	wv, hasWire := i.backend.(WireVerifier)
-	if !hasWire || len(raw) == 0 {
+	if !hasWire {
 		i.addWireStock(raw, nil)
 		return
 	}
@@ -54,6 +70,42 @@ func (i *IBFT) AddWireMessages(raw [][]byte) {
 		}
 	}
 	i.addWireStock(stock, nil)
+}
+
+// addWireSets: one device call settles IsValidValidator for the batch AND the handle* closure of every PREPARE /
+// COMMIT of the current view; the closure verdicts go into the table commitMessagesFor / prepareMessagesFor consult
+// (message_sets.go).  false = device unavailable, nothing was added.
+func (i *IBFT) addWireSets(ws WireSetVerifier, raw [][]byte) bool {
+	proposal := i.state.getProposal()
+	wire, off := concat(raw)
+	sender, valid, class, ok := ws.VerifyMessagesWire(wire, off, i.state.getHeight(), i.state.getRound(), proposal)
+	if !ok || len(class) != len(raw) {
+		return false
+	}
+	var stock [][]byte
+	tab := i.closures()
+	for k := range raw {
+		switch {
+		case class[k]&ibftgpu.WireClassNeedsHost != 0:
+			stock = append(stock, raw[k])
+		case !ibftgpu.Bit(sender, k):
+			// IsValidValidator == false: dropped
+		default:
+			msg := new(proto.IbftMessage)
+			if goproto.Unmarshal(raw[k], msg) != nil {
+				continue
+			}
+			if class[k]&ibftgpu.WireClassClosure != 0 {
+				tab.mu.Lock()
+				tab.sync(proposal)
+				tab.verdict[msg] = ibftgpu.Bit(valid, k)
+				tab.mu.Unlock()
+			}
+			i.addVerifiedMessage(msg)
+		}
+	}
+	i.addWireStock(stock, nil)
+	return true
 }
 
 // addVerifiedMessage is AddMessage (core/ibft.go:1101-1123) for a message whose sender the device has already

@@ -194,6 +194,26 @@ func (c *Ctx) VerifyMessages(payload []byte, off []uint32, msgSig65, from20, has
 	return senderMask, validMask, tally(ct), c.check(rc)
 }
 
+// Routing byte per raw message (ibft_verify_messages_wire, out_class).
+const (
+	WireClassNeedsHost = byte(C.IBFT_WIRE_CLASS_NEEDS_HOST)
+	WireClassClosure   = byte(C.IBFT_WIRE_CLASS_CLOSURE)
+)
+
+// VerifyMessagesWire = raw messages judged completely (ibft_verify_messages_wire): the device walks the bytes and
+// verifies both signatures of every PREPARE / COMMIT of the view (height, round) in one launch.
+func (c *Ctx) VerifyMessagesWire(wire []byte, off []uint32, height, round uint64, raw []byte, proposalRound uint64) (
+	senderMask, validMask []uint64, class []byte, t Tally, err error) {
+	n := len(off) - 1
+	senderMask, validMask = make([]uint64, (n+63)/64+1), make([]uint64, (n+63)/64+1)
+	class = make([]byte, n+1)
+	var ct C.ibft_tally_t
+	rc := C.ibft_verify_messages_wire(c.h, ptr8(wire), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(n), C.uint64_t(height),
+		C.uint64_t(round), ptr8(raw), C.size_t(len(raw)), C.uint64_t(proposalRound), nil,
+		(*C.uint64_t)(unsafe.Pointer(&senderMask[0])), (*C.uint64_t)(unsafe.Pointer(&validMask[0])), ptr8(class), nil, &ct)
+	return senderMask, validMask, class[:n], tally(ct), c.check(rc)
+}
+
 // PinnedBytes returns n bytes of page-locked memory (ibft_pinned_alloc) as a Go slice: column buffers the
 // flatten step writes into once and reuses every round.  When every column of a call lies in such buffers the
 // library reads them with one gather launch instead of one copy command per column.  C memory: invisible to
