@@ -60,6 +60,22 @@ func FlattenCommits(msgs []*proto.IbftMessage) *SealColumns {
 	return c
 }
 
+// FlattenPrepares mirrors the closure of handlePrepare (core/ibft.go:856-862): only the hash ExtractPrepareHash
+// returns (nil for a wrong type/payload) and its length; the other columns stay empty.
+func FlattenPrepares(msgs []*proto.IbftMessage) *SealColumns {
+	c := &SealColumns{}
+	for _, m := range msgs {
+		hash := ExtractPrepareHash(m)
+		c.Hash32, _ = putFixed(c.Hash32, hash, 32)
+		hl := len(hash)
+		if hl > 255 {
+			hl = 255
+		}
+		c.HashLen = append(c.HashLen, byte(hl))
+	}
+	return c
+}
+
 // SenderColumns are the inputs of ibft_verify_senders.
 type SenderColumns struct {
 	Payload  []byte
