@@ -2,8 +2,10 @@
 rounds.  Default: 10 000 rounds at N = 64 with seeds 1…10000 (every validator key, proposal and the 20 %
 Byzantine mix derive from the seed; odd seeds use weighted voting power) + 100 rounds at each larger N.
 Every round goes through ibft_verify_seals twice on a key-caching context (first pass: recover kernels,
-second pass: known-key kernels) and is compared with the CPU oracle: verdict of every row, Σ power, valid
-rows, distinct senders, quorum flag.  Workers generate rounds and oracle answers in parallel; the GPU
+second pass: known-key kernels) and — round 2 — as a whole COMMIT set through ibft_verify_messages twice
+(envelope signatures and committed seals in one verdict launch), and is compared with the CPU oracle: verdict
+of every row (seal verdicts; sender and closure verdicts of the set), Σ power, valid rows, distinct senders,
+quorum flag.  Workers generate rounds and oracle answers in parallel; the GPU
 consumer is this process.  Prints one JSON object."""
 import argparse
 import json
@@ -22,12 +24,20 @@ def make(job):
     n, seed = job
     from oracle import binding as B
     from oracle import workload as W
-    r = W.make_round(n, seed, byzantine=True, weighted=bool(seed & 1))
+    r = W.make_round(n, seed, byzantine=True, weighted=bool(seed & 1), with_envelopes=True)
+    if seed % 3 == 0:   # some forged envelopes too: a neighbour's signature
+        k = seed % n
+        r.msg_sig65[k] = r.msg_sig65[(k + 1) % n]
     vs = B.ValSet(r.addrs, r.power)
     exp = B.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=1)
     t = B.tally(vs, r.signer20, exp)
+    snd = B.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)
+    clo = B.verify_hashes(r.raw, r.round, r.hash32, r.hash_len).astype(bool) & exp.astype(bool)
+    ts = B.tally(vs, r.signer20, (snd & clo).astype(np.uint8))
     return (n, seed, r.addrs, r.power, r.hash32, r.seal65, r.signer20, r.pre_flags, exp.astype(bool),
-            (t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum))
+            (t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum),
+            (r.payload, r.off, r.msg_sig65, r.hash_len, r.raw, r.round, snd, clo,
+             (ts.power, ts.quorum, ts.valid_rows, ts.distinct_senders, ts.has_quorum)))
 
 
 def main():
@@ -47,10 +57,10 @@ def main():
     stat = {}
     t0 = time.time()
     with mp.get_context("fork").Pool(procs) as pool:
-        for (n, seed, addrs, power, h, s, f, pre, exp, et) in pool.imap(make, jobs, chunksize=8):
+        for (n, seed, addrs, power, h, s, f, pre, exp, et, env) in pool.imap(make, jobs, chunksize=8):
             st = stat.setdefault(n, {"rounds": 0, "rows": 0, "bad_rows": 0, "verdict_row_mismatches": 0,
                                      "tally_mismatches": 0, "quorum_mismatches": 0, "quorum_true": 0,
-                                     "passes": 0})
+                                     "passes": 0, "set_passes": 0, "set_row_mismatches": 0, "set_tally_mismatches": 0})
             bv.set_validators(seed, addrs, power)
             for _ in range(2):  # recover kernels, then known-key kernels for the keys just learned
                 got, t = bv.is_valid_committed_seal(h, s, f, pre)
@@ -58,6 +68,12 @@ def main():
                 st["tally_mismatches"] += int((t.power, t.quorum, t.valid_rows, t.distinct_senders) != et[:4])
                 st["quorum_mismatches"] += int(t.has_quorum != et[4])
                 st["passes"] += 1
+            payload, off, msig, hlen, raw, rnd, snd, clo, ets = env
+            for _ in range(2):  # the COMMIT set in one call: the keys are known by now; a fresh set of validators next round
+                gs, gv, t = bv.verify_messages(payload, off, msig, f, h, hlen, s, valid_pre=pre, raw=raw, round_=rnd)
+                st["set_row_mismatches"] += int((gs != snd).sum()) + int((gv != clo).sum())
+                st["set_tally_mismatches"] += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != ets)
+                st["set_passes"] += 1
             st["rounds"] += 1
             st["rows"] += n
             st["bad_rows"] += int((~exp).sum())
@@ -65,8 +81,8 @@ def main():
     bv.close()
     out = {"seconds": round(time.time() - t0, 1), "procs": procs, "by_n": {str(k): v for k, v in sorted(stat.items())},
            "total_rounds": sum(v["rounds"] for v in stat.values()),
-           "total_mismatches": sum(v["verdict_row_mismatches"] + v["tally_mismatches"] + v["quorum_mismatches"]
-                                   for v in stat.values())}
+           "total_mismatches": sum(v["verdict_row_mismatches"] + v["tally_mismatches"] + v["quorum_mismatches"] +
+                                   v["set_row_mismatches"] + v["set_tally_mismatches"] for v in stat.values())}
     print(json.dumps(out))
     sys.exit(0 if out["total_mismatches"] == 0 else 1)
 
