@@ -366,6 +366,34 @@ class BatchVerifier:
                                                C.byref(t)), "ibft_verify_messages")
         return mask_to_bool(ms, n), mask_to_bool(mv, n), t
 
+    def prepare_messages(self, payload, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None, valid_pre=None,
+                         raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
+        """verify_messages with the argument marshalling done ONCE: for a caller whose columns live in fixed buffers that
+        are refilled every round (what the integration prescribes).  Returns run() → (sender words u64[⌈n/64⌉], valid words,
+        Tally); the word arrays are reused between calls.  Decode with mask_to_bool(words, n)."""
+        pl = _bytes_col(payload)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        s = _u8(msg_sig65, (-1, 65)); f = _u8(from20, (-1, 20)); h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
+        n = len(s)
+        sl = None if seal65 is None else _u8(seal65, (-1, 65))
+        spre = None if sender_pre is None else _u8(sender_pre)
+        vpre = None if valid_pre is None else _u8(valid_pre)
+        rawb = None if raw is None else np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
+        dg = None if digest32 is None else np.frombuffer(bytes(digest32), dtype=np.uint8)
+        ms = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        keep = (pl, off, s, f, h, hl, sl, spre, vpre, rawb, dg)      # the pointers below stay valid while these live
+        args = (self._h, _p(pl), _p(off), _p(s), _p(f), _p(h), _p(hl), _p(sl), _p(spre), _p(vpre), n, _p(rawb),
+                0 if raw is None else len(raw), round_, _p(dg), _p(ms), _p(mv), C.byref(t))
+        fn, chk = self._L.ibft_verify_messages, self._chk
+
+        def run(_keep=keep):
+            chk(fn(*args), "ibft_verify_messages")
+            return ms, mv, t
+        run.n = n
+        return run
+
     # §8f rank 3: a3 straight from the wire bytes (PREPARE / COMMIT); rows["status"] == WIRE_NEEDS_HOST
     # are not judged (verdict 0) and go through the protobuf runtime + is_valid_validator
     def is_valid_validator_wire(self, wire: bytes, off):

@@ -165,3 +165,35 @@ def test_payload_lengths_around_the_keccak_rate_at_every_alignment(oracle, lanes
         assert bv.gather_batches() == 6
     finally:
         bv.close()
+
+
+def test_prepared_call_on_fixed_buffers_refilled_in_place(oracle):
+    """prepare_messages binds the column buffers once; refilling them in place (the next round) and calling run() again
+    judges the new content — pinned buffers, so the gather launch reads them."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    n = 500
+    r1 = W.make_round(n, 31, with_envelopes=True)
+    r2 = W.make_round(n, 31, byzantine=True, with_envelopes=True)      # same validators and proposal, some bad seals
+    assert (r1.addrs == r2.addrs).all() and r1.raw == r2.raw
+    size = max(len(r1.payload), len(r2.payload))
+    cols = dict(payload=V.pinned_copy(np.zeros(size, np.uint8)), off=V.pinned_copy(r1.off), sig=V.pinned_copy(r1.msg_sig65),
+                frm=V.pinned_copy(r1.signer20), h=V.pinned_copy(r1.hash32), hl=V.pinned_copy(r1.hash_len), seal=V.pinned_copy(r1.seal65),
+                vpre=V.pinned_copy(r1.pre_flags))
+    bv = V.BatchVerifier(max_rows=1024)
+    try:
+        bv.set_validators(r1.height, r1.addrs, r1.power)
+        run = bv.prepare_messages(cols["payload"], cols["off"], cols["sig"], cols["frm"], cols["h"], cols["hl"], cols["seal"],
+                                  valid_pre=cols["vpre"], raw=r1.raw, round_=r1.round)
+        for r in (r1, r2, r1):
+            cols["payload"][:len(r.payload)] = np.frombuffer(r.payload, np.uint8)
+            for k, a in (("off", r.off), ("sig", r.msg_sig65), ("frm", r.signer20), ("h", r.hash32), ("hl", r.hash_len),
+                         ("seal", r.seal65), ("vpre", r.pre_flags)):
+                cols[k][...] = a
+            ws, wv, t = run()
+            vs, senders, valid = _oracle_expect(oracle, r, True)
+            assert (V.mask_to_bool(ws, n) == senders).all() and (V.mask_to_bool(wv, n) == valid).all()
+            assert t.valid_rows == int((senders & valid).sum())
+        assert bv.gather_batches() == 3
+    finally:
+        bv.close()
