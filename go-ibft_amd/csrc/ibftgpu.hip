@@ -368,7 +368,7 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator
   return IBFT_OK;
 }
 
-int enqueue_tally(ibft_ctx *c, uint32_t n) {
+int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr) {
   if (c->read_pending) {  // a consumer stream is still copying the previous results (ibft_seals_export_on / exchange)
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_read, 0));
     c->read_pending = false;
@@ -386,6 +386,8 @@ int enqueue_tally(ibft_ctx *c, uint32_t n) {
   t.out = (uint64_t *)c->d_tally.p;
   t.host_mask = c->dh_mask;
   t.host_tally = c->dh_tally;
+  t.set_on = set ? 1u : 0u;
+  if (set) t.set = *set;
   const dim3 grid(std::max(1u, (n + ibftk::TALLY_ROWS_PER_BLOCK - 1) / ibftk::TALLY_ROWS_PER_BLOCK)), block(ibftk::TALLY_THREADS);
   // one workgroup (n ≤ 4 096): everything stays in the workgroup — no global atomics on the latency-critical sizes;
   // beyond: ticket form, each workgroup merging its LDS bitmap into the HBM one word by word.  A validator set whose
@@ -1286,7 +1288,6 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   ibftk::set_args sa{};
   sa.sender_pre = sender_pre ? d_pre : nullptr;
   sa.valid_pre = valid_pre ? d_pre + half : nullptr;
-  sa.work_mask = (uint64_t *)c->d_mask.p;
   sa.hash32 = d_hash + 32ull * half;
   sa.hash_len = (const uint8_t *)c->d_hash_len.p;
   sa.H4 = (const uint64_t *)c->d_H.p;
@@ -1297,9 +1298,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
   sa.host_sender = c->dh_set;
   sa.host_valid = c->dh_set ? c->dh_set + mask_words(c->max_rows) : nullptr;
-  hipLaunchKernelGGL(ibftk::message_set_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sa);
-  HIPCHK(c, hipGetLastError());
-  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  if ((rc = enqueue_tally(c, (uint32_t)n, &sa))) return rc;
   c->mask_dirty_words = 0;  // the combine kernel zeroed the seal words, the tally the sender words
   if (!c->dh_set)
     HIPCHK(c, hipMemcpyAsync(c->h_set, c->d_set.p, (size_t)mask_words(c->max_rows) * 16, hipMemcpyDeviceToHost, c->stream));
@@ -1501,7 +1500,6 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   // with the pre column: wavefronts whose rows are all dead (the seal rows of PREPAREs, other views, odd encodings) exit at once
   if ((rc = enqueue_recover(c, half + (uint32_t)n, true, 0, time_it))) return rc;
   ibftk::set_args sa{};
-  sa.work_mask = (uint64_t *)c->d_mask.p;
   sa.hash32 = d_hash + 32ull * half;
   sa.hash_len = (const uint8_t *)c->d_hash_len.p;
   sa.H4 = (const uint64_t *)c->d_H.p;
@@ -1515,9 +1513,7 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
   sa.host_sender = c->dh_set;
   sa.host_valid = c->dh_set ? c->dh_set + mask_words(c->max_rows) : nullptr;
-  hipLaunchKernelGGL(ibftk::message_set_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sa);
-  HIPCHK(c, hipGetLastError());
-  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  if ((rc = enqueue_tally(c, (uint32_t)n, &sa))) return rc;
   c->mask_dirty_words = 0;
   if (!c->dh_set)
     HIPCHK(c, hipMemcpyAsync(c->h_set, c->d_set.p, (size_t)mask_words(c->max_rows) * 16, hipMemcpyDeviceToHost, c->stream));

@@ -809,56 +809,6 @@ __global__ void payload_digest_kernel(const uint8_t *__restrict__ payload, const
     o[1] = make_uint4((uint32_t)d[2], (uint32_t)(d[2] >> 32), (uint32_t)d[3], (uint32_t)(d[3] >> 32));
   }
 }
-// After the verdict launch: word w of the work mask holds the envelope verdicts of rows 64w.., word half/64 + w the
-// seal verdicts of the same messages.  a1 is evaluated here (hash_eq_kernel's compare).  Delivered: sender words
-// (IsValidValidator), valid words (a1 ∧ a2 — handlePrepare's / handleCommit's closure; a1 alone without seals);
-// the work mask keeps sender ∧ valid for the tally, which then answers hasQuorumByMsgType for the set.
-struct set_args {
-  uint64_t *work_mask;
-  const uint8_t *hash32;    // n × 32: the proposal hash each message carries
-  const uint8_t *hash_len;  // n
-  const uint64_t *H4;       // keccak256(raw proposal ‖ BE64(round))
-  const uint8_t *sender_pre, *valid_pre;  // n each or null: rows the host rejected before any crypto
-  const uint8_t *no_seal;   // n or null: rows (PREPAREs of a mixed wire batch) whose valid bit is a1 alone
-  uint32_t n, half_words;   // half_words = 0: no seals (PREPARE)
-  uint64_t *sender_out, *valid_out;    // device copies (⌈n/64⌉ words each)
-  uint64_t *host_sender, *host_valid;  // mapped pinned host memory or null
-};
-__global__ void message_set_combine_kernel(set_args a) {
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  bool a1 = false, spre = false;
-  if (row < a.n) {
-    spre = a.sender_pre && a.sender_pre[row] != 0;
-    const uint4 *p = reinterpret_cast<const uint4 *>(a.hash32 + 32ull * row);
-    const uint4 x = p[0], y = p[1];
-    const uint32_t *h = reinterpret_cast<const uint32_t *>(a.H4);
-    const uint32_t diff = (x.x ^ h[0]) | (x.y ^ h[1]) | (x.z ^ h[2]) | (x.w ^ h[3]) | (y.x ^ h[4]) | (y.y ^ h[5]) |
-                          (y.z ^ h[6]) | (y.w ^ h[7]);
-    // valid_pre marks a dead seal side; a row flagged no_seal (a PREPARE among raw messages) has no seal side to be dead
-    const bool dead = a.valid_pre && a.valid_pre[row] != 0 && !(a.no_seal && a.no_seal[row] != 0);
-    a1 = diff == 0 && a.hash_len[row] == 32 && !dead;
-  }
-  const uint64_t bal = __ballot(a1), sbad = __ballot(spre);
-  const uint64_t skip_seal = __ballot(row < a.n && a.no_seal && a.no_seal[row] != 0);
-  if ((threadIdx.x & 63) != 0 || row >= a.n) return;
-  const uint32_t w = row >> 6;
-  const uint32_t left = a.n - row;  // ≥ 1
-  const uint64_t tail = left >= 64 ? ~0ull : (~0ull >> (64 - left));
-  const uint64_t S = a.work_mask[w] & tail & ~sbad;
-  uint64_t V = bal;
-  if (a.half_words) {
-    V &= a.work_mask[a.half_words + w] | skip_seal;
-    a.work_mask[a.half_words + w] = 0;
-  }
-  a.sender_out[w] = S;
-  a.valid_out[w] = V;
-  if (a.host_sender) {
-    a.host_sender[w] = S;
-    a.host_valid[w] = V;
-  }
-  a.work_mask[w] = S & V;
-}
-
 // The same set judged straight from the transport's bytes: wire_parse_kernel has filled the sender rows [0, n)
 // (digest of PayloadNoSig, Signature, From) and the seal column; this kernel lays the second group of verdict rows
 // [half, half + n) — the hash each message carries as digest, its committed seal as signature, From as signer — and
@@ -943,6 +893,57 @@ __device__ __forceinline__ bool words_ge(const uint64_t a[TALLY_SUM_WORDS], cons
   return true;
 }
 
+// After the verdict launch of a message set: word w of the work mask holds the envelope verdicts of rows 64w.., word
+// half/64 + w the seal verdicts of the same messages.  a1 is evaluated here (hash_eq_kernel's compare).  Delivered: sender
+// words (IsValidValidator), valid words (a1 ∧ a2 — handlePrepare's / handleCommit's closure; a1 alone without seals);
+// the tally goes on with sender ∧ valid, which answers hasQuorumByMsgType for the set.  This runs INSIDE the tally
+// kernel (a wavefront per verdict word, lane l judging row 64w + l): as a kernel of its own it cost 4.4 µs plus a
+// dependency gap per set.
+struct set_args {
+  const uint8_t *hash32;    // n × 32: the proposal hash each message carries
+  const uint8_t *hash_len;  // n
+  const uint64_t *H4;       // keccak256(raw proposal ‖ BE64(round))
+  const uint8_t *sender_pre, *valid_pre;  // n each or null: rows the host rejected before any crypto
+  const uint8_t *no_seal;   // n or null: rows (PREPAREs of a mixed wire batch) whose valid bit is a1 alone
+  uint32_t n, half_words;   // half_words = 0: no seals (PREPARE)
+  uint64_t *sender_out, *valid_out;    // device copies (⌈n/64⌉ words each)
+  uint64_t *host_sender, *host_valid;  // mapped pinned host memory or null
+};
+// called by a whole wavefront; returns sender ∧ valid for word w on every lane
+__device__ __forceinline__ uint64_t set_combine_word(const set_args &a, uint64_t *work_mask, uint32_t w, uint32_t lane) {
+  const uint32_t row = w * 64u + lane;
+  bool a1 = false, spre = false, nos = false;
+  if (row < a.n) {
+    spre = a.sender_pre && a.sender_pre[row] != 0;
+    nos = a.no_seal && a.no_seal[row] != 0;
+    const uint4 *p = reinterpret_cast<const uint4 *>(a.hash32 + 32ull * row);
+    const uint4 x = p[0], y = p[1];
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(a.H4);
+    const uint32_t diff = (x.x ^ h[0]) | (x.y ^ h[1]) | (x.z ^ h[2]) | (x.w ^ h[3]) | (y.x ^ h[4]) | (y.y ^ h[5]) |
+                          (y.z ^ h[6]) | (y.w ^ h[7]);
+    // valid_pre marks a dead seal side; a row flagged no_seal (a PREPARE among raw messages) has no seal side to be dead
+    const bool dead = a.valid_pre && a.valid_pre[row] != 0 && !nos;
+    a1 = diff == 0 && a.hash_len[row] == 32 && !dead;
+  }
+  const uint64_t bal = __ballot(a1), sbad = __ballot(spre), skip_seal = __ballot(nos);
+  const uint32_t first = w * 64u;
+  const uint32_t left = a.n > first ? a.n - first : 0u;
+  const uint64_t tail = left >= 64 ? ~0ull : (left ? (~0ull >> (64 - left)) : 0ull);
+  const uint64_t S = work_mask[w] & tail & ~sbad;
+  uint64_t V = bal;
+  if (a.half_words) V &= work_mask[a.half_words + w] | skip_seal;
+  if (lane == 0) {
+    if (a.half_words) work_mask[a.half_words + w] = 0;
+    a.sender_out[w] = S;
+    a.valid_out[w] = V;
+    if (a.host_sender) {
+      a.host_sender[w] = S;
+      a.host_valid[w] = V;
+    }
+  }
+  return S & V;
+}
+
 struct tally_args {
   uint64_t *work_mask;      // verdict words accumulated by the verdict kernels; consumed (zeroed) here
   uint64_t *mask;           // verdict words as fetch / export / exchange read them
@@ -955,6 +956,8 @@ struct tally_args {
   uint64_t *out;            // TALLY_OUT_WORDS
   uint64_t *host_mask, *host_tally;  // mapped pinned host memory (or null): no device-to-host copy commands
   uint32_t lds_bitmap;      // the launch carries ⌈n_validators/32⌉ words of dynamic LDS for the workgroup's bitmap
+  uint32_t set_on;          // a message set: the verdict words are combined here first (set_combine_word)
+  set_args set;
 };
 
 // MULTI = false: ONE workgroup (n ≤ TALLY_ROWS_PER_BLOCK, the latency-critical sizes): the distinct-sender set is
@@ -983,7 +986,23 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   }
   // The verdict kernels accumulate into work_mask (atomicOr / ballot words).  The tally CONSUMES it: the words
   // move to `mask`, to host_mask when given, and work_mask is left zeroed for the next launch.
-  if (tid < TALLY_ROWS_PER_BLOCK / 64) {
+  if (a.set_on) {
+    // every wavefront combines its share of the workgroup's verdict words (wave-uniform loop)
+    const uint32_t wv = tid >> 6, ln = tid & 63u;
+    for (uint32_t k = wv; k < TALLY_ROWS_PER_BLOCK / 64; k += TALLY_THREADS / 64) {
+      const uint32_t wi = row0 / 64 + k;
+      uint64_t w = 0;
+      if (wi < total_words) {
+        w = set_combine_word(a.set, a.work_mask, wi, ln);
+        if (ln == 0) {
+          a.work_mask[wi] = 0;
+          a.mask[wi] = w;
+          if (a.host_mask) a.host_mask[wi] = w;
+        }
+      }
+      if (ln == 0) wds[k] = w;
+    }
+  } else if (tid < TALLY_ROWS_PER_BLOCK / 64) {
     const uint32_t wi = row0 / 64 + tid;
     uint64_t w = 0;
     if (wi < total_words) {
