@@ -211,6 +211,7 @@ def sequence_latency(V, fx, flags: int, rounds: int, form: str = "calls", pinned
         bv.set_validators(int(fx["height"]), fx["addrs"], fx["power"])
 
         def five_calls():
+            bv.forget_proposal()                          # a new height has a new proposal: hashed once per sequence
             a, _ = bv.is_valid_validator(ppayload, poff, psig, pfrom)                 # PREPARE ingest
             b = bv.is_valid_proposal_hash(raw, rnd, phash, plen)                      # handlePrepare
             c, _ = bv.is_valid_validator(cpayload, coff, csig, cfrom)                 # COMMIT ingest
@@ -225,6 +226,7 @@ def sequence_latency(V, fx, flags: int, rounds: int, form: str = "calls", pinned
         run_c = bv.prepare_messages(cpayload, coff, csig, cfrom, chash, clen, cseal, raw=raw, round_=rnd)      # COMMIT set
 
         def two_sets():
+            bv.forget_proposal()                          # a new height has a new proposal: hashed once per sequence
             run_p()
             sw, vw, t = run_c()
             return t.valid_rows == n and t.has_quorum == 1, t

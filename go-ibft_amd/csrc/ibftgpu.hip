@@ -94,6 +94,11 @@ struct ibft_ctx {
   // against every PREPARE and COMMIT set of a round and on every wake-up, so it is hashed once
   std::vector<uint8_t> hashed_proposal;
   bool have_H = false;
+  // the proposal is hashed on a stream of its own (one lane, ≈9 µs per 136-byte block): a message set's verdict launch does
+  // not depend on it — only the combine step inside the tally does — so the two overlap
+  hipStream_t hstream = nullptr;
+  hipEvent_t ev_H = nullptr, ev_main = nullptr;
+  bool H_pending = false;  // the main stream has not yet been told to wait for ev_H
 
   // staged batch
   uint32_t staged_n = 0;
@@ -467,12 +472,25 @@ int ensure_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64
   c->hashed_proposal.resize(raw_len + 8);
   if (raw_len) memcpy(c->hashed_proposal.data(), raw, raw_len);
   memcpy(c->hashed_proposal.data() + raw_len, be, 8);
-  int rc = upload(c, c->d_raw, c->hashed_proposal.data(), c->hashed_proposal.size());
+  int rc = ensure(c, c->d_raw, c->hashed_proposal.size() + 256);  // slack: the kernel reads whole dwords
   if (rc) return rc;
-  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->stream, (const uint8_t *)c->d_raw.p,
+  // everything already enqueued on the main stream (readers of the previous d_H) first, then upload + hash on the side stream
+  HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->hstream, c->ev_main, 0));
+  HIPCHK(c, hipMemcpyAsync(c->d_raw.p, c->hashed_proposal.data(), c->hashed_proposal.size(), hipMemcpyHostToDevice, c->hstream));
+  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->hstream, (const uint8_t *)c->d_raw.p,
                      (uint32_t)c->hashed_proposal.size(), (uint64_t *)c->d_H.p);
   HIPCHK(c, hipGetLastError());
-  c->have_H = true;  // valid once the stream reaches this point; every reader is stream-ordered behind it
+  HIPCHK(c, hipEventRecord(c->ev_H, c->hstream));
+  c->H_pending = true;
+  c->have_H = true;  // valid once the main stream has waited for ev_H (wait_proposal_hash): every reader does that first
+  return IBFT_OK;
+}
+// the main stream goes on only when d_H holds the hash launched by ensure_proposal_hash
+int wait_proposal_hash(ibft_ctx *c) {
+  if (!c->H_pending) return IBFT_OK;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_H, 0));
+  c->H_pending = false;
   return IBFT_OK;
 }
 
@@ -784,6 +802,9 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   int rc = IBFT_OK;
   do {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
+    if (hipStreamCreateWithFlags(&c->hstream, hipStreamNonBlocking) != hipSuccess) { rc = IBFT_E_HIP; break; }
+    if (hipEventCreateWithFlags(&c->ev_H, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess) { rc = IBFT_E_HIP; break; }
     if ((rc = alloc_rows(c, c->max_rows))) break;
     if (hipMemsetAsync(c->d_acc.p, 0, c->d_acc.cap, c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_tally.p, 0, c->d_tally.cap, c->stream) != hipSuccess) { rc = IBFT_E_HIP; break; }
@@ -825,6 +846,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->hstream) (void)hipStreamSynchronize(c->hstream);
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
@@ -840,6 +862,9 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->h_set) (void)hipHostFree(c->h_set);
   if (c->h_class) (void)hipHostFree(c->h_class);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->ev_H) (void)hipEventDestroy(c->ev_H);
+  if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+  if (c->hstream) (void)hipStreamDestroy(c->hstream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -989,6 +1014,7 @@ int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_proposal_hash(c, raw, raw_len, round))) return rc;
+  if ((rc = wait_proposal_hash(c))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->h_digest, c->d_H.p, 32, hipMemcpyDeviceToHost, c->stream));
   if (hipStreamSynchronize(c->stream) != hipSuccess) {
     c->have_H = false;
@@ -1002,6 +1028,7 @@ int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
 static int hash_eq_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *hash_len, size_t n, uint64_t *out_mask) {
   int rc;
   c->wire_valid = false;
+  if ((rc = wait_proposal_hash(c))) return rc;
   ColumnCopies cc;
   cc.add(c->d_hash.p, hash32, n * 32);
   cc.add(c->d_hash_len.p, hash_len, n);
@@ -1016,6 +1043,13 @@ static int hash_eq_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *has
   rc = fetch_results(c, (uint32_t)n, out_mask, nullptr, false);
   if (rc) c->have_H = false;  // a failed stream leaves nothing to trust
   return rc;
+}
+
+int ibft_forget_proposal(ibft_ctx *c) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->have_H = false;
+  return IBFT_OK;
 }
 
 int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round,
@@ -1036,6 +1070,10 @@ int ibft_verify_hashes_digest(ibft_ctx *c, const uint8_t digest32[32], const uin
   std::lock_guard<std::mutex> lk(c->mu);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
+  {
+    int rcw = wait_proposal_hash(c);  // a hash still on its way must not land on top of the caller's digest
+    if (rcw) return rcw;
+  }
   c->have_H = false;  // d_H now holds the caller's digest, not the hash of the remembered proposal
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
   memcpy(c->h_digest, digest32, 32);
@@ -1241,6 +1279,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   if ((rc = alloc_rows(c, 2 * (((uint32_t)c->max_rows + 63u) & ~63u)))) return rc;
   // the proposal the set is checked against: its digest, or raw ‖ BE64(round) hashed once and remembered
   if (digest32) {
+    if ((rc = wait_proposal_hash(c))) return rc;  // a hash still on its way must not land on top of the caller's digest
     c->have_H = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
     memcpy(c->h_digest, digest32, 32);
@@ -1298,6 +1337,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
   sa.host_sender = c->dh_set;
   sa.host_valid = c->dh_set ? c->dh_set + mask_words(c->max_rows) : nullptr;
+  if ((rc = wait_proposal_hash(c))) return rc;  // the verdict launch above did not need the proposal's hash; the combine step does
   if ((rc = enqueue_tally(c, (uint32_t)n, &sa))) return rc;
   c->mask_dirty_words = 0;  // the combine kernel zeroed the seal words, the tally the sender words
   if (!c->dh_set)
@@ -1455,6 +1495,7 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   const uint32_t half = ((uint32_t)n + 63u) & ~63u;
   if ((rc = alloc_rows(c, 2 * (((uint32_t)c->max_rows + 63u) & ~63u)))) return rc;
   if (digest32) {
+    if ((rc = wait_proposal_hash(c))) return rc;  // a hash still on its way must not land on top of the caller's digest
     c->have_H = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is free again
     memcpy(c->h_digest, digest32, 32);
@@ -1513,6 +1554,7 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
   sa.host_sender = c->dh_set;
   sa.host_valid = c->dh_set ? c->dh_set + mask_words(c->max_rows) : nullptr;
+  if ((rc = wait_proposal_hash(c))) return rc;  // the verdict launch above did not need the proposal's hash; the combine step does
   if ((rc = enqueue_tally(c, (uint32_t)n, &sa))) return rc;
   c->mask_dirty_words = 0;
   if (!c->dh_set)

@@ -37,7 +37,7 @@ EXPORTS = [
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
-    "ibft_verify_messages_wire",
+    "ibft_verify_messages_wire", "ibft_forget_proposal",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp,
                                             C.POINTER(Tally)]
+    L.ibft_forget_proposal.argtypes = [vp]
     L.ibft_pinned_alloc.argtypes = [C.c_size_t]; L.ibft_pinned_alloc.restype = vp
     L.ibft_pinned_free.argtypes = [vp]; L.ibft_pinned_free.restype = None
     L.ibft_column_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -482,6 +483,10 @@ class BatchVerifier:
         self._chk(self._L.ibft_sign_seals(self._h, _p(sk), _p(hs), n, _p(sig), _p(signer), _p(ok)), "ibft_sign_seals")
         self._staged = n
         return sig, signer, ok.astype(bool)
+
+    def forget_proposal(self) -> None:
+        """the next call that names a proposal hashes it again (a new height has a new proposal)"""
+        self._chk(self._L.ibft_forget_proposal(self._h), "ibft_forget_proposal")
 
     def gather_batches(self) -> int:
         """batches whose (pinned) columns the device read itself in one gather launch"""

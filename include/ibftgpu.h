@@ -217,6 +217,11 @@ int ibft_wire_stage_seals(ibft_ctx *ctx);
 int ibft_tally(ibft_ctx *ctx, const uint8_t *sender20, const uint64_t *mask, size_t n,
                ibft_tally_t *tally);
 
+/* The context remembers the last (raw proposal, round) it hashed: ibft_verify_hashes / ibft_verify_messages
+ * with the same proposal do not hash it again.  ibft_forget_proposal drops that memory (the next call hashes);
+ * bench.py calls it once per measured sequence so that every height pays for its own proposal hash.         */
+int ibft_forget_proposal(ibft_ctx *ctx);
+
 /* ---- staged (device-resident) form of a2, used by bench.py and by multi-GPU ----
  * stage:  copy the batch into the context's HBM columns (H2D, synchronous).
  * launch: enqueue unpack → recover → tally on the context's stream (asynchronous);

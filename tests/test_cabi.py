@@ -77,6 +77,7 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.ibft_seals_stage(null, b, b, b, None, 1),
         lambda: lib.ibft_sign_seals(null, b, b, 1, b, None, None),
         lambda: lib.ibft_column_stats(null, None),
+        lambda: lib.ibft_forget_proposal(null),
         lambda: lib.ibft_verify_messages_wire(null, b, off, 1, 0, 0, b, 1, 0, None, m, m, None, None, C.byref(t)),
         lambda: lib.ibft_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, m, m, C.byref(t)),
         lambda: lib.ibft_seals_launch(null, 1),

@@ -50,6 +50,8 @@ for name, flags in (("cold", 0), ("warm", V.FLAG_PUBKEY_CACHE)):
     for _ in range(rounds):
         t00 = time.perf_counter()
         for k, f in calls:
+            if k in ("senders_prepare", "set_prepare"):
+                bv.forget_proposal()   # a new height: its proposal is hashed once
             bv.last_kernel_ms()
             t0 = time.perf_counter()
             f()
