@@ -93,6 +93,7 @@ struct ibft_ctx {
   // a1: the proposal whose Keccak the device holds in d_H (raw ‖ BE64(round)); the same proposal is checked
   // against every PREPARE and COMMIT set of a round and on every wake-up, so it is hashed once
   std::vector<uint8_t> hashed_proposal;
+  std::vector<uint8_t> padded_proposal;  // the same with Keccak's pad10*1, as uploaded
   bool have_H = false;
   // the proposal is hashed on a stream of its own (one lane, ≈9 µs per 136-byte block): a message set's verdict launch does
   // not depend on it — only the combine step inside the tally does — so the two overlap
@@ -472,14 +473,21 @@ int ensure_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64
   c->hashed_proposal.resize(raw_len + 8);
   if (raw_len) memcpy(c->hashed_proposal.data(), raw, raw_len);
   memcpy(c->hashed_proposal.data() + raw_len, be, 8);
-  int rc = ensure(c, c->d_raw, c->hashed_proposal.size() + 256);  // slack: the kernel reads whole dwords
+  // Keccak padding on the host: pad10*1 up to a multiple of the 136-byte rate (the kernel XORs whole 64-bit words)
+  const size_t mlen = c->hashed_proposal.size();
+  const size_t blocks = mlen / 136 + 1;
+  c->padded_proposal.assign(blocks * 136, 0);
+  memcpy(c->padded_proposal.data(), c->hashed_proposal.data(), mlen);
+  c->padded_proposal[mlen] ^= 0x01;
+  c->padded_proposal[blocks * 136 - 1] ^= 0x80;
+  int rc = ensure(c, c->d_raw, blocks * 136);
   if (rc) return rc;
   // everything already enqueued on the main stream (readers of the previous d_H) first, then upload + hash on the side stream
   HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->hstream, c->ev_main, 0));
-  HIPCHK(c, hipMemcpyAsync(c->d_raw.p, c->hashed_proposal.data(), c->hashed_proposal.size(), hipMemcpyHostToDevice, c->hstream));
-  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->hstream, (const uint8_t *)c->d_raw.p,
-                     (uint32_t)c->hashed_proposal.size(), (uint64_t *)c->d_H.p);
+  HIPCHK(c, hipMemcpyAsync(c->d_raw.p, c->padded_proposal.data(), blocks * 136, hipMemcpyHostToDevice, c->hstream));
+  hipLaunchKernelGGL(ibftk::proposal_hash_kernel, dim3(1), dim3(64), 0, c->hstream, (const uint64_t *)c->d_raw.p,
+                     (uint32_t)blocks, (uint64_t *)c->d_H.p);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev_H, c->hstream));
   c->H_pending = true;
