@@ -545,14 +545,32 @@ struct ColumnCopies {
   };
   Seg seg[ibftk::GATHER_MAX];
   int n = 0;
+  // optional: the PayloadNoSig column of a message set.  Pinned: it is never copied — digest blocks of the gather launch
+  // hash it straight from the host column into `digest_dst` (digest_done).  Pageable: payload and offsets are copied to
+  // pay_dst / off_dst like any column and the caller launches payload_digest_kernel.
+  const void *pay_src = nullptr, *off_src = nullptr;
+  void *pay_dst = nullptr, *off_dst = nullptr, *digest_dst = nullptr;
+  size_t pay_bytes = 0, rows = 0;
+  bool digest_done = false;
   void add(void *dst, const void *src, size_t bytes) {
     if (bytes && n < ibftk::GATHER_MAX) seg[n++] = Seg{dst, src, bytes};
   }
+  void payload(void *pdst, const void *psrc, size_t pbytes, void *odst, const void *osrc, size_t n_rows, void *ddst) {
+    pay_dst = pdst; pay_src = psrc; pay_bytes = pbytes; off_dst = odst; off_src = osrc; rows = n_rows; digest_dst = ddst;
+  }
   int flush(ibft_ctx *c) {
-    if (n == 0) return IBFT_OK;
+    const bool job = rows != 0;
+    if (n == 0 && !job) return IBFT_OK;
     bool pinned = c->gather_pinned;
     for (int i = 0; i < n && pinned; i++) pinned = seg[i].bytes < (1ull << 31) && pinned_registry().covers(seg[i].src, seg[i].bytes);
+    if (pinned && job)
+      pinned = pay_bytes < (1ull << 31) && pinned_registry().covers(off_src, (rows + 1) * 4) &&
+               (pay_bytes == 0 || pinned_registry().covers(pay_src, pay_bytes));
     if (!pinned) {
+      if (job) {
+        if (pay_bytes) HIPCHK(c, hipMemcpyAsync(pay_dst, pay_src, pay_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(off_dst, off_src, (rows + 1) * 4, hipMemcpyHostToDevice, c->stream));
+      }
       for (int i = 0; i < n; i++) HIPCHK(c, hipMemcpyAsync(seg[i].dst, seg[i].src, seg[i].bytes, hipMemcpyHostToDevice, c->stream));
       n = 0;
       return IBFT_OK;
@@ -568,6 +586,15 @@ struct ColumnCopies {
     }
     a.first_block[n] = blocks;
     a.n = (uint32_t)n;
+    if (job) {
+      a.pay_src = (const uint8_t *)pay_src;
+      a.off_src = (const uint32_t *)off_src;
+      a.digest_dst = (uint8_t *)digest_dst;
+      a.n_rows = (uint32_t)rows;
+      a.pay_bytes = (uint32_t)pay_bytes;
+      blocks += (uint32_t)((rows + 63) / 64);
+      digest_done = true;
+    }
     hipLaunchKernelGGL(ibftk::gather_columns_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     c->gathers++;
@@ -575,7 +602,6 @@ struct ColumnCopies {
     return IBFT_OK;
   }
 };
-
 
 // ---- RCCL, loaded on first use: a single-GPU deployment never needs the library ----------------------
 struct RcclApi {
@@ -1316,8 +1342,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   const size_t pbytes = off[n];
   if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
   ColumnCopies cc;
-  cc.add(c->d_payload.p, payload, pbytes);
-  cc.add(c->d_off.p, off, (n + 1) * 4);
+  cc.payload(c->d_payload.p, payload, pbytes, c->d_off.p, off, n, d_hash);
   cc.add(d_sig, msg_sig65, n * 65);
   cc.add(d_signer, from20, n * 20);
   cc.add(d_hash + 32ull * half, hash32, n * 32);  // the hashes the messages carry
@@ -1333,9 +1358,11 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
       HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
   }
   if ((rc = cc.flush(c))) return rc;
-  hipLaunchKernelGGL(ibftk::payload_digest_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
-                     (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n, d_hash);
-  HIPCHK(c, hipGetLastError());
+  if (!cc.digest_done) {  // pageable columns: the payload was copied, hash it from HBM
+    hipLaunchKernelGGL(ibftk::payload_digest_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream,
+                       (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n, d_hash);
+    HIPCHK(c, hipGetLastError());
+  }
   c->ev_used = 0;
   const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
   if ((rc = enqueue_recover(c, rows, false, 0, time_it))) return rc;

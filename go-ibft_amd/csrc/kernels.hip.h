@@ -70,14 +70,56 @@ __device__ __forceinline__ int valset_lookup(const uint32_t *__restrict__ vtab, 
 // read with 16-byte loads straight over PCIe (≈1.3 MB: ≈25 µs).  Pageable columns keep the per-column copies.
 constexpr int GATHER_MAX = 12;
 constexpr int GATHER_BLOCK_BYTES = 256 * 16;
+constexpr uint32_t GATHER_DIGEST_LDS = 32 * 1024;
 struct gather_args {
   const uint8_t *src[GATHER_MAX];
   uint8_t *dst[GATHER_MAX];
   uint32_t bytes[GATHER_MAX];
   uint32_t first_block[GATHER_MAX + 1];  // segment s owns blocks [first_block[s], first_block[s+1])
   uint32_t n;
+  // optional digest job (a message set): the PayloadNoSig column is NOT copied — the blocks after the copy blocks read 64
+  // rows each from the host column into LDS (coalesced) and write keccak256(row) into the digest column
+  const uint8_t *pay_src;   // host (pinned), or null
+  const uint32_t *off_src;  // host (pinned): n_rows + 1 offsets
+  uint8_t *digest_dst;      // HBM: n_rows × 32
+  uint32_t n_rows, pay_bytes;
 };
+__device__ __forceinline__ void hash_range_dwords(const uint8_t *__restrict__ in, uint32_t len, uint64_t out4[4]);
 __global__ void __launch_bounds__(256) gather_columns_kernel(gather_args a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lbuf[GATHER_DIGEST_LDS + 16];
+  if (blockIdx.x >= a.first_block[a.n]) {
+    // ---- digest blocks: one wavefront, 64 rows ----
+    if (threadIdx.x >= 64) return;
+    const uint32_t row0 = (blockIdx.x - a.first_block[a.n]) * 64u, lane = threadIdx.x;
+    if (row0 >= a.n_rows) return;
+    const uint32_t cnt = a.n_rows - row0 < 64u ? a.n_rows - row0 : 64u;
+    const uint32_t row = row0 + (lane < cnt ? lane : cnt - 1);
+    const uint32_t o0 = a.off_src[row], o1 = a.off_src[row + 1];
+    const uint32_t first = __shfl(o0, 0, 64), last = __shfl(o1, (int)cnt - 1, 64);
+    const uint32_t b0 = first & ~15u;
+    const bool staged = last - b0 <= GATHER_DIGEST_LDS && ((reinterpret_cast<uintptr_t>(a.pay_src) & 15u) == 0);  // wave-uniform
+    if (staged) {
+      for (uint32_t i = 16u * lane; b0 + i < last; i += 1024u) {  // 16-byte loads over PCIe, never past the column's end
+        if (b0 + i + 16u <= a.pay_bytes) {
+          *reinterpret_cast<uint4 *>(lbuf + i) = *reinterpret_cast<const uint4 *>(a.pay_src + b0 + i);
+        } else {
+          for (uint32_t j = 0; b0 + i + j < a.pay_bytes; j++) lbuf[i + j] = a.pay_src[b0 + i + j];
+        }
+      }
+      __syncthreads();  // the other wavefronts of this block have left
+    }
+    uint64_t d[4];
+    if (staged)
+      hash_range_dwords(lbuf + (o0 - b0), o1 - o0, d);  // dword reads may run a few bytes past the row: inside the buffer
+    else
+      keccak::hash_bytes(a.pay_src + o0, o1 - o0, d);   // rows too long for the buffer: exact byte reads from the host column
+    if (lane < cnt) {
+      uint4 *o = reinterpret_cast<uint4 *>(a.digest_dst + 32ull * row);
+      o[0] = make_uint4((uint32_t)d[0], (uint32_t)(d[0] >> 32), (uint32_t)d[1], (uint32_t)(d[1] >> 32));
+      o[1] = make_uint4((uint32_t)d[2], (uint32_t)(d[2] >> 32), (uint32_t)d[3], (uint32_t)(d[3] >> 32));
+    }
+    return;
+  }
   uint32_t s = 0;
 #pragma unroll 1
   while (s + 1 < a.n && blockIdx.x >= a.first_block[s + 1]) s++;
@@ -916,29 +958,37 @@ struct set_args {
   uint64_t *sender_out, *valid_out;    // device copies (⌈n/64⌉ words each)
   uint64_t *host_sender, *host_valid;  // mapped pinned host memory or null
 };
-// called by a whole wavefront; returns sender ∧ valid for word w on every lane
-__device__ __forceinline__ uint64_t set_combine_word(const set_args &a, uint64_t *work_mask, uint32_t w, uint32_t lane) {
-  const uint32_t row = w * 64u + lane;
-  bool a1 = false, spre = false, nos = false;
+// Per-row part (loads only, no stores: the caller issues several rows' loads before it waits for any of them)
+struct set_row_flags {
+  bool a1, spre, nos;
+};
+__device__ __forceinline__ set_row_flags set_row(const set_args &a, uint32_t row) {
+  set_row_flags f{false, false, false};
   if (row < a.n) {
-    spre = a.sender_pre && a.sender_pre[row] != 0;
-    nos = a.no_seal && a.no_seal[row] != 0;
+    f.spre = a.sender_pre && a.sender_pre[row] != 0;
+    f.nos = a.no_seal && a.no_seal[row] != 0;
     const uint4 *p = reinterpret_cast<const uint4 *>(a.hash32 + 32ull * row);
     const uint4 x = p[0], y = p[1];
     const uint32_t *h = reinterpret_cast<const uint32_t *>(a.H4);
     const uint32_t diff = (x.x ^ h[0]) | (x.y ^ h[1]) | (x.z ^ h[2]) | (x.w ^ h[3]) | (y.x ^ h[4]) | (y.y ^ h[5]) |
                           (y.z ^ h[6]) | (y.w ^ h[7]);
     // valid_pre marks a dead seal side; a row flagged no_seal (a PREPARE among raw messages) has no seal side to be dead
-    const bool dead = a.valid_pre && a.valid_pre[row] != 0 && !nos;
-    a1 = diff == 0 && a.hash_len[row] == 32 && !dead;
+    const bool dead = a.valid_pre && a.valid_pre[row] != 0 && !f.nos;
+    f.a1 = diff == 0 && a.hash_len[row] == 32 && !dead;
   }
-  const uint64_t bal = __ballot(a1), sbad = __ballot(spre), skip_seal = __ballot(nos);
+  return f;
+}
+// Per-word part, called by a whole wavefront with its lanes' flags and the two verdict words already loaded; returns
+// sender ∧ valid on every lane, lane 0 delivers the two words
+__device__ __forceinline__ uint64_t set_finish_word(const set_args &a, uint64_t *work_mask, uint32_t w, uint32_t lane,
+                                                    const set_row_flags &f, uint64_t sender_word, uint64_t seal_word) {
+  const uint64_t bal = __ballot(f.a1), sbad = __ballot(f.spre), skip_seal = __ballot(f.nos);
   const uint32_t first = w * 64u;
   const uint32_t left = a.n > first ? a.n - first : 0u;
   const uint64_t tail = left >= 64 ? ~0ull : (left ? (~0ull >> (64 - left)) : 0ull);
-  const uint64_t S = work_mask[w] & tail & ~sbad;
+  const uint64_t S = sender_word & tail & ~sbad;
   uint64_t V = bal;
-  if (a.half_words) V &= work_mask[a.half_words + w] | skip_seal;
+  if (a.half_words) V &= seal_word | skip_seal;
   if (lane == 0) {
     if (a.half_words) work_mask[a.half_words + w] = 0;
     a.sender_out[w] = S;
@@ -994,13 +1044,26 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   // The verdict kernels accumulate into work_mask (atomicOr / ballot words).  The tally CONSUMES it: the words
   // move to `mask`, to host_mask when given, and work_mask is left zeroed for the next launch.
   if (a.set_on) {
-    // every wavefront combines its share of the workgroup's verdict words (wave-uniform loop)
+    // every wavefront combines its share of the workgroup's verdict words; all loads first, then the ballots and stores
+    constexpr int WPW = (TALLY_ROWS_PER_BLOCK / 64) / (TALLY_THREADS / 64);  // words per wavefront
     const uint32_t wv = tid >> 6, ln = tid & 63u;
-    for (uint32_t k = wv; k < TALLY_ROWS_PER_BLOCK / 64; k += TALLY_THREADS / 64) {
+    set_row_flags fl[WPW];
+    uint64_t sw[WPW], lw[WPW];
+#pragma unroll
+    for (int q = 0; q < WPW; q++) {
+      const uint32_t wi = row0 / 64 + wv + (uint32_t)q * (TALLY_THREADS / 64);
+      const bool in = wi < total_words;
+      fl[q] = set_row(a.set, in ? wi * 64u + ln : 0xFFFFFFFFu);
+      sw[q] = in ? a.work_mask[wi] : 0ull;
+      lw[q] = (in && a.set.half_words) ? a.work_mask[a.set.half_words + wi] : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < WPW; q++) {
+      const uint32_t k = wv + (uint32_t)q * (TALLY_THREADS / 64);
       const uint32_t wi = row0 / 64 + k;
       uint64_t w = 0;
-      if (wi < total_words) {
-        w = set_combine_word(a.set, a.work_mask, wi, ln);
+      if (wi < total_words) {  // wave-uniform
+        w = set_finish_word(a.set, a.work_mask, wi, ln, fl[q], sw[q], lw[q]);
         if (ln == 0) {
           a.work_mask[wi] = 0;
           a.mask[wi] = w;

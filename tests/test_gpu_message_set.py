@@ -197,3 +197,31 @@ def test_prepared_call_on_fixed_buffers_refilled_in_place(oracle):
         assert bv.gather_batches() == 3
     finally:
         bv.close()
+
+
+def test_long_payload_rows_in_pinned_columns(oracle):
+    """64 rows that do not fit the gather launch's LDS buffer (32 KiB) are hashed straight from the host column."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    rng = np.random.default_rng(77)
+    lens = [int(x) for x in rng.integers(300, 1500, size=150)]
+    n = len(lens)
+    sks = [W.validator_key(5, i) for i in range(n)]
+    addrs = np.array([np.frombuffer(oracle.address(oracle.pubkey(sk)), np.uint8) for sk in sks])
+    rows = [rng.bytes(L) for L in lens]
+    off = np.zeros(n + 1, np.uint32)
+    off[1:] = np.cumsum(lens)
+    sig = np.array([np.frombuffer(oracle.sign(sks[i], oracle.keccak256(rows[i])), np.uint8) for i in range(n)])
+    sig[9, 40] ^= 2
+    payload = b"".join(rows)
+    vs = oracle.ValSet(addrs, np.ones(n, np.uint64))
+    exp = oracle.verify_senders(vs, payload, off, sig, addrs).astype(bool)
+    bv = V.BatchVerifier(max_rows=256)
+    try:
+        bv.set_validators(1, addrs, np.ones(n, np.uint64))
+        h = np.zeros((n, 32), np.uint8)
+        pin = [V.pinned_copy(x) for x in (payload, off, sig, addrs, h, np.full(n, 32, np.uint8))]
+        s, v, _ = bv.verify_messages(*pin, raw=b"x", round_=0)
+        assert (s == exp).all() and exp.sum() == n - 1 and not v.any() and bv.gather_batches() == 1
+    finally:
+        bv.close()
