@@ -88,26 +88,27 @@ __device__ __forceinline__ void hash_range_dwords(const uint8_t *__restrict__ in
 __global__ void __launch_bounds__(256) gather_columns_kernel(gather_args a) {
   __shared__ __attribute__((aligned(16))) uint8_t lbuf[GATHER_DIGEST_LDS + 16];
   if (blockIdx.x >= a.first_block[a.n]) {
-    // ---- digest blocks: one wavefront, 64 rows ----
-    if (threadIdx.x >= 64) return;
-    const uint32_t row0 = (blockIdx.x - a.first_block[a.n]) * 64u, lane = threadIdx.x;
+    // ---- digest blocks: 64 rows; all four wavefronts bring the rows into LDS (PCIe reads are latency-bound: many
+    // requests in flight), the first one hashes ----
+    const uint32_t row0 = (blockIdx.x - a.first_block[a.n]) * 64u, lane = threadIdx.x & 63u;
     if (row0 >= a.n_rows) return;
     const uint32_t cnt = a.n_rows - row0 < 64u ? a.n_rows - row0 : 64u;
     const uint32_t row = row0 + (lane < cnt ? lane : cnt - 1);
     const uint32_t o0 = a.off_src[row], o1 = a.off_src[row + 1];
     const uint32_t first = __shfl(o0, 0, 64), last = __shfl(o1, (int)cnt - 1, 64);
     const uint32_t b0 = first & ~15u;
-    const bool staged = last - b0 <= GATHER_DIGEST_LDS && ((reinterpret_cast<uintptr_t>(a.pay_src) & 15u) == 0);  // wave-uniform
+    const bool staged = last - b0 <= GATHER_DIGEST_LDS && ((reinterpret_cast<uintptr_t>(a.pay_src) & 15u) == 0);  // block-uniform
     if (staged) {
-      for (uint32_t i = 16u * lane; b0 + i < last; i += 1024u) {  // 16-byte loads over PCIe, never past the column's end
+      for (uint32_t i = 16u * threadIdx.x; b0 + i < last; i += 4096u) {  // 16-byte loads over PCIe, never past the column's end
         if (b0 + i + 16u <= a.pay_bytes) {
           *reinterpret_cast<uint4 *>(lbuf + i) = *reinterpret_cast<const uint4 *>(a.pay_src + b0 + i);
         } else {
           for (uint32_t j = 0; b0 + i + j < a.pay_bytes; j++) lbuf[i + j] = a.pay_src[b0 + i + j];
         }
       }
-      __syncthreads();  // the other wavefronts of this block have left
+      __syncthreads();
     }
+    if (threadIdx.x >= 64) return;
     uint64_t d[4];
     if (staged)
       hash_range_dwords(lbuf + (o0 - b0), o1 - o0, d);  // dword reads may run a few bytes past the row: inside the buffer
