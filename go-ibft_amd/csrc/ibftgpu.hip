@@ -116,6 +116,7 @@ struct ibft_ctx {
   uint8_t *h_class = nullptr, *dh_class = nullptr;  // one routing byte per wire row (ibft_verify_messages_wire)
   DevBuf d_class;
   bool gather_pinned = true;  // columns in ibft_pinned_alloc buffers are read by one gather launch (IBFT_NO_GATHER=1: never)
+  bool digest_in_gather = true;  // … whose extra blocks hash PayloadNoSig straight from the host column (IBFT_NO_DIGEST_FUSION=1: no)
   uint32_t gathers = 0;       // batches whose columns came in through the gather launch
   bool host_direct = false;                          // the last tally kernel delivered its results there
   hipEvent_t ev_ready = nullptr, ev_read = nullptr;  // ibft_seals_export_on: results ready / results read
@@ -575,6 +576,12 @@ struct ColumnCopies {
       n = 0;
       return IBFT_OK;
     }
+    if (job && !c->digest_in_gather) {  // the payload and its offsets as two more copied columns; the caller hashes from HBM
+      if (n + 2 > ibftk::GATHER_MAX) return IBFT_E_INVAL;
+      if (pay_bytes) seg[n++] = Seg{pay_dst, pay_src, pay_bytes};
+      seg[n++] = Seg{off_dst, off_src, (rows + 1) * 4};
+    }
+    const bool fused = job && c->digest_in_gather;
     ibftk::gather_args a{};
     uint32_t blocks = 0;
     for (int i = 0; i < n; i++) {
@@ -586,7 +593,7 @@ struct ColumnCopies {
     }
     a.first_block[n] = blocks;
     a.n = (uint32_t)n;
-    if (job) {
+    if (fused) {
       a.pay_src = (const uint8_t *)pay_src;
       a.off_src = (const uint32_t *)off_src;
       a.digest_dst = (uint8_t *)digest_dst;
@@ -838,6 +845,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   if (const char *e = getenv("IBFT_NO_EVENTS"))
     if (atoi(e) == 1) c->time_every = 0;
   if (getenv("IBFT_NO_GATHER")) c->gather_pinned = false;
+  if (getenv("IBFT_NO_DIGEST_FUSION")) c->digest_in_gather = false;
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("IBFT_ROWS_KERNEL_MAX")) c->rows_kernel_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;
