@@ -13,11 +13,16 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --rows $ROWS --steps 50 --warmup 5 --no-cpu-baseline --seq-rounds 20"
+# the headline leg only: the sequence legs launch the same kernel over 8 192 rows (a COMMIT set), which would mix two
+# launch shapes into one per-kernel average; their kernels are summarised by a second stats pass (…_seq_kernel_stats.csv)
+CMD="python $ROOT/bench.py --rows $ROWS --steps 50 --warmup 5 --no-cpu-baseline --no-sequence"
+SEQ="python $ROOT/bench.py --rows $ROWS --steps 10 --warmup 2 --no-cpu-baseline --no-warm --seq-rounds 30"
 PMC="python $ROOT/bench.py --rows $ROWS --steps 30 --warmup 3 --no-cpu-baseline --no-sequence"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- $CMD > "$OUT/stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats_seq" -o q --output-format csv -- $SEQ > "$OUT/stats_seq.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- $PMC > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- $PMC > "$OUT/write.log" 2>&1
 cd "$ROOT"
 python tools/summarize_prof.py "$OUT" "$SUM" "$TAG" "$ROWS"
+f=$(find "$OUT/stats_seq" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$SUM/${TAG}_seq_kernel_stats.csv"
