@@ -116,7 +116,11 @@ struct ibft_ctx {
   uint8_t *h_class = nullptr, *dh_class = nullptr;  // one routing byte per wire row (ibft_verify_messages_wire)
   DevBuf d_class;
   bool gather_pinned = true;  // columns in ibft_pinned_alloc buffers are read by one gather launch (IBFT_NO_GATHER=1: never)
-  bool digest_in_gather = true;  // … whose extra blocks hash PayloadNoSig straight from the host column (IBFT_NO_DIGEST_FUSION=1: no)
+  // … whose extra blocks can hash PayloadNoSig straight from the host column (IBFT_DIGEST_FUSION=1).  Off by default: it
+  // saves nothing measurable (gather + digest ≈ 46 µs either way) and the 8 192-row known-key kernel of a COMMIT set ran
+  // 0.25 ms instead of 0.17 ms behind the variant of the launch that carries the digest blocks' 32 KiB of LDS
+  // (profiles/r02q_n4096_seq_kernel_stats.csv against r02r)
+  bool digest_in_gather = false;
   uint32_t gathers = 0;       // batches whose columns came in through the gather launch
   bool host_direct = false;                          // the last tally kernel delivered its results there
   hipEvent_t ev_ready = nullptr, ev_read = nullptr;  // ibft_seals_export_on: results ready / results read
@@ -602,7 +606,10 @@ struct ColumnCopies {
       blocks += (uint32_t)((rows + 63) / 64);
       digest_done = true;
     }
-    hipLaunchKernelGGL(ibftk::gather_columns_kernel, dim3(blocks), dim3(256), 0, c->stream, a);
+    if (fused)
+      hipLaunchKernelGGL(ibftk::gather_columns_kernel<true>, dim3(blocks), dim3(256), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(ibftk::gather_columns_kernel<false>, dim3(blocks), dim3(256), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
     c->gathers++;
     n = 0;
@@ -845,7 +852,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   if (const char *e = getenv("IBFT_NO_EVENTS"))
     if (atoi(e) == 1) c->time_every = 0;
   if (getenv("IBFT_NO_GATHER")) c->gather_pinned = false;
-  if (getenv("IBFT_NO_DIGEST_FUSION")) c->digest_in_gather = false;
+  if (getenv("IBFT_DIGEST_FUSION")) c->digest_in_gather = true;
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("IBFT_ROWS_KERNEL_MAX")) c->rows_kernel_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;

@@ -85,9 +85,11 @@ struct gather_args {
   uint32_t n_rows, pay_bytes;
 };
 __device__ __forceinline__ void hash_range_dwords(const uint8_t *__restrict__ in, uint32_t len, uint64_t out4[4]);
+// DIGEST = true adds the digest blocks (and their 32 KiB of LDS per workgroup) to the launch.
+template <bool DIGEST>
 __global__ void __launch_bounds__(256) gather_columns_kernel(gather_args a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lbuf[GATHER_DIGEST_LDS + 16];
-  if (blockIdx.x >= a.first_block[a.n]) {
+  __shared__ __attribute__((aligned(16))) uint8_t lbuf[DIGEST ? GATHER_DIGEST_LDS + 16 : 16];
+  if (DIGEST && blockIdx.x >= a.first_block[a.n]) {
     // ---- digest blocks: 64 rows; all four wavefronts bring the rows into LDS (PCIe reads are latency-bound: many
     // requests in flight), the first one hashes ----
     const uint32_t row0 = (blockIdx.x - a.first_block[a.n]) * 64u, lane = threadIdx.x & 63u;
