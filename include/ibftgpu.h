@@ -23,6 +23,16 @@
  *   ibft_tally (+ the ibft_tally_t filled by the verify calls)
  *                        <- ValidatorManager.HasQuorum
  *                           /root/reference/core/validator_manager.go:77-96
+ *   ibft_verify_messages, ibft_verify_messages_wire
+ *                        <- all of the above for a whole PREPARE / COMMIT set in ONE call (from SoA columns / from the
+ *                           transport's bytes): IsValidValidator on arrival (core/ibft.go:1128) and the closure of
+ *                           handlePrepare / handleCommit (:856-862, :932-944) are pure, so a message is judged once,
+ *                           completely — both signatures of a COMMIT in one verdict launch
+ *   ibft_verify_senders_wire, ibft_wire_stage_seals
+ *                        <- proto.Unmarshal + PayloadNoSig (messages/proto/helper.go:12-27) + IsValidValidator
+ *   ibft_comm_*, ibft_group_*  validator shards over several MI355X, one RCCL all-reduce inside the library
+ *   ibft_sign_seals      <- n × Backend.BuildCommitMessage's seal (core/backend.go:12-34), simulators only
+ *   ibft_pinned_alloc    page-locked column buffers the device reads itself (one gather launch per call)
  *
  * Conventions (the reference fixes none of the arithmetic; these are the
  * Ethereum-style ones an IBFT backend uses, stated once, obeyed by CPU oracle and
@@ -48,7 +58,7 @@
  * Verifier for that batch (all-false would stall liveness, all-true would break
  * safety).  There is NO CPU fallback inside this library.
  *
- * Threading: a context is internally serialised (one mutex, one HIP stream); use
+ * Threading: a context is internally serialised (one mutex, one HIP stream + a side stream for the proposal hash); use
  * one context per concurrent caller (the four goroutines of
  * /root/reference/core/ibft.go:335-347 would each hold one).  Nothing is retained
  * from caller memory after a call returns (cgo pointer rules).
