@@ -183,4 +183,100 @@ void dev_wire_row(const uint8_t *m, uint32_t n, uint8_t *out263) {
   wire::process_row(m, n, &ri, out263 + 80, out263 + 112, out263 + 177, out263 + 197, out263 + 262);
   memcpy(out263, &ri, 80);
 }
+
+// §8f rank 2 from bytes: the certificate tree on the CPU — the same wire:: building blocks in the order the cert_*
+// kernels apply them (parse a level, count + list the nested messages, next level, …; propagate bottom-up; digests;
+// hash bits).  Columns are rows_cap long; returns the number of rows, or -1 when the tree does not fit rows_cap.
+// The wire buffer must carry 8 bytes of slack behind off[n] (dword reads).
+int64_t dev_cert_tree(const uint8_t *wire_bytes, const uint32_t *off, uint32_t n, uint32_t rows_cap, uint8_t *nodes_out,
+                      uint8_t *rows_out, uint8_t *digest32, uint8_t *sig65, uint8_t *from20, uint8_t *pre_flags,
+                      uint8_t *prop_digest32, uint8_t *cls, uint8_t *hash_bits, uint8_t *self_bits) {
+  if (n > rows_cap) return -1;
+  std::vector<wire::node_info> nodes(rows_cap);
+  std::vector<wire::row_info> rows(rows_cap);
+  std::vector<uint32_t> span(2 * (size_t)rows_cap);
+  for (uint32_t i = 0; i < n; i++) {
+    wire::node_info nd{};
+    nd.off = off[i];
+    nd.len = off[i + 1] - off[i];
+    nd.parent = wire::NO_PARENT;
+    nd.ordinal = i;
+    nodes[i] = nd;
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> levels;
+  uint32_t lo = 0, hi = n;
+  for (;;) {
+    for (uint32_t row = lo; row < hi; row++)
+      wire::process_tree_row(wire_bytes + nodes[row].off, nodes[row].len, &rows[row], &nodes[row], &span[2 * (size_t)row],
+                             digest32 + 32ull * row, sig65 + 65ull * row, from20 + 20ull * row, pre_flags + row);
+    levels.push_back({lo, hi});
+    // count (and check) the nested messages of every row of the level, then list them behind the level
+    uint32_t next = hi;
+    for (int fill = 0; fill < 2; fill++) {
+      uint32_t base = hi;
+      for (uint32_t row = lo; row < hi; row++) {
+        wire::node_info &nd = nodes[row];
+        if (!fill) nd.first_child = base;  // every row gets the running sum, like cert_scan_kernel
+        if (rows[row].status != wire::STATUS_OK || !(nd.flags & wire::TREE_HAS_CERT)) continue;
+        const bool pc = rows[row].payload_kind == wire::KIND_ROUND_CHANGE;
+        uint32_t pos = nd.off + span[2 * (size_t)row], last = 0, count = 0;
+        const uint32_t end = pos + span[2 * (size_t)row + 1];
+        bool ok = true;
+        while (pos < end) {
+          uint32_t len;
+          uint8_t role;
+          if (!wire::cert_child_header(wire_bytes, end, pc, last, pos, len, role)) {
+            ok = false;
+            break;
+          }
+          if (fill) {
+            if ((uint64_t)nd.first_child + count >= rows_cap) return -1;
+            wire::node_info c{};
+            c.off = pos;
+            c.len = len;
+            c.parent = row;
+            c.ordinal = count;
+            c.level = (uint8_t)(nd.level + 1);
+            c.role = role;
+            nodes[nd.first_child + count] = c;
+          }
+          count++;
+          pos += len;
+        }
+        if (!fill) {
+          if (!ok) {
+            rows[row].status = wire::STATUS_NEEDS_HOST;
+            count = 0;
+          }
+          nd.n_children = count;
+          nd.first_child = base;
+          base += count;
+        }
+      }
+      if (!fill) {
+        next = base;
+        if (next > rows_cap) return -1;
+        if (next == hi) break;
+      }
+    }
+    if (next == hi) break;
+    lo = hi;
+    hi = next;
+  }
+  const uint32_t total = hi;
+  for (size_t l = levels.size(); l-- > 1;)
+    for (uint32_t row = levels[l].first; row < levels[l].second; row++)
+      if (rows[row].status != wire::STATUS_OK && nodes[row].parent != wire::NO_PARENT) rows[nodes[row].parent].status = wire::STATUS_NEEDS_HOST;
+  for (uint32_t row = 0; row < total; row++)
+    wire::tree_digest_row(wire_bytes, &rows[row], &nodes[row], digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row);
+  for (uint32_t row = 0; row < total; row++) {
+    bool hb, sb;
+    wire::tree_compare_row(nodes.data(), rows.data(), prop_digest32, row, hb, sb, cls[row]);
+    hash_bits[row] = hb;
+    self_bits[row] = sb;
+  }
+  memcpy(nodes_out, nodes.data(), (size_t)total * sizeof(wire::node_info));
+  memcpy(rows_out, rows.data(), (size_t)total * sizeof(wire::row_info));
+  return total;
+}
 }

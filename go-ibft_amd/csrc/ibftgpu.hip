@@ -115,6 +115,11 @@ struct ibft_ctx {
   DevBuf d_set;
   uint8_t *h_class = nullptr, *dh_class = nullptr;  // one routing byte per wire row (ibft_verify_messages_wire)
   DevBuf d_class;
+  // certificates from wire bytes (ibft_verify_certificates_wire): tree nodes, where each row's nested messages lie,
+  // child counts of the level being expanded, proposal digests, hash / self words; the row count of the next level
+  // comes back through one mapped word
+  DevBuf d_cert_nodes, d_cert_span, d_cert_count, d_cert_prop, d_cert_masks, d_cert_total;
+  uint32_t *h_cert_total = nullptr, *dh_cert_total = nullptr;
   bool gather_pinned = true;  // columns in ibft_pinned_alloc buffers are read by one gather launch (IBFT_NO_GATHER=1: never)
   // … whose extra blocks can hash PayloadNoSig straight from the host column (IBFT_DIGEST_FUSION=1).  Off by default: it
   // saves nothing measurable (gather + digest ≈ 46 µs either way) and the 8 192-row known-key kernel of a COMMIT set ran
@@ -906,8 +911,10 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
-                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class})
+                    &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
+                    &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total})
     release(*b);
+  if (c->h_cert_total) (void)hipHostFree(c->h_cert_total);
   comm_release(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_read) (void)hipEventDestroy(c->ev_read);
@@ -1633,6 +1640,116 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   memcpy(out_sender_mask, c->h_set, mw * 8);
   memcpy(out_valid_mask, c->h_set + mask_words(c->max_rows), mw * 8);
   if (out_class) memcpy(out_class, c->h_class, n);
+  return IBFT_OK;
+}
+
+// §8f rank 2 from the transport's bytes: the whole certificate tree of a batch of PREPREPARE / ROUND_CHANGE messages —
+// every nested message a row — expanded level by level on the device (kernels.hip.h: cert_*_kernel), then ONE verdict
+// launch over all rows.  The host takes part once per level: it reads the next level's row count to size the launches.
+int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint32_t *off, size_t n, size_t rows_cap,
+                                  size_t *out_n_rows, ibft_cert_node_t *out_nodes, ibft_wire_row_t *out_rows,
+                                  uint8_t *out_class, uint64_t *out_sender_mask, uint64_t *out_hash_mask,
+                                  uint64_t *out_self_mask) {
+  static_assert(sizeof(ibft_cert_node_t) == sizeof(wire::node_info), "ABI");
+  static_assert(IBFT_CERT_DIGEST_MAX_BYTES == wire::TREE_DIGEST_MAX_BYTES, "ABI");
+  if (!c || !out_n_rows || (n && (!off || !out_sender_mask))) return IBFT_E_INVAL;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
+  *out_n_rows = 0;
+  std::lock_guard<std::mutex> lk(c->mu);
+  const size_t cap = std::min<size_t>(rows_cap, c->max_rows);
+  if (n > cap) return IBFT_E_TOOBIG;
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  if (n == 0) return IBFT_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  c->wire_valid = false;
+  c->staged_n = 0;
+  const size_t wbytes = off[n], m = c->max_rows;
+  if ((rc = ensure(c, c->d_payload, wbytes + 256))) return rc;
+  if ((rc = ensure(c, c->d_wire_rows, m * sizeof(wire::row_info)))) return rc;
+  if ((rc = ensure(c, c->d_cert_nodes, m * sizeof(wire::node_info)))) return rc;
+  if ((rc = ensure(c, c->d_cert_span, m * 8))) return rc;
+  if ((rc = ensure(c, c->d_cert_count, m * 4))) return rc;
+  if ((rc = ensure(c, c->d_cert_prop, m * 32))) return rc;
+  if ((rc = ensure(c, c->d_cert_masks, (size_t)mask_words(m) * 16))) return rc;
+  if ((rc = ensure(c, c->d_cert_total, 64))) return rc;
+  if (!c->h_cert_total) {
+    if (hipHostMalloc((void **)&c->h_cert_total, 64) != hipSuccess) return IBFT_E_NOMEM;
+    void *d = nullptr;
+    if (!getenv("IBFT_NO_HOST_DIRECT") && hipHostGetDevicePointer(&d, c->h_cert_total, 0) == hipSuccess) c->dh_cert_total = (uint32_t *)d;
+  }
+  const uint8_t *d_wire = (const uint8_t *)c->d_payload.p;
+  wire::node_info *d_nodes = (wire::node_info *)c->d_cert_nodes.p;
+  wire::row_info *d_rows = (wire::row_info *)c->d_wire_rows.p;
+  uint2 *d_span = (uint2 *)c->d_cert_span.p;
+  uint32_t *d_count = (uint32_t *)c->d_cert_count.p, *d_total = (uint32_t *)c->d_cert_total.p;
+  uint8_t *d_digest = (uint8_t *)c->d_hash.p, *d_sig = (uint8_t *)c->d_sig.p, *d_from = (uint8_t *)c->d_signer.p,
+          *d_pre = (uint8_t *)c->d_pre.p, *d_prop = (uint8_t *)c->d_cert_prop.p;
+  if (wbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, wire_bytes, wbytes, hipMemcpyHostToDevice, c->stream));
+  std::vector<wire::node_info> level0(n);
+  for (size_t i = 0; i < n; i++) {
+    wire::node_info nd{};
+    nd.off = off[i];
+    nd.len = off[i + 1] - off[i];
+    nd.parent = wire::NO_PARENT;
+    nd.ordinal = (uint32_t)i;
+    nd.role = wire::ROLE_ROOT;
+    level0[i] = nd;
+  }
+  HIPCHK(c, hipMemcpyAsync(d_nodes, level0.data(), n * sizeof(wire::node_info), hipMemcpyHostToDevice, c->stream));
+  std::vector<std::pair<uint32_t, uint32_t>> levels;
+  uint32_t lo = 0, hi = (uint32_t)n;
+  for (uint32_t level = 0;; level++) {
+    const uint32_t cnt = hi - lo;
+    hipLaunchKernelGGL(ibftk::cert_parse_kernel, dim3((cnt + 63) / 64), dim3(64), 0, c->stream, d_wire, d_nodes, lo, hi, d_rows, d_span,
+                       d_digest, d_sig, d_from, d_pre);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(ibftk::cert_walk_kernel<false>, dim3(cnt), dim3(64), 0, c->stream, d_wire, d_nodes, d_rows, (const uint2 *)d_span, lo, hi,
+                       d_count);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(ibftk::cert_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_count, d_nodes, lo, hi, hi, d_total,
+                       c->dh_cert_total);
+    HIPCHK(c, hipGetLastError());
+    if (!c->dh_cert_total) HIPCHK(c, hipMemcpyAsync(c->h_cert_total, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    levels.push_back({lo, hi});
+    const uint32_t total = *(volatile uint32_t *)c->h_cert_total;
+    if (total == 0) break;
+    if ((uint64_t)hi + total > cap || level == 254) return IBFT_E_TOOBIG;
+    hipLaunchKernelGGL(ibftk::cert_walk_kernel<true>, dim3(cnt), dim3(64), 0, c->stream, d_wire, d_nodes, d_rows, (const uint2 *)d_span, lo, hi,
+                       d_count);
+    HIPCHK(c, hipGetLastError());
+    lo = hi;
+    hi += total;
+  }
+  const uint32_t rows = hi;
+  for (size_t l = levels.size(); l-- > 1;) {
+    const uint32_t cnt = levels[l].second - levels[l].first;
+    hipLaunchKernelGGL(ibftk::cert_propagate_kernel, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, (const wire::node_info *)d_nodes, d_rows,
+                       levels[l].first, levels[l].second);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(ibftk::cert_digest_kernel, dim3((rows + 63) / 64), dim3(64), 0, c->stream, d_wire, d_nodes, (const wire::row_info *)d_rows,
+                     rows, d_digest, d_prop, d_pre);
+  HIPCHK(c, hipGetLastError());
+  uint64_t *d_hash_mask = (uint64_t *)c->d_cert_masks.p, *d_self_mask = d_hash_mask + mask_words(m);
+  hipLaunchKernelGGL(ibftk::cert_compare_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const wire::node_info *)d_nodes,
+                     (const wire::row_info *)d_rows, (const uint8_t *)d_prop, rows, d_hash_mask, d_self_mask, (uint8_t *)c->d_class.p);
+  HIPCHK(c, hipGetLastError());
+  c->ev_used = 0;
+  // the digest column holds keccak256(PayloadNoSig) of every row: the seal-style pass; rows that are not judged here are pre-flagged
+  if ((rc = enqueue_recover(c, rows, true, 0, false))) return rc;
+  if ((rc = enqueue_tally(c, rows))) return rc;
+  const size_t mw = (size_t)mask_words(rows);
+  if (out_nodes) HIPCHK(c, hipMemcpyAsync(out_nodes, d_nodes, (size_t)rows * sizeof(wire::node_info), hipMemcpyDeviceToHost, c->stream));
+  if (out_rows) HIPCHK(c, hipMemcpyAsync(out_rows, d_rows, (size_t)rows * sizeof(wire::row_info), hipMemcpyDeviceToHost, c->stream));
+  if (out_class) HIPCHK(c, hipMemcpyAsync(out_class, c->d_class.p, rows, hipMemcpyDeviceToHost, c->stream));
+  if (out_hash_mask) HIPCHK(c, hipMemcpyAsync(out_hash_mask, d_hash_mask, mw * 8, hipMemcpyDeviceToHost, c->stream));
+  if (out_self_mask) HIPCHK(c, hipMemcpyAsync(out_self_mask, d_self_mask, mw * 8, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = fetch_results(c, rows, out_sender_mask, nullptr, true))) return rc;
+  *out_n_rows = rows;
   return IBFT_OK;
 }
 

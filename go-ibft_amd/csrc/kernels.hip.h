@@ -896,6 +896,210 @@ __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, c
   if (host_row_class) host_row_class[row] = cls;
 }
 
+// ---- §8f rank 2 from the transport's bytes: the certificate tree (wire_dev.h, second half) -------------------------
+// ibft_verify_certificates_wire: PREPREPARE / ROUND_CHANGE messages carry messages (RoundChangeCertificate,
+// PreparedCertificate: core/ibft.go:470-551, 683-788 verify every one of them).  Level by level, rows [lo, hi) of one
+// level at a time:
+//   cert_parse_kernel       a lane per message: the DEEP walk of its own fields, sender columns, digest of a message
+//                           that has nothing below it; where its nested messages lie goes to cert_span
+//   cert_walk_kernel<false> a wavefront per message with a certificate: counts (and checks) the nested messages
+//   cert_scan_kernel        exclusive scan of the counts: every row's children become a contiguous row range of the next
+//                           level, in order; the total goes to the host, which sizes the next level's launches
+//   cert_walk_kernel<true>  the same walk again, writing the child rows
+// then, bottom-up, cert_propagate_kernel (a message with a non-canonical message below it is not canonical either),
+// cert_digest_kernel (PayloadNoSig digests of the messages that carry certificates, proposal hashes),
+// cert_compare_kernel (hash bits), and ONE verdict launch over all rows of all levels.
+constexpr uint32_t CERT_WIN_BYTES = 16 * 1024;
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  for (int o = 32; o; o >>= 1) {
+    const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = w < v ? w : v;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  for (int o = 32; o; o >>= 1) {
+    const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = w > v ? w : v;
+  }
+  return v;
+}
+__global__ void __launch_bounds__(64) cert_parse_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
+                                                        uint32_t lo, uint32_t hi, wire::row_info *__restrict__ rows,
+                                                        uint2 *__restrict__ cert_span, uint8_t *__restrict__ digest32,
+                                                        uint8_t *__restrict__ sig65, uint8_t *__restrict__ from20,
+                                                        uint8_t *__restrict__ pre_flags) {
+  __shared__ __attribute__((aligned(16))) uint8_t lbuf[WIRE_LDS_BYTES + 16];
+  const uint32_t lane = threadIdx.x, row = lo + blockIdx.x * 64u + lane;
+  const bool live = row < hi;
+  wire::node_info nd{};
+  if (live) nd = nodes[row];
+  // the 64 messages of a wavefront are usually neighbours in the buffer (children of one certificate): staged in LDS
+  // with coalesced dword loads when they span little enough, like wire_parse_kernel
+  const uint32_t b0 = wave_min_u32(live ? nd.off : 0xFFFFFFFFu) & ~3u, b1 = wave_max_u32(live ? nd.off + nd.len : 0u);
+  const bool staged = b1 >= b0 && b1 - b0 <= WIRE_LDS_BYTES;  // wave-uniform
+  if (staged) {
+    for (uint32_t i = 4u * lane; b0 + i < b1; i += 256u)
+      *reinterpret_cast<uint32_t *>(lbuf + i) = *reinterpret_cast<const uint32_t *>(wire_bytes + b0 + i);
+    __syncthreads();
+  }
+  if (!live) return;
+  const uint8_t *m = staged ? lbuf + (nd.off - b0) : wire_bytes + nd.off;
+  uint32_t span[2];
+  wire::process_tree_row(m, nd.len, rows + row, &nd, span, digest32 + 32ull * row, sig65 + 65ull * row, from20 + 20ull * row,
+                         pre_flags + row);
+  nodes[row] = nd;
+  cert_span[row] = make_uint2(span[0], span[1]);
+}
+// bytes [w0, …) of the buffer held in LDS, addressed by their position in the buffer
+struct lds_window {
+  const uint8_t *win;
+  uint32_t w0;
+  __device__ __forceinline__ uint8_t operator[](uint32_t a) const { return win[a - w0]; }
+};
+// A certificate is a run of length-prefixed messages: finding message k needs the lengths of the k − 1 before it, a
+// chain of dependent loads (≈1 µs each from HBM: a PreparedCertificate of 2 731 PREPAREs would take milliseconds).  So a
+// wavefront brings the certificate through LDS in 16 KiB windows (coalesced), lane 0 hops from header to header there,
+// and all lanes write the child rows it found.
+template <bool FILL>
+__global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
+                                                       wire::row_info *__restrict__ rows, const uint2 *__restrict__ cert_span,
+                                                       uint32_t lo, uint32_t hi, uint32_t *__restrict__ child_count) {
+  __shared__ __attribute__((aligned(16))) uint8_t win[CERT_WIN_BYTES + 16];
+  __shared__ uint32_t rec_pos[64], rec_len[64], rec_role[64];
+  __shared__ uint32_t sh_n, sh_pos, sh_last, sh_ok;
+  const uint32_t row = lo + blockIdx.x, lane = threadIdx.x;
+  if (row >= hi) return;
+  const wire::node_info nd = nodes[row];
+  const bool has = rows[row].status == wire::STATUS_OK && (nd.flags & wire::TREE_HAS_CERT);
+  if (!has || (FILL && nd.n_children == 0)) {
+    if (!FILL && lane == 0) child_count[row - lo] = 0;
+    return;
+  }
+  const bool pc = rows[row].payload_kind == wire::KIND_ROUND_CHANGE;
+  const uint2 span = cert_span[row];
+  uint32_t pos = nd.off + span.x, last = 0, count = 0;
+  const uint32_t end = pos + span.y;
+  bool ok = true;
+  while (pos < end && ok) {
+    const uint32_t w0 = pos & ~3u;
+    const uint32_t wend = end - w0 <= CERT_WIN_BYTES ? end : w0 + CERT_WIN_BYTES;
+    for (uint32_t i = 4u * lane; w0 + i < wend; i += 256u)
+      *reinterpret_cast<uint32_t *>(win + i) = *reinterpret_cast<const uint32_t *>(wire_bytes + w0 + i);
+    __syncthreads();
+    if (lane == 0) {
+      const lds_window W{win, w0};
+      uint32_t nrec = 0, p = pos, l = last, good = 1;
+      while (p < wend && nrec < 64u) {
+        if (p + 6u > wend && wend < end) break;  // tag + length prefix (≤ 6 bytes) may cross the window: next window starts here
+        uint32_t len;
+        uint8_t role;
+        if (!wire::cert_child_header(W, end, pc, l, p, len, role)) {
+          good = 0;
+          break;
+        }
+        rec_pos[nrec] = p;
+        rec_len[nrec] = len;
+        rec_role[nrec] = role;
+        nrec++;
+        p += len;  // the message itself is skipped: its own lane walks it on the next level
+      }
+      sh_n = nrec;
+      sh_pos = p;
+      sh_last = l;
+      sh_ok = good;
+    }
+    __syncthreads();
+    const uint32_t nrec = sh_n;
+    ok = sh_ok != 0;
+    if (FILL && lane < nrec) {
+      wire::node_info c{};
+      c.off = rec_pos[lane];
+      c.len = rec_len[lane];
+      c.parent = row;
+      c.ordinal = count + lane;
+      c.level = (uint8_t)(nd.level + 1);
+      c.role = (uint8_t)rec_role[lane];
+      nodes[nd.first_child + count + lane] = c;
+    }
+    count += nrec;
+    pos = sh_pos;
+    last = sh_last;
+    __syncthreads();
+  }
+  if (!FILL && lane == 0) {
+    if (!ok) {  // a malformed wrapper: the whole message goes the stock route, nothing below it is listed
+      rows[row].status = wire::STATUS_NEEDS_HOST;
+      count = 0;
+    }
+    nodes[row].n_children = count;
+    child_count[row - lo] = count;
+  }
+}
+// first_child of rows [lo, hi) = base + exclusive prefix sum of their child counts; the sum → total (device and host)
+__global__ void __launch_bounds__(1024) cert_scan_kernel(const uint32_t *__restrict__ child_count, wire::node_info *__restrict__ nodes,
+                                                         uint32_t lo, uint32_t hi, uint32_t base, uint32_t *__restrict__ total_dev,
+                                                         uint32_t *__restrict__ total_host) {
+  __shared__ uint32_t part[1024];
+  const uint32_t n = hi - lo, t = threadIdx.x, per = (n + 1023u) / 1024u;
+  const uint32_t b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
+  uint32_t sum = 0;
+  for (uint32_t i = b; i < e; i++) sum += child_count[i];
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024u; o <<= 1) {
+    const uint32_t v = t >= o ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = base + part[t] - sum;
+  for (uint32_t i = b; i < e; i++) {
+    nodes[lo + i].first_child = run;
+    run += child_count[i];
+  }
+  if (t == 1023u) {
+    *total_dev = part[1023];
+    if (total_host) *total_host = part[1023];
+  }
+}
+__global__ void cert_propagate_kernel(const wire::node_info *__restrict__ nodes, wire::row_info *__restrict__ rows, uint32_t lo,
+                                      uint32_t hi) {
+  const uint32_t row = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= hi) return;
+  const uint32_t parent = nodes[row].parent;
+  if (rows[row].status != wire::STATUS_OK && parent != wire::NO_PARENT) rows[parent].status = wire::STATUS_NEEDS_HOST;
+}
+__global__ void __launch_bounds__(64) cert_digest_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
+                                                         const wire::row_info *__restrict__ rows, uint32_t n,
+                                                         uint8_t *__restrict__ digest32, uint8_t *__restrict__ prop_digest32,
+                                                         uint8_t *__restrict__ pre_flags) {
+  const uint32_t row = blockIdx.x * 64u + threadIdx.x;
+  if (row >= n) return;
+  wire::node_info nd = nodes[row];
+  const uint8_t before = nd.flags;
+  wire::tree_digest_row(wire_bytes, rows + row, &nd, digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row);
+  if (nd.flags != before) nodes[row].flags = nd.flags;
+}
+// hash / self bits and the routing byte of every row (wire::tree_compare_row), one verdict word per wavefront
+__global__ void __launch_bounds__(256) cert_compare_kernel(const wire::node_info *__restrict__ nodes, const wire::row_info *__restrict__ rows,
+                                                           const uint8_t *__restrict__ prop_digest32, uint32_t n,
+                                                           uint64_t *__restrict__ hash_mask, uint64_t *__restrict__ self_mask,
+                                                           uint8_t *__restrict__ row_class) {
+  const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+  bool hash_bit = false, self_bit = false;
+  if (row < n) {
+    uint8_t cls;
+    wire::tree_compare_row(nodes, rows, prop_digest32, row, hash_bit, self_bit, cls);
+    row_class[row] = cls;
+  }
+  const uint64_t hb = __ballot(hash_bit), sb = __ballot(self_bit);
+  if ((threadIdx.x & 63u) == 0 && row < n) {
+    hash_mask[row >> 6] = hb;
+    self_mask[row >> 6] = sb;
+  }
+}
+
 // ---- a8: weighted quorum tally ------------------------------------------------------------
 // HasQuorum (core/validator_manager.go:77-96): Σ power over the DISTINCT member senders of the valid rows
 // ≥ ⌊2·total/3⌋+1.  Several workgroups (4 096 rows each) walk the verdict words: a validator's power is

@@ -49,6 +49,13 @@ WIRE_ROW = np.dtype([("height", "<u8"), ("round", "<u8"), ("status", "u1"), ("ty
                      ("has_view", "u1"), ("hash_len", "u1"), ("seal_len", "u1"), ("from_len", "u1"), ("sig_len", "u1"),
                      ("from", "u1", 20), ("proposal_hash", "u1", 32), ("pad", "u1", 4)])
 assert WIRE_ROW.itemsize == 80
+# ibft_cert_node_t (include/ibftgpu.h)
+CERT_NODE = np.dtype([("off", "<u4"), ("len", "<u4"), ("parent", "<u4"), ("ordinal", "<u4"), ("first_child", "<u4"),
+                      ("n_children", "<u4"), ("raw_off", "<u4"), ("raw_len", "<u4"), ("proposal_round", "<u8"),
+                      ("cut0", "<u4"), ("cut1", "<u4"), ("level", "u1"), ("role", "u1"), ("flags", "u1"), ("pad", "u1", 5)])
+assert CERT_NODE.itemsize == 56
+CERT_CLASS_NEEDS_HOST, CERT_CLASS_DIGEST_BY_HOST, CERT_CLASS_PROPOSAL_BY_HOST = 1, 2, 4
+CERT_NO_PARENT = 0xFFFFFFFF
 
 
 class GpuUnavailable(RuntimeError):
@@ -142,6 +149,7 @@ def load_library() -> C.CDLL:
     L.ibft_sync.argtypes = [vp]
     L.ibft_verify_senders_wire.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(Tally)]
     L.ibft_wire_stage_seals.argtypes = [vp]
+    L.ibft_verify_certificates_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp, vp]
     L.ibft_set_validators_u256.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.ibft_last_tally_wide.argtypes = [vp, C.POINTER(TallyWide)]
     L.ibft_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -430,6 +438,27 @@ class BatchVerifier:
                   "ibft_verify_messages_wire")
         self._last_class = cls[:n]
         return mask_to_bool(ms, n), mask_to_bool(mv, n), (rows if want_rows else cls[:n]), t
+
+    def verify_certificates_wire(self, wire, off, rows_cap: int | None = None, want_rows: bool = True):
+        """§8f rank 2 from bytes: the whole certificate tree of a batch of raw messages →
+        (n_rows, nodes[CERT_NODE], rows[WIRE_ROW] or None, class u8[n_rows], sender bool[n_rows], hash bool[n_rows],
+        self bool[n_rows]); see include/ibftgpu.h.  Raises RuntimeError (IBFT_E_TOOBIG) when the tree exceeds rows_cap."""
+        wb = _bytes_col(wire)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = len(off) - 1
+        cap = int(rows_cap if rows_cap is not None else self.max_rows)
+        words = (cap + 63) // 64 or 1
+        nodes = np.zeros(max(cap, 1), dtype=CERT_NODE)
+        rows = np.zeros(max(cap, 1), dtype=WIRE_ROW) if want_rows else None
+        cls = np.zeros(max(cap, 1), dtype=np.uint8)
+        ms, mh, mself = (np.zeros(words, dtype=np.uint64) for _ in range(3))
+        n_rows = C.c_size_t(0)
+        self._chk(self._L.ibft_verify_certificates_wire(self._h, _p(wb), _p(off), n, cap, C.byref(n_rows), _p(nodes),
+                                                        _p(rows) if want_rows else None, _p(cls), _p(ms), _p(mh), _p(mself)),
+                  "ibft_verify_certificates_wire")
+        k = int(n_rows.value)
+        return (k, nodes[:k], rows[:k] if want_rows else None, cls[:k], mask_to_bool(ms, k), mask_to_bool(mh, k),
+                mask_to_bool(mself, k))
 
     def wire_stage_seals(self):
         """the COMMIT seals of the last is_valid_validator_wire batch become the resident seal batch"""

@@ -30,6 +30,10 @@
  *                           completely — both signatures of a COMMIT in one verdict launch
  *   ibft_verify_senders_wire, ibft_wire_stage_seals
  *                        <- proto.Unmarshal + PayloadNoSig (messages/proto/helper.go:12-27) + IsValidValidator
+ *   ibft_verify_certificates_wire
+ *                        <- every IsValidValidator / IsValidProposalHash that validateProposal, validPC and
+ *                           handleRoundChangeMessage ask about the messages NESTED in PREPREPARE / ROUND_CHANGE
+ *                           messages (core/ibft.go:470-551, 683-788), from the transport's bytes
  *   ibft_comm_*, ibft_group_*  validator shards over several MI355X, one RCCL all-reduce inside the library
  *   ibft_sign_seals      <- n × Backend.BuildCommitMessage's seal (core/backend.go:12-34), simulators only
  *   ibft_pinned_alloc    page-locked column buffers the device reads itself (one gather launch per call)
@@ -206,7 +210,8 @@ typedef struct {
   uint64_t height, round;    /* View (0 when absent / omitted)                              */
   uint8_t status;            /* IBFT_WIRE_*                                                  */
   uint8_t type;              /* IbftMessage.type                                             */
-  uint8_t payload_kind;      /* oneof member: 0 none, 6 PrepareMessage, 7 CommitMessage      */
+  uint8_t payload_kind;      /* oneof member: 0 none, 6 PrepareMessage, 7 CommitMessage (5 PrePrepareMessage,
+                                8 RoundChangeMessage: ibft_verify_certificates_wire only)    */
   uint8_t has_view;
   uint8_t hash_len;          /* bytes of proposal_hash present (<= 32)                       */
   uint8_t seal_len;          /* bytes of committed_seal present (255 = more)                 */
@@ -341,6 +346,69 @@ int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const ui
                               uint64_t proposal_round, const uint8_t *digest32, uint64_t *out_sender_mask,
                               uint64_t *out_valid_mask, uint8_t *out_class, ibft_wire_row_t *out_rows,
                               ibft_tally_t *tally);
+
+/* ---- SURVEY.md §8f rank 2 from the transport's bytes: certificates --------------------------------------------
+ * A PREPREPARE message carries a RoundChangeCertificate, a ROUND_CHANGE message a PreparedCertificate
+ * (/root/reference/messages/proto/messages.proto:46-57, 73-101): IbftMessages inside IbftMessages.  The reference
+ * verifies every one of them — validateProposal / validPC / handleRoundChangeMessage → GetExtendedRCC
+ * (/root/reference/core/ibft.go:470-551, 683-788, 1162-1231; messages/messages.go:202-245): IsValidValidator on the
+ * envelope of each nested message (PayloadNoSig re-marshalled per message, proto/helper.go:12-27) and
+ * IsValidProposalHash on the hash each one carries — O(N²) signatures per round change, after proto.Unmarshal has
+ * materialised the whole pointer graph.  This call takes the messages AS THE TRANSPORT DELIVERED THEM (row i of the call
+ * is wire[off[i]..off[i+1]), any IbftMessage type) and judges the whole tree on the device:
+ *
+ *   rows      one per IbftMessage of the tree, breadth first: rows [0, n) are the call's messages (level 0), the
+ *             messages nested directly inside level-k rows are level k + 1 — children of row i before children of row
+ *             j > i, a row's children in wire order (PreparedCertificate: proposalMessage first, then prepareMessages;
+ *             RoundChangeCertificate: roundChangeMessages).  *out_n_rows = their number.  Because a decoded message
+ *             lists its nested messages in the same order, the host maps row → *proto.IbftMessage by position.
+ *   out_nodes[row]  where the row lies and what it is to its parent (ibft_cert_node_t), may be NULL
+ *   out_rows[row]   its parsed fields, as ibft_verify_senders_wire reports them; payload_kind 5 / 8 rows carry
+ *                   PrePrepareMessage.proposalHash in proposal_hash.  May be NULL
+ *   out_class[row]  0 = judged here.  IBFT_CERT_CLASS_NEEDS_HOST: the bytes of this message — or of a message below it —
+ *                   are not the canonical encoding (unknown fields, non-minimal varints, …): PayloadNoSig is not
+ *                   "bytes minus the signature field", the sender bit is 0 and the caller decides this message by the stock
+ *                   route (rows below it that are canonical are still judged).  IBFT_CERT_CLASS_DIGEST_BY_HOST: canonical
+ *                   but longer than IBFT_CERT_DIGEST_MAX_BYTES — Keccak is sequential, one lane absorbs ≈14 MB/s — so
+ *                   the sender bit is 0 and the host hashes bytes[0, cut0) ‖ bytes[cut1, len) itself (out_nodes) and asks
+ *                   ibft_verify_seals with that digest.  IBFT_CERT_CLASS_PROPOSAL_BY_HOST: the Proposal this message
+ *                   carries is that long: the self bit of this row and the hash bits of its children are undecided
+ *   out_sender_mask bit row = IsValidValidator(message): its envelope signature recovers to From, From is a validator
+ *   out_hash_mask   bit row = the 32-byte proposal hash this message carries equals keccak(lastPreparedProposal) of the
+ *                   ROUND_CHANGE message whose PreparedCertificate contains it (proposalMatchesCertificate,
+ *                   core/ibft.go:516-551: IsValidProposalHash(proposal, hash) for every message of the certificate); 0 for
+ *                   rows that are not inside a PreparedCertificate
+ *   out_self_mask   bit row = a PREPREPARE payload's proposalHash equals keccak(its own Proposal)
+ *                   (validateProposalCommon, core/ibft.go:640-651)
+ * All masks have ⌈rows_cap/64⌉ words.  The tree must fit rows_cap and the context's max_rows: IBFT_E_TOOBIG otherwise
+ * (no verdicts — split the call or take the stock route).  What stays with the caller is everything that is not
+ * arithmetic: types, views, rounds, proposer and quorum rules over the From / type / view columns.               */
+#define IBFT_CERT_CLASS_NEEDS_HOST 0x01u
+#define IBFT_CERT_CLASS_DIGEST_BY_HOST 0x02u
+#define IBFT_CERT_CLASS_PROPOSAL_BY_HOST 0x04u
+#define IBFT_CERT_DIGEST_MAX_BYTES (1u << 20)
+#define IBFT_CERT_ROLE_ROOT 0u          /* one of the call's n messages                          */
+#define IBFT_CERT_ROLE_PC_PROPOSAL 1u   /* PreparedCertificate.proposalMessage                   */
+#define IBFT_CERT_ROLE_PC_PREPARE 2u    /* PreparedCertificate.prepareMessages[k]                */
+#define IBFT_CERT_ROLE_RCC_MESSAGE 3u   /* RoundChangeCertificate.roundChangeMessages[k]         */
+#define IBFT_CERT_HAS_PROPOSAL 0x01u    /* flags: a Proposal sub-message is present              */
+#define IBFT_CERT_HAS_CERTIFICATE 0x02u /* flags: a certificate wrapper is present               */
+#define IBFT_CERT_NO_PARENT 0xFFFFFFFFu
+typedef struct {
+  uint32_t off, len;                /* the message's bytes in `wire`                                             */
+  uint32_t parent, ordinal;         /* containing row (IBFT_CERT_NO_PARENT for level 0), position among its children */
+  uint32_t first_child, n_children; /* its nested messages are rows [first_child, first_child + n_children)       */
+  uint32_t raw_off, raw_len;        /* Proposal.rawProposal it carries (PREPREPARE: proposal; ROUND_CHANGE:
+                                       lastPreparedProposal), in `wire`                                          */
+  uint64_t proposal_round;          /* Proposal.round                                                            */
+  uint32_t cut0, cut1;              /* its signature field (tag, length, bytes) relative to off                  */
+  uint8_t level, role, flags;       /* IBFT_CERT_ROLE_*, IBFT_CERT_HAS_* (the class bits 0x04 / 0x08 mirror out_class) */
+  uint8_t pad[5];
+} ibft_cert_node_t;
+int ibft_verify_certificates_wire(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, size_t rows_cap,
+                                  size_t *out_n_rows, ibft_cert_node_t *out_nodes, ibft_wire_row_t *out_rows,
+                                  uint8_t *out_class, uint64_t *out_sender_mask, uint64_t *out_hash_mask,
+                                  uint64_t *out_self_mask);
 
 /* ---- f4: the signing side, for SIMULATORS ----------------------------------
  * Replaces, for a process that plays n validators at once, the n calls of Backend.BuildCommitMessage
