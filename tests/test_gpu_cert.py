@@ -54,7 +54,7 @@ def test_longer_than_the_device_hashes(gpu_verifier):
 
 def test_round_change_certificate_n256(gpu_verifier):
     """BASELINE-style worst case at N = 256: a PREPREPARE whose RoundChangeCertificate holds 171 ROUND_CHANGE messages, each
-    with a PreparedCertificate of 1 + 170 messages — 29 584 nested signatures from one 3.6 MB message, one call; then the
+    with a PreparedCertificate of 1 + 170 messages — 29 412 nested signatures from one 4.1 MB message, one call; then the
     same with a fifth of the nested PREPAREs corrupted."""
     n = 256
     r = W.make_round(n, 815, height=5, round_=1, raw_len=256)
@@ -68,7 +68,8 @@ def test_round_change_certificate_n256(gpu_verifier):
     rcs = [CC.round_change(r, i, 5, 2, wire.Proposal(r.raw, 1), pcb) for i in range(q)]
     top = CC.preprepare(r, 2, 5, 2, rcc=wire.round_change_certificate(rcs))
     exp = run(gpu_verifier, r, "rcc n=256", [top.encode()])
-    assert exp.n_rows == 1 + q + q * q and all(exp.sender_ok) and all(exp.hash_bit[1 + q:]) and exp.self_bit[0]
+    assert exp.n_rows == 1 + q + q * q and all(exp.sender_ok[1:]) and all(exp.hash_bit[1 + q:]) and exp.self_bit[0]
+    assert exp.cls[0] == WC.CLASS_DIGEST_BY_HOST and not any(exp.cls[1:])  # the 4 MB envelope itself: its digest is the host's
     # Byzantine: every fifth nested PREPARE of every certificate is forged, for another proposal, or from a stranger
     outsider = b"\x07" * 32
     bad = []
