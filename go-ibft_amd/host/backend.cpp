@@ -207,6 +207,118 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
   return true;
 }
 
+// the messages nested directly inside m, in the order the device lists them (wire order): the RoundChangeCertificate's
+// messages of a PREPREPARE payload; proposalMessage, then prepareMessages, of a ROUND_CHANGE payload's PreparedCertificate
+static void nested_messages(const IbftMessage &m, std::vector<MsgPtr> &out) {
+  out.clear();
+  if (m.kind == PayloadKind::PREPREPARE && m.preprepare.certificate) {
+    out = m.preprepare.certificate->round_change_messages;
+  } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change.latest_prepared_certificate) {
+    const PreparedCertificate &pc = *m.round_change.latest_prepared_certificate;
+    if (pc.proposal_message) out.push_back(pc.proposal_message);
+    out.insert(out.end(), pc.prepare_messages.begin(), pc.prepare_messages.end());
+  }
+}
+// the proposal hash a message carries, by payload kind (what the device reports in ibft_wire_row_t.proposal_hash)
+static const bytes *carried_hash(const IbftMessage &m) {
+  switch (m.kind) {
+    case PayloadKind::PREPREPARE: return &m.preprepare.proposal_hash;
+    case PayloadKind::PREPARE: return &m.prepare.proposal_hash;
+    case PayloadKind::COMMIT: return &m.commit.proposal_hash;
+    default: return nullptr;
+  }
+}
+
+bool GpuBackend::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) {
+  out = CertVerdicts();
+  if (n == 0) return true;
+  const size_t cap = cert_rows_cap, words = (cap + 63) / 64;
+  out.nodes.resize(cap);
+  out.cls.assign(cap, 0);
+  std::vector<uint64_t> ms(words, 0), mh(words, 0), mself(words, 0);
+  size_t rows = 0;
+  last_rc = ibft_verify_certificates_wire(ctx_, wire, off, n, cap, &rows, out.nodes.data(), nullptr, out.cls.data(), ms.data(),
+                                          mh.data(), mself.data());
+  if (last_rc != IBFT_OK) return false;  // IBFT_E_TOOBIG included: the caller's stock route handles the batch
+  out.n_rows = rows;
+  out.nodes.resize(rows);
+  out.cls.resize(rows);
+  unpack_mask(ms, rows, out.sender);
+  unpack_mask(mh, rows, out.hash);
+  unpack_mask(mself, rows, out.self);
+  return true;
+}
+
+bool LoopBatch::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) {
+  out = CertVerdicts();
+  if (fail_certs) return false;
+  calls++;
+  cert_calls++;
+  struct Item {
+    MsgPtr m;  // null: did not decode
+    const IbftMessage *parent;
+  };
+  std::vector<Item> items;
+  for (size_t i = 0; i < n; i++) {
+    auto m = std::make_shared<IbftMessage>();
+    const bool ok = decode(wire + off[i], off[i + 1] - off[i], *m);
+    ibft_cert_node_t nd{};
+    nd.off = off[i];
+    nd.len = off[i + 1] - off[i];
+    nd.parent = IBFT_CERT_NO_PARENT;
+    nd.ordinal = (uint32_t)i;
+    out.nodes.push_back(nd);
+    items.push_back(Item{ok ? m : nullptr, nullptr});
+  }
+  std::vector<MsgPtr> kids;
+  for (size_t lo = 0, hi = items.size(); lo < hi;) {  // one level per turn
+    size_t base = hi;
+    for (size_t r = lo; r < hi; r++) {
+      out.nodes[r].first_child = (uint32_t)base;
+      if (!items[r].m) continue;
+      nested_messages(*items[r].m, kids);
+      out.nodes[r].n_children = (uint32_t)kids.size();
+      const bool pc = items[r].m->kind == PayloadKind::ROUND_CHANGE;
+      for (size_t k = 0; k < kids.size(); k++) {
+        ibft_cert_node_t c{};
+        c.parent = (uint32_t)r;
+        c.ordinal = (uint32_t)k;
+        c.level = (uint8_t)(out.nodes[r].level + 1);
+        c.role = (uint8_t)(!pc ? IBFT_CERT_ROLE_RCC_MESSAGE
+                               : (k == 0 && items[r].m->round_change.latest_prepared_certificate->proposal_message
+                                      ? IBFT_CERT_ROLE_PC_PROPOSAL
+                                      : IBFT_CERT_ROLE_PC_PREPARE));
+        out.nodes.push_back(c);
+        items.push_back(Item{kids[k], items[r].m.get()});
+      }
+      base += kids.size();
+    }
+    lo = hi;
+    hi = items.size();
+  }
+  const size_t rows = items.size();
+  out.n_rows = rows;
+  out.cls.assign(rows, 0);
+  out.sender.assign(rows, 0);
+  out.hash.assign(rows, 0);
+  out.self.assign(rows, 0);
+  for (size_t r = 0; r < rows; r++) {
+    if (!items[r].m) {
+      out.cls[r] = IBFT_CERT_CLASS_NEEDS_HOST;
+      continue;
+    }
+    const IbftMessage &m = *items[r].m;
+    out.sender[r] = v_->IsValidValidator(m);
+    const bytes *h = carried_hash(m);
+    const IbftMessage *p = items[r].parent;
+    if (h && p && p->kind == PayloadKind::ROUND_CHANGE && p->round_change.last_prepared_proposal)
+      out.hash[r] = v_->IsValidProposalHash(&*p->round_change.last_prepared_proposal, h);
+    if (m.kind == PayloadKind::PREPREPARE && m.preprepare.proposal)
+      out.self[r] = v_->IsValidProposalHash(&*m.preprepare.proposal, &m.preprepare.proposal_hash);
+  }
+  return true;
+}
+
 bool LoopBatch::VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
   if (fail_hashes) return false;
   calls++;
@@ -303,6 +415,79 @@ void HotPath::PruneVerdictCache(uint64_t below_height) {
     const IbftMessage &m = *it->second.keep;
     it = (!m.view || m.view->height < below_height) ? closure_cache_.erase(it) : std::next(it);
   }
+  for (auto it = cert_roots_.begin(); it != cert_roots_.end();) {
+    if (it->second.height >= below_height) {
+      ++it;
+      continue;
+    }
+    for (const IbftMessage *k : it->second.senders) cert_sender_.erase(k);
+    for (const auto &k : it->second.hashes) cert_hash_.erase(k);
+    it = cert_roots_.erase(it);
+  }
+}
+
+// The verdicts of one root row of a certificate call and of everything below it go into the arrival-time tables,
+// matched to the decoded objects by position: a decoded message lists its nested messages in the order the device lists
+// them.  A subtree whose row count differs from the decoded count (the device refused the wrapper as non-canonical) is left
+// to the stock route.
+void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root) {
+  CertRoot &cr = cert_roots_[root.get()];
+  cr.keep = root;
+  cr.height = root->view ? root->view->height : 0;
+  std::vector<std::pair<size_t, MsgPtr>> todo{{row, root}};
+  std::vector<MsgPtr> kids;
+  while (!todo.empty()) {
+    const size_t r = todo.back().first;
+    const MsgPtr m = todo.back().second;
+    todo.pop_back();
+    const uint8_t cls = cv.cls[r];
+    // a PREPREPARE's own (proposal, proposalHash): validateProposalCommon's IsValidProposalHash
+    if (!(cls & (IBFT_CERT_CLASS_NEEDS_HOST | IBFT_CERT_CLASS_PROPOSAL_BY_HOST))) {
+      const Proposal *own = extract_proposal(*m);
+      const bytes *oh = extract_proposal_hash(*m);
+      if (own && oh) {
+        cert_hash_[{own, oh}] = cv.self[r] != 0;
+        cr.hashes.push_back({own, oh});
+      }
+    }
+    nested_messages(*m, kids);
+    const ibft_cert_node_t &nd = cv.nodes[r];
+    if (nd.n_children != kids.size() || (size_t)nd.first_child + nd.n_children > cv.n_rows) continue;
+    const Proposal *last = extract_last_prepared_proposal(*m);
+    const bool hashes_decided = last && !(cls & (IBFT_CERT_CLASS_NEEDS_HOST | IBFT_CERT_CLASS_PROPOSAL_BY_HOST));
+    for (size_t k = 0; k < kids.size(); k++) {
+      const size_t c = nd.first_child + k;
+      if (!kids[k]) continue;
+      if (cv.cls[c] == 0) {
+        cert_sender_[kids[k].get()] = cv.sender[c] != 0;
+        cr.senders.push_back(kids[k].get());
+        cert_rows++;
+      }
+      if (hashes_decided && !(cv.cls[c] & IBFT_CERT_CLASS_NEEDS_HOST)) {
+        // the very pointers proposalMatchesCertificate will ask about (nil when type and payload disagree: not cached)
+        const bytes *h = cv.nodes[c].role == IBFT_CERT_ROLE_PC_PROPOSAL ? extract_proposal_hash(*kids[k]) : extract_prepare_hash(*kids[k]);
+        if (h) {
+          cert_hash_[{last, h}] = cv.hash[c] != 0;
+          cr.hashes.push_back({last, h});
+        }
+      }
+      todo.push_back({c, kids[k]});
+    }
+  }
+}
+
+bool HotPath::lookupHashVerdict(const Proposal *proposal, const bytes *hash, bool &ok) const {
+  auto it = hash_verdict_.find({proposal, hash});
+  if (it != hash_verdict_.end()) {
+    ok = it->second;
+    return true;
+  }
+  auto jt = cert_hash_.find({proposal, hash});
+  if (jt != cert_hash_.end()) {
+    ok = jt->second;
+    return true;
+  }
+  return false;
 }
 
 // IBFT.AddMessage with IsValidValidator already answered (by the device batch or the cache)
@@ -356,10 +541,43 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
     auto hit = verdict_cache_.find(raw[i]);
     if (hit != verdict_cache_.end()) {
       verdict[i] = hit->second.ok ? 1 : 0;
+      if (hit->second.carrier) msgs[i] = hit->second.carrier;  // the object the certificate tables know
       if (hit->second.closure >= 0 && hit->second.closure_epoch == closure_epoch_) closure[i] = hit->second.closure;
       st.cache_hits++;
     } else if (first_in_batch.emplace(raw[i], i).second) {
       ask.push_back(i);
+    }
+  }
+  const std::vector<size_t> asked = ask;  // every distinct undecided message of the batch (cached at the end)
+  // (0) messages that carry certificates: the whole tree — their own envelope and every message nested in them — in ONE
+  // device call, from the bytes as they arrived
+  if (use_batch && batch && use_certs) {
+    std::vector<size_t> carriers;
+    for (size_t i : ask)
+      if (msgs[i]->kind == PayloadKind::PREPREPARE || msgs[i]->kind == PayloadKind::ROUND_CHANGE) carriers.push_back(i);
+    if (!carriers.empty()) {
+      bytes wire;
+      std::vector<uint32_t> off{0};
+      for (size_t i : carriers) {
+        wire += raw[i];
+        off.push_back((uint32_t)wire.size());
+      }
+      CertVerdicts cv;
+      if (batch->VerifyCertificatesWire((const uint8_t *)wire.data(), off.data(), carriers.size(), cv) && cv.n_rows >= carriers.size()) {
+        st.device_calls++;
+        cert_calls++;
+        for (size_t j = 0; j < carriers.size(); j++) {
+          if (cv.cls[j] == 0) {
+            verdict[carriers[j]] = cv.sender[j] ? 1 : 0;
+            cert_rows++;
+          }
+          noteCertificateTree(cv, j, msgs[carriers[j]]);
+        }
+        std::vector<size_t> left;
+        for (size_t i : ask)
+          if (verdict[i] < 0) left.push_back(i);
+        ask.swap(left);
+      }
     }
   }
   // (1) messages of the current view with the proposal at hand: judged completely, one set call per type
@@ -449,18 +667,21 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
     }
     for (size_t j = 0; j < rest.size(); j++) verdict[rest[j]] = v[j] ? 1 : 0;
   }
-  st.device_rows = ask.size();
-  for (size_t i : ask) {
+  st.device_rows = asked.size();
+  for (size_t i : asked) {
     CachedVerdict cv{verdict[i] == 1, msgs[i]->view ? msgs[i]->view->height : 0};
     cv.closure = closure[i];
     cv.closure_epoch = closure_epoch_;
+    if (cert_roots_.count(msgs[i].get())) cv.carrier = msgs[i];
     verdict_cache_[raw[i]] = cv;
   }
   for (size_t i = 0; i < raw.size(); i++) {
     if (!msgs[i]) continue;
     if (verdict[i] < 0) {  // a repeat inside this batch
-      verdict[i] = verdict[first_in_batch[raw[i]]];
-      closure[i] = closure[first_in_batch[raw[i]]];
+      const size_t first = first_in_batch[raw[i]];
+      verdict[i] = verdict[first];
+      closure[i] = closure[first];
+      if (cert_roots_.count(msgs[first].get())) msgs[i] = msgs[first];
     }
     if (closure[i] >= 0 && verdict[i] == 1) closure_cache_[msgs[i].get()] = ClosureVerdict{msgs[i], closure[i] == 1};
     results[i] = addWithVerdict(msgs[i], verdict[i] == 1);
@@ -593,12 +814,22 @@ namespace ibft {
 bool HotPath::isValidValidatorCached(const IbftMessage &m) {
   auto it = sender_verdict_.find(&m);
   if (it != sender_verdict_.end()) return it->second;
+  auto jt = cert_sender_.find(&m);  // judged when the message that carries it arrived (IngestWire, use_certs)
+  if (jt != cert_sender_.end()) return jt->second;
   return verifier->IsValidValidator(m);
 }
 
-void HotPath::prefetchSenders(const std::vector<const IbftMessage *> &msgs) {
+void HotPath::prefetchSenders(const std::vector<const IbftMessage *> &all) {
   sender_verdict_.clear();
   last_cert_senders = 0;
+  cert_hits = 0;
+  std::vector<const IbftMessage *> msgs;  // what the arrival-time tables cannot answer
+  for (const IbftMessage *m : all) {
+    if (cert_sender_.count(m))
+      cert_hits++;
+    else
+      msgs.push_back(m);
+  }
   if (!(use_batch && batch) || msgs.empty()) return;
   std::vector<MsgPtr> owned;
   owned.reserve(msgs.size());
@@ -655,14 +886,14 @@ bool HotPath::proposalMatchesCertificate(const Proposal *proposal, const Prepare
   // ExtractProposalHash on a nil message would panic in the reference; treat as a nil hash
   hashes.push_back(certificate->proposal_message ? extract_proposal_hash(*certificate->proposal_message) : nullptr);
   for (auto &m : certificate->prepare_messages) hashes.push_back(m ? extract_prepare_hash(*m) : nullptr);
-  if (!hash_verdict_.empty()) {  // answered by handleRoundChangeMessage's pre-pass
-    bool all_known = true;
-    for (const bytes *h : hashes) all_known = all_known && hash_verdict_.count({proposal, h}) != 0;
-    if (all_known) {
-      for (const bytes *h : hashes)
-        if (!hash_verdict_[{proposal, h}]) return false;
-      return true;
+  if (!hash_verdict_.empty() || !cert_hash_.empty()) {  // answered by handleRoundChangeMessage's pre-pass, or on arrival
+    bool all_known = true, all_ok = true;
+    for (const bytes *h : hashes) {
+      bool ok = false;
+      all_known = all_known && lookupHashVerdict(proposal, h, ok);
+      all_ok = all_ok && ok;
     }
+    if (all_known) return all_ok;
   }
   last_cert_hashes = 0;
   if (use_batch && batch && proposal) {
@@ -696,7 +927,7 @@ bool HotPath::validateProposalCommon(const IbftMessage &msg, const View &view) {
   if (!proposal) return false;  // the reference dereferences it; a nil proposal cannot be valid
   if (proposal->round != view.round) return false;
   if (!verifier->IsProposer(msg.from, view.height, view.round)) return false;
-  if (!verifier->IsValidProposalHash(proposal, proposalHash)) return false;
+  if (!isValidProposalHashCached(proposal, proposalHash)) return false;
   return verifier->IsValidProposal(proposal->raw_proposal);
 }
 
@@ -705,6 +936,13 @@ bool HotPath::validateProposal0(const IbftMessage &msg, const View &view) {
   if (!validateProposalCommon(msg, view)) return false;
   if (verifier->IsProposer(verifier->ID(), view.height, view.round)) return false;
   return true;
+}
+
+MsgPtr HotPath::handlePrePrepare(const View &view) {
+  std::vector<MsgPtr> msgs = messages.GetValidMessages(view, PREPREPARE, [&](const IbftMessage &m) {
+    return view.round == 0 ? validateProposal0(m, view) : validateProposal(m, view);
+  });
+  return msgs.empty() ? nullptr : msgs[0];
 }
 
 bool HotPath::validateProposal(const IbftMessage &msg, const View &view) {
@@ -767,8 +1005,8 @@ bool HotPath::validateProposal(const IbftMessage &msg, const View &view) {
 namespace ibft {
 
 bool HotPath::isValidProposalHashCached(const Proposal *proposal, const bytes *hash) {
-  auto it = hash_verdict_.find({proposal, hash});
-  if (it != hash_verdict_.end()) return it->second;
+  bool ok = false;
+  if (lookupHashVerdict(proposal, hash, ok)) return ok;
   return verifier->IsValidProposalHash(proposal, hash);
 }
 
@@ -789,6 +1027,12 @@ void HotPath::prefetchCertificateHashes(const std::vector<MsgPtr> &rcs) {
     const Proposal *proposal = extract_last_prepared_proposal(*rc);
     const PreparedCertificate *cert = extract_latest_pc(*rc);
     if (!proposal || !cert) continue;  // proposalMatchesCertificate decides these without the backend
+    {  // everything about this certificate already settled when the message arrived?
+      bool known = true, ok = false;
+      known = lookupHashVerdict(proposal, cert->proposal_message ? extract_proposal_hash(*cert->proposal_message) : nullptr, ok);
+      for (auto &m : cert->prepare_messages) known = known && lookupHashVerdict(proposal, m ? extract_prepare_hash(*m) : nullptr, ok);
+      if (known) continue;
+    }
     Group &g = groups[{proposal->raw_proposal, proposal->round}];
     if (g.keys.empty()) g.rep = proposal;
     auto push = [&](const bytes *h) {
@@ -836,7 +1080,7 @@ std::vector<MsgPtr> HotPath::handleRoundChangeMessage(const View &view) {
       std::vector<const IbftMessage *> need;
       for (auto &rc : all) collect_pc(extract_latest_pc(*rc), need);
       prefetchSenders(need);
-      if (!need.empty() && sender_verdict_.empty()) fallbacks++;
+      if (cert_hits < need.size() && sender_verdict_.empty()) fallbacks++;  // something was asked and the batch failed
       prefetchCertificateHashes(all);
     };
   else

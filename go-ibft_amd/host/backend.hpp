@@ -30,6 +30,14 @@ struct Verifier {
   virtual bytes ID() { return bytes(); }
 };
 
+// rows of a certificate tree (ibft_verify_certificates_wire): nodes[row] says where a row's nested messages are
+// (first_child, n_children, role); cls / sender / hash / self are one byte per row
+struct CertVerdicts {
+  size_t n_rows = 0;
+  std::vector<ibft_cert_node_t> nodes;
+  std::vector<uint8_t> cls, sender, hash, self;
+};
+
 struct BatchVerifier {
   virtual ~BatchVerifier() = default;
   // verdict[i] == what handlePrepare's closure would return for msgs[i] (ibft.go:856-862)
@@ -45,6 +53,14 @@ struct BatchVerifier {
   // predicates are pure, so a message can be judged completely when it arrives.  false = not offered / device unavailable.
   virtual bool VerifyMessageSet(const Proposal * /*proposal*/, MessageType /*type*/, const std::vector<MsgPtr> & /*msgs*/,
                                 std::vector<uint8_t> & /*sender*/, std::vector<uint8_t> & /*closure*/) {
+    return false;
+  }
+  // §8f rank 2 from the transport's bytes (include/ibftgpu.h: ibft_verify_certificates_wire): n raw messages of any type;
+  // every IbftMessage nested in them — RoundChangeCertificate, PreparedCertificate, to any depth — becomes a row, breadth
+  // first, with its IsValidValidator verdict, the proposal-hash bits of proposalMatchesCertificate / validateProposalCommon
+  // and a class byte (0 = judged; otherwise the stock route decides that message).  false = not offered / device
+  // unavailable / tree too large.
+  virtual bool VerifyCertificatesWire(const uint8_t * /*wire*/, const uint32_t * /*off*/, size_t /*n*/, CertVerdicts & /*out*/) {
     return false;
   }
 };
@@ -91,6 +107,8 @@ class GpuBackend : public BatchVerifier {
   bool VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
                           const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
                           std::vector<uint8_t> &judged);
+  bool VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) override;
+  size_t cert_rows_cap = 65536;  // rows one certificate call may expand to (the context's max_rows bounds it too)
   int last_rc = 0;
 
  private:
@@ -108,9 +126,12 @@ class LoopBatch : public BatchVerifier {
   bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifyMessageSet(const Proposal *, MessageType, const std::vector<MsgPtr> &, std::vector<uint8_t> &,
                         std::vector<uint8_t> &) override;
-  bool fail_hashes = false, fail_seals = false, fail_senders = false, fail_sets = false;
+  // decodes the messages and asks the per-message Verifier about every nested message, in the row order of the device
+  bool VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) override;
+  bool fail_hashes = false, fail_seals = false, fail_senders = false, fail_sets = false, fail_certs = false;
   size_t calls = 0;      // batch calls answered
   size_t set_calls = 0;  // of which message-set calls
+  size_t cert_calls = 0; // of which certificate-tree calls
 
  private:
   Verifier *v_;
@@ -145,12 +166,18 @@ class HotPath {
     quorumIndex.Invalidate();
     verdict_cache_.clear();
     closure_cache_.clear();
+    cert_roots_.clear();
+    cert_sender_.clear();
+    cert_hash_.clear();
   }
   QuorumIndex quorumIndex;
   bool isAcceptableMessage(const IbftMessage &m);
   bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
   bool handlePrepare(const View &view);
   bool handleCommit(const View &view);
+  // handlePrePrepare (core/ibft.go:792-813): the first stored PREPREPARE of the view that validateProposal0 (round 0) /
+  // validateProposal accepts; nil = none
+  MsgPtr handlePrePrepare(const View &view);
   // handleRoundChangeMessage (core/ibft.go:470-512): the extended RCC for `view`, empty = nil.  With use_batch the
   // signatures of every prepared certificate carried by every stored ROUND-CHANGE message of the height and all
   // their proposal-hash checks (grouped by the proposal they refer to) are answered from ONE sender batch and one
@@ -174,6 +201,15 @@ class HotPath {
   };
   bool use_sets = true;
   size_t closure_hits = 0;  // messages of the last handlePrepare / handleCommit whose closure verdict was already known
+  // With use_certs (default) the PREPREPARE / ROUND_CHANGE messages of a micro-batch go to the device as they arrived
+  // (VerifyCertificatesWire): their own IsValidValidator AND every IsValidValidator / IsValidProposalHash that
+  // validateProposal, validPC and handleRoundChangeMessage will later ask about the messages nested in them are settled
+  // in that one call — no PayloadNoSig re-marshal of nested messages on the host — and wait in tables keyed by the
+  // decoded (stored) message objects, which a decoded message lists in the device's row order.  The certificate walks
+  // then send the device only what the tables cannot answer (normally nothing).
+  bool use_certs = true;
+  size_t cert_calls = 0, cert_rows = 0;  // certificate-tree calls made by IngestWire, rows they judged
+  size_t cert_hits = 0;  // sender verdicts the last certificate walk took from the arrival-time tables
   bool IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats = nullptr);
   // IBFT.AddMessage with IsValidValidator already answered (AddMessageFast when the quorum index is enabled)
   int addWithVerdict(MsgPtr m, bool sender_ok);
@@ -205,6 +241,8 @@ class HotPath {
     uint64_t height;
     int closure = -1;            // −1 unknown, else the handle* closure's verdict …
     uint64_t closure_epoch = 0;  // … against the proposal of this epoch
+    MsgPtr carrier;              // a message whose nested messages have verdicts in the arrival-time tables: a re-delivery of the
+                                 // same bytes is answered with THIS object, so that the tables keep applying to what is stored
   };
   // closure verdicts by stored message (the entry keeps the message alive, so its address cannot be reused)
   struct ClosureVerdict {
@@ -218,6 +256,19 @@ class HotPath {
   // the handle* walks: table hits first, one batch call for the rest, per-message closure when that fails
   std::vector<uint8_t> closureVerdicts(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &all);
   std::map<bytes, CachedVerdict> verdict_cache_;
+  // arrival-time verdicts about nested messages (use_certs): by identity of the decoded objects, which the root entry
+  // keeps alive (an address cannot be reused while its verdict is in the table)
+  struct CertRoot {
+    MsgPtr keep;
+    uint64_t height = 0;
+    std::vector<const IbftMessage *> senders;
+    std::vector<std::pair<const Proposal *, const bytes *>> hashes;
+  };
+  std::map<const IbftMessage *, CertRoot> cert_roots_;
+  std::map<const IbftMessage *, bool> cert_sender_;
+  std::map<std::pair<const Proposal *, const bytes *>, bool> cert_hash_;
+  void noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root);
+  bool lookupHashVerdict(const Proposal *proposal, const bytes *hash, bool &ok) const;
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);
 

@@ -321,6 +321,18 @@ int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_
   return 0;
 }
 void ibft_host_use_sets(ibft_host *h, int on) { h->hp.use_sets = on != 0; }
+void ibft_host_use_certs(ibft_host *h, int on) { h->hp.use_certs = on != 0; }
+void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits) {
+  if (calls) *calls = h->hp.cert_calls;
+  if (rows) *rows = h->hp.cert_rows;
+  if (hits) *hits = h->hp.cert_hits;
+}
+size_t ibft_host_loop_batch_cert_calls(ibft_host *h) { return h->loop ? h->loop->cert_calls : 0; }
+int ibft_host_handle_preprepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *msg) {
+  MsgPtr m = h->hp.handlePrePrepare(View{height, round, {}});
+  if (msg) msgs_to_buf(m ? std::vector<MsgPtr>{m} : std::vector<MsgPtr>{}, msg);
+  return m ? 1 : 0;
+}
 size_t ibft_host_last_set_rows(ibft_host *h) { return h->last_set_rows; }
 size_t ibft_host_closure_hits(ibft_host *h) { return h->hp.closure_hits; }
 size_t ibft_host_loop_batch_set_calls(ibft_host *h) { return h->loop ? h->loop->set_calls : 0; }
@@ -331,6 +343,7 @@ void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
   h->loop->fail_seals = (fail_mask & 2) != 0;
   h->loop->fail_senders = (fail_mask & 4) != 0;
   h->loop->fail_sets = (fail_mask & 8) != 0;
+  h->loop->fail_certs = (fail_mask & 16) != 0;
   h->hp.batch = h->loop.get();
 }
 size_t ibft_host_loop_batch_calls(ibft_host *h) { return h->loop ? h->loop->calls : 0; }

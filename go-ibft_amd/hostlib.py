@@ -105,8 +105,12 @@ def lib() -> C.CDLL:
         L.ibft_host_loop_batch_calls.argtypes = [vp]; L.ibft_host_loop_batch_calls.restype = C.c_size_t
         L.ibft_host_fallbacks.argtypes = [vp]; L.ibft_host_fallbacks.restype = C.c_size_t
         L.ibft_host_use_sets.argtypes = [vp, C.c_int]; L.ibft_host_use_sets.restype = None
-        for nm in ('ibft_host_last_set_rows', 'ibft_host_closure_hits', 'ibft_host_loop_batch_set_calls'):
+        for nm in ('ibft_host_last_set_rows', 'ibft_host_closure_hits', 'ibft_host_loop_batch_set_calls',
+                   'ibft_host_loop_batch_cert_calls'):
             getattr(L, nm).argtypes = [vp]; getattr(L, nm).restype = C.c_size_t
+        L.ibft_host_use_certs.argtypes = [vp, C.c_int]; L.ibft_host_use_certs.restype = None
+        L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
+        L.ibft_host_handle_preprepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         _lib = L
     return _lib
 
@@ -351,6 +355,25 @@ class Host:
         if rc != 0:
             raise RuntimeError(f"ibft_host_ingest_wire rc={rc}")
         return [x - 256 if x > 127 else x for x in res.raw[:len(wires)]], a.value, b.value, c.value
+
+    def use_certs(self, on: bool):
+        self.L.ibft_host_use_certs(self.h, 1 if on else 0)
+
+    def cert_stats(self):
+        """(certificate calls made by ingest, rows they judged, sender verdicts the last certificate walk took from the tables)"""
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self.L.ibft_host_cert_stats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def loop_batch_cert_calls(self) -> int:
+        return self.L.ibft_host_loop_batch_cert_calls(self.h)
+
+    def handle_preprepare(self, height, round_):
+        """handlePrePrepare → the accepted PREPREPARE's wire bytes, or None"""
+        b = Buf()
+        q = self.L.ibft_host_handle_preprepare(self.h, height, round_, C.byref(b))
+        out = unpack(_take(b))
+        return out[0] if q and out else None
 
     def use_sets(self, on: bool):
         self.L.ibft_host_use_sets(self.h, 1 if on else 0)

@@ -128,9 +128,24 @@ void ibft_host_use_sets(ibft_host *h, int on);
 size_t ibft_host_last_set_rows(ibft_host *h);   /* rows of the last ingest that went through set calls */
 size_t ibft_host_closure_hits(ibft_host *h);
 size_t ibft_host_loop_batch_set_calls(ibft_host *h);
+/* Certificates on arrival (include/ibftgpu.h: ibft_verify_certificates_wire).  ibft_host_ingest_wire sends the PREPREPARE
+ * and ROUND_CHANGE messages of a micro-batch to the device AS THEY ARRIVED: ONE call settles their own IsValidValidator and
+ * every IsValidValidator / IsValidProposalHash that validateProposal, validPC and handleRoundChangeMessage
+ * (core/ibft.go:470-551, 683-788, 1162-1231) will ask about the messages NESTED in them — no PayloadNoSig re-marshal of
+ * nested messages on the host.  The verdicts wait in tables keyed by the decoded (stored) message objects; the certificate
+ * walks (ibft_host_handle_preprepare, ibft_host_handle_round_change) then send the device only what the tables cannot
+ * answer.  Messages the device will not vouch for (non-canonical bytes, envelopes longer than it hashes) take the stock
+ * route, per message.  use_certs(0) = off.  cert_stats: certificate calls made by ingest, rows (messages, nested ones
+ * included) they judged, sender verdicts the last certificate walk took from the tables.                               */
+void ibft_host_use_certs(ibft_host *h, int on);
+void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits);
+size_t ibft_host_loop_batch_cert_calls(ibft_host *h);
+/* handlePrePrepare (core/ibft.go:792-813): 1 = a stored PREPREPARE of (height, round) passes validateProposal0 (round 0) /
+ * validateProposal; the first such message in msg.  Rejected ones are pruned from the store, as in the reference.   */
+int ibft_host_handle_preprepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *msg);
 /* A batch backend that loops over the callback Verifier (no device): the batch control flow — one call per walk,
  * verdict tables, fallback — for CPU-side tests.  fail_mask bits: 1 hash batches, 2 seal batches, 4 sender
- * batches, 8 message-set calls report "device unavailable".                                                                      */
+ * batches, 8 message-set calls, 16 certificate-tree calls report "device unavailable".                                            */
 void ibft_host_use_loop_batch(ibft_host *h, int fail_mask);
 size_t ibft_host_loop_batch_calls(ibft_host *h);
 /* batches that fell back to the per-message verifier because the batch backend reported failure            */

@@ -312,3 +312,86 @@ def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets):
         assert hits_p == 0 and ing.closure_hits() == 0
     assert ing.fallbacks() == 0
     ref.close(); ing.close()
+
+
+def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle):
+    """§8f ranks 1 + 2 with the real backend at N = 128: ROUND-CHANGE messages with quorum-sized PreparedCertificates and the
+    PREPREPARE whose RoundChangeCertificate is made of them arrive as wire bytes; IngestWire settles every nested signature
+    and proposal-hash check in ONE ibft_verify_certificates_wire call per micro-batch (no PayloadNoSig re-marshal of nested
+    messages on the host), handleRoundChangeMessage / handlePrePrepare then ask the device nothing — and decide exactly like
+    the per-message walks backed by the CPU oracle, Byzantine certificates included."""
+    import go_ibft_amd.hostlib as H
+    from oracle import wire as W, workload as WL
+    n = 128
+    r = WL.make_round(n, 4242)
+    addrs = [r.addrs[i].tobytes() for i in range(n)]
+    idx = {a: i for i, a in enumerate(addrs)}
+    quorum = 2 * n // 3 + 1
+    raw = r.raw
+    proposer = lambda hh, rr: addrs[(hh + rr) % n]
+
+    def signed(m):
+        m.signature = oracle.sign(r.sks[idx[m.sender]], oracle.keccak256(m.payload_no_sig()))
+        return m
+
+    def certificate(raw_block, bad_prepare=False):
+        h0 = oracle.proposal_hash(raw_block, 0)
+        pp = signed(W.IbftMessage(view=W.View(1, 0), sender=proposer(1, 0), type=W.PREPREPARE,
+                                  payload=W.preprepare_body(W.Proposal(raw_block, 0), h0, None)))
+        prs = [signed(W.IbftMessage(view=W.View(1, 0), sender=a, type=W.PREPARE, payload=W.prepare_body(h0)))
+               for a in addrs if a != pp.sender][: quorum - 1]
+        if bad_prepare:
+            prs[17].signature = prs[18].signature
+        return pp, prs
+    good, bad_sig, other = certificate(raw), certificate(raw, bad_prepare=True), certificate(b"another block")
+    senders = addrs[5: 5 + quorum + 4]
+    rcs = []
+    for k, a in enumerate(senders):
+        cert = bad_sig if k == 3 else other if k == 9 else good
+        rcs.append(signed(W.IbftMessage(view=W.View(1, 1), sender=a, type=W.ROUND_CHANGE,
+                                        payload=W.round_change_body(W.Proposal(raw, 0), W.prepared_certificate(*cert)))))
+    forged = W.IbftMessage(view=W.View(1, 1), sender=addrs[2], type=W.ROUND_CHANGE, signature=rcs[0].signature,
+                           payload=W.round_change_body(W.Proposal(raw, 0), W.prepared_certificate(*good)))  # envelope not signed by From
+    wires = [m.encode() for m in rcs] + [forged.encode()]
+    # the proposer of round 1 re-proposes the prepared block with the honest ROUND-CHANGE messages as its certificate
+    honest = [m for k, m in enumerate(rcs) if k not in (3, 9)][:quorum]
+    pp1 = signed(W.IbftMessage(view=W.View(1, 1), sender=proposer(1, 1), type=W.PREPREPARE,
+                               payload=W.preprepare_body(W.Proposal(raw, 1), oracle.proposal_hash(raw, 1),
+                                                         W.round_change_certificate(honest))))
+    pp_bad = signed(W.IbftMessage(view=W.View(1, 1), sender=proposer(1, 1), type=W.PREPREPARE,
+                                  payload=W.preprepare_body(W.Proposal(raw, 1), oracle.proposal_hash(raw, 1),
+                                                            W.round_change_certificate(honest[:-1] + [forged]))))  # one envelope inside is forged
+    gpu_verifier.set_validators(1, r.addrs, r.power)
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    ref, ing = H.Host(), H.Host()
+    for h in (ref, ing):
+        assert h.vm_init({a: 1 for a in addrs})
+        h.set_verifier(f1, f2, f3, is_proposer=lambda who, hh, rr: who == proposer(hh, rr))
+        h.set_id(addrs[0])
+        h.set_state(1, 0, None)
+    ing.attach_gpu(gpu_verifier)
+    ing.use_batch(True)
+    expect = [ref.add_message(x) for x in wires]
+    got, rows, hits, calls = ing.ingest_wire(wires)
+    assert [x != 0 for x in got] == [x != 0 for x in expect] and got[-1] == 0 and calls == 1   # ONE device call for the micro-batch
+    c_calls, c_rows, _ = ing.cert_stats()
+    assert c_calls == 1 and c_rows == len(wires) * (1 + quorum)                            # every message of every tree judged
+    for h in (ref, ing):
+        h.set_state(1, 1, None)
+    a = sorted(ref.handle_round_change(1, 1))
+    b = sorted(ing.handle_round_change(1, 1))
+    assert a == b and len(b) == len(rcs) - 2
+    nsend, nhash = ing.last_cert_batch()
+    assert nsend == 0 and nhash == 0 and ing.cert_stats()[2] == len(rcs) * quorum          # nothing left to ask: the tables answered
+    # the PREPREPAREs of round 1: 1.5 MB envelopes (the host hashes those itself, by the stock route), trees judged on arrival
+    for variant, ok in ((pp_bad, False), (pp1, True)):
+        for h in (ref, ing):
+            h.set_state(1, 1, None)
+        e = ref.add_message(variant.encode())
+        g, _, _, _ = ing.ingest_wire([variant.encode()])
+        assert (g[0] != 0) == (e != 0) and e != 0
+        pa, pb = ref.handle_preprepare(1, 1), ing.handle_preprepare(1, 1)
+        assert pa == pb and (pb is not None) == ok
+        assert ing.last_cert_batch()[0] == 0
+    assert ing.fallbacks() == 0
+    ref.close(); ing.close()

@@ -1,0 +1,123 @@
+"""§8f ranks 1 + 2 together, host side, WITHOUT a device: certificates judged on arrival.  IngestWire sends PREPREPARE /
+ROUND_CHANGE messages to the batch backend as they arrived (VerifyCertificatesWire — here the loop backend, which decodes
+and asks the callback Verifier in the device's row order); the verdicts about the NESTED messages wait in tables keyed by
+the stored message objects, and handleRoundChangeMessage / handlePrePrepare (core/ibft.go:470-512, 792-813 → validateProposal
+:683-788 → validPC :1162-1231, proposalMatchesCertificate :516-551) must then
+
+  * decide exactly like the per-message reference walk, and
+  * need no further batch call — everything they ask was settled when the carrying message arrived.
+"""
+import pytest
+
+import go_ibft_amd.hostlib as H
+from oracle import wire as W
+from test_host_roundchange import KINDS, PP, World, fake_hash, rc_message
+
+
+def build_traffic(w, height, raw, rounds=(1, 2, 3)):
+    """ROUND_CHANGE messages (honest and Byzantine certificates) and, per round, PREPREPAREs whose RoundChangeCertificate
+    is made of that round's ROUND_CHANGE messages"""
+    per_round = {}
+    for rnd in rounds:
+        senders = list(w.addrs)
+        w.rng.shuffle(senders)
+        msgs = []
+        # round 1: an honest quorum (an RCC exists); round 2: one Byzantine certificate among honest ones; round 3: anything
+        count = w.n if rnd < 3 else w.rng.randrange(w.n // 2, w.n + 1)
+        for k, a in enumerate(senders[:count]):
+            kind = w.rng.choice(KINDS) if rnd == 3 or (rnd == 2 and k == 0) else w.rng.choice([None, None, "no_certificate"])
+            cert_round = w.rng.randrange(0, rnd)
+            if kind == "no_certificate":
+                m = rc_message(w, height, rnd, a)
+            elif kind == "proposal_without_certificate":
+                m = rc_message(w, height, rnd, a, raw=raw, cert=None, cert_round=cert_round)
+            elif kind == "other_proposal":
+                m = rc_message(w, height, rnd, a, raw=raw, cert=w.certificate(height, cert_round, b"another"), cert_round=cert_round)
+            else:
+                # the mock backend marks bad signatures by message bytes, and honest certificates of one (height, round,
+                # proposal) share their nested messages: a Byzantine certificate gets a proposal of its own
+                r2 = raw if kind is None else raw + b"|" + kind.encode() + a
+                m = rc_message(w, height, rnd, a, raw=r2, cert=w.certificate(height, cert_round, r2, kind), cert_round=cert_round)
+            msgs.append(m)
+        per_round[rnd] = msgs
+    proposals = {}
+    for rnd in rounds:
+        prop = w.proposer(height, rnd)
+        proposals[rnd] = W.IbftMessage(view=W.View(height, rnd), sender=prop, type=PP, signature=b"sig-pp-" + prop,
+                                       payload=W.preprepare_body(W.Proposal(raw, rnd), fake_hash(raw, rnd),
+                                                                 W.round_change_certificate(per_round[rnd])))
+    return per_round, proposals
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("mode", ["certs", "certs_fail", "certs_off"])
+def test_certificates_on_arrival_equal_stock(seed, mode):
+    w = World(n=7 + seed % 4, seed=100 + seed)
+    height, raw = 3, b"block-%d" % seed
+    stock, fast = w.host(), w.host()
+    fast.use_loop_batch(16 if mode == "certs_fail" else 0)
+    fast.use_batch(True)
+    fast.use_certs(mode != "certs_off")
+    me = b"someone else"  # this node proposes nothing
+    for h in (stock, fast):
+        h.set_id(me)
+        h.set_state(height, 0, None)
+    per_round, proposals = build_traffic(w, height, raw)
+    batches = []
+    for rnd, msgs in per_round.items():
+        wires = [m.encode() for m in msgs]
+        batches += [wires[:3], wires[3:] + [proposals[rnd].encode()], wires[:2]]  # the last one: re-deliveries
+    for wires in batches:
+        if not wires:
+            continue
+        ra = stock.ingest_wire(wires)[0]
+        rb = fast.ingest_wire(wires)[0]
+        assert ra == rb, (seed, mode)
+    calls, rows, _ = fast.cert_stats()
+    if mode == "certs":
+        assert calls >= 3 and rows > 20 and fast.loop_batch_cert_calls() == calls
+    else:
+        assert calls == 0
+    for view_round in (1, 2, 3):
+        for h in (stock, fast):
+            h.set_state(height, view_round, None)
+        before = fast.loop_batch_calls()
+        a = stock.handle_round_change(height, view_round)
+        b = fast.handle_round_change(height, view_round)
+        assert sorted(a) == sorted(b), (seed, mode, view_round)
+        assert a or view_round == 3  # the honest rounds do produce an extended RCC
+        if mode == "certs":
+            assert fast.loop_batch_calls() == before, "the certificate walk asked the backend again"
+        pa = stock.handle_preprepare(height, view_round)
+        pb = fast.handle_preprepare(height, view_round)
+        assert pa == pb, (seed, mode, view_round)
+        if mode == "certs":
+            assert fast.loop_batch_calls() == before
+            if pb is not None:
+                assert fast.cert_stats()[2] > 0  # sender verdicts came from the arrival-time tables
+    assert fast.fallbacks() == 0 or mode == "certs_fail"
+    stock.close(); fast.close()
+
+
+def test_tables_follow_the_store():
+    """a validator-set change and a height prune drop the arrival-time verdicts; the walks still decide correctly"""
+    w = World(n=7, seed=7)
+    height, raw = 3, b"blk"
+    fast = w.host()
+    fast.use_loop_batch(0)
+    fast.use_batch(True)
+    fast.set_id(b"x")
+    fast.set_state(height, 0, None)
+    per_round, proposals = build_traffic(w, height, raw, rounds=(1,))
+    wires = [m.encode() for m in per_round[1]] + [proposals[1].encode()]
+    fast.ingest_wire(wires)
+    fast.set_state(height, 1, None)
+    first = fast.handle_round_change(height, 1)
+    # the same set again as a new validator set: tables cleared, the walk batches what it needs itself
+    assert fast.vm_init({a: 1 for a in w.addrs})
+    before = fast.loop_batch_calls()
+    again = fast.handle_round_change(height, 1)
+    assert sorted(first) == sorted(again)
+    if first:
+        assert fast.loop_batch_calls() > before
+    fast.close()
