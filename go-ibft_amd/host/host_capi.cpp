@@ -157,6 +157,55 @@ int ibft_host_verify_senders_wire(ibft_ctx *ctx, const uint8_t *wire, const uint
   return 0;
 }
 
+// Measurement aid (tools/cert_from_wire.py): every signature of a batch of certificate-carrying messages, two ways.
+// route 0: the transport's bytes straight to ibft_verify_certificates_wire.  route 1: the route of f2 before it — decode the
+// messages, collect every nested message, re-marshal PayloadNoSig of each, flatten into columns (host_ms) and
+// ibft_verify_senders.  rows = messages judged, valid = those whose sender check passed.
+int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int route, size_t *rows, size_t *valid,
+                          double *host_ms, double *total_ms) {
+  if (!ctx || !off || !rows || !valid) return IBFT_E_INVAL;
+  const auto t0 = std::chrono::steady_clock::now();
+  double hms = 0.0;
+  *rows = *valid = 0;
+  GpuBackend gb(ctx);
+  if (route == 0) {
+    CertVerdicts cv;
+    if (!gb.VerifyCertificatesWire(wire, off, n, cv)) return gb.last_rc ? gb.last_rc : IBFT_E_INVAL;
+    *rows = cv.n_rows;
+    for (uint8_t b : cv.sender) *valid += b;
+  } else {
+    std::vector<MsgPtr> all;
+    for (size_t i = 0; i < n; i++) {
+      auto m = std::make_shared<IbftMessage>();
+      if (!decode(wire + off[i], off[i + 1] - off[i], *m)) continue;
+      all.push_back(std::move(m));
+    }
+    for (size_t k = 0; k < all.size(); k++) {  // breadth first, like the device
+      const IbftMessage &m = *all[k];
+      if (m.kind == PayloadKind::PREPREPARE && m.preprepare.certificate) {
+        for (auto &c : m.preprepare.certificate->round_change_messages) all.push_back(c);
+      } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change.latest_prepared_certificate) {
+        const PreparedCertificate &pc = *m.round_change.latest_prepared_certificate;
+        if (pc.proposal_message) all.push_back(pc.proposal_message);
+        for (auto &c : pc.prepare_messages) all.push_back(c);
+      }
+    }
+    std::vector<uint8_t> v;
+    SenderColumns c;
+    flatten_senders(all, c);
+    hms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<uint64_t> mask((c.n + 63) / 64, 0);
+    const int rc = ibft_verify_senders(ctx, c.payload.data(), c.off.data(), c.sig65.data(), c.from20.data(), c.pre_flags.data(), c.n,
+                                       mask.data(), nullptr);
+    if (rc != IBFT_OK) return rc;
+    *rows = c.n;
+    for (size_t j = 0; j < c.n; j++) *valid += (mask[j >> 6] >> (j & 63)) & 1;
+  }
+  if (host_ms) *host_ms = hms;
+  if (total_ms) *total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
 int ibft_host_payload_no_sig(const uint8_t *wire, size_t len, ibft_host_buf *out) {
   IbftMessage m;
   if (!decode(wire, len, m)) return -1;

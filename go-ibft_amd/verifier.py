@@ -37,7 +37,7 @@ EXPORTS = [
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
-    "ibft_verify_messages_wire", "ibft_forget_proposal",
+    "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8

@@ -80,6 +80,7 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.ibft_forget_proposal(null),
         lambda: lib.ibft_verify_messages_wire(null, b, off, 1, 0, 0, b, 1, 0, None, m, m, None, None, C.byref(t)),
         lambda: lib.ibft_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, m, m, C.byref(t)),
+        lambda: lib.ibft_verify_certificates_wire(null, b, off, 1, 8, C.byref(C.c_size_t()), None, None, None, m, m, m),
         lambda: lib.ibft_seals_launch(null, 1),
         lambda: lib.ibft_seals_fetch(null, m, C.byref(t)),
         lambda: lib.ibft_seals_export(null, None, None),
@@ -87,6 +88,17 @@ def test_null_context_is_rejected_everywhere(lib):
     ]
     for i, call in enumerate(calls):
         assert call() == -1, i
+
+
+def test_cert_node_struct_matches_the_header():
+    """ibft_cert_node_t: 56 bytes, field order as in include/ibftgpu.h"""
+    import go_ibft_amd.verifier as V
+    hdr = open(os.path.join(ROOT, "include", "ibftgpu.h")).read()
+    body = hdr[hdr.index("typedef struct {\n  uint32_t off, len;"):hdr.index("} ibft_cert_node_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(off|len|parent|ordinal|first_child|n_children|raw_off|raw_len|proposal_round|cut0|cut1|level|role|flags|pad)\b(?=[,;\[])", body)
+    assert names == list(V.CERT_NODE.names)
+    assert V.CERT_NODE.itemsize == 56 and V.CERT_NODE.fields["proposal_round"][1] == 32 and V.CERT_NODE.fields["level"][1] == 48
 
 
 def test_wire_row_struct_matches_the_header():
