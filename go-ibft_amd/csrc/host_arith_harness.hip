@@ -268,7 +268,7 @@ int64_t dev_cert_tree(const uint8_t *wire_bytes, const uint32_t *off, uint32_t n
     for (uint32_t row = levels[l].first; row < levels[l].second; row++)
       if (rows[row].status != wire::STATUS_OK && nodes[row].parent != wire::NO_PARENT) rows[nodes[row].parent].status = wire::STATUS_NEEDS_HOST;
   for (uint32_t row = 0; row < total; row++)
-    wire::tree_digest_row(wire_bytes, &rows[row], &nodes[row], digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row);
+    wire::tree_digest_row(wire_bytes, &rows[row], &nodes[row], digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row, true);
   for (uint32_t row = 0; row < total; row++) {
     bool hb, sb;
     wire::tree_compare_row(nodes.data(), rows.data(), prop_digest32, row, hb, sb, cls[row]);

@@ -118,7 +118,7 @@ struct ibft_ctx {
   // certificates from wire bytes (ibft_verify_certificates_wire): tree nodes, where each row's nested messages lie,
   // child counts of the level being expanded, proposal digests, hash / self words; the row count of the next level
   // comes back through one mapped word
-  DevBuf d_cert_nodes, d_cert_span, d_cert_count, d_cert_prop, d_cert_masks, d_cert_total;
+  DevBuf d_cert_nodes, d_cert_span, d_cert_count, d_cert_prop, d_cert_masks, d_cert_total, d_cert_slot;
   uint32_t *h_cert_total = nullptr, *dh_cert_total = nullptr;
   bool gather_pinned = true;  // columns in ibft_pinned_alloc buffers are read by one gather launch (IBFT_NO_GATHER=1: never)
   // … whose extra blocks can hash PayloadNoSig straight from the host column (IBFT_DIGEST_FUSION=1).  Off by default: it
@@ -195,12 +195,13 @@ int alloc_rows(ibft_ctx *c, uint32_t rows) {
   return IBFT_OK;
 }
 
-ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre) {
+// row_base (a multiple of 64): the batch is rows [row_base, row_base + n) of the columns — its own verdict words
+ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre, uint32_t row_base = 0) {
   ibftk::recover_args a{};
-  a.hash32 = (const uint8_t *)c->d_hash.p;
-  a.sig65 = (const uint8_t *)c->d_sig.p;
-  a.signer20 = (const uint8_t *)c->d_signer.p;
-  a.pre_flags = with_pre ? (const uint8_t *)c->d_pre.p : nullptr;
+  a.hash32 = (const uint8_t *)c->d_hash.p + 32ull * row_base;
+  a.sig65 = (const uint8_t *)c->d_sig.p + 65ull * row_base;
+  a.signer20 = (const uint8_t *)c->d_signer.p + 20ull * row_base;
+  a.pre_flags = with_pre ? (const uint8_t *)c->d_pre.p + row_base : nullptr;
   a.payload = (const uint8_t *)c->d_payload.p;
   a.off = (const uint32_t *)c->d_off.p;
   a.gtab = (const uint32_t *)c->d_gtab.p;
@@ -208,8 +209,8 @@ ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre) {
   a.vslot_mask = c->vslot_mask;
   a.n = n;
   a.flags = c->flags;
-  a.mask = (uint64_t *)c->d_mask.p;
-  a.vidx = (int32_t *)c->d_vidx.p;
+  a.mask = (uint64_t *)c->d_mask.p + row_base / 64;
+  a.vidx = (int32_t *)c->d_vidx.p + row_base;
   if (c->cache_on) {
     a.pub = (uint32_t *)c->d_pub.p;
     a.pub_state = (uint32_t *)c->d_pub_state.p;
@@ -244,14 +245,17 @@ int clean_mask(ibft_ctx *c) {
 
 // enqueue the verdict kernels over the resident columns: warm kernel first when tables exist
 // (its rows are then skipped by the recover kernel), recover kernel for everything else
-int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it) {
+// keep_mask: a second batch of the same call (rows [row_base, row_base + n)): the work mask already holds the first batch's
+// bits and must not be zeroed again (the caller saw to it that this batch's words are clean)
+int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it, uint32_t row_base = 0, bool keep_mask = false) {
   if (n == 0) return IBFT_OK;
-  ibftk::recover_args a = make_args(c, n, with_pre);
+  ibftk::recover_args a = make_args(c, n, with_pre, row_base);
   struct dirty_on_exit {  // whatever is launched below writes verdict bits into the first ⌈n/64⌉ words of d_mask
     ibft_ctx *c;
     uint32_t words;
     ~dirty_on_exit() { c->mask_dirty_words = std::max(c->mask_dirty_words, words); }
-  } mark_dirty{c, (uint32_t)mask_words(n)};
+  } mark_dirty{c, (uint32_t)mask_words((size_t)row_base + n)};
+  auto clean_mask = [keep_mask](ibft_ctx *cc) { return keep_mask ? (int)IBFT_OK : ::clean_mask(cc); };
   int rc_clean = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (time_it) {
@@ -261,7 +265,7 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   }
   const bool warm = c->cache_on && c->learned_seen > 0;
   if (warm) {
-    a.warm_done = (uint8_t *)c->d_warm_done.p;
+    a.warm_done = (uint8_t *)c->d_warm_done.p + row_base;
     // lanes per signature: ≈ one wavefront per SIMD (1024 SIMDs × 64 lanes / n rows), a power of two
     uint32_t G = 1;
     if (c->kernel == IBFT_KERNEL_WAVE) {
@@ -912,7 +916,8 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
                     &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
-                    &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total})
+                    &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total,
+                    &c->d_cert_slot})
     release(*b);
   if (c->h_cert_total) (void)hipHostFree(c->h_cert_total);
   comm_release(c);
@@ -1672,6 +1677,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
   if ((rc = ensure(c, c->d_cert_nodes, m * sizeof(wire::node_info)))) return rc;
   if ((rc = ensure(c, c->d_cert_span, m * 8))) return rc;
   if ((rc = ensure(c, c->d_cert_count, m * 4))) return rc;
+  if ((rc = ensure(c, c->d_cert_slot, m * 4))) return rc;
   if ((rc = ensure(c, c->d_cert_prop, m * 32))) return rc;
   if ((rc = ensure(c, c->d_cert_masks, (size_t)mask_words(m) * 16))) return rc;
   if ((rc = ensure(c, c->d_cert_total, 64))) return rc;
@@ -1684,7 +1690,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
   wire::node_info *d_nodes = (wire::node_info *)c->d_cert_nodes.p;
   wire::row_info *d_rows = (wire::row_info *)c->d_wire_rows.p;
   uint2 *d_span = (uint2 *)c->d_cert_span.p;
-  uint32_t *d_count = (uint32_t *)c->d_cert_count.p, *d_total = (uint32_t *)c->d_cert_total.p;
+  uint32_t *d_count = (uint32_t *)c->d_cert_count.p, *d_total = (uint32_t *)c->d_cert_total.p, *d_slot = (uint32_t *)c->d_cert_slot.p;
   uint8_t *d_digest = (uint8_t *)c->d_hash.p, *d_sig = (uint8_t *)c->d_sig.p, *d_from = (uint8_t *)c->d_signer.p,
           *d_pre = (uint8_t *)c->d_pre.p, *d_prop = (uint8_t *)c->d_cert_prop.p;
   if (wbytes) HIPCHK(c, hipMemcpyAsync(c->d_payload.p, wire_bytes, wbytes, hipMemcpyHostToDevice, c->stream));
@@ -1700,7 +1706,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
   }
   HIPCHK(c, hipMemcpyAsync(d_nodes, level0.data(), n * sizeof(wire::node_info), hipMemcpyHostToDevice, c->stream));
   std::vector<std::pair<uint32_t, uint32_t>> levels;
-  uint32_t lo = 0, hi = (uint32_t)n;
+  uint32_t lo = 0, hi = (uint32_t)n, carriers = 0;
   for (uint32_t level = 0;; level++) {
     const uint32_t cnt = hi - lo;
     hipLaunchKernelGGL(ibftk::cert_parse_kernel, dim3((cnt + 63) / 64), dim3(64), 0, c->stream, d_wire, d_nodes, lo, hi, d_rows, d_span,
@@ -1709,13 +1715,14 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
     hipLaunchKernelGGL(ibftk::cert_walk_kernel<false>, dim3(cnt), dim3(64), 0, c->stream, d_wire, d_nodes, d_rows, (const uint2 *)d_span, lo, hi,
                        d_count);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(ibftk::cert_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_count, d_nodes, lo, hi, hi, d_total,
-                       c->dh_cert_total);
+    hipLaunchKernelGGL(ibftk::cert_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_count, d_nodes, lo, hi, hi, carriers,
+                       d_slot, d_total, c->dh_cert_total);
     HIPCHK(c, hipGetLastError());
-    if (!c->dh_cert_total) HIPCHK(c, hipMemcpyAsync(c->h_cert_total, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+    if (!c->dh_cert_total) HIPCHK(c, hipMemcpyAsync(c->h_cert_total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     levels.push_back({lo, hi});
-    const uint32_t total = *(volatile uint32_t *)c->h_cert_total;
+    const uint32_t total = ((volatile uint32_t *)c->h_cert_total)[0];
+    carriers += ((volatile uint32_t *)c->h_cert_total)[1];
     if (total == 0) break;
     if ((uint64_t)hi + total > cap || level == 254) return IBFT_E_TOOBIG;
     hipLaunchKernelGGL(ibftk::cert_walk_kernel<true>, dim3(cnt), dim3(64), 0, c->stream, d_wire, d_nodes, d_rows, (const uint2 *)d_span, lo, hi,
@@ -1731,24 +1738,32 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
                        levels[l].first, levels[l].second);
     HIPCHK(c, hipGetLastError());
   }
-  hipLaunchKernelGGL(ibftk::cert_digest_kernel, dim3((rows + 63) / 64), dim3(64), 0, c->stream, d_wire, d_nodes, (const wire::row_info *)d_rows,
+  // the deferred digests (messages that carry certificates, long messages): a wavefront per message; then every row's final
+  // pre-flag / class bits and the proposal hashes
+  if (carriers) {
+    hipLaunchKernelGGL(ibftk::cert_digest_wave_kernel, dim3(2 * carriers), dim3(64), 0, c->stream, d_wire, (const wire::node_info *)d_nodes,
+                       (const wire::row_info *)d_rows, (const uint32_t *)d_slot, d_digest, d_prop);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(ibftk::cert_finish_kernel, dim3((rows + 63) / 64), dim3(64), 0, c->stream, d_wire, d_nodes, (const wire::row_info *)d_rows,
                      rows, d_digest, d_prop, d_pre);
   HIPCHK(c, hipGetLastError());
+  c->ev_used = 0;
+  // ONE verdict launch over all rows of all levels: the digest column holds keccak256(PayloadNoSig) of every row — the seal-style
+  // pass; rows that are not judged here are pre-flagged
+  if ((rc = enqueue_recover(c, rows, true, 0, false))) return rc;
   uint64_t *d_hash_mask = (uint64_t *)c->d_cert_masks.p, *d_self_mask = d_hash_mask + mask_words(m);
   hipLaunchKernelGGL(ibftk::cert_compare_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream, (const wire::node_info *)d_nodes,
                      (const wire::row_info *)d_rows, (const uint8_t *)d_prop, rows, d_hash_mask, d_self_mask, (uint8_t *)c->d_class.p);
   HIPCHK(c, hipGetLastError());
-  c->ev_used = 0;
-  // the digest column holds keccak256(PayloadNoSig) of every row: the seal-style pass; rows that are not judged here are pre-flagged
-  if ((rc = enqueue_recover(c, rows, true, 0, false))) return rc;
-  if ((rc = enqueue_tally(c, rows))) return rc;
   const size_t mw = (size_t)mask_words(rows);
   if (out_nodes) HIPCHK(c, hipMemcpyAsync(out_nodes, d_nodes, (size_t)rows * sizeof(wire::node_info), hipMemcpyDeviceToHost, c->stream));
   if (out_rows) HIPCHK(c, hipMemcpyAsync(out_rows, d_rows, (size_t)rows * sizeof(wire::row_info), hipMemcpyDeviceToHost, c->stream));
   if (out_class) HIPCHK(c, hipMemcpyAsync(out_class, c->d_class.p, rows, hipMemcpyDeviceToHost, c->stream));
   if (out_hash_mask) HIPCHK(c, hipMemcpyAsync(out_hash_mask, d_hash_mask, mw * 8, hipMemcpyDeviceToHost, c->stream));
   if (out_self_mask) HIPCHK(c, hipMemcpyAsync(out_self_mask, d_self_mask, mw * 8, hipMemcpyDeviceToHost, c->stream));
-  if ((rc = fetch_results(c, rows, out_sender_mask, nullptr, true))) return rc;
+  // no tally: the rows of a tree belong to many certificates; their quorum rules are the caller's (From / type / view columns)
+  if ((rc = fetch_results(c, rows, out_sender_mask, nullptr, false))) return rc;
   *out_n_rows = rows;
   return IBFT_OK;
 }

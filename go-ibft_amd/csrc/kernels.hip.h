@@ -801,6 +801,27 @@ __global__ void qtab_commit_kernel(uint32_t *__restrict__ pub_state, uint32_t n_
 // first (a lane walking ≈200 bytes of HBM one dependent byte load at a time made this kernel 75 µs), and every lane
 // walks and hashes its message from there.  A wavefront whose messages exceed the buffer reads HBM directly.
 constexpr uint32_t WIRE_LDS_BYTES = 32 * 1024;
+// nbytes of HBM at src (16-byte aligned) → LDS, one wavefront: 16-byte loads, four in flight per lane.  (A dword per lane and
+// trip — the first form — is a chain of ≈1 µs round trips: 16 KiB took ≈50 µs.)  Reads up to 15 bytes past src + nbytes: the
+// payload buffer carries 256 bytes of slack; the LDS buffer must hold nbytes rounded up to 16.
+__device__ __forceinline__ void stage_bytes(uint8_t *lds, const uint8_t *src, uint32_t nbytes, uint32_t lane) {
+  const uint32_t chunks = (nbytes + 15u) >> 4;
+  const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+  uint4 *d4 = reinterpret_cast<uint4 *>(lds);
+  for (uint32_t c0 = 0; c0 < chunks; c0 += 256u) {
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      const uint32_t c = c0 + lane + 64u * k;
+      v[k] = c < chunks ? s4[c] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      const uint32_t c = c0 + lane + 64u * k;
+      if (c < chunks) d4[c] = v[k];
+    }
+  }
+}
 __global__ void __launch_bounds__(64) wire_parse_kernel(const uint8_t *__restrict__ wire_bytes, const uint32_t *__restrict__ off,
                                                         uint32_t n, wire::row_info *__restrict__ rows,
                                                         uint8_t *__restrict__ digest32, uint8_t *__restrict__ sig65,
@@ -809,12 +830,10 @@ __global__ void __launch_bounds__(64) wire_parse_kernel(const uint8_t *__restric
   __shared__ __attribute__((aligned(16))) uint8_t lbuf[WIRE_LDS_BYTES + 16];
   const uint32_t row0 = blockIdx.x * 64u, lane = threadIdx.x;
   const uint32_t cnt = n - row0 < 64u ? n - row0 : 64u;
-  const uint32_t b0 = off[row0] & ~3u, b1 = off[row0 + cnt];
+  const uint32_t b0 = off[row0] & ~15u, b1 = off[row0 + cnt];
   const bool staged = b1 - b0 <= WIRE_LDS_BYTES;  // wave-uniform
   if (staged) {
-    // aligned dwords of [b0, b1): reads up to 3 bytes past the batch — the buffer carries 256 bytes of slack
-    for (uint32_t i = 4u * lane; b0 + i < b1; i += 256u)
-      *reinterpret_cast<uint32_t *>(lbuf + i) = *reinterpret_cast<const uint32_t *>(wire_bytes + b0 + i);
+    stage_bytes(lbuf, wire_bytes + b0, b1 - b0, lane);
     __syncthreads();
   }
   const uint32_t row = row0 + lane;
@@ -936,11 +955,10 @@ __global__ void __launch_bounds__(64) cert_parse_kernel(const uint8_t *__restric
   if (live) nd = nodes[row];
   // the 64 messages of a wavefront are usually neighbours in the buffer (children of one certificate): staged in LDS
   // with coalesced dword loads when they span little enough, like wire_parse_kernel
-  const uint32_t b0 = wave_min_u32(live ? nd.off : 0xFFFFFFFFu) & ~3u, b1 = wave_max_u32(live ? nd.off + nd.len : 0u);
+  const uint32_t b0 = wave_min_u32(live ? nd.off : 0xFFFFFFFFu) & ~15u, b1 = wave_max_u32(live ? nd.off + nd.len : 0u);
   const bool staged = b1 >= b0 && b1 - b0 <= WIRE_LDS_BYTES;  // wave-uniform
   if (staged) {
-    for (uint32_t i = 4u * lane; b0 + i < b1; i += 256u)
-      *reinterpret_cast<uint32_t *>(lbuf + i) = *reinterpret_cast<const uint32_t *>(wire_bytes + b0 + i);
+    stage_bytes(lbuf, wire_bytes + b0, b1 - b0, lane);
     __syncthreads();
   }
   if (!live) return;
@@ -972,8 +990,9 @@ __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict
   if (row >= hi) return;
   const wire::node_info nd = nodes[row];
   const bool has = rows[row].status == wire::STATUS_OK && (nd.flags & wire::TREE_HAS_CERT);
+  const uint32_t deferred = rows[row].status == wire::STATUS_OK && wire::tree_deferred(nd) ? 0x80000000u : 0u;
   if (!has || (FILL && nd.n_children == 0)) {
-    if (!FILL && lane == 0) child_count[row - lo] = 0;
+    if (!FILL && lane == 0) child_count[row - lo] = deferred;
     return;
   }
   const bool pc = rows[row].payload_kind == wire::KIND_ROUND_CHANGE;
@@ -982,10 +1001,9 @@ __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict
   const uint32_t end = pos + span.y;
   bool ok = true;
   while (pos < end && ok) {
-    const uint32_t w0 = pos & ~3u;
+    const uint32_t w0 = pos & ~15u;
     const uint32_t wend = end - w0 <= CERT_WIN_BYTES ? end : w0 + CERT_WIN_BYTES;
-    for (uint32_t i = 4u * lane; w0 + i < wend; i += 256u)
-      *reinterpret_cast<uint32_t *>(win + i) = *reinterpret_cast<const uint32_t *>(wire_bytes + w0 + i);
+    stage_bytes(win, wire_bytes + w0, wend - w0, lane);
     __syncthreads();
     if (lane == 0) {
       const lds_window W{win, w0};
@@ -1033,34 +1051,49 @@ __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict
       count = 0;
     }
     nodes[row].n_children = count;
-    child_count[row - lo] = count;
+    child_count[row - lo] = count | (ok ? deferred : 0u);
   }
 }
-// first_child of rows [lo, hi) = base + exclusive prefix sum of their child counts; the sum → total (device and host)
+// first_child of rows [lo, hi) = base + exclusive prefix sum of their child counts; the sum → total[0] (device and host).
+// The rows whose digest is deferred (wire::tree_deferred: they carry a certificate, or are long) are listed the same way:
+// deferred_rows[slot_base + rank] = row, their count → total[1].  child_count[i] bit 31 = row lo + i is deferred.
 __global__ void __launch_bounds__(1024) cert_scan_kernel(const uint32_t *__restrict__ child_count, wire::node_info *__restrict__ nodes,
-                                                         uint32_t lo, uint32_t hi, uint32_t base, uint32_t *__restrict__ total_dev,
+                                                         uint32_t lo, uint32_t hi, uint32_t base, uint32_t slot_base,
+                                                         uint32_t *__restrict__ deferred_rows, uint32_t *__restrict__ total_dev,
                                                          uint32_t *__restrict__ total_host) {
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[1024], part2[1024];
   const uint32_t n = hi - lo, t = threadIdx.x, per = (n + 1023u) / 1024u;
   const uint32_t b = t * per < n ? t * per : n, e = b + per < n ? b + per : n;
-  uint32_t sum = 0;
-  for (uint32_t i = b; i < e; i++) sum += child_count[i];
+  uint32_t sum = 0, sum2 = 0;
+  for (uint32_t i = b; i < e; i++) {
+    const uint32_t c = child_count[i];
+    sum += c & 0x7FFFFFFFu;
+    sum2 += c >> 31;
+  }
   part[t] = sum;
+  part2[t] = sum2;
   __syncthreads();
   for (uint32_t o = 1; o < 1024u; o <<= 1) {
-    const uint32_t v = t >= o ? part[t - o] : 0u;
+    const uint32_t v = t >= o ? part[t - o] : 0u, v2 = t >= o ? part2[t - o] : 0u;
     __syncthreads();
     part[t] += v;
+    part2[t] += v2;
     __syncthreads();
   }
-  uint32_t run = base + part[t] - sum;
+  uint32_t run = base + part[t] - sum, run2 = slot_base + part2[t] - sum2;
   for (uint32_t i = b; i < e; i++) {
+    const uint32_t c = child_count[i];
     nodes[lo + i].first_child = run;
-    run += child_count[i];
+    run += c & 0x7FFFFFFFu;
+    if (c >> 31) deferred_rows[run2++] = lo + i;
   }
   if (t == 1023u) {
-    *total_dev = part[1023];
-    if (total_host) *total_host = part[1023];
+    total_dev[0] = part[1023];
+    total_dev[1] = part2[1023];
+    if (total_host) {
+      total_host[0] = part[1023];
+      total_host[1] = part2[1023];
+    }
   }
 }
 __global__ void cert_propagate_kernel(const wire::node_info *__restrict__ nodes, wire::row_info *__restrict__ rows, uint32_t lo,
@@ -1070,7 +1103,104 @@ __global__ void cert_propagate_kernel(const wire::node_info *__restrict__ nodes,
   const uint32_t parent = nodes[row].parent;
   if (rows[row].status != wire::STATUS_OK && parent != wire::NO_PARENT) rows[parent].status = wire::STATUS_NEEDS_HOST;
 }
-__global__ void __launch_bounds__(64) cert_digest_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
+// ---- Keccak-256 of one long message by one wavefront -------------------------------------------------------------------
+// A sponge is sequential, and one lane (or the scalar unit) spends ≈9–14 µs on a 136-byte block: ≈188 64-bit operations per round
+// at one instruction per ≈4 ticks.  A message that carries a certificate is tens of kilobytes, so here 25 lanes hold one
+// 64-bit word of the state each (lane i = x + 5y) and the words meet in LDS: per round every lane
+//   θ   writes its word, reads the two neighbouring COLUMNS (10 words), forms D[x] = C[x−1] ^ rotl(C[x+1], 1) itself;
+//   ρ,π rotates its word by its own offset and writes it to where π sends it;
+//   χ,ι reads the two words to its right in its row, combines, lane 0 adds the round constant.
+// Two dependent LDS round trips and ≈35 VALU instructions per round instead of ≈190 (or ≈380 32-bit ones).
+// PayloadNoSig of a canonical message = its bytes minus the signature field [cut0, cut1): lanes 0…16 fetch their 8 bytes of each
+// block with aligned dword loads, byte by byte only where a word straddles the cut or the end of the message.
+__device__ const uint8_t KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+__device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t r) { return r ? (v << r) | (v >> (64u - r)) : v; }
+// One job per wavefront: job 2k hashes PayloadNoSig of deferred row k → digest32[row]; job 2k + 1 hashes the Proposal that row
+// carries, keccak(rawProposal ‖ BE64(round)) → prop_digest32[row] (exits at once when there is none).  The message is
+// piece A = [a0, a0 + na) followed by piece B = [b0, b0 + nb) of the buffer, then `tail` (≤ 8 bytes, by value).
+__global__ void __launch_bounds__(64) cert_digest_wave_kernel(const uint8_t *__restrict__ wire_bytes, const wire::node_info *__restrict__ nodes,
+                                                              const wire::row_info *__restrict__ rows,
+                                                              const uint32_t *__restrict__ deferred_rows, uint8_t *__restrict__ digest32,
+                                                              uint8_t *__restrict__ prop_digest32) {
+  __shared__ uint64_t A[32], B[32];
+  const uint32_t row = deferred_rows[blockIdx.x >> 1], lane = threadIdx.x;
+  const bool proposal_job = blockIdx.x & 1u;
+  const wire::node_info nd = nodes[row];
+  if (rows[row].status != wire::STATUS_OK) return;  // block-uniform: not judged here
+  const uint8_t *m;
+  uint32_t cut0, gap, total;
+  uint64_t tail = 0;
+  if (!proposal_job) {
+    if (nd.len > wire::TREE_DIGEST_MAX_BYTES) return;
+    m = wire_bytes + nd.off;
+    cut0 = nd.cut0;
+    gap = nd.cut1 - nd.cut0;
+    total = nd.len - gap;
+  } else {
+    if (!(nd.flags & wire::TREE_HAS_PROPOSAL) || nd.raw_len > wire::TREE_DIGEST_MAX_BYTES) return;
+    m = wire_bytes + nd.raw_off;
+    cut0 = nd.raw_len;  // everything before the "cut" is the raw proposal; behind it come the 8 bytes of the round
+    gap = 0;
+    total = nd.raw_len + 8u;
+    for (int k = 0; k < 8; k++) tail |= (uint64_t)((nd.proposal_round >> (8 * (7 - k))) & 0xFFu) << (8 * k);  // BE64 as the bytes lie
+  }
+  const bool act = lane < 25u;
+  const uint32_t i = act ? lane : 0u, x = i % 5u, y = i / 5u;
+  const uint32_t cm = (x + 4u) % 5u, cp = (x + 1u) % 5u;              // the columns on either side
+  const uint32_t pi = y + 5u * ((2u * x + 3u * y) % 5u);                 // where π sends this lane's word
+  const uint32_t r1 = (x + 1u) % 5u + 5u * y, r2 = (x + 2u) % 5u + 5u * y;
+  const uint32_t rho = KECCAK_RHO[i];
+  uint64_t s = 0;
+  for (uint32_t done = 0;; done += 136u) {
+    const uint32_t left = total - done;
+    const bool last = left < 136u;
+    if (lane < 17u) {
+      const uint32_t v = done + 8u * lane;  // this lane's 8 bytes of the block, in the message
+      uint64_t w = 0;
+      const bool whole = proposal_job ? v + 8u <= cut0 : (v + 8u <= cut0 || v >= cut0);
+      if (!last && whole) {
+        const uint8_t *p = m + (v < cut0 ? v : v + gap);
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), sh = 8u * mis;
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - mis);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = mis ? q[2] : 0u;
+        const uint32_t lo = (uint32_t)(((uint64_t)d1 << 32 | d0) >> sh), hi = (uint32_t)(((uint64_t)d2 << 32 | d1) >> sh);
+        w = (uint64_t)lo | ((uint64_t)hi << 32);
+      } else {
+        for (uint32_t k = 0; k < 8u; k++) {
+          const uint32_t o = v + k, in_block = 8u * lane + k;
+          uint64_t byte = 0;
+          if (o < total) {
+            if (proposal_job)
+              byte = o < cut0 ? m[o] : (tail >> (8u * (o - cut0))) & 0xFFu;
+            else
+              byte = m[o < cut0 ? o : o + gap];
+          }
+          if (last && in_block == left) byte ^= 0x01u;
+          if (last && in_block == 135u) byte ^= 0x80u;
+          w |= byte << (8u * k);
+        }
+      }
+      s ^= w;
+    }
+#pragma unroll
+    for (int round = 0; round < 24; round++) {  // unrolled: the round constants are literals, nothing is loaded inside the chain
+      if (act) A[i] = s;
+      __syncthreads();  // one wavefront per workgroup: no s_barrier is emitted, only the ordering
+      const uint64_t c_minus = A[cm] ^ A[cm + 5] ^ A[cm + 10] ^ A[cm + 15] ^ A[cm + 20];
+      const uint64_t c_plus = A[cp] ^ A[cp + 5] ^ A[cp + 10] ^ A[cp + 15] ^ A[cp + 20];
+      s ^= c_minus ^ ((c_plus << 1) | (c_plus >> 63));
+      if (act) B[pi] = rotl64_var(s, rho);
+      __syncthreads();
+      s = B[i] ^ (~B[r1] & B[r2]);
+      s ^= lane == 0 ? keccak::rc(round) : 0ull;
+    }
+    if (last) break;
+  }
+  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 : digest32) + 32ull * row + 8u * lane) = s;
+}
+// After the deferred digests: every row's final pre-flag and class bits, and the hash of the Proposal it carries (a lane per row;
+// proposals are short next to the messages that carry certificates)
+__global__ void __launch_bounds__(64) cert_finish_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
                                                          const wire::row_info *__restrict__ rows, uint32_t n,
                                                          uint8_t *__restrict__ digest32, uint8_t *__restrict__ prop_digest32,
                                                          uint8_t *__restrict__ pre_flags) {
@@ -1078,7 +1208,7 @@ __global__ void __launch_bounds__(64) cert_digest_kernel(const uint8_t *__restri
   if (row >= n) return;
   wire::node_info nd = nodes[row];
   const uint8_t before = nd.flags;
-  wire::tree_digest_row(wire_bytes, rows + row, &nd, digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row);
+  wire::tree_digest_row(wire_bytes, rows + row, &nd, digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row, false);  // a deferred row's digests are there already
   if (nd.flags != before) nodes[row].flags = nd.flags;
 }
 // hash / self bits and the routing byte of every row (wire::tree_compare_row), one verdict word per wavefront

@@ -162,21 +162,32 @@ HD bool parse_proposal(const uint8_t *m, uint32_t pos, uint32_t end, tree_part &
 // BYTES is anything indexable by absolute position (the message itself, or a window of it held in LDS).
 template <typename BYTES>
 HD bool cert_child_header(const BYTES &m, uint32_t end, bool pc, uint32_t &last, uint32_t &pos, uint32_t &len, uint8_t &role) {
-  const uint8_t tag = m[pos++];
+  // tag + length prefix: at most 6 bytes, fetched together (independent loads: one LDS round trip on the device) and decoded
+  // from registers
+  uint8_t h[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) h[k] = pos + (uint32_t)k < end ? m[pos + (uint32_t)k] : (uint8_t)0;
+  const uint32_t avail = end - pos;  // ≥ 1
+  const uint8_t tag = h[0];
   const uint32_t f = tag >> 3;
   if ((tag & 0x80u) || (tag & 7u) != 2 || f == 0 || f < last || f > (pc ? 2u : 1u)) return false;
   if (pc && f == 1 && last == 1) return false;
   last = f;
   uint64_t l = 0;
-  for (int i = 0;; i++) {  // minimal varint, at most 5 bytes (a length ≥ 2^32 cannot lie inside the buffer)
-    if (i == 5 || pos >= end) return false;
-    const uint8_t b = m[pos++];
+  uint32_t used = 1;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {  // minimal varint, at most 5 bytes (a length ≥ 2^32 cannot lie inside the buffer)
+    if (used >= avail) return false;
+    const uint8_t b = h[1 + i];
+    used++;
     l |= (uint64_t)(b & 0x7Fu) << (7 * i);
     if (!(b & 0x80u)) {
       if (i > 0 && b == 0) return false;
       break;
     }
+    if (i == 4) return false;
   }
+  pos += used;
   if (l > (uint64_t)(end - pos)) return false;
   len = (uint32_t)l;
   role = pc ? (f == 1 ? ROLE_PC_PROPOSAL : ROLE_PC_PREPARE) : ROLE_RCC_MESSAGE;
@@ -420,9 +431,15 @@ HD void hash_proposal(const uint8_t *raw, uint32_t raw_len, uint64_t round, uint
   hash_pieces(raw, raw_len, raw, 0, be, 8, out4);
 }
 
-// One row of the tree: the DEEP walk, the columns of the sender check, the node's own facts.  A row without a
-// certificate wrapper has nothing below it: its digest is final here.  A row with one waits for the rows below
-// (tree_digest_row) — pre_flag says "0" for it until then.
+// A message's PayloadNoSig digest is DEFERRED when it cannot be final after the walk of its own fields, or would hold up
+// the 63 other lanes of its wavefront: it carries a certificate (canonical only if every message below it is), or it is
+// longer than a PREPARE / COMMIT (a PREPREPARE with its proposal: several Keccak blocks).  Deferred digests are computed
+// after the whole tree is known, a wavefront per message (kernels.hip.h: cert_digest_wave_kernel).
+constexpr uint32_t TREE_DEFER_BYTES = 256;
+HD bool tree_deferred(const node_info &nd) { return (nd.flags & TREE_HAS_CERT) || nd.len > TREE_DEFER_BYTES; }
+
+// One row of the tree: the DEEP walk, the columns of the sender check, the node's own facts.  The digest and the pre-flag
+// of a row that is not deferred are final here; a deferred row's pre-flag says "verdict 0" until tree_digest_row.
 HD void process_tree_row(const uint8_t *m, uint32_t n, row_info *ri_out, node_info *node, uint32_t cert_span[2],
                          uint8_t *digest32, uint8_t *sig65, uint8_t *from20, uint8_t *pre_flag) {
   const parsed p = parse_message_t<true>(m, n);
@@ -439,42 +456,44 @@ HD void process_tree_row(const uint8_t *m, uint32_t n, row_info *ri_out, node_in
   // where the nested messages lie (relative to the message): the walk of the next step counts and lists them
   cert_span[0] = has_cert ? p.t.cert_off : 0;
   cert_span[1] = has_cert ? p.t.cert_len : 0;
+  const bool now = ok && !tree_deferred(*node);
   uint64_t d[4] = {0, 0, 0, 0};
-  if (ok && !has_cert) hash_without(m, n, p.sig_field_start, p.sig_field_end, d);
+  if (now) hash_without(m, n, p.sig_field_start, p.sig_field_end, d);
   for (int j = 0; j < 4; j++)
     for (int b = 0; b < 8; b++) digest32[8 * j + b] = (uint8_t)(d[j] >> (8 * b));
   const bool sig_ok = ok && p.ri.sig_len == 65, from_ok = ok && p.ri.from_len == 20;
   for (int i = 0; i < 65; i++) sig65[i] = sig_ok ? m[p.sig_pos + i] : 0;
   for (int i = 0; i < 20; i++) from20[i] = from_ok ? p.ri.from[i] : 0;
-  *pre_flag = (uint8_t)((ok && !has_cert ? 0 : 1) | (sig_ok ? 0 : 2) | (from_ok ? 0 : 2));
+  *pre_flag = (uint8_t)((now ? 0 : 1) | (sig_ok ? 0 : 2) | (from_ok ? 0 : 2));
 }
-// After the levels below have been judged (a non-canonical child has already turned this row's status to
-// NEEDS_HOST): the digest of a row that carries a certificate, and of the Proposal a row carries.
+// After the levels below have been judged (a non-canonical child has already turned this row's status to NEEDS_HOST): the
+// pre-flag and class of a deferred row — and, with hash_here, its digest (the CPU harness; on the device a wavefront per
+// deferred row has written it, cert_digest_wave_kernel) — and the hash of the Proposal a row carries.
 HD void tree_digest_row(const uint8_t *wire, const row_info *ri, node_info *node, uint8_t *digest32, uint8_t *prop_digest32,
-                        uint8_t *pre_flag) {
+                        uint8_t *pre_flag, bool hash_here) {
   const bool ok = ri->status == STATUS_OK;
-  if (node->flags & TREE_HAS_CERT) {
-    uint64_t d[4] = {0, 0, 0, 0};
+  if (tree_deferred(*node)) {
     bool judged = false;
     if (ok && node->len <= TREE_DIGEST_MAX_BYTES) {
-      hash_without_long(wire + node->off, node->len, node->cut0, node->cut1, d);
+      if (hash_here) {
+        uint64_t d[4];
+        hash_without_long(wire + node->off, node->len, node->cut0, node->cut1, d);
+        for (int j = 0; j < 4; j++)
+          for (int b = 0; b < 8; b++) digest32[8 * j + b] = (uint8_t)(d[j] >> (8 * b));
+      }
       judged = true;
     } else if (ok) {
       node->flags |= TREE_TOO_BIG;
     }
-    for (int j = 0; j < 4; j++)
-      for (int b = 0; b < 8; b++) digest32[8 * j + b] = (uint8_t)(d[j] >> (8 * b));
     *pre_flag = (uint8_t)((judged ? 0 : 1) | (ri->sig_len == 65 && ri->from_len == 20 ? 0 : 2));
-  } else if (!ok) {
-    *pre_flag |= 1;
   }
+  // the Proposal's hash: here for a row that is not deferred (a short message, a short proposal) or on the CPU; the device's
+  // wavefront of a deferred row has written it next to the row's own digest
+  const bool prop_ok = ok && (node->flags & TREE_HAS_PROPOSAL) && node->raw_len <= TREE_DIGEST_MAX_BYTES;
+  if (ok && (node->flags & TREE_HAS_PROPOSAL) && !prop_ok) node->flags |= TREE_PROPOSAL_TOO_BIG;
+  if (prop_ok && !hash_here && tree_deferred(*node)) return;
   uint64_t h[4] = {0, 0, 0, 0};
-  if (ok && (node->flags & TREE_HAS_PROPOSAL)) {
-    if (node->raw_len <= TREE_DIGEST_MAX_BYTES)
-      hash_proposal(wire + node->raw_off, node->raw_len, node->proposal_round, h);
-    else
-      node->flags |= TREE_PROPOSAL_TOO_BIG;
-  }
+  if (prop_ok) hash_proposal(wire + node->raw_off, node->raw_len, node->proposal_round, h);
   for (int j = 0; j < 4; j++)
     for (int b = 0; b < 8; b++) prop_digest32[8 * j + b] = (uint8_t)(h[j] >> (8 * b));
 }

@@ -369,9 +369,9 @@ int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const ui
  *                   are not the canonical encoding (unknown fields, non-minimal varints, …): PayloadNoSig is not
  *                   "bytes minus the signature field", the sender bit is 0 and the caller decides this message by the stock
  *                   route (rows below it that are canonical are still judged).  IBFT_CERT_CLASS_DIGEST_BY_HOST: canonical
- *                   but longer than IBFT_CERT_DIGEST_MAX_BYTES — Keccak is sequential, one lane absorbs ≈14 MB/s — so
- *                   the sender bit is 0 and the host hashes bytes[0, cut0) ‖ bytes[cut1, len) itself (out_nodes) and asks
- *                   ibft_verify_seals with that digest.  IBFT_CERT_CLASS_PROPOSAL_BY_HOST: the Proposal this message
+ *                   but longer than IBFT_CERT_DIGEST_MAX_BYTES — Keccak is sequential: the wavefront that hashes a long
+ *                   message absorbs ≈25 MB/s — so the sender bit is 0 and the host hashes bytes[0, cut0) ‖ bytes[cut1, len)
+ *                   itself (out_nodes) and asks ibft_verify_seals with that digest.  IBFT_CERT_CLASS_PROPOSAL_BY_HOST: the Proposal this message
  *                   carries is that long: the self bit of this row and the hash bits of its children are undecided
  *   out_sender_mask bit row = IsValidValidator(message): its envelope signature recovers to From, From is a validator
  *   out_hash_mask   bit row = the 32-byte proposal hash this message carries equals keccak(lastPreparedProposal) of the

@@ -247,7 +247,7 @@ def expected_tree(msgs: list, valset_addrs, rows_cap: int = 1 << 30, digest_max:
                       cut0=o.cut0 if o is not None else 0, cut1=o.cut1 if o is not None else 0,
                       flags=o.flags if o is not None else 0)
             for k, (rel, ln, role) in enumerate(kids):
-                nxt.append(dict(off=nd["off"] + rel if ln else nd["off"] + rel, len=ln, parent=r, ordinal=k, level=nd["level"] + 1, role=role))
+                nxt.append(dict(off=nd["off"] + rel, len=ln, parent=r, ordinal=k, level=nd["level"] + 1, role=role))
             base += len(kids)
         if not nxt:
             break
@@ -268,7 +268,7 @@ def expected_tree(msgs: list, valset_addrs, rows_cap: int = 1 << 30, digest_max:
             cls[r] |= CLASS_NEEDS_HOST
             continue
         m = buf[nd["off"]:nd["off"] + nd["len"]]
-        if (o.flags & HAS_CERT) and nd["len"] > digest_max:
+        if nd["len"] > digest_max:
             nd["flags"] |= TOO_BIG
             cls[r] |= CLASS_DIGEST_BY_HOST
         else:

@@ -102,10 +102,11 @@ def test_longer_than_the_device_hashes(dev):
     r = W.make_round(4, 812, height=5, round_=1, raw_len=(1 << 20) + 5)
     rc = CC.round_change(r, 0, 5, 2, wire.Proposal(r.raw, 1), CC.pc_bytes(r, 5, 1, 1, [2, 3]))
     exp = check(dev, r, "1 MiB proposal", [rc.encode(), CC.prepare(r, 1, 5, 2).encode()])
-    # the ROUND_CHANGE and the PREPREPARE inside its certificate both carry the long proposal; the PREPREPARE has no
-    # certificate of its own, so its envelope is still hashed here
-    assert exp.cls[0] == WC.CLASS_DIGEST_BY_HOST | WC.CLASS_PROPOSAL_BY_HOST and exp.cls[1] == 0
-    assert exp.cls[2] == WC.CLASS_PROPOSAL_BY_HOST and exp.sender_ok[2] and not exp.sender_ok[0]
+    # the ROUND_CHANGE and the PREPREPARE inside its certificate both carry the long proposal and are that long themselves;
+    # the PREPAREs next to them are judged
+    both = WC.CLASS_DIGEST_BY_HOST | WC.CLASS_PROPOSAL_BY_HOST
+    assert exp.cls[0] == both and exp.cls[1] == 0 and exp.cls[2] == both and exp.cls[3] == 0
+    assert not exp.sender_ok[0] and not exp.sender_ok[2] and exp.sender_ok[1] and exp.sender_ok[3] and exp.sender_ok[4]
 
 
 def test_many_children_and_window_sized_certificates(dev):

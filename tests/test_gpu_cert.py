@@ -49,7 +49,8 @@ def test_longer_than_the_device_hashes(gpu_verifier):
     gpu_verifier.set_validators(5, r.addrs, r.power)
     rc = CC.round_change(r, 0, 5, 2, wire.Proposal(r.raw, 1), CC.pc_bytes(r, 5, 1, 1, [2, 3]))
     exp = run(gpu_verifier, r, "1 MiB proposal", [rc.encode(), CC.prepare(r, 1, 5, 2).encode()])
-    assert exp.cls[0] == WC.CLASS_DIGEST_BY_HOST | WC.CLASS_PROPOSAL_BY_HOST and exp.cls[2] == WC.CLASS_PROPOSAL_BY_HOST
+    both = WC.CLASS_DIGEST_BY_HOST | WC.CLASS_PROPOSAL_BY_HOST
+    assert exp.cls[0] == both and exp.cls[2] == both and exp.cls[1] == 0 and exp.sender_ok[3]
 
 
 def test_round_change_certificate_n256(gpu_verifier):
