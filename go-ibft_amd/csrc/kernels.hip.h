@@ -238,23 +238,66 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) sign_lane_kernel(sign_args a) 
   a.ok[row] = ok ? 1 : 0;
 }
 
-// ---- proposal hash + a1 ---------------------------------------------------------------
-// One sponge is sequential: a single lane walks it (the compiler turns the uniform code into scalar 64-bit ops:
-// ≈188 per round, ≈9 µs per 136-byte block at one instruction per ≈4 ticks — the floor for one wavefront).  The host
-// hands the message over already padded (raw ‖ BE64(round) ‖ pad10*1 to a multiple of the rate, 8-byte aligned), so
-// absorbing a block is seventeen 64-bit XORs.
-__global__ void proposal_hash_kernel(const uint64_t *__restrict__ padded, uint32_t blocks, uint64_t *__restrict__ out4) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    uint64_t s[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) s[i] = 0;
-    for (uint32_t b = 0; b < blocks; b++) {
-#pragma unroll
-      for (int i = 0; i < 17; i++) s[i] ^= padded[17u * b + i];
-      keccak::f1600(s);
-    }
-    for (int i = 0; i < 4; i++) out4[i] = s[i];
+// ---- Keccak-256 of one long message by one wavefront -------------------------------------------------------------------
+// A sponge is sequential, and one lane (or the scalar unit) spends ≈9–14 µs on a 136-byte block: ≈188 64-bit operations per round
+// at one instruction per ≈4 ticks.  A message that carries a certificate is tens of kilobytes, so here 25 lanes hold one
+// 64-bit word of the state each (lane i = x + 5y) and the words meet in LDS: per round every lane
+//   θ   writes its word, reads the two neighbouring COLUMNS (10 words), forms D[x] = C[x−1] ^ rotl(C[x+1], 1) itself;
+//   ρ,π rotates its word by its own offset and writes it to where π sends it;
+//   χ,ι reads the two words to its right in its row, combines, lane 0 adds the round constant.
+// Two dependent LDS round trips and ≈35 VALU instructions per round instead of ≈190 (or ≈380 32-bit ones).
+__device__ const uint8_t KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+__device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t r) { return r ? (v << r) | (v >> (64u - r)) : v; }
+// The lane's share of the state and where its neighbours are.  One wavefront per workgroup (no s_barrier is emitted for
+// __syncthreads, only the ordering of the LDS accesses); A and B are 32 × u64 of LDS each.
+struct wave_sponge {
+  uint64_t s;  // state word i = x + 5y of lane i < 25 (lanes 25…63 mirror lane 0 and never write)
+  uint32_t i, cm, cp, pi, r1, r2, rho;
+  bool act, first;
+  __device__ __forceinline__ void init(uint32_t lane) {
+    act = lane < 25u;
+    first = lane == 0;
+    i = act ? lane : 0u;
+    const uint32_t x = i % 5u, y = i / 5u;
+    cm = (x + 4u) % 5u;                       // the columns on either side
+    cp = (x + 1u) % 5u;
+    pi = y + 5u * ((2u * x + 3u * y) % 5u);   // where π sends this lane's word
+    r1 = (x + 1u) % 5u + 5u * y;
+    r2 = (x + 2u) % 5u + 5u * y;
+    rho = KECCAK_RHO[i];
+    s = 0;
   }
+  __device__ __forceinline__ void permute(uint64_t *A, uint64_t *B) {
+#pragma unroll
+    for (int round = 0; round < 24; round++) {  // unrolled: the round constants are literals, nothing is loaded inside the chain
+      if (act) A[i] = s;
+      __syncthreads();
+      const uint64_t c_minus = A[cm] ^ A[cm + 5] ^ A[cm + 10] ^ A[cm + 15] ^ A[cm + 20];
+      const uint64_t c_plus = A[cp] ^ A[cp + 5] ^ A[cp + 10] ^ A[cp + 15] ^ A[cp + 20];
+      s ^= c_minus ^ ((c_plus << 1) | (c_plus >> 63));
+      if (act) B[pi] = rotl64_var(s, rho);
+      __syncthreads();
+      s = B[i] ^ (~B[r1] & B[r2]);
+      s ^= first ? keccak::rc(round) : 0ull;
+    }
+  }
+};
+
+// ---- proposal hash + a1 ---------------------------------------------------------------
+// One sponge is sequential; one wavefront walks it with the state spread over 25 lanes (wave_sponge: ≈5.3 µs per 136-byte
+// block; a single lane — scalar 64-bit code, ≈188 operations per round — needed ≈9.4 µs).  The host hands the message over
+// already padded (raw ‖ BE64(round) ‖ pad10*1 to a multiple of the rate, 8-byte aligned), so absorbing a block is one 64-bit
+// load and XOR in lanes 0…16.
+__global__ void __launch_bounds__(64) proposal_hash_kernel(const uint64_t *__restrict__ padded, uint32_t blocks, uint64_t *__restrict__ out4) {
+  __shared__ uint64_t A[32], B[32];
+  const uint32_t lane = threadIdx.x;
+  wave_sponge sp;
+  sp.init(lane);
+  for (uint32_t b = 0; b < blocks; b++) {
+    if (lane < 17u) sp.s ^= padded[17u * b + lane];
+    sp.permute(A, B);
+  }
+  if (lane < 4u) out4[lane] = sp.s;
 }
 
 // bit i of mask = (hash_len[i] == 32 && hash32[i] == H); rows are 32 B so each lane
@@ -1103,18 +1146,7 @@ __global__ void cert_propagate_kernel(const wire::node_info *__restrict__ nodes,
   const uint32_t parent = nodes[row].parent;
   if (rows[row].status != wire::STATUS_OK && parent != wire::NO_PARENT) rows[parent].status = wire::STATUS_NEEDS_HOST;
 }
-// ---- Keccak-256 of one long message by one wavefront -------------------------------------------------------------------
-// A sponge is sequential, and one lane (or the scalar unit) spends ≈9–14 µs on a 136-byte block: ≈188 64-bit operations per round
-// at one instruction per ≈4 ticks.  A message that carries a certificate is tens of kilobytes, so here 25 lanes hold one
-// 64-bit word of the state each (lane i = x + 5y) and the words meet in LDS: per round every lane
-//   θ   writes its word, reads the two neighbouring COLUMNS (10 words), forms D[x] = C[x−1] ^ rotl(C[x+1], 1) itself;
-//   ρ,π rotates its word by its own offset and writes it to where π sends it;
-//   χ,ι reads the two words to its right in its row, combines, lane 0 adds the round constant.
-// Two dependent LDS round trips and ≈35 VALU instructions per round instead of ≈190 (or ≈380 32-bit ones).
-// PayloadNoSig of a canonical message = its bytes minus the signature field [cut0, cut1): lanes 0…16 fetch their 8 bytes of each
-// block with aligned dword loads, byte by byte only where a word straddles the cut or the end of the message.
-__device__ const uint8_t KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-__device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t r) { return r ? (v << r) | (v >> (64u - r)) : v; }
+// (Keccak by one wavefront: wave_sponge, above the proposal hash.)
 // One job per wavefront: job 2k hashes PayloadNoSig of deferred row k → digest32[row]; job 2k + 1 hashes the Proposal that row
 // carries, keccak(rawProposal ‖ BE64(round)) → prop_digest32[row] (exits at once when there is none).  The message is
 // piece A = [a0, a0 + na) followed by piece B = [b0, b0 + nb) of the buffer, then `tail` (≤ 8 bytes, by value).
@@ -1144,13 +1176,8 @@ __global__ void __launch_bounds__(64) cert_digest_wave_kernel(const uint8_t *__r
     total = nd.raw_len + 8u;
     for (int k = 0; k < 8; k++) tail |= (uint64_t)((nd.proposal_round >> (8 * (7 - k))) & 0xFFu) << (8 * k);  // BE64 as the bytes lie
   }
-  const bool act = lane < 25u;
-  const uint32_t i = act ? lane : 0u, x = i % 5u, y = i / 5u;
-  const uint32_t cm = (x + 4u) % 5u, cp = (x + 1u) % 5u;              // the columns on either side
-  const uint32_t pi = y + 5u * ((2u * x + 3u * y) % 5u);                 // where π sends this lane's word
-  const uint32_t r1 = (x + 1u) % 5u + 5u * y, r2 = (x + 2u) % 5u + 5u * y;
-  const uint32_t rho = KECCAK_RHO[i];
-  uint64_t s = 0;
+  wave_sponge sp;
+  sp.init(lane);
   for (uint32_t done = 0;; done += 136u) {
     const uint32_t left = total - done;
     const bool last = left < 136u;
@@ -1180,23 +1207,12 @@ __global__ void __launch_bounds__(64) cert_digest_wave_kernel(const uint8_t *__r
           w |= byte << (8u * k);
         }
       }
-      s ^= w;
+      sp.s ^= w;
     }
-#pragma unroll
-    for (int round = 0; round < 24; round++) {  // unrolled: the round constants are literals, nothing is loaded inside the chain
-      if (act) A[i] = s;
-      __syncthreads();  // one wavefront per workgroup: no s_barrier is emitted, only the ordering
-      const uint64_t c_minus = A[cm] ^ A[cm + 5] ^ A[cm + 10] ^ A[cm + 15] ^ A[cm + 20];
-      const uint64_t c_plus = A[cp] ^ A[cp + 5] ^ A[cp + 10] ^ A[cp + 15] ^ A[cp + 20];
-      s ^= c_minus ^ ((c_plus << 1) | (c_plus >> 63));
-      if (act) B[pi] = rotl64_var(s, rho);
-      __syncthreads();
-      s = B[i] ^ (~B[r1] & B[r2]);
-      s ^= lane == 0 ? keccak::rc(round) : 0ull;
-    }
+    sp.permute(A, B);
     if (last) break;
   }
-  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 : digest32) + 32ull * row + 8u * lane) = s;
+  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 : digest32) + 32ull * row + 8u * lane) = sp.s;
 }
 // After the deferred digests: every row's final pre-flag and class bits, and the hash of the Proposal it carries (a lane per row;
 // proposals are short next to the messages that carry certificates)

@@ -39,6 +39,12 @@ func (i *IBFT) AddWireMessages(raw [][]byte) {
 	if len(raw) == 0 {
 		return
 	}
+	if cv, hasCerts := i.backend.(CertificateVerifier); hasCerts {
+		// PREPREPARE / ROUND_CHANGE messages first: their own envelope and every message nested in them, one call
+		if raw = i.addWireCertificates(cv, raw); len(raw) == 0 {
+			return
+		}
+	}
 	if ws, hasSets := i.backend.(WireSetVerifier); hasSets && i.state.getProposal() != nil {
 		if i.addWireSets(ws, raw) {
 			return

@@ -214,6 +214,45 @@ func (c *Ctx) VerifyMessagesWire(wire []byte, off []uint32, height, round uint64
 	return senderMask, validMask, class[:n], tally(ct), c.check(rc)
 }
 
+// CertNode mirrors ibft_cert_node_t: one IbftMessage of a certificate tree (VerifyCertificatesWire).
+type CertNode struct {
+	Off, Len              uint32 // the message's bytes in the call's buffer
+	Parent, Ordinal       uint32 // containing row (CertNoParent for the call's own messages), position among its children
+	FirstChild, NChildren uint32 // its nested messages are rows [FirstChild, FirstChild+NChildren)
+	RawOff, RawLen        uint32 // Proposal.rawProposal it carries
+	ProposalRound         uint64
+	Cut0, Cut1            uint32 // its signature field, relative to Off: PayloadNoSig = bytes minus [Cut0, Cut1)
+	Level, Role, Flags    uint8
+	_                     [5]byte
+}
+
+const (
+	CertNoParent         = uint32(C.IBFT_CERT_NO_PARENT)
+	CertClassNeedsHost   = byte(C.IBFT_CERT_CLASS_NEEDS_HOST)       // not canonical here: the stock route decides this message
+	CertClassDigestHost  = byte(C.IBFT_CERT_CLASS_DIGEST_BY_HOST)   // canonical, longer than the device hashes
+	CertClassProposalHost = byte(C.IBFT_CERT_CLASS_PROPOSAL_BY_HOST) // the Proposal it carries is that long
+	CertRolePCProposal   = uint8(C.IBFT_CERT_ROLE_PC_PROPOSAL)
+	CertRolePCPrepare    = uint8(C.IBFT_CERT_ROLE_PC_PREPARE)
+	CertRoleRCCMessage   = uint8(C.IBFT_CERT_ROLE_RCC_MESSAGE)
+)
+
+// VerifyCertificatesWire = every IsValidValidator / IsValidProposalHash that validateProposal, validPC and
+// handleRoundChangeMessage (core/ibft.go:470-551, 683-788, 1162-1231) ask about the messages NESTED in the given raw
+// PREPREPARE / ROUND_CHANGE messages, and about those messages themselves, in one call (ibft_verify_certificates_wire).
+// Rows are breadth first: the call's messages, then their nested messages in wire order, and so on — the order in which
+// a decoded message lists them.  sender / hash / self are bit masks over the rows, class one routing byte per row.
+func (c *Ctx) VerifyCertificatesWire(wire []byte, off []uint32, rowsCap int) (nodes []CertNode, class []byte, sender, hash, self []uint64, err error) {
+	n := len(off) - 1
+	nodes = make([]CertNode, rowsCap+1)
+	class = make([]byte, rowsCap+1)
+	sender, hash, self = make([]uint64, (rowsCap+63)/64+1), make([]uint64, (rowsCap+63)/64+1), make([]uint64, (rowsCap+63)/64+1)
+	var rows C.size_t
+	rc := C.ibft_verify_certificates_wire(c.h, ptr8(wire), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(n), C.size_t(rowsCap), &rows,
+		(*C.ibft_cert_node_t)(unsafe.Pointer(&nodes[0])), nil, ptr8(class), (*C.uint64_t)(unsafe.Pointer(&sender[0])),
+		(*C.uint64_t)(unsafe.Pointer(&hash[0])), (*C.uint64_t)(unsafe.Pointer(&self[0])))
+	return nodes[:int(rows)], class[:int(rows)], sender, hash, self, c.check(rc)
+}
+
 // PinnedBytes returns n bytes of page-locked memory (ibft_pinned_alloc) as a Go slice: column buffers the
 // flatten step writes into once and reuses every round.  When every column of a call lies in such buffers the
 // library reads them with one gather launch instead of one copy command per column.  C memory: invisible to
