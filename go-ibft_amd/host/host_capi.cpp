@@ -161,13 +161,14 @@ int ibft_host_verify_senders_wire(ibft_ctx *ctx, const uint8_t *wire, const uint
 // route 0: the transport's bytes straight to ibft_verify_certificates_wire.  route 1: the route of f2 before it — decode the
 // messages, collect every nested message, re-marshal PayloadNoSig of each, flatten into columns (host_ms) and
 // ibft_verify_senders.  rows = messages judged, valid = those whose sender check passed.
-int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int route, size_t *rows, size_t *valid,
-                          double *host_ms, double *total_ms) {
+int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int route, size_t rows_cap, size_t *rows,
+                          size_t *valid, double *host_ms, double *total_ms) {
   if (!ctx || !off || !rows || !valid) return IBFT_E_INVAL;
   const auto t0 = std::chrono::steady_clock::now();
   double hms = 0.0;
   *rows = *valid = 0;
   GpuBackend gb(ctx);
+  if (rows_cap) gb.cert_rows_cap = rows_cap;
   if (route == 0) {
     CertVerdicts cv;
     if (!gb.VerifyCertificatesWire(wire, off, n, cv)) return gb.last_rc ? gb.last_rc : IBFT_E_INVAL;

@@ -170,17 +170,17 @@ def verify_senders_wire(batch_verifier, wire: bytes, off, stock: bool = False):
     return verdict[:n].astype(bool), ms.value, rows.value
 
 
-def cert_routes(batch_verifier, wire: bytes, off, route: int):
+def cert_routes(batch_verifier, wire: bytes, off, route: int, rows_cap: int = 0):
     """measurement aid: every sender check of a batch of certificate trees; route 0 = from the bytes
     (ibft_verify_certificates_wire), 1 = host decode + PayloadNoSig re-marshal + flatten + ibft_verify_senders.
     Returns (rows, valid, host_ms, total_ms)."""
     import numpy as np
     off = np.ascontiguousarray(off, dtype=np.uint32)
     L = lib()
-    L.ibft_host_cert_routes.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t),
+    L.ibft_host_cert_routes.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     rows, valid, hms, tms = C.c_size_t(0), C.c_size_t(0), C.c_double(0.0), C.c_double(0.0)
-    rc = L.ibft_host_cert_routes(batch_verifier._h, bytes(wire) or b"\0", off.ctypes.data_as(C.c_void_p), len(off) - 1, route,
+    rc = L.ibft_host_cert_routes(batch_verifier._h, bytes(wire) or b"\0", off.ctypes.data_as(C.c_void_p), len(off) - 1, route, rows_cap,
                                  C.byref(rows), C.byref(valid), C.byref(hms), C.byref(tms))
     if rc != 0:
         raise RuntimeError(f"ibft_host_cert_routes: {rc}")

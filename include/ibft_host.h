@@ -145,9 +145,10 @@ size_t ibft_host_loop_batch_cert_calls(ibft_host *h);
 int ibft_host_handle_preprepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *msg);
 /* Measurement aid (tools/cert_from_wire.py): the sender checks of every message of a batch of certificate trees, route 0 = the
  * bytes straight to ibft_verify_certificates_wire, route 1 = decode + collect nested messages + PayloadNoSig re-marshal +
- * flatten on the host (host_ms) + ibft_verify_senders.  rows / valid = messages judged / accepted.                       */
-int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int route, size_t *rows,
-                          size_t *valid, double *host_ms, double *total_ms);
+ * flatten on the host (host_ms) + ibft_verify_senders.  rows_cap: rows the tree may expand to (0 = 65 536; the context's
+ * max_rows bounds it too).  rows / valid = messages judged / accepted.                                                   */
+int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *off, size_t n, int route, size_t rows_cap,
+                          size_t *rows, size_t *valid, double *host_ms, double *total_ms);
 /* A batch backend that loops over the callback Verifier (no device): the batch control flow — one call per walk,
  * verdict tables, fallback — for CPU-side tests.  fail_mask bits: 1 hash batches, 2 seal batches, 4 sender
  * batches, 8 message-set calls, 16 certificate-tree calls report "device unavailable".                                            */
