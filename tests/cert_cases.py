@@ -246,3 +246,61 @@ def pack(msgs):
     off = np.zeros(len(msgs) + 1, dtype=np.uint32)
     off[1:] = np.cumsum([len(x) for x in msgs])
     return b"".join(msgs), off
+
+
+# ---- golden digests (tests/golden/cert_trees.json, made by tests/golden/make_cert_golden.py) --------------------
+def _row_bytes(struct_fields, ok_fields):
+    import struct
+    out = struct.pack("<7I5B", *struct_fields)
+    if ok_fields is not None:
+        out += struct.pack("<2Q9B4IQ", *ok_fields)
+    return out
+
+
+def digest_expected(exp: WC.Tree) -> str:
+    """what an answer must contain, hashed: tree shape, classes and bits of every row, parsed fields of the judged rows"""
+    import hashlib
+    h = hashlib.sha256()
+    for k in range(exp.n_rows):
+        e = exp.nodes[k]
+        ok = exp.status[k] == WC.OK
+        okf = None
+        if ok:
+            o = exp.rows[k]
+            okf = (o.height, o.round, o.type, o.kind, o.has_view, len(o.proposal_hash), min(len(o.sender), 255), min(len(o.signature), 255),
+                   min(len(o.committed_seal), 255) if o.kind == 7 else 0, e["flags"], 0, e["cut0"], e["cut1"],
+                   e["raw_off"] if e["flags"] & WC.HAS_PROPOSAL else 0, e["raw_len"] if e["flags"] & WC.HAS_PROPOSAL else 0,
+                   e["proposal_round"] if e["flags"] & WC.HAS_PROPOSAL else 0)
+        h.update(_row_bytes((e["off"], e["len"], e["parent"], e["ordinal"], e["level"], e["role"], e["n_children"],
+                             exp.cls[k], int(ok), int(exp.sender_ok[k]), int(exp.hash_bit[k]), int(exp.self_bit[k])), okf))
+    return h.hexdigest()[:16]
+
+
+def digest_actual(n_rows, nodes, rows, cls, sender, hashb, selfb) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for k in range(n_rows):
+        nd, ri = nodes[k], rows[k]
+        ok = int(ri["status"]) == 0
+        okf = None
+        if ok:
+            fl = int(nd["flags"])
+            hp = fl & WC.HAS_PROPOSAL
+            okf = (int(ri["height"]), int(ri["round"]), int(ri["type"]), int(ri["payload_kind"]), int(ri["has_view"]), int(ri["hash_len"]),
+                   int(ri["from_len"]), int(ri["sig_len"]), int(ri["seal_len"]) if int(ri["payload_kind"]) == 7 else 0, fl, 0,
+                   int(nd["cut0"]), int(nd["cut1"]), int(nd["raw_off"]) if hp else 0, int(nd["raw_len"]) if hp else 0,
+                   int(nd["proposal_round"]) if hp else 0)
+        h.update(_row_bytes((int(nd["off"]), int(nd["len"]), int(nd["parent"]), int(nd["ordinal"]), int(nd["level"]), int(nd["role"]),
+                             int(nd["n_children"]), int(cls[k]), int(ok), int(bool(sender[k])), int(bool(hashb[k])), int(bool(selfb[k]))), okf))
+    return h.hexdigest()[:16]
+
+
+GOLDEN_SEED, GOLDEN_VALIDATORS, GOLDEN_ROUND_SEED = 31337, 8, 811
+
+
+def golden_batches(count):
+    """the deterministic batches the golden digests refer to: handmade cases first, then byte-level fuzz"""
+    from oracle import workload as W
+    r = W.make_round(GOLDEN_VALIDATORS, GOLDEN_ROUND_SEED, height=5, round_=1)
+    hm = [m for _, m in handmade(r)]
+    return r, (hm + fuzz_batches(r, max(0, count - len(hm)), GOLDEN_SEED))[:count]

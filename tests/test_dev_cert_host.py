@@ -116,3 +116,22 @@ def test_many_children_and_window_sized_certificates(dev):
     rc = CC.round_change(r, 0, 5, 2, wire.Proposal(r.raw, 1), pc)
     exp = check(dev, r, "200 validators", [rc.encode()])
     assert exp.n_rows == 201 and all(exp.sender_ok) and all(exp.hash_bit[1:])
+
+
+def test_golden_trees(dev):
+    """tests/golden/cert_trees.json (oracle/wire_cert.py cross-checked message by message against the google.protobuf runtime,
+    tests/golden/make_cert_golden.py): one digest per batch over tree shape, classes, verdict bits and parsed fields"""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cert_trees.json")))
+    count = 700
+    r, batches = CC.golden_batches(count)
+    members = {bytes(a) for a in r.addrs}
+    for bi, msgs in enumerate(batches):
+        n, nodes, rows, digest, sig, frm, pre, prop, cls, hb, sb = run_dev(dev, msgs)
+        sender = np.zeros(n, dtype=bool)
+        for k in range(n):
+            if not pre[k]:
+                a = OB.recover_address(digest[k].tobytes(), sig[k].tobytes())
+                sender[k] = a is not None and a == frm[k].tobytes() and a in members
+        assert CC.digest_actual(n, nodes, rows, cls, sender, hb, sb) == gold["digests"][bi], bi

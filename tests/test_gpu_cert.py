@@ -97,3 +97,21 @@ def test_certificate_longer_than_the_walk_window(gpu_verifier):
         msgs.append(CC.round_change(r, k, 5, 2, wire.Proposal(r.raw, 1), pc).encode())
     exp = run(gpu_verifier, r, "long certificates", msgs)
     assert exp.n_rows == 7 + 7 + 599 + 130 + 64 + 65 + 1 + 257 and all(exp.sender_ok)
+
+
+def test_golden_trees(gpu_verifier):
+    """tests/golden/cert_trees.json: 2 000 batches (hand-made cases, then byte-level fuzz), one digest per batch over tree shape,
+    classes, sender / hash / self bits and parsed fields; the expectation was cross-checked against the google.protobuf runtime when
+    the fixture was made (tests/golden/make_cert_golden.py)"""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cert_trees.json")))
+    r, batches = CC.golden_batches(gold["count"])
+    gpu_verifier.set_validators(5, r.addrs, r.power)
+    bad = []
+    for bi, msgs in enumerate(batches):
+        buf, off = CC.pack(msgs)
+        n, nodes, rows, cls, sender, hb, sb = gpu_verifier.verify_certificates_wire(buf, off, rows_cap=4096)
+        if CC.digest_actual(n, nodes, rows, cls, sender, hb, sb) != gold["digests"][bi]:
+            bad.append(bi)
+    assert not bad, bad[:20]
