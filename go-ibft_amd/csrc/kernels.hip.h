@@ -1152,10 +1152,12 @@ __global__ void cert_propagate_kernel(const wire::node_info *__restrict__ nodes,
 // piece A = [a0, a0 + na) followed by piece B = [b0, b0 + nb) of the buffer, then `tail` (≤ 8 bytes, by value).
 __global__ void __launch_bounds__(64) cert_digest_wave_kernel(const uint8_t *__restrict__ wire_bytes, const wire::node_info *__restrict__ nodes,
                                                               const wire::row_info *__restrict__ rows,
-                                                              const uint32_t *__restrict__ deferred_rows, uint8_t *__restrict__ digest32,
-                                                              uint8_t *__restrict__ prop_digest32) {
+                                                              const uint32_t *__restrict__ deferred_rows, uint32_t region,
+                                                              uint8_t *__restrict__ digest32, uint8_t *__restrict__ prop_digest32) {
   __shared__ uint64_t A[32], B[32];
   const uint32_t row = deferred_rows[blockIdx.x >> 1], lane = threadIdx.x;
+  // region ≠ 0: the deferred rows form a batch of their own at rows [region, region + deferred) of the columns (cert_carrier_stage_kernel)
+  const uint32_t digest_row = region ? region + (blockIdx.x >> 1) : row;
   const bool proposal_job = blockIdx.x & 1u;
   const wire::node_info nd = nodes[row];
   if (rows[row].status != wire::STATUS_OK) return;  // block-uniform: not judged here
@@ -1212,20 +1214,44 @@ __global__ void __launch_bounds__(64) cert_digest_wave_kernel(const uint8_t *__r
     sp.permute(A, B);
     if (last) break;
   }
-  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 : digest32) + 32ull * row + 8u * lane) = sp.s;
+  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 + 32ull * row : digest32 + 32ull * digest_row) + 8u * lane) = sp.s;
 }
 // After the deferred digests: every row's final pre-flag and class bits, and the hash of the Proposal it carries (a lane per row;
 // proposals are short next to the messages that carry certificates)
+// two_launches: the deferred rows are judged as a batch of their own (cert_carrier_stage_kernel) while the verdict launch over the
+// other rows is already running — their pre-flags in the tree's own rows must keep saying "verdict 0".
 __global__ void __launch_bounds__(64) cert_finish_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
                                                          const wire::row_info *__restrict__ rows, uint32_t n,
                                                          uint8_t *__restrict__ digest32, uint8_t *__restrict__ prop_digest32,
-                                                         uint8_t *__restrict__ pre_flags) {
+                                                         uint8_t *__restrict__ pre_flags, uint32_t two_launches) {
   const uint32_t row = blockIdx.x * 64u + threadIdx.x;
   if (row >= n) return;
   wire::node_info nd = nodes[row];
   const uint8_t before = nd.flags;
-  wire::tree_digest_row(wire_bytes, rows + row, &nd, digest32 + 32ull * row, prop_digest32 + 32ull * row, pre_flags + row, false);  // a deferred row's digests are there already
+  uint8_t unused = 0;
+  wire::tree_digest_row(wire_bytes, rows + row, &nd, digest32 + 32ull * row, prop_digest32 + 32ull * row, two_launches ? &unused : pre_flags + row,
+                        false);  // a deferred row's digests are there already
   if (nd.flags != before) nodes[row].flags = nd.flags;
+}
+// The batch of the deferred rows: signature, From and pre-flag of deferred row k → row region + k of the columns (its digest is
+// written there by cert_digest_wave_kernel); after the second verdict launch cert_scatter_kernel brings the bits home.
+__global__ void cert_carrier_stage_kernel(const wire::node_info *__restrict__ nodes, const wire::row_info *__restrict__ rows,
+                                          const uint32_t *__restrict__ deferred_rows, uint32_t n_deferred, uint32_t region,
+                                          uint8_t *__restrict__ sig65, uint8_t *__restrict__ from20, uint8_t *__restrict__ pre_flags) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_deferred) return;
+  const uint32_t row = deferred_rows[k], dst = region + k;
+  const wire::row_info &ri = rows[row];
+  const bool judged = ri.status == wire::STATUS_OK && nodes[row].len <= wire::TREE_DIGEST_MAX_BYTES;
+  for (int i = 0; i < 65; i++) sig65[65ull * dst + i] = sig65[65ull * row + i];
+  for (int i = 0; i < 20; i++) from20[20ull * dst + i] = from20[20ull * row + i];
+  pre_flags[dst] = (uint8_t)((judged ? 0 : 1) | (ri.sig_len == 65 && ri.from_len == 20 ? 0 : 2));
+}
+__global__ void cert_scatter_kernel(const uint32_t *__restrict__ deferred_rows, uint32_t n_deferred, uint32_t region, uint64_t *__restrict__ mask) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_deferred) return;
+  const uint32_t src = region + k, row = deferred_rows[k];
+  if ((mask[src >> 6] >> (src & 63u)) & 1ull) atomicOr((unsigned long long *)(mask + (row >> 6)), 1ull << (row & 63u));
 }
 // hash / self bits and the routing byte of every row (wire::tree_compare_row), one verdict word per wavefront
 __global__ void __launch_bounds__(256) cert_compare_kernel(const wire::node_info *__restrict__ nodes, const wire::row_info *__restrict__ rows,
