@@ -118,7 +118,7 @@ struct ibft_ctx {
   // certificates from wire bytes (ibft_verify_certificates_wire): tree nodes, where each row's nested messages lie,
   // child counts of the level being expanded, proposal digests, hash / self words; the row count of the next level
   // comes back through one mapped word
-  DevBuf d_cert_nodes, d_cert_span, d_cert_count, d_cert_prop, d_cert_masks, d_cert_total, d_cert_slot;
+  DevBuf d_cert_nodes, d_cert_span, d_cert_count, d_cert_prop, d_cert_masks, d_cert_total, d_cert_slot, d_cert_tiles;
   uint32_t *h_cert_total = nullptr, *dh_cert_total = nullptr;
   hipEvent_t ev_cert_fork = nullptr, ev_cert_join = nullptr;  // the side stream (hstream) hashes the deferred rows next to the verdict launch
   bool cert_overlap = true;                                   // IBFT_CERT_OVERLAP=0: everything on one stream, one verdict launch
@@ -920,7 +920,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
                     &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
                     &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total,
-                    &c->d_cert_slot})
+                    &c->d_cert_slot, &c->d_cert_tiles})
     release(*b);
   if (c->h_cert_total) (void)hipHostFree(c->h_cert_total);
   if (c->ev_cert_fork) (void)hipEventDestroy(c->ev_cert_fork);
@@ -1686,6 +1686,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
   if ((rc = ensure(c, c->d_cert_prop, m * 32))) return rc;
   if ((rc = ensure(c, c->d_cert_masks, (size_t)mask_words(m) * 16))) return rc;
   if ((rc = ensure(c, c->d_cert_total, 64))) return rc;
+  if ((rc = ensure(c, c->d_cert_tiles, (m / 1024 + 2) * 8))) return rc;
   if (!c->h_cert_total) {
     if (hipHostMalloc((void **)&c->h_cert_total, 64) != hipSuccess) return IBFT_E_NOMEM;
     void *d = nullptr;
@@ -1726,8 +1727,18 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
     hipLaunchKernelGGL(ibftk::cert_walk_kernel<false>, dim3(cnt), dim3(64), 0, c->stream, d_wire, d_nodes, d_rows, (const uint2 *)d_span, lo, hi,
                        d_count);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(ibftk::cert_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_count, d_nodes, lo, hi, hi, carriers,
-                       d_slot, d_total, c->dh_cert_total);
+    if (cnt <= 8192u) {
+      hipLaunchKernelGGL(ibftk::cert_scan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t *)d_count, d_nodes, lo, hi, hi, carriers,
+                         d_slot, d_total, c->dh_cert_total);
+    } else {  // a long level: per-tile sums, their scan, per-tile scans 
+      const uint32_t tiles = (cnt + 1023u) / 1024u;
+      uint2 *d_tiles = (uint2 *)c->d_cert_tiles.p;
+      hipLaunchKernelGGL(ibftk::cert_scan_tiles_kernel, dim3(tiles), dim3(1024), 0, c->stream, (const uint32_t *)d_count, cnt, d_tiles);
+      hipLaunchKernelGGL(ibftk::cert_scan_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, d_tiles, tiles, hi, carriers, d_total,
+                         c->dh_cert_total);
+      hipLaunchKernelGGL(ibftk::cert_scan_apply_kernel, dim3(tiles), dim3(1024), 0, c->stream, (const uint32_t *)d_count, d_nodes, lo, cnt,
+                         (const uint2 *)d_tiles, d_slot);
+    }
     HIPCHK(c, hipGetLastError());
     if (!c->dh_cert_total) HIPCHK(c, hipMemcpyAsync(c->h_cert_total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1765,6 +1776,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
     HIPCHK(c, hipEventRecord(c->ev_cert_fork, c->stream));
     HIPCHK(c, hipStreamWaitEvent(ds, c->ev_cert_fork, 0));
   }
+  HIPCHK(c, hipMemsetAsync(d_prop, 0, (size_t)rows * 32, ds));  // rows without a Proposal: a zero digest (cert_finish_kernel skips them)
   if (carriers) {
     hipLaunchKernelGGL(ibftk::cert_digest_wave_kernel, dim3(2 * carriers), dim3(64), 0, ds, d_wire, (const wire::node_info *)d_nodes,
                        (const wire::row_info *)d_rows, (const uint32_t *)d_slot, region, d_digest, d_prop);

@@ -177,10 +177,15 @@ def cert_routes(batch_verifier, wire: bytes, off, route: int, rows_cap: int = 0)
     import numpy as np
     off = np.ascontiguousarray(off, dtype=np.uint32)
     L = lib()
-    L.ibft_host_cert_routes.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_size_t),
+    L.ibft_host_cert_routes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if isinstance(wire, np.ndarray):  # e.g. a page-locked buffer (verifier.pinned_copy): handed over as it is
+        wire_ptr, keep = wire.ctypes.data_as(C.c_void_p), wire
+    else:
+        keep = np.frombuffer(bytes(wire) or b"\0", dtype=np.uint8)
+        wire_ptr = keep.ctypes.data_as(C.c_void_p)
     rows, valid, hms, tms = C.c_size_t(0), C.c_size_t(0), C.c_double(0.0), C.c_double(0.0)
-    rc = L.ibft_host_cert_routes(batch_verifier._h, bytes(wire) or b"\0", off.ctypes.data_as(C.c_void_p), len(off) - 1, route, rows_cap,
+    rc = L.ibft_host_cert_routes(batch_verifier._h, wire_ptr, off.ctypes.data_as(C.c_void_p), len(off) - 1, route, rows_cap,
                                  C.byref(rows), C.byref(valid), C.byref(hms), C.byref(tms))
     if rc != 0:
         raise RuntimeError(f"ibft_host_cert_routes: {rc}")

@@ -21,8 +21,9 @@ import cert_cases as CC  # noqa: E402
 from oracle import wire  # noqa: E402  (input generation only)
 from oracle import workload as W  # noqa: E402
 
-sizes = [int(x) for x in sys.argv[1:]] or [64, 256]
-out = {"note": "wire bytes in ordinary host memory; every form ends with host-visible verdicts; keys: cold = no key known, "
+pinned = "--pinned" in sys.argv  # the wire bytes in an ibft_pinned_alloc buffer (what a transport that receives into such buffers hands over)
+sizes = [int(x) for x in sys.argv[1:] if not x.startswith("--")] or [64, 256]
+out = {"wire_memory": "ibft_pinned_alloc" if pinned else "ordinary (pageable)", "note": "wire bytes in ordinary host memory unless wire_memory says otherwise; every form ends with host-visible verdicts; keys: cold = no key known, "
                "warm = IBFT_FLAG_PUBKEY_CACHE after one pass"}
 for n in sizes:
     reps = 30 if n <= 256 else 6
@@ -33,6 +34,8 @@ for n in sizes:
     pcb = wire.prepared_certificate(pm, prepares)
     rcs = [CC.round_change(r, i, 5, 2, wire.Proposal(r.raw, 1), pcb).encode() for i in range(q)]
     buf, off = CC.pack(rcs)
+    if pinned:
+        buf = V.pinned_copy(np.frombuffer(buf, dtype=np.uint8))
     rows_expected = q * (q + 1)
     res = {"validators": n, "round_change_messages": q, "signatures": rows_expected, "wire_bytes": len(buf)}
     for name, flags in (("cold", 0), ("warm", V.FLAG_PUBKEY_CACHE)):
