@@ -1020,15 +1020,13 @@ struct lds_window {
 };
 // A certificate is a run of length-prefixed messages: finding message k needs the lengths of the k − 1 before it, a
 // chain of dependent loads (≈1 µs each from HBM: a PreparedCertificate of 2 731 PREPAREs would take milliseconds).  So a
-// wavefront brings the certificate through LDS in 16 KiB windows (coalesced), lane 0 hops from header to header there,
-// and all lanes write the child rows it found.
+// wavefront brings the certificate through LDS in 16 KiB windows (coalesced) and hops from header to header there — one
+// message at a time (≈0.6 µs each), or, where the messages are of one size, up to 64 at a time (RUN, below).
 template <bool FILL>
 __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
                                                        wire::row_info *__restrict__ rows, const uint2 *__restrict__ cert_span,
                                                        uint32_t lo, uint32_t hi, uint32_t *__restrict__ child_count) {
   __shared__ __attribute__((aligned(16))) uint8_t win[CERT_WIN_BYTES + 16];
-  __shared__ uint32_t rec_pos[64], rec_len[64], rec_role[64];
-  __shared__ uint32_t sh_n, sh_pos, sh_last, sh_ok;
   const uint32_t row = lo + blockIdx.x, lane = threadIdx.x;
   if (row >= hi) return;
   const wire::node_info nd = nodes[row];
@@ -1040,52 +1038,67 @@ __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict
   }
   const bool pc = rows[row].payload_kind == wire::KIND_ROUND_CHANGE;
   const uint2 span = cert_span[row];
+  // everything below is wave-uniform: every lane decodes the same header from LDS (broadcast reads) — except the RUN step
   uint32_t pos = nd.off + span.x, last = 0, count = 0;
   const uint32_t end = pos + span.y;
+  uint32_t H = 0, L = 0, S = 0;  // header bytes, body length and stride of the last message hopped over (S = 0: none yet)
+  uint8_t role_s = 0;
   bool ok = true;
+  auto emit = [&](uint32_t ordinal, uint32_t off, uint32_t len, uint8_t role) {
+    wire::node_info c{};
+    c.off = off;
+    c.len = len;
+    c.parent = row;
+    c.ordinal = ordinal;
+    c.level = (uint8_t)(nd.level + 1);
+    c.role = role;
+    nodes[nd.first_child + ordinal] = c;
+  };
   while (pos < end && ok) {
     const uint32_t w0 = pos & ~15u;
     const uint32_t wend = end - w0 <= CERT_WIN_BYTES ? end : w0 + CERT_WIN_BYTES;
     stage_bytes(win, wire_bytes + w0, wend - w0, lane);
     __syncthreads();
-    if (lane == 0) {
-      const lds_window W{win, w0};
-      uint32_t nrec = 0, p = pos, l = last, good = 1;
-      while (p < wend && nrec < 64u) {
-        if (p + 6u > wend && wend < end) break;  // tag + length prefix (≤ 6 bytes) may cross the window: next window starts here
-        uint32_t len;
-        uint8_t role;
-        if (!wire::cert_child_header(W, end, pc, l, p, len, role)) {
-          good = 0;
-          break;
+    const lds_window W{win, w0};
+    while (pos < wend) {
+      if (pos + 6u > wend && wend < end) break;  // tag + length prefix (≤ 6 bytes) may cross the window: the next window starts here
+      // RUN: the messages of a certificate are mostly of one size (PREPAREs of one view).  Lane j checks that a message of the last
+      // stride starts at pos + j·S — same field, same header, same length; if lanes 0 … k−1 all agree, the chain pos → pos + S → …
+      // is proven link by link and k messages are hopped over at once (one LDS round trip instead of k dependent ones).
+      if (S) {
+        const uint64_t q64 = (uint64_t)pos + (uint64_t)lane * S;
+        bool good = q64 + S <= end && (q64 + 6u <= wend || wend == end);  // fits the certificate; its header lies in the window
+        const uint32_t q = (uint32_t)q64;
+        if (good) {
+          uint32_t qq = q, len_j = 0, l2 = last;
+          uint8_t role_j = 0;
+          good = wire::cert_child_header(W, end, pc, l2, qq, len_j, role_j) && len_j == L && qq - q == H && role_j == role_s && l2 == last;
         }
-        rec_pos[nrec] = p;
-        rec_len[nrec] = len;
-        rec_role[nrec] = role;
-        nrec++;
-        p += len;  // the message itself is skipped: its own lane walks it on the next level
+        const uint64_t m = __ballot(good);
+        const uint32_t k = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);  // lanes 0 … k−1 agree
+        if (k) {
+          if (FILL && lane < k) emit(count + lane, q + H, L, role_s);
+          count += k;
+          pos += k * S;
+          continue;
+        }
       }
-      sh_n = nrec;
-      sh_pos = p;
-      sh_last = l;
-      sh_ok = good;
+      // one message
+      uint32_t p2 = pos, len1 = 0, l2 = last;
+      uint8_t role1 = 0;
+      if (!wire::cert_child_header(W, end, pc, l2, p2, len1, role1)) {
+        ok = false;
+        break;
+      }
+      if (FILL && lane == 0) emit(count, p2, len1, role1);
+      H = p2 - pos;
+      L = len1;
+      S = H + L;
+      role_s = role1;
+      last = l2;
+      count++;
+      pos = p2 + len1;  // the message itself is skipped: its own lane walks it on the next level
     }
-    __syncthreads();
-    const uint32_t nrec = sh_n;
-    ok = sh_ok != 0;
-    if (FILL && lane < nrec) {
-      wire::node_info c{};
-      c.off = rec_pos[lane];
-      c.len = rec_len[lane];
-      c.parent = row;
-      c.ordinal = count + lane;
-      c.level = (uint8_t)(nd.level + 1);
-      c.role = (uint8_t)rec_role[lane];
-      nodes[nd.first_child + count + lane] = c;
-    }
-    count += nrec;
-    pos = sh_pos;
-    last = sh_last;
     __syncthreads();
   }
   if (!FILL && lane == 0) {
