@@ -962,15 +962,18 @@ __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, c
 // ibft_verify_certificates_wire: PREPREPARE / ROUND_CHANGE messages carry messages (RoundChangeCertificate,
 // PreparedCertificate: core/ibft.go:470-551, 683-788 verify every one of them).  Level by level, rows [lo, hi) of one
 // level at a time:
-//   cert_parse_kernel       a lane per message: the DEEP walk of its own fields, sender columns, digest of a message
+//   cert_parse_kernel       a lane per message: the DEEP walk of its own fields, sender columns, digest of a short message
 //                           that has nothing below it; where its nested messages lie goes to cert_span
 //   cert_walk_kernel<false> a wavefront per message with a certificate: counts (and checks) the nested messages
 //   cert_scan_kernel        exclusive scan of the counts: every row's children become a contiguous row range of the next
-//                           level, in order; the total goes to the host, which sizes the next level's launches
+//   (cert_scan_tiles/_offsets/_apply for a long level)  level, in order, and the rows whose digest is deferred are listed;
+//                           the totals go to the host, which sizes the next level's launches
 //   cert_walk_kernel<true>  the same walk again, writing the child rows
 // then, bottom-up, cert_propagate_kernel (a message with a non-canonical message below it is not canonical either),
-// cert_digest_kernel (PayloadNoSig digests of the messages that carry certificates, proposal hashes),
-// cert_compare_kernel (hash bits), and ONE verdict launch over all rows of all levels.
+// cert_digest_wave_kernel (the deferred digests — messages that carry certificates, long messages — and the proposal hashes:
+// one wavefront per sponge, wave_sponge), cert_finish_kernel (final pre-flags and class bits), the verdict launch over all
+// rows — or, with the digests on a side stream, over the rows that are not deferred, and a second small one over the deferred
+// rows (cert_carrier_stage_kernel, cert_scatter_kernel) —, cert_compare_kernel (hash bits).
 constexpr uint32_t CERT_WIN_BYTES = 16 * 1024;
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   for (int o = 32; o; o >>= 1) {
