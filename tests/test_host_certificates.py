@@ -204,3 +204,67 @@ def test_validate_proposal_max_round_hash_rule():
     assert not mk(False).validate_proposal(wrong, 0, round_)      # the reference's (uninitialised) outcome
     assert not mk(True).validate_proposal(wrong, 0, round_)       # ... and for the reason the case names
     assert mk(True).validate_proposal(right, 0, round_)
+
+
+# ------------------------------------------------------------------ handlePrePrepare (core/ibft.go:792-813)
+RAW_BLOCK = b"valid ethereum block"
+
+
+def _filled_rc_messages(quorum, proposal, proposal_hash):
+    """generateFilledRCMessages (core/ibft_test.go:158-216)"""
+    prepares = [W.IbftMessage(view=W.View(0, 1), sender=b"node %d" % (k + 1), type=PR, payload=W.prepare_body(proposal_hash))
+                for k in range(quorum - 1)]
+    pm = W.IbftMessage(view=W.View(0, 1), sender=b"unique node", type=PP, payload=W.preprepare_body(proposal, proposal_hash, None))
+    pc = W.prepared_certificate(pm, prepares)
+    return [W.IbftMessage(view=W.View(0, 1), sender=b"node %d" % k, type=RC, payload=W.round_change_body(proposal, pc))
+            for k in range(quorum)]
+
+
+@pytest.mark.parametrize("mode", ["stock", "batch", "arrival"])
+def test_handle_preprepare_replays_run_new_round_validator(mode):
+    """The handlePrePrepare slice of TestRunNewRound_Validator_Zero (core/ibft_test.go:603-696) and
+    TestRunNewRound_Validator_NonZero (:701-866): a non-proposer accepts the proposer's PREPREPARE of round 0, and of round 1 with a
+    RoundChangeCertificate of plain ROUND-CHANGE messages ("new block") or of ROUND-CHANGE messages carrying the previously prepared
+    proposal and its certificate ("old block").  stock = per-message Verifier; batch = certificate batches gathered by the walk;
+    arrival = the messages come in through IngestWire and their certificates are judged then."""
+    def mk(cnt, view):
+        h = H.Host()
+        assert h.vm_init({b"node %d" % k: 1 for k in range(cnt)})
+        h.set_id(b"non proposer")
+        h.set_verifier(is_proposer=lambda who, hh, rr: who == b"proposer")
+        h.set_state(0, view[1], None)
+        if mode != "stock":
+            h.use_loop_batch(0)
+            h.use_batch(True)
+        return h
+
+    def deliver(h, wire):
+        if mode == "arrival":
+            assert h.ingest_wire([wire])[0][0] in (1, 2)
+        else:
+            assert h.store_add(wire) == 0
+    # round 0 (Validator_Zero): Proposal present, no hash, no certificate
+    h = mk(1, (0, 0))
+    p0 = W.IbftMessage(view=W.View(0, 0), sender=b"proposer", type=PP, payload=W.preprepare_body(W.Proposal(RAW_BLOCK, 0), b"", None))
+    deliver(h, p0.encode())
+    assert h.handle_preprepare(0, 0) == p0.encode()
+    h.close()
+    # round 1 (Validator_NonZero), both certificates
+    quorum = 4
+    proposal = W.Proposal(RAW_BLOCK, 1)
+    plain = [W.IbftMessage(view=W.View(0, 1), sender=b"node %d" % k, type=RC, payload=W.round_change_body(None, None)) for k in range(quorum)]
+    for rcs in (plain, _filled_rc_messages(quorum, proposal, b"proposal hash")):
+        h = mk(quorum, (0, 1))
+        p1 = W.IbftMessage(view=W.View(0, 1), sender=b"proposer", type=PP,
+                           payload=W.preprepare_body(proposal, b"proposal hash", W.round_change_certificate(rcs)))
+        deliver(h, p1.encode())
+        assert h.handle_preprepare(0, 1) == p1.encode()
+        if mode == "arrival":
+            assert h.cert_stats()[0] == 1 and h.loop_batch_cert_calls() == 1
+        # a PREPREPARE from somebody who is not the proposer is pruned and nothing is accepted
+        h2 = mk(quorum, (0, 1))
+        bad = W.IbftMessage(view=W.View(0, 1), sender=b"node 2", type=PP,
+                            payload=W.preprepare_body(proposal, b"proposal hash", W.round_change_certificate(rcs)))
+        deliver(h2, bad.encode())
+        assert h2.handle_preprepare(0, 1) is None and h2.store_num(0, 1, PP) == 0
+        h.close(); h2.close()
