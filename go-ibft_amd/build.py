@@ -7,10 +7,11 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libibftgpu.so")
-SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "modinv_dev.h",
+SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "cert_wave_dev.h", "modinv_dev.h",
            "sign_dev.h", "secp256k1_dev.h", "keccak_dev.h", os.path.join("..", "..", "include", "ibftgpu.h")]
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
+CERT_WAVE_HARNESS = os.path.join(CSRC, "libdev_cert_wave_host.so")
 
 
 def _digest(deps: list[str], extra: str = "") -> str:
@@ -81,6 +82,16 @@ def build_wave_harness(force: bool = False) -> str:
                                "-o", WAVE_HARNESS, os.path.join(CSRC, "host_wave_harness.hip")], cwd=CSRC)
         _mark(WAVE_HARNESS, deps)
     return WAVE_HARNESS
+
+
+def build_cert_wave_harness(force: bool = False) -> str:
+    """TEST-ONLY: cert_wave_dev.h (Keccak by one wavefront, the certificate walk) on the CPU through wave_emul.h."""
+    deps = ["host_cert_wave_harness.hip", "cert_wave_dev.h", "wave_emul.h", "wire_dev.h", "keccak_dev.h"]
+    if force or _stale(CERT_WAVE_HARNESS, deps):
+        subprocess.check_call(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-shared", "-fPIC",
+                               "-o", CERT_WAVE_HARNESS, os.path.join(CSRC, "host_cert_wave_harness.hip")], cwd=CSRC)
+        _mark(CERT_WAVE_HARNESS, deps)
+    return CERT_WAVE_HARNESS
 
 
 if __name__ == "__main__":

@@ -33,6 +33,7 @@
 #include "sign_dev.h"
 #include "wave_fe_dev.h"
 #include "wire_dev.h"
+#include "cert_wave_dev.h"
 
 namespace ibftk {
 
@@ -238,51 +239,6 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) sign_lane_kernel(sign_args a) 
   a.ok[row] = ok ? 1 : 0;
 }
 
-// ---- Keccak-256 of one long message by one wavefront -------------------------------------------------------------------
-// A sponge is sequential, and one lane (or the scalar unit) spends ≈9–14 µs on a 136-byte block: ≈188 64-bit operations per round
-// at one instruction per ≈4 ticks.  A message that carries a certificate is tens of kilobytes, so here 25 lanes hold one
-// 64-bit word of the state each (lane i = x + 5y) and the words meet in LDS: per round every lane
-//   θ   writes its word, reads the two neighbouring COLUMNS (10 words), forms D[x] = C[x−1] ^ rotl(C[x+1], 1) itself;
-//   ρ,π rotates its word by its own offset and writes it to where π sends it;
-//   χ,ι reads the two words to its right in its row, combines, lane 0 adds the round constant.
-// Two dependent LDS round trips and ≈35 VALU instructions per round instead of ≈190 (or ≈380 32-bit ones).
-__device__ const uint8_t KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-__device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t r) { return r ? (v << r) | (v >> (64u - r)) : v; }
-// The lane's share of the state and where its neighbours are.  One wavefront per workgroup (no s_barrier is emitted for
-// __syncthreads, only the ordering of the LDS accesses); A and B are 32 × u64 of LDS each.
-struct wave_sponge {
-  uint64_t s;  // state word i = x + 5y of lane i < 25 (lanes 25…63 mirror lane 0 and never write)
-  uint32_t i, cm, cp, pi, r1, r2, rho;
-  bool act, first;
-  __device__ __forceinline__ void init(uint32_t lane) {
-    act = lane < 25u;
-    first = lane == 0;
-    i = act ? lane : 0u;
-    const uint32_t x = i % 5u, y = i / 5u;
-    cm = (x + 4u) % 5u;                       // the columns on either side
-    cp = (x + 1u) % 5u;
-    pi = y + 5u * ((2u * x + 3u * y) % 5u);   // where π sends this lane's word
-    r1 = (x + 1u) % 5u + 5u * y;
-    r2 = (x + 2u) % 5u + 5u * y;
-    rho = KECCAK_RHO[i];
-    s = 0;
-  }
-  __device__ __forceinline__ void permute(uint64_t *A, uint64_t *B) {
-#pragma unroll
-    for (int round = 0; round < 24; round++) {  // unrolled: the round constants are literals, nothing is loaded inside the chain
-      if (act) A[i] = s;
-      __syncthreads();
-      const uint64_t c_minus = A[cm] ^ A[cm + 5] ^ A[cm + 10] ^ A[cm + 15] ^ A[cm + 20];
-      const uint64_t c_plus = A[cp] ^ A[cp + 5] ^ A[cp + 10] ^ A[cp + 15] ^ A[cp + 20];
-      s ^= c_minus ^ ((c_plus << 1) | (c_plus >> 63));
-      if (act) B[pi] = rotl64_var(s, rho);
-      __syncthreads();
-      s = B[i] ^ (~B[r1] & B[r2]);
-      s ^= first ? keccak::rc(round) : 0ull;
-    }
-  }
-};
-
 // ---- proposal hash + a1 ---------------------------------------------------------------
 // One sponge is sequential; one wavefront walks it with the state spread over 25 lanes (wave_sponge: ≈5.3 µs per 136-byte
 // block; a single lane — scalar 64-bit code, ≈188 operations per round — needed ≈9.4 µs).  The host hands the message over
@@ -291,7 +247,7 @@ struct wave_sponge {
 __global__ void __launch_bounds__(64) proposal_hash_kernel(const uint64_t *__restrict__ padded, uint32_t blocks, uint64_t *__restrict__ out4) {
   __shared__ uint64_t A[32], B[32];
   const uint32_t lane = threadIdx.x;
-  wave_sponge sp;
+  cw::wave_sponge sp;
   sp.init(lane);
   for (uint32_t b = 0; b < blocks; b++) {
     if (lane < 17u) sp.s ^= padded[17u * b + lane];
@@ -844,27 +800,6 @@ __global__ void qtab_commit_kernel(uint32_t *__restrict__ pub_state, uint32_t n_
 // first (a lane walking ≈200 bytes of HBM one dependent byte load at a time made this kernel 75 µs), and every lane
 // walks and hashes its message from there.  A wavefront whose messages exceed the buffer reads HBM directly.
 constexpr uint32_t WIRE_LDS_BYTES = 32 * 1024;
-// nbytes of HBM at src (16-byte aligned) → LDS, one wavefront: 16-byte loads, four in flight per lane.  (A dword per lane and
-// trip — the first form — is a chain of ≈1 µs round trips: 16 KiB took ≈50 µs.)  Reads up to 15 bytes past src + nbytes: the
-// payload buffer carries 256 bytes of slack; the LDS buffer must hold nbytes rounded up to 16.
-__device__ __forceinline__ void stage_bytes(uint8_t *lds, const uint8_t *src, uint32_t nbytes, uint32_t lane) {
-  const uint32_t chunks = (nbytes + 15u) >> 4;
-  const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-  uint4 *d4 = reinterpret_cast<uint4 *>(lds);
-  for (uint32_t c0 = 0; c0 < chunks; c0 += 256u) {
-    uint4 v[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) {
-      const uint32_t c = c0 + lane + 64u * k;
-      v[k] = c < chunks ? s4[c] : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) {
-      const uint32_t c = c0 + lane + 64u * k;
-      if (c < chunks) d4[c] = v[k];
-    }
-  }
-}
 __global__ void __launch_bounds__(64) wire_parse_kernel(const uint8_t *__restrict__ wire_bytes, const uint32_t *__restrict__ off,
                                                         uint32_t n, wire::row_info *__restrict__ rows,
                                                         uint8_t *__restrict__ digest32, uint8_t *__restrict__ sig65,
@@ -876,7 +811,7 @@ __global__ void __launch_bounds__(64) wire_parse_kernel(const uint8_t *__restric
   const uint32_t b0 = off[row0] & ~15u, b1 = off[row0 + cnt];
   const bool staged = b1 - b0 <= WIRE_LDS_BYTES;  // wave-uniform
   if (staged) {
-    stage_bytes(lbuf, wire_bytes + b0, b1 - b0, lane);
+    cw::stage_bytes(lbuf, wire_bytes + b0, b1 - b0, lane);
     __syncthreads();
   }
   const uint32_t row = row0 + lane;
@@ -974,7 +909,6 @@ __global__ void wire_set_stage_kernel(const wire::row_info *__restrict__ rows, c
 // one wavefront per sponge, wave_sponge), cert_finish_kernel (final pre-flags and class bits), the verdict launch over all
 // rows — or, with the digests on a side stream, over the rows that are not deferred, and a second small one over the deferred
 // rows (cert_carrier_stage_kernel, cert_scatter_kernel) —, cert_compare_kernel (hash bits).
-constexpr uint32_t CERT_WIN_BYTES = 16 * 1024;
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   for (int o = 32; o; o >>= 1) {
     const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64);
@@ -1004,7 +938,7 @@ __global__ void __launch_bounds__(64) cert_parse_kernel(const uint8_t *__restric
   const uint32_t b0 = wave_min_u32(live ? nd.off : 0xFFFFFFFFu) & ~15u, b1 = wave_max_u32(live ? nd.off + nd.len : 0u);
   const bool staged = b1 >= b0 && b1 - b0 <= WIRE_LDS_BYTES;  // wave-uniform
   if (staged) {
-    stage_bytes(lbuf, wire_bytes + b0, b1 - b0, lane);
+    cw::stage_bytes(lbuf, wire_bytes + b0, b1 - b0, lane);
     __syncthreads();
   }
   if (!live) return;
@@ -1015,21 +949,12 @@ __global__ void __launch_bounds__(64) cert_parse_kernel(const uint8_t *__restric
   nodes[row] = nd;
   cert_span[row] = make_uint2(span[0], span[1]);
 }
-// bytes [w0, …) of the buffer held in LDS, addressed by their position in the buffer
-struct lds_window {
-  const uint8_t *win;
-  uint32_t w0;
-  __device__ __forceinline__ uint8_t operator[](uint32_t a) const { return win[a - w0]; }
-};
-// A certificate is a run of length-prefixed messages: finding message k needs the lengths of the k − 1 before it, a
-// chain of dependent loads (≈1 µs each from HBM: a PreparedCertificate of 2 731 PREPAREs would take milliseconds).  So a
-// wavefront brings the certificate through LDS in 16 KiB windows (coalesced) and hops from header to header there — one
-// message at a time (≈0.6 µs each), or, where the messages are of one size, up to 64 at a time (RUN, below).
+// A wavefront per message with a certificate lists (FILL) or counts and checks (!FILL) its nested messages: cw::walk_certificate.
 template <bool FILL>
 __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict__ wire_bytes, wire::node_info *__restrict__ nodes,
                                                        wire::row_info *__restrict__ rows, const uint2 *__restrict__ cert_span,
                                                        uint32_t lo, uint32_t hi, uint32_t *__restrict__ child_count) {
-  __shared__ __attribute__((aligned(16))) uint8_t win[CERT_WIN_BYTES + 16];
+  __shared__ __attribute__((aligned(16))) uint8_t win[cw::CERT_WIN_BYTES + 16];
   const uint32_t row = lo + blockIdx.x, lane = threadIdx.x;
   if (row >= hi) return;
   const wire::node_info nd = nodes[row];
@@ -1041,13 +966,10 @@ __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict
   }
   const bool pc = rows[row].payload_kind == wire::KIND_ROUND_CHANGE;
   const uint2 span = cert_span[row];
-  // everything below is wave-uniform: every lane decodes the same header from LDS (broadcast reads) — except the RUN step
-  uint32_t pos = nd.off + span.x, last = 0, count = 0;
-  const uint32_t end = pos + span.y;
-  uint32_t H = 0, L = 0, S = 0;  // header bytes, body length and stride of the last message hopped over (S = 0: none yet)
-  uint8_t role_s = 0;
+  const uint32_t pos = nd.off + span.x;
   bool ok = true;
-  auto emit = [&](uint32_t ordinal, uint32_t off, uint32_t len, uint8_t role) {
+  uint32_t count = cw::walk_certificate(wire_bytes, pos, pos + span.y, pc, win, lane, ok, [&](uint32_t ordinal, uint32_t off, uint32_t len, uint8_t role) {
+    if (!FILL) return;
     wire::node_info c{};
     c.off = off;
     c.len = len;
@@ -1056,54 +978,7 @@ __global__ void __launch_bounds__(64) cert_walk_kernel(const uint8_t *__restrict
     c.level = (uint8_t)(nd.level + 1);
     c.role = role;
     nodes[nd.first_child + ordinal] = c;
-  };
-  while (pos < end && ok) {
-    const uint32_t w0 = pos & ~15u;
-    const uint32_t wend = end - w0 <= CERT_WIN_BYTES ? end : w0 + CERT_WIN_BYTES;
-    stage_bytes(win, wire_bytes + w0, wend - w0, lane);
-    __syncthreads();
-    const lds_window W{win, w0};
-    while (pos < wend) {
-      if (pos + 6u > wend && wend < end) break;  // tag + length prefix (≤ 6 bytes) may cross the window: the next window starts here
-      // RUN: the messages of a certificate are mostly of one size (PREPAREs of one view).  Lane j checks that a message of the last
-      // stride starts at pos + j·S — same field, same header, same length; if lanes 0 … k−1 all agree, the chain pos → pos + S → …
-      // is proven link by link and k messages are hopped over at once (one LDS round trip instead of k dependent ones).
-      if (S) {
-        const uint64_t q64 = (uint64_t)pos + (uint64_t)lane * S;
-        bool good = q64 + S <= end && (q64 + 6u <= wend || wend == end);  // fits the certificate; its header lies in the window
-        const uint32_t q = (uint32_t)q64;
-        if (good) {
-          uint32_t qq = q, len_j = 0, l2 = last;
-          uint8_t role_j = 0;
-          good = wire::cert_child_header(W, end, pc, l2, qq, len_j, role_j) && len_j == L && qq - q == H && role_j == role_s && l2 == last;
-        }
-        const uint64_t m = __ballot(good);
-        const uint32_t k = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);  // lanes 0 … k−1 agree
-        if (k) {
-          if (FILL && lane < k) emit(count + lane, q + H, L, role_s);
-          count += k;
-          pos += k * S;
-          continue;
-        }
-      }
-      // one message
-      uint32_t p2 = pos, len1 = 0, l2 = last;
-      uint8_t role1 = 0;
-      if (!wire::cert_child_header(W, end, pc, l2, p2, len1, role1)) {
-        ok = false;
-        break;
-      }
-      if (FILL && lane == 0) emit(count, p2, len1, role1);
-      H = p2 - pos;
-      L = len1;
-      S = H + L;
-      role_s = role1;
-      last = l2;
-      count++;
-      pos = p2 + len1;  // the message itself is skipped: its own lane walks it on the next level
-    }
-    __syncthreads();
-  }
+  });
   if (!FILL && lane == 0) {
     if (!ok) {  // a malformed wrapper: the whole message goes the stock route, nothing below it is listed
       rows[row].status = wire::STATUS_NEEDS_HOST;
@@ -1233,7 +1108,7 @@ __global__ void cert_propagate_kernel(const wire::node_info *__restrict__ nodes,
   const uint32_t parent = nodes[row].parent;
   if (rows[row].status != wire::STATUS_OK && parent != wire::NO_PARENT) rows[parent].status = wire::STATUS_NEEDS_HOST;
 }
-// (Keccak by one wavefront: wave_sponge, above the proposal hash.)
+// (Keccak by one wavefront: cert_wave_dev.h, cw::sponge_message.)
 // One job per wavefront: job 2k hashes PayloadNoSig of deferred row k → digest32[row]; job 2k + 1 hashes the Proposal that row
 // carries, keccak(rawProposal ‖ BE64(round)) → prop_digest32[row] (exits at once when there is none).  The message is
 // piece A = [a0, a0 + na) followed by piece B = [b0, b0 + nb) of the buffer, then `tail` (≤ 8 bytes, by value).
@@ -1265,43 +1140,8 @@ __global__ void __launch_bounds__(64) cert_digest_wave_kernel(const uint8_t *__r
     total = nd.raw_len + 8u;
     for (int k = 0; k < 8; k++) tail |= (uint64_t)((nd.proposal_round >> (8 * (7 - k))) & 0xFFu) << (8 * k);  // BE64 as the bytes lie
   }
-  wave_sponge sp;
-  sp.init(lane);
-  for (uint32_t done = 0;; done += 136u) {
-    const uint32_t left = total - done;
-    const bool last = left < 136u;
-    if (lane < 17u) {
-      const uint32_t v = done + 8u * lane;  // this lane's 8 bytes of the block, in the message
-      uint64_t w = 0;
-      const bool whole = proposal_job ? v + 8u <= cut0 : (v + 8u <= cut0 || v >= cut0);
-      if (!last && whole) {
-        const uint8_t *p = m + (v < cut0 ? v : v + gap);
-        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), sh = 8u * mis;
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(p - mis);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = mis ? q[2] : 0u;
-        const uint32_t lo = (uint32_t)(((uint64_t)d1 << 32 | d0) >> sh), hi = (uint32_t)(((uint64_t)d2 << 32 | d1) >> sh);
-        w = (uint64_t)lo | ((uint64_t)hi << 32);
-      } else {
-        for (uint32_t k = 0; k < 8u; k++) {
-          const uint32_t o = v + k, in_block = 8u * lane + k;
-          uint64_t byte = 0;
-          if (o < total) {
-            if (proposal_job)
-              byte = o < cut0 ? m[o] : (tail >> (8u * (o - cut0))) & 0xFFu;
-            else
-              byte = m[o < cut0 ? o : o + gap];
-          }
-          if (last && in_block == left) byte ^= 0x01u;
-          if (last && in_block == 135u) byte ^= 0x80u;
-          w |= byte << (8u * k);
-        }
-      }
-      sp.s ^= w;
-    }
-    sp.permute(A, B);
-    if (last) break;
-  }
-  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 + 32ull * row : digest32 + 32ull * digest_row) + 8u * lane) = sp.s;
+  const uint64_t word = cw::sponge_message(m, cut0, gap, total, tail, proposal_job, lane, A, B);
+  if (lane < 4u) *reinterpret_cast<uint64_t *>((proposal_job ? prop_digest32 + 32ull * row : digest32 + 32ull * digest_row) + 8u * lane) = word;
 }
 // After the deferred digests: every row's final pre-flag and class bits, and the hash of the Proposal it carries (a lane per row;
 // proposals are short next to the messages that carry certificates)
