@@ -171,3 +171,13 @@ def test_walk_fuzzed_certificates(dev):
         exp = check_walk(dev, cert, True, b"w" * 3)
         stats["ok" if exp is not None else "bad"] += 1
     assert stats["ok"] > 40 and stats["bad"] > 40, stats
+
+
+def test_sponge_public_keccak_vectors(dev):
+    """the third-party Keccak-256 known answers of tests/golden/kats.json through the device sponge source"""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kats.json")))
+    for v in k["public_keccak_vectors"]:
+        m = v["message"].encode()
+        assert keccak_without(dev, m, len(m), len(m)).hex().startswith(v.get("digest", v.get("digest_prefix"))), v["source"]

@@ -80,8 +80,9 @@ def test_public_key_point_and_keccak_vectors(oracle):
     for v in k["public_point_vectors"]:
         assert oracle.pubkey(v["k"].to_bytes(32, "big")).hex() == v["x"] + v["y"]
     for v in k["public_keccak_vectors"]:
-        assert oracle.keccak256(v["message"].encode()).hex() == v["digest"], v["source"]
-        assert pyref.keccak256(v["message"].encode()).hex() == v["digest"]
+        want = v.get("digest", v.get("digest_prefix"))  # some sources publish the first four bytes only (function selectors)
+        assert oracle.keccak256(v["message"].encode()).hex().startswith(want) and len(want) in (8, 64), v["source"]
+        assert pyref.keccak256(v["message"].encode()).hex().startswith(want)
     # the RFC 6979 vectors carry their message: the digest in the file is its SHA-256
     import hashlib
     for v in k["public_recover_vectors"]:
