@@ -380,7 +380,8 @@ int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const ui
  *                   rows that are not inside a PreparedCertificate
  *   out_self_mask   bit row = a PREPREPARE payload's proposalHash equals keccak(its own Proposal)
  *                   (validateProposalCommon, core/ibft.go:640-651)
- * All masks have ⌈rows_cap/64⌉ words.  The tree must fit rows_cap and the context's max_rows: IBFT_E_TOOBIG otherwise
+ * All masks have room for ⌈rows_cap/64⌉ words (the first ⌈*out_n_rows/64⌉ are written); out_hash_mask, out_self_mask and out_class may
+ * be NULL.  The tree must fit rows_cap and the context's max_rows: IBFT_E_TOOBIG otherwise
  * (no verdicts — split the call or take the stock route).  What stays with the caller is everything that is not
  * arithmetic: types, views, rounds, proposer and quorum rules over the From / type / view columns.               */
 #define IBFT_CERT_CLASS_NEEDS_HOST 0x01u
