@@ -268,3 +268,57 @@ def test_handle_preprepare_replays_run_new_round_validator(mode):
         deliver(h2, bad.encode())
         assert h2.handle_preprepare(0, 1) is None and h2.store_num(0, 1, PP) == 0
         h.close(); h2.close()
+
+
+@pytest.mark.parametrize("mode", ["stock", "batch", "arrival"])
+def test_future_proposal_and_future_rcc_replays(mode):
+    """The certificate slices of TestIBFT_FutureProposal (core/ibft_test.go:1328-1506: watchForFutureProposal → handlePrePrepare at a
+    future round, new block / old block) and of TestIBFT_WatchForFutureRCC (:2801-2896: watchForRoundChangeCertificates →
+    handleRoundChangeMessage over ROUND-CHANGE messages of round 10 that carry filled certificates)."""
+    quorum, node_id = 4, b"node ID"
+    good_hash = b"proposal hash"
+
+    def mk(**verifier):
+        h = H.Host()
+        assert h.vm_init({b"node %d" % k: 1 for k in range(quorum)})
+        h.set_id(node_id)
+        h.set_verifier(**verifier)
+        h.set_state(0, 0, None)
+        if mode != "stock":
+            h.use_loop_batch(0)
+            h.use_batch(True)
+        return h
+
+    def deliver(h, wires):
+        if mode == "arrival":
+            assert all(x in (1, 2) for x in h.ingest_wire(wires)[0])
+        else:
+            for wv in wires:
+                assert h.store_add(wv) == 0
+    # --- TestIBFT_FutureProposal
+    fp = dict(is_proposer=lambda who, hh, rr: who != node_id,
+              is_valid_proposal_hash=lambda p, hsh: p is not None and p[0] == RAW_BLOCK and hsh == good_hash)
+    empty_rcs = [W.IbftMessage(view=W.View(0, 1), sender=b"node %d" % k, type=RC, payload=W.round_change_body(None, None)) for k in range(quorum)]
+    filled = _filled_rc_messages(quorum, W.Proposal(RAW_BLOCK, 0), good_hash)
+    for m in filled:
+        m.view = W.View(0, 2)   # setRoundForMessages(messages, 2)
+    for view, rcs in (((0, 1), empty_rcs), ((0, 2), filled)):
+        h = mk(**fp)
+        p = W.IbftMessage(view=W.View(*view), sender=b"proposer", type=PP,
+                          payload=W.preprepare_body(W.Proposal(RAW_BLOCK, view[1]), good_hash, W.round_change_certificate(rcs)))
+        deliver(h, [p.encode()])
+        assert h.handle_preprepare(*view) == p.encode()          # the future proposal is signalled for its round
+        assert h.handle_preprepare(view[0], view[1] + 1) is None   # nothing for another round
+        h.close()
+    # --- TestIBFT_WatchForFutureRCC
+    rcc_round = 10
+    rcs = _filled_rc_messages(quorum, W.Proposal(RAW_BLOCK, 0), good_hash)
+    for m in rcs:
+        m.view = W.View(0, rcc_round)
+    h = mk(is_proposer=lambda who, hh, rr: who == b"unique node")
+    deliver(h, [m.encode() for m in rcs])
+    got = h.handle_round_change(0, rcc_round)
+    assert sorted(got) == sorted(m.encode() for m in rcs)
+    if mode == "arrival":
+        assert h.cert_stats()[2] == quorum * quorum and h.last_cert_batch() == (0, 0)   # every nested verdict came from the tables
+    h.close()
