@@ -13,8 +13,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -67,9 +71,14 @@ struct ibft_ctx {
 
   // multi-GPU exchange (ibft_comm_*): rows of a batch sharded over `xworld` contexts, one all-reduce merges them
   ncclComm_t comm = nullptr;
+  bool xlocal = false;  // a rank of a group whose collective is the library's own sum kernel (no communicator)
   uint32_t xrank = 0, xworld = 1;
   hipStream_t xstream = nullptr;
   DevBuf d_xbuf[2], d_xres[2];
+  DevBuf d_seen_out;    // the last tally's distinct-sender bitmap (⌈n_validators/64⌉ u64 words): what the ranks exchange
+  hipEvent_t ev_xpack = nullptr;  // local collective: this rank's buffer is packed / the summed buffers are back
+  uint32_t x_K[2] = {1, 1};       // verdict arrays of the exchange in each slot (1: seal / sender batch, 2: message set)
+  uint32_t set_n = 0;             // rows of the last message set (its words are in d_set)
   uint64_t *h_xres[2] = {nullptr, nullptr}, *dh_xres[2] = {nullptr, nullptr};
   size_t h_xres_words = 0;
   hipEvent_t ev_xdone[2] = {nullptr, nullptr};
@@ -186,7 +195,9 @@ int alloc_rows(ibft_ctx *c, uint32_t rows) {
   if ((rc = ensure(c, c->d_off, (m + 1) * 4))) return rc;
   if ((rc = ensure(c, c->d_mask, (size_t)mask_words(m) * 8))) return rc;
   if ((rc = ensure(c, c->d_mask_out, (size_t)mask_words(m) * 8))) return rc;
-  if (c->d_mask.p != old_mask) c->mask_dirty_words = ~0u;  // fresh memory: the next verdict launch zeroes it first
+  // fresh memory — or words beyond the rows the last clean covered (a small context's mask buffer is never smaller
+  // than 256 bytes, so growing row_cap need not reallocate it): the next verdict launch zeroes the whole mask first
+  if (c->d_mask.p != old_mask || rows > c->row_cap) c->mask_dirty_words = ~0u;
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
   if ((rc = ensure(c, c->d_tally, (size_t)ibftk::TALLY_OUT_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_acc, (size_t)ibftk::TALLY_ACC_WORDS * 8))) return rc;
@@ -410,6 +421,15 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
   t.host_tally = c->dh_tally;
   t.set_on = set ? 1u : 0u;
   if (set) t.set = *set;
+  if (c->comm || c->xlocal) {  // a rank of a sharded batch: the bitmap of this launch is what the exchange merges
+    const size_t bytes = (size_t)((c->n_validators + 63) / 64) * 8;
+    if (bytes > c->d_seen_out.cap) {
+      int rc = ensure(c, c->d_seen_out, bytes);
+      if (rc) return rc;
+      HIPCHK(c, hipMemsetAsync(c->d_seen_out.p, 0, c->d_seen_out.cap, c->stream));  // (an odd trailing 32-bit word stays 0)
+    }
+    t.seen_out = (uint32_t *)c->d_seen_out.p;
+  }
   const dim3 grid(std::max(1u, (n + ibftk::TALLY_ROWS_PER_BLOCK - 1) / ibftk::TALLY_ROWS_PER_BLOCK)), block(ibftk::TALLY_THREADS);
   // one workgroup (n ≤ 4 096): everything stays in the workgroup — no global atomics on the latency-critical sizes;
   // beyond: ticket form, each workgroup merging its LDS bitmap into the HBM one word by word.  A validator set whose
@@ -684,6 +704,9 @@ void comm_release(ibft_ctx *c) {
     c->h_xres[i] = c->dh_xres[i] = nullptr;
   }
   c->h_xres_words = 0;
+  if (c->ev_xpack) (void)hipEventDestroy(c->ev_xpack);
+  c->ev_xpack = nullptr;
+  c->xlocal = false;
   if (c->xstream) (void)hipStreamDestroy(c->xstream);
   c->xstream = nullptr;
   c->xrank = 0;
@@ -705,31 +728,43 @@ int ensure_handoff_events(ibft_ctx *c) {
 }
 
 struct xplan {
-  uint32_t slot, w, total_words, n_pieces, slots, my_words;
+  uint32_t slot, w, total_words, seen_words, n_pieces, slots, my_words, K;
 };
-// before the collective: order behind the tally, pack this rank's words + partial tally into the exchange buffer
-int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x) {
-  if (!c->comm || !c->have_valset) return c->comm ? IBFT_E_NOVALSET : IBFT_E_INVAL;
+// u64 slots of the exchange buffer: K verdict arrays, one bitmap segment per rank, the count of valid rows
+uint32_t exchange_slots(uint32_t K, uint32_t words_per_rank, uint32_t world, uint32_t n_validators) {
+  return K * words_per_rank * world + world * ((n_validators + 63) / 64) + 1;
+}
+// before the collective: order behind the tally, pack this rank's words + its sender bitmap into the exchange buffer.
+// n_local rows of this rank (seal batch: the staged one; message set: the last set), K verdict arrays.
+int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x, uint32_t K = 1) {
+  if (!(c->comm || c->xlocal) || !c->have_valset) return (c->comm || c->xlocal) ? IBFT_E_NOVALSET : IBFT_E_INVAL;
   if (c->x_issued - c->x_fetched >= 2) {
     c->last_error = "two exchanges already in flight: call ibft_seals_fetch_merged first";
     return IBFT_E_INVAL;
   }
   HIPCHK(c, hipSetDevice(c->device));
   const uint64_t per = shard_rows_per_rank(n_total, c->xworld);
+  const uint32_t n_local = K == 2 ? c->set_n : c->staged_n;
+  x.K = K;
   x.slot = c->x_issued & 1u;
   x.w = (uint32_t)(per / 64);
   x.total_words = x.w * c->xworld;
+  x.seen_words = (c->n_validators + 63) / 64;
   x.n_pieces = 2 * c->power_words;
-  x.slots = x.total_words + x.n_pieces + 2;
-  x.my_words = (uint32_t)mask_words(c->staged_n);
+  x.slots = exchange_slots(K, x.w, c->xworld, c->n_validators);
+  x.my_words = (uint32_t)mask_words(n_local);
   const uint64_t lo = std::min<uint64_t>((uint64_t)c->xrank * per, n_total), hi = std::min<uint64_t>(lo + per, n_total);
-  if ((uint64_t)c->staged_n != hi - lo) {
+  if ((uint64_t)n_local != hi - lo) {
     c->last_error = "the resident batch is not this rank's shard of n_total rows (ibft_shard_range)";
+    return IBFT_E_INVAL;
+  }
+  if (!c->d_seen_out.p) {
+    c->last_error = "no tally has run since the context joined the exchange";
     return IBFT_E_INVAL;
   }
   int rc;
   if ((rc = ensure(c, c->d_xbuf[x.slot], (size_t)x.slots * 8))) return rc;
-  const size_t res_words = (size_t)x.total_words + 16;
+  const size_t res_words = (size_t)K * x.total_words + 16;
   if ((rc = ensure(c, c->d_xres[x.slot], res_words * 8))) return rc;
   if (res_words > c->h_xres_words) {  // (re)allocate the mapped result buffers; nothing is in flight on a fresh size
     if (c->x_issued != c->x_fetched) HIPCHK(c, hipStreamSynchronize(c->xstream));
@@ -745,44 +780,104 @@ int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x) {
   if ((rc = ensure_handoff_events(c))) return rc;
   HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));  // everything launched so far, the tally included
   HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
-  hipLaunchKernelGGL(ibftk::exchange_pack_kernel, dim3((x.slots + 255) / 256), dim3(256), 0, c->xstream,
-                     (const uint64_t *)c->d_mask_out.p, (const uint64_t *)c->d_tally.p, (uint64_t *)c->d_xbuf[x.slot].p,
-                     c->xrank * x.w, x.my_words, x.total_words, x.n_pieces);
+  ibftk::exchange_pack_args pa{};
+  if (K == 2) {
+    pa.mask[0] = (const uint64_t *)c->d_set.p;
+    pa.mask[1] = (const uint64_t *)c->d_set.p + mask_words(c->max_rows);
+  } else {
+    pa.mask[0] = pa.mask[1] = (const uint64_t *)c->d_mask_out.p;
+  }
+  pa.seen = (const uint32_t *)c->d_seen_out.p;
+  pa.tally_out = (const uint64_t *)c->d_tally.p;
+  pa.xbuf = (uint64_t *)c->d_xbuf[x.slot].p;
+  pa.K = K;
+  pa.world = c->xworld;
+  pa.rank = c->xrank;
+  pa.words_per_rank = x.w;
+  pa.my_words = x.my_words;
+  pa.seen_words = x.seen_words;
+  hipLaunchKernelGGL(ibftk::exchange_pack_kernel, dim3((x.slots + 255) / 256), dim3(256), 0, c->xstream, pa);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev_read, c->xstream));
-  c->read_pending = true;  // the next tally overwrites d_mask_out / d_tally only after the pack has read them
+  c->read_pending = true;  // the next tally overwrites d_mask_out / d_set / d_tally / d_seen_out only after the pack has read them
   return IBFT_OK;
 }
 int exchange_collective(ibft_ctx *c, RcclApi *api, const xplan &x) {
   NCCLCHK(c, api, api->AllReduce(c->d_xbuf[x.slot].p, c->d_xbuf[x.slot].p, x.slots, ncclUint64, ncclSum, c->comm, c->xstream));
   return IBFT_OK;
 }
+// The same step without a communicator: every rank's buffer is addressable from rank 0's device (one device listed
+// several times, or peer access), so rank 0's exchange stream sums the buffers in place of ncclAllReduce — behind every
+// rank's pack, in front of every rank's unpack.
+int exchange_collective_local(const std::vector<ibft_ctx *> &ctx, const std::vector<xplan> &plan) {
+  ibft_ctx *c0 = ctx[0];
+  ibftk::exchange_sum_args sa{};
+  sa.world = (uint32_t)ctx.size();
+  sa.slots = plan[0].slots;
+  for (size_t i = 0; i < ctx.size(); i++) {
+    ibft_ctx *c = ctx[i];
+    if (plan[i].slots != sa.slots) return IBFT_E_INVAL;
+    sa.buf[i] = (uint64_t *)c->d_xbuf[plan[i].slot].p;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev_xpack, c->xstream));
+  }
+  HIPCHK(c0, hipSetDevice(c0->device));
+  for (size_t i = 1; i < ctx.size(); i++) HIPCHK(c0, hipStreamWaitEvent(c0->xstream, ctx[i]->ev_xpack, 0));
+  hipLaunchKernelGGL(ibftk::exchange_sum_kernel, dim3((sa.slots + 255) / 256), dim3(256), 0, c0->xstream, sa);
+  HIPCHK(c0, hipGetLastError());
+  HIPCHK(c0, hipEventRecord(c0->ev_xpack, c0->xstream));
+  for (size_t i = 1; i < ctx.size(); i++) {
+    HIPCHK(ctx[i], hipSetDevice(ctx[i]->device));
+    HIPCHK(ctx[i], hipStreamWaitEvent(ctx[i]->xstream, c0->ev_xpack, 0));
+  }
+  return IBFT_OK;
+}
 int exchange_post(ibft_ctx *c, uint64_t n_total, const xplan &x) {
   HIPCHK(c, hipSetDevice(c->device));
-  hipLaunchKernelGGL(ibftk::exchange_unpack_kernel, dim3((x.total_words + 1 + 255) / 256), dim3(256), 0, c->xstream,
-                     (const uint64_t *)c->d_xbuf[x.slot].p, x.total_words, x.n_pieces, (const uint64_t *)c->d_quorum.p,
-                     (uint64_t *)c->d_xres[x.slot].p, c->dh_xres[x.slot]);
+  ibftk::exchange_unpack_args ua{};
+  ua.xbuf = (const uint64_t *)c->d_xbuf[x.slot].p;
+  ua.vpower32 = (const uint32_t *)c->d_vpower.p;
+  ua.quorum = (const uint64_t *)c->d_quorum.p;
+  ua.dst = (uint64_t *)c->d_xres[x.slot].p;
+  ua.host_dst = c->dh_xres[x.slot];
+  ua.K = x.K;
+  ua.world = c->xworld;
+  ua.words_per_rank = x.w;
+  ua.seen_words = x.seen_words;
+  ua.n_pieces = x.n_pieces;
+  ua.n_validators = c->n_validators;
+  const uint32_t copy_blocks = (x.K * x.total_words + ibftk::XUNPACK_THREADS - 1) / ibftk::XUNPACK_THREADS;
+  hipLaunchKernelGGL(ibftk::exchange_unpack_kernel, dim3(copy_blocks + 1), dim3(ibftk::XUNPACK_THREADS), 0, c->xstream, ua);
   HIPCHK(c, hipGetLastError());
   if (!c->dh_xres[x.slot])
-    HIPCHK(c, hipMemcpyAsync(c->h_xres[x.slot], c->d_xres[x.slot].p, ((size_t)x.total_words + 16) * 8, hipMemcpyDeviceToHost,
-                             c->xstream));
+    HIPCHK(c, hipMemcpyAsync(c->h_xres[x.slot], c->d_xres[x.slot].p, ((size_t)x.K * x.total_words + 16) * 8,
+                             hipMemcpyDeviceToHost, c->xstream));
   HIPCHK(c, hipEventRecord(c->ev_xdone[x.slot], c->xstream));
   c->x_total[x.slot] = n_total;
+  c->x_K[x.slot] = x.K;
   c->x_issued++;
   return IBFT_OK;
 }
-int fetch_merged_locked(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
+// out_mask: the first verdict array; out_mask2: the second one of a message-set exchange (K = 2)
+int fetch_merged_locked(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally, uint64_t *out_mask2 = nullptr) {
   if (c->x_fetched == c->x_issued) return IBFT_E_INVAL;
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t slot = c->x_fetched & 1u;
   HIPCHK(c, hipEventSynchronize(c->ev_xdone[slot]));
   c->x_fetched++;
+  if (c->cache_on && c->dh_tally) {  // keys this shard's rows taught the device (delivered by the tally kernel) → tables
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(c->h_tally + 4);
+    int rcb = build_new_tables(c, lw[0], lw[1]);
+    if (rcb) return rcb;
+  }
   const uint64_t n_total = c->x_total[slot];
+  const uint32_t K = c->x_K[slot];
   const uint64_t per = shard_rows_per_rank(n_total, c->xworld);
   const size_t total_words = (size_t)(per / 64) * c->xworld, mw = (size_t)((n_total + 63) / 64);
   const uint64_t *res = c->h_xres[slot];
   if (out_mask && mw) memcpy(out_mask, res, mw * 8);
-  const uint64_t *t = res + total_words;
+  if (out_mask2 && mw && K == 2) memcpy(out_mask2, res + total_words, mw * 8);
+  const uint64_t *t = res + (size_t)K * total_words;
   for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = t[4 + i];
   if (tally) {
     memset(tally, 0, sizeof *tally);
@@ -793,24 +888,91 @@ int fetch_merged_locked(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
     tally->valid_rows = (uint32_t)(t[2] & 0xFFFFFFFFull);
     tally->distinct_senders = (uint32_t)(t[2] >> 32);
     tally->has_quorum = (uint32_t)t[3];
+    tally->shard_overlap = (uint32_t)t[4 + ibftk::TALLY_SUM_WORDS];
   }
   return IBFT_OK;
 }
 int comm_attach(ibft_ctx *c, ncclComm_t comm, uint32_t rank, uint32_t world) {
   HIPCHK(c, hipSetDevice(c->device));
   c->comm = comm;
+  c->xlocal = comm == nullptr;
   c->xrank = rank;
   c->xworld = world;
   HIPCHK(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
   for (int i = 0; i < 2; i++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_xdone[i], hipEventDisableTiming));
+  HIPCHK(c, hipEventCreateWithFlags(&c->ev_xpack, hipEventDisableTiming));
   return IBFT_OK;
 }
 
 }  // namespace
 
+// One host thread per device of a group: staging and launching a shard costs tens of microseconds of host time per
+// device, which one thread would pay W times in a row.
+class GroupWorker {
+ public:
+  GroupWorker() : th_([this] { loop(); }) {}
+  ~GroupWorker() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  void post(std::function<int()> fn) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      task_ = std::move(fn);
+      busy_ = true;
+    }
+    cv_.notify_all();
+  }
+  int wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return !busy_; });
+    return rc_;
+  }
+
+ private:
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [this] { return stop_ || (busy_ && task_); });
+      if (stop_) return;
+      std::function<int()> fn = std::move(task_);
+      task_ = nullptr;
+      lk.unlock();
+      const int rc = fn();
+      lk.lock();
+      rc_ = rc;
+      busy_ = false;
+      cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::function<int()> task_;
+  bool busy_ = false, stop_ = false;
+  int rc_ = 0;
+  std::thread th_;
+};
+
 struct ibft_group {
   std::mutex mu;
   std::vector<ibft_ctx *> ctx;
+  bool local = false;  // the collective is exchange_sum_kernel on rank 0's exchange stream, not ncclAllReduce
+  std::vector<std::unique_ptr<GroupWorker>> worker;
+  // run fn(i) for every rank on its own thread; the first non-zero return code (by rank) is the result
+  int each(const std::function<int(uint32_t)> &fn) {
+    if (ctx.size() == 1) return fn(0);
+    for (uint32_t i = 0; i < ctx.size(); i++) worker[i]->post([&fn, i] { return fn(i); });
+    int rc = IBFT_OK;
+    for (uint32_t i = 0; i < ctx.size(); i++) {
+      const int r = worker[i]->wait();
+      if (r && !rc) rc = r;
+    }
+    return rc;
+  }
 };
 
 extern "C" {
@@ -1327,24 +1489,23 @@ void ibft_pinned_free(void *p) {
 }
 
 // A whole PREPARE or COMMIT set in one call (kernels.hip.h: "a message set in one pass").
-int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
-                         const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
-                         const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw, size_t raw_len,
-                         uint64_t round,
-                         const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally) {
-  if (!c || (n && (!off || !msg_sig65 || !from20 || !hash32 || !hash_len || !out_sender_mask || !out_valid_mask)))
-    return IBFT_E_INVAL;
+// a message set up to and including its tally, everything asynchronous past the uploads (c->mu held)
+static int messages_launch_locked(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
+                                  const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
+                                  const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw, size_t raw_len,
+                                  uint64_t round, const uint8_t *digest32) {
+  if (n && (!off || !msg_sig65 || !from20 || !hash32 || !hash_len)) return IBFT_E_INVAL;
   if ((raw_len && !raw) || raw_len > (1ull << 31)) return IBFT_E_INVAL;
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !payload) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   c->wire_valid = false;
   c->staged_n = 0;
+  c->set_n = (uint32_t)n;
   const uint32_t half = ((uint32_t)n + 63u) & ~63u;
   const uint32_t rows = seal65 ? half + (uint32_t)n : (uint32_t)n;  // verdict rows of the one launch
   if ((rc = alloc_rows(c, 2 * (((uint32_t)c->max_rows + 63u) & ~63u)))) return rc;
@@ -1361,12 +1522,8 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   }
   if (n == 0) {
     if (hash_needed && (rc = launch_proposal_hash(c))) return rc;
-    if (tally) {
-      memset(tally, 0, sizeof *tally);
-      tally->quorum_lo = c->quorum_w[0];
-      tally->quorum_hi = c->quorum_w[1];
-    }
-    for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = 0;
+    // an empty shard of a sharded set still contributes (zero) words, an empty bitmap and a zero count to the exchange
+    if (c->comm || c->xlocal) return enqueue_tally(c, 0);
     return IBFT_OK;
   }
   uint8_t *d_hash = (uint8_t *)c->d_hash.p, *d_sig = (uint8_t *)c->d_sig.p, *d_signer = (uint8_t *)c->d_signer.p,
@@ -1406,7 +1563,6 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   sa.H4 = (const uint64_t *)c->d_H.p;
   sa.n = (uint32_t)n;
   sa.half_words = seal65 ? half / 64 : 0;
-  const size_t mw = (size_t)mask_words(n);
   sa.sender_out = (uint64_t *)c->d_set.p;
   sa.valid_out = (uint64_t *)c->d_set.p + mask_words(c->max_rows);
   sa.host_sender = c->dh_set;
@@ -1418,6 +1574,29 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   c->mask_dirty_words = 0;  // the combine kernel zeroed the seal words, the tally the sender words
   if (!c->dh_set)
     HIPCHK(c, hipMemcpyAsync(c->h_set, c->d_set.p, (size_t)mask_words(c->max_rows) * 16, hipMemcpyDeviceToHost, c->stream));
+  return IBFT_OK;
+}
+
+int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
+                         const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
+                         const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw, size_t raw_len,
+                         uint64_t round,
+                         const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally) {
+  if (!c || (n && (!out_sender_mask || !out_valid_mask))) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  int rc = messages_launch_locked(c, payload, off, msg_sig65, from20, hash32, hash_len, seal65, sender_pre, valid_pre, n, raw,
+                                  raw_len, round, digest32);
+  if (rc) return rc;
+  if (n == 0) {
+    if (tally) {
+      memset(tally, 0, sizeof *tally);
+      tally->quorum_lo = c->quorum_w[0];
+      tally->quorum_hi = c->quorum_w[1];
+    }
+    for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = 0;
+    return IBFT_OK;
+  }
+  const size_t mw = (size_t)mask_words(n);
   if ((rc = fetch_results(c, (uint32_t)n, nullptr, tally, true))) {
     c->have_H = false;
     return rc;
@@ -1482,14 +1661,13 @@ int ibft_verify_seals(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, 
   return fetch_results(c, c->staged_n, out_mask, tally, true);
 }
 
-int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,
-                        const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
-                        ibft_tally_t *tally) {
-  if (!c || (n && (!off || !sig65 || !from20 || !out_mask))) return IBFT_E_INVAL;
+// a3 up to and including the tally (c->mu held)
+static int senders_launch_locked(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,
+                                 const uint8_t *from20, const uint8_t *pre_flags, size_t n) {
+  if (n && (!off || !sig65 || !from20)) return IBFT_E_INVAL;
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !payload) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
@@ -1499,7 +1677,7 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
   if ((rc = ensure(c, c->d_payload, pbytes + 256))) return rc;
   ColumnCopies cc;
   cc.add(c->d_payload.p, payload, pbytes);
-  cc.add(c->d_off.p, off, (n + 1) * 4);
+  if (n) cc.add(c->d_off.p, off, (n + 1) * 4);
   cc.add(c->d_sig.p, sig65, n * 65);
   cc.add(c->d_signer.p, from20, n * 20);
   if (pre_flags) cc.add(c->d_pre.p, pre_flags, n);
@@ -1508,7 +1686,16 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
   c->staged_pre = pre_flags != nullptr;
   c->ev_used = 0;
   if ((rc = enqueue_recover(c, (uint32_t)n, pre_flags != nullptr, 1, true))) return rc;
-  if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
+  return enqueue_tally(c, (uint32_t)n);
+}
+
+int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,
+                        const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
+                        ibft_tally_t *tally) {
+  if (!c || (n && (!off || !out_mask))) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  int rc = senders_launch_locked(c, payload, off, sig65, from20, pre_flags, n);
+  if (rc) return rc;
   return fetch_results(c, (uint32_t)n, out_mask, tally, true);
 }
 
@@ -1868,11 +2055,13 @@ int ibft_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *
   return IBFT_OK;
 }
 
-int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t power_words, uint32_t *words_per_rank, uint32_t *slots) {
-  if (!world || (power_words != 1 && power_words != 4)) return IBFT_E_INVAL;
+int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t n_validators, uint32_t n_masks, uint32_t *words_per_rank,
+                         uint32_t *seen_words, uint32_t *slots) {
+  if (!world || (n_masks != 1 && n_masks != 2)) return IBFT_E_INVAL;
   const uint64_t w = shard_rows_per_rank(n_total, world) / 64;
   if (words_per_rank) *words_per_rank = (uint32_t)w;
-  if (slots) *slots = (uint32_t)(w * world + 2 * power_words + 2);
+  if (seen_words) *seen_words = (n_validators + 63) / 64;
+  if (slots) *slots = exchange_slots(n_masks, (uint32_t)w, world, n_validators);
   return IBFT_OK;
 }
 
@@ -1912,6 +2101,7 @@ int ibft_comm_destroy(ibft_ctx *c) {
 
 int ibft_seals_exchange(ibft_ctx *c, uint64_t n_total) {
   if (!c) return IBFT_E_INVAL;
+  if (c->xlocal) return IBFT_E_INVAL;  // a rank of a local group: only the group can run the collective
   RcclApi *api = rccl();
   if (!api) return IBFT_E_RCCL;
   std::lock_guard<std::mutex> lk(c->mu);
@@ -1929,12 +2119,21 @@ int ibft_seals_fetch_merged(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally
 }
 
 int ibft_group_create(const int32_t *devices, uint32_t n_dev, uint32_t flags, uint32_t max_rows_total, ibft_group **out) {
-  if (!out || !devices || !n_dev || n_dev > 64) return IBFT_E_INVAL;
+  if (!out || !devices || !n_dev || n_dev > (uint32_t)ibftk::XSUM_MAX_RANKS) return IBFT_E_INVAL;
   *out = nullptr;
-  RcclApi *api = rccl();
-  if (!api) return IBFT_E_RCCL;
+  // Which collective: RCCL needs one rank per DEVICE.  A group that lists a device more than once (several contexts
+  // sharing one MI355X: how the exchange is exercised with W > 1 on a one-GPU box) — or IBFT_GROUP_COLLECTIVE=local
+  // with peer-accessible devices — sums the buffers with the library's own kernel instead.
+  bool local = false;
+  for (uint32_t i = 0; i < n_dev; i++)
+    for (uint32_t j = 0; j < i; j++) local = local || devices[i] == devices[j];
+  const char *mode = getenv("IBFT_GROUP_COLLECTIVE");
+  if (mode && !strcmp(mode, "local")) local = true;
+  RcclApi *api = local ? nullptr : rccl();
+  if (!local && !api) return IBFT_E_RCCL;
   ibft_group *g = new (std::nothrow) ibft_group();
   if (!g) return IBFT_E_NOMEM;
+  g->local = local;
   const uint64_t total = max_rows_total ? max_rows_total : (uint64_t)DEFAULT_MAX_ROWS * n_dev;
   int rc = IBFT_OK;
   for (uint32_t i = 0; i < n_dev && rc == IBFT_OK; i++) {
@@ -1943,7 +2142,22 @@ int ibft_group_create(const int32_t *devices, uint32_t n_dev, uint32_t flags, ui
     rc = ibft_ctx_create(&cfg, &c);
     if (rc == IBFT_OK) g->ctx.push_back(c);
   }
-  if (rc == IBFT_OK) {
+  if (rc == IBFT_OK && local) {
+    // rank 0's device must be able to address every rank's exchange buffer
+    for (uint32_t i = 1; i < n_dev && rc == IBFT_OK; i++) {
+      if (devices[i] == devices[0]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) != hipSuccess || !can) {
+        rc = IBFT_E_INVAL;
+        break;
+      }
+      (void)hipSetDevice(devices[0]);
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[i], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) rc = IBFT_E_HIP;
+      (void)hipGetLastError();
+    }
+    for (uint32_t i = 0; i < n_dev && rc == IBFT_OK; i++) rc = comm_attach(g->ctx[i], nullptr, i, n_dev);
+  } else if (rc == IBFT_OK) {
     ncclUniqueId u;
     std::vector<ncclComm_t> comms(n_dev, nullptr);
     // one thread initialises every rank: the calls only complete inside the group (ncclCommInitRank's contract)
@@ -1958,15 +2172,19 @@ int ibft_group_create(const int32_t *devices, uint32_t n_dev, uint32_t flags, ui
     ibft_group_destroy(g);
     return rc;
   }
+  if (n_dev > 1)
+    for (uint32_t i = 0; i < n_dev; i++) g->worker.emplace_back(new GroupWorker());
   *out = g;
   return IBFT_OK;
 }
 
 void ibft_group_destroy(ibft_group *g) {
   if (!g) return;
+  g->worker.clear();  // joins the threads
   for (ibft_ctx *c : g->ctx) ibft_ctx_destroy(c);
   delete g;
 }
+int ibft_group_is_local(const ibft_group *g) { return g ? (g->local ? 1 : 0) : IBFT_E_INVAL; }
 
 uint32_t ibft_group_size(const ibft_group *g) { return g ? (uint32_t)g->ctx.size() : 0; }
 ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i) { return (g && i < g->ctx.size()) ? g->ctx[i] : nullptr; }
@@ -1974,57 +2192,133 @@ ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i) { return (g && i < g->ctx.si
 int ibft_group_set_validators(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n) {
   if (!g) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(g->mu);
-  for (ibft_ctx *c : g->ctx) {  // the validator table is replicated on every device (28 B per validator)
-    const int rc = ibft_set_validators(c, height, addrs20, power, n);
-    if (rc) return rc;
-  }
-  return IBFT_OK;
+  // the validator table is replicated on every device (28 B per validator); every device on its own thread
+  return g->each([&](uint32_t i) { return ibft_set_validators(g->ctx[i], height, addrs20, power, n); });
 }
 
 int ibft_group_set_validators_u256(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint8_t *power_be32, size_t n) {
   if (!g) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(g->mu);
-  for (ibft_ctx *c : g->ctx) {
-    const int rc = ibft_set_validators_u256(c, height, addrs20, power_be32, n);
-    if (rc) return rc;
+  return g->each([&](uint32_t i) { return ibft_set_validators_u256(g->ctx[i], height, addrs20, power_be32, n); });
+}
+
+// the exchange of a group call: every rank packed (exchange_pre) → collective → unpack → results of rank 0 to the caller
+static int group_exchange(ibft_group *g, uint64_t n, std::vector<xplan> &plan, uint64_t *out_mask, uint64_t *out_mask2,
+                          ibft_tally_t *tally) {
+  const uint32_t world = (uint32_t)g->ctx.size();
+  int rc;
+  if (g->local) {
+    if ((rc = exchange_collective_local(g->ctx, plan))) return rc;
+  } else {
+    RcclApi *api = rccl();
+    if (!api) return IBFT_E_RCCL;
+    // single thread: the calls go inside a group
+    bool ok = api->GroupStart() == ncclSuccess;
+    for (uint32_t i = 0; ok && i < world; i++) ok = exchange_collective(g->ctx[i], api, plan[i]) == IBFT_OK;
+    ok = api->GroupEnd() == ncclSuccess && ok;
+    if (!ok) return IBFT_E_RCCL;
   }
+  for (uint32_t i = 0; i < world; i++)
+    if ((rc = exchange_post(g->ctx[i], n, plan[i]))) return rc;
+  for (uint32_t i = world; i-- > 0;)  // every rank holds the merged result; device 0's copy is handed to the caller
+    if ((rc = fetch_merged_locked(g->ctx[i], i == 0 ? out_mask : nullptr, i == 0 ? tally : nullptr, i == 0 ? out_mask2 : nullptr)))
+      return rc;
   return IBFT_OK;
 }
 
 int ibft_group_verify_seals(ibft_group *g, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
                             const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!g || (n && (!hash32 || !sig65 || !signer20 || !out_mask))) return IBFT_E_INVAL;
-  RcclApi *api = rccl();
-  if (!api) return IBFT_E_RCCL;
   std::lock_guard<std::mutex> lk(g->mu);
   const uint32_t world = (uint32_t)g->ctx.size();
   std::vector<std::unique_lock<std::mutex>> locks;
   for (ibft_ctx *c : g->ctx) locks.emplace_back(c->mu);
-  int rc;
-  // every device verifies its own 64-aligned row range: stage, verdict kernel, tally — all asynchronous past the upload
-  for (uint32_t i = 0; i < world; i++) {
-    ibft_ctx *c = g->ctx[i];
+  for (ibft_ctx *c : g->ctx)
     if (!c->have_valset) return IBFT_E_NOVALSET;
+  // every device verifies its own 64-aligned row range: stage, verdict kernel, tally, pack — all asynchronous past the
+  // upload, every device driven by its own host thread
+  std::vector<xplan> plan(world);
+  int rc = g->each([&](uint32_t i) {
+    ibft_ctx *c = g->ctx[i];
     uint64_t lo, hi;
     (void)ibft_shard_range(n, i, world, &lo, &hi);
-    if ((rc = seals_stage_locked(c, hash32 + 32 * lo, sig65 + 65 * lo, signer20 + 20 * lo, pre_flags ? pre_flags + lo : nullptr,
-                                 (size_t)(hi - lo), false)))
-      return rc;
-    if ((rc = seals_launch_locked(c, 1))) return rc;
-  }
-  // one all-reduce merges the verdict words and the tally partials (single thread: the calls go inside a group)
+    int r;
+    if ((r = seals_stage_locked(c, hash32 + 32 * lo, sig65 + 65 * lo, signer20 + 20 * lo, pre_flags ? pre_flags + lo : nullptr,
+                                (size_t)(hi - lo), false)))
+      return r;
+    if ((r = seals_launch_locked(c, 1))) return r;
+    return exchange_pre(c, n, plan[i], 1);
+  });
+  if (rc) return rc;
+  return group_exchange(g, n, plan, out_mask, nullptr, tally);
+}
+
+// rows [lo, hi) of a payload column as a column of their own: offsets rebased to the shard's first byte
+static void shard_offsets(const uint32_t *off, uint64_t lo, uint64_t hi, std::vector<uint32_t> &out) {
+  out.resize((size_t)(hi - lo) + 1);
+  for (uint64_t i = lo; i <= hi; i++) out[(size_t)(i - lo)] = off[i] - off[lo];
+}
+
+int ibft_group_verify_senders(ibft_group *g, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,
+                              const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
+                              ibft_tally_t *tally) {
+  if (!g || (n && (!off || !sig65 || !from20 || !out_mask))) return IBFT_E_INVAL;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(g->mu);
+  const uint32_t world = (uint32_t)g->ctx.size();
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (ibft_ctx *c : g->ctx) locks.emplace_back(c->mu);
   std::vector<xplan> plan(world);
-  for (uint32_t i = 0; i < world; i++)
-    if ((rc = exchange_pre(g->ctx[i], n, plan[i]))) return rc;
-  bool ok = api->GroupStart() == ncclSuccess;
-  for (uint32_t i = 0; ok && i < world; i++) ok = exchange_collective(g->ctx[i], api, plan[i]) == IBFT_OK;
-  ok = api->GroupEnd() == ncclSuccess && ok;
-  if (!ok) return IBFT_E_RCCL;
-  for (uint32_t i = 0; i < world; i++)
-    if ((rc = exchange_post(g->ctx[i], n, plan[i]))) return rc;
-  for (uint32_t i = world; i-- > 0;)  // every rank holds the merged result; device 0's copy is handed to the caller
-    if ((rc = fetch_merged_locked(g->ctx[i], i == 0 ? out_mask : nullptr, i == 0 ? tally : nullptr))) return rc;
-  return IBFT_OK;
+  std::vector<std::vector<uint32_t>> loff(world);
+  int rc = g->each([&](uint32_t i) {
+    ibft_ctx *c = g->ctx[i];
+    uint64_t lo, hi;
+    (void)ibft_shard_range(n, i, world, &lo, &hi);
+    if (n) shard_offsets(off, lo, hi, loff[i]);
+    int r = senders_launch_locked(c, n ? payload + off[lo] : nullptr, n ? loff[i].data() : nullptr, sig65 + 65 * lo,
+                                  from20 + 20 * lo, pre_flags ? pre_flags + lo : nullptr, (size_t)(hi - lo));
+    if (r) return r;
+    return exchange_pre(c, n, plan[i], 1);
+  });
+  if (rc) return rc;
+  return group_exchange(g, n, plan, out_mask, nullptr, tally);
+}
+
+int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
+                               const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
+                               const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw,
+                               size_t raw_len, uint64_t round, const uint8_t *digest32, uint64_t *out_sender_mask,
+                               uint64_t *out_valid_mask, ibft_tally_t *tally) {
+  if (!g || (n && (!off || !msg_sig65 || !from20 || !hash32 || !hash_len || !out_sender_mask || !out_valid_mask)))
+    return IBFT_E_INVAL;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(g->mu);
+  const uint32_t world = (uint32_t)g->ctx.size();
+  std::vector<std::unique_lock<std::mutex>> locks;
+  for (ibft_ctx *c : g->ctx) locks.emplace_back(c->mu);
+  std::vector<xplan> plan(world);
+  std::vector<std::vector<uint32_t>> loff(world);
+  // every device judges its own 64-aligned range of MESSAGES completely (both signatures of a COMMIT are rows of its
+  // one verdict launch); the proposal is hashed (and remembered) by every device for itself
+  int rc = g->each([&](uint32_t i) {
+    ibft_ctx *c = g->ctx[i];
+    uint64_t lo, hi;
+    (void)ibft_shard_range(n, i, world, &lo, &hi);
+    if (n) shard_offsets(off, lo, hi, loff[i]);
+    int r = messages_launch_locked(c, n ? payload + off[lo] : nullptr, n ? loff[i].data() : nullptr, msg_sig65 + 65 * lo,
+                                   from20 + 20 * lo, hash32 + 32 * lo, hash_len + lo, seal65 ? seal65 + 65 * lo : nullptr,
+                                   sender_pre ? sender_pre + lo : nullptr, valid_pre ? valid_pre + lo : nullptr,
+                                   (size_t)(hi - lo), raw, raw_len, round, digest32);
+    if (r) return r;
+    return exchange_pre(c, n, plan[i], 2);
+  });
+  if (rc) {
+    for (ibft_ctx *c : g->ctx) c->have_H = false;
+    return rc;
+  }
+  return group_exchange(g, n, plan, out_sender_mask, out_valid_mask, tally);
 }
 
 }  // extern "C"

@@ -1321,6 +1321,8 @@ struct tally_args {
   uint64_t *out;            // TALLY_OUT_WORDS
   uint64_t *host_mask, *host_tally;  // mapped pinned host memory (or null): no device-to-host copy commands
   uint32_t lds_bitmap;      // the launch carries ⌈n_validators/32⌉ words of dynamic LDS for the workgroup's bitmap
+  uint32_t *seen_out;       // or null: the launch's distinct-sender bitmap is left here (⌈n_validators/32⌉ words) — what a
+                            // sharded batch exchanges, because the SET of senders merges across shards and sums do not
   uint32_t set_on;          // a message set: the verdict words are combined here first (set_combine_word)
   set_args set;
 };
@@ -1480,8 +1482,10 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     __syncthreads();
     if (!last_flag) return;
     // ---- the last workgroup: every other one has added its pieces and set its bits ----
-    for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS)
+    for (uint32_t i = tid; i < (a.n_validators + 31) / 32; i += TALLY_THREADS) {
+      if (a.seen_out) a.seen_out[i] = __hip_atomic_load(a.seen + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.seen + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid != 0) return;
 #pragma unroll
     for (int k = 0; k < TALLY_MAX_PIECES; k++)
@@ -1492,6 +1496,8 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     for (int k = 0; k < TALLY_ACC_WORDS; k++)
       __hip_atomic_store(a.acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
+    if (a.seen_out)  // (the barrier above is behind every row's atomicOr)
+      for (uint32_t i = tid; i < seen_words; i += TALLY_THREADS) a.seen_out[i] = lseen[i];
     if (tid != 0) return;
 #pragma unroll
     for (int k = 0; k < TALLY_MAX_PIECES; k++) {
@@ -1528,52 +1534,142 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
 }
 
 // ---- multi-GPU: the one exchange step -------------------------------------------------
-// Exchange buffer of a sharded batch (u64 slots): [ verdict words of rank 0 | … | rank W−1 | 2·PW piece sums |
-// valid rows | distinct senders ].  A rank fills its own word range and its partial tally, everything else is
-// zero: after ncclAllReduce(sum) the words are the global verdict mask (disjoint shards: sum ≡ OR) and the
-// pieces add without carries lost (32-bit pieces in 64-bit slots).  has_quorum is recomputed from the sum.
-__global__ void exchange_pack_kernel(const uint64_t *__restrict__ mask, const uint64_t *__restrict__ tally_out,
-                                     uint64_t *__restrict__ xbuf, uint32_t my_off, uint32_t my_words,
-                                     uint32_t total_words, uint32_t n_pieces) {
+// Exchange buffer of a sharded batch (u64 slots):
+//   [ K × (verdict words of rank 0 | … | rank W−1) | W × ⌈n_validators/64⌉ distinct-sender bitmap words | valid rows ]
+// A rank fills its own word range of each of the K verdict arrays (K = 1: a seal / sender batch, K = 2: the sender and
+// the valid words of a message set), its own bitmap segment and its count of valid rows; everything else is zero.
+// After the all-reduce(SUM) the words are the global verdict masks (disjoint shards: sum ≡ OR) and every rank holds
+// every rank's bitmap.  The tally is NOT additive: HasQuorum counts a validator once however many rows it has
+// (a map[string]struct{} in core/validator_manager.go:86-92, 147-155), and rows of one sender may lie in two shards —
+// so the unpack step ORs the W segments and recomputes power, distinct senders and has_quorum from the merged
+// bitmap, exactly what tally_kernel computes from its own bitmap on one device.
+struct exchange_pack_args {
+  const uint64_t *mask[2];   // this rank's verdict words (my_words each); mask[1] unused when K = 1
+  const uint32_t *seen;      // this rank's distinct-sender bitmap (tally_args::seen_out), 2·seen_words 32-bit words
+  const uint64_t *tally_out; // this rank's tally (word 2: valid rows | distinct << 32)
+  uint64_t *xbuf;
+  uint32_t K, world, rank, words_per_rank, my_words, seen_words;
+};
+__global__ void exchange_pack_kernel(exchange_pack_args a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total_words) {
-    xbuf[i] = (i >= my_off && i < my_off + my_words) ? mask[i - my_off] : 0ull;
-  } else if (i < total_words + n_pieces) {
-    xbuf[i] = tally_out[TALLY_OUT_PIECES + (i - total_words)];
-  } else if (i == total_words + n_pieces) {
-    xbuf[i] = tally_out[2] & 0xFFFFFFFFull;
-  } else if (i == total_words + n_pieces + 1) {
-    xbuf[i] = tally_out[2] >> 32;
+  const uint32_t total_words = a.words_per_rank * a.world;
+  const uint32_t seen_base = a.K * total_words, cnt = seen_base + a.world * a.seen_words;
+  if (i < seen_base) {
+    const uint32_t k = i / total_words, j = i - k * total_words, off = a.rank * a.words_per_rank;
+    a.xbuf[i] = (j >= off && j < off + a.my_words) ? a.mask[k][j - off] : 0ull;
+  } else if (i < cnt) {
+    const uint32_t r = (i - seen_base) / a.seen_words, j = (i - seen_base) - r * a.seen_words;
+    a.xbuf[i] = r == a.rank ? ((uint64_t)a.seen[2 * j] | ((uint64_t)a.seen[2 * j + 1] << 32)) : 0ull;
+  } else if (i == cnt) {
+    a.xbuf[i] = a.tally_out[2] & 0xFFFFFFFFull;
   }
 }
-// merged buffer → [ total_words verdict words | TALLY_OUT_WORDS-style tally ] in device memory and, when given,
-// mapped host memory
-__global__ void exchange_unpack_kernel(const uint64_t *__restrict__ xbuf, uint32_t total_words, uint32_t n_pieces,
-                                       const uint64_t *__restrict__ quorum, uint64_t *__restrict__ dst,
-                                       uint64_t *__restrict__ host_dst) {
+
+// The collective itself when every rank's buffer is addressable from one device (a group that lists one device
+// several times, or peer-mapped devices): out[i] = Σ_r buf_r[i], written back into every rank's buffer — what
+// ncclAllReduce(sum, u64) leaves there.
+constexpr int XSUM_MAX_RANKS = 64;
+struct exchange_sum_args {
+  uint64_t *buf[XSUM_MAX_RANKS];
+  uint32_t world, slots;
+};
+__global__ void exchange_sum_kernel(exchange_sum_args a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total_words) {
-    const uint64_t w = xbuf[i];
-    dst[i] = w;
-    if (host_dst) host_dst[i] = w;
-  } else if (i == total_words) {
-    uint64_t piece[TALLY_MAX_PIECES];
-#pragma unroll
-    for (int k = 0; k < TALLY_MAX_PIECES; k++) piece[k] = (uint32_t)k < n_pieces ? xbuf[total_words + k] : 0ull;
-    uint64_t w[TALLY_SUM_WORDS];
-    pieces_to_words(piece, TALLY_MAX_PIECES, w);
-    uint64_t t[2 + 2 + TALLY_SUM_WORDS];
-    t[0] = w[0];
-    t[1] = w[1];
-    t[2] = (xbuf[total_words + n_pieces] & 0xFFFFFFFFull) | (xbuf[total_words + n_pieces + 1] << 32);
-    t[3] = words_ge(w, quorum) ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < TALLY_SUM_WORDS; k++) t[4 + k] = w[k];
-#pragma unroll
-    for (int k = 0; k < 4 + TALLY_SUM_WORDS; k++) {
-      dst[total_words + k] = t[k];
-      if (host_dst) host_dst[total_words + k] = t[k];
+  if (i >= a.slots) return;
+  uint64_t s = 0;
+  for (uint32_t r = 0; r < a.world; r++) s += a.buf[r][i];
+  for (uint32_t r = 0; r < a.world; r++) a.buf[r][i] = s;
+}
+
+// merged buffer → [ K·total_words verdict words | TALLY_OUT_WORDS-style tally ] in device memory and, when given,
+// mapped host memory.  The last workgroup is the tally over the merged bitmap.
+constexpr int XUNPACK_THREADS = 1024;
+struct exchange_unpack_args {
+  const uint64_t *xbuf;
+  const uint32_t *vpower32;  // n_validators × n_pieces 32-bit pieces
+  const uint64_t *quorum;
+  uint64_t *dst, *host_dst;
+  uint32_t K, world, words_per_rank, seen_words, n_pieces, n_validators;
+};
+__global__ void __launch_bounds__(XUNPACK_THREADS) exchange_unpack_kernel(exchange_unpack_args a) {
+  const uint32_t total_words = a.words_per_rank * a.world;
+  const uint32_t seen_base = a.K * total_words;
+  if (blockIdx.x + 1 < gridDim.x) {
+    const uint32_t i = blockIdx.x * XUNPACK_THREADS + threadIdx.x;
+    if (i < seen_base) {
+      const uint64_t w = a.xbuf[i];
+      a.dst[i] = w;
+      if (a.host_dst) a.host_dst[i] = w;
     }
+    return;
+  }
+  __shared__ uint64_t part[TALLY_MAX_PIECES + 2][XUNPACK_THREADS / 64];
+  const uint32_t tid = threadIdx.x;
+  uint64_t p[TALLY_MAX_PIECES];
+#pragma unroll
+  for (int k = 0; k < TALLY_MAX_PIECES; k++) p[k] = 0;
+  uint64_t distinct = 0, overlap = 0;
+  for (uint32_t j = tid; j < a.seen_words; j += XUNPACK_THREADS) {
+    uint64_t m = 0, per_rank = 0;
+    for (uint32_t r = 0; r < a.world; r++) {
+      const uint64_t s = a.xbuf[seen_base + r * a.seen_words + j];
+      m |= s;
+      per_rank += (uint64_t)__popcll(s);
+    }
+    const uint64_t here = (uint64_t)__popcll(m);
+    distinct += here;
+    overlap += per_rank - here;  // senders with valid rows in more than one shard: counted once
+    while (m) {
+      const uint32_t b = (uint32_t)__ffsll((long long)m) - 1u;
+      m &= m - 1;
+      const uint32_t v = 64u * j + b;
+      if (v < a.n_validators) {
+#pragma unroll
+        for (int k = 0; k < TALLY_MAX_PIECES; k++)
+          if ((uint32_t)k < a.n_pieces) p[k] += a.vpower32[(size_t)v * a.n_pieces + k];
+      }
+    }
+  }
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < TALLY_MAX_PIECES; k++) {
+    const uint64_t sum = wave_sum_u64(p[k]);
+    if (lane == 0) part[k][wave] = sum;
+  }
+  {
+    const uint64_t sd = wave_sum_u64(distinct), so = wave_sum_u64(overlap);
+    if (lane == 0) {
+      part[TALLY_MAX_PIECES][wave] = sd;
+      part[TALLY_MAX_PIECES + 1][wave] = so;
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  uint64_t piece[TALLY_MAX_PIECES];
+#pragma unroll
+  for (int k = 0; k < TALLY_MAX_PIECES; k++) {
+    piece[k] = 0;
+    for (int w = 0; w < XUNPACK_THREADS / 64; w++) piece[k] += part[k][w];
+  }
+  uint64_t d = 0, o = 0;
+  for (int w = 0; w < XUNPACK_THREADS / 64; w++) {
+    d += part[TALLY_MAX_PIECES][w];
+    o += part[TALLY_MAX_PIECES + 1][w];
+  }
+  uint64_t w[TALLY_SUM_WORDS];
+  pieces_to_words(piece, TALLY_MAX_PIECES, w);
+  uint64_t t[5 + TALLY_SUM_WORDS];
+  t[0] = w[0];
+  t[1] = w[1];
+  t[2] = (a.xbuf[seen_base + a.world * a.seen_words] & 0xFFFFFFFFull) | (d << 32);
+  t[3] = words_ge(w, a.quorum) ? 1 : 0;
+#pragma unroll
+  for (int k = 0; k < TALLY_SUM_WORDS; k++) t[4 + k] = w[k];
+  t[4 + TALLY_SUM_WORDS] = o;
+#pragma unroll
+  for (int k = 0; k < 5 + TALLY_SUM_WORDS; k++) {
+    a.dst[seen_base + k] = t[k];
+    if (a.host_dst) a.host_dst[seen_base + k] = t[k];
   }
 }
 

@@ -36,7 +36,8 @@ EXPORTS = [
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
-    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
+    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages",
+    "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire",
 ]
 COMM_ID_BYTES = 128
@@ -71,7 +72,7 @@ class Tally(C.Structure):
     _fields_ = [("quorum_lo", C.c_uint64), ("quorum_hi", C.c_uint64),
                 ("power_lo", C.c_uint64), ("power_hi", C.c_uint64),
                 ("valid_rows", C.c_uint32), ("distinct_senders", C.c_uint32),
-                ("has_quorum", C.c_uint32), ("reserved", C.c_uint32)]
+                ("has_quorum", C.c_uint32), ("shard_overlap", C.c_uint32)]
 
     @property
     def power(self) -> int:
@@ -153,7 +154,8 @@ def load_library() -> C.CDLL:
     L.ibft_set_validators_u256.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.ibft_last_tally_wide.argtypes = [vp, C.POINTER(TallyWide)]
     L.ibft_shard_range.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.ibft_exchange_layout.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ibft_exchange_layout.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_comm_unique_id.argtypes = [vp]
     L.ibft_comm_init.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.ibft_comm_destroy.argtypes = [vp]
@@ -166,6 +168,10 @@ def load_library() -> C.CDLL:
     L.ibft_group_set_validators.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.ibft_group_set_validators_u256.argtypes = [vp, C.c_uint64, vp, vp, C.c_size_t]
     L.ibft_group_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
+    L.ibft_group_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
+    L.ibft_group_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp,
+                                             vp, vp, C.POINTER(Tally)]
+    L.ibft_group_is_local.argtypes = [vp]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
     _lib = L
@@ -221,13 +227,13 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return lo.value, hi.value
 
 
-def exchange_layout(n_total: int, world: int, power_words: int = 1) -> tuple[int, int]:
-    """ibft_exchange_layout (pure): (verdict words per rank, u64 slots of the exchange buffer)"""
-    w, s = C.c_uint32(), C.c_uint32()
-    rc = load_library().ibft_exchange_layout(n_total, world, power_words, C.byref(w), C.byref(s))
+def exchange_layout(n_total: int, world: int, n_validators: int, n_masks: int = 1) -> tuple[int, int, int]:
+    """ibft_exchange_layout (pure): (verdict words per rank, bitmap words per rank, u64 slots of the exchange buffer)"""
+    w, b, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = load_library().ibft_exchange_layout(n_total, world, n_validators, n_masks, C.byref(w), C.byref(b), C.byref(s))
     if rc:
         raise ValueError(f"ibft_exchange_layout: {rc}")
-    return w.value, s.value
+    return w.value, b.value, s.value
 
 
 def comm_unique_id() -> bytes:
@@ -587,8 +593,9 @@ class BatchVerifier:
 
 
 class DeviceGroup:
-    """ibft_group: one process, several MI355X — rows sharded over the devices, one RCCL all-reduce inside
-    the library merges verdict words and tally partials (what a Go Backend would call for N beyond one GPU)."""
+    """ibft_group: one process, several MI355X — rows sharded over the devices, one all-reduce inside the library merges
+    verdict words and the ranks' distinct-sender bitmaps (what a Go Backend would call for N beyond one GPU).  A device
+    listed several times gives several contexts on that device and the library's own sum kernel as the collective."""
 
     def __init__(self, devices, flags: int = 0, max_rows_total: int = 0):
         self._L = load_library()
@@ -632,6 +639,43 @@ class DeviceGroup:
         self._chk(self._L.ibft_group_verify_seals(self._g, _p(h), _p(s), _p(f), _p(pre), n, _p(mask), C.byref(t)),
                   "ibft_group_verify_seals")
         return mask_to_bool(mask, n), t
+
+    def is_valid_validator(self, payload: bytes, off, sig65, from20, pre_flags=None):
+        pl = _bytes_col(payload)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        s = _u8(sig65, (-1, 65)); f = _u8(from20, (-1, 20))
+        n = len(s)
+        pre = None if pre_flags is None else _u8(pre_flags)
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_group_verify_senders(self._g, _p(pl), _p(off), _p(s), _p(f), _p(pre), n, _p(mask), C.byref(t)),
+                  "ibft_group_verify_senders")
+        return mask_to_bool(mask, n), t
+
+    def verify_messages(self, payload: bytes, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None,
+                        valid_pre=None, raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
+        """a whole PREPARE / COMMIT set sharded by message → (sender bool[n], valid bool[n], merged Tally)"""
+        pl = _bytes_col(payload)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        s = _u8(msg_sig65, (-1, 65)); f = _u8(from20, (-1, 20)); h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
+        n = len(s)
+        sl = None if seal65 is None else _u8(seal65, (-1, 65))
+        spre = None if sender_pre is None else _u8(sender_pre)
+        vpre = None if valid_pre is None else _u8(valid_pre)
+        rawb = None if raw is None else np.frombuffer(bytes(raw) or b"\0", dtype=np.uint8)
+        dg = None if digest32 is None else np.frombuffer(bytes(digest32), dtype=np.uint8)
+        ms = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_group_verify_messages(self._g, _p(pl), _p(off), _p(s), _p(f), _p(h), _p(hl), _p(sl), _p(spre),
+                                                     _p(vpre), n, _p(rawb), 0 if raw is None else len(raw), round_, _p(dg),
+                                                     _p(ms), _p(mv), C.byref(t)), "ibft_group_verify_messages")
+        return mask_to_bool(ms, n), mask_to_bool(mv, n), t
+
+    @property
+    def is_local(self) -> bool:
+        """True: the collective is the library's own sum kernel (a device listed more than once), False: RCCL"""
+        return self._L.ibft_group_is_local(self._g) == 1
 
     def last_tally_wide(self) -> TallyWide:
         t = TallyWide()

@@ -130,7 +130,9 @@ typedef struct {
   uint32_t valid_rows;           /* popcount of the verdict mask                        */
   uint32_t distinct_senders;     /* distinct member senders among the valid rows        */
   uint32_t has_quorum;           /* power >= quorum                                     */
-  uint32_t reserved;
+  uint32_t shard_overlap;        /* sharded calls (ibft_seals_fetch_merged, ibft_group_*): Σ over validators of (shards in which
+                                    the validator has a valid row) − 1.  Such a validator is counted ONCE in power and
+                                    distinct_senders, like everywhere else; 0 from the single-device calls             */
 } ibft_tally_t;
 
 int ibft_version(void);
@@ -434,15 +436,25 @@ int ibft_sync(ibft_ctx *ctx);
  * length is a multiple of 64 (every 64-bit verdict word is owned by one rank; the last rank takes the
  * remainder): rank k verifies rows [lo, hi) of ibft_shard_range on its own device, with the validator
  * table replicated (ibft_set_validators on every context).  The one exchange step the north star names —
- * "RCCL all-reduce over xGMI of the per-message valid-bitmask" — happens INSIDE this library:
- * ncclAllReduce(sum, u64) over [verdict words of every shard | 32-bit pieces of the partial voting power |
- * valid rows | distinct senders] (disjoint shards: sum ≡ OR; 32-bit pieces in 64-bit slots: no carry is
- * lost), then has_quorum is recomputed from the merged power.  librccl is dlopen()ed on first use
- * (IBFT_RCCL_LIB overrides the name), so single-GPU users never need it.  A sender is assumed to appear in
- * one shard only (the store is keyed by sender, /root/reference/messages/messages.go:64).
+ * "RCCL all-reduce over xGMI of the per-message valid-bitmask" — happens INSIDE this library: ONE
+ * ncclAllReduce(sum, u64) over
+ *   [ K × verdict words of every shard | one distinct-sender bitmap segment per rank | valid rows ]
+ * (K = 1 for a seal / sender batch, 2 for a message set: sender words and valid words).  The verdict words are
+ * disjoint (sum ≡ OR).  The tally is NOT additive — ValidatorManager.HasQuorum counts a validator once however
+ * many of its messages are valid (a set of addresses: /root/reference/core/validator_manager.go:86-92, 147-155),
+ * and nothing stops rows of one sender from landing in two shards — so every rank ships the bitmap of the
+ * validators its tally counted (⌈n_validators/64⌉ words in its own segment of the buffer; the segments of the
+ * ranks are not disjoint as sets, hence one segment per rank instead of one summed bitmap), and after the
+ * all-reduce every rank ORs the segments and recomputes power, distinct_senders and has_quorum from the MERGED
+ * bitmap — bit for bit what ibft_verify_seals computes for the same rows on one device (tests/test_gpu_comm.py
+ * feeds the same sender to both sides of a shard seam).  ibft_tally_t.shard_overlap reports how often that happened.
+ * Buffer size: 8 B × (K·⌈n_total/64⌉ + world·⌈n_validators/64⌉ + 1), e.g. 72 KiB for 65 536 rows / validators on
+ * 8 devices — latency-bound on any link.  librccl is dlopen()ed on first use (IBFT_RCCL_LIB overrides the name),
+ * so single-GPU users never need it.
  *
  * Two ways to drive it:
- *  (1) one process, all GPUs — what a Go Backend would call: ibft_group_create + ibft_group_verify_seals;
+ *  (1) one process, all GPUs — what a Go Backend would call: ibft_group_create + ibft_group_verify_seals /
+ *      _senders / _messages (one host thread per device inside the library);
  *  (2) one process (or thread) per GPU: every rank creates its context, rank 0 calls ibft_comm_unique_id and
  *      hands the 128 bytes to the others (any side channel), everybody calls ibft_comm_init (collective);
  *      per batch: ibft_seals_stage + ibft_seals_launch on the rank's shard, ibft_seals_exchange (asynchronous:
@@ -450,9 +462,10 @@ int ibft_sync(ibft_ctx *ctx);
  *      exchanges in flight), ibft_seals_fetch_merged (oldest exchange first) → global mask + merged tally.  */
 #define IBFT_COMM_ID_BYTES 128
 int ibft_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi); /* pure */
-/* u64 slots of the exchange buffer and verdict words per rank (pure; power_words = 1 for u64 powers, 4 for u256) */
-int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t power_words, uint32_t *words_per_rank,
-                         uint32_t *slots);
+/* layout of the exchange buffer (pure): verdict words per rank, bitmap words per rank, u64 slots in all;
+ * n_masks = K above.  Any out pointer may be NULL.                                                        */
+int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t n_validators, uint32_t n_masks,
+                         uint32_t *words_per_rank, uint32_t *seen_words, uint32_t *slots);
 int ibft_comm_unique_id(uint8_t id[IBFT_COMM_ID_BYTES]);
 int ibft_comm_init(ibft_ctx *ctx, const uint8_t id[IBFT_COMM_ID_BYTES], uint32_t rank, uint32_t world);
 int ibft_comm_destroy(ibft_ctx *ctx);
@@ -461,19 +474,37 @@ int ibft_seals_exchange(ibft_ctx *ctx, uint64_t n_total);
 int ibft_seals_fetch_merged(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
 
 typedef struct ibft_group ibft_group;
-/* one context per listed device + one communicator over them; max_rows_total = largest n (0 = 65536 per device) */
+/* One context per listed device + the collective over them; max_rows_total = largest n (0 = 65536 per device).
+ * Distinct devices: an RCCL communicator.  A list that names a device more than once (several contexts sharing
+ * one MI355X — how the sharded path is exercised with world > 1 on a one-GPU box) cannot be an RCCL communicator
+ * (one rank per device); the all-reduce is then the library's own sum kernel over the ranks' buffers on rank 0's
+ * exchange stream, everything around it — pack, unpack, streams, double buffering — being the same code.
+ * IBFT_GROUP_COLLECTIVE=local selects that kernel for distinct devices too (needs peer access from device[0]).  */
 int ibft_group_create(const int32_t *devices, uint32_t n_devices, uint32_t flags, uint32_t max_rows_total,
                       ibft_group **out);
 void ibft_group_destroy(ibft_group *g);
 uint32_t ibft_group_size(const ibft_group *g);
+int ibft_group_is_local(const ibft_group *g); /* 1: the library's sum kernel is the collective, 0: RCCL */
 ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i); /* the i-th device's context (diagnostics, ibft_last_tally_wide) */
 int ibft_group_set_validators(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n);
 int ibft_group_set_validators_u256(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint8_t *power_be32,
                                    size_t n);
 /* IsValidCommittedSeal + HasQuorum for n rows sharded over the group's devices: same arguments and results as
- * ibft_verify_seals, out_mask / tally are the merged (global) ones.                                         */
+ * ibft_verify_seals, out_mask / tally are the merged (global) ones — identical to ibft_verify_seals on the whole
+ * batch whatever the rows contain (duplicated senders across shards included).                              */
 int ibft_group_verify_seals(ibft_group *g, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
                             const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally);
+/* IsValidValidator + HasQuorum, sharded: ibft_verify_senders' arguments and results.                        */
+int ibft_group_verify_senders(ibft_group *g, const uint8_t *payload, const uint32_t *off, const uint8_t *sig65,
+                              const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
+                              ibft_tally_t *tally);
+/* A whole PREPARE / COMMIT set sharded by MESSAGE: ibft_verify_messages' arguments and results (BASELINE config #3's
+ * sequence at validator counts beyond one device's batch); the exchange carries both verdict arrays (K = 2).  */
+int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
+                               const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len,
+                               const uint8_t *seal65, const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n,
+                               const uint8_t *raw, size_t raw_len, uint64_t round, const uint8_t *digest32,
+                               uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,8 @@ type Tally struct {
 	ValidRows          uint32
 	DistinctSenders    uint32
 	HasQuorum          bool
+	// sharded calls: how often a validator had valid rows in more than one shard (it is counted once)
+	ShardOverlap uint32
 }
 
 // Ctx owns one ibft_ctx (one HIP stream, resident columns on one GPU).  Use one Ctx per
@@ -330,7 +332,8 @@ func (c *Ctx) SignSeals(sk, hashes []byte) (seals, signers, ok []byte, err error
 
 // Group is one process driving several MI355X (ibft_group_*): the rows of a batch are sharded over the
 // devices in 64-aligned ranges and ONE RCCL all-reduce inside the library merges the verdict words and the
-// tally partials — for validator sets beyond a single GPU's batch (BASELINE configs #4 / #5).
+// ranks' distinct-sender bitmaps (a validator with valid rows in two shards is counted once, as HasQuorum's
+// address set does) — for validator sets beyond a single GPU's batch (BASELINE configs #4 / #5).
 type Group struct{ g *C.ibft_group }
 
 func NewGroup(devices []int32, o Options) (*Group, error) {
@@ -384,9 +387,41 @@ func (g *Group) VerifySeals(hash32, sig65, signer20, preFlags []byte) ([]uint64,
 	return mask, tally(t), nil
 }
 
+// VerifySenders = IsValidValidator + HasQuorum, sharded like VerifySeals (payload/off: concatenated
+// PayloadNoSig bytes and their n+1 offsets).
+func (g *Group) VerifySenders(payload []byte, off []uint32, sig65, from20, preFlags []byte) ([]uint64, Tally, error) {
+	n := len(sig65) / 65
+	mask := make([]uint64, (n+63)/64+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_group_verify_senders(g.g, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0])), ptr8(sig65),
+		ptr8(from20), ptr8(preFlags), C.size_t(n), (*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
+	if rc != C.IBFT_OK {
+		return nil, Tally{}, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	return mask, tally(t), nil
+}
+
+// VerifyMessages judges a whole PREPARE / COMMIT set sharded by message (Ctx.VerifyMessages' columns and
+// results; seal65 nil for a PREPARE set; digest32 nil to have raw ‖ BE64(round) hashed on the devices).
+func (g *Group) VerifyMessages(payload []byte, off []uint32, msgSig65, from20, hash32, hashLen, seal65,
+	senderPre, validPre, raw []byte, round uint64, digest32 []byte) (senders, valid []uint64, t Tally, err error) {
+	n := len(msgSig65) / 65
+	senders = make([]uint64, (n+63)/64+1)
+	valid = make([]uint64, (n+63)/64+1)
+	var ct C.ibft_tally_t
+	rc := C.ibft_group_verify_messages(g.g, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0])), ptr8(msgSig65),
+		ptr8(from20), ptr8(hash32), ptr8(hashLen), ptr8(seal65), ptr8(senderPre), ptr8(validPre), C.size_t(n),
+		ptr8(raw), C.size_t(len(raw)), C.uint64_t(round), ptr8(digest32),
+		(*C.uint64_t)(unsafe.Pointer(&senders[0])), (*C.uint64_t)(unsafe.Pointer(&valid[0])), &ct)
+	if rc != C.IBFT_OK {
+		return nil, nil, Tally{}, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	return senders, valid, tally(ct), nil
+}
+
 func tally(t C.ibft_tally_t) Tally {
 	return Tally{uint64(t.quorum_lo), uint64(t.quorum_hi), uint64(t.power_lo), uint64(t.power_hi),
-		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0}
+		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0, uint32(t.shard_overlap)}
 }
 
 // Bit reports row i's verdict.

@@ -85,6 +85,13 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.ibft_seals_fetch(null, m, C.byref(t)),
         lambda: lib.ibft_seals_export(null, None, None),
         lambda: lib.ibft_seals_export_on(null, None, None, None),
+        lambda: lib.ibft_seals_exchange(null, 64),
+        lambda: lib.ibft_seals_fetch_merged(null, m, C.byref(t)),
+        lambda: lib.ibft_group_verify_seals(null, b, b, b, None, 1, m, C.byref(t)),
+        lambda: lib.ibft_group_verify_senders(null, b, off, b, b, None, 1, m, C.byref(t)),
+        lambda: lib.ibft_group_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, m, m, C.byref(t)),
+        lambda: lib.ibft_group_set_validators(null, 1, b, b, 1),
+        lambda: lib.ibft_group_is_local(null),
     ]
     for i, call in enumerate(calls):
         assert call() == -1, i

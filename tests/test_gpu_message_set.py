@@ -225,3 +225,29 @@ def test_long_payload_rows_in_pinned_columns(oracle):
         assert (s == exp).all() and exp.sum() == n - 1 and not v.any() and bv.gather_batches() == 1
     finally:
         bv.close()
+
+
+def test_small_context_set_after_a_plain_batch(oracle):
+    """Regression (found by the sharded-set tests of round 3): a context for fewer than 2 048 rows keeps its verdict
+    words in a 256-byte buffer that never needs reallocating, so the first message set — which doubles the verdict rows —
+    must not trust the "mask is clean" bookkeeping of an earlier plain batch: the seal words [half/64, …) had never been
+    zeroed and stale bits made forged seals valid.  A plain batch first, then a Byzantine COMMIT set, on one context."""
+    import go_ibft_amd.verifier as V
+    import torch
+    from oracle import workload as W
+    # dirty the allocator's free lists first: fresh process memory is zero and hides the bug
+    junk = [torch.full((64,), -1, dtype=torch.int64, device="cuda") for _ in range(64)]
+    del junk
+    torch.cuda.empty_cache()
+    for n in (200, 256, 700):
+        r = W.make_round(n, 7300 + n, byzantine=True, with_envelopes=True, weighted=True)
+        vs, senders, valid = _oracle_expect(oracle, r, True)
+        bv = V.BatchVerifier(max_rows=n)
+        try:
+            bv.set_validators(r.height, r.addrs, r.power)
+            a2, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)   # plain batch: words [0, n/64)
+            s, v, t = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                         valid_pre=r.pre_flags, raw=r.raw, round_=r.round)
+            assert (s == senders).all() and (v == valid).all(), [(i, r.kinds[i]) for i in np.flatnonzero(v != valid)[:8]]
+        finally:
+            bv.close()
