@@ -93,7 +93,8 @@ def test_bench_sharded_path_with_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, IBFT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2",
-                          "--no-cpu-baseline", "--no-sequence", "--no-warm"], env=env, capture_output=True, text=True,
+                          "--no-cpu-baseline", "--no-sequence", "--no-warm", "--no-sweep", "--no-certificates",
+                          "--no-host-mirror", "--extended-steps", "0"], env=env, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])   # the JSON line is the last thing on stdout

@@ -3,7 +3,7 @@
 # evidence for it.  Everything lands under gpurun_out/ (summaries in gpurun_out/profiles/).
 #   what: tests ubench stages bench prof pmc (default: all)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift || true
 WHAT=${*:-tests ubench stages bench prof pmc}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
