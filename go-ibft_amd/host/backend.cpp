@@ -6,6 +6,7 @@
 #include <chrono>
 
 #include <cstring>
+#include <random>
 
 namespace ibft {
 
@@ -365,8 +366,8 @@ bool LoopBatch::VerifyMessageSet(const Proposal *proposal, MessageType type, con
   return true;
 }
 
-bool HotPath::isAcceptableMessage(const IbftMessage &m) {
-  if (!verifier || !verifier->IsValidValidator(m)) return false;  // ibft.go:1128
+bool HotPath::isAcceptableMessage(const IbftMessage &m, const bool *sender_ok) {
+  if (sender_ok ? !*sender_ok : (!verifier || !verifier->IsValidValidator(m))) return false;  // ibft.go:1128
   if (!m.view) return false;                                       // :1133
   if (height > m.view->height) return false;                       // :1139
   if (height == m.view->height) return m.view->round >= round;     // :1144
@@ -378,14 +379,14 @@ bool HotPath::hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type)
     case PREPREPARE: return msgs.size() >= 1;
     case PREPARE: return validatorManager.HasPrepareQuorum(proposalMessage.get(), msgs);
     case ROUND_CHANGE:
-    case COMMIT: return validatorManager.HasQuorum(convertMessageToAddressSet(msgs));
+    case COMMIT: return validatorManager.HasQuorumOf(msgs);
     default: return false;
   }
 }
 
-int HotPath::AddMessage(MsgPtr m) {
+int HotPath::AddMessage(MsgPtr m, bool accepted) {
   if (!m) return 0;
-  if (!isAcceptableMessage(*m)) return 0;
+  if (!accepted && !isAcceptableMessage(*m)) return 0;
   View view = *m->view;
   uint32_t type = m->type;
   messages.AddMessage(m);
@@ -396,11 +397,14 @@ int HotPath::AddMessage(MsgPtr m) {
   return 1;
 }
 
-void HotPath::EnableQuorumIndex() {
-  index_enabled_ = true;
+// The store's hooks are installed once, for every mirror (the prune of the receive-side memory must not depend
+// on the quorum index being enabled).
+HotPath::HotPath() {
+  std::random_device rd;
+  fp_seed_ = ((uint64_t)rd() << 32) ^ rd() ^ (uint64_t)(uintptr_t)this;
   messages.SetHooks(
       [this](uint32_t type, uint64_t h, uint64_t r, const bytes &from, int delta) {
-        quorumIndex.OnSender(type, h, r, from, delta, validatorManager);
+        if (index_enabled_) quorumIndex.OnSender(type, h, r, from, delta, validatorManager);
       },
       [this](uint64_t below) {
         quorumIndex.OnPrune(below);
@@ -408,46 +412,29 @@ void HotPath::EnableQuorumIndex() {
       });
 }
 
+void HotPath::EnableQuorumIndex() { index_enabled_ = true; }
+
 void HotPath::PruneVerdictCache(uint64_t below_height) {
-  for (auto it = verdict_cache_.begin(); it != verdict_cache_.end();)
-    it = it->second.height < below_height ? verdict_cache_.erase(it) : std::next(it);
-  for (auto it = closure_cache_.begin(); it != closure_cache_.end();) {
-    const IbftMessage &m = *it->second.keep;
-    it = (!m.view || m.view->height < below_height) ? closure_cache_.erase(it) : std::next(it);
-  }
-  for (auto it = cert_roots_.begin(); it != cert_roots_.end();) {
-    if (it->second.height >= below_height) {
-      ++it;
-      continue;
-    }
-    for (const IbftMessage *k : it->second.senders) cert_sender_.erase(k);
-    for (const auto &k : it->second.hashes) cert_hash_.erase(k);
-    it = cert_roots_.erase(it);
-  }
+  for (auto it = seen_.begin(); it != seen_.end();) it = it->second.height < below_height ? seen_.erase(it) : std::next(it);
 }
 
-// The verdicts of one root row of a certificate call and of everything below it go into the arrival-time tables,
-// matched to the decoded objects by position: a decoded message lists its nested messages in the order the device lists
-// them.  A subtree whose row count differs from the decoded count (the device refused the wrapper as non-canonical) is left
-// to the stock route.
+// The verdicts of one root row of a certificate call and of everything below it are noted IN the decoded objects, matched
+// by position: a decoded message lists its nested messages in the order the device lists them.  A subtree whose row count
+// differs from the decoded count (the device refused the wrapper as non-canonical) is left to the stock route.
 void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root) {
-  CertRoot &cr = cert_roots_[root.get()];
-  cr.keep = root;
-  cr.height = root->view ? root->view->height : 0;
-  std::vector<std::pair<size_t, MsgPtr>> todo{{row, root}};
+  std::vector<std::pair<size_t, const IbftMessage *>> todo{{row, root.get()}};
   std::vector<MsgPtr> kids;
   while (!todo.empty()) {
     const size_t r = todo.back().first;
-    const MsgPtr m = todo.back().second;
+    const IbftMessage *m = todo.back().second;
     todo.pop_back();
     const uint8_t cls = cv.cls[r];
     // a PREPREPARE's own (proposal, proposalHash): validateProposalCommon's IsValidProposalHash
     if (!(cls & (IBFT_CERT_CLASS_NEEDS_HOST | IBFT_CERT_CLASS_PROPOSAL_BY_HOST))) {
       const Proposal *own = extract_proposal(*m);
-      const bytes *oh = extract_proposal_hash(*m);
-      if (own && oh) {
-        cert_hash_[{own, oh}] = cv.self[r] != 0;
-        cr.hashes.push_back({own, oh});
+      if (own && extract_proposal_hash(*m)) {
+        m->verdicts.self = cv.self[r] != 0;
+        m->verdicts.self_of = own;
       }
     }
     nested_messages(*m, kids);
@@ -459,96 +446,199 @@ void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgP
       const size_t c = nd.first_child + k;
       if (!kids[k]) continue;
       if (cv.cls[c] == 0) {
-        cert_sender_[kids[k].get()] = cv.sender[c] != 0;
-        cr.senders.push_back(kids[k].get());
+        noteSender(*kids[k], cv.sender[c] != 0);
         cert_rows++;
       }
       if (hashes_decided && !(cv.cls[c] & IBFT_CERT_CLASS_NEEDS_HOST)) {
-        // the very pointers proposalMatchesCertificate will ask about (nil when type and payload disagree: not cached)
+        // about the very hash proposalMatchesCertificate will ask about (nil when type and payload disagree: not noted)
         const bytes *h = cv.nodes[c].role == IBFT_CERT_ROLE_PC_PROPOSAL ? extract_proposal_hash(*kids[k]) : extract_prepare_hash(*kids[k]);
         if (h) {
-          cert_hash_[{last, h}] = cv.hash[c] != 0;
-          cr.hashes.push_back({last, h});
+          kids[k]->verdicts.hash = cv.hash[c] != 0;
+          kids[k]->verdicts.hash_of = last;
         }
       }
-      todo.push_back({c, kids[k]});
+      todo.push_back({c, kids[k].get()});
     }
   }
 }
 
-bool HotPath::lookupHashVerdict(const Proposal *proposal, const bytes *hash, bool &ok) const {
-  auto it = hash_verdict_.find({proposal, hash});
-  if (it != hash_verdict_.end()) {
-    ok = it->second;
-    return true;
+bool HotPath::lookupHashVerdict(const IbftMessage *m, const Proposal *proposal, const bytes *hash, bool &ok) const {
+  if (!hash_verdict_.empty()) {
+    auto it = hash_verdict_.find({proposal, hash});
+    if (it != hash_verdict_.end()) {
+      ok = it->second;
+      return true;
+    }
   }
-  auto jt = cert_hash_.find({proposal, hash});
-  if (jt != cert_hash_.end()) {
-    ok = jt->second;
-    return true;
+  if (m && proposal && hash) {
+    if (m->verdicts.hash_of == proposal && (hash == extract_proposal_hash(*m) || hash == extract_prepare_hash(*m))) {
+      ok = m->verdicts.hash != 0;
+      return true;
+    }
+    if (m->verdicts.self_of == proposal && hash == extract_proposal_hash(*m)) {
+      ok = m->verdicts.self != 0;
+      return true;
+    }
   }
   return false;
 }
 
-// IBFT.AddMessage with IsValidValidator already answered (by the device batch or the cache)
+// IBFT.AddMessage with IsValidValidator already answered (by the device batch or the message's arrival-time verdict)
 int HotPath::addWithVerdict(MsgPtr m, bool sender_ok) {
-  struct TableVerifier : Verifier {
-    Verifier *inner;
-    bool verdict;
-    bool IsValidProposalHash(const Proposal *p, const bytes *h) override { return inner->IsValidProposalHash(p, h); }
-    bool IsValidCommittedSeal(const bytes *h, const CommittedSeal *s) override { return inner->IsValidCommittedSeal(h, s); }
-    bool IsValidValidator(const IbftMessage &) override { return verdict; }
-    bool IsProposer(const bytes &id, uint64_t hh, uint64_t rr) override { return inner->IsProposer(id, hh, rr); }
-    bool IsValidProposal(const bytes &raw) override { return inner->IsValidProposal(raw); }
-    bytes ID() override { return inner->ID(); }
-  } tv;
-  tv.inner = verifier;
-  tv.verdict = sender_ok;
-  Verifier *saved = verifier;
-  verifier = &tv;
-  const int rc = index_enabled_ ? AddMessageFast(std::move(m)) : AddMessage(std::move(m));
-  verifier = saved;
-  return rc;
+  if (!m) return 0;
+  if (!isAcceptableMessage(*m, &sender_ok)) return 0;
+  return index_enabled_ ? AddMessageFast(std::move(m), true) : AddMessage(std::move(m), true);
 }
 
 void HotPath::syncClosureKey(const Proposal *proposal) {
+  // same proposal as last time? (raw ‖ BE64(round), compared without building the key)
+  bool same = false;
+  if (!proposal) {
+    same = closure_key_.empty();
+  } else if (closure_key_.size() == proposal->raw_proposal.size() + 8) {
+    uint8_t be[8];
+    for (int i = 0; i < 8; i++) be[i] = (uint8_t)(proposal->round >> (8 * (7 - i)));
+    same = memcmp(closure_key_.data(), proposal->raw_proposal.data(), proposal->raw_proposal.size()) == 0 &&
+           memcmp(closure_key_.data() + proposal->raw_proposal.size(), be, 8) == 0;
+  }
+  if (same) return;
   bytes key;
   if (proposal) {
     key = proposal->raw_proposal;
     for (int i = 7; i >= 0; i--) key.push_back((char)(proposal->round >> (8 * i)));
   }
-  if (key != closure_key_) {  // another proposal (or none): what the table says no longer applies
-    closure_key_ = std::move(key);
-    closure_cache_.clear();
-    closure_epoch_++;
-  }
+  closure_key_ = std::move(key);  // another proposal (or none): the closure verdicts noted so far no longer apply
+  closure_epoch_++;
 }
 
+namespace {
+inline uint64_t mix64(uint64_t a, uint64_t b) {
+  const unsigned __int128 r = (unsigned __int128)a * b;
+  return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+// keyed 128-bit fingerprint of a message's bytes (the key is per mirror: collisions cannot be prepared offline)
+inline void fingerprint(const uint8_t *p, size_t n, uint64_t seed, uint64_t &f1, uint64_t &f2) {
+  uint64_t a = seed ^ 0x9E3779B97F4A7C15ull, b = (seed * 0xD6E8FEB86659FD93ull) ^ (uint64_t)n;
+  while (n >= 16) {
+    uint64_t x, y;
+    memcpy(&x, p, 8);
+    memcpy(&y, p + 8, 8);
+    a = mix64(a ^ x, 0xA0761D6478BD642Full ^ y);
+    b = mix64(b ^ y, 0xE7037ED1A0B428DBull ^ x);
+    p += 16;
+    n -= 16;
+  }
+  uint8_t tail[16] = {0};
+  if (n) memcpy(tail, p, n);
+  uint64_t x, y;
+  memcpy(&x, tail, 8);
+  memcpy(&y, tail + 8, 8);
+  a = mix64(a ^ x, 0x8EBC6AF09C88C6E3ull ^ y);
+  b = mix64(b ^ y, 0x589965CC75374CC3ull ^ x);
+  f1 = mix64(a, b ^ 0x1D8E4E27C47D124Full);
+  f2 = mix64(b, a ^ 0xEB44ACCAB455D165ull);
+}
+}  // namespace
+
 bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats) {
-  results.assign(raw.size(), -1);
+  bytes wire;
+  std::vector<uint32_t> off{0};
+  size_t total = 0;
+  for (const bytes &r : raw) total += r.size();
+  wire.reserve(total);
+  for (const bytes &r : raw) {
+    wire += r;
+    off.push_back((uint32_t)wire.size());
+  }
+  std::vector<int8_t> res(raw.size(), -1);
+  const bool ok = IngestFlat((const uint8_t *)wire.data(), off.data(), raw.size(), res.data(), stats);
+  results.assign(res.begin(), res.end());
+  return ok;
+}
+
+bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats) {
+  for (size_t i = 0; i < n; i++) results[i] = -1;
   IngestStats st;
+  if (n == 0) {
+    if (stats) *stats = st;
+    return true;
+  }
   const Proposal *proposal = getProposal();
   syncClosureKey(proposal);
-  std::vector<MsgPtr> msgs(raw.size());
-  std::vector<int> verdict(raw.size(), -1);  // −1 unknown, 0 / 1 decided
-  std::vector<int> closure(raw.size(), -1);  // the handle* closure where it is already known
-  std::vector<size_t> ask;                   // rows the device has to judge: first occurrence of each distinct message
-  std::map<bytes, size_t> first_in_batch;
-  for (size_t i = 0; i < raw.size(); i++) {
-    auto m = std::make_shared<IbftMessage>();
-    if (!decode((const uint8_t *)raw[i].data(), raw[i].size(), *m)) continue;  // proto.Unmarshal error: dropped
-    msgs[i] = std::move(m);
-    auto hit = verdict_cache_.find(raw[i]);
-    if (hit != verdict_cache_.end()) {
-      verdict[i] = hit->second.ok ? 1 : 0;
-      if (hit->second.carrier) msgs[i] = hit->second.carrier;  // the object the certificate tables know
-      if (hit->second.closure >= 0 && hit->second.closure_epoch == closure_epoch_) closure[i] = hit->second.closure;
+  // ONE copy of the batch: the buffer every message decoded below points into (and keeps alive)
+  const uint8_t *wire;
+  const std::shared_ptr<const void> backing = make_backing(wire_in, off[n], &wire);
+  std::vector<MsgPtr> msgs(n);
+  std::vector<int8_t> verdict(n, -1);       // −1 unknown, 0 / 1 decided
+  std::vector<uint64_t> fp1(n), fp2(n);
+  std::vector<int32_t> dup_of(n, -1);       // a repeat inside this batch: the row that is asked instead
+  std::vector<uint8_t> stale(n, 0);         // rejected without any arithmetic (not a validator's From / a view that cannot be accepted)
+  std::vector<size_t> ask;                  // rows the device has to judge: first occurrence of each distinct new message
+  std::unordered_map<uint64_t, size_t> first_in_batch;
+  first_in_batch.reserve(n * 2);
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t *row = wire + off[i];
+    const size_t len = off[i + 1] - off[i];
+    fingerprint(row, len, fp_seed_, fp1[i], fp2[i]);
+    auto hit = seen_.find(fp1[i]);
+    if (hit != seen_.end() && hit->second.fp2 == fp2[i] && hit->second.len == len && memcmp(hit->second.wire, row, len) == 0) {
+      msgs[i] = hit->second.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
+      verdict[i] = 1;
       st.cache_hits++;
-    } else if (first_in_batch.emplace(raw[i], i).second) {
-      ask.push_back(i);
+      continue;
     }
+    auto rej = seen_rejected_.find(fp1[i]);
+    if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
+      verdict[i] = 0;  // rejected before (the reference would judge it again — and reject it again)
+      st.cache_hits++;
+      results[i] = 0;
+      continue;
+    }
+    auto ins = first_in_batch.emplace(fp1[i], i);
+    if (!ins.second) {
+      const size_t f = ins.first->second;
+      if (fp2[f] == fp2[i] && off[f + 1] - off[f] == len && memcmp(wire + off[f], row, len) == 0) {
+        dup_of[i] = (int32_t)f;
+        continue;
+      }
+    }
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode_in(backing, row, len, *m)) continue;  // proto.Unmarshal error: dropped (results −1)
+    msgs[i] = std::move(m);
+    // What AddMessage rejects whatever the signature says costs no device work (and, for a PREPREPARE / ROUND_CHANGE, no
+    // expansion of its certificates): a nil view or a view below the state's cannot pass isAcceptableMessage
+    // (core/ibft.go:1133-1148).  (Membership of From is the Backend's business — a mock accepts anybody — so it is NOT
+    // pre-judged here; the device rejects a non-member like any other bad signature.)
+    const IbftMessage &mm = *msgs[i];
+    const bool view_ok = mm.view && !(height > mm.view->height) && !(height == mm.view->height && mm.view->round < round);
+    if (use_batch && batch && !view_ok) {
+      stale[i] = 1;
+      verdict[i] = 0;
+      continue;
+    }
+    ask.push_back(i);
   }
-  const std::vector<size_t> asked = ask;  // every distinct undecided message of the batch (cached at the end)
+  const std::vector<size_t> asked = ask;  // every distinct undecided message of the batch
+  std::vector<uint8_t> was_asked(n, 0);
+  for (size_t i : asked) was_asked[i] = 1;
+  // rows [lo, hi) of the batch as one wire + offsets: the batch's own buffer when they are ALL its rows, a copy otherwise
+  bytes sub_wire;
+  std::vector<uint32_t> sub_off;
+  auto rows_as_wire = [&](const std::vector<size_t> &rows, const uint8_t *&w, const uint32_t *&o) {
+    if (rows.size() == n) {
+      w = wire;
+      o = off;
+      return;
+    }
+    sub_wire.clear();
+    sub_off.assign(1, 0);
+    for (size_t i : rows) {
+      sub_wire.append((const char *)wire + off[i], off[i + 1] - off[i]);
+      sub_off.push_back((uint32_t)sub_wire.size());
+    }
+    w = (const uint8_t *)sub_wire.data();
+    o = sub_off.data();
+  };
   // (0) messages that carry certificates: the whole tree — their own envelope and every message nested in them — in ONE
   // device call, from the bytes as they arrived
   if (use_batch && batch && use_certs) {
@@ -556,14 +646,11 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
     for (size_t i : ask)
       if (msgs[i]->kind == PayloadKind::PREPREPARE || msgs[i]->kind == PayloadKind::ROUND_CHANGE) carriers.push_back(i);
     if (!carriers.empty()) {
-      bytes wire;
-      std::vector<uint32_t> off{0};
-      for (size_t i : carriers) {
-        wire += raw[i];
-        off.push_back((uint32_t)wire.size());
-      }
+      const uint8_t *w;
+      const uint32_t *o;
+      rows_as_wire(carriers, w, o);
       CertVerdicts cv;
-      if (batch->VerifyCertificatesWire((const uint8_t *)wire.data(), off.data(), carriers.size(), cv) && cv.n_rows >= carriers.size()) {
+      if (batch->VerifyCertificatesWire(w, o, carriers.size(), cv) && cv.n_rows >= carriers.size()) {
         st.device_calls++;
         cert_calls++;
         for (size_t j = 0; j < carriers.size(); j++) {
@@ -571,7 +658,8 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
             verdict[carriers[j]] = cv.sender[j] ? 1 : 0;
             cert_rows++;
           }
-          noteCertificateTree(cv, j, msgs[carriers[j]]);
+          // what the device said about the nested messages is only worth noting for a carrier that will be stored
+          if (verdict[carriers[j]] != 0) noteCertificateTree(cv, j, msgs[carriers[j]]);
         }
         std::vector<size_t> left;
         for (size_t i : ask)
@@ -586,20 +674,16 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
   bool wire_sets_done = false;
   if (gpu_sets && !ask.empty()) {
     // the device walks the bytes AND judges every PREPARE / COMMIT of this view completely: one call for the micro-batch
-    bytes wire;
-    std::vector<uint32_t> off{0};
-    for (size_t i : ask) {
-      wire += raw[i];
-      off.push_back((uint32_t)wire.size());
-    }
+    const uint8_t *w;
+    const uint32_t *o;
+    rows_as_wire(ask, w, o);
     std::vector<uint8_t> vs, vc, judged;
-    if (gpu_sets->VerifyMessagesWire((const uint8_t *)wire.data(), off.data(), ask.size(), height, round, *proposal, vs, vc,
-                                     judged)) {
+    if (gpu_sets->VerifyMessagesWire(w, o, ask.size(), height, round, *proposal, vs, vc, judged)) {
       st.device_calls++;
       for (size_t j = 0; j < ask.size(); j++) {
         verdict[ask[j]] = vs[j] ? 1 : 0;
         if (judged[j]) {
-          closure[ask[j]] = vc[j] ? 1 : 0;
+          noteClosure(*msgs[ask[j]], vc[j] != 0);
           st.set_rows++;
         }
       }
@@ -629,7 +713,7 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
         st.set_rows += sub.size();
         for (size_t k = 0; k < sub.size(); k++) {
           verdict[of_type[t][k]] = vs[k] ? 1 : 0;
-          closure[of_type[t][k]] = vc[k] ? 1 : 0;
+          noteClosure(*sub[k], vc[k] != 0);
         }
       } else {  // not offered, or the device call failed: these rows take the sender route below
         rest.insert(rest.end(), of_type[t].begin(), of_type[t].end());
@@ -646,13 +730,10 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
     if (use_batch && batch) {
       st.device_calls++;
       if (auto *gpu = dynamic_cast<GpuBackend *>(batch)) {  // the device walks the bytes themselves (§8f rank 3)
-        bytes wire;
-        std::vector<uint32_t> off{0};
-        for (size_t i : rest) {
-          wire += raw[i];
-          off.push_back((uint32_t)wire.size());
-        }
-        ok = gpu->VerifySendersWire((const uint8_t *)wire.data(), off.data(), rest.size(), v);
+        const uint8_t *w;
+        const uint32_t *o;
+        rows_as_wire(rest, w, o);
+        ok = gpu->VerifySendersWire(w, o, rest.size(), v);
       } else {
         std::vector<MsgPtr> sub;
         for (size_t i : rest) sub.push_back(msgs[i]);
@@ -668,32 +749,41 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
     for (size_t j = 0; j < rest.size(); j++) verdict[rest[j]] = v[j] ? 1 : 0;
   }
   st.device_rows = asked.size();
-  for (size_t i : asked) {
-    CachedVerdict cv{verdict[i] == 1, msgs[i]->view ? msgs[i]->view->height : 0};
-    cv.closure = closure[i];
-    cv.closure_epoch = closure_epoch_;
-    if (cert_roots_.count(msgs[i].get())) cv.carrier = msgs[i];
-    verdict_cache_[raw[i]] = cv;
-  }
-  for (size_t i = 0; i < raw.size(); i++) {
-    if (!msgs[i]) continue;
-    if (verdict[i] < 0) {  // a repeat inside this batch
-      const size_t first = first_in_batch[raw[i]];
-      verdict[i] = verdict[first];
-      closure[i] = closure[first];
-      if (cert_roots_.count(msgs[first].get())) msgs[i] = msgs[first];
+  // IBFT.AddMessage per message, in arrival order, with the verdict attached; what was stored is remembered for its
+  // re-deliveries, what was rejected by its fingerprint
+  for (size_t i = 0; i < n; i++) {
+    if (dup_of[i] >= 0) {  // a repeat inside this batch: the first occurrence's object and verdict
+      msgs[i] = msgs[(size_t)dup_of[i]];
+      verdict[i] = verdict[(size_t)dup_of[i]];
     }
-    if (closure[i] >= 0 && verdict[i] == 1) closure_cache_[msgs[i].get()] = ClosureVerdict{msgs[i], closure[i] == 1};
-    results[i] = addWithVerdict(msgs[i], verdict[i] == 1);
+    if (!msgs[i]) continue;
+    if (verdict[i] == 1) noteSender(*msgs[i], true);
+    const bool fresh = was_asked[i] != 0;
+    results[i] = (int8_t)addWithVerdict(msgs[i], verdict[i] == 1);
+    if (!fresh) continue;
+    if (results[i] > 0) {
+      if (seen_.size() >= seen_cap) seen_.clear();
+      const IbftMessage &m = *msgs[i];
+      seen_[fp1[i]] = Seen{fp2[i], msgs[i], wire + off[i], off[i + 1] - off[i], m.view ? m.view->height : 0};
+    } else if (verdict[i] == 0) {
+      if (rejected_fifo_.size() < rejected_cap) {
+        rejected_fifo_.push_back(fp1[i]);
+      } else if (rejected_cap) {
+        seen_rejected_.erase(rejected_fifo_[rejected_head_]);
+        rejected_fifo_[rejected_head_] = fp1[i];
+        rejected_head_ = (rejected_head_ + 1) % rejected_cap;
+      }
+      if (rejected_cap) seen_rejected_[fp1[i]] = fp2[i];
+    }
   }
   if (stats) *stats = st;
   return true;
 }
 
 
-int HotPath::AddMessageFast(MsgPtr m) {
+int HotPath::AddMessageFast(MsgPtr m, bool accepted) {
   if (!m) return 0;
-  if (!isAcceptableMessage(*m)) return 0;
+  if (!accepted && !isAcceptableMessage(*m)) return 0;
   const View view = *m->view;
   const uint32_t type = m->type;
   messages.AddMessage(m);
@@ -711,10 +801,9 @@ int HotPath::AddMessageFast(MsgPtr m) {
     case PREPREPARE: q = pc.second >= 1; break;
     case PREPARE: {  // HasPrepareQuorum: proposer joins the set; a PREPARE from the proposer voids it
       if (!proposalMessage) break;
-      if (messages.Has(view, PREPARE, proposalMessage->from)) break;
-      auto p = validatorManager.powers().find(proposalMessage->from);
-      unsigned __int128 w = p == validatorManager.powers().end() ? 0 : p->second;
-      q = validatorManager.initialized() && pc.first + w >= validatorManager.quorum();
+      const unsigned __int128 w = validatorManager.powerOf(proposalMessage->from);
+      q = validatorManager.initialized() && pc.first + w >= validatorManager.quorum() &&
+          !messages.Has(view, PREPARE, proposalMessage->from);  // (the store is only asked once the power suffices)
       break;
     }
     case ROUND_CHANGE:
@@ -733,9 +822,8 @@ std::vector<uint8_t> HotPath::closureVerdicts(const Proposal *proposal, MessageT
   std::vector<MsgPtr> rest;
   std::vector<size_t> rest_idx;
   for (size_t k = 0; k < all.size(); k++) {
-    auto it = use_sets ? closure_cache_.find(all[k].get()) : closure_cache_.end();
-    if (it != closure_cache_.end()) {
-      v[k] = it->second.ok;
+    if (use_sets && closureKnown(*all[k])) {  // judged completely when it arrived
+      v[k] = all[k]->verdicts.closure;
       closure_hits++;
     } else {
       rest.push_back(all[k]);
@@ -812,10 +900,11 @@ bool HotPath::handleCommit(const View &view) {
 namespace ibft {
 
 bool HotPath::isValidValidatorCached(const IbftMessage &m) {
-  auto it = sender_verdict_.find(&m);
-  if (it != sender_verdict_.end()) return it->second;
-  auto jt = cert_sender_.find(&m);  // judged when the message that carries it arrived (IngestWire, use_certs)
-  if (jt != cert_sender_.end()) return jt->second;
+  if (!sender_verdict_.empty()) {
+    auto it = sender_verdict_.find(&m);
+    if (it != sender_verdict_.end()) return it->second;
+  }
+  if (senderKnown(m)) return m.verdicts.sender;  // judged when the message that carries it arrived (IngestWire, use_certs)
   return verifier->IsValidValidator(m);
 }
 
@@ -823,9 +912,9 @@ void HotPath::prefetchSenders(const std::vector<const IbftMessage *> &all) {
   sender_verdict_.clear();
   last_cert_senders = 0;
   cert_hits = 0;
-  std::vector<const IbftMessage *> msgs;  // what the arrival-time tables cannot answer
+  std::vector<const IbftMessage *> msgs;  // what the arrival-time verdicts cannot answer
   for (const IbftMessage *m : all) {
-    if (cert_sender_.count(m))
+    if (senderKnown(*m))
       cert_hits++;
     else
       msgs.push_back(m);
@@ -836,6 +925,7 @@ void HotPath::prefetchSenders(const std::vector<const IbftMessage *> &all) {
   for (const IbftMessage *m : msgs) owned.push_back(MsgPtr(MsgPtr(), const_cast<IbftMessage *>(m)));  // non-owning alias
   std::vector<uint8_t> v;
   if (!batch->VerifySenderBatch(owned, v) || v.size() != msgs.size()) return;  // device unavailable: stock path
+  sender_verdict_.reserve(msgs.size() * 2);
   for (size_t i = 0; i < msgs.size(); i++) sender_verdict_[msgs[i]] = v[i] != 0;
   last_cert_senders = msgs.size();
 }
@@ -864,7 +954,7 @@ bool HotPath::validPCImpl(const PreparedCertificate *certificate, uint64_t round
   std::vector<MsgPtr> all;
   all.push_back(certificate->proposal_message);
   for (auto &m : certificate->prepare_messages) all.push_back(m);
-  if (!validatorManager.HasQuorum(convertMessageToAddressSet(all))) return false;
+  if (!validatorManager.HasQuorumOf(all)) return false;
   if (certificate->proposal_message->type != PREPREPARE) return false;
   for (auto &m : certificate->prepare_messages)
     if (m->type != PREPARE) return false;
@@ -883,14 +973,19 @@ bool HotPath::proposalMatchesCertificate(const Proposal *proposal, const Prepare
   if (!proposal && !certificate) return true;
   if (!certificate) return false;
   std::vector<const bytes *> hashes;
+  std::vector<const IbftMessage *> carriers;  // the message each hash comes from
   // ExtractProposalHash on a nil message would panic in the reference; treat as a nil hash
   hashes.push_back(certificate->proposal_message ? extract_proposal_hash(*certificate->proposal_message) : nullptr);
-  for (auto &m : certificate->prepare_messages) hashes.push_back(m ? extract_prepare_hash(*m) : nullptr);
-  if (!hash_verdict_.empty() || !cert_hash_.empty()) {  // answered by handleRoundChangeMessage's pre-pass, or on arrival
+  carriers.push_back(certificate->proposal_message.get());
+  for (auto &m : certificate->prepare_messages) {
+    hashes.push_back(m ? extract_prepare_hash(*m) : nullptr);
+    carriers.push_back(m.get());
+  }
+  {  // answered by handleRoundChangeMessage's pre-pass, or when the carrying message arrived
     bool all_known = true, all_ok = true;
-    for (const bytes *h : hashes) {
+    for (size_t k = 0; k < hashes.size() && all_known; k++) {
       bool ok = false;
-      all_known = all_known && lookupHashVerdict(proposal, h, ok);
+      all_known = lookupHashVerdict(carriers[k], proposal, hashes[k], ok);
       all_ok = all_ok && ok;
     }
     if (all_known) return all_ok;
@@ -927,7 +1022,7 @@ bool HotPath::validateProposalCommon(const IbftMessage &msg, const View &view) {
   if (!proposal) return false;  // the reference dereferences it; a nil proposal cannot be valid
   if (proposal->round != view.round) return false;
   if (!verifier->IsProposer(msg.from, view.height, view.round)) return false;
-  if (!isValidProposalHashCached(proposal, proposalHash)) return false;
+  if (!isValidProposalHashCached(msg, proposal, proposalHash)) return false;
   return verifier->IsValidProposal(proposal->raw_proposal);
 }
 
@@ -1004,9 +1099,9 @@ bool HotPath::validateProposal(const IbftMessage &msg, const View &view) {
 // ---- handleRoundChangeMessage (core/ibft.go:470-512) ------------------------------------------------
 namespace ibft {
 
-bool HotPath::isValidProposalHashCached(const Proposal *proposal, const bytes *hash) {
+bool HotPath::isValidProposalHashCached(const IbftMessage &m, const Proposal *proposal, const bytes *hash) {
   bool ok = false;
-  if (lookupHashVerdict(proposal, hash, ok)) return ok;
+  if (lookupHashVerdict(&m, proposal, hash, ok)) return ok;
   return verifier->IsValidProposalHash(proposal, hash);
 }
 
@@ -1029,8 +1124,10 @@ void HotPath::prefetchCertificateHashes(const std::vector<MsgPtr> &rcs) {
     if (!proposal || !cert) continue;  // proposalMatchesCertificate decides these without the backend
     {  // everything about this certificate already settled when the message arrived?
       bool known = true, ok = false;
-      known = lookupHashVerdict(proposal, cert->proposal_message ? extract_proposal_hash(*cert->proposal_message) : nullptr, ok);
-      for (auto &m : cert->prepare_messages) known = known && lookupHashVerdict(proposal, m ? extract_prepare_hash(*m) : nullptr, ok);
+      known = lookupHashVerdict(cert->proposal_message.get(), proposal,
+                                cert->proposal_message ? extract_proposal_hash(*cert->proposal_message) : nullptr, ok);
+      for (auto &m : cert->prepare_messages)
+        known = known && lookupHashVerdict(m.get(), proposal, m ? extract_prepare_hash(*m) : nullptr, ok);
       if (known) continue;
     }
     Group &g = groups[{proposal->raw_proposal, proposal->round}];

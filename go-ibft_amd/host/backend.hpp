@@ -158,21 +158,21 @@ class HotPath {
     return proposalMessage ? extract_proposal(*proposalMessage) : nullptr;
   }
   // IBFT.AddMessage: 0 = rejected, 1 = stored, 2 = stored and SignalEvent fired
-  int AddMessage(MsgPtr m);
+  int AddMessage(MsgPtr m, bool accepted = false);  // accepted: isAcceptableMessage already answered true
   // Same decisions with the O(1) quorum probe (QuorumIndex) instead of the O(#stored) walk;
   // call EnableQuorumIndex() once, and NotifyValidatorSetChanged() after validatorManager.Init.
-  int AddMessageFast(MsgPtr m);
+  int AddMessageFast(MsgPtr m, bool accepted = false);
   void EnableQuorumIndex();
   void NotifyValidatorSetChanged() {
     quorumIndex.Invalidate();
-    verdict_cache_.clear();
-    closure_cache_.clear();
-    cert_roots_.clear();
-    cert_sender_.clear();
-    cert_hash_.clear();
+    valset_epoch_++;   // every sender verdict noted in a message object was computed against the old set: ignored from now on
+    seen_.clear();
+    seen_rejected_.clear();
   }
   QuorumIndex quorumIndex;
-  bool isAcceptableMessage(const IbftMessage &m);
+  // sender_ok: IsValidValidator already answered (by a device batch or the arrival-time verdict in the message); null = ask
+  // the per-message verifier (the stock path)
+  bool isAcceptableMessage(const IbftMessage &m, const bool *sender_ok = nullptr);
   bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
   bool handlePrepare(const View &view);
   bool handleCommit(const View &view);
@@ -212,9 +212,19 @@ class HotPath {
   size_t cert_calls = 0, cert_rows = 0;  // certificate-tree calls made by IngestWire, rows they judged
   size_t cert_hits = 0;  // sender verdicts the last certificate walk took from the arrival-time tables
   bool IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats = nullptr);
+  // The same for a micro-batch in the device's own layout — row i is wire[off[i] .. off[i+1]), rows back to back: what a
+  // transport that receives into one buffer (or the cgo shim's SoA batcher) holds.  The bytes are copied ONCE (the buffer
+  // every decoded message of the batch points into) and, when no row is answered from the cache, handed to the device
+  // as they are.  results[i]: −1 undecodable, else AddMessage's 0 / 1 / 2.
+  bool IngestFlat(const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats = nullptr);
   // IBFT.AddMessage with IsValidValidator already answered (AddMessageFast when the quorum index is enabled)
   int addWithVerdict(MsgPtr m, bool sender_ok);
   void PruneVerdictCache(uint64_t below_height);
+  // Bounds of the receive-side memory: messages remembered for re-delivery (each entry pins one stored message)
+  // and fingerprints of rejected ones.  When `seen_cap` is reached the table is dropped (re-deliveries are judged again).
+  size_t seen_cap = 1u << 18, rejected_cap = 1u << 14;
+  size_t seen_entries() const { return seen_.size(); }
+  HotPath();
   // Certificate checks (§8f rank 2), restated from core/ibft.go: validPC :1162-1231,
   // proposalMatchesCertificate :516-551, validateProposalCommon :629-655, validateProposal0
   // :658-680, validateProposal :683-788.  With use_batch, every IsValidValidator /
@@ -230,52 +240,53 @@ class HotPath {
   size_t last_cert_senders = 0, last_cert_hashes = 0;
 
  private:
-  // verdict tables filled by the batch pre-pass; empty = ask the per-message verifier
-  std::map<const IbftMessage *, bool> sender_verdict_;
-  std::map<std::pair<const Proposal *, const bytes *>, bool> hash_verdict_;  // (proposal, hash) by identity
-  bool isValidValidatorCached(const IbftMessage &m);
-  bool isValidProposalHashCached(const Proposal *proposal, const bytes *hash);
-  void prefetchCertificateHashes(const std::vector<MsgPtr> &rcs);
-  bool index_enabled_ = false;
-  struct CachedVerdict {
-    bool ok;
-    uint64_t height;
-    int closure = -1;            // −1 unknown, else the handle* closure's verdict …
-    uint64_t closure_epoch = 0;  // … against the proposal of this epoch
-    MsgPtr carrier;              // a message whose nested messages have verdicts in the arrival-time tables: a re-delivery of the
-                                 // same bytes is answered with THIS object, so that the tables keep applying to what is stored
-  };
-  // closure verdicts by stored message (the entry keeps the message alive, so its address cannot be reused)
-  struct ClosureVerdict {
-    MsgPtr keep;
-    bool ok;
-  };
-  std::map<const IbftMessage *, ClosureVerdict> closure_cache_;
-  bytes closure_key_;          // raw proposal ‖ BE64(round) the table refers to
-  uint64_t closure_epoch_ = 1;
-  void syncClosureKey(const Proposal *proposal);
-  // the handle* walks: table hits first, one batch call for the rest, per-message closure when that fails
-  std::vector<uint8_t> closureVerdicts(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &all);
-  std::map<bytes, CachedVerdict> verdict_cache_;
-  // arrival-time verdicts about nested messages (use_certs): by identity of the decoded objects, which the root entry
-  // keeps alive (an address cannot be reused while its verdict is in the table)
-  struct CertRoot {
-    MsgPtr keep;
-    uint64_t height = 0;
-    std::vector<const IbftMessage *> senders;
-    std::vector<std::pair<const Proposal *, const bytes *>> hashes;
-  };
+  // verdict tables filled by the batch pre-pass of a certificate walk (transient: cleared when the walk returns)
+  std::unordered_map<const IbftMessage *, bool> sender_verdict_;
   struct PairHash {
     size_t operator()(const std::pair<const Proposal *, const bytes *> &k) const {
       return std::hash<const void *>()(k.first) * 1000003u ^ std::hash<const void *>()(k.second);
     }
   };
-  std::map<const IbftMessage *, CertRoot> cert_roots_;
-  // hashed: a round change at N = 256 files ≈ 29 000 sender and as many hash verdicts per micro-batch
-  std::unordered_map<const IbftMessage *, bool> cert_sender_;
-  std::unordered_map<std::pair<const Proposal *, const bytes *>, bool, PairHash> cert_hash_;
+  std::unordered_map<std::pair<const Proposal *, const bytes *>, bool, PairHash> hash_verdict_;  // (proposal, hash) by identity
+  bool isValidValidatorCached(const IbftMessage &m);
+  // m: the message that carries `hash` (its arrival-time verdict, if any, is in m.verdicts)
+  bool lookupHashVerdict(const IbftMessage *m, const Proposal *proposal, const bytes *hash, bool &ok) const;
+  bool isValidProposalHashCached(const IbftMessage &m, const Proposal *proposal, const bytes *hash);
+  void prefetchCertificateHashes(const std::vector<MsgPtr> &rcs);
+  bool index_enabled_ = false;
+  // Arrival-time verdicts live IN the message objects (proto.hpp: Verdicts) and are valid for these epochs
+  uint32_t valset_epoch_ = 1;   // bumped by NotifyValidatorSetChanged
+  uint32_t closure_epoch_ = 1;  // bumped when the proposal the closure verdicts refer to changes
+  bytes closure_key_;           // raw proposal ‖ BE64(round) the closure verdicts refer to
+  void syncClosureKey(const Proposal *proposal);
+  bool senderKnown(const IbftMessage &m) const { return m.verdicts.sender_epoch == valset_epoch_; }
+  bool closureKnown(const IbftMessage &m) const { return m.verdicts.closure_epoch == closure_epoch_; }
+  void noteSender(const IbftMessage &m, bool ok) const {
+    m.verdicts.sender = ok;
+    m.verdicts.sender_epoch = valset_epoch_;
+  }
+  void noteClosure(const IbftMessage &m, bool ok) const {
+    m.verdicts.closure = ok;
+    m.verdicts.closure_epoch = closure_epoch_;
+  }
+  // the handle* walks: arrival-time verdicts first, one batch call for the rest, per-message closure when that fails
+  std::vector<uint8_t> closureVerdicts(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &all);
+  // Messages seen before, by a keyed 128-bit fingerprint of their wire bytes: a byte-identical re-delivery (gossip) of a
+  // STORED message is answered with the stored object (compared byte for byte on a hit) — no decode, no device work; a
+  // re-delivery of a rejected one by its fingerprint alone, from a bounded FIFO.
+  struct Seen {
+    uint64_t fp2;
+    MsgPtr msg;           // the stored message (keeps its bytes: wire_of / wire_len point into its backing)
+    const uint8_t *wire;
+    uint32_t len;
+    uint64_t height;
+  };
+  std::unordered_map<uint64_t, Seen> seen_;
+  std::unordered_map<uint64_t, uint64_t> seen_rejected_;  // fp1 → fp2
+  std::vector<uint64_t> rejected_fifo_;
+  size_t rejected_head_ = 0;
+  uint64_t fp_seed_;
   void noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root);
-  bool lookupHashVerdict(const Proposal *proposal, const bytes *hash, bool &ok) const;
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);
 

@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "backend.hpp"
 
@@ -86,11 +87,15 @@ void msgs_to_buf(const std::vector<MsgPtr> &msgs, ibft_host_buf *out) {
   to_buf(o, msgs.size(), out);
 }
 void seals_to_buf(const std::vector<std::optional<CommittedSeal>> &seals, ibft_host_buf *out) {
+  static const bytes none;
   bytes o;
+  size_t total = 0;
+  for (auto &s : seals) total += 9 + (s ? s->signer.size() + s->signature.size() : 0);
+  o.reserve(total);
   for (auto &s : seals) {
     o.push_back(s ? 1 : 0);
-    pack_bytes(o, s ? s->signer : bytes());
-    pack_bytes(o, s ? s->signature : bytes());
+    pack_bytes(o, s ? s->signer : none);
+    pack_bytes(o, s ? s->signature : none);
   }
   to_buf(o, seals.size(), out);
 }
@@ -98,6 +103,10 @@ void seals_to_buf(const std::vector<std::optional<CommittedSeal>> &seals, ibft_h
 }  // namespace
 
 struct ibft_host {
+  // One mirror = one IBFT instance.  The reference calls AddMessage from transport goroutines while the round goroutine
+  // walks the store (core/ibft.go:335-347); every entry point below takes this mutex, so any thread may call any of them
+  // (the ingest queue's worker included) and each call sees the mirror between two other calls, never inside one.
+  std::recursive_mutex mu;
   HotPath hp;
   CallbackVerifier cbv;
   std::unique_ptr<GpuBackend> gpu;
@@ -221,18 +230,21 @@ int ibft_host_reencode(const uint8_t *wire, size_t len, ibft_host_buf *out) {
 }
 
 int ibft_host_store_add(ibft_host *h, const uint8_t *wire, size_t len) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   auto m = std::make_shared<IbftMessage>();
   if (!decode(wire, len, *m)) return -1;
   h->hp.messages.AddMessage(std::move(m));
   return 0;
 }
 size_t ibft_host_store_num(ibft_host *h, uint64_t height, uint64_t round, uint32_t type) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   return h->hp.messages.numMessages(View{height, round, {}}, (MessageType)type);
 }
-void ibft_host_store_prune(ibft_host *h, uint64_t height) { h->hp.messages.PruneByHeight(height); }
+void ibft_host_store_prune(ibft_host *h, uint64_t height) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.messages.PruneByHeight(height); }
 
 int ibft_host_store_get_valid(ibft_host *h, uint64_t height, uint64_t round, uint32_t type,
                               ibft_host_msg_pred pred, void *user, ibft_host_buf *out) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   auto msgs = h->hp.messages.GetValidMessages(View{height, round, {}}, (MessageType)type, [&](const IbftMessage &m) {
     if (!pred) return true;
     bytes w = encode(m);
@@ -243,6 +255,7 @@ int ibft_host_store_get_valid(ibft_host *h, uint64_t height, uint64_t round, uin
 }
 int ibft_host_store_get_extended_rcc(ibft_host *h, uint64_t height, ibft_host_msg_pred pred,
                                      ibft_host_rcc_pred rcc_pred, void *user, ibft_host_buf *out) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   auto msgs = h->hp.messages.GetExtendedRCC(
       height,
       [&](const IbftMessage &m) {
@@ -255,6 +268,7 @@ int ibft_host_store_get_extended_rcc(ibft_host *h, uint64_t height, ibft_host_ms
   return 0;
 }
 int ibft_host_store_get_most_rc(ibft_host *h, uint64_t min_round, uint64_t height, ibft_host_buf *out) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   msgs_to_buf(h->hp.messages.GetMostRoundChangeMessages(min_round, height), out);
   return 0;
 }
@@ -279,6 +293,7 @@ int ibft_host_extract_committed_seals(const uint8_t *packed, size_t len, ibft_ho
 }
 
 int ibft_host_vm_init(ibft_host *h, const uint8_t *packed_addrs, size_t len, const uint64_t *power, size_t n) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<bytes> addrs;
   if (!unpack_list(packed_addrs, len, addrs) || addrs.size() != n) return -2;
   std::vector<std::pair<bytes, uint64_t>> p;
@@ -288,12 +303,14 @@ int ibft_host_vm_init(ibft_host *h, const uint8_t *packed_addrs, size_t len, con
   return ok ? 0 : -1;
 }
 int ibft_host_vm_has_quorum(ibft_host *h, const uint8_t *packed_senders, size_t len) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<bytes> s;
   if (!unpack_list(packed_senders, len, s)) return -1;
   return h->hp.validatorManager.HasQuorum(std::set<bytes>(s.begin(), s.end())) ? 1 : 0;
 }
 int ibft_host_vm_has_prepare_quorum(ibft_host *h, const uint8_t *proposal_wire, size_t proposal_len,
                                     const uint8_t *packed_msgs, size_t len) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<MsgPtr> msgs;
   if (!unpack_msgs(packed_msgs, len, msgs)) return -1;
   IbftMessage pm;
@@ -305,6 +322,7 @@ int ibft_host_vm_has_prepare_quorum(ibft_host *h, const uint8_t *proposal_wire, 
   return h->hp.validatorManager.HasPrepareQuorum(pp, msgs) ? 1 : 0;
 }
 void ibft_host_vm_quorum(ibft_host *h, uint64_t *lo, uint64_t *hi) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   unsigned __int128 q = h->hp.validatorManager.quorum();
   *lo = (uint64_t)q;
   *hi = (uint64_t)(q >> 64);
@@ -312,6 +330,7 @@ void ibft_host_vm_quorum(ibft_host *h, uint64_t *lo, uint64_t *hi) {
 
 int ibft_host_set_state(ibft_host *h, uint64_t height, uint64_t round, const uint8_t *proposal_wire,
                         size_t proposal_len) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   h->hp.height = height;
   h->hp.round = round;
   h->hp.proposalMessage.reset();
@@ -323,28 +342,33 @@ int ibft_host_set_state(ibft_host *h, uint64_t height, uint64_t round, const uin
   return 0;
 }
 void ibft_host_set_verifier(ibft_host *h, const ibft_host_verifier *v) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   h->cbv.cb = v ? *v : ibft_host_verifier{};
 }
 void ibft_host_attach_gpu(ibft_host *h, ibft_ctx *ctx) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   h->gpu = ctx ? std::make_unique<GpuBackend>(ctx) : nullptr;
   h->hp.batch = h->gpu.get();
 }
-void ibft_host_use_batch(ibft_host *h, int on) { h->hp.use_batch = on != 0; }
+void ibft_host_use_batch(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_batch = on != 0; }
 
 int ibft_host_add_message(ibft_host *h, const uint8_t *wire, size_t len) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   auto m = std::make_shared<IbftMessage>();
   if (!decode(wire, len, *m)) return -1;
   return h->hp.AddMessage(std::move(m));
 }
 
-void ibft_host_enable_quorum_index(ibft_host *h) { h->hp.EnableQuorumIndex(); }
+void ibft_host_enable_quorum_index(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.EnableQuorumIndex(); }
 int ibft_host_add_message_fast(ibft_host *h, const uint8_t *wire, size_t len) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   auto m = std::make_shared<IbftMessage>();
   if (!decode(wire, len, *m)) return -1;
   return h->hp.AddMessageFast(std::move(m));
 }
 
 int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len, uint8_t *results, size_t n) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<MsgPtr> msgs;
   if (!unpack_msgs(packed, len, msgs) || msgs.size() != n) return -1;
   if (!h->hp.batch) return -2;
@@ -356,38 +380,74 @@ int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len
   return 0;
 }
 
-int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_t *results, size_t n, size_t *device_rows,
-                          size_t *cache_hits, size_t *device_calls) {
-  std::vector<bytes> raw;
-  if (!unpack_list(packed, len, raw) || raw.size() != n) return -1;
-  std::vector<int> res;
+static int ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results, size_t *device_rows,
+                       size_t *cache_hits, size_t *device_calls) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   HotPath::IngestStats st;
-  if (!h->hp.IngestWire(raw, res, &st)) return -3;
-  for (size_t i = 0; i < n; i++) results[i] = (int8_t)res[i];
+  if (!h->hp.IngestFlat(wire, off, n, results, &st)) return -3;
   if (device_rows) *device_rows = st.device_rows;
   if (cache_hits) *cache_hits = st.cache_hits;
   if (device_calls) *device_calls = st.device_calls;
   h->last_set_rows = st.set_rows;
   return 0;
 }
-void ibft_host_use_sets(ibft_host *h, int on) { h->hp.use_sets = on != 0; }
-void ibft_host_use_certs(ibft_host *h, int on) { h->hp.use_certs = on != 0; }
+int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_t *results, size_t n, size_t *device_rows,
+                          size_t *cache_hits, size_t *device_calls) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  // repeated {u32 length, bytes} → rows back to back + offsets (one pass, one buffer)
+  std::vector<uint8_t> wire;
+  std::vector<uint32_t> off{0};
+  wire.reserve(len);
+  off.reserve(n + 1);
+  size_t pos = 0;
+  while (pos < len) {
+    if (len - pos < 4) return -1;
+    uint32_t l;
+    memcpy(&l, packed + pos, 4);
+    pos += 4;
+    if (l > len - pos) return -1;
+    wire.insert(wire.end(), packed + pos, packed + pos + l);
+    off.push_back((uint32_t)wire.size());
+    pos += l;
+  }
+  if (off.size() != n + 1) return -1;
+  return ingest_flat(h, wire.data(), off.data(), n, results, device_rows, cache_hits, device_calls);
+}
+int ibft_host_ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results,
+                          size_t *device_rows, size_t *cache_hits, size_t *device_calls) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  if (!h || (n && (!wire || !off || !results))) return -1;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return -1;
+  return ingest_flat(h, wire, off, n, results, device_rows, cache_hits, device_calls);
+}
+size_t ibft_host_seen_entries(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.seen_entries(); }
+void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_cap) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  h->hp.seen_cap = stored_cap;
+  h->hp.rejected_cap = rejected_cap;
+}
+void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
+void ibft_host_use_certs(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_certs = on != 0; }
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   if (calls) *calls = h->hp.cert_calls;
   if (rows) *rows = h->hp.cert_rows;
   if (hits) *hits = h->hp.cert_hits;
 }
-size_t ibft_host_loop_batch_cert_calls(ibft_host *h) { return h->loop ? h->loop->cert_calls : 0; }
+size_t ibft_host_loop_batch_cert_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->loop ? h->loop->cert_calls : 0; }
 int ibft_host_handle_preprepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *msg) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   MsgPtr m = h->hp.handlePrePrepare(View{height, round, {}});
   if (msg) msgs_to_buf(m ? std::vector<MsgPtr>{m} : std::vector<MsgPtr>{}, msg);
   return m ? 1 : 0;
 }
-size_t ibft_host_last_set_rows(ibft_host *h) { return h->last_set_rows; }
-size_t ibft_host_closure_hits(ibft_host *h) { return h->hp.closure_hits; }
-size_t ibft_host_loop_batch_set_calls(ibft_host *h) { return h->loop ? h->loop->set_calls : 0; }
+size_t ibft_host_last_set_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->last_set_rows; }
+size_t ibft_host_closure_hits(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.closure_hits; }
+size_t ibft_host_loop_batch_set_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->loop ? h->loop->set_calls : 0; }
 
 void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   h->loop.reset(new LoopBatch(&h->cbv));
   h->loop->fail_hashes = (fail_mask & 1) != 0;
   h->loop->fail_seals = (fail_mask & 2) != 0;
@@ -396,17 +456,19 @@ void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
   h->loop->fail_certs = (fail_mask & 16) != 0;
   h->hp.batch = h->loop.get();
 }
-size_t ibft_host_loop_batch_calls(ibft_host *h) { return h->loop ? h->loop->calls : 0; }
-size_t ibft_host_fallbacks(ibft_host *h) { return h->hp.fallbacks; }
+size_t ibft_host_loop_batch_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->loop ? h->loop->calls : 0; }
+size_t ibft_host_fallbacks(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.fallbacks; }
 
 int ibft_host_handle_round_change(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *rcc) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<MsgPtr> out = h->hp.handleRoundChangeMessage(View{height, round, {}});
   if (rcc) msgs_to_buf(out, rcc);
   return out.empty() ? 0 : 1;
 }
 
-void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len) { h->cbv.id.assign((const char *)id, len); }
+void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->cbv.id.assign((const char *)id, len); }
 int ibft_host_valid_pc(ibft_host *h, const uint8_t *pc_wire, size_t len, uint64_t round_limit, uint64_t height) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   if (!pc_wire) return h->hp.validPC(nullptr, round_limit, height) ? 1 : 0;
   PreparedCertificate pc;
   if (!decode(pc_wire, len, pc)) return -1;
@@ -414,6 +476,7 @@ int ibft_host_valid_pc(ibft_host *h, const uint8_t *pc_wire, size_t len, uint64_
 }
 int ibft_host_proposal_matches_certificate(ibft_host *h, const uint8_t *proposal_wire, size_t plen,
                                            const uint8_t *pc_wire, size_t clen) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   Proposal p;
   PreparedCertificate pc;
   if (proposal_wire && !decode(proposal_wire, plen, p)) return -1;
@@ -421,26 +484,31 @@ int ibft_host_proposal_matches_certificate(ibft_host *h, const uint8_t *proposal
   return h->hp.proposalMatchesCertificate(proposal_wire ? &p : nullptr, pc_wire ? &pc : nullptr) ? 1 : 0;
 }
 int ibft_host_validate_proposal0(ibft_host *h, const uint8_t *msg_wire, size_t len, uint64_t height, uint64_t round) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   IbftMessage m;
   if (!decode(msg_wire, len, m)) return -1;
   return h->hp.validateProposal0(m, View{height, round, {}}) ? 1 : 0;
 }
 int ibft_host_validate_proposal(ibft_host *h, const uint8_t *msg_wire, size_t len, uint64_t height, uint64_t round) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   IbftMessage m;
   if (!decode(msg_wire, len, m)) return -1;
   return h->hp.validateProposal(m, View{height, round, {}}) ? 1 : 0;
 }
 void ibft_host_last_cert_batch(ibft_host *h, size_t *senders, size_t *hashes) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   if (senders) *senders = h->hp.last_cert_senders;
   if (hashes) *hashes = h->hp.last_cert_hashes;
 }
 
 int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   bool q = h->hp.handlePrepare(View{height, round, {}});
   if (prepared) msgs_to_buf(q ? h->hp.preparedMessages : std::vector<MsgPtr>{}, prepared);
   return q ? 1 : 0;
 }
 int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
   bool q = h->hp.handleCommit(View{height, round, {}});
   if (seals) seals_to_buf(q ? h->hp.committedSeals : std::vector<std::optional<CommittedSeal>>{}, seals);
   return q ? 1 : 0;

@@ -1,19 +1,28 @@
 // messages.cpp — see messages.hpp for the reference lines each method follows.
 #include "messages.hpp"
 
+#include <string_view>
+#include <unordered_set>
+
 namespace ibft {
 
 void Messages::AddMessage(MsgPtr m) {
   int s = slot(m->type);
   if (s < 0 || !m->view) return;  // the reference would panic on an unknown type / nil view
   std::unique_lock lk(mux_[s]);
-  auto &view_msgs = maps_[s][m->view->height][m->view->round];
   const uint64_t h = m->view->height, r = m->view->round;
-  auto it = view_msgs.find(m->from);
-  if (it == view_msgs.end()) {
-    const bytes from = m->from;
-    view_msgs.emplace(from, std::move(m));
-    if (sender_hook_) sender_hook_((uint32_t)s, h, r, from, +1);
+  // consecutive messages mostly belong to one view: remember where its senders are (std::map nodes do not move)
+  LastView &lv = last_[s];
+  if (!lv.msgs || lv.height != h || lv.round != r) {
+    lv.msgs = &maps_[s][h][r];
+    lv.height = h;
+    lv.round = r;
+  }
+  protoMessages &view_msgs = *lv.msgs;
+  auto it = view_msgs.lower_bound(m->from);  // one descent for the lookup and the insert
+  if (it == view_msgs.end() || it->first != m->from) {
+    auto ins = view_msgs.emplace_hint(it, m->from, std::move(m));
+    if (sender_hook_) sender_hook_((uint32_t)s, h, r, ins->first, +1);
   } else {
     it->second = std::move(m);  // last writer wins, sender set unchanged
   }
@@ -44,6 +53,7 @@ void Messages::PruneByHeight(uint64_t height) {
     std::unique_lock lk(mux_[s]);
     auto &m = maps_[s];
     m.erase(m.begin(), m.lower_bound(height));  // delete every msgHeight < height
+    last_[s] = LastView{};
   }
   if (height_hook_) height_hook_(height);
 }
@@ -151,6 +161,9 @@ bool ValidatorManager::Init(const std::vector<std::pair<bytes, uint64_t>> &power
   for (auto &kv : p) total += kv.second;
   if (total == 0) return false;  // errVotingPowerNotCorrect: state is left unchanged
   power_ = std::move(p);
+  fast_.clear();
+  fast_.reserve(power_.size() * 2);
+  for (auto &kv : power_) fast_.emplace(kv.first, kv.second);
   quorum_ = (total * 2) / 3 + 1;  // calculateQuorum :130-135
   initialized_ = true;
   return true;
@@ -159,36 +172,42 @@ bool ValidatorManager::Init(const std::vector<std::pair<bytes, uint64_t>> &power
 bool ValidatorManager::HasQuorum(const std::set<bytes> &senders) const {
   if (!initialized_) return false;  // :82-84
   unsigned __int128 sum = 0;
-  for (auto &s : senders) {
-    auto it = power_.find(s);
-    if (it != power_.end()) sum += it->second;
-  }
+  for (auto &s : senders) sum += powerOf(s);  // unknown senders contribute 0 (:88-92)
+  return sum >= quorum_;
+}
+
+// The same over the From of a list of messages (convertMessageToAddressSet + HasQuorum, :77-96, :147-155): the SET of
+// senders, each counted once — a flat hash set of views instead of one tree node per sender.
+bool ValidatorManager::HasQuorumOf(const std::vector<MsgPtr> &msgs, const bytes *extra) const {
+  if (!initialized_) return false;
+  std::unordered_set<std::string_view> seen;
+  seen.reserve(msgs.size() * 2 + 2);
+  unsigned __int128 sum = 0;
+  if (extra && seen.insert(std::string_view(extra->data(), extra->size())).second) sum += powerOf(*extra);
+  for (auto &m : msgs)
+    if (seen.insert(std::string_view(m->from.data(), m->from.size())).second) sum += powerOf(m->from);
   return sum >= quorum_;
 }
 
 bool ValidatorManager::HasPrepareQuorum(const IbftMessage *proposal, const std::vector<MsgPtr> &msgs) const {
   if (!proposal) return false;
-  std::set<bytes> senders{proposal->from};
-  for (auto &m : msgs) {
+  for (auto &m : msgs)
     if (m->from == proposal->from) return false;  // proposer among PREPARE signers :117-121
-    senders.insert(m->from);
-  }
-  return HasQuorum(senders);
+  return HasQuorumOf(msgs, &proposal->from);
 }
 
 void QuorumIndex::OnSender(uint32_t type, uint64_t height, uint64_t round, const bytes &from, int delta,
                            const ValidatorManager &vm) {
   std::lock_guard<std::mutex> lk(mu_);
-  auto it = e_.find({type, height, round});
-  if (it == e_.end() || !it->second.valid || it->second.epoch != epoch_) return;  // stale: rebuilt on demand
-  auto p = vm.powers().find(from);
-  unsigned __int128 w = p == vm.powers().end() ? 0 : p->second;  // unknown senders contribute 0
+  Entry *e = find(type, height, round);
+  if (!e || !e->valid || e->epoch != epoch_) return;  // stale: rebuilt on demand
+  const unsigned __int128 w = vm.powerOf(from);       // unknown senders contribute 0
   if (delta > 0) {
-    it->second.power += w;
-    it->second.count++;
+    e->power += w;
+    e->count++;
   } else {
-    it->second.power -= w;
-    it->second.count--;
+    e->power -= w;
+    e->count--;
   }
 }
 
@@ -196,18 +215,24 @@ void QuorumIndex::OnPrune(uint64_t below_height) {
   std::lock_guard<std::mutex> lk(mu_);
   for (auto it = e_.begin(); it != e_.end();)
     it = std::get<1>(it->first) < below_height ? e_.erase(it) : std::next(it);
+  last_ = nullptr;
 }
 
 std::pair<unsigned __int128, size_t> QuorumIndex::Get(uint32_t type, uint64_t height, uint64_t round,
                                                       const std::function<std::vector<bytes>()> &rebuild,
                                                       const ValidatorManager &vm) {
   std::lock_guard<std::mutex> lk(mu_);
-  Entry &e = e_[{type, height, round}];
+  Entry *pe = find(type, height, round);
+  if (!pe) {
+    pe = &e_[{type, height, round}];
+    last_key_ = {type, height, round};
+    last_ = pe;
+  }
+  Entry &e = *pe;
   if (!e.valid || e.epoch != epoch_) {
     e = Entry{};
     for (const bytes &from : rebuild()) {
-      auto p = vm.powers().find(from);
-      if (p != vm.powers().end()) e.power += p->second;
+      e.power += vm.powerOf(from);
       e.count++;
     }
     e.valid = true;

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <set>
 #include <shared_mutex>
+#include <unordered_map>
 
 #include "proto.hpp"
 
@@ -58,6 +59,11 @@ class Messages {
   using roundMessageMap = std::map<uint64_t, protoMessages>;  // round -> ...
   using heightMessageMap = std::map<uint64_t, roundMessageMap>;
   heightMessageMap maps_[4];
+  struct LastView {
+    protoMessages *msgs = nullptr;
+    uint64_t height = 0, round = 0;
+  };
+  LastView last_[4];  // where the senders of the view of the last AddMessage are (per type)
   std::shared_mutex mux_[4];
   SenderHook sender_hook_;
   HeightHook height_hook_;
@@ -71,14 +77,23 @@ class ValidatorManager {
   // setCurrentVotingPower (:61-75); false = errVotingPowerNotCorrect
   bool Init(const std::vector<std::pair<bytes, uint64_t>> &powers);
   bool HasQuorum(const std::set<bytes> &senders) const;                                  // :77-96
+  // HasQuorum(convertMessageToAddressSet(msgs) ∪ {extra}) without materialising the set
+  bool HasQuorumOf(const std::vector<MsgPtr> &msgs, const bytes *extra = nullptr) const;
   // :99-127.  proposal == nullptr -> false
   bool HasPrepareQuorum(const IbftMessage *proposal, const std::vector<MsgPtr> &msgs) const;
   unsigned __int128 quorum() const { return quorum_; }
   bool initialized() const { return initialized_; }
   const std::map<bytes, uint64_t> &powers() const { return power_; }
+  // O(1): voting power of `from` (0 for a non-member) and membership
+  uint64_t powerOf(const bytes &from) const {
+    auto it = fast_.find(from);
+    return it == fast_.end() ? 0 : it->second;
+  }
+  bool isValidator(const bytes &from) const { return fast_.find(from) != fast_.end(); }
 
  private:
   std::map<bytes, uint64_t> power_;
+  std::unordered_map<bytes, uint64_t> fast_;
   unsigned __int128 quorum_ = 0;
   bool initialized_ = false;
 };
@@ -107,6 +122,17 @@ class QuorumIndex {
     bool valid = false;
   };
   std::map<std::tuple<uint32_t, uint64_t, uint64_t>, Entry> e_;
+  std::tuple<uint32_t, uint64_t, uint64_t> last_key_{};
+  Entry *last_ = nullptr;  // entry of the last view asked about (std::map nodes do not move)
+  Entry *find(uint32_t type, uint64_t height, uint64_t round) {
+    const std::tuple<uint32_t, uint64_t, uint64_t> k{type, height, round};
+    if (last_ && last_key_ == k) return last_;
+    auto it = e_.find(k);
+    if (it == e_.end()) return nullptr;
+    last_key_ = k;
+    last_ = &it->second;
+    return last_;
+  }
   uint64_t epoch_ = 1;
   std::mutex mu_;
 };

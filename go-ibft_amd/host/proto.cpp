@@ -1,7 +1,11 @@
 // proto.cpp — wire encode/decode + Extract* helpers (see proto.hpp for the reference lines).
 #include "proto.hpp"
 
+#include <cstdlib>
+#include <cstring>
 #include <set>
+#include <string_view>
+#include <unordered_set>
 
 namespace ibft {
 
@@ -27,6 +31,16 @@ void put_varint_field(bytes &o, uint32_t num, uint64_t v) {  // proto3: zero omi
     put_varint(o, (uint64_t)num << 3);
     put_varint(o, v);
   }
+}
+
+// decode mode of the current thread: byte fields become views into tl_backing (which every decoded message keeps), or
+// owned copies (standalone Proposal / values with nothing to keep a buffer alive)
+thread_local const std::shared_ptr<const void> *tl_backing = nullptr;
+inline void set_bytes(bytes &dst, const uint8_t *q, size_t l) {
+  if (tl_backing)
+    dst = bytes::view((const char *)q, l);
+  else
+    dst.assign((const char *)q, l);
 }
 
 struct Reader {
@@ -107,7 +121,7 @@ bool decode_proposal(const uint8_t *p, size_t n, Proposal &o) {
     size_t l;
     if (tag == ((1u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
-      o.raw_proposal.assign((const char *)q, l);
+      set_bytes(o.raw_proposal, q, l);
     } else if (tag == ((2u << 3) | 0)) {
       if (!r.varint(o.round)) return false;
     } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
@@ -183,7 +197,7 @@ bool decode_preprepare(const uint8_t *p, size_t n, PrePrepareMessage &o, int dep
       if (!decode_proposal(q, l, *o.proposal)) return false;
     } else if (tag == ((2u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
-      o.proposal_hash.assign((const char *)q, l);
+      set_bytes(o.proposal_hash, q, l);
     } else if (tag == ((3u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
       if (!o.certificate) o.certificate.emplace();
@@ -207,7 +221,7 @@ bool decode_prepare(const uint8_t *p, size_t n, PrepareMessage &o) {
     size_t l;
     if (tag == ((1u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
-      o.proposal_hash.assign((const char *)q, l);
+      set_bytes(o.proposal_hash, q, l);
     } else if ((tag >> 3) == 1) {
       return false;
     } else if (!keep_unknown(r, tag, start, o.unknown)) {
@@ -227,10 +241,10 @@ bool decode_commit(const uint8_t *p, size_t n, CommitMessage &o) {
     size_t l;
     if (tag == ((1u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
-      o.proposal_hash.assign((const char *)q, l);
+      set_bytes(o.proposal_hash, q, l);
     } else if (tag == ((2u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
-      o.committed_seal.assign((const char *)q, l);
+      set_bytes(o.committed_seal, q, l);
     } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
       return false;
     } else if (!keep_unknown(r, tag, start, o.unknown)) {
@@ -267,6 +281,7 @@ bool decode_round_change(const uint8_t *p, size_t n, RoundChangeMessage &o, int 
 
 bool decode_msg(const uint8_t *p, size_t n, IbftMessage &m, int depth) {
   if (depth > 64) return false;  // protobuf-go's default recursion limit is far above any real nesting
+  if (tl_backing) m.backing = *tl_backing;
   Reader r{p, p + n};
   while (r.p < r.end) {
     const uint8_t *start = r.p;
@@ -281,10 +296,10 @@ bool decode_msg(const uint8_t *p, size_t n, IbftMessage &m, int depth) {
       if (!decode_view(q, l, *m.view)) return false;
     } else if (num == 2 && wt == 2) {
       if (!r.len_delim(q, l)) return false;
-      m.from.assign((const char *)q, l);
+      set_bytes(m.from, q, l);
     } else if (num == 3 && wt == 2) {
       if (!r.len_delim(q, l)) return false;
-      m.signature.assign((const char *)q, l);
+      set_bytes(m.signature, q, l);
     } else if (num == 4 && wt == 0) {
       uint64_t v;
       if (!r.varint(v)) return false;
@@ -295,10 +310,12 @@ bool decode_msg(const uint8_t *p, size_t n, IbftMessage &m, int depth) {
       PayloadKind k = num == 5 ? PayloadKind::PREPREPARE : num == 6 ? PayloadKind::PREPARE
                       : num == 7 ? PayloadKind::COMMIT : PayloadKind::ROUND_CHANGE;
       if (m.kind != k) {
-        m.preprepare = {};
-        m.prepare = {};
-        m.commit = {};
-        m.round_change = {};
+        if (m.kind != PayloadKind::NONE) {  // another member was set before: the last one on the wire wins
+          m.preprepare = {};
+          m.prepare = {};
+          m.commit = {};
+          m.round_change = {};
+        }
         m.kind = k;
       }
       bool ok = k == PayloadKind::PREPREPARE  ? decode_preprepare(q, l, m.preprepare, depth)
@@ -390,16 +407,39 @@ bytes encode(const IbftMessage &m, bool with_signature) {
   return o;
 }
 
+std::shared_ptr<const void> make_backing(const uint8_t *p, size_t n, const uint8_t **copy) {
+  uint8_t *b = static_cast<uint8_t *>(malloc(n ? n : 1));
+  if (n) memcpy(b, p, n);
+  *copy = b;
+  return std::shared_ptr<const void>(b, free);
+}
+namespace {
+struct BackingScope {
+  const std::shared_ptr<const void> *saved;
+  explicit BackingScope(const std::shared_ptr<const void> *b) : saved(tl_backing) { tl_backing = b; }
+  ~BackingScope() { tl_backing = saved; }
+};
+}  // namespace
+bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out) {
+  BackingScope scope(&backing);
+  return decode_msg(p, n, out, 0);
+}
 bool decode(const uint8_t *p, size_t n, IbftMessage &out) {
   out = IbftMessage{};
-  return decode_msg(p, n, out, 0);
+  const uint8_t *q;
+  std::shared_ptr<const void> backing = make_backing(p, n, &q);
+  return decode_in(backing, q, n, out);
 }
 bool decode(const uint8_t *p, size_t n, PreparedCertificate &out) {
   out = PreparedCertificate{};
-  return decode_pc(p, n, out, 0);
+  const uint8_t *q;
+  std::shared_ptr<const void> backing = make_backing(p, n, &q);  // kept by the messages of the certificate
+  BackingScope scope(&backing);
+  return decode_pc(q, n, out, 0);
 }
 bool decode(const uint8_t *p, size_t n, Proposal &out) {
   out = Proposal{};
+  BackingScope scope(nullptr);  // nothing would keep a buffer alive: owned copies
   return decode_proposal(p, n, out);
 }
 
@@ -410,7 +450,9 @@ const bytes *extract_commit_hash(const IbftMessage &m) {
 }
 std::optional<CommittedSeal> extract_committed_seal(const IbftMessage &m) {
   if (m.kind != PayloadKind::COMMIT) return std::nullopt;  // only the payload is checked (helpers.go:39-42)
-  return CommittedSeal{m.from, m.commit.committed_seal};
+  // views: the seal is read while the message is alive (the list form below keeps the message)
+  return CommittedSeal{bytes::view(m.from.data(), m.from.size()),
+                       bytes::view(m.commit.committed_seal.data(), m.commit.committed_seal.size()), nullptr};
 }
 const bytes *extract_prepare_hash(const IbftMessage &m) {
   if (m.type != PREPARE || m.kind != PayloadKind::PREPARE) return nullptr;
@@ -445,15 +487,17 @@ bool extract_committed_seals(const std::vector<MsgPtr> &msgs, std::vector<std::o
       return false;
     }
     out.push_back(extract_committed_seal(*m));
+    if (out.back()) out.back()->keep = m;  // the views stay valid for as long as the seal list lives
   }
   return true;
 }
 
 bool has_unique_senders(const std::vector<MsgPtr> &msgs) {
   if (msgs.empty()) return false;
-  std::set<bytes> seen;
+  std::unordered_set<std::string_view> seen;
+  seen.reserve(msgs.size() * 2);
   for (const auto &m : msgs)
-    if (!seen.insert(m->from).second) return false;
+    if (!seen.insert(std::string_view(m->from.data(), m->from.size())).second) return false;
   return true;
 }
 
@@ -467,7 +511,8 @@ bool are_valid_pc_messages(const std::vector<MsgPtr> &msgs, uint64_t height, uin
   // messages[0].View.Round: a nil View would panic in the reference; treat as invalid
   if (!msgs[0]->view) return false;
   const uint64_t round = msgs[0]->view->round;
-  std::set<bytes> senders;
+  std::unordered_set<std::string_view> senders;
+  senders.reserve(msgs.size() * 2);
   const bytes *hash = nullptr;
   for (const auto &m : msgs) {
     if (!m->view) return false;
@@ -486,7 +531,7 @@ bool are_valid_pc_messages(const std::vector<MsgPtr> &msgs, uint64_t height, uin
     // an explicitly-encoded empty one is indistinguishable here and treated as nil too
     if (hash == nullptr || hash->empty()) hash = extracted;
     if (!ok || !bytes_equal(hash, extracted)) return false;
-    if (!senders.insert(m->from).second) return false;
+    if (!senders.insert(std::string_view(m->from.data(), m->from.size())).second) return false;
   }
   return true;
 }

@@ -13,9 +13,9 @@
 #include <string>
 #include <vector>
 
-namespace ibft {
+#include "bytes.hpp"
 
-using bytes = std::string;  // byte strings; std::string gives value semantics + hashing
+namespace ibft {
 
 enum MessageType : uint32_t { PREPREPARE = 0, PREPARE = 1, COMMIT = 2, ROUND_CHANGE = 3 };
 
@@ -68,6 +68,19 @@ struct RoundChangeMessage {
 // Which member of the `payload` oneof is set (messages.proto:36-43); NONE = nil Payload.
 enum class PayloadKind { NONE, PREPREPARE, PREPARE, COMMIT, ROUND_CHANGE };
 
+// What the hot path has learned about a message — NOT part of its wire state (never encoded, never compared).  The three
+// Verifier predicates are pure functions of the message bytes, the proposal and the validator set, so a verdict computed
+// when the message arrived can sit in the message object itself: it lives exactly as long as the message, needs no side
+// table, and is ignored (epoch mismatch) once the validator set or the proposal it was computed against has changed.
+struct Verdicts {
+  uint32_t sender_epoch = 0;   // validator-set epoch of `sender` (0 = unknown)
+  uint32_t closure_epoch = 0;  // proposal epoch of `closure` (0 = unknown)
+  const void *hash_of = nullptr;   // the Proposal object `hash` was judged against (a nested message of a PreparedCertificate:
+                                   // its carrier's lastPreparedProposal — proposalMatchesCertificate, core/ibft.go:516-551)
+  const void *self_of = nullptr;   // a PREPREPARE's own Proposal object `self` was judged against (validateProposalCommon)
+  uint8_t sender = 0, closure = 0, hash = 0, self = 0;
+};
+
 struct IbftMessage {
   std::optional<View> view;  // nil-able pointer in Go
   bytes from;
@@ -79,6 +92,10 @@ struct IbftMessage {
   CommitMessage commit;
   RoundChangeMessage round_change;
   bytes unknown;
+  // the buffer the byte fields of a DECODED message (and of everything nested in it) point into; null for a message
+  // that was built field by field
+  std::shared_ptr<const void> backing;
+  mutable Verdicts verdicts;
 };
 
 // ---- wire encoding ---------------------------------------------------------------------
@@ -92,6 +109,11 @@ bytes encode(const RoundChangeCertificate &rcc);
 // ---- wire decoding (what proto.Unmarshal does for these messages) -------------------------
 // Returns false on malformed input (truncated varint/length, bad wire type for a known field).
 bool decode(const uint8_t *p, size_t n, IbftMessage &out);
+// The same without copying the wire: [p, p + n) lies inside `backing`, which the message (and every message nested in it)
+// keeps alive; all byte fields are views into it.
+bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out);
+// a heap copy of [p, p + n) to decode into (one allocation)
+std::shared_ptr<const void> make_backing(const uint8_t *p, size_t n, const uint8_t **copy);
 bool decode(const uint8_t *p, size_t n, PreparedCertificate &out);
 bool decode(const uint8_t *p, size_t n, Proposal &out);
 
@@ -99,6 +121,7 @@ bool decode(const uint8_t *p, size_t n, Proposal &out);
 // A null pointer return mirrors a nil []byte / nil pointer in the reference.
 struct CommittedSeal {  // messages/helpers.go:15-19
   bytes signer, signature;
+  MsgPtr keep;  // set by extract_committed_seals: signer / signature are views into this message
 };
 const bytes *extract_commit_hash(const IbftMessage &m);        // helpers.go:51-62
 std::optional<CommittedSeal> extract_committed_seal(const IbftMessage &m);  // helpers.go:38-48

@@ -101,6 +101,10 @@ def lib() -> C.CDLL:
         L.ibft_host_handle_round_change.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         L.ibft_host_ingest_wire.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ibft_host_ingest_flat.argtypes = [vp, vp, vp, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ibft_host_seen_entries.argtypes = [vp]; L.ibft_host_seen_entries.restype = C.c_size_t
+        L.ibft_host_set_seen_caps.argtypes = [vp, C.c_size_t, C.c_size_t]; L.ibft_host_set_seen_caps.restype = None
         L.ibft_host_use_loop_batch.argtypes = [vp, C.c_int]
         L.ibft_host_loop_batch_calls.argtypes = [vp]; L.ibft_host_loop_batch_calls.restype = C.c_size_t
         L.ibft_host_fallbacks.argtypes = [vp]; L.ibft_host_fallbacks.restype = C.c_size_t
@@ -377,6 +381,47 @@ class Host:
         if rc != 0:
             raise RuntimeError(f"ibft_host_ingest_wire rc={rc}")
         return [x - 256 if x > 127 else x for x in res.raw[:len(wires)]], a.value, b.value, c.value
+
+    def ingest_packed(self, packed: bytes, n: int) -> bytes:
+        """ingest_wire for a micro-batch that is already packed (repeated {u32 length, bytes}) → the n result bytes as
+        they are (0 / 1 / 2, 0xFF = undecodable): no per-message Python work"""
+        res = C.create_string_buffer(max(n, 1))
+        rc = self.L.ibft_host_ingest_wire(self.h, packed, len(packed), res, n, None, None, None)
+        if rc != 0:
+            raise RuntimeError(f"ibft_host_ingest_wire rc={rc}")
+        return res.raw[:n]
+
+    def ingest_flat(self, wire, off, want_stats: bool = False):
+        """ibft_host_ingest_flat: wire = numpy uint8 (rows back to back), off = numpy uint32 (n + 1) → the n result bytes
+        (and (device rows, cache hits, device calls) with want_stats)"""
+        n = len(off) - 1
+        res = C.create_string_buffer(max(n, 1))
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        rc = self.L.ibft_host_ingest_flat(self.h, wire.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n, res,
+                                          C.byref(a), C.byref(b), C.byref(c))
+        if rc != 0:
+            raise RuntimeError(f"ibft_host_ingest_flat rc={rc}")
+        return (res.raw[:n], (a.value, b.value, c.value)) if want_stats else res.raw[:n]
+
+    def seen_entries(self) -> int:
+        return self.L.ibft_host_seen_entries(self.h)
+
+    def set_seen_caps(self, stored_cap: int, rejected_cap: int):
+        self.L.ibft_host_set_seen_caps(self.h, stored_cap, rejected_cap)
+
+    def handle_commit_raw(self, height, round_):
+        """handleCommit → (quorum, the packed seal list as bytes); unpack_seals() decodes it"""
+        b = Buf()
+        q = self.L.ibft_host_handle_commit(self.h, height, round_, C.byref(b))
+        return bool(q), _take(b)
+
+    def handle_prepare_quiet(self, height, round_) -> bool:
+        """handlePrepare without marshalling the prepared messages back (a Go caller holds the objects)"""
+        return self.L.ibft_host_handle_prepare(self.h, height, round_, None) == 1
+
+    def handle_round_change_count(self, height, round_) -> int:
+        """handleRoundChangeMessage → 1 when an extended RCC exists (0 = nil), nothing marshalled back"""
+        return self.L.ibft_host_handle_round_change(self.h, height, round_, None)
 
     def use_certs(self, on: bool):
         self.L.ibft_host_use_certs(self.h, 1 if on else 0)

@@ -117,6 +117,17 @@ int ibft_host_add_messages_batch(ibft_host *h, const uint8_t *packed, size_t len
  * batch backend, or when the device call fails, the per-message verifier answers (ibft_host_fallbacks).   */
 int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_t *results, size_t n,
                           size_t *device_rows, size_t *cache_hits, size_t *device_calls);
+/* The same for a micro-batch in the DEVICE's layout: row i is wire[off[i] .. off[i+1]), rows back to back, n + 1 offsets —
+ * what a transport that receives into one buffer (or the cgo shim's SoA batcher) holds.  The mirror copies the bytes once
+ * (every decoded message of the batch points into that copy) and hands them to the device as they are.               */
+int ibft_host_ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results,
+                          size_t *device_rows, size_t *cache_hits, size_t *device_calls);
+/* Receive-side memory (bounded): messages remembered for byte-identical re-deliveries — only messages that AddMessage
+ * STORED are remembered (the entry is the stored message itself, verdicts included; it goes when the store prunes its
+ * height), rejected ones leave a 16-byte keyed fingerprint in a FIFO of rejected_cap entries.  When stored_cap entries are
+ * reached the table is dropped and re-deliveries are judged again.  Defaults: 262 144 / 16 384.                        */
+size_t ibft_host_seen_entries(ibft_host *h);
+void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_cap);
 /* Message sets (include/ibftgpu.h: ibft_verify_messages).  When the proposal of the current view is already
  * accepted, ibft_host_ingest_wire sends the PREPARE / COMMIT messages of that view through ONE set call per
  * type: IsValidValidator and the handlePrepare / handleCommit closure (core/ibft.go:856-862, :932-944) are

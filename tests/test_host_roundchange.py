@@ -280,3 +280,49 @@ def test_messages_judged_completely_on_arrival(mode):
     a, b = ref.handle_commit(1, 1), ing.handle_commit(1, 1)
     assert a[0] == b[0] and ing.closure_hits() == 0 and ing.loop_batch_calls() == before + 1
     ref.close(); ing.close()
+
+
+def test_flat_ingest_receive_side_memory_is_bounded_and_follows_the_store():
+    """the receive side remembers only messages that AddMessage STORED (the entry is the stored message),
+    rejected ones leave a fingerprint in a bounded FIFO, pruning the store prunes the memory WITHOUT the quorum index being
+    enabled, and the tables have caps.  Through ibft_host_ingest_flat (rows back to back + offsets) ≡ ibft_host_ingest_wire."""
+    import numpy as np
+    w, proposal, prepares, commits = _commit_world(n=12, bad=())
+    w.bad_wires.add(commits[5].encode())
+    w.bad_wires.add(commits[9].encode())
+    wires = [m.encode() for m in commits]
+    flat = np.frombuffer(b"".join(wires), dtype=np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in wires])]).astype(np.uint32)
+    a, b = w.host(), w.host()
+    for h in (a, b):
+        h.set_state(1, 0, proposal.encode())
+        h.use_loop_batch(0)
+        h.use_batch(True)                                 # NOTE: no enable_quorum_index()
+    ra, rows_a, hits_a, calls_a = a.ingest_wire(wires)
+    rb, (rows_b, hits_b, calls_b) = b.ingest_flat(flat, off, want_stats=True)
+    assert list(rb) == [x & 0xFF for x in ra] and (rows_a, hits_a, calls_a) == (rows_b, hits_b, calls_b) == (12, 0, 1)
+    assert ra[5] == 0 and ra[9] == 0 and b.seen_entries() == 10          # the two rejected ones are not remembered as messages
+    before = b.loop_batch_calls()
+    rb2, (rows, hits, calls) = b.ingest_flat(flat, off, want_stats=True)  # re-delivery: stored ones AND rejected ones answered
+    assert (rows, hits, calls) == (0, 12, 0) and b.loop_batch_calls() == before
+    assert [x != 0 for x in rb2] == [x != 0 for x in rb]
+    # the rejected-FIFO is bounded: with room for one fingerprint, the older rejected message is judged again
+    c = w.host()
+    c.set_state(1, 0, proposal.encode()); c.use_loop_batch(0); c.use_batch(True)
+    c.set_seen_caps(1 << 18, 1)
+    c.ingest_wire(wires)
+    _, rows, hits, _ = c.ingest_wire([wires[5], wires[9]])
+    assert (rows, hits) == (1, 1)
+    # the stored-message table is capped: at the cap it is dropped, re-deliveries are judged again (never wrongly answered)
+    d = w.host()
+    d.set_state(1, 0, proposal.encode()); d.use_loop_batch(0); d.use_batch(True)
+    d.set_seen_caps(4, 16)
+    rd, _, _, _ = d.ingest_wire(wires)
+    assert [x != 0 for x in rd] == [x != 0 for x in ra] and d.seen_entries() <= 4
+    rd2, rows, hits, _ = d.ingest_wire(wires)
+    assert [x != 0 for x in rd2] == [x != 0 for x in ra] and rows + hits == 12 and rows >= 6
+    # pruning the store drops what was remembered about older heights — the height hook is always installed
+    b.store_prune(2)
+    assert b.seen_entries() == 0
+    for h in (a, b, c, d):
+        h.close()

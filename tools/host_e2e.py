@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""tools/host_e2e.py — what a caller of include/ibft_host.h experiences (run on the GPU box).
+
+(1) BASELINE config #3 end to end: the 4 095 PREPARE and 4 096 COMMIT messages of one height, AS WIRE BYTES, in
+    micro-batches of 256 → ibft_host_ingest_wire (IBFT.AddMessage ×8 191, core/ibft.go:1101-1123) → handlePrepare →
+    handleCommit → the seals for InsertProposal.  A fresh mirror per repetition (nothing cached), the device context
+    shared; cold = no key known, warm = key cache.  Phases timed separately; `device` = the same messages straight to
+    libibftgpu.so (two ibft_verify_messages_wire calls) for the share of the host mirror in the total.
+(2) the round change at N = 256: Q ROUND_CHANGE messages with their prepared certificates (29 412 signatures) →
+    ibft_host_ingest_wire → handleRoundChangeMessage.
+Prints one JSON object; bench.py embeds the same measurement as quorum_latency.host_mirror_from_wire."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def config3_messages(fx):
+    """the fixture's PREPARE / COMMIT sets as complete IbftMessage wire bytes (input preparation: encoding only, the
+    signatures are the fixture's)"""
+    from oracle import wire as W
+    n = len(fx["addrs"])
+    h, rnd = int(fx["height"]), int(fx["round"])
+    raw = fx["raw"].tobytes()
+    H = fx["proposal_hash"].tobytes()
+    view = W.View(h, rnd)
+    pp = W.IbftMessage(view=view, sender=fx["addrs"][0].tobytes(), signature=bytes(65), type=W.PREPREPARE,
+                       payload=W.preprepare_body(W.Proposal(raw, rnd), H, None)).encode()
+    prepares, commits = [], []
+    for i in range(n):
+        a = fx["addrs"][i].tobytes()
+        if i:
+            prepares.append(W.IbftMessage(view=view, sender=a, signature=fx["prepare_sig65"][i - 1].tobytes(), type=W.PREPARE,
+                                          payload=W.prepare_body(fx["hash32"][i].tobytes())).encode())
+        commits.append(W.IbftMessage(view=view, sender=a, signature=fx["msg_sig65"][i].tobytes(), type=W.COMMIT,
+                                     payload=W.commit_body(fx["hash32"][i].tobytes(), fx["seal65"][i].tobytes())).encode())
+    return pp, prepares, commits
+
+
+def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256):
+    n = len(fx["addrs"])
+    h, rnd = int(fx["height"]), int(fx["round"])
+    pp, prepares, commits = config3_messages(fx)
+    powers = {fx["addrs"][i].tobytes(): int(fx["power"][i]) for i in range(n)}
+    want_seals = sorted((fx["addrs"][i].tobytes(), fx["seal65"][i].tobytes()) for i in range(n))
+    bv = V.BatchVerifier(flags=flags, max_rows=max(n, 1024))
+    phases = {k: [] for k in ("ingest_prepares", "handle_prepare", "ingest_commits", "handle_commit", "total")}
+    batches_p = [H.pack(prepares[i:i + micro]) for i in range(0, len(prepares), micro)]
+    batches_c = [H.pack(commits[i:i + micro]) for i in range(0, len(commits), micro)]
+    counts_p = [len(prepares[i:i + micro]) for i in range(0, len(prepares), micro)]
+    counts_c = [len(commits[i:i + micro]) for i in range(0, len(commits), micro)]
+    try:
+        bv.set_validators(h, fx["addrs"], fx["power"])
+        for rep in range(reps + 3):
+            host = H.Host()
+            assert host.vm_init(powers)
+            host.set_state(h, rnd, pp)
+            host.attach_gpu(bv)
+            host.use_batch(True)
+            host.enable_quorum_index()
+            bv.forget_proposal()
+            t0 = time.perf_counter()
+            sig = 0
+            for p, k in zip(batches_p, counts_p):
+                sig += host.ingest_packed(p, k).count(b"\x02")
+            t1 = time.perf_counter()
+            okp = host.handle_prepare_quiet(h, rnd)
+            t2 = time.perf_counter()
+            for p, k in zip(batches_c, counts_c):
+                sig += host.ingest_packed(p, k).count(b"\x02")
+            t3 = time.perf_counter()
+            okc, seals_raw = host.handle_commit_raw(h, rnd)
+            t4 = time.perf_counter()
+            assert okp and okc and sig > 0 and host.fallbacks() == 0
+            if rep == 0:
+                assert sorted(H.unpack_seals(seals_raw)) == want_seals
+            host.close()
+            if rep >= 3:
+                for k, v in zip(phases, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
+                    phases[k].append(v * 1e3)
+        # the device share: the same bytes straight to the library, one call per message set
+        wp = np.frombuffer(b"".join(prepares), dtype=np.uint8)
+        op = np.concatenate([[0], np.cumsum([len(m) for m in prepares])]).astype(np.uint32)
+        wc = np.frombuffer(b"".join(commits), dtype=np.uint8)
+        oc = np.concatenate([[0], np.cumsum([len(m) for m in commits])]).astype(np.uint32)
+        raw = fx["raw"].tobytes()
+        dev = []
+        for rep in range(reps + 3):
+            bv.forget_proposal()
+            t0 = time.perf_counter()
+            bv.verify_messages_wire(wp, op, h, rnd, raw=raw, want_rows=False)
+            s, v, _, t = bv.verify_messages_wire(wc, oc, h, rnd, raw=raw, want_rows=False)
+            dev.append((time.perf_counter() - t0) * 1e3)
+        assert s.all() and v.all() and t.has_quorum == 1
+    finally:
+        bv.close()
+    out = {k: float(np.median(v)) for k, v in phases.items()}
+    out["p10_p90_total_ms"] = [float(x) for x in np.percentile(phases["total"], [10, 90])]
+    out["device_two_set_calls_ms"] = float(np.median(dev[3:]))
+    out["host_share"] = 1.0 - out["device_two_set_calls_ms"] / out["total"]
+    out.update({"messages": len(prepares) + len(commits), "micro_batch": micro, "reps": reps,
+                "signatures": 3 * n - 1, "sig_verifies_per_s": (3 * n - 1) / (out["total"] * 1e-3)})
+    return out
+
+
+def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
+    import cert_cases as CC
+    from oracle import wire, workload as W
+    r = W.make_round(n, 900 + n, height=5, round_=1, raw_len=1024)
+    q = (2 * n) // 3 + 1
+    pm = CC.preprepare(r, 1, 5, 1)
+    prepares = [CC.prepare(r, j, 5, 1) for j in range(n) if j != 1][: q - 1]
+    pcb = wire.prepared_certificate(pm, prepares)
+    rcs = [CC.round_change(r, i, 5, 2, wire.Proposal(r.raw, 1), pcb).encode() for i in range(q)]
+    powers = {r.addrs[i].tobytes(): int(r.power[i]) for i in range(n)}
+    packed = H.pack(rcs)
+    res = {"validators": n, "round_change_messages": q, "signatures": q * (q + 1)}
+    for name, flags in (("cold", 0), ("warm", V.FLAG_PUBKEY_CACHE)):
+        bv = V.BatchVerifier(flags=flags, max_rows=65536)
+        ing, hrc = [], []
+        try:
+            bv.set_validators(5, r.addrs, r.power)
+            for rep in range(reps + 2):
+                host = H.Host()
+                assert host.vm_init(powers)
+                host.set_id(r.addrs[0].tobytes())
+                # the one Backend callback the certificate walk needs besides the device's verdicts (171 calls per walk)
+                host.set_verifier(is_proposer=lambda who, hh, rr: who == r.addrs[rr % n].tobytes())
+                host.set_state(5, 2, None)
+                host.attach_gpu(bv)
+                host.use_batch(True)
+                host.enable_quorum_index()
+                t0 = time.perf_counter()
+                rc = host.ingest_packed(packed, len(rcs))
+                t1 = time.perf_counter()
+                rcc = host.handle_round_change_count(5, 2)
+                t2 = time.perf_counter()
+                assert set(rc) <= {1, 2} and rcc == 1 and host.fallbacks() == 0, (rc[:4], rcc)
+                host.close()
+                if rep >= 2:
+                    ing.append((t1 - t0) * 1e3)
+                    hrc.append((t2 - t1) * 1e3)
+        finally:
+            bv.close()
+        res[name] = {"ingest_ms": float(np.median(ing)), "handle_round_change_ms": float(np.median(hrc)),
+                     "total_ms": float(np.median(np.array(ing) + np.array(hrc)))}
+    return res
+
+
+if __name__ == "__main__":
+    import go_ibft_amd.hostlib as H
+    import go_ibft_amd.verifier as V
+    with np.load(os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")) as z:
+        fx = {k: z[k] for k in z.files}
+    out = {"config3_cold": host_mirror_from_wire(V, H, fx, 0, 30),
+           "config3_warm": host_mirror_from_wire(V, H, fx, V.FLAG_PUBKEY_CACHE, 30)}
+    if "--no-rc" not in sys.argv:
+        out["round_change_n256"] = round_change_through_the_mirror(V, H)
+    print(json.dumps(out, indent=1))
