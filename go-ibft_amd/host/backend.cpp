@@ -421,7 +421,7 @@ void HotPath::PruneVerdictCache(uint64_t below_height) {
 // The verdicts of one root row of a certificate call and of everything below it are noted IN the decoded objects, matched
 // by position: a decoded message lists its nested messages in the order the device lists them.  A subtree whose row count
 // differs from the decoded count (the device refused the wrapper as non-canonical) is left to the stock route.
-void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root) {
+void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root, bool note) {
   std::vector<std::pair<size_t, const IbftMessage *>> todo{{row, root.get()}};
   std::vector<MsgPtr> kids;
   while (!todo.empty()) {
@@ -432,7 +432,7 @@ void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgP
     // a PREPREPARE's own (proposal, proposalHash): validateProposalCommon's IsValidProposalHash
     if (!(cls & (IBFT_CERT_CLASS_NEEDS_HOST | IBFT_CERT_CLASS_PROPOSAL_BY_HOST))) {
       const Proposal *own = extract_proposal(*m);
-      if (own && extract_proposal_hash(*m)) {
+      if (note && own && extract_proposal_hash(*m)) {
         m->verdicts.self = cv.self[r] != 0;
         m->verdicts.self_of = own;
       }
@@ -446,10 +446,10 @@ void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgP
       const size_t c = nd.first_child + k;
       if (!kids[k]) continue;
       if (cv.cls[c] == 0) {
-        noteSender(*kids[k], cv.sender[c] != 0);
-        cert_rows++;
+        if (note) noteSender(*kids[k], cv.sender[c] != 0);
+        cert_rows++;  // rows the device judged (counted whether or not the carrier turns out to be storable)
       }
-      if (hashes_decided && !(cv.cls[c] & IBFT_CERT_CLASS_NEEDS_HOST)) {
+      if (note && hashes_decided && !(cv.cls[c] & IBFT_CERT_CLASS_NEEDS_HOST)) {
         // about the very hash proposalMatchesCertificate will ask about (nil when type and payload disagree: not noted)
         const bytes *h = cv.nodes[c].role == IBFT_CERT_ROLE_PC_PROPOSAL ? extract_proposal_hash(*kids[k]) : extract_prepare_hash(*kids[k]);
         if (h) {
@@ -556,12 +556,21 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
   return ok;
 }
 
-bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats) {
+bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats,
+                         uint8_t *types) {
   for (size_t i = 0; i < n; i++) results[i] = -1;
+  if (types) memset(types, 0xFF, n);
   IngestStats st;
   if (n == 0) {
     if (stats) *stats = st;
     return true;
+  }
+  std::vector<uint32_t> rebased;  // rows of a larger buffer: offsets from the first row's first byte
+  if (off[0] != 0) {
+    rebased.resize(n + 1);
+    for (size_t i = 0; i <= n; i++) rebased[i] = off[i] - off[0];
+    wire_in += off[0];
+    off = rebased.data();
   }
   const Proposal *proposal = getProposal();
   syncClosureKey(proposal);
@@ -658,8 +667,8 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
             verdict[carriers[j]] = cv.sender[j] ? 1 : 0;
             cert_rows++;
           }
-          // what the device said about the nested messages is only worth noting for a carrier that will be stored
-          if (verdict[carriers[j]] != 0) noteCertificateTree(cv, j, msgs[carriers[j]]);
+          // what the device said about the nested messages is only worth noting for a carrier that can be stored
+          noteCertificateTree(cv, j, msgs[carriers[j]], verdict[carriers[j]] != 0);
         }
         std::vector<size_t> left;
         for (size_t i : ask)
@@ -757,6 +766,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       verdict[i] = verdict[(size_t)dup_of[i]];
     }
     if (!msgs[i]) continue;
+    if (types) types[i] = (uint8_t)(msgs[i]->type <= 3 ? msgs[i]->type : 0xFE);
     if (verdict[i] == 1) noteSender(*msgs[i], true);
     const bool fresh = was_asked[i] != 0;
     results[i] = (int8_t)addWithVerdict(msgs[i], verdict[i] == 1);

@@ -216,7 +216,10 @@ class HotPath {
   // transport that receives into one buffer (or the cgo shim's SoA batcher) holds.  The bytes are copied ONCE (the buffer
   // every decoded message of the batch points into) and, when no row is answered from the cache, handed to the device
   // as they are.  results[i]: −1 undecodable, else AddMessage's 0 / 1 / 2.
-  bool IngestFlat(const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats = nullptr);
+  // types (optional, n bytes): IbftMessage.type of every row that decoded (0xFF otherwise) — what a caller needs to turn a
+  // result of 2 into the SignalEvent(type, view) of core/ibft.go:1119.
+  bool IngestFlat(const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats = nullptr,
+                  uint8_t *types = nullptr);
   // IBFT.AddMessage with IsValidValidator already answered (AddMessageFast when the quorum index is enabled)
   int addWithVerdict(MsgPtr m, bool sender_ok);
   void PruneVerdictCache(uint64_t below_height);
@@ -286,7 +289,7 @@ class HotPath {
   std::vector<uint64_t> rejected_fifo_;
   size_t rejected_head_ = 0;
   uint64_t fp_seed_;
-  void noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root);
+  void noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root, bool note);
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);
 

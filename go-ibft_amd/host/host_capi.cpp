@@ -3,7 +3,10 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include "backend.hpp"
 
@@ -36,6 +39,7 @@ struct CallbackVerifier : Verifier {
     return cb.is_valid_validator(cb.user, (const uint8_t *)w.data(), w.size()) != 0;
   }
   bool IsProposer(const bytes &id, uint64_t height, uint64_t round) override {
+    if (!rr_addrs.empty()) return id == rr_addrs[(size_t)(((unsigned __int128)height * rr_height_weight + round) % rr_addrs.size())];
     if (!cb.is_proposer) return false;
     return cb.is_proposer(cb.user, (const uint8_t *)id.data(), id.size(), height, round) != 0;
   }
@@ -45,6 +49,8 @@ struct CallbackVerifier : Verifier {
   }
   bytes ID() override { return id; }
   bytes id;
+  std::vector<bytes> rr_addrs;  // a native round-robin proposer rule (ibft_host_set_round_robin_proposer)
+  uint64_t rr_height_weight = 1;
 };
 
 void pack_bytes(bytes &o, const bytes &item) {
@@ -102,6 +108,71 @@ void seals_to_buf(const std::vector<std::optional<CommittedSeal>> &seals, ibft_h
 
 }  // namespace
 
+struct ibft_host;
+namespace {
+// The receive-side queue ("queue → micro-batches → device"): transport threads push what arrives and
+// return at once; ONE worker per mirror takes EVERYTHING that is pending and ingests it as one batch.  The batch size
+// adapts by itself — while a device call is in flight (0.3 ms for any batch up to a few thousand rows: the device is
+// latency-bound there) arrivals pile up and form the next, larger batch — so under load a height's 8 191 messages reach
+// the device in a handful of calls instead of 32 micro-batches, and an idle mirror still answers a lone message at once.
+class IngestQueue {
+ public:
+  IngestQueue(ibft_host *h, size_t max_rows, uint32_t linger_us)
+      : h_(h), max_rows_(max_rows ? max_rows : 65536), linger_us_(linger_us), th_([this] { loop(); }) {}
+  ~IngestQueue() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  void push(const uint8_t *wire, const uint32_t *off, size_t n) {
+    if (!n) return;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      const uint32_t base = (uint32_t)wire_.size();
+      wire_.insert(wire_.end(), wire + off[0], wire + off[n]);
+      for (size_t i = 1; i <= n; i++) off_.push_back(base + (off[i] - off[0]));
+      pushed_ += n;
+      last_push_ = std::chrono::steady_clock::now();
+    }
+    cv_.notify_all();
+  }
+  void drain(ibft_host_queue_stats *out) {
+    std::unique_lock<std::mutex> lk(mu_);
+    const uint64_t target = pushed_;
+    done_cv_.wait(lk, [&] { return stats_.ingested >= target || stop_; });
+    if (out) {
+      *out = stats_;
+      out->pushed = pushed_;
+    }
+  }
+  void set_signal(ibft_host_signal_fn fn, void *user) {
+    std::lock_guard<std::mutex> lk(mu_);
+    on_signal_ = fn;
+    user_ = user;
+  }
+
+ private:
+  void loop();
+  ibft_host *h_;
+  size_t max_rows_;
+  uint32_t linger_us_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<uint8_t> wire_;
+  std::vector<uint32_t> off_{0};
+  uint64_t pushed_ = 0;
+  std::chrono::steady_clock::time_point last_push_;
+  ibft_host_queue_stats stats_{};
+  ibft_host_signal_fn on_signal_ = nullptr;
+  void *user_ = nullptr;
+  bool stop_ = false;
+  std::thread th_;
+};
+}  // namespace
+
 struct ibft_host {
   // One mirror = one IBFT instance.  The reference calls AddMessage from transport goroutines while the round goroutine
   // walks the store (core/ibft.go:335-347); every entry point below takes this mutex, so any thread may call any of them
@@ -112,7 +183,84 @@ struct ibft_host {
   std::unique_ptr<GpuBackend> gpu;
   std::unique_ptr<LoopBatch> loop;
   size_t last_set_rows = 0;
+  std::unique_ptr<IngestQueue> queue;  // declared last: its worker is joined before anything above is destroyed
 };
+
+namespace {
+void IngestQueue::loop() {
+  std::vector<uint8_t> wire;
+  std::vector<uint32_t> off;
+  std::vector<int8_t> res;
+  std::vector<uint8_t> types;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return stop_ || off_.size() > 1; });
+      if (stop_) return;
+      if (linger_us_ && off_.size() - 1 < max_rows_) {
+        // a short wait for a burst to finish arriving, as long as messages keep coming
+        const auto dl = std::chrono::microseconds(linger_us_);
+        while (!stop_ && off_.size() - 1 < max_rows_ && std::chrono::steady_clock::now() - last_push_ < dl)
+          cv_.wait_for(lk, dl / 4 + std::chrono::microseconds(1));
+        if (stop_) return;
+      }
+      wire.swap(wire_);
+      off.swap(off_);
+      wire_.clear();
+      off_.assign(1, 0);
+    }
+    const size_t n = off.size() - 1;
+    res.assign(n, -1);
+    types.assign(n, 0xFF);
+    ibft_host_queue_stats d{};
+    uint64_t sig_height = 0, sig_round = 0;
+    for (size_t lo = 0; lo < n; lo += max_rows_) {
+      const size_t k = std::min(max_rows_, n - lo);
+      std::lock_guard<std::recursive_mutex> hk(h_->mu);
+      // rows [lo, lo + k): offsets rebased by IngestFlat's contract (off[0] may be non-zero: it reads wire[off[i] .. off[i+1]))
+      HotPath::IngestStats st;
+      h_->hp.IngestFlat(wire.data(), off.data() + lo, k, res.data() + lo, &st, types.data() + lo);
+      d.batches++;
+      d.device_calls += st.device_calls;
+      d.cache_hits += st.cache_hits;
+      if (k > d.max_batch_rows) d.max_batch_rows = k;
+      sig_height = h_->hp.height;
+      sig_round = h_->hp.round;
+    }
+    for (size_t i = 0; i < n; i++) {
+      if (res[i] < 0)
+        d.undecodable++;
+      else if (res[i] == 0)
+        d.rejected++;
+      else
+        d.stored++;
+      if (res[i] == 2 && types[i] < 4) d.signals[types[i]]++;
+    }
+    ibft_host_signal_fn fn;
+    void *user;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stats_.ingested += n;
+      stats_.stored += d.stored;
+      stats_.rejected += d.rejected;
+      stats_.undecodable += d.undecodable;
+      stats_.batches += d.batches;
+      stats_.device_calls += d.device_calls;
+      stats_.cache_hits += d.cache_hits;
+      if (d.max_batch_rows > stats_.max_batch_rows) stats_.max_batch_rows = d.max_batch_rows;
+      for (int t = 0; t < 4; t++) stats_.signals[t] += d.signals[t];
+      fn = on_signal_;
+      user = user_;
+    }
+    // SignalEvent (core/ibft.go:1119), coalesced per type like the 1-deep subscription channels (event_subscription.go:80-83);
+    // called WITHOUT the mirror's lock: the callee may call ibft_host_handle_* right away
+    if (fn)
+      for (uint32_t t = 0; t < 4; t++)
+        if (d.signals[t]) fn(user, t, sig_height, sig_round);
+    done_cv_.notify_all();
+  }
+}
+}  // namespace
 
 extern "C" {
 
@@ -121,7 +269,10 @@ ibft_host *ibft_host_new(void) {
   h->hp.verifier = &h->cbv;
   return h;
 }
-void ibft_host_free(ibft_host *h) { delete h; }
+void ibft_host_free(ibft_host *h) {
+  ibft_host_queue_stop(h);
+  delete h;
+}
 void ibft_host_buf_free(ibft_host_buf *b) {
   if (b && b->data) free(b->data);
   if (b) *b = ibft_host_buf{nullptr, 0, 0};
@@ -421,6 +572,35 @@ int ibft_host_ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off
     if (off[i + 1] < off[i]) return -1;
   return ingest_flat(h, wire, off, n, results, device_rows, cache_hits, device_calls);
 }
+int ibft_host_queue_start(ibft_host *h, size_t max_rows, uint32_t linger_us) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  if (h->queue) return -1;
+  h->queue.reset(new IngestQueue(h, max_rows, linger_us));
+  return 0;
+}
+void ibft_host_queue_on_signal(ibft_host *h, ibft_host_signal_fn fn, void *user) {
+  if (h->queue) h->queue->set_signal(fn, user);
+}
+int ibft_host_queue_push(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n) {
+  if (!h->queue || (n && (!wire || !off))) return -1;  // (no mirror lock: pushing never waits for an ingest in progress)
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return -1;
+  h->queue->push(wire, off, n);
+  return 0;
+}
+int ibft_host_queue_drain(ibft_host *h, ibft_host_queue_stats *out) {
+  if (!h->queue) return -1;
+  h->queue->drain(out);
+  return 0;
+}
+void ibft_host_queue_stop(ibft_host *h) {
+  std::unique_ptr<IngestQueue> q;
+  {
+    std::lock_guard<std::recursive_mutex> lk_(h->mu);
+    q = std::move(h->queue);
+  }
+  q.reset();  // joins the worker (which may be waiting for the mirror's lock) outside the lock
+}
 size_t ibft_host_seen_entries(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.seen_entries(); }
 void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_cap) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
@@ -466,6 +646,14 @@ int ibft_host_handle_round_change(ibft_host *h, uint64_t height, uint64_t round,
   return out.empty() ? 0 : 1;
 }
 
+int ibft_host_set_round_robin_proposer(ibft_host *h, const uint8_t *packed_addrs, size_t len, int use_height) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  std::vector<bytes> a;
+  if (!unpack_list(packed_addrs, len, a)) return -1;
+  h->cbv.rr_addrs = std::move(a);
+  h->cbv.rr_height_weight = use_height ? 1 : 0;
+  return 0;
+}
 void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->cbv.id.assign((const char *)id, len); }
 int ibft_host_valid_pc(ibft_host *h, const uint8_t *pc_wire, size_t len, uint64_t round_limit, uint64_t height) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);

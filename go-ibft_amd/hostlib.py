@@ -48,6 +48,14 @@ PROPOSER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t,
 VALID_PROPOSAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
 
 
+class QueueStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("pushed", "ingested", "stored", "rejected", "undecodable", "batches",
+                                           "device_calls", "cache_hits", "max_batch_rows")] + [("signals", C.c_uint64 * 4)]
+
+
+SIGNAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64)
+
+
 class VerifierCB(C.Structure):
     _fields_ = [("is_valid_proposal_hash", PROP_HASH_FN), ("is_valid_committed_seal", SEAL_FN),
                 ("is_valid_validator", VALIDATOR_FN), ("user", C.c_void_p),
@@ -91,6 +99,7 @@ def lib() -> C.CDLL:
         L.ibft_host_add_message_fast.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.ibft_host_add_messages_batch.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.ibft_host_set_id.argtypes = [vp, C.c_char_p, C.c_size_t]
+        L.ibft_host_set_round_robin_proposer.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int]
         L.ibft_host_valid_pc.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]
         L.ibft_host_proposal_matches_certificate.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.ibft_host_validate_proposal0.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]
@@ -103,6 +112,11 @@ def lib() -> C.CDLL:
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.ibft_host_ingest_flat.argtypes = [vp, vp, vp, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t),
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ibft_host_queue_start.argtypes = [vp, C.c_size_t, C.c_uint32]
+        L.ibft_host_queue_push.argtypes = [vp, vp, vp, C.c_size_t]
+        L.ibft_host_queue_drain.argtypes = [vp, C.POINTER(QueueStats)]
+        L.ibft_host_queue_stop.argtypes = [vp]; L.ibft_host_queue_stop.restype = None
+        L.ibft_host_queue_on_signal.argtypes = [vp, SIGNAL_FN, vp]; L.ibft_host_queue_on_signal.restype = None
         L.ibft_host_seen_entries.argtypes = [vp]; L.ibft_host_seen_entries.restype = C.c_size_t
         L.ibft_host_set_seen_caps.argtypes = [vp, C.c_size_t, C.c_size_t]; L.ibft_host_set_seen_caps.restype = None
         L.ibft_host_use_loop_batch.argtypes = [vp, C.c_int]
@@ -338,6 +352,11 @@ class Host:
     def set_id(self, node_id: bytes):
         self.L.ibft_host_set_id(self.h, node_id, len(node_id))
 
+    def set_round_robin_proposer(self, addrs, use_height: bool = True):
+        """native IsProposer: addrs[(height·use_height + round) mod n] (core/helpers_test.go:214-225)"""
+        p = pack(list(addrs))
+        assert self.L.ibft_host_set_round_robin_proposer(self.h, p, len(p), 1 if use_height else 0) == 0
+
     def valid_pc(self, pc_wire, round_limit: int, height: int) -> bool:
         return self.L.ibft_host_valid_pc(self.h, pc_wire, len(pc_wire or b""), round_limit, height) == 1
 
@@ -402,6 +421,30 @@ class Host:
         if rc != 0:
             raise RuntimeError(f"ibft_host_ingest_flat rc={rc}")
         return (res.raw[:n], (a.value, b.value, c.value)) if want_stats else res.raw[:n]
+
+    # --- the receive-side queue (adaptive batching)
+    def queue_start(self, max_rows: int = 65536, linger_us: int = 0):
+        assert self.L.ibft_host_queue_start(self.h, max_rows, linger_us) == 0
+
+    def queue_push(self, wire, off):
+        """rows back to back (numpy uint8) + n + 1 offsets (numpy uint32): copied, returns at once"""
+        if self.L.ibft_host_queue_push(self.h, wire.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(off) - 1) != 0:
+            raise RuntimeError("ibft_host_queue_push")
+
+    def queue_drain(self) -> QueueStats:
+        st = QueueStats()
+        if self.L.ibft_host_queue_drain(self.h, C.byref(st)) != 0:
+            raise RuntimeError("ibft_host_queue_drain")
+        return st
+
+    def queue_on_signal(self, fn):
+        """fn(type, height, round) from the queue's worker thread — the SignalEvent of core/ibft.go:1119"""
+        cb = SIGNAL_FN(lambda u, t, hh, rr: fn(t, hh, rr))
+        self._keep.append(cb)
+        self.L.ibft_host_queue_on_signal(self.h, cb, None)
+
+    def queue_stop(self):
+        self.L.ibft_host_queue_stop(self.h)
 
     def seen_entries(self) -> int:
         return self.L.ibft_host_seen_entries(self.h)

@@ -122,6 +122,26 @@ int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_
  * (every decoded message of the batch points into that copy) and hands them to the device as they are.               */
 int ibft_host_ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results,
                           size_t *device_rows, size_t *cache_hits, size_t *device_calls);
+/* The receive-side queue: transport threads PUSH what arrives (rows back to back + offsets, copied,
+ * never blocks on an ingest in progress); one worker per mirror takes everything pending and ingests it as ONE batch
+ * (ibft_host_ingest_flat on at most max_rows rows at a time).  The batch size adapts to the load by itself: arrivals pile up
+ * while a device call is in flight and form the next batch.  linger_us > 0: the worker waits that long after the last push
+ * for a burst to finish arriving (0 = never wait).  on_signal (optional) is the SignalEvent(type, view) of
+ * core/ibft.go:1118-1119, once per ingested batch and message type that reached its quorum probe, called from the worker
+ * WITHOUT the mirror's lock (the callee may call ibft_host_handle_* at once).  drain waits until everything pushed before
+ * the call has been ingested and reports the counters since queue_start.  The mirror's other entry points stay usable from
+ * any thread meanwhile (they are serialised with the worker).                                                       */
+typedef struct {
+  uint64_t pushed, ingested, stored, rejected, undecodable;
+  uint64_t batches, device_calls, cache_hits, max_batch_rows;
+  uint64_t signals[4]; /* results of 2 by IbftMessage.type */
+} ibft_host_queue_stats;
+typedef void (*ibft_host_signal_fn)(void *user, uint32_t type, uint64_t height, uint64_t round);
+int ibft_host_queue_start(ibft_host *h, size_t max_rows, uint32_t linger_us);
+void ibft_host_queue_on_signal(ibft_host *h, ibft_host_signal_fn fn, void *user);
+int ibft_host_queue_push(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n);
+int ibft_host_queue_drain(ibft_host *h, ibft_host_queue_stats *out);
+void ibft_host_queue_stop(ibft_host *h);
 /* Receive-side memory (bounded): messages remembered for byte-identical re-deliveries — only messages that AddMessage
  * STORED are remembered (the entry is the stored message itself, verdicts included; it goes when the store prunes its
  * height), rejected ones leave a 16-byte keyed fingerprint in a FIFO of rejected_cap entries.  When stored_cap entries are
@@ -172,6 +192,11 @@ size_t ibft_host_fallbacks(ibft_host *h);
  * ibft_host_use_batch(1) and a GPU attached, all sender signatures / hashes of the certificate go
  * to the device in one batch; ibft_host_last_cert_batch reports how many.  Return 1/0, -1 = undecodable. */
 void ibft_host_set_id(ibft_host *h, const uint8_t *id, size_t len);
+/* A native Backend.IsProposer (core/backend.go:46-48) for measurements and simulators: the round-robin rule of the
+ * reference's cluster tests (core/helpers_test.go:214-225), proposer = addrs[(height·use_height + round) mod n] — a
+ * certificate walk asks IsProposer once per nested message (core/ibft.go:1206-1225), 29 000 times for a round change at
+ * N = 256, which a callback into an interpreter would dominate.  An empty list restores the is_proposer callback.  */
+int ibft_host_set_round_robin_proposer(ibft_host *h, const uint8_t *packed_addrs, size_t len, int use_height);
 int ibft_host_valid_pc(ibft_host *h, const uint8_t *pc_wire, size_t len, uint64_t round_limit, uint64_t height);
 int ibft_host_proposal_matches_certificate(ibft_host *h, const uint8_t *proposal_wire, size_t plen,
                                            const uint8_t *pc_wire, size_t clen);

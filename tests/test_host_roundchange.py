@@ -326,3 +326,59 @@ def test_flat_ingest_receive_side_memory_is_bounded_and_follows_the_store():
     assert b.seen_entries() == 0
     for h in (a, b, c, d):
         h.close()
+
+
+def test_ingest_queue_adaptive_batches_equal_direct_ingest():
+    """SURVEY §8f rank 1 "queue → micro-batches": transport threads push, one worker ingests whatever is pending as one
+    batch.  Same store, same signals as ibft_host_ingest_wire on the same messages; pushes from several threads; the
+    SignalEvent callback fires from the worker and may call handle_* at once."""
+    import threading
+    import numpy as np
+    w, proposal, prepares, commits = _commit_world(n=40, bad=(3, 11))
+    w.bad_wires.add(commits[7].encode())
+    wires = [m.encode() for m in prepares + commits] + [b"\xff\xff\xff"]
+    ref, q = w.host(), w.host()
+    for h in (ref, q):
+        h.set_state(1, 0, proposal.encode())
+        h.use_loop_batch(0)
+        h.use_batch(True)
+        h.enable_quorum_index()
+    expect, *_ = ref.ingest_wire(wires)
+    q.queue_start(max_rows=16, linger_us=200)
+    signalled = []
+    done = threading.Event()
+
+    def on_signal(t, hh, rr):
+        signalled.append((t, hh, rr))
+        if t == CM and q.store_num(hh, rr, CM) > 0:         # a mirror call from the worker thread: its lock is not held
+            done.set()
+    q.queue_on_signal(on_signal)
+
+    def producer(chunk):
+        for k in range(0, len(chunk), 5):
+            part = chunk[k:k + 5]
+            flat = np.frombuffer(b"".join(part), dtype=np.uint8)
+            off = np.concatenate([[0], np.cumsum([len(x) for x in part])]).astype(np.uint32)
+            q.queue_push(flat, off)
+    threads = [threading.Thread(target=producer, args=(wires[i::3],)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    st = q.queue_drain()
+    assert st.pushed == st.ingested == len(wires) and st.undecodable == 1
+    assert st.stored == sum(1 for x in expect if x > 0) and st.rejected == sum(1 for x in expect if x == 0)
+    assert st.max_batch_rows <= 16 and st.batches >= len(wires) // 16
+    assert st.signals[PR] > 0 and st.signals[CM] > 0 and (CM, 1, 0) in signalled
+    for t in (PR, CM):
+        assert q.store_num(1, 0, t) == ref.store_num(1, 0, t)
+    assert done.wait(5)
+    a, b = ref.handle_prepare(1, 0), q.handle_prepare(1, 0)
+    assert (a[0], sorted(a[1])) == (b[0], sorted(b[1]))
+    a, b = ref.handle_commit(1, 0), q.handle_commit(1, 0)
+    assert (a[0], sorted(a[1])) == (b[0], sorted(b[1]))
+    q.queue_stop()
+    q.queue_start()                                          # restartable
+    q.queue_push(np.frombuffer(wires[0], dtype=np.uint8), np.array([0, len(wires[0])], dtype=np.uint32))
+    assert q.queue_drain().ingested == 1
+    ref.close(); q.close()                                   # close() stops the worker

@@ -109,6 +109,62 @@ def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256):
     return out
 
 
+def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_us: int = 0):
+    """the same height through the mirror's receive-side QUEUE: the transport pushes its micro-batches of 256 as fast as it
+    can (ibft_host_queue_push returns at once), the mirror's worker ingests whatever is pending as one batch — the batch
+    size adapts to the load — then drain + handlePrepare, the COMMITs the same way, handleCommit, seals out"""
+    n = len(fx["addrs"])
+    h, rnd = int(fx["height"]), int(fx["round"])
+    pp, prepares, commits = config3_messages(fx)
+    powers = {fx["addrs"][i].tobytes(): int(fx["power"][i]) for i in range(n)}
+    want_seals = sorted((fx["addrs"][i].tobytes(), fx["seal65"][i].tobytes()) for i in range(n))
+
+    def flat(msgs):
+        out = []
+        for i in range(0, len(msgs), micro):
+            part = msgs[i:i + micro]
+            out.append((np.frombuffer(b"".join(part), dtype=np.uint8),
+                        np.concatenate([[0], np.cumsum([len(x) for x in part])]).astype(np.uint32)))
+        return out
+    fp, fc = flat(prepares), flat(commits)
+    bv = V.BatchVerifier(flags=flags, max_rows=max(n, 1024))
+    tot, stats = [], None
+    try:
+        bv.set_validators(h, fx["addrs"], fx["power"])
+        for rep in range(reps + 3):
+            host = H.Host()
+            assert host.vm_init(powers)
+            host.set_state(h, rnd, pp)
+            host.attach_gpu(bv)
+            host.use_batch(True)
+            host.enable_quorum_index()
+            host.queue_start(max_rows=max(n, 1024), linger_us=linger_us)
+            bv.forget_proposal()
+            t0 = time.perf_counter()
+            for w_, o_ in fp:
+                host.queue_push(w_, o_)
+            host.queue_drain()
+            okp = host.handle_prepare_quiet(h, rnd)
+            for w_, o_ in fc:
+                host.queue_push(w_, o_)
+            st = host.queue_drain()
+            okc, seals_raw = host.handle_commit_raw(h, rnd)
+            t1 = time.perf_counter()
+            assert okp and okc and st.stored == len(prepares) + len(commits) and host.fallbacks() == 0
+            if rep == 0:
+                assert sorted(H.unpack_seals(seals_raw)) == want_seals
+            stats = {"batches": int(st.batches), "device_calls": int(st.device_calls), "max_batch_rows": int(st.max_batch_rows)}
+            host.close()
+            if rep >= 3:
+                tot.append((t1 - t0) * 1e3)
+    finally:
+        bv.close()
+    p = np.percentile(tot, [10, 50, 90])
+    return {"total": float(p[1]), "p10_p90_total_ms": [float(p[0]), float(p[2])], "last_rep": stats, "micro_batch_pushed": micro,
+            "linger_us": linger_us, "messages": len(prepares) + len(commits), "signatures": 3 * n - 1,
+            "sig_verifies_per_s": (3 * n - 1) / (p[1] * 1e-3)}
+
+
 def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
     import cert_cases as CC
     from oracle import wire, workload as W
@@ -130,8 +186,9 @@ def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
                 host = H.Host()
                 assert host.vm_init(powers)
                 host.set_id(r.addrs[0].tobytes())
-                # the one Backend callback the certificate walk needs besides the device's verdicts (171 calls per walk)
-                host.set_verifier(is_proposer=lambda who, hh, rr: who == r.addrs[rr % n].tobytes())
+                # the one Backend answer the certificate walk needs besides the device's verdicts: IsProposer, once per
+                # nested message — native (a Python callback per call costs more than the whole walk)
+                host.set_round_robin_proposer([r.addrs[i].tobytes() for i in range(n)], use_height=False)
                 host.set_state(5, 2, None)
                 host.attach_gpu(bv)
                 host.use_batch(True)
@@ -159,7 +216,9 @@ if __name__ == "__main__":
     with np.load(os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")) as z:
         fx = {k: z[k] for k in z.files}
     out = {"config3_cold": host_mirror_from_wire(V, H, fx, 0, 30),
-           "config3_warm": host_mirror_from_wire(V, H, fx, V.FLAG_PUBKEY_CACHE, 30)}
+           "config3_warm": host_mirror_from_wire(V, H, fx, V.FLAG_PUBKEY_CACHE, 30),
+           "config3_queue_cold": host_mirror_queue(V, H, fx, 0, 30),
+           "config3_queue_warm": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30)}
     if "--no-rc" not in sys.argv:
         out["round_change_n256"] = round_change_through_the_mirror(V, H)
     print(json.dumps(out, indent=1))
