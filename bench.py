@@ -603,6 +603,25 @@ def main():
             rec["certificates"] = certificates_leg(V)
         except Exception as e:  # noqa: BLE001
             rec["certificates"] = {"error": repr(e)}
+    if world == 1 and rank == 0 and not args.no_host_mirror and main_leg["rd"]["fx"] is not None:
+        # what a caller of include/ibft_host.h experiences: the same height as 8 191 wire messages through the mirror
+        # (ingest → store → handlePrepare / handleCommit → seals), and the N = 256 round change (tools/host_e2e.py)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import host_e2e as E
+            import go_ibft_amd.hostlib as HL
+            fx = main_leg["rd"]["fx"]
+            hm = {"definition": "BASELINE config #3 end to end through include/ibft_host.h: 4 095 PREPARE + 4 096 COMMIT wire "
+                                "messages -> ibft_host_ingest_wire (micro-batches of 256) or the mirror's receive queue (adaptive "
+                                "batches) -> handlePrepare -> handleCommit -> seals; a fresh mirror per repetition, p50",
+                  "micro_batches_cold": E.host_mirror_from_wire(V, HL, fx, 0, 20),
+                  "micro_batches_warm": E.host_mirror_from_wire(V, HL, fx, V.FLAG_PUBKEY_CACHE, 20),
+                  "queue_cold": E.host_mirror_queue(V, HL, fx, 0, 20),
+                  "queue_warm": E.host_mirror_queue(V, HL, fx, V.FLAG_PUBKEY_CACHE, 20),
+                  "round_change_n256": E.round_change_through_the_mirror(V, HL, 256, 6)}
+            rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = hm
+        except Exception as e:  # noqa: BLE001
+            rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = {"error": repr(e)}
     if world == 8 and os.environ.get("IBFT_BENCH_SKIP_CONFIG5") != "1":
         # BASELINE config #5: 65 536 validators, 8 × 8192 rows, 20 % Byzantine seals, parity vs the CPU oracle
         try:

@@ -659,7 +659,10 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       const uint32_t *o;
       rows_as_wire(carriers, w, o);
       CertVerdicts cv;
-      if (batch->VerifyCertificatesWire(w, o, carriers.size(), cv) && cv.n_rows >= carriers.size()) {
+      const auto td = std::chrono::steady_clock::now();
+      const bool cert_ok = batch->VerifyCertificatesWire(w, o, carriers.size(), cv);
+      st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+      if (cert_ok && cv.n_rows >= carriers.size()) {
         st.device_calls++;
         cert_calls++;
         for (size_t j = 0; j < carriers.size(); j++) {
@@ -687,7 +690,10 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     const uint32_t *o;
     rows_as_wire(ask, w, o);
     std::vector<uint8_t> vs, vc, judged;
-    if (gpu_sets->VerifyMessagesWire(w, o, ask.size(), height, round, *proposal, vs, vc, judged)) {
+    const auto td = std::chrono::steady_clock::now();
+    const bool sets_ok = gpu_sets->VerifyMessagesWire(w, o, ask.size(), height, round, *proposal, vs, vc, judged);
+    st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+    if (sets_ok) {
       st.device_calls++;
       for (size_t j = 0; j < ask.size(); j++) {
         verdict[ask[j]] = vs[j] ? 1 : 0;
@@ -716,8 +722,10 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       std::vector<MsgPtr> sub;
       for (size_t i : of_type[t]) sub.push_back(msgs[i]);
       std::vector<uint8_t> vs, vc;
-      if (batch->VerifyMessageSet(proposal, t ? COMMIT : PREPARE, sub, vs, vc) && vs.size() == sub.size() &&
-          vc.size() == sub.size()) {
+      const auto td = std::chrono::steady_clock::now();
+      const bool set_ok = batch->VerifyMessageSet(proposal, t ? COMMIT : PREPARE, sub, vs, vc);
+      st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+      if (set_ok && vs.size() == sub.size() && vc.size() == sub.size()) {
         st.device_calls++;
         st.set_rows += sub.size();
         for (size_t k = 0; k < sub.size(); k++) {
@@ -738,6 +746,12 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     bool ok = false;
     if (use_batch && batch) {
       st.device_calls++;
+      const auto td = std::chrono::steady_clock::now();
+      struct AddTime {
+        IngestStats &st;
+        std::chrono::steady_clock::time_point t0;
+        ~AddTime() { st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+      } add_time{st, td};
       if (auto *gpu = dynamic_cast<GpuBackend *>(batch)) {  // the device walks the bytes themselves (§8f rank 3)
         const uint8_t *w;
         const uint32_t *o;

@@ -199,6 +199,7 @@ class HotPath {
   // table keyed by the stored message and handlePrepare / handleCommit only send the device what the table cannot answer.
   struct IngestStats {
     size_t device_rows = 0, cache_hits = 0, device_calls = 0, set_rows = 0;
+    double device_ms = 0.0;  // wall time inside the batch backend's calls (the rest of an ingest is the mirror's own work)
   };
   bool use_sets = true;
   size_t closure_hits = 0;  // messages of the last handlePrepare / handleCommit whose closure verdict was already known

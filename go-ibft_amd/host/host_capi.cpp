@@ -219,7 +219,10 @@ void IngestQueue::loop() {
       std::lock_guard<std::recursive_mutex> hk(h_->mu);
       // rows [lo, lo + k): offsets rebased by IngestFlat's contract (off[0] may be non-zero: it reads wire[off[i] .. off[i+1]))
       HotPath::IngestStats st;
+      const auto t0 = std::chrono::steady_clock::now();
       h_->hp.IngestFlat(wire.data(), off.data() + lo, k, res.data() + lo, &st, types.data() + lo);
+      d.ingest_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      d.device_us += (uint64_t)(st.device_ms * 1e3);
       d.batches++;
       d.device_calls += st.device_calls;
       d.cache_hits += st.cache_hits;
@@ -247,6 +250,8 @@ void IngestQueue::loop() {
       stats_.batches += d.batches;
       stats_.device_calls += d.device_calls;
       stats_.cache_hits += d.cache_hits;
+      stats_.ingest_us += d.ingest_us;
+      stats_.device_us += d.device_us;
       if (d.max_batch_rows > stats_.max_batch_rows) stats_.max_batch_rows = d.max_batch_rows;
       for (int t = 0; t < 4; t++) stats_.signals[t] += d.signals[t];
       fn = on_signal_;

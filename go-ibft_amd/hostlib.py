@@ -50,7 +50,8 @@ VALID_PROPOSAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_s
 
 class QueueStats(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("pushed", "ingested", "stored", "rejected", "undecodable", "batches",
-                                           "device_calls", "cache_hits", "max_batch_rows")] + [("signals", C.c_uint64 * 4)]
+                                           "device_calls", "cache_hits", "max_batch_rows")] + [("signals", C.c_uint64 * 4),
+                                                                                              ("ingest_us", C.c_uint64), ("device_us", C.c_uint64)]
 
 
 SIGNAL_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64)

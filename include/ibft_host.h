@@ -135,6 +135,7 @@ typedef struct {
   uint64_t pushed, ingested, stored, rejected, undecodable;
   uint64_t batches, device_calls, cache_hits, max_batch_rows;
   uint64_t signals[4]; /* results of 2 by IbftMessage.type */
+  uint64_t ingest_us, device_us; /* wall time of the worker inside ingests, and the part of it inside device calls */
 } ibft_host_queue_stats;
 typedef void (*ibft_host_signal_fn)(void *user, uint32_t type, uint64_t height, uint64_t round);
 int ibft_host_queue_start(ibft_host *h, size_t max_rows, uint32_t linger_us);

@@ -153,7 +153,8 @@ def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_
             assert okp and okc and st.stored == len(prepares) + len(commits) and host.fallbacks() == 0
             if rep == 0:
                 assert sorted(H.unpack_seals(seals_raw)) == want_seals
-            stats = {"batches": int(st.batches), "device_calls": int(st.device_calls), "max_batch_rows": int(st.max_batch_rows)}
+            stats = {"batches": int(st.batches), "device_calls": int(st.device_calls), "max_batch_rows": int(st.max_batch_rows),
+                     "worker_ingest_ms": st.ingest_us / 1e3, "of_which_device_ms": st.device_us / 1e3}
             host.close()
             if rep >= 3:
                 tot.append((t1 - t0) * 1e3)
