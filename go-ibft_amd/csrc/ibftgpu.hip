@@ -109,6 +109,11 @@ struct ibft_ctx {
   hipStream_t hstream = nullptr;
   hipEvent_t ev_H = nullptr;
   bool H_pending = false;  // the main stream has not yet been told to wait for ev_H
+  // Where the proposal is hashed: on the host by default (IBFT_PROPOSAL_HASH=device selects the wavefront sponge kernel)
+  bool hash_on_host = true;
+  bool H_copy_issued = false;   // ev_H marks a copy out of the pinned staging slot
+  uint8_t H_host[32] = {0};     // the digest d_H holds, when the host computed it
+  bool have_H_host = false;
 
   // staged batch
   uint32_t staged_n = 0;
@@ -515,7 +520,73 @@ bool note_proposal(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t rou
   memcpy(c->hashed_proposal.data() + raw_len, be, 8);
   return true;
 }
+// Keccak-256 of a ‖ b on the HOST, with the device code's own permutation (keccak_dev.h compiles for both sides).
+// Keccak is a sequential sponge: one host core absorbs ≈340 MB/s (3.6 µs for 1 KiB, ≈3 ms for 1 MiB) where the one
+// wavefront that can work on a message absorbs 25 MB/s (profiles/r02_a1_sizes_v2.json: 41 ms for 1 MiB).
+void host_keccak256(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, uint8_t out32[32]) {
+  uint64_t s[25] = {0};
+  uint8_t block[136];
+  size_t fill = 0;
+  auto absorb = [&](const uint8_t *p, size_t n) {
+    while (n) {
+      if (fill == 0 && n >= 136) {  // whole blocks straight from the source
+        for (int i = 0; i < 17; i++) {
+          uint64_t w;
+          memcpy(&w, p + 8 * i, 8);
+          s[i] ^= w;
+        }
+        keccak::f1600(s);
+        p += 136;
+        n -= 136;
+        continue;
+      }
+      const size_t k = std::min(n, (size_t)136 - fill);
+      memcpy(block + fill, p, k);
+      fill += k;
+      p += k;
+      n -= k;
+      if (fill == 136) {
+        for (int i = 0; i < 17; i++) {
+          uint64_t w;
+          memcpy(&w, block + 8 * i, 8);
+          s[i] ^= w;
+        }
+        keccak::f1600(s);
+        fill = 0;
+      }
+    }
+  };
+  if (na) absorb(a, na);
+  if (nb) absorb(b, nb);
+  memset(block + fill, 0, 136 - fill);
+  block[fill] ^= 0x01;
+  block[135] ^= 0x80;
+  for (int i = 0; i < 17; i++) {
+    uint64_t w;
+    memcpy(&w, block + 8 * i, 8);
+    s[i] ^= w;
+  }
+  keccak::f1600(s);
+  memcpy(out32, s, 32);
+}
+
 int launch_proposal_hash(ibft_ctx *c) {
+  if (c->hash_on_host) {
+    // the digest is computed here, on the calling thread — behind the verdict launch of a message set, which is already
+    // running on the device — and reaches d_H through the side stream like the device-computed one did
+    if (c->H_copy_issued) HIPCHK(c, hipEventSynchronize(c->ev_H));  // the staging slot is free again
+    uint8_t *stage = reinterpret_cast<uint8_t *>(c->h_digest) + 32;
+    host_keccak256(c->hashed_proposal.data(), c->hashed_proposal.size(), nullptr, 0, stage);
+    memcpy(c->H_host, stage, 32);
+    HIPCHK(c, hipMemcpyAsync(c->d_H.p, stage, 32, hipMemcpyHostToDevice, c->hstream));
+    HIPCHK(c, hipEventRecord(c->ev_H, c->hstream));
+    c->H_copy_issued = true;
+    c->H_pending = true;
+    c->have_H = true;
+    c->have_H_host = true;
+    return IBFT_OK;
+  }
+  c->have_H_host = false;
   // Keccak padding on the host: pad10*1 up to a multiple of the 136-byte rate (the kernel XORs whole 64-bit words)
   const size_t mlen = c->hashed_proposal.size();
   const size_t blocks = mlen / 136 + 1;
@@ -1025,6 +1096,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   if (const char *e = getenv("IBFT_NO_EVENTS"))
     if (atoi(e) == 1) c->time_every = 0;
   if (getenv("IBFT_NO_GATHER")) c->gather_pinned = false;
+  if (const char *e = getenv("IBFT_PROPOSAL_HASH")) c->hash_on_host = strcmp(e, "device") != 0;
   if (const char *e = getenv("IBFT_CERT_OVERLAP")) c->cert_overlap = atoi(e) != 0;
   if (getenv("IBFT_DIGEST_FUSION")) c->digest_in_gather = true;
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
@@ -1241,12 +1313,22 @@ int ibft_last_tally_wide(ibft_ctx *c, ibft_tally_wide_t *out) {
   return IBFT_OK;
 }
 
+int ibft_keccak256(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, uint8_t out32[32]) {
+  if (!out32 || (na && !a) || (nb && !b)) return IBFT_E_INVAL;
+  host_keccak256(a, na, b, nb, out32);
+  return IBFT_OK;
+}
+
 int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round, uint8_t out32[32]) {
   if (!c || (raw_len && !raw) || !out32 || raw_len > (1ull << 31)) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_proposal_hash(c, raw, raw_len, round))) return rc;
+  if (c->have_H && c->have_H_host) {  // hashed on the host: the digest is at hand (d_H receives it on the side stream)
+    memcpy(out32, c->H_host, 32);
+    return IBFT_OK;
+  }
   if ((rc = wait_proposal_hash(c))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->h_digest, c->d_H.p, 32, hipMemcpyDeviceToHost, c->stream));
   if (hipStreamSynchronize(c->stream) != hipSuccess) {

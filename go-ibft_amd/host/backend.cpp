@@ -247,6 +247,63 @@ bool GpuBackend::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off
   unpack_mask(ms, rows, out.sender);
   unpack_mask(mh, rows, out.hash);
   unpack_mask(mself, rows, out.self);
+  // What the device hands back because ONE sponge would have to absorb it (a message, or a Proposal, beyond
+  // IBFT_CERT_DIGEST_MAX_BYTES): hashed here with the library's host Keccak (≈340 MB/s against the 25 MB/s of a wavefront),
+  // the envelope then judged as a (digest, signature, From) row of ibft_verify_seals.  Rare — blocks above 1 MiB — so the
+  // parsed fields (From, carried hashes) are fetched by a second call only when such a row exists.
+  bool by_host = false;
+  for (size_t r = 0; r < rows; r++)
+    by_host = by_host || ((out.cls[r] & (IBFT_CERT_CLASS_DIGEST_BY_HOST | IBFT_CERT_CLASS_PROPOSAL_BY_HOST)) &&
+                          !(out.cls[r] & IBFT_CERT_CLASS_NEEDS_HOST));
+  if (!by_host) return true;
+  std::vector<ibft_wire_row_t> wr(cap);
+  std::vector<uint8_t> cls2(cap, 0);
+  size_t rows2 = 0;
+  if (ibft_verify_certificates_wire(ctx_, wire, off, n, cap, &rows2, nullptr, wr.data(), cls2.data(), ms.data(), mh.data(),
+                                    mself.data()) != IBFT_OK || rows2 != rows)
+    return true;  // the classes stand: the caller's stock route decides those rows
+  std::vector<size_t> drows;
+  std::vector<uint8_t> dg, sg, fr;
+  for (size_t r = 0; r < rows; r++) {
+    const ibft_cert_node_t &nd = out.nodes[r];
+    const uint8_t *m = wire + nd.off;
+    if ((out.cls[r] & IBFT_CERT_CLASS_PROPOSAL_BY_HOST) && !(out.cls[r] & IBFT_CERT_CLASS_NEEDS_HOST) &&
+        (nd.flags & IBFT_CERT_HAS_PROPOSAL)) {
+      uint8_t be[8], H[32];
+      for (int i = 0; i < 8; i++) be[i] = (uint8_t)(nd.proposal_round >> (8 * (7 - i)));
+      ibft_keccak256(wire + nd.raw_off, nd.raw_len, be, 8, H);
+      if (wr[r].payload_kind == 5)  // a PREPREPARE's own (proposal, proposalHash)
+        out.self[r] = wr[r].hash_len == 32 && memcmp(wr[r].proposal_hash, H, 32) == 0;
+      if (wr[r].payload_kind == 8)  // a ROUND_CHANGE's lastPreparedProposal against the hashes its certificate carries
+        for (uint32_t k = 0; k < nd.n_children && (size_t)nd.first_child + k < rows; k++) {
+          const size_t c = nd.first_child + k;
+          out.hash[c] = wr[c].hash_len == 32 && memcmp(wr[c].proposal_hash, H, 32) == 0;
+        }
+      out.cls[r] &= (uint8_t)~IBFT_CERT_CLASS_PROPOSAL_BY_HOST;
+    }
+    if ((out.cls[r] & IBFT_CERT_CLASS_DIGEST_BY_HOST) && !(out.cls[r] & IBFT_CERT_CLASS_NEEDS_HOST)) {
+      // PayloadNoSig = the bytes without the signature field [cut0, cut1) (the device vouched that they are canonical)
+      if (nd.cut1 < nd.cut0 || nd.cut1 > nd.len || wr[r].from_len != 20 || wr[r].sig_len != 65 || nd.cut1 - nd.cut0 < 65) {
+        out.sender[r] = 0;  // no 65-byte signature / 20-byte From: IsValidValidator is false without any arithmetic
+        out.cls[r] &= (uint8_t)~IBFT_CERT_CLASS_DIGEST_BY_HOST;
+        continue;
+      }
+      uint8_t d[32];
+      ibft_keccak256(m, nd.cut0, m + nd.cut1, nd.len - nd.cut1, d);
+      drows.push_back(r);
+      dg.insert(dg.end(), d, d + 32);
+      sg.insert(sg.end(), m + nd.cut1 - 65, m + nd.cut1);
+      fr.insert(fr.end(), wr[r].from, wr[r].from + 20);
+    }
+  }
+  if (!drows.empty()) {
+    std::vector<uint64_t> dm((drows.size() + 63) / 64, 0);
+    if (ibft_verify_seals(ctx_, dg.data(), sg.data(), fr.data(), nullptr, drows.size(), dm.data(), nullptr) == IBFT_OK)
+      for (size_t j = 0; j < drows.size(); j++) {
+        out.sender[drows[j]] = (dm[j >> 6] >> (j & 63)) & 1;
+        out.cls[drows[j]] &= (uint8_t)~IBFT_CERT_CLASS_DIGEST_BY_HOST;
+      }
+  }
   return true;
 }
 

@@ -38,7 +38,7 @@ EXPORTS = [
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages",
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
-    "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire",
+    "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -172,6 +172,7 @@ def load_library() -> C.CDLL:
     L.ibft_group_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp,
                                              vp, vp, C.POINTER(Tally)]
     L.ibft_group_is_local.argtypes = [vp]
+    L.ibft_keccak256.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
     _lib = L
@@ -234,6 +235,16 @@ def exchange_layout(n_total: int, world: int, n_validators: int, n_masks: int = 
     if rc:
         raise ValueError(f"ibft_exchange_layout: {rc}")
     return w.value, b.value, s.value
+
+
+def keccak256(a: bytes, b: bytes = b"") -> bytes:
+    """ibft_keccak256: keccak256(a ‖ b) by the library's host routine (no device needed)"""
+    a, b = bytes(a), bytes(b)
+    out = C.create_string_buffer(32)
+    rc = load_library().ibft_keccak256(a or None, len(a), b or None, len(b), out)
+    if rc:
+        raise ValueError(f"ibft_keccak256: {rc}")
+    return out.raw
 
 
 def comm_unique_id() -> bytes:

@@ -176,12 +176,21 @@ int ibft_verify_hashes(ibft_ctx *ctx, const uint8_t *raw, size_t raw_len, uint64
  * a sequential sponge, one lane walks it at ≈13 µs per 136-byte block (profiles/r02_a1_sizes.json).         */
 int ibft_verify_hashes_digest(ibft_ctx *ctx, const uint8_t digest32[32], const uint8_t *hash32,
                               const uint8_t *hash_len, size_t n, uint64_t *out_mask);
-/* keccak256(raw ‖ BE64(round)) computed on the device (what BuildPrepareMessage's
- * caller would sign).  The context remembers the last proposal it hashed: ibft_verify_hashes /
- * ibft_proposal_hash with the same (raw, round) — every PREPARE and COMMIT set of a round, every wake-up —
- * skip the upload and the hash.                                                    */
+/* keccak256(raw ‖ BE64(round)) (what BuildPrepareMessage's caller would sign).  The context remembers the last
+ * proposal it hashed: ibft_verify_hashes / ibft_proposal_hash with the same (raw, round) — every PREPARE and COMMIT set
+ * of a round, every wake-up — skip the hash.  WHERE it is hashed: on the calling host thread, with the library's own
+ * permutation (csrc/keccak_dev.h compiles for both sides).  Keccak is a sequential sponge — one message cannot be spread
+ * over the chip — and one host core absorbs ≈340 MB/s (3.6 µs for 1 KiB, ≈3 ms for 1 MiB) where the one wavefront that
+ * can work on it absorbs 25 MB/s (41 ms for 1 MiB, round 2); the 32-byte digest then reaches the device on the side
+ * stream, behind the verdict launch it overlaps with.  IBFT_PROPOSAL_HASH=device selects the wavefront kernel (A/B,
+ * tests).  The device keeps every hash of which there are MANY to do in parallel: PayloadNoSig of every message, the
+ * address of every recovered key, the digests of a certificate tree.                                               */
 int ibft_proposal_hash(ibft_ctx *ctx, const uint8_t *raw, size_t raw_len, uint64_t round,
                        uint8_t out32[32]);
+
+/* keccak256(a ‖ b) on the host (either part may be empty) — the same routine: for callers that hash what the device
+ * hands back (IBFT_CERT_CLASS_DIGEST_BY_HOST rows: a = bytes[0, cut0), b = bytes[cut1, len)).  No context, no device.  */
+int ibft_keccak256(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, uint8_t out32[32]);
 
 /* a2.  hash32 n×32 (per-row proposalHash from ExtractCommitHash), sig65 n×65,
  * signer20 n×20 (msg.From).  tally may be NULL.                                   */

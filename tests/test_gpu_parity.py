@@ -312,3 +312,50 @@ def test_proposal_hash_is_remembered_and_digest_form_agrees(oracle):
                     assert (bv.is_valid_proposal_hash(raw, rnd, hashes, hl) == exp).all()
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("route", ["host", "device"])
+def test_proposal_hash_routes_agree_at_block_sizes(oracle, route, monkeypatch):
+    """a1 (IsValidProposalHash): keccak256(raw ‖ BE64(round)) by the library's host routine (the default since round 3:
+    a sponge is sequential, one host core absorbs 13× what the one wavefront that can work on a message absorbs) and by
+    the wavefront kernel (IBFT_PROPOSAL_HASH=device) — sizes around the 136-byte rate, 64 KiB, 1 MiB — against the oracle,
+    through ibft_proposal_hash, ibft_verify_hashes and a COMMIT set whose combine step waits for the digest."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    monkeypatch.setenv("IBFT_PROPOSAL_HASH", route)
+    rng = np.random.default_rng(5)
+    bv = V.BatchVerifier(max_rows=256)
+    try:
+        r = W.make_round(40, 77, byzantine=True, with_envelopes=True)
+        bv.set_validators(r.height, r.addrs, r.power)
+        for L in (0, 1, 127, 128, 135, 136, 137, 271, 272, 1024, 65536, 1 << 20):
+            raw = rng.bytes(L)
+            for rnd in (0, 7, 2**40 + 3):
+                H = oracle.proposal_hash(raw, rnd)
+                assert bv.proposal_hash(raw, rnd) == H, (route, L, rnd)
+            hashes = np.tile(np.frombuffer(H, np.uint8), (100, 1)).copy()
+            hashes[::7, 3] ^= 1
+            hl = np.full(100, 32, np.uint8)
+            bv.forget_proposal()
+            got = bv.is_valid_proposal_hash(raw, rnd, hashes, hl)
+            assert (got == oracle.verify_hashes(raw, rnd, hashes, hl).astype(bool)).all(), (route, L)
+        # a COMMIT set against a 64 KiB proposal: the verdict launch runs while the proposal is hashed
+        raw = rng.bytes(65536)
+        H = np.frombuffer(oracle.proposal_hash(raw, r.round), np.uint8)
+        h32 = np.tile(H, (r.n, 1))
+        h32[5, 0] ^= 1
+        bv.forget_proposal()
+        s, v, _ = bv.verify_messages(r.payload, r.off, r.msg_sig65, r.signer20, h32, r.hash_len, None, raw=raw, round_=r.round)
+        assert (v == oracle.verify_hashes(raw, r.round, h32, r.hash_len).astype(bool)).all() and not v[5]
+    finally:
+        bv.close()
+
+
+def test_host_keccak_entry_point(oracle):
+    """ibft_keccak256(a ‖ b): what the mirror hashes DIGEST_BY_HOST rows with (no context, no device)"""
+    import go_ibft_amd.verifier as V
+    rng = np.random.default_rng(9)
+    for n in (0, 1, 135, 136, 137, 1000, 300000):
+        x = rng.bytes(n)
+        assert V.keccak256(x) == oracle.keccak256(x)
+        assert V.keccak256(x[: n // 3], x[n // 3:]) == oracle.keccak256(x)

@@ -10,9 +10,10 @@ from oracle import binding as B      # checker only: expected digests / verdicts
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 rng = np.random.default_rng(1)
-bv = V.BatchVerifier(max_rows=n)
-out = {"rows": n, "note": "ms per call, host columns -> host-visible verdict mask (H2D, kernels, D2H included); p50 of 20 (first call: of 5 distinct proposals)"}
-for L in (1024, 65536, 1 << 20):
+bv = V.BatchVerifier(max_rows=n)      # IBFT_PROPOSAL_HASH=device in the environment selects the wavefront sponge (round 2's route)
+out = {"rows": n, "proposal_hashed_by": os.environ.get("IBFT_PROPOSAL_HASH", "host"),
+       "note": "ms per call, host columns -> host-visible verdict mask (H2D, kernels, D2H included); p50 of 20 (first call: of 5 distinct proposals)"}
+for L in (1024, 65536, 1 << 20, 8 << 20):
     first, again, dig = [], [], []
     for rep in range(5):
         raw = rng.bytes(L)
