@@ -233,12 +233,14 @@ def test_small_context_set_after_a_plain_batch(oracle):
     must not trust the "mask is clean" bookkeeping of an earlier plain batch: the seal words [half/64, …) had never been
     zeroed and stale bits made forged seals valid.  A plain batch first, then a Byzantine COMMIT set, on one context."""
     import go_ibft_amd.verifier as V
-    import torch
     from oracle import workload as W
-    # dirty the allocator's free lists first: fresh process memory is zero and hides the bug
-    junk = [torch.full((64,), -1, dtype=torch.int64, device="cuda") for _ in range(64)]
-    del junk
-    torch.cuda.empty_cache()
+    # dirty the allocator's free lists first (fresh process memory is zero and hides the bug): a context that has run a
+    # batch full of valid rows leaves set verdict words behind in the memory it frees
+    r0 = W.make_round(300, 7299, with_envelopes=True)
+    junk = V.BatchVerifier(max_rows=300)
+    junk.set_validators(r0.height, r0.addrs, r0.power)
+    junk.verify_messages(r0.payload, r0.off, r0.msg_sig65, r0.signer20, r0.hash32, r0.hash_len, r0.seal65, raw=r0.raw, round_=r0.round)
+    junk.close()
     for n in (200, 256, 700):
         r = W.make_round(n, 7300 + n, byzantine=True, with_envelopes=True, weighted=True)
         vs, senders, valid = _oracle_expect(oracle, r, True)
