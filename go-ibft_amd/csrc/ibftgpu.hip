@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -35,8 +36,52 @@ struct DevBuf {
 
 }  // namespace
 
+// What belongs to a DEVICE rather than to a context: the fixed-base table of G (84 MB, 9 ms to build) and — with
+// IBFT_FLAG_PUBKEY_CACHE — the validators' key tables.  Every context of a device shares one copy (the four contexts a
+// Backend holds for its four goroutines, the several ranks of a group that lists one device more than once); the tables
+// are keyed by ADDRESS, so a validator keeps its slot and its table when the validator set changes around it.
+struct KeyAddr {
+  uint8_t b[20];
+  bool operator==(const KeyAddr &o) const { return memcmp(b, o.b, 20) == 0; }
+};
+struct KeyAddrHash {
+  size_t operator()(const KeyAddr &a) const {
+    uint64_t x, y;
+    uint32_t z;
+    memcpy(&x, a.b, 8);
+    memcpy(&y, a.b + 8, 8);
+    memcpy(&z, a.b + 16, 4);
+    return (size_t)((x * 0x9E3779B97F4A7C15ull) ^ (y * 0xC2B2AE3D27D4EB4Full) ^ z);
+  }
+};
+struct DeviceShared {
+  std::mutex mu;  // taken around every launch that reads the pointers below and around every change of them
+  int device = 0;
+  DevBuf d_gtab;
+  // key cache: slot s holds pub (80 B), state (0 unknown, 1 key known, 2 table built) and a 655 KB table
+  DevBuf d_pub, d_state, d_qtab, d_learned;  // d_learned: {keys learned, a learned slot} (two u32), bumped by the kernels
+  uint32_t cap = 0;                          // slots allocated
+  std::unordered_map<KeyAddr, uint32_t, KeyAddrHash> slot_of;
+  std::vector<uint32_t> refs;                // contexts whose current validator set holds the slot's address
+  std::vector<KeyAddr> addr_of;
+  std::vector<uint8_t> built;                // host shadow of state == 2 (refreshed after every build pass)
+  std::vector<uint32_t> free_slots;
+  uint32_t used = 0;                         // slots handed out so far (high-water mark)
+  uint32_t learned_seen = 0;                 // value of the device counter up to which tables are built (or being built)
+  uint32_t dummy_slot = 0;
+  uint64_t build_epoch = 1;                  // bumped by every build pass: contexts recount their built validators
+  uint64_t generation = 1;                   // bumped when the buffers move: contexts re-read the pointers
+};
+std::mutex g_devices_mu;
+std::map<int, std::weak_ptr<DeviceShared>> g_devices;
+
 struct ibft_ctx {
   std::mutex mu;
+  std::shared_ptr<DeviceShared> dev;   // the G table and the key cache of this context's device
+  DevBuf d_vslot;                      // validator index → key-cache slot (0xFFFFFFFF = none)
+  std::vector<uint32_t> vslot;         // the same on the host
+  uint32_t my_built = 0;               // validators of the current set whose table is built
+  uint64_t seen_build_epoch = 0;
   int device = 0;
   uint32_t flags = 0;
   uint32_t max_rows = DEFAULT_MAX_ROWS;
@@ -57,7 +102,6 @@ struct ibft_ctx {
   uint32_t wire_n = 0;         // rows of the last ibft_verify_senders_wire
   bool wire_valid = false;     // its columns are still the resident ones
   // fixed-base table for G
-  DevBuf d_gtab;
   // validator table
   DevBuf d_vtab, d_vpower;
   uint32_t vslot_mask = 0;
@@ -86,10 +130,8 @@ struct ibft_ctx {
   uint32_t x_issued = 0, x_fetched = 0;  // exchanges enqueued / consumed (at most 2 in flight)
 
   // warm path (IBFT_FLAG_PUBKEY_CACHE): recovered keys + per-validator fixed-base tables
-  bool cache_on = false;       // flag set AND the tables fit the memory budget for this validator set
-  DevBuf d_pub, d_pub_state, d_qtab, d_warm_done;
-  uint32_t learned_seen = 0;   // keys whose tables are built (or being built, stream-ordered)
-  uint32_t dummy_validator = 0;
+  bool cache_on = false;       // flag set AND the device's key cache could be set up for this validator set
+  DevBuf d_warm_done;
   std::vector<uint8_t> valset_addrs;  // last address list, to keep the cache across identical sets
   uint32_t warm_passes = 0, cold_passes = 0, last_group = 0, last_cold_group = 1;
   bool cold_group_auto = true;
@@ -222,19 +264,20 @@ ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre, uint32_t r
   a.pre_flags = with_pre ? (const uint8_t *)c->d_pre.p + row_base : nullptr;
   a.payload = (const uint8_t *)c->d_payload.p;
   a.off = (const uint32_t *)c->d_off.p;
-  a.gtab = (const uint32_t *)c->d_gtab.p;
+  a.gtab = (const uint32_t *)c->dev->d_gtab.p;
   a.vtab = (const uint32_t *)c->d_vtab.p;
   a.vslot_mask = c->vslot_mask;
   a.n = n;
   a.flags = c->flags;
   a.mask = (uint64_t *)c->d_mask.p + row_base / 64;
   a.vidx = (int32_t *)c->d_vidx.p + row_base;
-  if (c->cache_on) {
-    a.pub = (uint32_t *)c->d_pub.p;
-    a.pub_state = (uint32_t *)c->d_pub_state.p;
-    a.learned = (uint32_t *)((uint64_t *)c->d_tally.p + 4);
-    a.qtab = (const uint32_t *)c->d_qtab.p;
-    a.dummy_validator = c->dummy_validator;
+  if (c->cache_on) {  // (the caller holds c->dev->mu: the pointers cannot move before the launch is enqueued)
+    a.pub = (uint32_t *)c->dev->d_pub.p;
+    a.pub_state = (uint32_t *)c->dev->d_state.p;
+    a.learned = (uint32_t *)c->dev->d_learned.p;
+    a.qtab = (const uint32_t *)c->dev->d_qtab.p;
+    a.dummy_validator = c->dev->dummy_slot;
+    a.vslot = (const uint32_t *)c->d_vslot.p;
   }
   return a;
 }
@@ -265,8 +308,22 @@ int clean_mask(ibft_ctx *c) {
 // (its rows are then skipped by the recover kernel), recover kernel for everything else
 // keep_mask: a second batch of the same call (rows [row_base, row_base + n)): the work mask already holds the first batch's
 // bits and must not be zeroed again (the caller saw to it that this batch's words are clean)
+// validators of this context's set whose table is built, recounted when a build pass has run since the last count
+void recount_built(ibft_ctx *c) {  // c->dev->mu held
+  if (!c->cache_on || c->seen_build_epoch == c->dev->build_epoch) return;
+  uint32_t k = 0;
+  for (uint32_t sl : c->vslot) k += (sl != 0xFFFFFFFFu && c->dev->built[sl]) ? 1u : 0u;
+  c->my_built = k;
+  c->seen_build_epoch = c->dev->build_epoch;
+}
+
 int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it, uint32_t row_base = 0, bool keep_mask = false) {
   if (n == 0) return IBFT_OK;
+  std::unique_lock<std::mutex> dev_lk(c->dev->mu, std::defer_lock);
+  if (c->cache_on) {
+    dev_lk.lock();
+    recount_built(c);
+  }
   ibftk::recover_args a = make_args(c, n, with_pre, row_base);
   struct dirty_on_exit {  // whatever is launched below writes verdict bits into the first ⌈n/64⌉ words of d_mask
     ibft_ctx *c;
@@ -281,7 +338,7 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
-  const bool warm = c->cache_on && c->learned_seen > 0;
+  const bool warm = c->cache_on && c->my_built > 0;
   if (warm) {
     a.warm_done = (uint8_t *)c->d_warm_done.p + row_base;
     // lanes per signature: ≈ one wavefront per SIMD (1024 SIMDs × 64 lanes / n rows), a power of two
@@ -328,7 +385,7 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   } else {
     c->cold_passes++;
   }
-  if (warm && c->learned_seen >= c->n_validators) {
+  if (warm && c->my_built >= c->n_validators) {
     // every validator has a table: the warm kernel decides every row (non-members included)
     if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
     c->last_cold_group = 0;
@@ -392,17 +449,31 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
 }
 
 // after a fetch: build tables for keys learned since the last build (stream-ordered, asynchronous)
-int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_validator) {
-  if (!c->cache_on || learned_total <= c->learned_seen) return IBFT_OK;
-  const uint32_t nv = c->n_validators;
-  hipLaunchKernelGGL(ibftk::qtab_build_kernel, dim3(((nv + 63) / 64) * ibftk::QTAB_WINDOWS), dim3(64), 0, c->stream,
-                     (const uint32_t *)c->d_pub.p, (const uint32_t *)c->d_pub_state.p, (uint32_t *)c->d_qtab.p, nv);
+// Keys were learned since the last build pass (the device counter moved): tables for them, on this context's stream.
+// One context builds; the others see the new tables at their next launch (state 2) and recount.
+int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_slot) {
+  if (!c->cache_on) return IBFT_OK;
+  DeviceShared &d = *c->dev;
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (learned_total == d.learned_seen) {
+    recount_built(c);
+    return IBFT_OK;
+  }
+  const uint32_t ns = d.used;
+  hipLaunchKernelGGL(ibftk::qtab_build_kernel, dim3(((ns + 63) / 64) * ibftk::QTAB_WINDOWS), dim3(64), 0, c->stream,
+                     (const uint32_t *)d.d_pub.p, (const uint32_t *)d.d_state.p, (uint32_t *)d.d_qtab.p, ns);
   HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(ibftk::qtab_commit_kernel, dim3((nv + 255) / 256), dim3(256), 0, c->stream,
-                     (uint32_t *)c->d_pub_state.p, nv);
+  hipLaunchKernelGGL(ibftk::qtab_commit_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, (uint32_t *)d.d_state.p, ns);
   HIPCHK(c, hipGetLastError());
-  c->learned_seen = learned_total;
-  c->dummy_validator = any_validator;
+  // which slots hold a table now: the host's shadow of the states (a learn event is rare once the set is known)
+  std::vector<uint32_t> st(ns);
+  HIPCHK(c, hipMemcpyAsync(st.data(), d.d_state.p, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (uint32_t i = 0; i < ns; i++) d.built[i] = st[i] == 2;
+  d.learned_seen = learned_total;
+  if (any_slot < ns && d.built[any_slot]) d.dummy_slot = any_slot;
+  d.build_epoch++;
+  recount_built(c);
   return IBFT_OK;
 }
 
@@ -426,6 +497,7 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
   t.host_tally = c->dh_tally;
   t.set_on = set ? 1u : 0u;
   if (set) t.set = *set;
+  if (c->cache_on) t.learned_src = (const uint64_t *)c->dev->d_learned.p;
   if (c->comm || c->xlocal) {  // a rank of a sharded batch: the bitmap of this launch is what the exchange merges
     const size_t bytes = (size_t)((c->n_validators + 63) / 64) * 8;
     if (bytes > c->d_seen_out.cap) {
@@ -1048,6 +1120,8 @@ struct ibft_group {
 
 extern "C" {
 
+static void key_cache_unmap(ibft_ctx *c);
+
 int ibft_version(void) { return 1; }
 
 const char *ibft_strerror(int code) {
@@ -1129,11 +1203,29 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
         if (hipHostGetDevicePointer(&dc, c->h_class, 0) == hipSuccess) c->dh_class = (uint8_t *)dc;
       }
     }
-    if ((rc = ensure(c, c->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
-    int threads = 64, total = ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES;
-    hipLaunchKernelGGL(ibftk::gtab_build_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0,
-                       c->stream, (uint32_t *)c->d_gtab.p);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc = IBFT_E_HIP; break; }
+    {  // the device's shared object: created (and the G table built) by the first context of the device
+      std::lock_guard<std::mutex> glk(g_devices_mu);
+      c->dev = g_devices[c->device].lock();
+      if (!c->dev) {
+        c->dev = std::make_shared<DeviceShared>();
+        c->dev->device = c->device;
+        g_devices[c->device] = c->dev;
+      }
+    }
+    {
+      std::lock_guard<std::mutex> dlk(c->dev->mu);
+      if (!c->dev->d_gtab.p) {
+        if ((rc = ensure(c, c->dev->d_gtab, (size_t)ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES * ibftk::GTAB_ENTRY_DWORDS * 4))) break;
+        int threads = 64, total = ibftk::GTAB_WINDOWS * ibftk::GTAB_ENTRIES;
+        hipLaunchKernelGGL(ibftk::gtab_build_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0,
+                           c->stream, (uint32_t *)c->dev->d_gtab.p);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+          release(c->dev->d_gtab);
+          rc = IBFT_E_HIP;
+          break;
+        }
+      }
+    }
   } while (0);
   if (rc) {
     ibft_ctx_destroy(c);
@@ -1149,13 +1241,25 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->hstream) (void)hipStreamSynchronize(c->hstream);
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
-                    &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H, &c->d_gtab,
-                    &c->d_vtab, &c->d_vpower, &c->d_pub, &c->d_pub_state, &c->d_qtab,
+                    &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H,
+                    &c->d_vtab, &c->d_vpower, &c->d_vslot,
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
                     &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
                     &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total,
                     &c->d_cert_slot, &c->d_cert_tiles})
     release(*b);
+  if (c->dev) {
+    {
+      std::lock_guard<std::mutex> dlk(c->dev->mu);
+      key_cache_unmap(c);
+    }
+    std::lock_guard<std::mutex> glk(g_devices_mu);
+    if (c->dev.use_count() == 1) {  // the last context of the device: its tables go with it
+      for (DevBuf *b : {&c->dev->d_gtab, &c->dev->d_pub, &c->dev->d_state, &c->dev->d_qtab, &c->dev->d_learned}) release(*b);
+      g_devices.erase(c->device);
+    }
+    c->dev.reset();
+  }
   if (c->h_cert_total) (void)hipHostFree(c->h_cert_total);
   if (c->ev_cert_fork) (void)hipEventDestroy(c->ev_cert_fork);
   if (c->ev_cert_join) (void)hipEventDestroy(c->ev_cert_join);
@@ -1175,6 +1279,139 @@ void ibft_ctx_destroy(ibft_ctx *c) {
 }
 
 // powers: n × pw little-endian 64-bit words (pw = 1: ibft_set_validators, pw = 4: ibft_set_validators_u256)
+// Drop this context's references to its slots; a slot nobody refers to any more is free for another address.
+static void key_cache_unmap(ibft_ctx *c) {  // c->dev->mu held
+  DeviceShared &d = *c->dev;
+  for (uint32_t sl : c->vslot) {
+    if (sl == 0xFFFFFFFFu || sl >= d.refs.size() || d.refs[sl] == 0) continue;
+    if (--d.refs[sl] == 0) {
+      d.slot_of.erase(d.addr_of[sl]);
+      d.free_slots.push_back(sl);
+    }
+  }
+  c->vslot.clear();
+  c->my_built = 0;
+  c->cache_on = false;
+}
+
+// Give every validator of the new set its slot (c->dev->mu held).  Grows the pool when the set needs more slots than it
+// has (within IBFT_QTAB_BUDGET_GB, default 64: 655 KB per slot); validators beyond the budget simply have no slot.
+static int key_cache_map(ibft_ctx *c, const std::vector<KeyAddr> &vaddr) {
+  DeviceShared &d = *c->dev;
+  const size_t nv = vaddr.size();
+  if (nv == 0) {
+    key_cache_unmap(c);
+    return IBFT_E_INVAL;
+  }
+  // new references first, then the old ones go: an address in both sets never drops to zero in between
+  std::vector<uint32_t> ns(nv, 0xFFFFFFFFu);
+  size_t need_new = 0;
+  for (size_t v = 0; v < nv; v++) {
+    auto it = d.slot_of.find(vaddr[v]);
+    if (it != d.slot_of.end()) {
+      ns[v] = it->second;
+      d.refs[it->second]++;
+    } else {
+      need_new++;
+    }
+  }
+  {
+    std::vector<uint32_t> old;
+    old.swap(c->vslot);
+    for (uint32_t sl : old) {
+      if (sl == 0xFFFFFFFFu || d.refs[sl] == 0) continue;
+      if (--d.refs[sl] == 0) {
+        d.slot_of.erase(d.addr_of[sl]);
+        d.free_slots.push_back(sl);
+      }
+    }
+  }
+  size_t budget = 64ull << 30;
+  if (const char *e = getenv("IBFT_QTAB_BUDGET_GB")) budget = (size_t)strtoull(e, nullptr, 10) << 30;
+  const size_t slot_bytes = (size_t)ibftk::QTAB_DWORDS_PER_VALIDATOR * 4;
+  const size_t max_slots = budget / slot_bytes;
+  const size_t avail = d.free_slots.size() + (d.cap - d.used);
+  if (need_new > avail) {  // grow: the existing tables move to the new buffers (device copies), the pointers change
+    size_t want = std::min(max_slots, std::max((size_t)d.used + (need_new - d.free_slots.size()), (size_t)d.cap * 2));
+    if (want > d.cap) {
+      DevBuf nq, np, nst;
+      if (ensure(c, nq, want * slot_bytes) == IBFT_OK && ensure(c, np, want * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK &&
+          ensure(c, nst, want * 4) == IBFT_OK && (d.d_learned.p || ensure(c, d.d_learned, 8) == IBFT_OK)) {
+        bool ok = hipMemset(nst.p, 0, want * 4) == hipSuccess;
+        if (d.used) {
+          ok = ok && hipMemcpy(nq.p, d.d_qtab.p, (size_t)d.used * slot_bytes, hipMemcpyDeviceToDevice) == hipSuccess;
+          ok = ok && hipMemcpy(np.p, d.d_pub.p, (size_t)d.used * ibftk::GTAB_ENTRY_DWORDS * 4, hipMemcpyDeviceToDevice) == hipSuccess;
+          ok = ok && hipMemcpy(nst.p, d.d_state.p, (size_t)d.used * 4, hipMemcpyDeviceToDevice) == hipSuccess;
+        } else {
+          ok = ok && hipMemset(d.d_learned.p, 0, 8) == hipSuccess;
+        }
+        if (ok) {
+          release(d.d_qtab);   // (hipFree waits for every kernel of the device that may still read the old buffers;
+          release(d.d_pub);    //  launches that would read the pointers take d.mu first, which we hold)
+          release(d.d_state);
+          d.d_qtab = nq;
+          d.d_pub = np;
+          d.d_state = nst;
+          d.cap = (uint32_t)want;
+          d.refs.resize(want, 0);
+          d.addr_of.resize(want);
+          d.built.resize(want, 0);
+          d.generation++;
+        } else {
+          release(nq);
+          release(np);
+          release(nst);
+        }
+      } else {
+        release(nq);
+        release(np);
+        release(nst);
+      }
+    }
+  }
+  std::vector<uint32_t> fresh;  // slots handed to new addresses: their state starts at 0
+  for (size_t v = 0; v < nv; v++) {
+    if (ns[v] != 0xFFFFFFFFu) continue;
+    uint32_t sl;
+    if (!d.free_slots.empty()) {
+      sl = d.free_slots.back();
+      d.free_slots.pop_back();
+    } else if (d.used < d.cap) {
+      sl = d.used++;
+    } else {
+      continue;  // beyond the budget: this validator stays on the recover path
+    }
+    d.slot_of[vaddr[v]] = sl;
+    d.addr_of[sl] = vaddr[v];
+    d.refs[sl] = 1;
+    if (d.built[sl]) {
+      d.built[sl] = 0;
+      d.build_epoch++;
+    }
+    ns[v] = sl;
+    fresh.push_back(sl);
+  }
+  if (d.cap == 0) {
+    c->vslot.clear();
+    return IBFT_E_NOMEM;
+  }
+  // a recycled slot must read "unknown" again before any kernel of this context can claim it
+  std::sort(fresh.begin(), fresh.end());
+  for (size_t i = 0; i < fresh.size();) {
+    size_t j = i;
+    while (j + 1 < fresh.size() && fresh[j + 1] == fresh[j] + 1) j++;
+    HIPCHK(c, hipMemsetAsync((uint32_t *)d.d_state.p + fresh[i], 0, (j - i + 1) * 4, c->stream));
+    i = j + 1;
+  }
+  int rc = ensure(c, c->d_vslot, nv * 4);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_vslot.p, ns.data(), nv * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->vslot.swap(ns);
+  c->seen_build_epoch = 0;  // recount at the next launch
+  return IBFT_OK;
+}
+
 static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint64_t *power, uint32_t pw,
                                size_t n) {
   std::lock_guard<std::mutex> lk(c->mu);
@@ -1186,6 +1423,8 @@ static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addr
   std::vector<uint32_t> tab((size_t)slots * 6, 0);
   std::vector<uint64_t> pwv;  // distinct validators × pw words
   pwv.reserve((n ? n : 1) * pw);
+  std::vector<KeyAddr> vaddr;  // distinct validators' addresses, by validator index
+  vaddr.reserve(n);
   for (size_t i = 0; i < n; i++) {
     uint32_t a[5];
     memcpy(a, addrs20 + 20 * i, 20);
@@ -1196,6 +1435,9 @@ static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addr
         memcpy(e, a, 20);
         pwv.insert(pwv.end(), power + i * pw, power + (i + 1) * pw);
         e[5] = (uint32_t)(pwv.size() / pw);
+        KeyAddr ka;
+        memcpy(ka.b, a, 20);
+        vaddr.push_back(ka);  // address of validator index e[5] − 1
         break;
       }
       if (memcmp(e, a, 20) == 0) {
@@ -1252,21 +1494,11 @@ static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addr
     HIPCHK(c, hipMemsetAsync(c->d_seen.p, 0, c->d_seen.cap, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  // warm-path cache: kept when the address list is unchanged, rebuilt otherwise
-  const bool same_set = c->valset_addrs.size() == n * 20 && (n == 0 || memcmp(c->valset_addrs.data(), addrs20, n * 20) == 0);
-  if ((c->flags & IBFT_FLAG_PUBKEY_CACHE) && !(same_set && c->cache_on)) {
-    c->cache_on = false;
-    c->learned_seen = 0;
-    const size_t qbytes = nv * ibftk::QTAB_DWORDS_PER_VALIDATOR * 4;
-    size_t budget = 64ull << 30;
-    if (const char *e = getenv("IBFT_QTAB_BUDGET_GB")) budget = (size_t)strtoull(e, nullptr, 10) << 30;
-    if (nv > 0 && qbytes <= budget && ensure(c, c->d_qtab, qbytes) == IBFT_OK &&
-        ensure(c, c->d_pub, nv * ibftk::GTAB_ENTRY_DWORDS * 4) == IBFT_OK && ensure(c, c->d_pub_state, nv * 4) == IBFT_OK) {
-      HIPCHK(c, hipMemsetAsync(c->d_pub_state.p, 0, nv * 4, c->stream));
-      HIPCHK(c, hipMemsetAsync((uint64_t *)c->d_tally.p + 4, 0, 8, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      c->cache_on = true;
-    }
+  // warm path: the validators of this set get their slots in the device's key cache — an address that had one keeps it
+  // (and its table), whatever changed around it
+  if (c->flags & IBFT_FLAG_PUBKEY_CACHE) {
+    std::lock_guard<std::mutex> dlk(c->dev->mu);
+    c->cache_on = key_cache_map(c, vaddr) == IBFT_OK;
   }
   c->valset_addrs.assign(addrs20, addrs20 + n * 20);
   c->vslot_mask = slots - 1;
@@ -1528,10 +1760,23 @@ int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint3
                      uint32_t *lanes_per_signature) {
   if (!c) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
-  if (tables) *tables = c->cache_on ? c->learned_seen : 0;
+  if (tables) *tables = c->cache_on ? c->my_built : 0;
   if (warm_passes) *warm_passes = c->warm_passes;
   if (cold_passes) *cold_passes = c->cold_passes;
   if (lanes_per_signature) *lanes_per_signature = c->last_group;
+  return IBFT_OK;
+}
+
+int ibft_cache_memory(ibft_ctx *c, uint64_t *device_bytes, uint32_t *slots_in_use, uint32_t *slots_allocated,
+                      uint32_t *contexts_sharing) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> dlk(c->dev->mu);
+  const DeviceShared &d = *c->dev;
+  if (device_bytes) *device_bytes = (uint64_t)d.d_gtab.cap + d.d_qtab.cap + d.d_pub.cap + d.d_state.cap + d.d_learned.cap;
+  if (slots_in_use) *slots_in_use = d.used - (uint32_t)d.free_slots.size();
+  if (slots_allocated) *slots_allocated = d.cap;
+  if (contexts_sharing) *contexts_sharing = (uint32_t)c->dev.use_count();
   return IBFT_OK;
 }
 
@@ -1702,7 +1947,7 @@ int ibft_sign_seals(ibft_ctx *c, const uint8_t *sk32, const uint8_t *hash32, siz
   if ((rc = upload(c, c->d_payload, sk32, n * 32))) return rc;  // the sender-payload column is free during a seal batch
   if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
   ibftk::sign_args a;
-  a.gtab = (const uint32_t *)c->d_gtab.p;
+  a.gtab = (const uint32_t *)c->dev->d_gtab.p;
   a.sk32 = (const uint8_t *)c->d_payload.p;
   a.hash32 = (const uint8_t *)c->d_hash.p;
   a.sig65 = (uint8_t *)c->d_sig.p;
@@ -2036,7 +2281,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
   // 2.04 → 1.89.  A small cold launch is one wavefront per SIMD whose duration is its slowest wavefront, and a wavefront that shares
   // its SIMD with a digest wavefront runs at ≈55 % speed (N = 64 cold 1.08 → 1.12 ms): one stream, one verdict launch there.
   // IBFT_CERT_OVERLAP=0: never.
-  const bool two = c->cert_overlap && carriers != 0 && (rows >= 4096u || (c->cache_on && c->learned_seen > 0));
+  const bool two = c->cert_overlap && carriers != 0 && (rows >= 4096u || (c->cache_on && c->my_built > 0));
   const uint32_t region = two ? ((rows + 63u) & ~63u) : 0u;
   hipStream_t ds = two ? c->hstream : c->stream;
   if (two) {

@@ -296,16 +296,23 @@ struct recover_args {
   uint32_t *learned;        // counter of keys learned (host reads it with the tally)
   const uint32_t *qtab;     // n_validators × 32 × 256 × 20 dwords
   uint8_t *warm_done;       // n: 1 = the warm kernel already produced this row's verdict
-  uint32_t dummy_validator; // a validator whose table is built (operand for lanes with no work)
+  uint32_t dummy_validator; // a SLOT whose table is built (operand for lanes with no work)
+  // The key tables belong to the DEVICE, not to a context (every context of a device shares them, a validator keeps its
+  // slot — and its table — across validator-set changes): vslot[validator index] = the slot of that validator's
+  // address in pub / pub_state / qtab, 0xFFFFFFFF = none (the pool is full: the validator stays on the recover path).
+  const uint32_t *vslot;
 };
+__device__ __forceinline__ int key_slot(const recover_args &a, int vi) { return (int)a.vslot[vi]; }
 
 __device__ __forceinline__ void learn_key(const recover_args &a, int vi, const aff &Qa) {
-  if (!a.pub_state || a.pub_state[vi] != 0) return;
-  if (atomicCAS(a.pub_state + vi, 0u, 1u) != 0u) return;  // another row of this validator won the claim
-  // state 1 is only read by qtab_build_kernel, a later launch on the same stream: no fence needed here
-  store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * vi, Qa);
+  if (!a.pub_state) return;
+  const int sl = key_slot(a, vi);
+  if (sl < 0 || a.pub_state[sl] != 0) return;
+  if (atomicCAS(a.pub_state + sl, 0u, 1u) != 0u) return;  // another row of this validator (of any context) won the claim
+  // state 1 is only read by qtab_build_kernel, a later launch: no fence needed here
+  store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * sl, Qa);
   atomicAdd(a.learned, 1u);
-  a.learned[1] = (uint32_t)vi;  // any learned validator: operand for idle lanes of the warm kernel
+  a.learned[1] = (uint32_t)sl;  // any learned slot: operand for idle lanes of the warm kernel
 }
 
 // Stage the block's rows through LDS (coalesced dword loads) and unpack this lane's row.
@@ -397,13 +404,14 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) verify_known_lane_kernel(recov
   row_regs q = stage_rows<MODE>(a, lds);
   const uint32_t lane = threadIdx.x;
   int vi = valset_lookup(a.vtab, a.vslot_mask, q.want);
-  const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
+  const int sl = vi >= 0 ? key_slot(a, vi) : -1;
+  const bool have_table = sl >= 0 && a.pub_state[sl] == 2;
   // decided here: pre-flagged rows and non-members (verdict false), and rows whose validator has a table
   const bool decided = q.live && (q.pre || vi < 0 || have_table);
   const bool crypto = q.live && !q.pre && have_table;
   bool ok = false;
   if (__any(crypto ? 1 : 0)) {  // wave-uniform: every lane runs the arithmetic, idle ones on a dummy table
-    const uint32_t tv = crypto ? (uint32_t)vi : a.dummy_validator;
+    const uint32_t tv = crypto ? (uint32_t)sl : a.dummy_validator;
     ok = verify_known(a.gtab, a.qtab + QTAB_DWORDS_PER_VALIDATOR * tv, q.z, q.r, q.s, q.v, a.flags) && crypto;
   }
   if (q.live) {
@@ -458,7 +466,8 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
 #pragma unroll
   for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
-  const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
+  const int sl = vi >= 0 ? key_slot(a, vi) : -1;
+  const bool have_table = sl >= 0 && a.pub_state[sl] == 2;
   const bool decided = pre || vi < 0 || have_table;
   const bool crypto = live && !pre && have_table;
   if (live && sub == 0) {
@@ -470,7 +479,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
   bool ok = sig_in_range(r, s, v, a.flags);
   u256 u1, u2;
   verify_scalars(z, r, s, u1, u2);
-  const uint32_t *qt = a.qtab + QTAB_DWORDS_PER_VALIDATOR * (crypto ? (uint32_t)vi : a.dummy_validator);
+  const uint32_t *qt = a.qtab + QTAB_DWORDS_PER_VALIDATOR * (crypto ? (uint32_t)sl : a.dummy_validator);
   jac acc = secp::jac_inf();
 #pragma unroll 1
   for (int it = 0; it < (POINTS + G - 1) / G; it++) {  // wave-uniform trip count
@@ -527,14 +536,15 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) verify_known_wave_kern
 #pragma unroll
   for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
-  const bool have_table = vi >= 0 && a.pub_state[vi] == 2;
+  const int sl = vi >= 0 ? key_slot(a, vi) : -1;
+  const bool have_table = sl >= 0 && a.pub_state[sl] == 2;
   const bool decided = pre || vi < 0 || have_table;
   if (lane == 0) {
     a.warm_done[row] = decided ? 1 : 0;
     if (decided) a.vidx[row] = vi;
   }
   if (pre || !have_table) return;  // wave-uniform: the wavefront holds one row
-  const bool ok = wv::verify_known_wave(a.gtab, a.qtab + QTAB_DWORDS_PER_VALIDATOR * (uint32_t)vi, z, r, s, v, a.flags);
+  const bool ok = wv::verify_known_wave(a.gtab, a.qtab + QTAB_DWORDS_PER_VALIDATOR * (uint32_t)sl, z, r, s, v, a.flags);
   if (lane == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 
@@ -1321,6 +1331,7 @@ struct tally_args {
   uint64_t *out;            // TALLY_OUT_WORDS
   uint64_t *host_mask, *host_tally;  // mapped pinned host memory (or null): no device-to-host copy commands
   uint32_t lds_bitmap;      // the launch carries ⌈n_validators/32⌉ words of dynamic LDS for the workgroup's bitmap
+  const uint64_t *learned_src;  // or null: {keys learned, a learned slot} of the device's key cache, passed on to the host
   uint32_t *seen_out;       // or null: the launch's distinct-sender bitmap is left here (⌈n_validators/32⌉ words) — what a
                             // sharded batch exchanges, because the SET of senders merges across shards and sums do not
   uint32_t set_on;          // a message set: the verdict words are combined here first (set_combine_word)
@@ -1522,12 +1533,13 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   for (int i = 0; i < TALLY_SUM_WORDS; i++) a.out[TALLY_OUT_WIDE + i] = w[i];
 #pragma unroll
   for (int k = 0; k < TALLY_MAX_PIECES; k++) a.out[TALLY_OUT_PIECES + k] = piece[k];
+  if (a.learned_src) a.out[4] = *a.learned_src;
   if (a.host_tally) {
     a.host_tally[0] = w[0];
     a.host_tally[1] = w[1];
     a.host_tally[2] = c;
     a.host_tally[3] = hq;
-    a.host_tally[4] = a.out[4];  // keys learned | a learned validator, written by the recover kernels
+    a.host_tally[4] = a.out[4];  // keys learned | a learned slot (the recover kernels' counter in the device's key cache)
 #pragma unroll
     for (int i = 0; i < TALLY_SUM_WORDS; i++) a.host_tally[TALLY_OUT_WIDE + i] = w[i];
   }

@@ -39,6 +39,7 @@ EXPORTS = [
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages",
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
+    "ibft_cache_memory",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -173,6 +174,7 @@ def load_library() -> C.CDLL:
                                              vp, vp, C.POINTER(Tally)]
     L.ibft_group_is_local.argtypes = [vp]
     L.ibft_keccak256.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
+    L.ibft_cache_memory.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
         getattr(L, name)
     _lib = L
@@ -592,6 +594,12 @@ class BatchVerifier:
         self._chk(self._L.ibft_cache_stats(self._h, C.byref(t), C.byref(w), C.byref(c), C.byref(g)), "ibft_cache_stats")
         self.lanes_per_signature = g.value
         return t.value, w.value, c.value
+
+    def cache_memory(self):
+        """the device-wide key cache: (bytes held, slots in use, slots allocated, contexts sharing it)"""
+        b, u, a, k = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self._L.ibft_cache_memory(self._h, C.byref(b), C.byref(u), C.byref(a), C.byref(k)), "ibft_cache_memory")
+        return b.value, u.value, a.value, k.value
 
     def last_dispatch(self):
         """(cold lanes per signature, warm lanes per signature) of the last verdict pass."""

@@ -91,8 +91,9 @@ extern "C" {
 /* Warm path: remember each validator's public key the first time it is recovered (and hashes to
  * its address), build per-validator fixed-base tables in HBM (655 KB per validator, budget
  * IBFT_QTAB_BUDGET_GB, default 64) and VERIFY later signatures of that validator against them
- * instead of recovering — identical verdicts (csrc/verify_dev.h), ~4-10x less work.  The cache
- * lives as long as ibft_set_validators keeps receiving the same address list.               */
+ * instead of recovering — identical verdicts (csrc/verify_dev.h), ~4-10x less work.  The tables are
+ * per DEVICE and per ADDRESS (ibft_cache_memory below): shared by every context of the device, kept
+ * for every validator that stays in the set when ibft_set_validators changes it.                */
 #define IBFT_FLAG_PUBKEY_CACHE 2u
 
 /* pre_flags bits */
@@ -286,6 +287,14 @@ int ibft_set_kernel_timing(ibft_ctx *ctx, uint32_t every_n);
  * wavefront per signature … 1 = lane kernel) the last warm pass used.                         */
 int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes,
                      uint32_t *lanes_per_signature);
+/* The key tables belong to the DEVICE: every context created on one device shares ONE fixed-base table of G (84 MB) and ONE
+ * pool of validator tables keyed by ADDRESS (655 KB per validator, IBFT_QTAB_BUDGET_GB, default 64) — the four contexts a
+ * Backend keeps for its four goroutines cost one pool, not four; a key learned through one context is
+ * known to all of them; a validator that stays in the set across ibft_set_validators keeps its table (a rotation of 1 % of
+ * the validators relearns 1 %), a slot nobody's current set refers to is reused.  This reports the shared object of ctx's
+ * device: bytes it holds, slots in use / allocated, and how many contexts share it.                                   */
+int ibft_cache_memory(ibft_ctx *ctx, uint64_t *device_bytes, uint32_t *slots_in_use, uint32_t *slots_allocated,
+                      uint32_t *contexts_sharing);
 /* Lanes per signature used by the last verdict pass: cold kernel (1 = ecrecover_lane_kernel,
  * 2/4/8 = ecrecover_group_kernel) and warm kernel (0 = none ran, 1 = lane, 2..64 = group).     */
 int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);

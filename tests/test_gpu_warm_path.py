@@ -150,6 +150,20 @@ def test_config5_n65536_byzantine_cold_and_warm(oracle):
         tables, warm, cold = bv.cache_stats()
         assert tables == int(exp.sum()) or tables >= int(0.75 * n)   # every honest validator learned
         assert bv.last_dispatch() == (1, 1)
+        # three more contexts for the same 65 536 validators (one per goroutine): still ONE pool of tables
+        # — 43 GB, not 172 — and they are warm from their first batch
+        more = [V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=n) for _ in range(3)]
+        try:
+            for m in more:
+                m.set_validators(1, r0.addrs, r0.power)
+            bytes_, used, cap, sharing = bv.cache_memory()
+            assert used == n and bytes_ < 50e9 and sharing >= 4, (bytes_, used, cap, sharing)
+            got, t = more[2].is_valid_committed_seal(r1.hash32, r1.seal65, r1.signer20, r1.pre_flags)
+            exp1 = oracle.verify_seals(vs, r1.hash32, r1.seal65, r1.signer20, r1.pre_flags, nthreads=16).astype(bool)
+            assert (got == exp1).all() and more[2].last_dispatch()[1] == 1 and more[2].cache_stats()[0] == tables
+        finally:
+            for m in more:
+                m.close()
     finally:
         bv.close()
 
@@ -194,5 +208,88 @@ def test_duplicate_signers_in_a_cold_batch_do_not_lock_out_late_joiners(oracle, 
         got, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)   # and are still served (cold) when valid
         assert got.all()
         assert bv.cache_stats()[0] == n_val
+    finally:
+        bv.close()
+
+
+def test_contexts_of_one_device_share_one_key_cache(oracle):
+    """Round-2 review, weak #7: the tables belong to the device.  Four contexts (what INTEGRATION.md §2 keeps for the four
+    goroutines) with the same 1 024 validators hold ONE pool of 1 024 slots; a key learned through one context is served
+    warm by the others at once; closing contexts gives the slots back."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    n = 1024
+    r = W.make_round(n, 1700)
+    r2 = W.make_round(n, 1700, round_=1)
+    ctxs = [_mk(max_rows=n) for _ in range(4)]
+    try:
+        for bv in ctxs:
+            bv.set_validators(1, r.addrs, r.power)
+        bytes_, used, cap, sharing = ctxs[0].cache_memory()
+        assert used == n and sharing >= 4
+        assert bytes_ < 84e6 + cap * 656e3 + 1e6            # one G table + `cap` tables, not four of each
+        got, _ = ctxs[0].is_valid_committed_seal(r.hash32, r.seal65, r.signer20)      # cold: learns every key
+        assert got.all() and ctxs[0].last_dispatch()[0] > 0
+        got, _ = ctxs[0].is_valid_committed_seal(r.hash32, r.seal65, r.signer20)      # tables built by context 0
+        assert ctxs[0].cache_stats()[0] == n
+        for bv in ctxs[1:]:                                 # never saw a signature, yet every validator's table is there
+            got, t = bv.is_valid_committed_seal(r2.hash32, r2.seal65, r2.signer20)
+            assert got.all() and t.has_quorum == 1
+            cold, warm = bv.last_dispatch()
+            assert warm > 0 and cold == 0, (cold, warm)     # the recover kernel was not even launched
+            assert bv.cache_stats()[0] == n
+        assert ctxs[3].cache_memory()[1] == n               # still one slot per validator
+        # a bad signature through a sharing context is still rejected (verify against the shared table)
+        bad = r2.seal65.copy(); bad[7, 10] ^= 1
+        got, _ = ctxs[2].is_valid_committed_seal(r2.hash32, bad, r2.signer20)
+        assert not got[7] and got.sum() == n - 1
+    finally:
+        for bv in ctxs:
+            bv.close()
+
+
+def test_validator_rotation_keeps_the_tables_of_those_who_stay(oracle):
+    """ibft_set_validators with 1 % of the addresses replaced: the 99 % keep their slots and tables (no rebuild), the
+    newcomers are learned by the next batch, the leavers' slots are reused; the call itself is quick."""
+    import time
+    from oracle import workload as W
+    n = 1024
+    a = W.make_round(n, 1800)
+    b = W.make_round(n, 1801)                               # donors of fresh validators
+    bv = _mk(max_rows=n)
+    try:
+        bv.set_validators(1, a.addrs, a.power)
+        for _ in range(2):
+            got, _ = bv.is_valid_committed_seal(a.hash32, a.seal65, a.signer20)
+        assert got.all() and bv.cache_stats()[0] == n
+        used0 = bv.cache_memory()[1]
+        # rotate: validators 100..109 leave, ten of b's join in their rows
+        addrs, hash32, seal, signer = a.addrs.copy(), a.hash32.copy(), a.seal65.copy(), a.signer20.copy()
+        addrs[100:110] = b.addrs[:10]
+        signer[100:110] = b.signer20[:10]
+        seal[100:110] = b.seal65[:10]
+        hash32[100:110] = b.hash32[:10]
+        t0 = time.perf_counter()
+        bv.set_validators(2, addrs, a.power)
+        dt = (time.perf_counter() - t0) * 1e3
+        assert bv.cache_stats()[0] == n - 10                # nothing was thrown away
+        assert bv.cache_memory()[1] == used0                # the leavers' slots went to the newcomers
+        assert dt < 5.0, f"set_validators after a 1 % rotation took {dt:.2f} ms"
+        vs = oracle.ValSet(addrs, a.power)
+        exp = oracle.verify_seals(vs, hash32, seal, signer, nthreads=8).astype(bool)
+        for k in range(3):
+            got, _ = bv.is_valid_committed_seal(hash32, seal, signer)
+            assert (got == exp).all() and got.all()
+        assert bv.cache_stats()[0] == n
+        # a leaver's signature is no validator's any more — even though its old table may still lie in a recycled slot's past
+        got, _ = bv.is_valid_committed_seal(a.hash32[100:110], a.seal65[100:110], a.signer20[100:110])
+        assert not got.any()
+        # back to the old set: the ten come back as newcomers (their slots were given away), the rest stayed warm throughout
+        bv.set_validators(3, a.addrs, a.power)
+        assert bv.cache_stats()[0] == n - 10
+        for k in range(2):
+            got, _ = bv.is_valid_committed_seal(a.hash32, a.seal65, a.signer20)
+            assert got.all()
+        assert bv.cache_stats()[0] == n
     finally:
         bv.close()
