@@ -1408,7 +1408,9 @@ static int key_cache_map(ibft_ctx *c, const std::vector<KeyAddr> &vaddr) {
   HIPCHK(c, hipMemcpyAsync(c->d_vslot.p, ns.data(), nv * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->vslot.swap(ns);
-  c->seen_build_epoch = 0;  // recount at the next launch
+  c->cache_on = true;
+  c->seen_build_epoch = 0;
+  recount_built(c);  // how many of THIS set's validators have a table already (all who stayed, any another context learned)
   return IBFT_OK;
 }
 
