@@ -455,11 +455,13 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_slot) {
   if (!c->cache_on) return IBFT_OK;
   DeviceShared &d = *c->dev;
   std::lock_guard<std::mutex> lk(d.mu);
-  if (learned_total == d.learned_seen) {
+  if ((int32_t)(learned_total - d.learned_seen) <= 0) {  // (another context's pass may already have covered a newer count)
     recount_built(c);
     return IBFT_OK;
   }
   const uint32_t ns = d.used;
+  hipLaunchKernelGGL(ibftk::qtab_claim_kernel, dim3((ns + 255) / 256), dim3(256), 0, c->stream, (uint32_t *)d.d_state.p, ns);
+  HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(ibftk::qtab_build_kernel, dim3(((ns + 63) / 64) * ibftk::QTAB_WINDOWS), dim3(64), 0, c->stream,
                      (const uint32_t *)d.d_pub.p, (const uint32_t *)d.d_state.p, (uint32_t *)d.d_qtab.p, ns);
   HIPCHK(c, hipGetLastError());
@@ -469,7 +471,7 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_slot) {
   std::vector<uint32_t> st(ns);
   HIPCHK(c, hipMemcpyAsync(st.data(), d.d_state.p, (size_t)ns * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (uint32_t i = 0; i < ns; i++) d.built[i] = st[i] == 2;
+  for (uint32_t i = 0; i < ns; i++) d.built[i] = st[i] == ibftk::KEY_BUILT;
   d.learned_seen = learned_total;
   if (any_slot < ns && d.built[any_slot]) d.dummy_slot = any_slot;
   d.build_epoch++;

@@ -303,14 +303,19 @@ struct recover_args {
   const uint32_t *vslot;
 };
 __device__ __forceinline__ int key_slot(const recover_args &a, int vi) { return (int)a.vslot[vi]; }
+// states of a key-cache slot.  0 → WRITING (claimed by one row's compare-and-swap) → KNOWN (the key is in `pub`) → BUILDING
+// (claimed by one build pass: keys that become KNOWN while the pass runs wait for the next one) → BUILT (the table is complete)
+constexpr uint32_t KEY_UNKNOWN = 0, KEY_KNOWN = 1, KEY_BUILT = 2, KEY_WRITING = 3, KEY_BUILDING = 5;
 
 __device__ __forceinline__ void learn_key(const recover_args &a, int vi, const aff &Qa) {
   if (!a.pub_state) return;
   const int sl = key_slot(a, vi);
-  if (sl < 0 || a.pub_state[sl] != 0) return;
-  if (atomicCAS(a.pub_state + sl, 0u, 1u) != 0u) return;  // another row of this validator (of any context) won the claim
-  // state 1 is only read by qtab_build_kernel, a later launch: no fence needed here
+  if (sl < 0 || a.pub_state[sl] != KEY_UNKNOWN) return;
+  if (atomicCAS(a.pub_state + sl, KEY_UNKNOWN, KEY_WRITING) != KEY_UNKNOWN) return;  // another row of this validator won the claim
+  // The tables are shared by every context of the device, so a build pass of ANOTHER context (another stream) may scan the
+  // states while this kernel runs: the key is published (state KEY_KNOWN, release) only after it has been written.
   store_affine(a.pub + (size_t)GTAB_ENTRY_DWORDS * sl, Qa);
+  __hip_atomic_store(a.pub_state + sl, KEY_KNOWN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   atomicAdd(a.learned, 1u);
   a.learned[1] = (uint32_t)sl;  // any learned slot: operand for idle lanes of the warm kernel
 }
@@ -405,7 +410,7 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) verify_known_lane_kernel(recov
   const uint32_t lane = threadIdx.x;
   int vi = valset_lookup(a.vtab, a.vslot_mask, q.want);
   const int sl = vi >= 0 ? key_slot(a, vi) : -1;
-  const bool have_table = sl >= 0 && a.pub_state[sl] == 2;
+  const bool have_table = sl >= 0 && a.pub_state[sl] == KEY_BUILT;
   // decided here: pre-flagged rows and non-members (verdict false), and rows whose validator has a table
   const bool decided = q.live && (q.pre || vi < 0 || have_table);
   const bool crypto = q.live && !q.pre && have_table;
@@ -467,7 +472,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
   for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
   const int sl = vi >= 0 ? key_slot(a, vi) : -1;
-  const bool have_table = sl >= 0 && a.pub_state[sl] == 2;
+  const bool have_table = sl >= 0 && a.pub_state[sl] == KEY_BUILT;
   const bool decided = pre || vi < 0 || have_table;
   const bool crypto = live && !pre && have_table;
   if (live && sub == 0) {
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) verify_known_wave_kern
   for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
   const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
   const int sl = vi >= 0 ? key_slot(a, vi) : -1;
-  const bool have_table = sl >= 0 && a.pub_state[sl] == 2;
+  const bool have_table = sl >= 0 && a.pub_state[sl] == KEY_BUILT;
   const bool decided = pre || vi < 0 || have_table;
   if (lane == 0) {
     a.warm_done[row] = decided ? 1 : 0;
@@ -789,11 +794,19 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) IBFT_ROWS_WAVES_PER_EU
 // ---- warm path table build -------------------------------------------------------------------
 // Lane ↔ (validator, window): a wavefront holds ONE window index for 64 consecutive validators so
 // that the doubling loop's trip count is wave-uniform.
+// A build pass is three launches on one stream: claim (KNOWN → BUILDING: the set of slots this pass builds is fixed here,
+// whatever other contexts learn meanwhile), build, commit (BUILDING → BUILT).  Passes are serialised by the host (the
+// device's mutex).
+__global__ void qtab_claim_kernel(uint32_t *__restrict__ pub_state, uint32_t n_slots) {
+  uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n_slots && __hip_atomic_load(pub_state + v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == KEY_KNOWN)
+    pub_state[v] = KEY_BUILDING;  // (the acquire pairs with learn_key's release: `pub` of this slot is complete)
+}
 __global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restrict__ pub, const uint32_t *__restrict__ pub_state,
                                                         uint32_t *__restrict__ qtab, uint32_t n_validators) {
   const uint32_t w = blockIdx.x % QTAB_WINDOWS;
   const uint32_t v = (blockIdx.x / QTAB_WINDOWS) * 64 + threadIdx.x;
-  const bool work = v < n_validators && pub_state[v] == 1;
+  const bool work = v < n_validators && pub_state[v] == KEY_BUILDING;
   if (!__any(work ? 1 : 0)) return;
   aff Q = work ? load_affine(pub + (size_t)GTAB_ENTRY_DWORDS * v) : secp::generator();
   uint32_t *out = qtab + QTAB_DWORDS_PER_VALIDATOR * (work ? v : 0u) + (size_t)GTAB_ENTRY_DWORDS * QTAB_ENTRIES * w;
@@ -801,7 +814,7 @@ __global__ void __launch_bounds__(64) qtab_build_kernel(const uint32_t *__restri
 }
 __global__ void qtab_commit_kernel(uint32_t *__restrict__ pub_state, uint32_t n_validators) {
   uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n_validators && pub_state[v] == 1) pub_state[v] = 2;
+  if (v < n_validators && pub_state[v] == KEY_BUILDING) pub_state[v] = KEY_BUILT;
 }
 
 // ---- §8f rank 3: IbftMessage wire bytes → verifier columns (wire_dev.h) -----------------------------

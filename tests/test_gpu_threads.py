@@ -122,3 +122,50 @@ def test_export_on_a_consumer_stream():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", _EXPORT_ON_SCRIPT, root], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "EXPORT_ON_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_concurrent_contexts_share_the_key_cache(oracle):
+    """The key tables are per device (round 3): six threads, six contexts with the key cache — four on ONE validator set,
+    two on others — learn, build and verify at the same time.  A key published by one context's kernel while another
+    context's build pass scans the slots must never yield a half-written table: every verdict of every pass equals the
+    oracle's, and in the end every context counts a table for each of its honest validators."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    shared = [W.make_round(600, 2100, round_=k, byzantine=True, weighted=True) for k in range(3)]   # same keys, new seals
+    others = [W.make_round(350 + 50 * i, 2200 + i, byzantine=True) for i in range(2)]
+    vs = oracle.ValSet(shared[0].addrs, shared[0].power)
+    exp_shared = [oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=4).astype(bool) for r in shared]
+    exp_others = [oracle.verify_seals(oracle.ValSet(r.addrs, r.power), r.hash32, r.seal65, r.signer20, r.pre_flags,
+                                      nthreads=4).astype(bool) for r in others]
+    errors, tables = [], {}
+    start = threading.Barrier(6)
+
+    def worker(i):
+        try:
+            bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=1024)
+            if i < 4:
+                bv.set_validators(1, shared[0].addrs, shared[0].power)
+            else:
+                bv.set_validators(1, others[i - 4].addrs, others[i - 4].power)
+            start.wait()
+            for it in range(15):
+                if i < 4:
+                    r, exp = shared[(it + i) % 3], exp_shared[(it + i) % 3]
+                else:
+                    r, exp = others[i - 4], exp_others[i - 4]
+                got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+                if not (got == exp).all():
+                    errors.append((i, it, "verdict mismatch", np.flatnonzero(got != exp)[:6].tolist()))
+            tables[i] = bv.cache_stats()[0]
+            bv.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    honest = int(np.logical_or.reduce(exp_shared).sum())           # validators with at least one valid seal in some round
+    assert all(tables[i] == honest for i in range(4)), (tables, honest)
