@@ -41,27 +41,60 @@ type certHashKey struct {
 	carrier  *proto.IbftMessage // the message whose proposal hash is compared with keccak(proposal)
 }
 
-// certTable holds arrival-time verdicts about nested messages.  Keys are the decoded objects, which the stored carrier
-// message keeps alive — an address cannot be reused while its verdict is remembered.  Dropped when the validator set
-// changes (RoundStarts of a new height) together with the store's PruneByHeight.
+// A verdict is only as good as the validator set it was computed against: judgedAt is the height the state (and therefore
+// the validator table on the device) was at when the carrying message arrived.  A lookup at another height ignores the
+// entry and asks the backend, exactly as the reference would (ADVICE r2: a verdict of height H must not answer at H+1).
+type certVerdict struct {
+	ok       bool
+	judgedAt uint64
+}
+
+// certRoot remembers which keys one stored carrier contributed, so that pruning costs O(pruned).
+type certRoot struct {
+	senders []*proto.IbftMessage
+	hashes  []certHashKey
+}
+
+// certTable holds arrival-time verdicts about nested messages.  Keys are the decoded objects of STORED carriers (a tree is
+// noted only after addVerifiedMessage accepted its carrier); entries are filed per height and dropped when the state moves
+// past it — AddWireMessages prunes on entry, so the tables never outlive the store's PruneByHeight by more than one batch.
 type certTable struct {
-	mu     sync.Mutex
-	sender map[*proto.IbftMessage]bool
-	hash   map[certHashKey]bool
+	mu       sync.Mutex
+	sender   map[*proto.IbftMessage]certVerdict
+	hash     map[certHashKey]certVerdict
+	byHeight map[uint64][]*certRoot
 }
 
 var certTables sync.Map // *IBFT → *certTable  (a field of IBFT in a real merge)
 
 func (i *IBFT) certificates() *certTable {
-	t, _ := certTables.LoadOrStore(i, &certTable{sender: map[*proto.IbftMessage]bool{}, hash: map[certHashKey]bool{}})
+	t, _ := certTables.LoadOrStore(i, &certTable{
+		sender:   map[*proto.IbftMessage]certVerdict{},
+		hash:     map[certHashKey]certVerdict{},
+		byHeight: map[uint64][]*certRoot{},
+	})
 	return t.(*certTable)
 }
 
-// dropCertificateVerdicts: call where the validator set may change (moveToNewRound of a new height, after PruneByHeight).
-func (i *IBFT) dropCertificateVerdicts() {
+// dropCertificateVerdicts forgets everything judged below `height` (the state's current height): called at the top of
+// AddWireMessages, i.e. at most one batch after RunSequence's PruneByHeight (core/ibft.go:317).  O(entries dropped).
+func (i *IBFT) dropCertificateVerdicts(height uint64) {
 	t := i.certificates()
 	t.mu.Lock()
-	t.sender, t.hash = map[*proto.IbftMessage]bool{}, map[certHashKey]bool{}
+	for h, roots := range t.byHeight {
+		if h >= height {
+			continue
+		}
+		for _, r := range roots {
+			for _, k := range r.senders {
+				delete(t.sender, k)
+			}
+			for _, k := range r.hashes {
+				delete(t.hash, k)
+			}
+		}
+		delete(t.byHeight, h)
+	}
 	t.mu.Unlock()
 }
 
@@ -111,15 +144,21 @@ func (i *IBFT) addWireCertificates(cv CertificateVerifier, raw [][]byte) (rest [
 		return append(rest, carrierRaw...)
 	}
 	t := i.certificates()
+	judgedAt := i.state.getHeight()
 	for k, msg := range carriers {
-		t.mu.Lock()
-		i.noteCertificateTree(t, nodes, class, sender, hash, self, k, msg)
-		t.mu.Unlock()
 		switch {
 		case class[k] != 0:
 			rest = append(rest, carrierRaw[k]) // not canonical here, or too long to hash on the device: stock route
 		case ibftgpu.Bit(sender, k):
-			i.addVerifiedMessage(msg)
+			// the tree is worth remembering only for a carrier that was actually stored (ADVICE r2): a forged envelope, a
+			// stale view leave nothing behind
+			if i.addVerifiedMessage(msg) {
+				root := &certRoot{}
+				t.mu.Lock()
+				i.noteCertificateTree(t, root, judgedAt, nodes, class, sender, hash, self, k, msg)
+				t.byHeight[judgedAt] = append(t.byHeight[judgedAt], root)
+				t.mu.Unlock()
+			}
 		}
 	}
 	return rest
@@ -128,10 +167,12 @@ func (i *IBFT) addWireCertificates(cv CertificateVerifier, raw [][]byte) (rest [
 // noteCertificateTree files the verdicts of row `row` (= msg) and of everything below it, matching rows to decoded
 // messages by position.  A subtree whose row count differs from the decoded count (the device refused the wrapper as
 // non-canonical) is left to the stock route.  Caller holds t.mu.
-func (i *IBFT) noteCertificateTree(t *certTable, nodes []ibftgpu.CertNode, class []byte, sender, hash, self []uint64, row int, msg *proto.IbftMessage) {
+func (i *IBFT) noteCertificateTree(t *certTable, root *certRoot, judgedAt uint64, nodes []ibftgpu.CertNode, class []byte, sender, hash, self []uint64, row int, msg *proto.IbftMessage) {
 	undecided := ibftgpu.CertClassNeedsHost | ibftgpu.CertClassProposalHost
 	if own := messages.ExtractProposal(msg); own != nil && class[row]&undecided == 0 {
-		t.hash[certHashKey{own, msg}] = ibftgpu.Bit(self, row) // validateProposalCommon's IsValidProposalHash
+		key := certHashKey{own, msg}
+		t.hash[key] = certVerdict{ibftgpu.Bit(self, row), judgedAt} // validateProposalCommon's IsValidProposalHash
+		root.hashes = append(root.hashes, key)
 	}
 	kids := nestedMessages(msg)
 	nd := nodes[row]
@@ -145,12 +186,15 @@ func (i *IBFT) noteCertificateTree(t *certTable, nodes []ibftgpu.CertNode, class
 			continue
 		}
 		if class[c] == 0 {
-			t.sender[child] = ibftgpu.Bit(sender, c)
+			t.sender[child] = certVerdict{ibftgpu.Bit(sender, c), judgedAt}
+			root.senders = append(root.senders, child)
 		}
 		if last != nil && class[row]&undecided == 0 && class[c]&ibftgpu.CertClassNeedsHost == 0 {
-			t.hash[certHashKey{last, child}] = ibftgpu.Bit(hash, c) // proposalMatchesCertificate
+			key := certHashKey{last, child}
+			t.hash[key] = certVerdict{ibftgpu.Bit(hash, c), judgedAt} // proposalMatchesCertificate
+			root.hashes = append(root.hashes, key)
 		}
-		i.noteCertificateTree(t, nodes, class, sender, hash, self, c, child)
+		i.noteCertificateTree(t, root, judgedAt, nodes, class, sender, hash, self, c, child)
 	}
 }
 
@@ -160,8 +204,8 @@ func (i *IBFT) isValidValidatorTabled(m *proto.IbftMessage) bool {
 	t.mu.Lock()
 	v, known := t.sender[m]
 	t.mu.Unlock()
-	if known {
-		return v
+	if known && v.judgedAt == i.state.getHeight() { // judged against the validator set that is in force now
+		return v.ok
 	}
 	return i.backend.IsValidValidator(m)
 }
@@ -174,8 +218,8 @@ func (i *IBFT) isValidProposalHashTabled(proposal *proto.Proposal, carrier *prot
 		t.mu.Lock()
 		v, known := t.hash[certHashKey{proposal, carrier}]
 		t.mu.Unlock()
-		if known {
-			return v
+		if known { // (a hash comparison does not depend on the validator set: valid at any height)
+			return v.ok
 		}
 	}
 	return i.backend.IsValidProposalHash(proposal, hash)

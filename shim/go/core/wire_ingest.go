@@ -40,6 +40,7 @@ func (i *IBFT) AddWireMessages(raw [][]byte) {
 		return
 	}
 	if cv, hasCerts := i.backend.(CertificateVerifier); hasCerts {
+		i.dropCertificateVerdicts(i.state.getHeight()) // what was judged at earlier heights goes with the store's prune
 		// PREPREPARE / ROUND_CHANGE messages first: their own envelope and every message nested in them, one call
 		if raw = i.addWireCertificates(cv, raw); len(raw) == 0 {
 			return
@@ -117,9 +118,9 @@ func (i *IBFT) addWireSets(ws WireSetVerifier, raw [][]byte) bool {
 // addVerifiedMessage is AddMessage (core/ibft.go:1101-1123) for a message whose sender the device has already
 // vouched for: isAcceptableMessage (core/ibft.go:1126-1149) minus its first check, then the same store +
 // quorum probe + signal.
-func (i *IBFT) addVerifiedMessage(message *proto.IbftMessage) {
+func (i *IBFT) addVerifiedMessage(message *proto.IbftMessage) (stored bool) {
 	if message == nil || !i.isAcceptableView(message) {
-		return
+		return false
 	}
 	i.messages.AddMessage(message)
 	if message.View.Height == i.state.getHeight() {
@@ -131,6 +132,7 @@ func (i *IBFT) addVerifiedMessage(message *proto.IbftMessage) {
 			i.messages.SignalEvent(message.Type, message.View)
 		}
 	}
+	return true
 }
 
 // isAcceptableView is the part of isAcceptableMessage (core/ibft.go:1132-1148) that follows the sender check.
