@@ -212,10 +212,10 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
 // messages of a PREPREPARE payload; proposalMessage, then prepareMessages, of a ROUND_CHANGE payload's PreparedCertificate
 static void nested_messages(const IbftMessage &m, std::vector<MsgPtr> &out) {
   out.clear();
-  if (m.kind == PayloadKind::PREPREPARE && m.preprepare.certificate) {
-    out = m.preprepare.certificate->round_change_messages;
-  } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change.latest_prepared_certificate) {
-    const PreparedCertificate &pc = *m.round_change.latest_prepared_certificate;
+  if (m.kind == PayloadKind::PREPREPARE && m.preprepare().certificate) {
+    out = m.preprepare().certificate->round_change_messages;
+  } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().latest_prepared_certificate) {
+    const PreparedCertificate &pc = *m.round_change().latest_prepared_certificate;
     if (pc.proposal_message) out.push_back(pc.proposal_message);
     out.insert(out.end(), pc.prepare_messages.begin(), pc.prepare_messages.end());
   }
@@ -223,7 +223,7 @@ static void nested_messages(const IbftMessage &m, std::vector<MsgPtr> &out) {
 // the proposal hash a message carries, by payload kind (what the device reports in ibft_wire_row_t.proposal_hash)
 static const bytes *carried_hash(const IbftMessage &m) {
   switch (m.kind) {
-    case PayloadKind::PREPREPARE: return &m.preprepare.proposal_hash;
+    case PayloadKind::PREPREPARE: return &m.preprepare().proposal_hash;
     case PayloadKind::PREPARE: return &m.prepare.proposal_hash;
     case PayloadKind::COMMIT: return &m.commit.proposal_hash;
     default: return nullptr;
@@ -343,7 +343,7 @@ bool LoopBatch::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off,
         c.ordinal = (uint32_t)k;
         c.level = (uint8_t)(out.nodes[r].level + 1);
         c.role = (uint8_t)(!pc ? IBFT_CERT_ROLE_RCC_MESSAGE
-                               : (k == 0 && items[r].m->round_change.latest_prepared_certificate->proposal_message
+                               : (k == 0 && items[r].m->round_change().latest_prepared_certificate->proposal_message
                                       ? IBFT_CERT_ROLE_PC_PROPOSAL
                                       : IBFT_CERT_ROLE_PC_PREPARE));
         out.nodes.push_back(c);
@@ -369,10 +369,10 @@ bool LoopBatch::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off,
     out.sender[r] = v_->IsValidValidator(m);
     const bytes *h = carried_hash(m);
     const IbftMessage *p = items[r].parent;
-    if (h && p && p->kind == PayloadKind::ROUND_CHANGE && p->round_change.last_prepared_proposal)
-      out.hash[r] = v_->IsValidProposalHash(&*p->round_change.last_prepared_proposal, h);
-    if (m.kind == PayloadKind::PREPREPARE && m.preprepare.proposal)
-      out.self[r] = v_->IsValidProposalHash(&*m.preprepare.proposal, &m.preprepare.proposal_hash);
+    if (h && p && p->kind == PayloadKind::ROUND_CHANGE && p->round_change().last_prepared_proposal)
+      out.hash[r] = v_->IsValidProposalHash(&*p->round_change().last_prepared_proposal, h);
+    if (m.kind == PayloadKind::PREPREPARE && m.preprepare().proposal)
+      out.self[r] = v_->IsValidProposalHash(&*m.preprepare().proposal, &m.preprepare().proposal_hash);
   }
   return true;
 }
@@ -439,6 +439,26 @@ bool HotPath::hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type)
     case COMMIT: return validatorManager.HasQuorumOf(msgs);
     default: return false;
   }
+}
+
+// hasQuorumByMsgType for the messages a GetValidMessages walk just returned: they are ALL the stored messages of the view
+// (the walk pruned the rest), one per sender — so with the quorum index on, Σ power of the view is already known (the
+// store's hooks kept it through the prunes) and no sender set has to be rebuilt.
+bool HotPath::hasQuorumOfStoredView(const View &view, uint32_t type, const std::vector<MsgPtr> &msgs) {
+  if (!index_enabled_ || !validatorManager.initialized()) return hasQuorumByMsgType(msgs, type);
+  auto rebuild = [&]() {
+    std::vector<bytes> senders;
+    for (auto &x : msgs) senders.push_back(x->from);
+    return senders;
+  };
+  auto pc = quorumIndex.Get(type, view.height, view.round, rebuild, validatorManager);
+  if (pc.second != msgs.size()) return hasQuorumByMsgType(msgs, type);  // (cannot happen; the walk is the authority)
+  if (type == PREPARE) {
+    if (!proposalMessage) return false;
+    if (messages.Has(view, PREPARE, proposalMessage->from)) return false;  // proposer among PREPARE signers (:117-121)
+    return pc.first + validatorManager.powerOf(proposalMessage->from) >= validatorManager.quorum();
+  }
+  return pc.first >= validatorManager.quorum();
 }
 
 int HotPath::AddMessage(MsgPtr m, bool accepted) {
@@ -945,7 +965,7 @@ bool HotPath::handlePrepare(const View &view) {
       return verifier->IsValidProposalHash(proposal, extract_prepare_hash(m));
     });
   }
-  if (!hasQuorumByMsgType(prepareMessages, PREPARE)) return false;
+  if (!hasQuorumOfStoredView(view, PREPARE, prepareMessages)) return false;
   // sendCommitMessage(view) is the Go side's business; finalizePrepare: state.go
   preparedMessages = prepareMessages;
   stateName = StateName::commit;
@@ -967,7 +987,7 @@ bool HotPath::handleCommit(const View &view) {
       return verifier->IsValidCommittedSeal(proposalHash, seal ? &*seal : nullptr);
     });
   }
-  if (!hasQuorumByMsgType(commitMessages, COMMIT)) return false;
+  if (!hasQuorumOfStoredView(view, COMMIT, commitMessages)) return false;
   std::vector<std::optional<CommittedSeal>> seals;
   if (!extract_committed_seals(commitMessages, seals)) return false;  // safe check, ibft.go:952-958
   committedSeals = std::move(seals);

@@ -174,6 +174,7 @@ class HotPath {
   // the per-message verifier (the stock path)
   bool isAcceptableMessage(const IbftMessage &m, const bool *sender_ok = nullptr);
   bool hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type);
+  bool hasQuorumOfStoredView(const View &view, uint32_t type, const std::vector<MsgPtr> &msgs);
   bool handlePrepare(const View &view);
   bool handleCommit(const View &view);
   // handlePrePrepare (core/ibft.go:792-813): the first stored PREPREPARE of the view that validateProposal0 (round 0) /

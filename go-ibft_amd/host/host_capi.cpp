@@ -348,10 +348,10 @@ int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *of
     }
     for (size_t k = 0; k < all.size(); k++) {  // breadth first, like the device
       const IbftMessage &m = *all[k];
-      if (m.kind == PayloadKind::PREPREPARE && m.preprepare.certificate) {
-        for (auto &c : m.preprepare.certificate->round_change_messages) all.push_back(c);
-      } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change.latest_prepared_certificate) {
-        const PreparedCertificate &pc = *m.round_change.latest_prepared_certificate;
+      if (m.kind == PayloadKind::PREPREPARE && m.preprepare().certificate) {
+        for (auto &c : m.preprepare().certificate->round_change_messages) all.push_back(c);
+      } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().latest_prepared_certificate) {
+        const PreparedCertificate &pc = *m.round_change().latest_prepared_certificate;
         if (pc.proposal_message) all.push_back(pc.proposal_message);
         for (auto &c : pc.prepare_messages) all.push_back(c);
       }

@@ -19,12 +19,9 @@ void Messages::AddMessage(MsgPtr m) {
     lv.round = r;
   }
   protoMessages &view_msgs = *lv.msgs;
-  auto it = view_msgs.lower_bound(m->from);  // one descent for the lookup and the insert
-  if (it == view_msgs.end() || it->first != m->from) {
-    auto ins = view_msgs.emplace_hint(it, m->from, std::move(m));
-    if (sender_hook_) sender_hook_((uint32_t)s, h, r, ins->first, +1);
-  } else {
-    it->second = std::move(m);  // last writer wins, sender set unchanged
+  const IbftMessage *raw = m.get();
+  if (view_msgs.put(std::move(m))) {  // a new sender (otherwise: last writer wins, sender set unchanged)
+    if (sender_hook_) sender_hook_((uint32_t)s, h, r, raw->from, +1);
   }
 }
 
@@ -35,7 +32,7 @@ bool Messages::Has(const View &view, MessageType type, const bytes &from) {
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return false;
   auto r = h->second.find(view.round);
-  return r != h->second.end() && r->second.count(from) != 0;
+  return r != h->second.end() && r->second.contains(from);
 }
 
 size_t Messages::numMessages(const View &view, MessageType type) {
@@ -67,15 +64,15 @@ std::vector<MsgPtr> Messages::GetValidMessages(const View &view, MessageType typ
   if (h == maps_[s].end()) return valid;
   auto r = h->second.find(view.round);
   if (r == h->second.end()) return valid;
-  for (auto it = r->second.begin(); it != r->second.end();) {
-    if (!isValid(*it->second)) {
-      if (sender_hook_) sender_hook_((uint32_t)s, view.height, view.round, it->first, -1);
-      it = r->second.erase(it);  // prune out invalid messages, messages.go:193-196
-    } else {
-      valid.push_back(it->second);
-      ++it;
+  valid.reserve(r->second.size());
+  r->second.filter([&](const MsgPtr &m) {
+    if (!isValid(*m)) {
+      if (sender_hook_) sender_hook_((uint32_t)s, view.height, view.round, m->from, -1);
+      return false;  // prune out invalid messages, messages.go:193-196
     }
-  }
+    valid.push_back(m);
+    return true;
+  });
   return valid;
 }
 
@@ -91,19 +88,22 @@ std::vector<MsgPtr> Messages::GetValidMessagesBatch(const View &view, MessageTyp
   if (r == h->second.end()) return valid;
   std::vector<MsgPtr> all;
   all.reserve(r->second.size());
-  for (auto &kv : r->second) all.push_back(kv.second);
+  r->second.for_each([&](const MsgPtr &m) { all.push_back(m); });
   std::vector<uint8_t> v = verdicts(all);
   if (v.size() != all.size()) return valid;  // backend failure: nothing pruned, nothing returned
+  bool any_bad = false;
+  for (uint8_t x : v) any_bad = any_bad || !x;
+  if (!any_bad) return all;  // (the usual case: every stored message survives)
   size_t i = 0;
-  for (auto it = r->second.begin(); it != r->second.end(); ++i) {
-    if (!v[i]) {
-      if (sender_hook_) sender_hook_((uint32_t)s, view.height, view.round, it->first, -1);
-      it = r->second.erase(it);
+  r->second.filter([&](const MsgPtr &m) {
+    const bool ok = v[i++] != 0;
+    if (!ok) {
+      if (sender_hook_) sender_hook_((uint32_t)s, view.height, view.round, m->from, -1);
     } else {
-      valid.push_back(it->second);
-      ++it;
+      valid.push_back(m);
     }
-  }
+    return ok;
+  });
   return valid;
 }
 
@@ -118,7 +118,7 @@ std::vector<MsgPtr> Messages::GetExtendedRCC(
   if (prepass) {
     std::vector<MsgPtr> all;
     for (auto &rm : h->second)
-      for (auto &kv : rm.second) all.push_back(kv.second);
+      rm.second.for_each([&](const MsgPtr &m) { all.push_back(m); });
     prepass(all);
   }
   uint64_t highest = 0;
@@ -126,8 +126,9 @@ std::vector<MsgPtr> Messages::GetExtendedRCC(
     const uint64_t round = rm.first;
     if (round <= highest) continue;  // messages.go:222-224 (so round 0 is never considered)
     std::vector<MsgPtr> valid;
-    for (auto &kv : rm.second)
-      if (isValidMessage(*kv.second)) valid.push_back(kv.second);
+    rm.second.for_each([&](const MsgPtr &m) {
+      if (isValidMessage(*m)) valid.push_back(m);
+    });
     if (!isValidRCC(round, valid)) continue;
     highest = round;
     extended = std::move(valid);
@@ -150,7 +151,7 @@ std::vector<MsgPtr> Messages::GetMostRoundChangeMessages(uint64_t minRound, uint
     }
   }
   if (best == 0) return out;  // "no messages found" — also when the best round IS 0, messages.go:273-276
-  for (auto &kv : h->second[best]) out.push_back(kv.second);
+  h->second[best].for_each([&](const MsgPtr &m) { out.push_back(m); });
   return out;
 }
 

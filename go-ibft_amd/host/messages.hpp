@@ -8,8 +8,9 @@
 // /root/reference/core/validator_manager.go:50-155.
 //
 // Iteration order: Go map iteration is random, so callers may only rely on the SET of
-// returned messages; this mirror iterates in sender-byte order (deterministic).
+// returned messages; this mirror iterates in the senders' arrival order (deterministic).
 #pragma once
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -22,6 +23,86 @@
 namespace ibft {
 
 using Predicate = std::function<bool(const IbftMessage &)>;
+
+// sender → message of one (type, height, round): a flat hash index over a vector of messages.  The key of an entry is the
+// From of the message it holds (no copy, no tree node per sender); iteration is in ARRIVAL order of the senders
+// (deterministic; Go's map order is random, callers may only rely on the set).
+class SenderMap {
+ public:
+  size_t size() const { return live_; }
+  bool contains(const bytes &from) const { return locate(from) != npos; }
+  // insert, or replace the message of the same sender (last writer wins); true = a new sender
+  bool put(MsgPtr m) {
+    const size_t at = locate(m->from);
+    if (at != npos) {
+      entries_[at] = std::move(m);
+      return false;
+    }
+    if ((entries_.size() + 1) * 2 > index_.size()) rebuild(std::max<size_t>(64, (entries_.size() + 1) * 4));
+    entries_.push_back(std::move(m));
+    link(entries_.size() - 1);
+    live_++;
+    return true;
+  }
+  // visit the live entries in arrival order; f(const MsgPtr &) → false erases the entry
+  template <class F>
+  void filter(F &&f) {
+    bool erased = false;
+    for (size_t i = 0; i < entries_.size(); i++) {
+      if (!entries_[i]) continue;
+      if (!f(entries_[i])) {
+        entries_[i].reset();
+        live_--;
+        erased = true;
+      }
+    }
+    if (erased) compact();
+  }
+  template <class F>
+  void for_each(F &&f) const {
+    for (const MsgPtr &m : entries_)
+      if (m) f(m);
+  }
+
+ private:
+  static constexpr size_t npos = (size_t)-1;
+  static size_t hash_of(const bytes &b) { return bytes_hash()(b); }
+  size_t locate(const bytes &from) const {
+    if (index_.empty()) return npos;
+    const size_t mask = index_.size() - 1;
+    for (size_t s = hash_of(from) & mask;; s = (s + 1) & mask) {
+      const uint32_t e = index_[s];
+      if (e == 0) return npos;
+      if (entries_[e - 1] && entries_[e - 1]->from == from) return e - 1;
+    }
+  }
+  void link(size_t i) {
+    const size_t mask = index_.size() - 1;
+    size_t s = hash_of(entries_[i]->from) & mask;
+    while (index_[s] != 0) s = (s + 1) & mask;
+    index_[s] = (uint32_t)(i + 1);
+  }
+  void rebuild(size_t slots) {
+    size_t n = 64;
+    while (n < slots) n <<= 1;
+    index_.assign(n, 0);
+    for (size_t i = 0; i < entries_.size(); i++)
+      if (entries_[i]) link(i);
+  }
+  void compact() {  // drop the erased entries (arrival order of the rest is kept) and re-index
+    size_t k = 0;
+    for (size_t i = 0; i < entries_.size(); i++)
+      if (entries_[i]) {
+        if (k != i) entries_[k] = std::move(entries_[i]);
+        k++;
+      }
+    entries_.resize(k);
+    rebuild(std::max<size_t>(64, k * 4));
+  }
+  std::vector<MsgPtr> entries_;
+  std::vector<uint32_t> index_;  // open addressing: entry number + 1, 0 = empty
+  size_t live_ = 0;
+};
 
 class Messages {
  public:
@@ -55,7 +136,7 @@ class Messages {
   std::vector<MsgPtr> GetMostRoundChangeMessages(uint64_t minRound, uint64_t height);
 
  private:
-  using protoMessages = std::map<bytes, MsgPtr>;             // sender -> message
+  using protoMessages = SenderMap;                           // sender -> message
   using roundMessageMap = std::map<uint64_t, protoMessages>;  // round -> ...
   using heightMessageMap = std::map<uint64_t, roundMessageMap>;
   heightMessageMap maps_[4];

@@ -311,17 +311,17 @@ bool decode_msg(const uint8_t *p, size_t n, IbftMessage &m, int depth) {
                       : num == 7 ? PayloadKind::COMMIT : PayloadKind::ROUND_CHANGE;
       if (m.kind != k) {
         if (m.kind != PayloadKind::NONE) {  // another member was set before: the last one on the wire wins
-          m.preprepare = {};
+          m.preprepare_.reset();
           m.prepare = {};
           m.commit = {};
-          m.round_change = {};
+          m.round_change_.reset();
         }
         m.kind = k;
       }
-      bool ok = k == PayloadKind::PREPREPARE  ? decode_preprepare(q, l, m.preprepare, depth)
+      bool ok = k == PayloadKind::PREPREPARE  ? decode_preprepare(q, l, m.preprepare_mut(), depth)
                 : k == PayloadKind::PREPARE   ? decode_prepare(q, l, m.prepare)
                 : k == PayloadKind::COMMIT    ? decode_commit(q, l, m.commit)
-                                              : decode_round_change(q, l, m.round_change, depth);
+                                              : decode_round_change(q, l, m.round_change_mut(), depth);
       if (!ok) return false;
     } else if (num >= 1 && num <= 8) {
       return false;  // known field with the wrong wire type
@@ -397,10 +397,10 @@ bytes encode(const IbftMessage &m, bool with_signature) {
   if (with_signature) put_bytes_field(o, 3, m.signature);
   put_varint_field(o, 4, m.type);
   switch (m.kind) {
-    case PayloadKind::PREPREPARE: put_len_field(o, 5, encode(m.preprepare)); break;
+    case PayloadKind::PREPREPARE: put_len_field(o, 5, encode(m.preprepare())); break;
     case PayloadKind::PREPARE: put_len_field(o, 6, encode(m.prepare)); break;
     case PayloadKind::COMMIT: put_len_field(o, 7, encode(m.commit)); break;
-    case PayloadKind::ROUND_CHANGE: put_len_field(o, 8, encode(m.round_change)); break;
+    case PayloadKind::ROUND_CHANGE: put_len_field(o, 8, encode(m.round_change())); break;
     case PayloadKind::NONE: break;
   }
   o += m.unknown;
@@ -460,23 +460,23 @@ const bytes *extract_prepare_hash(const IbftMessage &m) {
 }
 const Proposal *extract_proposal(const IbftMessage &m) {
   if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
-  return m.preprepare.proposal ? &*m.preprepare.proposal : nullptr;
+  return m.preprepare().proposal ? &*m.preprepare().proposal : nullptr;
 }
 const bytes *extract_proposal_hash(const IbftMessage &m) {
   if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
-  return &m.preprepare.proposal_hash;
+  return &m.preprepare().proposal_hash;
 }
 const RoundChangeCertificate *extract_round_change_certificate(const IbftMessage &m) {
   if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
-  return m.preprepare.certificate ? &*m.preprepare.certificate : nullptr;
+  return m.preprepare().certificate ? &*m.preprepare().certificate : nullptr;
 }
 const PreparedCertificate *extract_latest_pc(const IbftMessage &m) {
   if (m.type != ROUND_CHANGE || m.kind != PayloadKind::ROUND_CHANGE) return nullptr;
-  return m.round_change.latest_prepared_certificate ? &*m.round_change.latest_prepared_certificate : nullptr;
+  return m.round_change().latest_prepared_certificate ? &*m.round_change().latest_prepared_certificate : nullptr;
 }
 const Proposal *extract_last_prepared_proposal(const IbftMessage &m) {
   if (m.type != ROUND_CHANGE || m.kind != PayloadKind::ROUND_CHANGE) return nullptr;
-  return m.round_change.last_prepared_proposal ? &*m.round_change.last_prepared_proposal : nullptr;
+  return m.round_change().last_prepared_proposal ? &*m.round_change().last_prepared_proposal : nullptr;
 }
 
 bool extract_committed_seals(const std::vector<MsgPtr> &msgs, std::vector<std::optional<CommittedSeal>> &out) {

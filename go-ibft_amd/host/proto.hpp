@@ -81,16 +81,48 @@ struct Verdicts {
   uint8_t sender = 0, closure = 0, hash = 0, self = 0;
 };
 
+// A member most messages never use (the PREPREPARE / ROUND_CHANGE payloads, ≈ 500 bytes of the message object between them):
+// allocated on the first write, read as an empty value until then.  The object, once allocated, never moves (pointers into
+// it — extract_proposal, extract_latest_pc — stay valid for the life of the message).
+template <class T>
+class Lazy {
+ public:
+  Lazy() = default;
+  Lazy(const Lazy &o) : p_(o.p_ ? new T(*o.p_) : nullptr) {}
+  Lazy(Lazy &&) noexcept = default;
+  Lazy &operator=(const Lazy &o) {
+    if (this != &o) p_.reset(o.p_ ? new T(*o.p_) : nullptr);
+    return *this;
+  }
+  Lazy &operator=(Lazy &&) noexcept = default;
+  const T &get() const {
+    static const T empty{};
+    return p_ ? *p_ : empty;
+  }
+  T &mut() {
+    if (!p_) p_.reset(new T());
+    return *p_;
+  }
+  void reset() { p_.reset(); }
+
+ private:
+  std::unique_ptr<T> p_;
+};
+
 struct IbftMessage {
   std::optional<View> view;  // nil-able pointer in Go
   bytes from;
   bytes signature;
   uint32_t type = PREPREPARE;
   PayloadKind kind = PayloadKind::NONE;
-  PrePrepareMessage preprepare;
   PrepareMessage prepare;
   CommitMessage commit;
-  RoundChangeMessage round_change;
+  const PrePrepareMessage &preprepare() const { return preprepare_.get(); }
+  PrePrepareMessage &preprepare_mut() { return preprepare_.mut(); }
+  const RoundChangeMessage &round_change() const { return round_change_.get(); }
+  RoundChangeMessage &round_change_mut() { return round_change_.mut(); }
+  Lazy<PrePrepareMessage> preprepare_;
+  Lazy<RoundChangeMessage> round_change_;
   bytes unknown;
   // the buffer the byte fields of a DECODED message (and of everything nested in it) point into; null for a message
   // that was built field by field
