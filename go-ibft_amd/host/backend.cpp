@@ -7,6 +7,7 @@
 
 #include <cstring>
 #include <random>
+#include <thread>
 
 namespace ibft {
 
@@ -658,7 +659,9 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   std::vector<int8_t> verdict(n, -1);       // −1 unknown, 0 / 1 decided
   std::vector<uint64_t> fp1(n), fp2(n);
   std::vector<int32_t> dup_of(n, -1);       // a repeat inside this batch: the row that is asked instead
-  std::vector<uint8_t> stale(n, 0);         // rejected without any arithmetic (not a validator's From / a view that cannot be accepted)
+  std::vector<uint8_t> stale(n, 0);         // rejected without any arithmetic (a view that cannot be accepted)
+  std::vector<uint8_t> kinds(n, 0);         // PayloadKind of each new row (from the peek)
+  std::vector<size_t> to_decode;            // new rows whose top-level walk succeeded
   std::vector<size_t> ask;                  // rows the device has to judge: first occurrence of each distinct new message
   std::unordered_map<uint64_t, size_t> first_in_batch;
   first_in_batch.reserve(n * 2);
@@ -688,21 +691,51 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
         continue;
       }
     }
-    auto m = std::make_shared<IbftMessage>();
-    if (!decode_in(backing, row, len, *m)) continue;  // proto.Unmarshal error: dropped (results −1)
-    msgs[i] = std::move(m);
-    // What AddMessage rejects whatever the signature says costs no device work (and, for a PREPREPARE / ROUND_CHANGE, no
-    // expansion of its certificates): a nil view or a view below the state's cannot pass isAcceptableMessage
-    // (core/ibft.go:1133-1148).  (Membership of From is the Backend's business — a mock accepts anybody — so it is NOT
-    // pre-judged here; the device rejects a non-member like any other bad signature.)
-    const IbftMessage &mm = *msgs[i];
-    const bool view_ok = mm.view && !(height > mm.view->height) && !(height == mm.view->height && mm.view->round < round);
+    // A look at the message without decoding it: rows whose top-level walk fails are dropped (proto.Unmarshal error:
+    // results −1).  What AddMessage rejects whatever the signature says costs no device work (and, for a PREPREPARE /
+    // ROUND_CHANGE, no expansion of its certificates): a nil view or a view below the state's cannot pass
+    // isAcceptableMessage (core/ibft.go:1133-1148).  (Membership of From is the Backend's business — a mock accepts anybody
+    // — so it is NOT pre-judged here; the device rejects a non-member like any other bad signature.)
+    const Peek pk = peek(row, len);
+    if (!pk.ok) continue;
+    to_decode.push_back(i);
+    kinds[i] = (uint8_t)pk.kind;
+    const bool view_ok = pk.has_view && !(height > pk.height) && !(height == pk.height && pk.round < round);
     if (use_batch && batch && !view_ok) {
       stale[i] = 1;
       verdict[i] = 0;
       continue;
     }
     ask.push_back(i);
+  }
+  // Decoding (one object per new message) does not depend on the device and the device does not depend on it: with the
+  // GPU backend — which takes the BYTES — a helper thread decodes while this thread is inside the device calls.
+  auto decode_all = [&]() {
+    for (size_t i : to_decode) {
+      auto m = std::make_shared<IbftMessage>();
+      if (decode_in(backing, wire + off[i], off[i + 1] - off[i], *m)) msgs[i] = std::move(m);  // else: dropped (results −1)
+    }
+  };
+  const bool bytes_backend = use_batch && batch && dynamic_cast<GpuBackend *>(batch) != nullptr;
+  std::thread decoder;
+  if (bytes_backend && to_decode.size() >= 512)
+    decoder = std::thread(decode_all);
+  else
+    decode_all();
+  auto decoded = [&]() {  // from here on msgs[] is needed
+    if (decoder.joinable()) decoder.join();
+  };
+  struct JoinOnExit {
+    std::thread &t;
+    ~JoinOnExit() {
+      if (t.joinable()) t.join();
+    }
+  } join_on_exit{decoder};
+  if (!decoder.joinable()) {  // decoded already: rows that did not decode leave the batch here, as before
+    std::vector<size_t> keep;
+    for (size_t i : ask)
+      if (msgs[i]) keep.push_back(i);
+    ask.swap(keep);
   }
   const std::vector<size_t> asked = ask;  // every distinct undecided message of the batch
   std::vector<uint8_t> was_asked(n, 0);
@@ -730,7 +763,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   if (use_batch && batch && use_certs) {
     std::vector<size_t> carriers;
     for (size_t i : ask)
-      if (msgs[i]->kind == PayloadKind::PREPREPARE || msgs[i]->kind == PayloadKind::ROUND_CHANGE) carriers.push_back(i);
+      if (kinds[i] == (uint8_t)PayloadKind::PREPREPARE || kinds[i] == (uint8_t)PayloadKind::ROUND_CHANGE) carriers.push_back(i);
     if (!carriers.empty()) {
       const uint8_t *w;
       const uint32_t *o;
@@ -739,6 +772,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       const auto td = std::chrono::steady_clock::now();
       const bool cert_ok = batch->VerifyCertificatesWire(w, o, carriers.size(), cv);
       st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+      decoded();
       if (cert_ok && cv.n_rows >= carriers.size()) {
         st.device_calls++;
         cert_calls++;
@@ -748,7 +782,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
             cert_rows++;
           }
           // what the device said about the nested messages is only worth noting for a carrier that can be stored
-          noteCertificateTree(cv, j, msgs[carriers[j]], verdict[carriers[j]] != 0);
+          if (msgs[carriers[j]]) noteCertificateTree(cv, j, msgs[carriers[j]], verdict[carriers[j]] != 0);
         }
         std::vector<size_t> left;
         for (size_t i : ask)
@@ -770,11 +804,12 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     const auto td = std::chrono::steady_clock::now();
     const bool sets_ok = gpu_sets->VerifyMessagesWire(w, o, ask.size(), height, round, *proposal, vs, vc, judged);
     st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+    decoded();
     if (sets_ok) {
       st.device_calls++;
       for (size_t j = 0; j < ask.size(); j++) {
         verdict[ask[j]] = vs[j] ? 1 : 0;
-        if (judged[j]) {
+        if (judged[j] && msgs[ask[j]]) {
           noteClosure(*msgs[ask[j]], vc[j] != 0);
           st.set_rows++;
         }
@@ -782,6 +817,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       wire_sets_done = true;
     }
   }
+  decoded();
   if (wire_sets_done) {
     // nothing left
   } else if (use_batch && batch && use_sets && proposal && !gpu_sets) {
@@ -844,7 +880,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     if (!ok) {  // no batch backend, or the device call failed: the per-message verifier
       if (use_batch && batch) fallbacks++;
       v.assign(rest.size(), 0);
-      for (size_t j = 0; j < rest.size(); j++) v[j] = verifier && verifier->IsValidValidator(*msgs[rest[j]]);
+      for (size_t j = 0; j < rest.size(); j++) v[j] = msgs[rest[j]] && verifier && verifier->IsValidValidator(*msgs[rest[j]]);
     }
     for (size_t j = 0; j < rest.size(); j++) verdict[rest[j]] = v[j] ? 1 : 0;
   }

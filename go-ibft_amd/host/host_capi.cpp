@@ -651,6 +651,17 @@ int ibft_host_handle_round_change(ibft_host *h, uint64_t height, uint64_t round,
   return out.empty() ? 0 : 1;
 }
 
+// test hook: the receive side's look at a message before it is decoded, next to what the decoder finds.
+// out[0..5] = peek {ok, has_view, height, round, type, kind}; out[6..11] = the same six read off the decoded message.
+int ibft_host_peek_vs_decode(const uint8_t *wire, size_t len, uint64_t out[12]) {
+  const Peek pk = peek(wire, len);
+  out[0] = pk.ok; out[1] = pk.has_view; out[2] = pk.height; out[3] = pk.round; out[4] = pk.type; out[5] = (uint64_t)pk.kind;
+  IbftMessage m;
+  const bool ok = decode(wire, len, m);
+  out[6] = ok; out[7] = ok && m.view.has_value(); out[8] = (ok && m.view) ? m.view->height : 0;
+  out[9] = (ok && m.view) ? m.view->round : 0; out[10] = ok ? m.type : 0; out[11] = ok ? (uint64_t)m.kind : 0;
+  return 0;
+}
 int ibft_host_set_round_robin_proposer(ibft_host *h, const uint8_t *packed_addrs, size_t len, int use_height) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<bytes> a;

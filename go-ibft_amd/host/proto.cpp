@@ -407,6 +407,66 @@ bytes encode(const IbftMessage &m, bool with_signature) {
   return o;
 }
 
+Peek peek(const uint8_t *p, size_t n) {
+  Peek out;
+  Reader r{p, p + n};
+  while (r.p < r.end) {
+    uint64_t tag;
+    if (!r.varint(tag)) return out;
+    const uint32_t num = (uint32_t)(tag >> 3), wt = (uint32_t)(tag & 7);
+    const uint8_t *q;
+    size_t l;
+    uint64_t v;
+    if (num == 1 && wt == 2) {
+      if (!r.len_delim(q, l)) return out;
+      out.has_view = true;
+      Reader vr{q, q + l};
+      while (vr.p < vr.end) {
+        uint64_t vt;
+        if (!vr.varint(vt)) return out;
+        if (vt == ((1u << 3) | 0)) {
+          if (!vr.varint(out.height)) return out;
+        } else if (vt == ((2u << 3) | 0)) {
+          if (!vr.varint(out.round)) return out;
+        } else if ((vt >> 3) == 1 || (vt >> 3) == 2) {
+          return out;
+        } else {  // unknown field of View: skipped
+          const uint8_t *uq;
+          size_t ul;
+          switch (vt & 7) {
+            case 0: if (!vr.varint(v)) return out; break;
+            case 1: if (vr.end - vr.p < 8) return out; vr.p += 8; break;
+            case 2: if (!vr.len_delim(uq, ul)) return out; break;
+            case 5: if (vr.end - vr.p < 4) return out; vr.p += 4; break;
+            default: return out;
+          }
+        }
+      }
+    } else if ((num == 2 || num == 3) && wt == 2) {
+      if (!r.len_delim(q, l)) return out;
+    } else if (num == 4 && wt == 0) {
+      if (!r.varint(v)) return out;
+      out.type = (uint32_t)v;
+    } else if (num >= 5 && num <= 8 && wt == 2) {
+      if (!r.len_delim(q, l)) return out;
+      out.kind = num == 5 ? PayloadKind::PREPREPARE : num == 6 ? PayloadKind::PREPARE
+                 : num == 7 ? PayloadKind::COMMIT : PayloadKind::ROUND_CHANGE;
+    } else if (num >= 1 && num <= 8) {
+      return out;  // known field with the wrong wire type
+    } else {
+      switch (wt) {
+        case 0: if (!r.varint(v)) return out; break;
+        case 1: if (r.end - r.p < 8) return out; r.p += 8; break;
+        case 2: if (!r.len_delim(q, l)) return out; break;
+        case 5: if (r.end - r.p < 4) return out; r.p += 4; break;
+        default: return out;
+      }
+    }
+  }
+  out.ok = true;
+  return out;
+}
+
 std::shared_ptr<const void> make_backing(const uint8_t *p, size_t n, const uint8_t **copy) {
   uint8_t *b = static_cast<uint8_t *>(malloc(n ? n : 1));
   if (n) memcpy(b, p, n);

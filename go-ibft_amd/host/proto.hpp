@@ -144,6 +144,16 @@ bool decode(const uint8_t *p, size_t n, IbftMessage &out);
 // The same without copying the wire: [p, p + n) lies inside `backing`, which the message (and every message nested in it)
 // keeps alive; all byte fields are views into it.
 bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out);
+// What the receive side needs to know about a message BEFORE it is decoded (and without allocating anything): whether the
+// top-level walk succeeds at all, the view, the type and which payload member is set — merged exactly as decode() merges
+// repeated fields (the last View fields and the last payload member on the wire win).
+struct Peek {
+  bool ok = false, has_view = false;
+  uint64_t height = 0, round = 0;
+  uint32_t type = PREPREPARE;
+  PayloadKind kind = PayloadKind::NONE;
+};
+Peek peek(const uint8_t *p, size_t n);
 // a heap copy of [p, p + n) to decode into (one allocation)
 std::shared_ptr<const void> make_backing(const uint8_t *p, size_t n, const uint8_t **copy);
 bool decode(const uint8_t *p, size_t n, PreparedCertificate &out);

@@ -122,6 +122,11 @@ int ibft_host_ingest_wire(ibft_host *h, const uint8_t *packed, size_t len, int8_
  * (every decoded message of the batch points into that copy) and hands them to the device as they are.               */
 int ibft_host_ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results,
                           size_t *device_rows, size_t *cache_hits, size_t *device_calls);
+/* Test hook: the receive side looks at a message before decoding it (view, type, payload member — to drop stale views and
+ * to route certificate carriers while a helper thread decodes).  out[0..5] = that look {ok, has_view, height, round, type,
+ * payload kind}, out[6..11] = the same six from the full decoder; the look must succeed whenever the decoder does and agree
+ * with it.                                                                                                            */
+int ibft_host_peek_vs_decode(const uint8_t *wire, size_t len, uint64_t out[12]);
 /* The receive-side queue: transport threads PUSH what arrives (rows back to back + offsets, copied,
  * never blocks on an ingest in progress); one worker per mirror takes everything pending and ingests it as ONE batch
  * (ibft_host_ingest_flat on at most max_rows rows at a time).  The batch size adapts to the load by itself: arrivals pile up
