@@ -445,11 +445,15 @@ def main():
             torch.cuda.synchronize()
             bv.sync()
 
+        # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed loop costs ≈40 ms.
+        # Collect BEFORE the warm-up (not between warm-up and timing: 40 ms of idle device is enough for its clocks to fall,
+        # and the first tens of passes after a pause run ≈4 % slower — measured: the same kernel 0.460 ms in a 25-pass leg that
+        # started behind the collection, 0.440 ms over the 400 passes of the leg next to it), keep the collector off while timing.
+        gc.collect()
+        gc.disable()
         if dist is None:
-            # The clocks of an idle device take tens of milliseconds of work to come back up (measured: the same kernel runs
-            # 0.460 ms in a 25-step leg after a pause and 0.440 ms in the 400-step leg before it), and the legs above leave
-            # a pause (checks, re-staging).  PREWARM untimed passes bring the device to the state a node under load is in; they
-            # are not part of the W warm-up steps the caller asked for and are reported in the line (config.prewarm_steps).
+            # PREWARM untimed passes bring the device to the state a node under load is in; they are not part of the W warm-up
+            # steps the caller asked for and are reported in the line (config.prewarm_steps).
             for _ in range(PREWARM_STEPS if (keep is not None and path == "cold") else 0):
                 step()
             for _ in range(warmup):
@@ -457,10 +461,6 @@ def main():
         elif warmup:
             run_sharded(warmup)
         fence()
-        # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed
-        # loop costs ≈40 ms.  Collect now, keep the collector off while timing.
-        gc.collect()
-        gc.disable()
         lat, kernel_ms, kernel_launches = [], 0.0, 0
         t0 = time.perf_counter()
         if dist is None:
