@@ -543,9 +543,13 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
       HIPCHK(c, hipMemcpyAsync(c->h_mask, have_tally ? c->d_mask_out.p : c->d_mask.p, mw * 8, hipMemcpyDeviceToHost,
                                c->stream));
     // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator, power in full}: one copy
-    if ((tally && have_tally) || c->cache_on)
+    if (tally && have_tally)
       HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, (size_t)(ibftk::TALLY_OUT_WIDE + ibftk::TALLY_SUM_WORDS) * 8,
                                hipMemcpyDeviceToHost, c->stream));
+    // {keys learned, a learned slot}: the device-wide counter itself (a tally kernel passes it on in word 4 of its results;
+    // calls without a tally — the certificate tree, plain hash batches — read it here)
+    if (c->cache_on)
+      HIPCHK(c, hipMemcpyAsync(c->h_tally + 4, c->dev->d_learned.p, 8, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->cache_on) {

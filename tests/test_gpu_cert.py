@@ -115,3 +115,27 @@ def test_golden_trees(gpu_verifier):
         if CC.digest_actual(n, nodes, rows, cls, sender, hb, sb) != gold["digests"][bi]:
             bad.append(bi)
     assert not bad, bad[:20]
+
+
+def test_certificate_calls_feed_the_key_cache():
+    """The certificate path has no tally kernel to carry the "keys learned" counter to the host: a key-caching context must
+    still notice what its certificate calls taught the device, build the tables and serve the next call warm (a regression
+    of round 3's device-wide key cache showed up as warm = cold in the bench line's certificates leg)."""
+    import go_ibft_amd.verifier as V
+    n = 64
+    r = W.make_round(n, 871, height=5, round_=1, raw_len=64)
+    q = (2 * n) // 3 + 1
+    pm = CC.preprepare(r, 1, 5, 1)
+    pcb = wire.prepared_certificate(pm, [CC.prepare(r, j, 5, 1) for j in range(n) if j != 1][: q - 1])
+    msgs = [CC.round_change(r, i, 5, 2, wire.Proposal(r.raw, 1), pcb).encode() for i in range(q)]
+    buf, off = CC.pack(msgs)
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=4096)
+    try:
+        bv.set_validators(5, r.addrs, r.power)
+        for _ in range(3):
+            k, _, _, cls, snd, _, _ = bv.verify_certificates_wire(buf, off, rows_cap=4096, want_rows=False)
+            assert k == q * (q + 1) and snd.all() and not cls.any()
+        tables, warm, cold = bv.cache_stats()
+        assert tables >= q and warm >= 1, (tables, warm, cold)       # every signer of the tree has a table; a warm pass ran
+    finally:
+        bv.close()
