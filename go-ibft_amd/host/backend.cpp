@@ -424,6 +424,38 @@ bool LoopBatch::VerifyMessageSet(const Proposal *proposal, MessageType type, con
   return true;
 }
 
+bool LoopBatch::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
+                                   const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
+                                   std::vector<uint8_t> &judged) {
+  if (fail_sets) return false;
+  calls++;
+  set_calls++;
+  sender.assign(n, 0);
+  closure.assign(n, 0);
+  judged.assign(n, 0);
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t *row = wire + off[i];
+    const size_t len = off[i + 1] - off[i];
+    IbftMessage m;
+    if (!decode(row, len, m)) continue;  // dropped by the caller as well
+    sender[i] = v_->IsValidValidator(m);
+    const bool here = m.view && m.view->height == height && m.view->round == round;
+    const bool kind_ok = (m.type == PREPARE && m.kind == PayloadKind::PREPARE) || (m.type == COMMIT && m.kind == PayloadKind::COMMIT);
+    if (!here || !kind_ok || m.from.empty()) continue;
+    const bytes again = encode(m);
+    if (again.size() != len || memcmp(again.data(), row, len) != 0) continue;  // not the canonical bytes: not vouched for
+    judged[i] = 1;
+    if (m.type == PREPARE) {
+      closure[i] = v_->IsValidProposalHash(&proposal, extract_prepare_hash(m));
+    } else {
+      const bytes *h = extract_commit_hash(m);
+      std::optional<CommittedSeal> seal = extract_committed_seal(m);
+      closure[i] = v_->IsValidProposalHash(&proposal, h) && v_->IsValidCommittedSeal(h, seal ? &*seal : nullptr);
+    }
+  }
+  return true;
+}
+
 bool HotPath::isAcceptableMessage(const IbftMessage &m, const bool *sender_ok) {
   if (sender_ok ? !*sender_ok : (!verifier || !verifier->IsValidValidator(m))) return false;  // ibft.go:1128
   if (!m.view) return false;                                       // :1133
@@ -662,6 +694,14 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   std::vector<uint8_t> stale(n, 0);         // rejected without any arithmetic (a view that cannot be accepted)
   std::vector<uint8_t> kinds(n, 0);         // PayloadKind of each new row (from the peek)
   std::vector<size_t> to_decode;            // new rows whose top-level walk succeeded
+  // Rows that may never become objects (backend.hpp: use_lean): a PREPARE / COMMIT of the current view whose fields occur
+  // once.  Decoding them is put off until the backend has spoken: what it vouches for is stored as a row.
+  const bool lean_mode = use_lean && use_batch && batch && use_sets && proposal && index_enabled_;
+  std::vector<uint8_t> cand(lean_mode ? n : 0, 0), as_row(lean_mode ? n : 0, 0);
+  std::vector<LeanRow> lrow(lean_mode ? n : 0);
+  std::vector<uint8_t> ptype(n, 0xFF);
+  std::vector<Seen> again;                  // stored rows delivered again
+  std::vector<int32_t> again_at(n, -1);
   std::vector<size_t> ask;                  // rows the device has to judge: first occurrence of each distinct new message
   std::unordered_map<uint64_t, size_t> first_in_batch;
   first_in_batch.reserve(n * 2);
@@ -671,10 +711,23 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     fingerprint(row, len, fp_seed_, fp1[i], fp2[i]);
     auto hit = seen_.find(fp1[i]);
     if (hit != seen_.end() && hit->second.fp2 == fp2[i] && hit->second.len == len && memcmp(hit->second.wire, row, len) == 0) {
-      msgs[i] = hit->second.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
-      verdict[i] = 1;
-      st.cache_hits++;
-      continue;
+      const Seen &sn = hit->second;
+      if (!sn.lean) {
+        msgs[i] = sn.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
+        verdict[i] = 1;
+        st.cache_hits++;
+        continue;
+      }
+      if (sn.closure_epoch == closure_epoch_ && sn.valset_epoch == valset_epoch_) {
+        // a stored row: stored again (its sender's row is overwritten by itself), if its view is still acceptable
+        st.cache_hits++;
+        ptype[i] = (uint8_t)sn.type;
+        verdict[i] = 2;  // stored again below, in arrival order
+        again_at[i] = (int32_t)again.size();
+        again.push_back(sn);
+        continue;
+      }
+      seen_.erase(hit);  // judged against another proposal / validator set: a new message
     }
     auto rej = seen_rejected_.find(fp1[i]);
     if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
@@ -698,8 +751,21 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     // — so it is NOT pre-judged here; the device rejects a non-member like any other bad signature.)
     const Peek pk = peek(row, len);
     if (!pk.ok) continue;
-    to_decode.push_back(i);
     kinds[i] = (uint8_t)pk.kind;
+    ptype[i] = (uint8_t)(pk.type <= 3 ? pk.type : 0xFE);
+    if (lean_mode && pk.simple && pk.from_len && pk.has_view && pk.height == height && pk.round == round &&
+        ((pk.type == PREPARE && pk.kind == PayloadKind::PREPARE) || (pk.type == COMMIT && pk.kind == PayloadKind::COMMIT))) {
+      cand[i] = 1;
+      LeanRow &lr = lrow[i];
+      lr.wire = row;
+      lr.len = (uint32_t)len;
+      lr.from_off = pk.from_off; lr.from_len = pk.from_len;
+      lr.hash_off = pk.hash_off; lr.hash_len = pk.hash_len;
+      lr.seal_off = pk.seal_off; lr.seal_len = pk.seal_len;
+      ask.push_back(i);
+      continue;
+    }
+    to_decode.push_back(i);
     const bool view_ok = pk.has_view && !(height > pk.height) && !(height == pk.height && pk.round < round);
     if (use_batch && batch && !view_ok) {
       stale[i] = 1;
@@ -715,6 +781,11 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       auto m = std::make_shared<IbftMessage>();
       if (decode_in(backing, wire + off[i], off[i + 1] - off[i], *m)) msgs[i] = std::move(m);  // else: dropped (results −1)
     }
+  };
+  auto decode_candidate = [&](size_t i) {  // a candidate that needs an object after all
+    cand[i] = 0;
+    auto m = std::make_shared<IbftMessage>();
+    if (decode_in(backing, wire + off[i], off[i + 1] - off[i], *m)) msgs[i] = std::move(m);
   };
   const bool bytes_backend = use_batch && batch && dynamic_cast<GpuBackend *>(batch) != nullptr;
   std::thread decoder;
@@ -734,7 +805,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   if (!decoder.joinable()) {  // decoded already: rows that did not decode leave the batch here, as before
     std::vector<size_t> keep;
     for (size_t i : ask)
-      if (msgs[i]) keep.push_back(i);
+      if (msgs[i] || (lean_mode && cand[i])) keep.push_back(i);
     ask.swap(keep);
   }
   const std::vector<size_t> asked = ask;  // every distinct undecided message of the batch
@@ -793,8 +864,10 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   }
   // (1) messages of the current view with the proposal at hand: judged completely, one set call per type
   std::vector<size_t> rest;
-  GpuBackend *gpu_sets = (use_batch && use_sets && proposal) ? dynamic_cast<GpuBackend *>(batch) : nullptr;
+  // (a backend that judges bytes: the GPU always; the loop backend when rows are kept, so that the row path runs without a device)
+  BatchVerifier *gpu_sets = (use_batch && use_sets && proposal && (bytes_backend || lean_mode)) ? batch : nullptr;
   bool wire_sets_done = false;
+  bool wire_sets_offered = gpu_sets != nullptr;
   if (gpu_sets && !ask.empty()) {
     // the device walks the bytes AND judges every PREPARE / COMMIT of this view completely: one call for the micro-batch
     const uint8_t *w;
@@ -805,22 +878,45 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     const bool sets_ok = gpu_sets->VerifyMessagesWire(w, o, ask.size(), height, round, *proposal, vs, vc, judged);
     st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
     decoded();
-    if (sets_ok) {
+    if (sets_ok && vs.size() == ask.size() && vc.size() == ask.size() && judged.size() == ask.size()) {
       st.device_calls++;
       for (size_t j = 0; j < ask.size(); j++) {
-        verdict[ask[j]] = vs[j] ? 1 : 0;
-        if (judged[j] && msgs[ask[j]]) {
-          noteClosure(*msgs[ask[j]], vc[j] != 0);
+        const size_t i = ask[j];
+        verdict[i] = vs[j] ? 1 : 0;
+        if (lean_mode && cand[i]) {
+          if (judged[j]) {  // vouched canonical: a row if its sender is valid, rejected (without ever being decoded) if not
+            st.set_rows++;
+            if (vs[j]) {
+              as_row[i] = 1;
+              lrow[i].closure = vc[j] ? 1 : 0;
+            }
+            continue;
+          }
+          decode_candidate(i);
+        }
+        if (judged[j] && msgs[i]) {
+          noteClosure(*msgs[i], vc[j] != 0);
           st.set_rows++;
         }
       }
       wire_sets_done = true;
+    } else if (!bytes_backend) {
+      wire_sets_offered = false;  // (the loop backend's set call failed: the object routes below, as before)
     }
   }
   decoded();
+  if (lean_mode && !wire_sets_done)
+    for (size_t i : ask)
+      if (cand[i]) decode_candidate(i);
+  {  // rows that do not decode leave the batch (results −1), whichever thread decoded them
+    std::vector<size_t> keep;
+    for (size_t i : ask)
+      if (msgs[i] || (lean_mode && cand[i])) keep.push_back(i);
+    ask.swap(keep);
+  }
   if (wire_sets_done) {
     // nothing left
-  } else if (use_batch && batch && use_sets && proposal && !gpu_sets) {
+  } else if (use_batch && batch && use_sets && proposal && !wire_sets_offered) {
     std::vector<size_t> of_type[2];
     for (size_t i : ask) {
       const IbftMessage &m = *msgs[i];
@@ -885,12 +981,55 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     for (size_t j = 0; j < rest.size(); j++) verdict[rest[j]] = v[j] ? 1 : 0;
   }
   st.device_rows = asked.size();
+  auto remember_rejected = [&](size_t i) {
+    if (rejected_fifo_.size() < rejected_cap) {
+      rejected_fifo_.push_back(fp1[i]);
+    } else if (rejected_cap) {
+      seen_rejected_.erase(rejected_fifo_[rejected_head_]);
+      rejected_fifo_[rejected_head_] = fp1[i];
+      rejected_head_ = (rejected_head_ + 1) % rejected_cap;
+    }
+    if (rejected_cap) seen_rejected_[fp1[i]] = fp2[i];
+  };
   // IBFT.AddMessage per message, in arrival order, with the verdict attached; what was stored is remembered for its
   // re-deliveries, what was rejected by its fingerprint
   for (size_t i = 0; i < n; i++) {
+    if (verdict[i] == 2) {  // a stored row delivered again: its sender's row is overwritten by itself, if its view is still acceptable
+      if (types) types[i] = ptype[i];
+      const Seen &sn = again[(size_t)again_at[i]];
+      if (height > sn.height || (height == sn.height && sn.round < round))
+        results[i] = 0;
+      else
+        results[i] = (int8_t)addLeanRow(sn.type, sn.height, sn.round, sn.row, sn.backing);
+      continue;
+    }
+    size_t src = i;
     if (dup_of[i] >= 0) {  // a repeat inside this batch: the first occurrence's object and verdict
-      msgs[i] = msgs[(size_t)dup_of[i]];
-      verdict[i] = verdict[(size_t)dup_of[i]];
+      src = (size_t)dup_of[i];
+      msgs[i] = msgs[src];
+      verdict[i] = verdict[src];
+    }
+    if (lean_mode && cand[src]) {  // judged from its bytes, never decoded
+      if (types) types[i] = ptype[src];
+      if (!as_row[src]) {
+        results[i] = 0;  // IsValidValidator failed (isAcceptableMessage, core/ibft.go:1128)
+      } else {
+        results[i] = (int8_t)addLeanRow(ptype[src], height, round, lrow[src], backing);
+        if (src == i && results[i] > 0) {
+          if (seen_.size() >= seen_cap) seen_.clear();
+          Seen sn{fp2[i], nullptr, wire + off[i], off[i + 1] - off[i], height};
+          sn.lean = true;
+          sn.type = ptype[i];
+          sn.round = round;
+          sn.row = lrow[i];
+          sn.backing = backing;
+          sn.closure_epoch = closure_epoch_;
+          sn.valset_epoch = valset_epoch_;
+          seen_[fp1[i]] = std::move(sn);
+        }
+      }
+      if (src == i && results[i] == 0) remember_rejected(i);
+      continue;
     }
     if (!msgs[i]) continue;
     if (types) types[i] = (uint8_t)(msgs[i]->type <= 3 ? msgs[i]->type : 0xFE);
@@ -903,14 +1042,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       const IbftMessage &m = *msgs[i];
       seen_[fp1[i]] = Seen{fp2[i], msgs[i], wire + off[i], off[i + 1] - off[i], m.view ? m.view->height : 0};
     } else if (verdict[i] == 0) {
-      if (rejected_fifo_.size() < rejected_cap) {
-        rejected_fifo_.push_back(fp1[i]);
-      } else if (rejected_cap) {
-        seen_rejected_.erase(rejected_fifo_[rejected_head_]);
-        rejected_fifo_[rejected_head_] = fp1[i];
-        rejected_head_ = (rejected_head_ + 1) % rejected_cap;
-      }
-      if (rejected_cap) seen_rejected_[fp1[i]] = fp2[i];
+      remember_rejected(i);
     }
   }
   if (stats) *stats = st;
@@ -918,20 +1050,9 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
 }
 
 
-int HotPath::AddMessageFast(MsgPtr m, bool accepted) {
-  if (!m) return 0;
-  if (!accepted && !isAcceptableMessage(*m)) return 0;
-  const View view = *m->view;
-  const uint32_t type = m->type;
-  messages.AddMessage(m);
-  if (view.height != height) return 1;
-  // hasQuorumByMsgType over the stored (unverified) messages of the view, without walking them
-  auto rebuild = [&]() {
-    std::vector<bytes> senders;
-    for (auto &x : messages.GetValidMessages(view, (MessageType)type, [](const IbftMessage &) { return true; }))
-      senders.push_back(x->from);
-    return senders;
-  };
+// hasQuorumByMsgType over the stored (unverified) messages of a view, without walking them: 2 = quorum (SignalEvent), 1 = not yet
+int HotPath::quorumProbe(uint32_t type, const View &view) {
+  auto rebuild = [&]() { return messages.SendersOf(view, (MessageType)type); };
   auto pc = quorumIndex.Get(type, view.height, view.round, rebuild, validatorManager);
   bool q = false;
   switch (type) {
@@ -948,6 +1069,105 @@ int HotPath::AddMessageFast(MsgPtr m, bool accepted) {
     default: break;
   }
   return q ? 2 : 1;
+}
+
+int HotPath::AddMessageFast(MsgPtr m, bool accepted) {
+  if (!m) return 0;
+  if (!accepted && !isAcceptableMessage(*m)) return 0;
+  const View view = *m->view;
+  const uint32_t type = m->type;
+  messages.AddMessage(m);
+  if (view.height != height) return 1;
+  return quorumProbe(type, view);
+}
+
+// IBFT.AddMessage for a message that is kept as a row: IsValidValidator and the view checks of isAcceptableMessage were
+// answered before (by the backend that judged the bytes, by the look at the view); store, then the quorum probe.
+int HotPath::addLeanRow(uint32_t type, uint64_t h, uint64_t r, const LeanRow &row, const std::shared_ptr<const void> &backing) {
+  if (!messages.AddLean(type, h, r, row, backing, closure_epoch_, valset_epoch_)) {
+    // the view is held as objects (somebody asked for them): this message becomes an object too
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode_in(backing, row.wire, row.len, *m)) return -1;
+    noteSender(*m, true);
+    noteClosure(*m, row.closure != 0);
+    return AddMessageFast(std::move(m), true);
+  }
+  lean_rows++;
+  if (h != height) return 1;
+  View v;
+  v.height = h;
+  v.round = r;
+  return quorumProbe(type, v);
+}
+
+// handlePrepare / handleCommit over a view that is held as rows: the closure verdicts came with the rows, so the walk is
+// a filter over them; the quorum is the index's (the store's hooks followed the prunes).
+bool HotPath::handleLean(const View &view, MessageType type, bool &quorum) {
+  if (!(use_lean && use_sets && index_enabled_ && use_batch && batch)) {
+    (void)messages.LeanFor(view, type, 0, 0);  // (epoch 0 never matches: any rows become objects for the generic walk)
+    return false;
+  }
+  syncClosureKey(getProposal());
+  LeanView *lv = messages.LeanFor(view, type, closure_epoch_, valset_epoch_);
+  if (!lv) return false;
+  closure_hits = 0;
+  const size_t left = messages.FilterLean(view, type, [&](const LeanRow &row) {
+    closure_hits++;
+    return row.closure != 0;
+  });
+  quorum = false;
+  if (validatorManager.initialized()) {
+    auto rebuild = [&]() { return messages.SendersOf(view, type); };
+    auto pc = quorumIndex.Get(type, view.height, view.round, rebuild, validatorManager);
+    if (pc.second == left) {
+      if (type == PREPARE) {
+        quorum = proposalMessage && !messages.Has(view, PREPARE, proposalMessage->from) &&
+                 pc.first + validatorManager.powerOf(proposalMessage->from) >= validatorManager.quorum();
+      } else {
+        quorum = pc.first >= validatorManager.quorum();
+      }
+    } else {  // (cannot happen: the hooks follow every change) — the generic walk is the authority
+      (void)messages.LeanFor(view, type, 0, 0);
+      return false;
+    }
+  }
+  if (!quorum) return true;
+  if (type == PREPARE) {
+    preparedMessages.clear();
+    prepared_as_rows = true;
+    prepared_view = view;
+    stateName = StateName::commit;
+  } else {
+    // ExtractCommittedSeals (messages/helpers.go:22-35): {Signer: From, Signature: committedSeal} of every survivor, read
+    // off the rows' bytes; the seal list keeps the buffers alive
+    std::vector<std::optional<CommittedSeal>> seals;
+    seals.reserve(left);
+    lv = messages.LeanFor(view, type, closure_epoch_, valset_epoch_);
+    if (lv)
+      lv->for_each([&](const LeanRow &row) {
+        CommittedSeal cs{bytes::view((const char *)row.wire + row.from_off, row.from_len),
+                         bytes::view((const char *)row.wire + row.seal_off, row.seal_len), nullptr, lv->buffers[row.buf]};
+        seals.emplace_back(std::move(cs));
+      });
+    committedSeals = std::move(seals);
+    stateName = StateName::fin;
+  }
+  return true;
+}
+
+std::vector<bytes> HotPath::PreparedWire() {
+  std::vector<bytes> out;
+  if (prepared_as_rows) {
+    if (LeanView *lv = messages.LeanFor(prepared_view, PREPARE, closure_epoch_, valset_epoch_)) {
+      lv->for_each([&](const LeanRow &row) { out.emplace_back((const char *)row.wire, row.len); });
+      return out;
+    }
+    // the rows were materialised meanwhile: the objects of the view are the prepared messages
+    for (auto &m : messages.GetValidMessages(prepared_view, PREPARE, [](const IbftMessage &) { return true; })) out.push_back(encode(*m));
+    return out;
+  }
+  for (auto &m : preparedMessages) out.push_back(encode(*m));
+  return out;
 }
 
 // The verdicts of a handle* walk in batch mode: what arrived through IngestWire's set calls is already in the table;
@@ -990,6 +1210,11 @@ std::vector<uint8_t> HotPath::closureVerdicts(const Proposal *proposal, MessageT
 }
 
 bool HotPath::handlePrepare(const View &view) {
+  prepared_as_rows = false;
+  {
+    bool q = false;
+    if (handleLean(view, PREPARE, q)) return q;
+  }
   std::vector<MsgPtr> prepareMessages;
   const Proposal *proposal = getProposal();
   closure_hits = 0;
@@ -1009,6 +1234,10 @@ bool HotPath::handlePrepare(const View &view) {
 }
 
 bool HotPath::handleCommit(const View &view) {
+  {
+    bool q = false;
+    if (handleLean(view, COMMIT, q)) return q;
+  }
   std::vector<MsgPtr> commitMessages;
   const Proposal *proposal = getProposal();
   closure_hits = 0;

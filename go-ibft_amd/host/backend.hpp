@@ -64,6 +64,15 @@ struct BatchVerifier {
   virtual bool VerifyCertificatesWire(const uint8_t * /*wire*/, const uint32_t * /*off*/, size_t /*n*/, CertVerdicts & /*out*/) {
     return false;
   }
+  // A batch of raw messages judged COMPLETELY from their bytes (include/ibftgpu.h: ibft_verify_messages_wire): sender[i] =
+  // IsValidValidator(message i); judged[i] != 0 for the messages the backend vouches are the CANONICAL encoding of a PREPARE
+  // / COMMIT of the view (height, round) — closure[i] is then the handlePrepare / handleCommit closure against `proposal`.
+  // Such a message can be kept as a row (messages.hpp: LeanRow).  false = not offered / device unavailable.
+  virtual bool VerifyMessagesWire(const uint8_t * /*wire*/, const uint32_t * /*off*/, size_t /*n*/, uint64_t /*height*/,
+                                  uint64_t /*round*/, const Proposal & /*proposal*/, std::vector<uint8_t> & /*sender*/,
+                                  std::vector<uint8_t> & /*closure*/, std::vector<uint8_t> & /*judged*/) {
+    return false;
+  }
 };
 
 // SoA columns handed to the C ABI (plain bytes, no pointers inside: cgo-safe layout)
@@ -107,7 +116,7 @@ class GpuBackend : public BatchVerifier {
   // `proposal`, both signatures of a COMMIT verified in the same launch.  Rows the device flags take the stock sender route.
   bool VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
                           const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
-                          std::vector<uint8_t> &judged);
+                          std::vector<uint8_t> &judged) override;
   bool VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) override;
   size_t cert_rows_cap = 65536;  // rows one certificate call may expand to (the context's max_rows bounds it too)
   int last_rc = 0;
@@ -129,6 +138,11 @@ class LoopBatch : public BatchVerifier {
                         std::vector<uint8_t> &) override;
   // decodes the messages and asks the per-message Verifier about every nested message, in the row order of the device
   bool VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) override;
+  // decodes, re-encodes (judged = the bytes ARE the canonical encoding of a PREPARE / COMMIT of the view) and asks the
+  // per-message Verifier: the row-keeping ingest path without a device (counts as a message-set call; fail_sets fails it)
+  bool VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
+                          const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
+                          std::vector<uint8_t> &judged) override;
   bool fail_hashes = false, fail_seals = false, fail_senders = false, fail_sets = false, fail_certs = false;
   size_t calls = 0;      // batch calls answered
   size_t set_calls = 0;  // of which message-set calls
@@ -211,6 +225,14 @@ class HotPath {
   // decoded (stored) message objects, which a decoded message lists in the device's row order.  The certificate walks
   // then send the device only what the tables cannot answer (normally nothing).
   bool use_certs = true;
+  // With use_lean (default; needs the quorum index, use_sets, the proposal at hand and a backend that judges bytes
+  // completely): a PREPARE / COMMIT the backend vouched for is kept as a ROW — no object is built for it — and
+  // handlePrepare / handleCommit run over the rows; anything that wants objects materialises them (messages.hpp).
+  bool use_lean = true;
+  size_t lean_rows = 0;        // messages ingested as rows so far
+  bool prepared_as_rows = false;  // the last successful handlePrepare ran over rows: PC.PrepareMessages = PreparedWire()
+  View prepared_view{};
+  std::vector<bytes> PreparedWire();  // the prepared messages' wire bytes (rows: as stored; objects: encoded)
   size_t cert_calls = 0, cert_rows = 0;  // certificate-tree calls made by IngestWire, rows they judged
   size_t cert_hits = 0;  // sender verdicts the last certificate walk took from the arrival-time tables
   bool IngestWire(const std::vector<bytes> &raw, std::vector<int> &results, IngestStats *stats = nullptr);
@@ -281,11 +303,22 @@ class HotPath {
   // re-delivery of a rejected one by its fingerprint alone, from a bounded FIFO.
   struct Seen {
     uint64_t fp2;
-    MsgPtr msg;           // the stored message (keeps its bytes: wire_of / wire_len point into its backing)
+    MsgPtr msg;           // the stored message (keeps its bytes: wire / len point into its backing); null for a row
     const uint8_t *wire;
     uint32_t len;
     uint64_t height;
+    // a message stored as a row: what is needed to store it again (a re-delivery overwrites its sender's row)
+    bool lean = false;
+    uint32_t type = 0;
+    uint64_t round = 0;
+    LeanRow row{};
+    std::shared_ptr<const void> backing;
+    uint32_t closure_epoch = 0, valset_epoch = 0;  // what the row's verdicts were computed against
   };
+  // IBFT.AddMessage for a message kept as a row (sender and view already accepted): store + quorum probe
+  int addLeanRow(uint32_t type, uint64_t h, uint64_t r, const LeanRow &row, const std::shared_ptr<const void> &backing);
+  int quorumProbe(uint32_t type, const View &view);  // the 1 / 2 of AddMessageFast, from the quorum index
+  bool handleLean(const View &view, MessageType type, bool &quorum);  // true = the view was held as rows and is handled
   std::unordered_map<uint64_t, Seen> seen_;
   std::unordered_map<uint64_t, uint64_t> seen_rejected_;  // fp1 → fp2
   std::vector<uint64_t> rejected_fifo_;

@@ -613,6 +613,8 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
   h->hp.rejected_cap = rejected_cap;
 }
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
+void ibft_host_use_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_lean = on != 0; }
+size_t ibft_host_rows_kept(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.lean_rows; }
 void ibft_host_use_certs(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_certs = on != 0; }
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
@@ -708,7 +710,12 @@ void ibft_host_last_cert_batch(ibft_host *h, size_t *senders, size_t *hashes) {
 int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *prepared) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   bool q = h->hp.handlePrepare(View{height, round, {}});
-  if (prepared) msgs_to_buf(q ? h->hp.preparedMessages : std::vector<MsgPtr>{}, prepared);
+  if (prepared) {  // PC.PrepareMessages: the stored bytes when the view is held as rows, the objects' encoding otherwise
+    bytes o;
+    std::vector<bytes> w = q ? h->hp.PreparedWire() : std::vector<bytes>{};
+    for (const bytes &b : w) pack_bytes(o, b);
+    to_buf(o, w.size(), prepared);
+  }
   return q ? 1 : 0;
 }
 int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals) {

@@ -11,6 +11,7 @@ void Messages::AddMessage(MsgPtr m) {
   if (s < 0 || !m->view) return;  // the reference would panic on an unknown type / nil view
   std::unique_lock lk(mux_[s]);
   const uint64_t h = m->view->height, r = m->view->round;
+  if (!lean_[s].empty()) materialize_locked(s, h, r);
   // consecutive messages mostly belong to one view: remember where its senders are (std::map nodes do not move)
   LastView &lv = last_[s];
   if (!lv.msgs || lv.height != h || lv.round != r) {
@@ -29,6 +30,8 @@ bool Messages::Has(const View &view, MessageType type, const bytes &from) {
   int s = slot(type);
   if (s < 0) return false;
   std::shared_lock lk(mux_[s]);
+  auto lv = lean_[s].find({view.height, view.round});
+  if (lv != lean_[s].end()) return lv->second.contains(std::string_view(from.data(), from.size()));
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return false;
   auto r = h->second.find(view.round);
@@ -39,6 +42,8 @@ size_t Messages::numMessages(const View &view, MessageType type) {
   int s = slot(type);
   if (s < 0) return 0;
   std::shared_lock lk(mux_[s]);
+  auto lv = lean_[s].find({view.height, view.round});
+  if (lv != lean_[s].end()) return lv->second.size();
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return 0;
   auto r = h->second.find(view.round);
@@ -51,6 +56,7 @@ void Messages::PruneByHeight(uint64_t height) {
     auto &m = maps_[s];
     m.erase(m.begin(), m.lower_bound(height));  // delete every msgHeight < height
     last_[s] = LastView{};
+    lean_[s].erase(lean_[s].begin(), lean_[s].lower_bound({height, 0}));
   }
   if (height_hook_) height_hook_(height);
 }
@@ -60,6 +66,7 @@ std::vector<MsgPtr> Messages::GetValidMessages(const View &view, MessageType typ
   int s = slot(type);
   if (s < 0) return valid;
   std::unique_lock lk(mux_[s]);  // write lock held across the callbacks, messages.go:174-176
+  if (!lean_[s].empty()) materialize_locked(s, view.height, view.round);
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return valid;
   auto r = h->second.find(view.round);
@@ -82,6 +89,7 @@ std::vector<MsgPtr> Messages::GetValidMessagesBatch(const View &view, MessageTyp
   int s = slot(type);
   if (s < 0) return valid;
   std::unique_lock lk(mux_[s]);
+  if (!lean_[s].empty()) materialize_locked(s, view.height, view.round);
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return valid;
   auto r = h->second.find(view.round);
@@ -152,6 +160,113 @@ std::vector<MsgPtr> Messages::GetMostRoundChangeMessages(uint64_t minRound, uint
   }
   if (best == 0) return out;  // "no messages found" — also when the best round IS 0, messages.go:273-276
   h->second[best].for_each([&](const MsgPtr &m) { out.push_back(m); });
+  return out;
+}
+
+// ---- rows ---------------------------------------------------------------------------------------------------------
+void Messages::materialize_locked(int s, uint64_t height, uint64_t round) {
+  auto it = lean_[s].find({height, round});
+  if (it == lean_[s].end()) return;
+  LeanView lv = std::move(it->second);
+  lean_[s].erase(it);
+  protoMessages &view_msgs = maps_[s][height][round];
+  last_[s] = LastView{};
+  lv.for_each([&](const LeanRow &row) {
+    auto m = std::make_shared<IbftMessage>();
+    if (!decode_in(lv.buffers[row.buf], row.wire, row.len, *m)) return;  // (a row was vouched canonical: it decodes)
+    // what was known about the row goes with the object
+    m->verdicts.sender = 1;
+    m->verdicts.sender_epoch = lv.valset_epoch;
+    m->verdicts.closure = row.closure;
+    m->verdicts.closure_epoch = lv.closure_epoch;
+    view_msgs.put(std::move(m));  // (the sender hooks fired when the row was added: nothing changes for the counters)
+  });
+}
+
+bool Messages::AddLean(uint32_t type, uint64_t height, uint64_t round, const LeanRow &row,
+                       const std::shared_ptr<const void> &backing, uint32_t closure_epoch, uint32_t valset_epoch) {
+  int s = slot(type);
+  if (s != PREPARE && s != COMMIT) return false;
+  std::unique_lock lk(mux_[s]);
+  auto it = lean_[s].find({height, round});
+  if (it == lean_[s].end()) {
+    auto h = maps_[s].find(height);
+    if (h != maps_[s].end()) {
+      auto r = h->second.find(round);
+      if (r != h->second.end() && r->second.size() != 0) return false;  // the view is held as objects
+    }
+    it = lean_[s].emplace(std::make_pair(height, round), LeanView{}).first;
+    it->second.closure_epoch = closure_epoch;
+    it->second.valset_epoch = valset_epoch;
+  } else if (it->second.closure_epoch != closure_epoch || it->second.valset_epoch != valset_epoch) {
+    materialize_locked(s, height, round);  // judged against another proposal / validator set: objects from here on
+    return false;
+  }
+  if (it->second.put(row, backing) && sender_hook_) {
+    const std::string_view f = row.from();
+    sender_hook_((uint32_t)s, height, round, bytes::view(f.data(), f.size()), +1);
+  }
+  return true;
+}
+
+LeanView *Messages::LeanFor(const View &view, MessageType type, uint32_t closure_epoch, uint32_t valset_epoch) {
+  int s = slot(type);
+  if (s < 0) return nullptr;
+  std::unique_lock lk(mux_[s]);
+  auto it = lean_[s].find({view.height, view.round});
+  if (it == lean_[s].end()) return nullptr;
+  if (it->second.closure_epoch != closure_epoch || it->second.valset_epoch != valset_epoch) {
+    materialize_locked(s, view.height, view.round);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+size_t Messages::FilterLean(const View &view, MessageType type, const std::function<bool(const LeanRow &)> &f) {
+  int s = slot(type);
+  if (s < 0) return 0;
+  std::unique_lock lk(mux_[s]);  // the lock GetValidMessages holds across its walk
+  auto it = lean_[s].find({view.height, view.round});
+  if (it == lean_[s].end()) return 0;
+  it->second.filter([&](const LeanRow &row) {
+    if (f(row)) return true;
+    if (sender_hook_) {
+      const std::string_view fr = row.from();
+      sender_hook_((uint32_t)s, view.height, view.round, bytes::view(fr.data(), fr.size()), -1);
+    }
+    return false;  // pruned, as GetValidMessages prunes what its predicate rejects (messages.go:193-196)
+  });
+  return it->second.size();
+}
+
+void Messages::MaterializeAll() {
+  for (int s : {(int)PREPARE, (int)COMMIT}) {
+    std::unique_lock lk(mux_[s]);
+    while (!lean_[s].empty()) {
+      const auto key = lean_[s].begin()->first;
+      materialize_locked(s, key.first, key.second);
+    }
+  }
+}
+
+std::vector<bytes> Messages::SendersOf(const View &view, MessageType type) {
+  std::vector<bytes> out;
+  int s = slot(type);
+  if (s < 0) return out;
+  std::shared_lock lk(mux_[s]);
+  auto lv = lean_[s].find({view.height, view.round});
+  if (lv != lean_[s].end()) {
+    lv->second.for_each([&](const LeanRow &row) {
+      const std::string_view f = row.from();
+      out.emplace_back(f.data(), f.size());
+    });
+    return out;
+  }
+  auto h = maps_[s].find(view.height);
+  if (h == maps_[s].end()) return out;
+  auto r = h->second.find(view.round);
+  if (r == h->second.end()) return out;
+  r->second.for_each([&](const MsgPtr &m) { out.push_back(m->from); });
   return out;
 }
 

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <set>
 #include <shared_mutex>
+#include <string_view>
 #include <unordered_map>
 
 #include "proto.hpp"
@@ -104,6 +105,83 @@ class SenderMap {
   size_t live_ = 0;
 };
 
+// A PREPARE / COMMIT message kept as a ROW instead of an object: where its bytes lie and where the few fields the hot path
+// reads are inside them.  What a batch backend that takes the transport's bytes has judged completely (canonical encoding,
+// envelope signature, closure) needs no pointer graph until somebody asks for one — a certificate being built, a test, a
+// walk by the per-message path — and is decoded ("materialised") then, with its verdicts noted in the object.
+struct LeanRow {
+  const uint8_t *wire = nullptr;  // the message's bytes, inside buffers[buf] of its view
+  uint32_t len = 0, buf = 0;
+  uint32_t from_off = 0, from_len = 0, hash_off = 0, hash_len = 0, seal_off = 0, seal_len = 0;
+  uint8_t closure = 0;            // handlePrepare's / handleCommit's closure verdict (against the view's closure epoch)
+  std::string_view from() const { return std::string_view((const char *)wire + from_off, from_len); }
+};
+class LeanView {
+ public:
+  uint32_t closure_epoch = 0, valset_epoch = 0;  // what the rows' verdicts were computed against
+  std::vector<std::shared_ptr<const void>> buffers;
+  size_t size() const { return live_; }
+  bool contains(std::string_view from) const { return locate(from) != npos; }
+  // insert, or replace the row of the same sender; true = a new sender
+  bool put(LeanRow row, const std::shared_ptr<const void> &backing) {
+    if (buffers.empty() || buffers.back() != backing) buffers.push_back(backing);
+    row.buf = (uint32_t)buffers.size() - 1;
+    const size_t at = locate(row.from());
+    if (at != npos) {
+      rows_[at] = row;
+      return false;
+    }
+    if ((rows_.size() + 1) * 2 > index_.size()) rebuild(std::max<size_t>(64, (rows_.size() + 1) * 4));
+    rows_.push_back(row);
+    dead_.push_back(0);
+    link(rows_.size() - 1);
+    live_++;
+    return true;
+  }
+  template <class F>
+  void filter(F &&f) {  // f(const LeanRow &) → false erases the row
+    for (size_t i = 0; i < rows_.size(); i++)
+      if (!dead_[i] && !f(rows_[i])) {
+        dead_[i] = 1;
+        live_--;
+      }
+  }
+  template <class F>
+  void for_each(F &&f) const {
+    for (size_t i = 0; i < rows_.size(); i++)
+      if (!dead_[i]) f(rows_[i]);
+  }
+
+ private:
+  static constexpr size_t npos = (size_t)-1;
+  size_t locate(std::string_view from) const {
+    if (index_.empty()) return npos;
+    const size_t mask = index_.size() - 1;
+    for (size_t s = std::hash<std::string_view>()(from) & mask;; s = (s + 1) & mask) {
+      const uint32_t e = index_[s];
+      if (e == 0) return npos;
+      if (!dead_[e - 1] && rows_[e - 1].from() == from) return e - 1;
+    }
+  }
+  void link(size_t i) {
+    const size_t mask = index_.size() - 1;
+    size_t s = std::hash<std::string_view>()(rows_[i].from()) & mask;
+    while (index_[s] != 0) s = (s + 1) & mask;
+    index_[s] = (uint32_t)(i + 1);
+  }
+  void rebuild(size_t slots) {
+    size_t n = 64;
+    while (n < slots) n <<= 1;
+    index_.assign(n, 0);
+    for (size_t i = 0; i < rows_.size(); i++)
+      if (!dead_[i]) link(i);
+  }
+  std::vector<LeanRow> rows_;
+  std::vector<uint8_t> dead_;
+  std::vector<uint32_t> index_;
+  size_t live_ = 0;
+};
+
 class Messages {
  public:
   // Observer of the sender SET of a view: called with +1 when a sender appears in
@@ -134,6 +212,17 @@ class Messages {
                                      const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC,
                                      const std::function<void(const std::vector<MsgPtr> &)> &prepass = nullptr);
   std::vector<MsgPtr> GetMostRoundChangeMessages(uint64_t minRound, uint64_t height);
+  // ---- rows (LeanRow above).  A (type, height, round) holds EITHER rows or objects: AddLean refuses (false) while objects
+  // are stored for the view or its rows were judged against other epochs; every object-level access materialises the rows first.
+  bool AddLean(uint32_t type, uint64_t height, uint64_t round, const LeanRow &row, const std::shared_ptr<const void> &backing,
+               uint32_t closure_epoch, uint32_t valset_epoch);
+  // the view's rows when it is held as rows AND they were judged against these epochs; otherwise the rows (if any) are
+  // materialised and nullptr is returned.  The pointer is valid until the next call that touches the view.
+  LeanView *LeanFor(const View &view, MessageType type, uint32_t closure_epoch, uint32_t valset_epoch);
+  // prune the rows f rejects (hooks fire, as for GetValidMessages); returns the survivors' count
+  size_t FilterLean(const View &view, MessageType type, const std::function<bool(const LeanRow &)> &f);
+  void MaterializeAll();  // every view held as rows becomes objects (validator set changed: the rows' verdicts are void)
+  std::vector<bytes> SendersOf(const View &view, MessageType type);  // distinct senders of a view, rows or objects
 
  private:
   using protoMessages = SenderMap;                           // sender -> message
@@ -145,6 +234,8 @@ class Messages {
     uint64_t height = 0, round = 0;
   };
   LastView last_[4];  // where the senders of the view of the last AddMessage are (per type)
+  std::map<std::pair<uint64_t, uint64_t>, LeanView> lean_[4];  // (height, round) → rows; only PREPARE / COMMIT are ever used
+  void materialize_locked(int s, uint64_t height, uint64_t round);  // mux_[s] held
   std::shared_mutex mux_[4];
   SenderHook sender_hook_;
   HeightHook height_hook_;

@@ -409,6 +409,8 @@ bytes encode(const IbftMessage &m, bool with_signature) {
 
 Peek peek(const uint8_t *p, size_t n) {
   Peek out;
+  bool repeated = false, payload_plain = true, seen_twice[9] = {false};
+  int views = 0;
   Reader r{p, p + n};
   while (r.p < r.end) {
     uint64_t tag;
@@ -420,6 +422,7 @@ Peek peek(const uint8_t *p, size_t n) {
     if (num == 1 && wt == 2) {
       if (!r.len_delim(q, l)) return out;
       out.has_view = true;
+      views++;
       Reader vr{q, q + l};
       while (vr.p < vr.end) {
         uint64_t vt;
@@ -444,13 +447,45 @@ Peek peek(const uint8_t *p, size_t n) {
       }
     } else if ((num == 2 || num == 3) && wt == 2) {
       if (!r.len_delim(q, l)) return out;
+      uint32_t &o = num == 2 ? out.from_off : out.sig_off, &n_ = num == 2 ? out.from_len : out.sig_len;
+      if (n_ || seen_twice[num]) repeated = true;
+      seen_twice[num] = true;
+      o = (uint32_t)(q - p);
+      n_ = (uint32_t)l;
     } else if (num == 4 && wt == 0) {
       if (!r.varint(v)) return out;
       out.type = (uint32_t)v;
     } else if (num >= 5 && num <= 8 && wt == 2) {
       if (!r.len_delim(q, l)) return out;
+      if (out.kind != PayloadKind::NONE) repeated = true;
       out.kind = num == 5 ? PayloadKind::PREPREPARE : num == 6 ? PayloadKind::PREPARE
                  : num == 7 ? PayloadKind::COMMIT : PayloadKind::ROUND_CHANGE;
+      if (num == 6 || num == 7) {  // PrepareMessage {1: proposalHash} / CommitMessage {1: proposalHash, 2: committedSeal}
+        Reader pr{q, q + l};
+        bool h_seen = false, s_seen = false;
+        while (pr.p < pr.end) {
+          uint64_t pt;
+          const uint8_t *fq;
+          size_t fl;
+          if (!pr.varint(pt)) return out;
+          if (pt == ((1u << 3) | 2)) {
+            if (!pr.len_delim(fq, fl)) return out;
+            if (h_seen) repeated = true;
+            h_seen = true;
+            out.hash_off = (uint32_t)(fq - p);
+            out.hash_len = (uint32_t)fl;
+          } else if (num == 7 && pt == ((2u << 3) | 2)) {
+            if (!pr.len_delim(fq, fl)) return out;
+            if (s_seen) repeated = true;
+            s_seen = true;
+            out.seal_off = (uint32_t)(fq - p);
+            out.seal_len = (uint32_t)fl;
+          } else {
+            payload_plain = false;  // a wrong wire type or an unknown field: the decoder decides
+            break;
+          }
+        }
+      }
     } else if (num >= 1 && num <= 8) {
       return out;  // known field with the wrong wire type
     } else {
@@ -464,6 +499,7 @@ Peek peek(const uint8_t *p, size_t n) {
     }
   }
   out.ok = true;
+  out.simple = !repeated && payload_plain && views <= 1;
   return out;
 }
 

@@ -152,6 +152,12 @@ struct Peek {
   uint64_t height = 0, round = 0;
   uint32_t type = PREPREPARE;
   PayloadKind kind = PayloadKind::NONE;
+  // where the byte fields of a PREPARE / COMMIT lie (offsets from the message's first byte; length 0 = absent), for a
+  // message whose fields occur ONCE (what a canonical encoding guarantees): From, Signature, the payload's proposalHash
+  // and committedSeal.  simple = false when a field repeats or the payload holds anything else (the row is then not kept
+  // as a row: it is decoded).
+  uint32_t from_off = 0, from_len = 0, sig_off = 0, sig_len = 0, hash_off = 0, hash_len = 0, seal_off = 0, seal_len = 0;
+  bool simple = false;
 };
 Peek peek(const uint8_t *p, size_t n);
 // a heap copy of [p, p + n) to decode into (one allocation)
@@ -163,7 +169,8 @@ bool decode(const uint8_t *p, size_t n, Proposal &out);
 // A null pointer return mirrors a nil []byte / nil pointer in the reference.
 struct CommittedSeal {  // messages/helpers.go:15-19
   bytes signer, signature;
-  MsgPtr keep;  // set by extract_committed_seals: signer / signature are views into this message
+  MsgPtr keep;  // set by extract_committed_seals: signer / signature are views into this message …
+  std::shared_ptr<const void> keep_buf;  // … or into this buffer (a seal read off a message that is kept as a row)
 };
 const bytes *extract_commit_hash(const IbftMessage &m);        // helpers.go:51-62
 std::optional<CommittedSeal> extract_committed_seal(const IbftMessage &m);  // helpers.go:38-48

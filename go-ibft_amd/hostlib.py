@@ -128,6 +128,8 @@ def lib() -> C.CDLL:
                    'ibft_host_loop_batch_cert_calls'):
             getattr(L, nm).argtypes = [vp]; getattr(L, nm).restype = C.c_size_t
         L.ibft_host_use_certs.argtypes = [vp, C.c_int]; L.ibft_host_use_certs.restype = None
+        L.ibft_host_use_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rows.restype = None
+        L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
         L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
         L.ibft_host_handle_preprepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         _lib = L
@@ -469,6 +471,14 @@ class Host:
 
     def use_certs(self, on: bool):
         self.L.ibft_host_use_certs(self.h, 1 if on else 0)
+
+    def use_rows(self, on: bool):
+        """Keep the PREPARE / COMMIT messages a batch backend judged from their bytes as rows (default) or as objects."""
+        self.L.ibft_host_use_rows(self.h, 1 if on else 0)
+
+    @property
+    def rows_kept(self) -> int:
+        return int(self.L.ibft_host_rows_kept(self.h))
 
     def cert_stats(self):
         """(certificate calls made by ingest, rows they judged, sender verdicts the last certificate walk took from the tables)"""

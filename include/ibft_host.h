@@ -175,6 +175,17 @@ size_t ibft_host_loop_batch_set_calls(ibft_host *h);
  * route, per message.  use_certs(0) = off.  cert_stats: certificate calls made by ingest, rows (messages, nested ones
  * included) they judged, sender verdicts the last certificate walk took from the tables.                               */
 void ibft_host_use_certs(ibft_host *h, int on);
+/* Rows instead of objects (default on; needs the quorum index, use_sets, the accepted proposal and a batch backend): a
+ * PREPARE / COMMIT of the current view that the backend judged completely FROM ITS BYTES (ibft_verify_messages_wire: the
+ * canonical encoding, IsValidValidator, the handlePrepare / handleCommit closure) is stored as a row — where its bytes
+ * lie, where From / proposalHash / committedSeal are inside them, its closure verdict — and never decoded;
+ * handlePrepare / handleCommit filter the rows, the quorum comes from the index, the committed seals are read off the
+ * bytes.  Anything that asks the store for OBJECTS (store_* accessors, the per-message walks, a validator-set or proposal
+ * change) turns the view's rows into objects first, verdicts noted: the answers are the same either way
+ * (tests/test_host_rows.py).  use_rows(0) = every message becomes an object on arrival.  rows_kept: messages stored as
+ * rows so far.                                                                                                        */
+void ibft_host_use_rows(ibft_host *h, int on);
+size_t ibft_host_rows_kept(ibft_host *h);
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits);
 size_t ibft_host_loop_batch_cert_calls(ibft_host *h);
 /* handlePrePrepare (core/ibft.go:792-813): 1 = a stored PREPREPARE of (height, round) passes validateProposal0 (round 0) /
