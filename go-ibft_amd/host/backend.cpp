@@ -700,47 +700,58 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   std::vector<uint8_t> cand(lean_mode ? n : 0, 0), as_row(lean_mode ? n : 0, 0);
   std::vector<LeanRow> lrow(lean_mode ? n : 0);
   std::vector<uint8_t> ptype(n, 0xFF);
-  std::vector<Seen> again;                  // stored rows delivered again
+  struct Again {
+    uint32_t type;
+    LeanRow row;
+    std::shared_ptr<const void> backing;
+  };
+  std::vector<Again> again;                 // stored rows delivered again
   std::vector<int32_t> again_at(n, -1);
   std::vector<size_t> ask;                  // rows the device has to judge: first occurrence of each distinct new message
-  std::unordered_map<uint64_t, size_t> first_in_batch;
-  first_in_batch.reserve(n * 2);
+  // repeats inside the batch: an open-addressing table over the fingerprints (entry = row + 1)
+  size_t fib_mask = 63;
+  while (fib_mask + 1 < 2 * n) fib_mask = fib_mask * 2 + 1;
+  std::vector<uint32_t> fib(fib_mask + 1, 0);
+  auto first_in_batch = [&](size_t i, const uint8_t *row, size_t len) -> int32_t {  // the earlier row with these bytes, or −1 (and i is entered)
+    for (size_t sl = fp1[i] & fib_mask;; sl = (sl + 1) & fib_mask) {
+      const uint32_t e = fib[sl];
+      if (e == 0) {
+        fib[sl] = (uint32_t)i + 1;
+        return -1;
+      }
+      const size_t f = e - 1;
+      if (fp1[f] == fp1[i] && fp2[f] == fp2[i] && off[f + 1] - off[f] == len && memcmp(wire + off[f], row, len) == 0) return (int32_t)f;
+    }
+  };
+  // the rows already stored for the current view, per type: the store itself remembers them (a re-delivery is the sender's
+  // row with the same bytes), so rows need no entry in seen_
+  LeanView *stored_rows[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (lean_mode) {
+    View cur;
+    cur.height = height;
+    cur.round = round;
+    stored_rows[PREPARE] = messages.LeanFor(cur, PREPARE, closure_epoch_, valset_epoch_);
+    stored_rows[COMMIT] = messages.LeanFor(cur, COMMIT, closure_epoch_, valset_epoch_);
+  }
   for (size_t i = 0; i < n; i++) {
     const uint8_t *row = wire + off[i];
     const size_t len = off[i + 1] - off[i];
     fingerprint(row, len, fp_seed_, fp1[i], fp2[i]);
-    auto hit = seen_.find(fp1[i]);
-    if (hit != seen_.end() && hit->second.fp2 == fp2[i] && hit->second.len == len && memcmp(hit->second.wire, row, len) == 0) {
-      const Seen &sn = hit->second;
-      if (!sn.lean) {
-        msgs[i] = sn.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
+    if (!seen_.empty()) {
+      auto hit = seen_.find(fp1[i]);
+      if (hit != seen_.end() && hit->second.fp2 == fp2[i] && hit->second.len == len && memcmp(hit->second.wire, row, len) == 0) {
+        msgs[i] = hit->second.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
         verdict[i] = 1;
         st.cache_hits++;
         continue;
       }
-      if (sn.closure_epoch == closure_epoch_ && sn.valset_epoch == valset_epoch_) {
-        // a stored row: stored again (its sender's row is overwritten by itself), if its view is still acceptable
+    }
+    if (!seen_rejected_.empty()) {
+      auto rej = seen_rejected_.find(fp1[i]);
+      if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
+        verdict[i] = 0;  // rejected before (the reference would judge it again — and reject it again)
         st.cache_hits++;
-        ptype[i] = (uint8_t)sn.type;
-        verdict[i] = 2;  // stored again below, in arrival order
-        again_at[i] = (int32_t)again.size();
-        again.push_back(sn);
-        continue;
-      }
-      seen_.erase(hit);  // judged against another proposal / validator set: a new message
-    }
-    auto rej = seen_rejected_.find(fp1[i]);
-    if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
-      verdict[i] = 0;  // rejected before (the reference would judge it again — and reject it again)
-      st.cache_hits++;
-      results[i] = 0;
-      continue;
-    }
-    auto ins = first_in_batch.emplace(fp1[i], i);
-    if (!ins.second) {
-      const size_t f = ins.first->second;
-      if (fp2[f] == fp2[i] && off[f + 1] - off[f] == len && memcmp(wire + off[f], row, len) == 0) {
-        dup_of[i] = (int32_t)f;
+        results[i] = 0;
         continue;
       }
     }
@@ -750,11 +761,22 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     // isAcceptableMessage (core/ibft.go:1133-1148).  (Membership of From is the Backend's business — a mock accepts anybody
     // — so it is NOT pre-judged here; the device rejects a non-member like any other bad signature.)
     const Peek pk = peek(row, len);
-    if (!pk.ok) continue;
-    kinds[i] = (uint8_t)pk.kind;
-    ptype[i] = (uint8_t)(pk.type <= 3 ? pk.type : 0xFE);
-    if (lean_mode && pk.simple && pk.from_len && pk.has_view && pk.height == height && pk.round == round &&
+    if (pk.ok && lean_mode && pk.simple && pk.from_len && pk.has_view && pk.height == height && pk.round == round &&
         ((pk.type == PREPARE && pk.kind == PayloadKind::PREPARE) || (pk.type == COMMIT && pk.kind == PayloadKind::COMMIT))) {
+      kinds[i] = (uint8_t)pk.kind;
+      ptype[i] = (uint8_t)pk.type;
+      if (const LeanView *lv = stored_rows[pk.type]) {
+        const LeanRow *was = lv->find(std::string_view((const char *)row + pk.from_off, pk.from_len));
+        if (was && was->len == len && memcmp(was->wire, row, len) == 0) {
+          // a stored row delivered again: stored again below, in arrival order (its sender's row is overwritten by itself)
+          st.cache_hits++;
+          verdict[i] = 2;
+          again_at[i] = (int32_t)again.size();
+          again.push_back(Again{pk.type, *was, lv->buffers[was->buf]});
+          continue;
+        }
+      }
+      if ((dup_of[i] = first_in_batch(i, row, len)) >= 0) continue;
       cand[i] = 1;
       LeanRow &lr = lrow[i];
       lr.wire = row;
@@ -765,6 +787,10 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       ask.push_back(i);
       continue;
     }
+    if ((dup_of[i] = first_in_batch(i, row, len)) >= 0) continue;
+    if (!pk.ok) continue;
+    kinds[i] = (uint8_t)pk.kind;
+    ptype[i] = (uint8_t)(pk.type <= 3 ? pk.type : 0xFE);
     to_decode.push_back(i);
     const bool view_ok = pk.has_view && !(height > pk.height) && !(height == pk.height && pk.round < round);
     if (use_batch && batch && !view_ok) {
@@ -993,14 +1019,22 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   };
   // IBFT.AddMessage per message, in arrival order, with the verdict attached; what was stored is remembered for its
   // re-deliveries, what was rejected by its fingerprint
+  // (consecutive rows of one type are stored as a run: one lock, one look at the counters — addLeanRun)
+  std::vector<const LeanRow *> run_rows;
+  std::vector<size_t> run_at;
+  uint32_t run_type = 0;
+  auto flush_run = [&]() {
+    if (run_rows.empty()) return;
+    addLeanRun(run_type, run_rows, run_at, backing, results);
+    run_rows.clear();
+    run_at.clear();
+  };
   for (size_t i = 0; i < n; i++) {
-    if (verdict[i] == 2) {  // a stored row delivered again: its sender's row is overwritten by itself, if its view is still acceptable
+    if (verdict[i] == 2) {  // a stored row of the current view delivered again
+      flush_run();
       if (types) types[i] = ptype[i];
-      const Seen &sn = again[(size_t)again_at[i]];
-      if (height > sn.height || (height == sn.height && sn.round < round))
-        results[i] = 0;
-      else
-        results[i] = (int8_t)addLeanRow(sn.type, sn.height, sn.round, sn.row, sn.backing);
+      const Again &sn = again[(size_t)again_at[i]];
+      results[i] = (int8_t)addLeanRow(sn.type, height, round, sn.row, sn.backing);
       continue;
     }
     size_t src = i;
@@ -1012,25 +1046,17 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     if (lean_mode && cand[src]) {  // judged from its bytes, never decoded
       if (types) types[i] = ptype[src];
       if (!as_row[src]) {
-        results[i] = 0;  // IsValidValidator failed (isAcceptableMessage, core/ibft.go:1128)
+        results[i] = 0;  // IsValidValidator failed (isAcceptableMessage, core/ibft.go:1128): the store is not touched
+        if (src == i) remember_rejected(i);
       } else {
-        results[i] = (int8_t)addLeanRow(ptype[src], height, round, lrow[src], backing);
-        if (src == i && results[i] > 0) {
-          if (seen_.size() >= seen_cap) seen_.clear();
-          Seen sn{fp2[i], nullptr, wire + off[i], off[i + 1] - off[i], height};
-          sn.lean = true;
-          sn.type = ptype[i];
-          sn.round = round;
-          sn.row = lrow[i];
-          sn.backing = backing;
-          sn.closure_epoch = closure_epoch_;
-          sn.valset_epoch = valset_epoch_;
-          seen_[fp1[i]] = std::move(sn);
-        }
+        if (!run_rows.empty() && run_type != ptype[src]) flush_run();
+        run_type = ptype[src];
+        run_rows.push_back(&lrow[src]);
+        run_at.push_back(i);
       }
-      if (src == i && results[i] == 0) remember_rejected(i);
       continue;
     }
+    flush_run();
     if (!msgs[i]) continue;
     if (types) types[i] = (uint8_t)(msgs[i]->type <= 3 ? msgs[i]->type : 0xFE);
     if (verdict[i] == 1) noteSender(*msgs[i], true);
@@ -1045,6 +1071,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       remember_rejected(i);
     }
   }
+  flush_run();
   if (stats) *stats = st;
   return true;
 }
@@ -1098,6 +1125,55 @@ int HotPath::addLeanRow(uint32_t type, uint64_t h, uint64_t r, const LeanRow &ro
   v.height = h;
   v.round = r;
   return quorumProbe(type, v);
+}
+
+// addLeanRow for a run of rows of the current view: the counters of the view are read once, moved per row while the store
+// takes the rows under one lock, and written back once; results[at[k]] = 1 / 2 as AddMessage would have signalled after row k.
+void HotPath::addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows, const std::vector<size_t> &at,
+                         const std::shared_ptr<const void> &backing, int8_t *results) {
+  View v;
+  v.height = height;
+  v.round = round;
+  auto rebuild = [&]() { return messages.SendersOf(v, (MessageType)type); };
+  auto pc = quorumIndex.Get(type, height, round, rebuild, validatorManager);
+  unsigned __int128 power = pc.first, dpower = 0;
+  size_t dcount = 0;
+  const bool vm_ok = validatorManager.initialized();
+  const unsigned __int128 quorum = vm_ok ? validatorManager.quorum() : 0;
+  // HasPrepareQuorum: the proposer's power joins the set; a PREPARE from the proposer voids it
+  std::string_view proposer;
+  unsigned __int128 w_proposer = 0;
+  if (type == PREPARE && proposalMessage) {
+    proposer = std::string_view(proposalMessage->from.data(), proposalMessage->from.size());
+    w_proposer = validatorManager.powerOf(proposer);
+  }
+  int proposer_prepared = -1;  // not looked at yet
+  const size_t taken = messages.AddLeanRun(
+      type, height, round, rows.data(), rows.size(), backing, closure_epoch_, valset_epoch_,
+      [&](size_t k, bool fresh, const LeanView &lv) {
+        if (fresh) {
+          const std::string_view from = rows[k]->from();
+          const uint64_t w = validatorManager.powerOf(from);
+          power += w;
+          dpower += w;
+          dcount++;
+          if (proposer_prepared == 0 && from == proposer) proposer_prepared = 1;
+        }
+        bool q = false;
+        if (type == COMMIT) {
+          q = vm_ok && power >= quorum;
+        } else if (proposalMessage && vm_ok && power + w_proposer >= quorum) {
+          if (proposer_prepared < 0) proposer_prepared = lv.contains(proposer) ? 1 : 0;
+          q = proposer_prepared == 0;
+        }
+        results[at[k]] = q ? 2 : 1;
+      });
+  if (taken == 0) {  // the view is held as objects: message by message
+    for (size_t k = 0; k < rows.size(); k++) results[at[k]] = (int8_t)addLeanRow(type, height, round, *rows[k], backing);
+    return;
+  }
+  quorumIndex.Add(type, height, round, dpower, dcount);
+  lean_rows += taken;
 }
 
 // handlePrepare / handleCommit over a view that is held as rows: the closure verdicts came with the rows, so the walk is

@@ -303,20 +303,16 @@ class HotPath {
   // re-delivery of a rejected one by its fingerprint alone, from a bounded FIFO.
   struct Seen {
     uint64_t fp2;
-    MsgPtr msg;           // the stored message (keeps its bytes: wire / len point into its backing); null for a row
+    MsgPtr msg;           // the stored message (keeps its bytes: wire / len point into its backing)
     const uint8_t *wire;
     uint32_t len;
     uint64_t height;
-    // a message stored as a row: what is needed to store it again (a re-delivery overwrites its sender's row)
-    bool lean = false;
-    uint32_t type = 0;
-    uint64_t round = 0;
-    LeanRow row{};
-    std::shared_ptr<const void> backing;
-    uint32_t closure_epoch = 0, valset_epoch = 0;  // what the row's verdicts were computed against
   };
+  // (a message stored as a ROW needs no entry: the store finds its sender's row and compares the bytes)
   // IBFT.AddMessage for a message kept as a row (sender and view already accepted): store + quorum probe
   int addLeanRow(uint32_t type, uint64_t h, uint64_t r, const LeanRow &row, const std::shared_ptr<const void> &backing);
+  void addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows, const std::vector<size_t> &at,
+                  const std::shared_ptr<const void> &backing, int8_t *results);
   int quorumProbe(uint32_t type, const View &view);  // the 1 / 2 of AddMessageFast, from the quorum index
   bool handleLean(const View &view, MessageType type, bool &quorum);  // true = the view was held as rows and is handled
   std::unordered_map<uint64_t, Seen> seen_;

@@ -190,8 +190,27 @@ class bytes {
   char inl_[kInline];
 };
 
+// hash of a short key (an address): 8 bytes at a time, multiply-fold
+inline uint64_t hash_key(const char *p, size_t n) noexcept {
+  uint64_t h = (uint64_t)n * 0x9E3779B97F4A7C15ull;
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+    p += 8;
+    n -= 8;
+  }
+  if (n) {
+    uint64_t w = 0;
+    memcpy(&w, p, n);
+    h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+    h ^= h >> 29;
+  }
+  return h;
+}
 struct bytes_hash {
-  size_t operator()(const bytes &b) const noexcept { return std::hash<std::string_view>()(std::string_view(b.data(), b.size())); }
+  size_t operator()(const bytes &b) const noexcept { return (size_t)hash_key(b.data(), b.size()); }
 };
 
 }  // namespace ibft

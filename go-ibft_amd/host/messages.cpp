@@ -209,6 +209,31 @@ bool Messages::AddLean(uint32_t type, uint64_t height, uint64_t round, const Lea
   return true;
 }
 
+size_t Messages::AddLeanRun(uint32_t type, uint64_t height, uint64_t round, const LeanRow *const *rows, size_t n,
+                            const std::shared_ptr<const void> &backing, uint32_t closure_epoch, uint32_t valset_epoch,
+                            const std::function<void(size_t, bool, const LeanView &)> &after) {
+  int s = slot(type);
+  if (s != PREPARE && s != COMMIT) return 0;
+  std::unique_lock lk(mux_[s]);
+  auto it = lean_[s].find({height, round});
+  if (it == lean_[s].end()) {
+    auto h = maps_[s].find(height);
+    if (h != maps_[s].end()) {
+      auto r = h->second.find(round);
+      if (r != h->second.end() && r->second.size() != 0) return 0;  // the view is held as objects
+    }
+    it = lean_[s].emplace(std::make_pair(height, round), LeanView{}).first;
+    it->second.closure_epoch = closure_epoch;
+    it->second.valset_epoch = valset_epoch;
+  } else if (it->second.closure_epoch != closure_epoch || it->second.valset_epoch != valset_epoch) {
+    materialize_locked(s, height, round);
+    return 0;
+  }
+  LeanView &lv = it->second;
+  for (size_t k = 0; k < n; k++) after(k, lv.put(*rows[k], backing), lv);
+  return n;
+}
+
 LeanView *Messages::LeanFor(const View &view, MessageType type, uint32_t closure_epoch, uint32_t valset_epoch) {
   int s = slot(type);
   if (s < 0) return nullptr;
@@ -277,9 +302,18 @@ bool ValidatorManager::Init(const std::vector<std::pair<bytes, uint64_t>> &power
   for (auto &kv : p) total += kv.second;
   if (total == 0) return false;  // errVotingPowerNotCorrect: state is left unchanged
   power_ = std::move(p);
-  fast_.clear();
-  fast_.reserve(power_.size() * 2);
-  for (auto &kv : power_) fast_.emplace(kv.first, kv.second);
+  seat_addr_.clear();
+  seat_power_.clear();
+  size_t slots = 64;
+  while (slots < power_.size() * 4) slots <<= 1;
+  seat_slot_.assign(slots, 0);
+  for (auto &kv : power_) {
+    seat_addr_.push_back(kv.first);
+    seat_power_.push_back(kv.second);
+    size_t sl = hash_key(kv.first.data(), kv.first.size()) & (slots - 1);
+    while (seat_slot_[sl] != 0) sl = (sl + 1) & (slots - 1);
+    seat_slot_[sl] = (uint32_t)seat_addr_.size();
+  }
   quorum_ = (total * 2) / 3 + 1;  // calculateQuorum :130-135
   initialized_ = true;
   return true;
@@ -327,6 +361,13 @@ void QuorumIndex::OnSender(uint32_t type, uint64_t height, uint64_t round, const
   }
 }
 
+void QuorumIndex::Add(uint32_t type, uint64_t height, uint64_t round, unsigned __int128 dpower, size_t dcount) {
+  std::lock_guard<std::mutex> lk(mu_);
+  Entry *e = find(type, height, round);
+  if (!e || !e->valid || e->epoch != epoch_) return;  // stale: rebuilt on demand
+  e->power += dpower;
+  e->count += dcount;
+}
 void QuorumIndex::OnPrune(uint64_t below_height) {
   std::lock_guard<std::mutex> lk(mu_);
   for (auto it = e_.begin(); it != e_.end();)

@@ -122,11 +122,17 @@ class LeanView {
   std::vector<std::shared_ptr<const void>> buffers;
   size_t size() const { return live_; }
   bool contains(std::string_view from) const { return locate(from) != npos; }
+  const LeanRow *find(std::string_view from) const {
+    const size_t at = locate(from);
+    return at == npos ? nullptr : &rows_[at];
+  }
   // insert, or replace the row of the same sender; true = a new sender
   bool put(LeanRow row, const std::shared_ptr<const void> &backing) {
     if (buffers.empty() || buffers.back() != backing) buffers.push_back(backing);
     row.buf = (uint32_t)buffers.size() - 1;
-    const size_t at = locate(row.from());
+    const std::string_view from = row.from();
+    const uint64_t h = hash_key(from.data(), from.size());
+    const size_t at = locate(from, h);
     if (at != npos) {
       rows_[at] = row;
       return false;
@@ -134,7 +140,7 @@ class LeanView {
     if ((rows_.size() + 1) * 2 > index_.size()) rebuild(std::max<size_t>(64, (rows_.size() + 1) * 4));
     rows_.push_back(row);
     dead_.push_back(0);
-    link(rows_.size() - 1);
+    link(rows_.size() - 1, h);
     live_++;
     return true;
   }
@@ -154,18 +160,19 @@ class LeanView {
 
  private:
   static constexpr size_t npos = (size_t)-1;
-  size_t locate(std::string_view from) const {
+  size_t locate(std::string_view from) const { return locate(from, hash_key(from.data(), from.size())); }
+  size_t locate(std::string_view from, uint64_t h) const {
     if (index_.empty()) return npos;
     const size_t mask = index_.size() - 1;
-    for (size_t s = std::hash<std::string_view>()(from) & mask;; s = (s + 1) & mask) {
+    for (size_t s = h & mask;; s = (s + 1) & mask) {
       const uint32_t e = index_[s];
       if (e == 0) return npos;
       if (!dead_[e - 1] && rows_[e - 1].from() == from) return e - 1;
     }
   }
-  void link(size_t i) {
+  void link(size_t i, uint64_t h) {
     const size_t mask = index_.size() - 1;
-    size_t s = std::hash<std::string_view>()(rows_[i].from()) & mask;
+    size_t s = h & mask;
     while (index_[s] != 0) s = (s + 1) & mask;
     index_[s] = (uint32_t)(i + 1);
   }
@@ -174,7 +181,10 @@ class LeanView {
     while (n < slots) n <<= 1;
     index_.assign(n, 0);
     for (size_t i = 0; i < rows_.size(); i++)
-      if (!dead_[i]) link(i);
+      if (!dead_[i]) {
+        const std::string_view f = rows_[i].from();
+        link(i, hash_key(f.data(), f.size()));
+      }
   }
   std::vector<LeanRow> rows_;
   std::vector<uint8_t> dead_;
@@ -216,6 +226,12 @@ class Messages {
   // are stored for the view or its rows were judged against other epochs; every object-level access materialises the rows first.
   bool AddLean(uint32_t type, uint64_t height, uint64_t round, const LeanRow &row, const std::shared_ptr<const void> &backing,
                uint32_t closure_epoch, uint32_t valset_epoch);
+  // A run of rows of ONE view under one lock.  after(k, new_sender, view_rows) is called for every row once it is stored
+  // (the sender hook is NOT called: the caller keeps the counters of a run itself).  Returns the rows taken: 0 when the
+  // view is held as objects or was judged against other epochs (the caller stores those messages one by one).
+  size_t AddLeanRun(uint32_t type, uint64_t height, uint64_t round, const LeanRow *const *rows, size_t n,
+                    const std::shared_ptr<const void> &backing, uint32_t closure_epoch, uint32_t valset_epoch,
+                    const std::function<void(size_t, bool, const LeanView &)> &after);
   // the view's rows when it is held as rows AND they were judged against these epochs; otherwise the rows (if any) are
   // materialised and nullptr is returned.  The pointer is valid until the next call that touches the view.
   LeanView *LeanFor(const View &view, MessageType type, uint32_t closure_epoch, uint32_t valset_epoch);
@@ -257,15 +273,29 @@ class ValidatorManager {
   bool initialized() const { return initialized_; }
   const std::map<bytes, uint64_t> &powers() const { return power_; }
   // O(1): voting power of `from` (0 for a non-member) and membership
-  uint64_t powerOf(const bytes &from) const {
-    auto it = fast_.find(from);
-    return it == fast_.end() ? 0 : it->second;
+  uint64_t powerOf(const bytes &from) const { return powerOf(std::string_view(from.data(), from.size())); }
+  uint64_t powerOf(std::string_view from) const {
+    const int64_t at = seat(from);
+    return at < 0 ? 0 : seat_power_[(size_t)at];
   }
-  bool isValidator(const bytes &from) const { return fast_.find(from) != fast_.end(); }
+  bool isValidator(const bytes &from) const { return seat(std::string_view(from.data(), from.size())) >= 0; }
 
  private:
   std::map<bytes, uint64_t> power_;
-  std::unordered_map<bytes, uint64_t> fast_;
+  // open addressing over the addresses (slot = seat + 1, 0 = empty): one probe and one 20-byte compare per lookup
+  std::vector<uint32_t> seat_slot_;
+  std::vector<bytes> seat_addr_;
+  std::vector<uint64_t> seat_power_;
+  int64_t seat(std::string_view from) const {
+    if (seat_slot_.empty()) return -1;
+    const size_t mask = seat_slot_.size() - 1;
+    for (size_t s = hash_key(from.data(), from.size()) & mask;; s = (s + 1) & mask) {
+      const uint32_t e = seat_slot_[s];
+      if (e == 0) return -1;
+      const bytes &a = seat_addr_[e - 1];
+      if (a.size() == from.size() && memcmp(a.data(), from.data(), from.size()) == 0) return (int64_t)e - 1;
+    }
+  }
   unsigned __int128 quorum_ = 0;
   bool initialized_ = false;
 };
@@ -279,6 +309,8 @@ class QuorumIndex {
  public:
   void OnSender(uint32_t type, uint64_t height, uint64_t round, const bytes &from, int delta,
                 const ValidatorManager &vm);
+  // the counters of a view moved by (Δpower, Δsenders) — a run of rows stored without the per-sender hook
+  void Add(uint32_t type, uint64_t height, uint64_t round, unsigned __int128 dpower, size_t dcount);
   void OnPrune(uint64_t below_height);
   void Invalidate() { epoch_++; }  // validator set changed: sums are recomputed on next use
   // (Σ power, number of stored senders); `rebuild` lists the view's senders when the entry is stale
