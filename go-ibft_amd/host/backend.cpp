@@ -1112,7 +1112,7 @@ int HotPath::AddMessageFast(MsgPtr m, bool accepted) {
 // answered before (by the backend that judged the bytes, by the look at the view); store, then the quorum probe.
 int HotPath::addLeanRow(uint32_t type, uint64_t h, uint64_t r, const LeanRow &row, const std::shared_ptr<const void> &backing) {
   if (!messages.AddLean(type, h, r, row, backing, closure_epoch_, valset_epoch_)) {
-    // the view is held as objects (somebody asked for them): this message becomes an object too
+    // the view's rows were judged against another proposal / validator set (they are objects now): an object too
     auto m = std::make_shared<IbftMessage>();
     if (!decode_in(backing, row.wire, row.len, *m)) return -1;
     noteSender(*m, true);
@@ -1168,7 +1168,7 @@ void HotPath::addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows
         }
         results[at[k]] = q ? 2 : 1;
       });
-  if (taken == 0) {  // the view is held as objects: message by message
+  if (taken == 0) {  // the view's rows were judged against other epochs: message by message
     for (size_t k = 0; k < rows.size(); k++) results[at[k]] = (int8_t)addLeanRow(type, height, round, *rows[k], backing);
     return;
   }
@@ -1176,48 +1176,57 @@ void HotPath::addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows
   lean_rows += taken;
 }
 
-// handlePrepare / handleCommit over a view that is held as rows: the closure verdicts came with the rows, so the walk is
-// a filter over them; the quorum is the index's (the store's hooks followed the prunes).
+// handlePrepare / handleCommit over a view that holds rows: the rows' closure verdicts came with them, so their walk is a
+// filter; the few objects the view may hold besides (messages the backend did not vouch for byte by byte) take the batch
+// walk; the quorum is the index's (the store's hooks followed the prunes).
 bool HotPath::handleLean(const View &view, MessageType type, bool &quorum) {
   if (!(use_lean && use_sets && index_enabled_ && use_batch && batch)) {
     (void)messages.LeanFor(view, type, 0, 0);  // (epoch 0 never matches: any rows become objects for the generic walk)
     return false;
   }
-  syncClosureKey(getProposal());
+  const Proposal *proposal = getProposal();
+  syncClosureKey(proposal);
   LeanView *lv = messages.LeanFor(view, type, closure_epoch_, valset_epoch_);
   if (!lv) return false;
-  closure_hits = 0;
+  size_t row_hits = 0;
   const size_t left = messages.FilterLean(view, type, [&](const LeanRow &row) {
-    closure_hits++;
+    row_hits++;
     return row.closure != 0;
   });
+  closure_hits = 0;
+  std::vector<MsgPtr> objects = messages.GetValidMessagesBatch(
+      view, type, [&](const std::vector<MsgPtr> &all) { return closureVerdicts(proposal, type, all); }, /*objects_only=*/true);
+  closure_hits += row_hits;
   quorum = false;
   if (validatorManager.initialized()) {
     auto rebuild = [&]() { return messages.SendersOf(view, type); };
     auto pc = quorumIndex.Get(type, view.height, view.round, rebuild, validatorManager);
-    if (pc.second == left) {
-      if (type == PREPARE) {
-        quorum = proposalMessage && !messages.Has(view, PREPARE, proposalMessage->from) &&
-                 pc.first + validatorManager.powerOf(proposalMessage->from) >= validatorManager.quorum();
-      } else {
-        quorum = pc.first >= validatorManager.quorum();
-      }
-    } else {  // (cannot happen: the hooks follow every change) — the generic walk is the authority
+    if (pc.second != left + objects.size()) {  // (cannot happen: the hooks follow every change) — the generic walk is the authority
       (void)messages.LeanFor(view, type, 0, 0);
       return false;
+    }
+    if (type == PREPARE) {
+      quorum = proposalMessage && !messages.Has(view, PREPARE, proposalMessage->from) &&
+               pc.first + validatorManager.powerOf(proposalMessage->from) >= validatorManager.quorum();
+    } else {
+      quorum = pc.first >= validatorManager.quorum();
     }
   }
   if (!quorum) return true;
   if (type == PREPARE) {
-    preparedMessages.clear();
+    preparedMessages = std::move(objects);  // (+ the rows: PreparedWire())
     prepared_as_rows = true;
     prepared_view = view;
     stateName = StateName::commit;
   } else {
-    // ExtractCommittedSeals (messages/helpers.go:22-35): {Signer: From, Signature: committedSeal} of every survivor, read
-    // off the rows' bytes; the seal list keeps the buffers alive
+    // ExtractCommittedSeals (messages/helpers.go:22-35): {Signer: From, Signature: committedSeal} of every survivor — read
+    // off the rows' bytes (the seal list keeps the buffers alive), extracted from the objects
     std::vector<std::optional<CommittedSeal>> seals;
-    seals.reserve(left);
+    if (!extract_committed_seals(objects, seals)) {  // safe check, ibft.go:952-958
+      quorum = false;
+      return true;
+    }
+    seals.reserve(left + objects.size());
     lv = messages.LeanFor(view, type, closure_epoch_, valset_epoch_);
     if (lv)
       lv->for_each([&](const LeanRow &row) {
@@ -1236,9 +1245,10 @@ std::vector<bytes> HotPath::PreparedWire() {
   if (prepared_as_rows) {
     if (LeanView *lv = messages.LeanFor(prepared_view, PREPARE, closure_epoch_, valset_epoch_)) {
       lv->for_each([&](const LeanRow &row) { out.emplace_back((const char *)row.wire, row.len); });
+      for (auto &m : preparedMessages) out.push_back(encode(*m));
       return out;
     }
-    // the rows were materialised meanwhile: the objects of the view are the prepared messages
+    // the rows were turned into objects meanwhile: the objects of the view are the prepared messages
     for (auto &m : messages.GetValidMessages(prepared_view, PREPARE, [](const IbftMessage &) { return true; })) out.push_back(encode(*m));
     return out;
   }

@@ -11,7 +11,11 @@ void Messages::AddMessage(MsgPtr m) {
   if (s < 0 || !m->view) return;  // the reference would panic on an unknown type / nil view
   std::unique_lock lk(mux_[s]);
   const uint64_t h = m->view->height, r = m->view->round;
-  if (!lean_[s].empty()) materialize_locked(s, h, r);
+  bool had_row = false;
+  if (!lean_[s].empty()) {  // the sender's row, if any, is replaced by this object (last writer wins)
+    auto lv = lean_[s].find({h, r});
+    if (lv != lean_[s].end()) had_row = lv->second.erase(std::string_view(m->from.data(), m->from.size()));
+  }
   // consecutive messages mostly belong to one view: remember where its senders are (std::map nodes do not move)
   LastView &lv = last_[s];
   if (!lv.msgs || lv.height != h || lv.round != r) {
@@ -21,7 +25,7 @@ void Messages::AddMessage(MsgPtr m) {
   }
   protoMessages &view_msgs = *lv.msgs;
   const IbftMessage *raw = m.get();
-  if (view_msgs.put(std::move(m))) {  // a new sender (otherwise: last writer wins, sender set unchanged)
+  if (view_msgs.put(std::move(m)) && !had_row) {  // a new sender (otherwise: last writer wins, sender set unchanged)
     if (sender_hook_) sender_hook_((uint32_t)s, h, r, raw->from, +1);
   }
 }
@@ -31,7 +35,7 @@ bool Messages::Has(const View &view, MessageType type, const bytes &from) {
   if (s < 0) return false;
   std::shared_lock lk(mux_[s]);
   auto lv = lean_[s].find({view.height, view.round});
-  if (lv != lean_[s].end()) return lv->second.contains(std::string_view(from.data(), from.size()));
+  if (lv != lean_[s].end() && lv->second.contains(std::string_view(from.data(), from.size()))) return true;
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return false;
   auto r = h->second.find(view.round);
@@ -43,11 +47,11 @@ size_t Messages::numMessages(const View &view, MessageType type) {
   if (s < 0) return 0;
   std::shared_lock lk(mux_[s]);
   auto lv = lean_[s].find({view.height, view.round});
-  if (lv != lean_[s].end()) return lv->second.size();
+  const size_t rows = lv != lean_[s].end() ? lv->second.size() : 0;
   auto h = maps_[s].find(view.height);
-  if (h == maps_[s].end()) return 0;
+  if (h == maps_[s].end()) return rows;
   auto r = h->second.find(view.round);
-  return r == h->second.end() ? 0 : r->second.size();
+  return rows + (r == h->second.end() ? 0 : r->second.size());
 }
 
 void Messages::PruneByHeight(uint64_t height) {
@@ -84,12 +88,12 @@ std::vector<MsgPtr> Messages::GetValidMessages(const View &view, MessageType typ
 }
 
 std::vector<MsgPtr> Messages::GetValidMessagesBatch(const View &view, MessageType type,
-                                                    const BatchPredicate &verdicts) {
+                                                    const BatchPredicate &verdicts, bool objects_only) {
   std::vector<MsgPtr> valid;
   int s = slot(type);
   if (s < 0) return valid;
   std::unique_lock lk(mux_[s]);
-  if (!lean_[s].empty()) materialize_locked(s, view.height, view.round);
+  if (!objects_only && !lean_[s].empty()) materialize_locked(s, view.height, view.round);
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return valid;
   auto r = h->second.find(view.round);
@@ -190,11 +194,6 @@ bool Messages::AddLean(uint32_t type, uint64_t height, uint64_t round, const Lea
   std::unique_lock lk(mux_[s]);
   auto it = lean_[s].find({height, round});
   if (it == lean_[s].end()) {
-    auto h = maps_[s].find(height);
-    if (h != maps_[s].end()) {
-      auto r = h->second.find(round);
-      if (r != h->second.end() && r->second.size() != 0) return false;  // the view is held as objects
-    }
     it = lean_[s].emplace(std::make_pair(height, round), LeanView{}).first;
     it->second.closure_epoch = closure_epoch;
     it->second.valset_epoch = valset_epoch;
@@ -202,11 +201,19 @@ bool Messages::AddLean(uint32_t type, uint64_t height, uint64_t round, const Lea
     materialize_locked(s, height, round);  // judged against another proposal / validator set: objects from here on
     return false;
   }
-  if (it->second.put(row, backing) && sender_hook_) {
-    const std::string_view f = row.from();
+  SenderMap *objs = objects_of(s, height, round);
+  const std::string_view f = row.from();
+  const bool had_object = objs && objs->size() && objs->erase(bytes::view(f.data(), f.size()));
+  if (it->second.put(row, backing) && !had_object && sender_hook_)
     sender_hook_((uint32_t)s, height, round, bytes::view(f.data(), f.size()), +1);
-  }
   return true;
+}
+
+SenderMap *Messages::objects_of(int s, uint64_t height, uint64_t round) {
+  auto h = maps_[s].find(height);
+  if (h == maps_[s].end()) return nullptr;
+  auto r = h->second.find(round);
+  return r == h->second.end() ? nullptr : &r->second;
 }
 
 size_t Messages::AddLeanRun(uint32_t type, uint64_t height, uint64_t round, const LeanRow *const *rows, size_t n,
@@ -217,11 +224,6 @@ size_t Messages::AddLeanRun(uint32_t type, uint64_t height, uint64_t round, cons
   std::unique_lock lk(mux_[s]);
   auto it = lean_[s].find({height, round});
   if (it == lean_[s].end()) {
-    auto h = maps_[s].find(height);
-    if (h != maps_[s].end()) {
-      auto r = h->second.find(round);
-      if (r != h->second.end() && r->second.size() != 0) return 0;  // the view is held as objects
-    }
     it = lean_[s].emplace(std::make_pair(height, round), LeanView{}).first;
     it->second.closure_epoch = closure_epoch;
     it->second.valset_epoch = valset_epoch;
@@ -230,7 +232,17 @@ size_t Messages::AddLeanRun(uint32_t type, uint64_t height, uint64_t round, cons
     return 0;
   }
   LeanView &lv = it->second;
-  for (size_t k = 0; k < n; k++) after(k, lv.put(*rows[k], backing), lv);
+  SenderMap *objs = objects_of(s, height, round);
+  if (objs && objs->size() == 0) objs = nullptr;
+  for (size_t k = 0; k < n; k++) {
+    bool had_object = false;
+    if (objs) {
+      const std::string_view f = rows[k]->from();
+      had_object = objs->erase(bytes::view(f.data(), f.size()));
+    }
+    const bool fresh = lv.put(*rows[k], backing) && !had_object;
+    after(k, fresh, lv);
+  }
   return n;
 }
 
@@ -280,13 +292,11 @@ std::vector<bytes> Messages::SendersOf(const View &view, MessageType type) {
   if (s < 0) return out;
   std::shared_lock lk(mux_[s]);
   auto lv = lean_[s].find({view.height, view.round});
-  if (lv != lean_[s].end()) {
+  if (lv != lean_[s].end())
     lv->second.for_each([&](const LeanRow &row) {
       const std::string_view f = row.from();
       out.emplace_back(f.data(), f.size());
     });
-    return out;
-  }
   auto h = maps_[s].find(view.height);
   if (h == maps_[s].end()) return out;
   auto r = h->second.find(view.round);

@@ -45,6 +45,13 @@ class SenderMap {
     live_++;
     return true;
   }
+  bool erase(const bytes &from) {  // (the slot stays in the index: locate() steps over it, the next compaction drops it)
+    const size_t at = locate(from);
+    if (at == npos) return false;
+    entries_[at].reset();
+    live_--;
+    return true;
+  }
   // visit the live entries in arrival order; f(const MsgPtr &) → false erases the entry
   template <class F>
   void filter(F &&f) {
@@ -122,6 +129,13 @@ class LeanView {
   std::vector<std::shared_ptr<const void>> buffers;
   size_t size() const { return live_; }
   bool contains(std::string_view from) const { return locate(from) != npos; }
+  bool erase(std::string_view from) {
+    const size_t at = locate(from);
+    if (at == npos) return false;
+    dead_[at] = 1;
+    live_--;
+    return true;
+  }
   const LeanRow *find(std::string_view from) const {
     const size_t at = locate(from);
     return at == npos ? nullptr : &rows_[at];
@@ -214,7 +228,10 @@ class Messages {
   // message of the view (under the same per-type lock the reference holds across its
   // callback loop) and returns one verdict per message; rejected ones are deleted.
   using BatchPredicate = std::function<std::vector<uint8_t>(const std::vector<MsgPtr> &)>;
-  std::vector<MsgPtr> GetValidMessagesBatch(const View &view, MessageType type, const BatchPredicate &verdicts);
+  // objects_only: the view's ROWS are left alone (not decoded, not shown to `verdicts`) — the walk over a view that is
+  // held partly as rows judges the rows by their noted verdicts (FilterLean) and only its objects here
+  std::vector<MsgPtr> GetValidMessagesBatch(const View &view, MessageType type, const BatchPredicate &verdicts,
+                                            bool objects_only = false);
   // prepass (optional): called ONCE, under the same lock, with every ROUND-CHANGE message stored for `height`
   // before the walk — lets a batch backend answer all the nested signature / hash questions of the walk with one
   // device call; the walk itself and what it returns are untouched.
@@ -222,13 +239,16 @@ class Messages {
                                      const std::function<bool(uint64_t, const std::vector<MsgPtr> &)> &isValidRCC,
                                      const std::function<void(const std::vector<MsgPtr> &)> &prepass = nullptr);
   std::vector<MsgPtr> GetMostRoundChangeMessages(uint64_t minRound, uint64_t height);
-  // ---- rows (LeanRow above).  A (type, height, round) holds EITHER rows or objects: AddLean refuses (false) while objects
-  // are stored for the view or its rows were judged against other epochs; every object-level access materialises the rows first.
+  // ---- rows (LeanRow above).  A (type, height, round) may hold rows AND objects, a sender in at most one of them (the
+  // last writer wins, as in the reference's map): storing an object drops its sender's row and vice versa, and the sender
+  // hook fires only when the sender is new to the VIEW.  AddLean refuses (false) when the view's rows were judged against
+  // other epochs; the accessors that hand out objects turn the view's rows into objects first.
   bool AddLean(uint32_t type, uint64_t height, uint64_t round, const LeanRow &row, const std::shared_ptr<const void> &backing,
                uint32_t closure_epoch, uint32_t valset_epoch);
   // A run of rows of ONE view under one lock.  after(k, new_sender, view_rows) is called for every row once it is stored
-  // (the sender hook is NOT called: the caller keeps the counters of a run itself).  Returns the rows taken: 0 when the
-  // view is held as objects or was judged against other epochs (the caller stores those messages one by one).
+  // — new_sender: the sender had nothing in the view, neither row nor object (the sender hook is NOT called: the caller
+  // keeps the counters of a run itself).  Returns the rows taken: 0 when the view's rows were judged against other epochs
+  // (they become objects; the caller stores these messages one by one).
   size_t AddLeanRun(uint32_t type, uint64_t height, uint64_t round, const LeanRow *const *rows, size_t n,
                     const std::shared_ptr<const void> &backing, uint32_t closure_epoch, uint32_t valset_epoch,
                     const std::function<void(size_t, bool, const LeanView &)> &after);
@@ -252,6 +272,7 @@ class Messages {
   LastView last_[4];  // where the senders of the view of the last AddMessage are (per type)
   std::map<std::pair<uint64_t, uint64_t>, LeanView> lean_[4];  // (height, round) → rows; only PREPARE / COMMIT are ever used
   void materialize_locked(int s, uint64_t height, uint64_t round);  // mux_[s] held
+  SenderMap *objects_of(int s, uint64_t height, uint64_t round);     // mux_[s] held; nullptr = none
   std::shared_mutex mux_[4];
   SenderHook sender_hook_;
   HeightHook height_hook_;

@@ -266,13 +266,15 @@ def test_extended_rcc_with_quorum_sized_certificates_batch_equals_stock(gpu_veri
     assert len(out[True]) == len(rcs) - 2 and wires[3] not in out[True] and wires[9] not in out[True]
 
 
-@pytest.mark.parametrize("sets", [False, True])
-def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets):
+@pytest.mark.parametrize("sets,rows", [(False, False), (True, False), (True, True)])
+def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets, rows):
     """§8f rank 1 with the real backend.  sets off: a micro-batch of raw messages → one ibft_verify_senders_wire call.
     sets on (default): the same bytes → one ibft_verify_messages_wire call that also settles the handlePrepare /
     handleCommit closure of every PREPARE / COMMIT of the current view (both signatures of a COMMIT in one verdict
-    launch), so handlePrepare / handleCommit then decide without another device call.  Re-delivery → the verdict cache.  Everything equals per-message IBFT.AddMessage and the
-    stock walks with the oracle-backed verifier."""
+    launch), so handlePrepare / handleCommit then decide without another device call.  rows on (default): what the device
+    judged completely is stored as rows and never decoded (include/ibft_host.h: ibft_host_use_rows).  Re-delivery → the
+    verdict cache / the stored row.  Everything equals per-message IBFT.AddMessage and the stock walks with the
+    oracle-backed verifier."""
     import go_ibft_amd.hostlib as H
     r, proposal, prepares, commits = _build_round(oracle, 300, 77, byzantine=True)
     gpu_verifier.set_validators(r.height, r.addrs, r.power)
@@ -287,14 +289,16 @@ def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets):
     ing.attach_gpu(gpu_verifier)
     ing.use_batch(True)
     ing.use_sets(sets)
+    ing.use_rows(rows)
     ing.enable_quorum_index()
     expect = [ref.add_message(x) for x in wires]
-    got, rows, hits, calls = ing.ingest_wire(wires)
-    assert got == expect and (rows, hits, calls) == (len(wires), 0, 1)   # ONE device call for the micro-batch either way
+    got, asked, hits, calls = ing.ingest_wire(wires)
+    assert got == expect and (asked, hits, calls) == (len(wires), 0, 1)   # ONE device call for the micro-batch either way
     assert ing.last_set_rows() >= 0.9 * len(wires) if sets else ing.last_set_rows() == 0
+    assert ing.rows_kept >= 0.8 * sum(1 for x in got if x > 0) if rows else ing.rows_kept == 0
     assert 0 in got and 2 in got
-    again, rows, hits, calls = ing.ingest_wire(wires)
-    assert (rows, hits, calls) == (0, len(wires), 0) and [x != 0 for x in again] == [x != 0 for x in expect]
+    again, asked, hits, calls = ing.ingest_wire(wires)
+    assert (asked, hits, calls) == (0, len(wires), 0) and [x != 0 for x in again] == [x != 0 for x in expect]
     for t in (1, 2):
         assert ref.store_num(r.height, r.round, t) == ing.store_num(r.height, r.round, t)
     okp, prepared = ref.handle_prepare(r.height, r.round)
@@ -306,6 +310,8 @@ def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets):
     assert okc and (okc, sorted(seals)) == (okc2, sorted(seals2))
     for t in (1, 2):
         assert ref.store_num(r.height, r.round, t) == ing.store_num(r.height, r.round, t)
+    for t in (1, 2):
+        assert sorted(ref.store_get_valid(r.height, r.round, t)) == sorted(ing.store_get_valid(r.height, r.round, t))
     if sets:    # every stored message had its closure verdict waiting
         assert hits_p >= len(prepared2) and ing.closure_hits() >= len(seals2)
     else:

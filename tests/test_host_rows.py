@@ -180,3 +180,38 @@ def test_failing_set_call_leaves_the_object_routes():
     assert rows.rows_kept == 0
     _same_answers(rows, objs)
     rows.close(); objs.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_a_view_may_hold_rows_and_objects(seed):
+    """A message the backend does not vouch for byte by byte (here: the type field written twice — it decodes to the same
+    message, it is acceptable, it is not the canonical encoding) is stored as an object in the SAME view as the rows; a sender is in at
+    most one of the two (the last writer wins, whichever form it takes) and is counted once.  One such message does not
+    turn the view's rows into objects."""
+    rng = random.Random(100 + seed)
+    w, ver, proposal, prepares, commits = _world(13, 20 + seed, bad_hash=(2,), forged=(), bad_seal=(3,))
+    odd = lambda m: bytes([0x20, m.type]) + m.encode()                        # field 4 (type) twice: the last one wins
+    traffic = []
+    for k, m in enumerate(prepares + commits):
+        form = rng.choice(["row", "row", "row", "odd", "row-then-odd", "odd-then-row"])
+        traffic += {"row": [m.encode()], "odd": [odd(m)], "row-then-odd": [m.encode(), odd(m)],
+                    "odd-then-row": [odd(m), m.encode()]}[form]
+    rng.shuffle(traffic)
+    rows, objs, stock = _host(w, ver, proposal, True), _host(w, ver, proposal, False), _host(w, ver, proposal, False, batch=False)
+    got_r, got_o, got_s = [], [], []
+    k = 0
+    while k < len(traffic):
+        step = rng.choice([1, 2, 5, 40])
+        got_r += rows.ingest_wire(traffic[k:k + step])[0]
+        got_o += objs.ingest_wire(traffic[k:k + step])[0]
+        got_s += [stock.add_message(x) for x in traffic[k:k + step]]
+        k += step
+        for t in (PR, CM):
+            assert rows.store_num(1, 0, t) == objs.store_num(1, 0, t) == stock.store_num(1, 0, t)
+    assert got_r == got_o == got_s
+    canonical = sum(1 for x in traffic if not x.startswith(b"\x20"))
+    assert rows.rows_kept == canonical                                        # every canonical message went in as a row …
+    _same_answers(rows, objs)
+    _same_answers(rows, stock, fresh=False)
+    for h in (rows, objs, stock):
+        h.close()

@@ -43,7 +43,7 @@ def config3_messages(fx):
     return pp, prepares, commits
 
 
-def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256):
+def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256, rows: bool = True):
     n = len(fx["addrs"])
     h, rnd = int(fx["height"]), int(fx["round"])
     pp, prepares, commits = config3_messages(fx)
@@ -64,6 +64,7 @@ def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256):
             host.attach_gpu(bv)
             host.use_batch(True)
             host.enable_quorum_index()
+            host.use_rows(rows)
             bv.forget_proposal()
             t0 = time.perf_counter()
             sig = 0
@@ -78,6 +79,7 @@ def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256):
             okc, seals_raw = host.handle_commit_raw(h, rnd)
             t4 = time.perf_counter()
             assert okp and okc and sig > 0 and host.fallbacks() == 0
+            kept = host.rows_kept
             if rep == 0:
                 assert sorted(H.unpack_seals(seals_raw)) == want_seals
             host.close()
@@ -104,12 +106,12 @@ def host_mirror_from_wire(V, H, fx, flags: int, reps: int, micro: int = 256):
     out["p10_p90_total_ms"] = [float(x) for x in np.percentile(phases["total"], [10, 90])]
     out["device_two_set_calls_ms"] = float(np.median(dev[3:]))
     out["host_share"] = 1.0 - out["device_two_set_calls_ms"] / out["total"]
-    out.update({"messages": len(prepares) + len(commits), "micro_batch": micro, "reps": reps,
+    out.update({"messages": len(prepares) + len(commits), "micro_batch": micro, "reps": reps, "stored_as_rows": kept,
                 "signatures": 3 * n - 1, "sig_verifies_per_s": (3 * n - 1) / (out["total"] * 1e-3)})
     return out
 
 
-def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_us: int = 0):
+def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_us: int = 0, rows: bool = True):
     """the same height through the mirror's receive-side QUEUE: the transport pushes its micro-batches of 256 as fast as it
     can (ibft_host_queue_push returns at once), the mirror's worker ingests whatever is pending as one batch — the batch
     size adapts to the load — then drain + handlePrepare, the COMMITs the same way, handleCommit, seals out"""
@@ -138,6 +140,7 @@ def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_
             host.attach_gpu(bv)
             host.use_batch(True)
             host.enable_quorum_index()
+            host.use_rows(rows)
             host.queue_start(max_rows=max(n, 1024), linger_us=linger_us)
             bv.forget_proposal()
             t0 = time.perf_counter()
@@ -153,7 +156,7 @@ def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_
             assert okp and okc and st.stored == len(prepares) + len(commits) and host.fallbacks() == 0
             if rep == 0:
                 assert sorted(H.unpack_seals(seals_raw)) == want_seals
-            stats = {"batches": int(st.batches), "device_calls": int(st.device_calls), "max_batch_rows": int(st.max_batch_rows),
+            stats = {"stored_as_rows": host.rows_kept, "batches": int(st.batches), "device_calls": int(st.device_calls), "max_batch_rows": int(st.max_batch_rows),
                      "worker_ingest_ms": st.ingest_us / 1e3, "of_which_device_ms": st.device_us / 1e3}
             host.close()
             if rep >= 3:
@@ -219,7 +222,10 @@ if __name__ == "__main__":
     out = {"config3_cold": host_mirror_from_wire(V, H, fx, 0, 30),
            "config3_warm": host_mirror_from_wire(V, H, fx, V.FLAG_PUBKEY_CACHE, 30),
            "config3_queue_cold": host_mirror_queue(V, H, fx, 0, 30),
-           "config3_queue_warm": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30)}
+           "config3_queue_warm": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30),
+           # the same with every message decoded into an object on arrival (ibft_host_use_rows(0)): what the rows save
+           "config3_cold_objects": host_mirror_from_wire(V, H, fx, 0, 30, rows=False),
+           "config3_queue_warm_objects": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30, rows=False)}
     if "--no-rc" not in sys.argv:
         out["round_change_n256"] = round_change_through_the_mirror(V, H)
     print(json.dumps(out, indent=1))
