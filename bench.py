@@ -628,9 +628,11 @@ def main():
             import host_e2e as E
             import go_ibft_amd.hostlib as HL
             fx = main_leg["rd"]["fx"]
+            HL.retain_heap()        # ibft_host_retain_heap: what a node calls at start-up (freed C heap stays in the process)
             hm = {"definition": "BASELINE config #3 end to end through include/ibft_host.h: 4 095 PREPARE + 4 096 COMMIT wire "
                                 "messages -> ibft_host_ingest_wire (micro-batches of 256) or the mirror's receive queue (adaptive "
-                                "batches) -> handlePrepare -> handleCommit -> seals; a fresh mirror per repetition, p50",
+                                "batches) -> handlePrepare -> handleCommit -> seals; a fresh mirror per repetition, p50; PREPARE / COMMIT "
+                                "messages kept as rows (ibft_host_use_rows), ibft_host_retain_heap called",
                   "micro_batches_cold": E.host_mirror_from_wire(V, HL, fx, 0, 20),
                   "micro_batches_warm": E.host_mirror_from_wire(V, HL, fx, V.FLAG_PUBKEY_CACHE, 20),
                   "queue_cold": E.host_mirror_queue(V, HL, fx, 0, 20),

@@ -2,6 +2,7 @@
 #include "../../include/ibft_host.h"
 
 #include <cstdlib>
+#include <malloc.h>
 #include <cstring>
 #include <algorithm>
 #include <condition_variable>
@@ -613,6 +614,15 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
   h->hp.rejected_cap = rejected_cap;
 }
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
+int ibft_host_retain_heap(size_t bytes) {
+  // glibc: freed memory at the top of the heap above M_TRIM_THRESHOLD goes back to the kernel, blocks above
+  // M_MMAP_THRESHOLD are mapped and unmapped one by one — either way the next height's buffers are fresh pages again
+  const size_t cap = bytes > ((size_t)1 << 30) ? ((size_t)1 << 30) : bytes;
+  int ok = mallopt(M_TRIM_THRESHOLD, (int)cap);
+  ok &= mallopt(M_TOP_PAD, (int)(cap / 8 > ((size_t)64 << 20) ? ((size_t)64 << 20) : cap / 8));
+  ok &= mallopt(M_MMAP_THRESHOLD, (int)(cap > ((size_t)32 << 20) ? ((size_t)32 << 20) : cap));
+  return ok ? 0 : -1;
+}
 void ibft_host_use_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_lean = on != 0; }
 size_t ibft_host_rows_kept(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.lean_rows; }
 void ibft_host_use_certs(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_certs = on != 0; }

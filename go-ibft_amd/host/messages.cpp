@@ -320,9 +320,10 @@ bool ValidatorManager::Init(const std::vector<std::pair<bytes, uint64_t>> &power
   for (auto &kv : power_) {
     seat_addr_.push_back(kv.first);
     seat_power_.push_back(kv.second);
-    size_t sl = hash_key(kv.first.data(), kv.first.size()) & (slots - 1);
+    const uint64_t hk = hash_key(kv.first.data(), kv.first.size());
+    size_t sl = hk & (slots - 1);
     while (seat_slot_[sl] != 0) sl = (sl + 1) & (slots - 1);
-    seat_slot_[sl] = (uint32_t)seat_addr_.size();
+    seat_slot_[sl] = (hk & 0xFFFFFFFF00000000ull) | (uint64_t)seat_addr_.size();
   }
   quorum_ = (total * 2) / 3 + 1;  // calculateQuorum :130-135
   initialized_ = true;

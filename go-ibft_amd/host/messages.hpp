@@ -153,6 +153,7 @@ class LeanView {
     }
     if ((rows_.size() + 1) * 2 > index_.size()) rebuild(std::max<size_t>(64, (rows_.size() + 1) * 4));
     rows_.push_back(row);
+    hash_.push_back(h);
     dead_.push_back(0);
     link(rows_.size() - 1, h);
     live_++;
@@ -175,34 +176,37 @@ class LeanView {
  private:
   static constexpr size_t npos = (size_t)-1;
   size_t locate(std::string_view from) const { return locate(from, hash_key(from.data(), from.size())); }
+  // index entry: the key's hash (upper half) next to the row number + 1 (lower half) — a probe that lands on another
+  // sender's slot is told apart without touching that sender's bytes
   size_t locate(std::string_view from, uint64_t h) const {
     if (index_.empty()) return npos;
     const size_t mask = index_.size() - 1;
+    const uint64_t tag = h & 0xFFFFFFFF00000000ull;
     for (size_t s = h & mask;; s = (s + 1) & mask) {
-      const uint32_t e = index_[s];
+      const uint64_t e = index_[s];
       if (e == 0) return npos;
-      if (!dead_[e - 1] && rows_[e - 1].from() == from) return e - 1;
+      if ((e & 0xFFFFFFFF00000000ull) != tag) continue;
+      const size_t at = (size_t)(e & 0xFFFFFFFFull) - 1;
+      if (!dead_[at] && rows_[at].from() == from) return at;
     }
   }
   void link(size_t i, uint64_t h) {
     const size_t mask = index_.size() - 1;
     size_t s = h & mask;
     while (index_[s] != 0) s = (s + 1) & mask;
-    index_[s] = (uint32_t)(i + 1);
+    index_[s] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)(i + 1);
   }
   void rebuild(size_t slots) {
     size_t n = 64;
     while (n < slots) n <<= 1;
     index_.assign(n, 0);
     for (size_t i = 0; i < rows_.size(); i++)
-      if (!dead_[i]) {
-        const std::string_view f = rows_[i].from();
-        link(i, hash_key(f.data(), f.size()));
-      }
+      if (!dead_[i]) link(i, hash_[i]);
   }
   std::vector<LeanRow> rows_;
+  std::vector<uint64_t> hash_;  // hash_key of each row's sender
   std::vector<uint8_t> dead_;
-  std::vector<uint32_t> index_;
+  std::vector<uint64_t> index_;
   size_t live_ = 0;
 };
 
@@ -303,18 +307,21 @@ class ValidatorManager {
 
  private:
   std::map<bytes, uint64_t> power_;
-  // open addressing over the addresses (slot = seat + 1, 0 = empty): one probe and one 20-byte compare per lookup
-  std::vector<uint32_t> seat_slot_;
+  // open addressing over the addresses: slot = hash (upper half) | seat + 1 (lower half), 0 = empty — one probe and,
+  // on a matching hash, one 20-byte compare per lookup
+  std::vector<uint64_t> seat_slot_;
   std::vector<bytes> seat_addr_;
   std::vector<uint64_t> seat_power_;
   int64_t seat(std::string_view from) const {
     if (seat_slot_.empty()) return -1;
     const size_t mask = seat_slot_.size() - 1;
-    for (size_t s = hash_key(from.data(), from.size()) & mask;; s = (s + 1) & mask) {
-      const uint32_t e = seat_slot_[s];
+    const uint64_t h = hash_key(from.data(), from.size()), tag = h & 0xFFFFFFFF00000000ull;
+    for (size_t s = h & mask;; s = (s + 1) & mask) {
+      const uint64_t e = seat_slot_[s];
       if (e == 0) return -1;
-      const bytes &a = seat_addr_[e - 1];
-      if (a.size() == from.size() && memcmp(a.data(), from.data(), from.size()) == 0) return (int64_t)e - 1;
+      if ((e & 0xFFFFFFFF00000000ull) != tag) continue;
+      const bytes &a = seat_addr_[(size_t)(e & 0xFFFFFFFFull) - 1];
+      if (a.size() == from.size() && memcmp(a.data(), from.data(), from.size()) == 0) return (int64_t)(e & 0xFFFFFFFFull) - 1;
     }
   }
   unsigned __int128 quorum_ = 0;

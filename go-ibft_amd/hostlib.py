@@ -66,6 +66,11 @@ class VerifierCB(C.Structure):
 _lib = None
 
 
+def retain_heap(nbytes: int = 256 << 20) -> bool:
+    """Process-wide (include/ibft_host.h: ibft_host_retain_heap): keep freed C heap instead of returning it to the kernel."""
+    return lib().ibft_host_retain_heap(nbytes) == 0
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -129,6 +134,7 @@ def lib() -> C.CDLL:
             getattr(L, nm).argtypes = [vp]; getattr(L, nm).restype = C.c_size_t
         L.ibft_host_use_certs.argtypes = [vp, C.c_int]; L.ibft_host_use_certs.restype = None
         L.ibft_host_use_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rows.restype = None
+        L.ibft_host_retain_heap.argtypes = [C.c_size_t]; L.ibft_host_retain_heap.restype = C.c_int
         L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
         L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
         L.ibft_host_handle_preprepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]

@@ -184,6 +184,13 @@ void ibft_host_use_certs(ibft_host *h, int on);
  * change) turns the view's rows into objects first, verdicts noted: the answers are the same either way
  * (tests/test_host_rows.py).  use_rows(0) = every message becomes an object on arrival.  rows_kept: messages stored as
  * rows so far.                                                                                                        */
+/* PROCESS-WIDE, optional: keep up to `bytes` of freed C heap in the process (glibc mallopt: M_TRIM_THRESHOLD, M_TOP_PAD,
+ * M_MMAP_THRESHOLD) instead of handing it back to the kernel.  The mirror's memory has the rhythm of the chain — the
+ * messages of a height are stored, then pruned — and with the default thresholds every height's buffers are fresh pages
+ * again: first-touch page faults were ≈25 % of the mirror's own time for a height of config #3.  Call it
+ * once at start-up if the C heap of the process is yours to tune (in a Go node it is: the Go heap is not malloc's).
+ * 0 = set, −1 = the C library refused a value.                                                                        */
+int ibft_host_retain_heap(size_t bytes);
 void ibft_host_use_rows(ibft_host *h, int on);
 size_t ibft_host_rows_kept(ibft_host *h);
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits);

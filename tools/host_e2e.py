@@ -217,6 +217,8 @@ def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
 if __name__ == "__main__":
     import go_ibft_amd.hostlib as H
     import go_ibft_amd.verifier as V
+    if "--no-retain-heap" not in sys.argv:
+        H.retain_heap()                 # what a node would do at start-up (include/ibft_host.h: ibft_host_retain_heap)
     with np.load(os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")) as z:
         fx = {k: z[k] for k in z.files}
     out = {"config3_cold": host_mirror_from_wire(V, H, fx, 0, 30),
@@ -228,4 +230,5 @@ if __name__ == "__main__":
            "config3_queue_warm_objects": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30, rows=False)}
     if "--no-rc" not in sys.argv:
         out["round_change_n256"] = round_change_through_the_mirror(V, H)
+    out["retain_heap"] = "--no-retain-heap" not in sys.argv
     print(json.dumps(out, indent=1))
