@@ -215,7 +215,7 @@ static void nested_messages(const IbftMessage &m, std::vector<MsgPtr> &out) {
   out.clear();
   if (m.kind == PayloadKind::PREPREPARE && m.preprepare().certificate) {
     out = m.preprepare().certificate->round_change_messages;
-  } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().latest_prepared_certificate) {
+  } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().realise_certificate() && m.round_change().latest_prepared_certificate) {
     const PreparedCertificate &pc = *m.round_change().latest_prepared_certificate;
     if (pc.proposal_message) out.push_back(pc.proposal_message);
     out.insert(out.end(), pc.prepare_messages.begin(), pc.prepare_messages.end());
@@ -236,33 +236,29 @@ bool GpuBackend::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off
   if (n == 0) return true;
   const size_t cap = cert_rows_cap, words = (cap + 63) / 64;
   out.nodes.resize(cap);
+  out.rows.resize(cap);
   out.cls.assign(cap, 0);
   std::vector<uint64_t> ms(words, 0), mh(words, 0), mself(words, 0);
   size_t rows = 0;
-  last_rc = ibft_verify_certificates_wire(ctx_, wire, off, n, cap, &rows, out.nodes.data(), nullptr, out.cls.data(), ms.data(),
-                                          mh.data(), mself.data());
+  last_rc = ibft_verify_certificates_wire(ctx_, wire, off, n, cap, &rows, out.nodes.data(), out.rows.data(), out.cls.data(),
+                                          ms.data(), mh.data(), mself.data());
   if (last_rc != IBFT_OK) return false;  // IBFT_E_TOOBIG included: the caller's stock route handles the batch
   out.n_rows = rows;
   out.nodes.resize(rows);
+  out.rows.resize(rows);
   out.cls.resize(rows);
   unpack_mask(ms, rows, out.sender);
   unpack_mask(mh, rows, out.hash);
   unpack_mask(mself, rows, out.self);
   // What the device hands back because ONE sponge would have to absorb it (a message, or a Proposal, beyond
   // IBFT_CERT_DIGEST_MAX_BYTES): hashed here with the library's host Keccak (≈340 MB/s against the 25 MB/s of a wavefront),
-  // the envelope then judged as a (digest, signature, From) row of ibft_verify_seals.  Rare — blocks above 1 MiB — so the
-  // parsed fields (From, carried hashes) are fetched by a second call only when such a row exists.
+  // the envelope then judged as a (digest, signature, From) row of ibft_verify_seals.  Rare — blocks above 1 MiB.
   bool by_host = false;
   for (size_t r = 0; r < rows; r++)
     by_host = by_host || ((out.cls[r] & (IBFT_CERT_CLASS_DIGEST_BY_HOST | IBFT_CERT_CLASS_PROPOSAL_BY_HOST)) &&
                           !(out.cls[r] & IBFT_CERT_CLASS_NEEDS_HOST));
   if (!by_host) return true;
-  std::vector<ibft_wire_row_t> wr(cap);
-  std::vector<uint8_t> cls2(cap, 0);
-  size_t rows2 = 0;
-  if (ibft_verify_certificates_wire(ctx_, wire, off, n, cap, &rows2, nullptr, wr.data(), cls2.data(), ms.data(), mh.data(),
-                                    mself.data()) != IBFT_OK || rows2 != rows)
-    return true;  // the classes stand: the caller's stock route decides those rows
+  const std::vector<ibft_wire_row_t> &wr = out.rows;
   std::vector<size_t> drows;
   std::vector<uint8_t> dg, sg, fr;
   for (size_t r = 0; r < rows; r++) {
@@ -361,12 +357,52 @@ bool LoopBatch::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off,
   out.sender.assign(rows, 0);
   out.hash.assign(rows, 0);
   out.self.assign(rows, 0);
+  out.rows.assign(rows, ibft_wire_row_t{});
+  // like the device, this backend vouches (class 0) only for bytes that ARE the canonical encoding — of the message and of
+  // everything below it: a root whose re-encoding differs from its bytes is handed back, with its whole subtree
+  std::vector<uint8_t> handed_back(rows, 0);
+  for (size_t r = 0; r < rows; r++) {
+    if (r < n && items[r].m) {
+      const bytes again = encode(*items[r].m);
+      handed_back[r] = again.size() != off[r + 1] - off[r] || memcmp(again.data(), wire + off[r], again.size()) != 0;
+    } else if (r >= n) {
+      handed_back[r] = handed_back[out.nodes[r].parent];
+    }
+  }
   for (size_t r = 0; r < rows; r++) {
     if (!items[r].m) {
       out.cls[r] = IBFT_CERT_CLASS_NEEDS_HOST;
       continue;
     }
     const IbftMessage &m = *items[r].m;
+    {  // the parsed fields, as the device reports them
+      ibft_wire_row_t &w = out.rows[r];
+      w.status = IBFT_WIRE_OK;
+      w.has_view = m.view ? 1 : 0;
+      w.height = m.view ? m.view->height : 0;
+      w.round = m.view ? m.view->round : 0;
+      w.type = (uint8_t)(m.type <= 255 ? m.type : 255);
+      w.payload_kind = m.kind == PayloadKind::PREPREPARE ? 5 : m.kind == PayloadKind::PREPARE ? 6 : m.kind == PayloadKind::COMMIT ? 7
+                       : m.kind == PayloadKind::ROUND_CHANGE ? 8 : 0;
+      w.from_len = (uint8_t)(m.from.size() <= 20 ? m.from.size() : 255);
+      if (m.from.size() <= 20) memcpy(w.from, m.from.data(), m.from.size());
+      w.sig_len = (uint8_t)(m.signature.size() < 255 ? m.signature.size() : 255);
+      if (const bytes *ch = carried_hash(m)) {
+        w.hash_len = (uint8_t)(ch->size() <= 32 ? ch->size() : 255);
+        if (ch->size() <= 32) memcpy(w.proposal_hash, ch->data(), ch->size());
+      }
+      if (m.kind == PayloadKind::ROUND_CHANGE) {
+        if (m.round_change().last_prepared_proposal) out.nodes[r].flags |= IBFT_CERT_HAS_PROPOSAL;
+        if (m.round_change().latest_prepared_certificate) out.nodes[r].flags |= IBFT_CERT_HAS_CERTIFICATE;
+      } else if (m.kind == PayloadKind::PREPREPARE) {
+        if (m.preprepare().proposal) out.nodes[r].flags |= IBFT_CERT_HAS_PROPOSAL;
+        if (m.preprepare().certificate) out.nodes[r].flags |= IBFT_CERT_HAS_CERTIFICATE;
+      }
+    }
+    if (handed_back[r]) {
+      out.cls[r] = IBFT_CERT_CLASS_NEEDS_HOST;  // (the sender bit stays 0: the stock route decides this message)
+      continue;
+    }
     out.sender[r] = v_->IsValidValidator(m);
     const bytes *h = carried_hash(m);
     const IbftMessage *p = items[r].parent;
@@ -531,6 +567,79 @@ void HotPath::PruneVerdictCache(uint64_t below_height) {
 // The verdicts of one root row of a certificate call and of everything below it are noted IN the decoded objects, matched
 // by position: a decoded message lists its nested messages in the order the device lists them.  A subtree whose row count
 // differs from the decoded count (the device refused the wrapper as non-canonical) is left to the stock route.
+// validPC (core/ibft.go:1162-1231) ∧ proposalMatchesCertificate (:516-551) for the ROUND_CHANGE message at `row`, read off
+// the backend's rows: view / type / payload kind / From / carried hash of every nested message (ibft_wire_row_t), its
+// IsValidValidator bit and its IsValidProposalHash(lastPreparedProposal, hash) bit.  Only the REGULAR shape is decided here —
+// every nested message judged (class 0), with a view, a From of at most 20 bytes and a 32-byte hash under the payload its
+// type announces; anything else (−1) is left to the walk over the decoded objects, which is the authority for the corner cases.
+int HotPath::roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row) {
+  if (row >= cv.n_rows || cv.rows.size() != cv.n_rows || cv.cls[row] != 0) return -1;
+  const ibft_wire_row_t &rc = cv.rows[row];
+  const ibft_cert_node_t &nd = cv.nodes[row];
+  if (rc.status != IBFT_WIRE_OK || !rc.has_view || rc.type != ROUND_CHANGE || rc.payload_kind != 8) return -1;
+  const bool has_proposal = nd.flags & IBFT_CERT_HAS_PROPOSAL, has_cert = nd.flags & IBFT_CERT_HAS_CERTIFICATE;
+  if (!has_cert) return has_proposal ? 0 : 1;  // validPC(nil) is true; a proposal without a certificate does not match
+  if (!has_proposal) return -1;                // IsValidProposalHash(nil, hash): the backend's business
+  const size_t lo = nd.first_child, n = nd.n_children;
+  if (lo + n > cv.n_rows) return -1;
+  if (n == 0) return 0;  // ProposalMessage == nil (and no PREPARE either)
+  if (cv.nodes[lo].role != IBFT_CERT_ROLE_PC_PROPOSAL) return 0;  // ProposalMessage == nil
+  if (n == 1) return 0;                                            // PrepareMessages == nil
+  for (size_t c = lo; c < lo + n; c++) {
+    const ibft_wire_row_t &w = cv.rows[c];
+    if (cv.cls[c] != 0 || w.status != IBFT_WIRE_OK || !w.has_view || w.from_len > 20 || cv.nodes[c].n_children != 0) return -1;
+    if (c > lo && cv.nodes[c].role != IBFT_CERT_ROLE_PC_PREPARE) return -1;
+  }
+  if (!validatorManager.initialized()) return 0;  // HasQuorum of anything is false
+  // the proposal message is a PREPREPARE, the others are PREPAREs (:1189-1199)
+  if (cv.rows[lo].type != PREPREPARE) return 0;
+  for (size_t c = lo + 1; c < lo + n; c++)
+    if (cv.rows[c].type != PREPARE) return 0;
+  // (type and payload agree from here on, or the hash extraction rules of the helpers apply: not decided here)
+  if (cv.rows[lo].payload_kind != 5 || cv.rows[lo].hash_len != 32) return -1;
+  for (size_t c = lo + 1; c < lo + n; c++)
+    if (cv.rows[c].payload_kind != 6 || cv.rows[c].hash_len != 32) return -1;
+  // AreValidPCMessages (messages/helpers.go:167-214): one height, one round below the limit, one hash, unique senders;
+  // HasQuorum over the sender set (:1184)
+  const uint64_t height = rc.height, limit = rc.round, round = cv.rows[lo].round;
+  size_t slots = 64;
+  while (slots < 4 * n) slots <<= 1;
+  rc_set_.assign(slots, 0);
+  unsigned __int128 power = 0;
+  bool ok = true;
+  for (size_t c = lo; c < lo + n && ok; c++) {
+    const ibft_wire_row_t &w = cv.rows[c];
+    ok = w.height == height && w.round == round && w.round < limit && memcmp(w.proposal_hash, cv.rows[lo].proposal_hash, 32) == 0;
+    if (!ok) break;
+    const std::string_view from((const char *)w.from, w.from_len);
+    const uint64_t hk = hash_key(from.data(), from.size());
+    for (size_t sl = hk & (slots - 1);; sl = (sl + 1) & (slots - 1)) {
+      const uint64_t e = rc_set_[sl];
+      if (e == 0) {
+        rc_set_[sl] = (hk & 0xFFFFFFFF00000000ull) | (uint64_t)(c - lo + 1);
+        break;
+      }
+      if ((e & 0xFFFFFFFF00000000ull) != (hk & 0xFFFFFFFF00000000ull)) continue;
+      const ibft_wire_row_t &o = cv.rows[lo + (size_t)(e & 0xFFFFFFFFull) - 1];
+      if (o.from_len == w.from_len && memcmp(o.from, w.from, w.from_len) == 0) {
+        ok = false;  // the same sender twice
+        break;
+      }
+    }
+    power += validatorManager.powerOf(from);
+  }
+  if (!ok || power < validatorManager.quorum()) return 0;
+  // the proposal message comes from the proposer of its view and is validly signed; the PREPAREs are validly signed and
+  // none of them comes from the proposer (:1207-1228); every hash is the hash of the last prepared proposal (:516-551)
+  for (size_t c = lo; c < lo + n; c++) {
+    const ibft_wire_row_t &w = cv.rows[c];
+    if (!cv.sender[c] || !cv.hash[c]) return 0;
+    const bool proposer = verifier && verifier->IsProposer(bytes::view((const char *)w.from, w.from_len), w.height, w.round);
+    if (proposer != (c == lo)) return 0;
+  }
+  return 1;
+}
+
 void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root, bool note) {
   std::vector<std::pair<size_t, const IbftMessage *>> todo{{row, root.get()}};
   std::vector<MsgPtr> kids;
@@ -629,6 +738,27 @@ inline uint64_t mix64(uint64_t a, uint64_t b) {
 // keyed 128-bit fingerprint of a message's bytes (the key is per mirror: collisions cannot be prepared offline)
 inline void fingerprint(const uint8_t *p, size_t n, uint64_t seed, uint64_t &f1, uint64_t &f2) {
   uint64_t a = seed ^ 0x9E3779B97F4A7C15ull, b = (seed * 0xD6E8FEB86659FD93ull) ^ (uint64_t)n;
+  if (n >= 256) {  // a long message (certificates inside): eight independent chains over 64-byte strides — the multiplies of
+                   // one chain wait for each other, and a round change brings megabytes
+    uint64_t c = a ^ 0x2D358DCCAA6C78A5ull, d = b ^ 0x8BB84B93962EACC9ull, e = a ^ 0x4B33A62ED433D4A3ull,
+             f = b ^ 0x4D5A2DA51DE1AA47ull, g = a ^ 0x9FB21C651E98DF25ull, h = b ^ 0xC3A5C85C97CB3127ull;
+    while (n >= 64) {
+      uint64_t w[8];
+      memcpy(w, p, 64);
+      a = mix64(a ^ w[0], 0xA0761D6478BD642Full ^ w[1]);
+      b = mix64(b ^ w[1], 0xE7037ED1A0B428DBull ^ w[0]);
+      c = mix64(c ^ w[2], 0xA0761D6478BD642Full ^ w[3]);
+      d = mix64(d ^ w[3], 0xE7037ED1A0B428DBull ^ w[2]);
+      e = mix64(e ^ w[4], 0xA0761D6478BD642Full ^ w[5]);
+      f = mix64(f ^ w[5], 0xE7037ED1A0B428DBull ^ w[4]);
+      g = mix64(g ^ w[6], 0xA0761D6478BD642Full ^ w[7]);
+      h = mix64(h ^ w[7], 0xE7037ED1A0B428DBull ^ w[6]);
+      p += 64;
+      n -= 64;
+    }
+    a = mix64(a ^ c, 0x8EBC6AF09C88C6E3ull ^ e) ^ mix64(g, 0x589965CC75374CC3ull ^ c);
+    b = mix64(b ^ d, 0x1D8E4E27C47D124Full ^ f) ^ mix64(h, 0xEB44ACCAB455D165ull ^ d);
+  }
   while (n >= 16) {
     uint64_t x, y;
     memcpy(&x, p, 8);
@@ -802,10 +932,15 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   }
   // Decoding (one object per new message) does not depend on the device and the device does not depend on it: with the
   // GPU backend — which takes the BYTES — a helper thread decodes while this thread is inside the device calls.
+  // (the PreparedCertificate of a ROUND_CHANGE message waits for the backend's word: what the backend vouches for is
+  // judged from its rows and stays undecoded — roundChangeVerdictFromRows — everything else is decoded right after the call)
+  const bool defer_certificates = use_rc_rows && use_batch && batch && use_certs;
+  std::vector<uint8_t> vouched(defer_certificates ? n : 0, 0);
   auto decode_all = [&]() {
     for (size_t i : to_decode) {
       auto m = std::make_shared<IbftMessage>();
-      if (decode_in(backing, wire + off[i], off[i + 1] - off[i], *m)) msgs[i] = std::move(m);  // else: dropped (results −1)
+      const bool defer = defer_certificates && kinds[i] == (uint8_t)PayloadKind::ROUND_CHANGE;
+      if (decode_in(backing, wire + off[i], off[i + 1] - off[i], *m, defer)) msgs[i] = std::move(m);  // else: dropped (results −1)
     }
   };
   auto decode_candidate = [&](size_t i) {  // a candidate that needs an object after all
@@ -878,8 +1013,32 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
             verdict[carriers[j]] = cv.sender[j] ? 1 : 0;
             cert_rows++;
           }
+          MsgPtr &m = msgs[carriers[j]];
+          if (!m) continue;
+          const bool deferred = m->kind == PayloadKind::ROUND_CHANGE && m->round_change().certificate_deferred;
+          if (defer_certificates && cv.cls[j] == 0 && m->kind == PayloadKind::ROUND_CHANGE) {
+            vouched[carriers[j]] = 1;  // well-formed and canonical down to the last nested message: may stay undecoded
+            const int rc_ok = roundChangeVerdictFromRows(cv, j);
+            if (rc_ok >= 0) {
+              const uint32_t nested = cv.nodes[j].n_children;
+              if (verdict[carriers[j]] != 0) {
+                m->verdicts.rc_ok = (uint8_t)rc_ok;
+                m->verdicts.rc_rows = nested;
+                m->verdicts.rc_epoch = valset_epoch_;
+                rc_from_rows++;
+              }
+              if (deferred || nested == 0) {
+                cert_rows += nested;  // rows the device judged (counted whether or not the carrier turns out to be storable)
+                continue;
+              }
+            }
+          }
+          if (deferred && !m->round_change().realise_certificate()) {
+            m.reset();  // proto.Unmarshal would have failed on this message: dropped (results −1)
+            continue;
+          }
           // what the device said about the nested messages is only worth noting for a carrier that can be stored
-          if (msgs[carriers[j]]) noteCertificateTree(cv, j, msgs[carriers[j]], verdict[carriers[j]] != 0);
+          noteCertificateTree(cv, j, m, verdict[carriers[j]] != 0);
         }
         std::vector<size_t> left;
         for (size_t i : ask)
@@ -931,6 +1090,11 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     }
   }
   decoded();
+  if (defer_certificates)  // certificates nobody vouched for are decoded now; a message whose certificate does not decode is dropped
+    for (size_t i : to_decode)
+      if (msgs[i] && !vouched[i] && msgs[i]->kind == PayloadKind::ROUND_CHANGE && msgs[i]->round_change().certificate_deferred &&
+          !msgs[i]->round_change().realise_certificate())
+        msgs[i].reset();
   if (lean_mode && !wire_sets_done)
     for (size_t i : ask)
       if (cand[i]) decode_candidate(i);
@@ -1612,7 +1776,10 @@ void HotPath::prefetchCertificateHashes(const std::vector<MsgPtr> &rcs) {
 std::vector<MsgPtr> HotPath::handleRoundChangeMessage(const View &view) {
   const uint64_t h = view.height;
   const bool hasAcceptedProposal = getProposal() != nullptr;
+  size_t row_hits = 0;
+  auto rowsDecided = [&](const IbftMessage &msg) { return use_rc_rows && msg.verdicts.rc_epoch == valset_epoch_; };
   auto isValidMsgFn = [&](const IbftMessage &msg) {
+    if (rowsDecided(msg)) return msg.verdicts.rc_ok != 0;  // decided from the backend's rows when the message arrived
     const Proposal *proposal = extract_last_prepared_proposal(msg);
     const PreparedCertificate *certificate = extract_latest_pc(msg);
     if (!msg.view) return false;  // the reference dereferences msg.View; a stored message always has one
@@ -1627,10 +1794,19 @@ std::vector<MsgPtr> HotPath::handleRoundChangeMessage(const View &view) {
   if (use_batch && batch)
     prepass = [&](const std::vector<MsgPtr> &all) {
       std::vector<const IbftMessage *> need;
-      for (auto &rc : all) collect_pc(extract_latest_pc(*rc), need);
+      std::vector<MsgPtr> undecided;
+      for (auto &rc : all) {
+        if (rowsDecided(*rc)) {
+          row_hits += rc->verdicts.rc_rows;  // (its nested messages stay undecoded)
+          continue;
+        }
+        collect_pc(extract_latest_pc(*rc), need);
+        undecided.push_back(rc);
+      }
       prefetchSenders(need);
       if (cert_hits < need.size() && sender_verdict_.empty()) fallbacks++;  // something was asked and the batch failed
-      prefetchCertificateHashes(all);
+      cert_hits += row_hits;  // sender verdicts the walk does not ask for at all
+      prefetchCertificateHashes(undecided);
     };
   else
     sender_verdict_.clear();

@@ -36,6 +36,7 @@ struct Verifier {
 struct CertVerdicts {
   size_t n_rows = 0;
   std::vector<ibft_cert_node_t> nodes;
+  std::vector<ibft_wire_row_t> rows;  // the parsed fields of every row (view, type, payload kind, From, carried proposal hash)
   std::vector<uint8_t> cls, sender, hash, self;
 };
 
@@ -229,6 +230,11 @@ class HotPath {
   // completely): a PREPARE / COMMIT the backend vouched for is kept as a ROW — no object is built for it — and
   // handlePrepare / handleCommit run over the rows; anything that wants objects materialises them (messages.hpp).
   bool use_lean = true;
+  // With use_rc_rows (default): the certificate of a ROUND_CHANGE message the backend vouched for is judged from the
+  // backend's rows when the message arrives and is NOT decoded (proto.hpp: RoundChangeMessage::certificate_deferred);
+  // handleRoundChangeMessage takes the noted verdict.  rc_from_rows: messages decided that way so far.
+  bool use_rc_rows = true;
+  size_t rc_from_rows = 0;
   size_t lean_rows = 0;        // messages ingested as rows so far
   bool prepared_as_rows = false;  // the last successful handlePrepare ran over rows: PC.PrepareMessages = PreparedWire()
   View prepared_view{};
@@ -321,6 +327,10 @@ class HotPath {
   size_t rejected_head_ = 0;
   uint64_t fp_seed_;
   void noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root, bool note);
+  // isValidMsgFn of handleRoundChangeMessage for the ROUND_CHANGE message at `row`, from the rows alone (no nested message
+  // is decoded): 1 / 0 = the verdict, −1 = not decided here (an irregular shape: the object walk decides)
+  int roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row);
+  std::vector<uint64_t> rc_set_;  // scratch: the sender set of one certificate
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);
 

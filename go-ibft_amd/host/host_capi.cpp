@@ -351,7 +351,7 @@ int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *of
       const IbftMessage &m = *all[k];
       if (m.kind == PayloadKind::PREPREPARE && m.preprepare().certificate) {
         for (auto &c : m.preprepare().certificate->round_change_messages) all.push_back(c);
-      } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().latest_prepared_certificate) {
+      } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().realise_certificate() && m.round_change().latest_prepared_certificate) {
         const PreparedCertificate &pc = *m.round_change().latest_prepared_certificate;
         if (pc.proposal_message) all.push_back(pc.proposal_message);
         for (auto &c : pc.prepare_messages) all.push_back(c);
@@ -614,6 +614,8 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
   h->hp.rejected_cap = rejected_cap;
 }
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
+void ibft_host_use_rc_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_rc_rows = on != 0; }
+size_t ibft_host_rc_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.rc_from_rows; }
 int ibft_host_retain_heap(size_t bytes) {
   // glibc: freed memory at the top of the heap above M_TRIM_THRESHOLD goes back to the kernel, blocks above
   // M_MMAP_THRESHOLD are mapped and unmapped one by one — either way the next height's buffers are fresh pages again

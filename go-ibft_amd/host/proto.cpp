@@ -36,6 +36,7 @@ void put_varint_field(bytes &o, uint32_t num, uint64_t v) {  // proto3: zero omi
 // decode mode of the current thread: byte fields become views into tl_backing (which every decoded message keeps), or
 // owned copies (standalone Proposal / values with nothing to keep a buffer alive)
 thread_local const std::shared_ptr<const void> *tl_backing = nullptr;
+thread_local bool tl_defer_certificate = false;  // decode_in(..., defer_certificate)
 inline void set_bytes(bytes &dst, const uint8_t *q, size_t l) {
   if (tl_backing)
     dst = bytes::view((const char *)q, l);
@@ -268,6 +269,13 @@ bool decode_round_change(const uint8_t *p, size_t n, RoundChangeMessage &o, int 
       if (!decode_proposal(q, l, *o.last_prepared_proposal)) return false;
     } else if (tag == ((2u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
+      if (tl_defer_certificate && depth == 0 && tl_backing && !o.latest_prepared_certificate && !o.certificate_deferred) {
+        o.certificate_deferred = true;  // (a second occurrence of the field — never canonical — is merged below)
+        o.certificate_wire = bytes::view((const char *)q, l);
+        o.certificate_backing = *tl_backing;
+        continue;
+      }
+      if (o.certificate_deferred && !o.realise_certificate()) return false;
       if (!o.latest_prepared_certificate) o.latest_prepared_certificate.emplace();
       if (!decode_pc(q, l, *o.latest_prepared_certificate, depth)) return false;
     } else if ((tag >> 3) == 1 || (tag >> 3) == 2) {
@@ -385,7 +393,10 @@ static bytes encode(const CommitMessage &c) {
 static bytes encode(const RoundChangeMessage &r) {
   bytes o;
   if (r.last_prepared_proposal) put_len_field(o, 1, encode(*r.last_prepared_proposal));
-  if (r.latest_prepared_certificate) put_len_field(o, 2, encode(*r.latest_prepared_certificate));
+  if (r.certificate_deferred)
+    put_len_field(o, 2, r.certificate_wire);  // (canonical by the condition under which a certificate stays deferred)
+  else if (r.latest_prepared_certificate)
+    put_len_field(o, 2, encode(*r.latest_prepared_certificate));
   o += r.unknown;
   return o;
 }
@@ -516,8 +527,29 @@ struct BackingScope {
   ~BackingScope() { tl_backing = saved; }
 };
 }  // namespace
-bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out) {
+bool RoundChangeMessage::realise_certificate() const {
+  if (!certificate_deferred) return true;
+  certificate_deferred = false;
+  const std::shared_ptr<const void> keep = std::move(certificate_backing);
+  const bytes w = std::move(certificate_wire);
+  certificate_backing.reset();
+  certificate_wire = bytes();
+  BackingScope scope(&keep);
+  const bool saved = tl_defer_certificate;
+  tl_defer_certificate = false;
+  PreparedCertificate pc;
+  const bool ok = decode_pc((const uint8_t *)w.data(), w.size(), pc, 0);
+  tl_defer_certificate = saved;
+  if (ok) const_cast<RoundChangeMessage *>(this)->latest_prepared_certificate = std::move(pc);
+  return ok;
+}
+bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out, bool defer_certificate) {
   BackingScope scope(&backing);
+  struct DeferScope {
+    bool saved;
+    explicit DeferScope(bool d) : saved(tl_defer_certificate) { tl_defer_certificate = d; }
+    ~DeferScope() { tl_defer_certificate = saved; }
+  } defer_scope(defer_certificate);
   return decode_msg(p, n, out, 0);
 }
 bool decode(const uint8_t *p, size_t n, IbftMessage &out) {
@@ -568,6 +600,7 @@ const RoundChangeCertificate *extract_round_change_certificate(const IbftMessage
 }
 const PreparedCertificate *extract_latest_pc(const IbftMessage &m) {
   if (m.type != ROUND_CHANGE || m.kind != PayloadKind::ROUND_CHANGE) return nullptr;
+  if (m.round_change().certificate_deferred) (void)m.round_change().realise_certificate();
   return m.round_change().latest_prepared_certificate ? &*m.round_change().latest_prepared_certificate : nullptr;
 }
 const Proposal *extract_last_prepared_proposal(const IbftMessage &m) {

@@ -63,6 +63,15 @@ struct RoundChangeMessage {
   std::optional<Proposal> last_prepared_proposal;
   std::optional<PreparedCertificate> latest_prepared_certificate;
   bytes unknown;
+  // A certificate that has not been decoded yet (decode_in(..., defer_certificate)): its bytes, to be decoded by
+  // realise_certificate() when somebody asks for the objects (extract_latest_pc, nested_messages) and copied as they are
+  // by encode().  Only a certificate whose bytes are known to be well-formed AND canonical may stay in this state — the
+  // receive path keeps it for messages a batch backend vouched for (class 0 of ibft_verify_certificates_wire) and decodes
+  // every other one at once, dropping the message if that fails as proto.Unmarshal would have.
+  mutable bool certificate_deferred = false;
+  mutable bytes certificate_wire;                      // a view into `certificate_backing`
+  mutable std::shared_ptr<const void> certificate_backing;
+  bool realise_certificate() const;                    // false: the deferred bytes do not decode (the certificate stays absent)
 };
 
 // Which member of the `payload` oneof is set (messages.proto:36-43); NONE = nil Payload.
@@ -79,6 +88,12 @@ struct Verdicts {
                                    // its carrier's lastPreparedProposal — proposalMatchesCertificate, core/ibft.go:516-551)
   const void *self_of = nullptr;   // a PREPREPARE's own Proposal object `self` was judged against (validateProposalCommon)
   uint8_t sender = 0, closure = 0, hash = 0, self = 0;
+  // a ROUND_CHANGE message: validPC(latestPC, view.round, view.height) ∧ proposalMatchesCertificate(lastPreparedProposal,
+  // latestPC) — handleRoundChangeMessage's isValidMsgFn (core/ibft.go:478-489) — decided when the message arrived, from the
+  // rows a batch backend returned for its certificate; rc_rows = the nested messages that verdict covers
+  uint32_t rc_epoch = 0;  // validator-set epoch of `rc_ok` (0 = unknown)
+  uint32_t rc_rows = 0;
+  uint8_t rc_ok = 0;
 };
 
 // A member most messages never use (the PREPREPARE / ROUND_CHANGE payloads, ≈ 500 bytes of the message object between them):
@@ -143,7 +158,9 @@ bytes encode(const RoundChangeCertificate &rcc);
 bool decode(const uint8_t *p, size_t n, IbftMessage &out);
 // The same without copying the wire: [p, p + n) lies inside `backing`, which the message (and every message nested in it)
 // keeps alive; all byte fields are views into it.
-bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out);
+// defer_certificate: the PreparedCertificate of a top-level ROUND_CHANGE payload is not decoded (RoundChangeMessage above).
+bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out,
+               bool defer_certificate = false);
 // What the receive side needs to know about a message BEFORE it is decoded (and without allocating anything): whether the
 // top-level walk succeeds at all, the view, the type and which payload member is set — merged exactly as decode() merges
 // repeated fields (the last View fields and the last payload member on the wire win).

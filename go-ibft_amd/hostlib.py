@@ -135,6 +135,8 @@ def lib() -> C.CDLL:
         L.ibft_host_use_certs.argtypes = [vp, C.c_int]; L.ibft_host_use_certs.restype = None
         L.ibft_host_use_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rows.restype = None
         L.ibft_host_retain_heap.argtypes = [C.c_size_t]; L.ibft_host_retain_heap.restype = C.c_int
+        L.ibft_host_use_rc_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rc_rows.restype = None
+        L.ibft_host_rc_from_rows.argtypes = [vp]; L.ibft_host_rc_from_rows.restype = C.c_size_t
         L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
         L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
         L.ibft_host_handle_preprepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
@@ -477,6 +479,14 @@ class Host:
 
     def use_certs(self, on: bool):
         self.L.ibft_host_use_certs(self.h, 1 if on else 0)
+
+    def use_rc_rows(self, on: bool):
+        """Judge a ROUND_CHANGE message's certificate from the backend's rows on arrival (default) or by the object walk."""
+        self.L.ibft_host_use_rc_rows(self.h, 1 if on else 0)
+
+    @property
+    def rc_from_rows(self) -> int:
+        return int(self.L.ibft_host_rc_from_rows(self.h))
 
     def use_rows(self, on: bool):
         """Keep the PREPARE / COMMIT messages a batch backend judged from their bytes as rows (default) or as objects."""

@@ -184,6 +184,18 @@ void ibft_host_use_certs(ibft_host *h, int on);
  * change) turns the view's rows into objects first, verdicts noted: the answers are the same either way
  * (tests/test_host_rows.py).  use_rows(0) = every message becomes an object on arrival.  rows_kept: messages stored as
  * rows so far.                                                                                                        */
+/* Round-change certificates judged from the backend's rows (default on; needs use_certs and a batch backend):
+ * ibft_verify_certificates_wire returns, for every message nested in a ROUND_CHANGE message's PreparedCertificate, its view,
+ * type, From and carried hash next to its IsValidValidator and IsValidProposalHash bits — everything validPC
+ * (core/ibft.go:1162-1231) and proposalMatchesCertificate (:516-551) look at.  For a message the backend vouched for the
+ * mirror evaluates both on those rows when the message ARRIVES, notes the verdict in the stored message and does not
+ * decode the certificate at all (it is decoded if somebody asks for the objects, and copied byte for byte when the message
+ * is encoded again); handleRoundChangeMessage takes the noted verdict.  Irregular shapes (a nested message the backend did
+ * not judge, type and payload that disagree, hashes that are not 32 bytes, …) are left to the walk over the decoded objects,
+ * and so is everything once the validator set changes.  use_rc_rows(0) = decode and walk, as before.  rc_from_rows:
+ * ROUND_CHANGE messages decided that way so far.                                                                      */
+void ibft_host_use_rc_rows(ibft_host *h, int on);
+size_t ibft_host_rc_from_rows(ibft_host *h);
 /* PROCESS-WIDE, optional: keep up to `bytes` of freed C heap in the process (glibc mallopt: M_TRIM_THRESHOLD, M_TOP_PAD,
  * M_MMAP_THRESHOLD) instead of handing it back to the kernel.  The mirror's memory has the rhythm of the chain — the
  * messages of a height are stored, then pruned — and with the default thresholds every height's buffers are fresh pages

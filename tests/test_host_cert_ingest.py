@@ -36,6 +36,8 @@ def build_traffic(w, height, raw, rounds=(1, 2, 3)):
             else:
                 # the mock backend marks bad signatures by message bytes, and honest certificates of one (height, round,
                 # proposal) share their nested messages: a Byzantine certificate gets a proposal of its own
+                if kind in ("short_hash_everywhere", "commit_among_prepares"):
+                    w.irregular = True   # shapes whose hash questions are not settled on arrival: the walk asks the backend once more
                 r2 = raw if kind is None else raw + b"|" + kind.encode() + a
                 m = rc_message(w, height, rnd, a, raw=r2, cert=w.certificate(height, cert_round, r2, kind), cert_round=cert_round)
             msgs.append(m)
@@ -50,14 +52,17 @@ def build_traffic(w, height, raw, rounds=(1, 2, 3)):
 
 
 @pytest.mark.parametrize("seed", range(10))
-@pytest.mark.parametrize("mode", ["certs", "certs_fail", "certs_off"])
+@pytest.mark.parametrize("mode", ["certs", "certs_objects", "certs_fail", "certs_off"])
 def test_certificates_on_arrival_equal_stock(seed, mode):
+    """certs: a ROUND_CHANGE message's certificate is judged from the backend's rows on arrival and stays undecoded
+    (ibft_host_use_rc_rows, the default); certs_objects: decoded, verdicts noted in the nested objects, the walk over them."""
     w = World(n=7 + seed % 4, seed=100 + seed)
     height, raw = 3, b"block-%d" % seed
     stock, fast = w.host(), w.host()
     fast.use_loop_batch(16 if mode == "certs_fail" else 0)
     fast.use_batch(True)
     fast.use_certs(mode != "certs_off")
+    fast.use_rc_rows(mode != "certs_objects")
     me = b"someone else"  # this node proposes nothing
     for h in (stock, fast):
         h.set_id(me)
@@ -74,10 +79,11 @@ def test_certificates_on_arrival_equal_stock(seed, mode):
         rb = fast.ingest_wire(wires)[0]
         assert ra == rb, (seed, mode)
     calls, rows, _ = fast.cert_stats()
-    if mode == "certs":
+    if mode in ("certs", "certs_objects"):
         assert calls >= 3 and rows > 20 and fast.loop_batch_cert_calls() == calls
+        assert fast.rc_from_rows > 5 if mode == "certs" else fast.rc_from_rows == 0
     else:
-        assert calls == 0
+        assert calls == 0 and fast.rc_from_rows == 0
     for view_round in (1, 2, 3):
         for h in (stock, fast):
             h.set_state(height, view_round, None)
@@ -86,12 +92,12 @@ def test_certificates_on_arrival_equal_stock(seed, mode):
         b = fast.handle_round_change(height, view_round)
         assert sorted(a) == sorted(b), (seed, mode, view_round)
         assert a or view_round == 3  # the honest rounds do produce an extended RCC
-        if mode == "certs":
+        if mode in ("certs", "certs_objects") and not getattr(w, "irregular", False):
             assert fast.loop_batch_calls() == before, "the certificate walk asked the backend again"
         pa = stock.handle_preprepare(height, view_round)
         pb = fast.handle_preprepare(height, view_round)
         assert pa == pb, (seed, mode, view_round)
-        if mode == "certs":
+        if mode in ("certs", "certs_objects") and not getattr(w, "irregular", False):
             assert fast.loop_batch_calls() == before
             if pb is not None:
                 assert fast.cert_stats()[2] > 0  # sender verdicts came from the arrival-time tables
@@ -121,3 +127,48 @@ def test_tables_follow_the_store():
     if first:
         assert fast.loop_batch_calls() > before
     fast.close()
+
+
+@pytest.mark.parametrize("kind", [k for k in dict.fromkeys(KINDS) if k is not None])
+def test_every_certificate_rule_from_rows(kind):
+    """One ROUND_CHANGE set per rule of validPC / AreValidPCMessages / proposalMatchesCertificate: honest messages plus ONE whose
+    certificate breaks that rule.  The verdict computed from the backend's rows on arrival (no nested message decoded), the
+    walk over decoded objects with arrival-time verdicts, and the reference's per-message walk keep exactly the same messages."""
+    n = 10
+    w = World(n=n, seed=KINDS.index(kind))
+    height, rnd, raw = 3, 2, b"the block"
+    msgs = []
+    for k, a in enumerate(w.addrs):
+        cert_round = 1 if k % 2 else 0
+        if k != 4:
+            msgs.append(rc_message(w, height, rnd, a, raw=raw, cert=w.certificate(height, cert_round, raw), cert_round=cert_round))
+        elif kind == "no_certificate":
+            msgs.append(rc_message(w, height, rnd, a))
+        elif kind == "proposal_without_certificate":
+            msgs.append(rc_message(w, height, rnd, a, raw=raw, cert=None, cert_round=cert_round))
+        elif kind == "other_proposal":
+            msgs.append(rc_message(w, height, rnd, a, raw=raw, cert=w.certificate(height, cert_round, b"another"), cert_round=cert_round))
+        else:
+            r2 = b"%02d-block|" % KINDS.index(kind) + kind.encode()   # (fake_hash looks at the first 8 bytes: nested messages of its own)
+            msgs.append(rc_message(w, height, rnd, a, raw=r2, cert=w.certificate(height, cert_round, r2, kind), cert_round=cert_round))
+    wires = [m.encode() for m in msgs]
+    hosts = {"stock": w.host(), "rows": w.host(), "objects": w.host()}
+    for name, h in hosts.items():
+        h.set_id(b"someone else")
+        h.set_state(height, rnd, None)
+        if name != "stock":
+            h.use_loop_batch(0)
+            h.use_batch(True)
+            h.use_rc_rows(name == "rows")
+    res = {name: h.ingest_wire(wires)[0] for name, h in hosts.items()}
+    assert res["stock"] == res["rows"] == res["objects"]
+    out = {name: sorted(h.handle_round_change(height, rnd)) for name, h in hosts.items()}
+    assert out["stock"] == out["rows"] == out["objects"]
+    accepted_by_default = kind in ("no_certificate", "unknown_field_in_prepare")
+    assert (wires[4] in out["stock"]) == accepted_by_default and len(out["stock"]) == n - (0 if accepted_by_default else 1)
+    irregular = kind == "short_hash_everywhere"
+    assert hosts["rows"].rc_from_rows == n - (1 if irregular else 0) and hosts["objects"].rc_from_rows == 0
+    # the messages handed out again are the bytes that came in, whether or not their certificates were ever decoded
+    assert sorted(hosts["rows"].store_get_valid(height, rnd, 3)) == sorted(wires)
+    for h in hosts.values():
+        h.close()

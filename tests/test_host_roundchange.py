@@ -77,6 +77,38 @@ class World:
                                    payload=W.prepare_body(fake_hash(b"other", round_)))
         elif corrupt == "too_few_prepares":
             prs = prs[: q // 2]
+        # ---- the rest of validPC's / AreValidPCMessages' rules (core/ibft.go:1162-1231, messages/helpers.go:167-214)
+        elif corrupt == "duplicate_sender":
+            prs[-1] = prs[0]
+        elif corrupt == "prepare_from_proposer":
+            prs[0] = W.IbftMessage(view=W.View(height, round_), sender=prop, type=PR, signature=b"sig-pr-" + prop, payload=W.prepare_body(hsh))
+        elif corrupt == "proposal_not_from_proposer":
+            pp = W.IbftMessage(view=W.View(height, round_), sender=others[-1], type=PP, signature=b"sig-pp-" + others[-1],
+                               payload=W.preprepare_body(W.Proposal(raw, round_), hsh, None))
+        elif corrupt == "one_prepare_of_another_round":
+            k = self.rng.randrange(len(prs))
+            prs[k] = W.IbftMessage(view=W.View(height, round_ + 1), sender=prs[k].sender, type=PR, signature=prs[k].signature, payload=W.prepare_body(hsh))
+        elif corrupt == "one_prepare_of_another_height":
+            k = self.rng.randrange(len(prs))
+            prs[k] = W.IbftMessage(view=W.View(height + 1, round_), sender=prs[k].sender, type=PR, signature=prs[k].signature, payload=W.prepare_body(hsh))
+        elif corrupt == "commit_among_prepares":     # type COMMIT: "all messages in the PC are Prepare messages" fails
+            k = self.rng.randrange(len(prs))
+            prs[k] = W.IbftMessage(view=W.View(height, round_), sender=prs[k].sender, type=CM, signature=prs[k].signature,
+                                   payload=W.commit_body(hsh, b"seal"))
+        elif corrupt == "unknown_field_in_prepare":   # a PrepareMessage with a field 2 nobody knows: still a valid PREPARE (not a corruption)
+            k = self.rng.randrange(len(prs))
+            prs[k] = W.IbftMessage(view=W.View(height, round_), sender=prs[k].sender, type=PR, signature=prs[k].signature,
+                                   payload=W.commit_body(hsh, b"seal"))
+        elif corrupt == "short_hash_everywhere":     # 31-byte hashes that agree with each other (and with nothing the backend accepts)
+            pp = W.IbftMessage(view=W.View(height, round_), sender=prop, type=PP, signature=b"sig-pp-" + prop,
+                               payload=W.preprepare_body(W.Proposal(raw, round_), hsh[:31], None))
+            prs = [W.IbftMessage(view=W.View(height, round_), sender=m.sender, type=PR, signature=m.signature, payload=W.prepare_body(hsh[:31]))
+                   for m in prs]
+        elif corrupt == "stranger_among_prepares":   # a sender outside the validator set: validly "signed" for the mock, no voting power
+            prs[0] = W.IbftMessage(view=W.View(height, round_), sender=b"a stranger", type=PR, signature=b"sig", payload=W.prepare_body(hsh))
+        elif corrupt == "quorum_minus_one_plus_stranger":
+            prs = prs[: q - 2] + [W.IbftMessage(view=W.View(height, round_), sender=b"a stranger", type=PR, signature=b"sig",
+                                                payload=W.prepare_body(hsh))]
         return pp, prs
 
 
@@ -87,7 +119,9 @@ def rc_message(w, height, round_, sender, raw=None, cert=None, cert_round=0):
 
 
 KINDS = [None, None, None, "bad_prepare_signature", "bad_proposal_signature", "wrong_hash_in_prepare", "too_few_prepares",
-         "no_certificate", "proposal_without_certificate", "other_proposal"]
+         "no_certificate", "proposal_without_certificate", "other_proposal", "duplicate_sender", "prepare_from_proposer",
+         "proposal_not_from_proposer", "one_prepare_of_another_round", "one_prepare_of_another_height", "commit_among_prepares",
+         "unknown_field_in_prepare", "short_hash_everywhere", "stranger_among_prepares", "quorum_minus_one_plus_stranger"]
 
 
 @pytest.mark.parametrize("seed", range(12))
