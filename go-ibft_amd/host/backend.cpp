@@ -1236,6 +1236,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     }
   }
   flush_run();
+  last_ingest_device_ms = st.device_ms;
   if (stats) *stats = st;
   return true;
 }

@@ -235,6 +235,7 @@ class HotPath {
   // handleRoundChangeMessage takes the noted verdict.  rc_from_rows: messages decided that way so far.
   bool use_rc_rows = true;
   size_t rc_from_rows = 0;
+  double last_ingest_device_ms = 0.0;  // wall time the last IngestFlat spent inside the batch backend's calls
   size_t lean_rows = 0;        // messages ingested as rows so far
   bool prepared_as_rows = false;  // the last successful handlePrepare ran over rows: PC.PrepareMessages = PreparedWire()
   View prepared_view{};

@@ -616,6 +616,7 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
 void ibft_host_use_rc_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_rc_rows = on != 0; }
 size_t ibft_host_rc_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.rc_from_rows; }
+double ibft_host_last_ingest_device_ms(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.last_ingest_device_ms; }
 int ibft_host_retain_heap(size_t bytes) {
   // glibc: freed memory at the top of the heap above M_TRIM_THRESHOLD goes back to the kernel, blocks above
   // M_MMAP_THRESHOLD are mapped and unmapped one by one — either way the next height's buffers are fresh pages again

@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
         L.ibft_host_use_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rows.restype = None
         L.ibft_host_retain_heap.argtypes = [C.c_size_t]; L.ibft_host_retain_heap.restype = C.c_int
         L.ibft_host_use_rc_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rc_rows.restype = None
+        L.ibft_host_last_ingest_device_ms.argtypes = [vp]; L.ibft_host_last_ingest_device_ms.restype = C.c_double
         L.ibft_host_rc_from_rows.argtypes = [vp]; L.ibft_host_rc_from_rows.restype = C.c_size_t
         L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
         L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
@@ -479,6 +480,9 @@ class Host:
 
     def use_certs(self, on: bool):
         self.L.ibft_host_use_certs(self.h, 1 if on else 0)
+
+    def last_ingest_device_ms(self) -> float:
+        return float(self.L.ibft_host_last_ingest_device_ms(self.h))
 
     def use_rc_rows(self, on: bool):
         """Judge a ROUND_CHANGE message's certificate from the backend's rows on arrival (default) or by the object walk."""

@@ -194,6 +194,8 @@ void ibft_host_use_certs(ibft_host *h, int on);
  * not judge, type and payload that disagree, hashes that are not 32 bytes, …) are left to the walk over the decoded objects,
  * and so is everything once the validator set changes.  use_rc_rows(0) = decode and walk, as before.  rc_from_rows:
  * ROUND_CHANGE messages decided that way so far.                                                                      */
+/* wall time the last ibft_host_ingest_* call spent inside the batch backend (the device calls), in milliseconds */
+double ibft_host_last_ingest_device_ms(ibft_host *h);
 void ibft_host_use_rc_rows(ibft_host *h, int on);
 size_t ibft_host_rc_from_rows(ibft_host *h);
 /* PROCESS-WIDE, optional: keep up to `bytes` of freed C heap in the process (glibc mallopt: M_TRIM_THRESHOLD, M_TOP_PAD,

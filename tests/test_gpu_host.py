@@ -320,12 +320,15 @@ def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets, rows):
     ref.close(); ing.close()
 
 
-def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle):
+@pytest.mark.parametrize("rc_rows", [True, False])
+def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle, rc_rows):
     """§8f ranks 1 + 2 with the real backend at N = 128: ROUND-CHANGE messages with quorum-sized PreparedCertificates and the
     PREPREPARE whose RoundChangeCertificate is made of them arrive as wire bytes; IngestWire settles every nested signature
     and proposal-hash check in ONE ibft_verify_certificates_wire call per micro-batch (no PayloadNoSig re-marshal of nested
     messages on the host), handleRoundChangeMessage / handlePrePrepare then ask the device nothing — and decide exactly like
-    the per-message walks backed by the CPU oracle, Byzantine certificates included."""
+    the per-message walks backed by the CPU oracle, Byzantine certificates included.  rc_rows (default): the certificate of a
+    ROUND_CHANGE message is judged from the device's rows on arrival (validPC + proposalMatchesCertificate in row form) and
+    never decoded; off: decoded, verdicts noted in the nested objects, the walk over them."""
     import go_ibft_amd.hostlib as H
     from oracle import wire as W, workload as WL
     n = 128
@@ -377,16 +380,18 @@ def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle)
         h.set_state(1, 0, None)
     ing.attach_gpu(gpu_verifier)
     ing.use_batch(True)
+    ing.use_rc_rows(rc_rows)
     expect = [ref.add_message(x) for x in wires]
     got, rows, hits, calls = ing.ingest_wire(wires)
     assert [x != 0 for x in got] == [x != 0 for x in expect] and got[-1] == 0 and calls == 1   # ONE device call for the micro-batch
+    assert ing.rc_from_rows == (len(rcs) if rc_rows else 0)                                # (the forged envelope is not stored)
     c_calls, c_rows, _ = ing.cert_stats()
     assert c_calls == 1 and c_rows == len(wires) * (1 + quorum)                            # every message of every tree judged
     for h in (ref, ing):
         h.set_state(1, 1, None)
     a = sorted(ref.handle_round_change(1, 1))
     b = sorted(ing.handle_round_change(1, 1))
-    assert a == b and len(b) == len(rcs) - 2
+    assert a == b and len(b) == len(rcs) - 2 and set(b) <= set(wires)                      # handed out as the bytes that came in
     nsend, nhash = ing.last_cert_batch()
     assert nsend == 0 and nhash == 0 and ing.cert_stats()[2] == len(rcs) * quorum          # nothing left to ask: the tables answered
     # the PREPREPAREs of round 1: 1.5 MB envelopes (the host hashes those itself, by the stock route), trees judged on arrival

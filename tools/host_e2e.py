@@ -169,7 +169,7 @@ def host_mirror_queue(V, H, fx, flags: int, reps: int, micro: int = 256, linger_
             "sig_verifies_per_s": (3 * n - 1) / (p[1] * 1e-3)}
 
 
-def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
+def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10, rc_rows: bool = True):
     import cert_cases as CC
     from oracle import wire, workload as W
     r = W.make_round(n, 900 + n, height=5, round_=1, raw_len=1024)
@@ -183,7 +183,7 @@ def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
     res = {"validators": n, "round_change_messages": q, "signatures": q * (q + 1)}
     for name, flags in (("cold", 0), ("warm", V.FLAG_PUBKEY_CACHE)):
         bv = V.BatchVerifier(flags=flags, max_rows=65536)
-        ing, hrc = [], []
+        ing, hrc, dev = [], [], []
         try:
             bv.set_validators(5, r.addrs, r.power)
             for rep in range(reps + 2):
@@ -197,19 +197,24 @@ def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10):
                 host.attach_gpu(bv)
                 host.use_batch(True)
                 host.enable_quorum_index()
+                host.use_rc_rows(rc_rows)
                 t0 = time.perf_counter()
                 rc = host.ingest_packed(packed, len(rcs))
                 t1 = time.perf_counter()
                 rcc = host.handle_round_change_count(5, 2)
                 t2 = time.perf_counter()
                 assert set(rc) <= {1, 2} and rcc == 1 and host.fallbacks() == 0, (rc[:4], rcc)
+                assert host.rc_from_rows == (q if rc_rows else 0)
+                dev_ms = host.last_ingest_device_ms()
                 host.close()
                 if rep >= 2:
                     ing.append((t1 - t0) * 1e3)
                     hrc.append((t2 - t1) * 1e3)
+                    dev.append(dev_ms)
         finally:
             bv.close()
-        res[name] = {"ingest_ms": float(np.median(ing)), "handle_round_change_ms": float(np.median(hrc)),
+        res[name] = {"ingest_ms": float(np.median(ing)), "of_which_device_ms": float(np.median(dev)),
+                     "handle_round_change_ms": float(np.median(hrc)),
                      "total_ms": float(np.median(np.array(ing) + np.array(hrc)))}
     return res
 
@@ -230,5 +235,6 @@ if __name__ == "__main__":
            "config3_queue_warm_objects": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30, rows=False)}
     if "--no-rc" not in sys.argv:
         out["round_change_n256"] = round_change_through_the_mirror(V, H)
+        out["round_change_n256_object_walk"] = round_change_through_the_mirror(V, H, rc_rows=False)
     out["retain_heap"] = "--no-retain-heap" not in sys.argv
     print(json.dumps(out, indent=1))
