@@ -992,10 +992,58 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   };
   // (0) messages that carry certificates: the whole tree — their own envelope and every message nested in them — in ONE
   // device call, from the bytes as they arrived
+  size_t forged_now = 0;  // carriers of this batch whose own envelope failed
   if (use_batch && batch && use_certs) {
     std::vector<size_t> carriers;
     for (size_t i : ask)
       if (kinds[i] == (uint8_t)PayloadKind::PREPREPARE || kinds[i] == (uint8_t)PayloadKind::ROUND_CHANGE) carriers.push_back(i);
+    // Expanding a tree before its carrier is authenticated lets anybody buy up to N² signature checks with one message (the
+    // reference spends ONE IsValidValidator on a stranger's message).  While forged carriers keep arriving, the envelopes
+    // of the carriers are judged first — one more backend call — and only the trees of authenticated ones are expanded.
+    const bool roots_first = !carriers.empty() && (cert_roots_first == 1 || (cert_roots_first == 2 && forged_carriers_ >= 4.0));
+    if (roots_first) {
+      decoded();
+      std::vector<uint8_t> v;
+      bool ok = false;
+      const auto td = std::chrono::steady_clock::now();
+      if (auto *gpu = dynamic_cast<GpuBackend *>(batch)) {
+        const uint8_t *w;
+        const uint32_t *o;
+        rows_as_wire(carriers, w, o);
+        ok = gpu->VerifySendersWire(w, o, carriers.size(), v);
+      } else {
+        std::vector<MsgPtr> sub;
+        std::vector<size_t> at;
+        for (size_t j = 0; j < carriers.size(); j++)
+          if (msgs[carriers[j]]) {
+            sub.push_back(msgs[carriers[j]]);
+            at.push_back(j);
+          }
+        std::vector<uint8_t> vs;
+        ok = batch->VerifySenderBatch(sub, vs) && vs.size() == sub.size();
+        v.assign(carriers.size(), 1);  // (what did not decode is dropped anyway)
+        for (size_t k = 0; ok && k < at.size(); k++) v[at[k]] = vs[k];
+      }
+      st.device_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+      if (ok && v.size() == carriers.size()) {
+        st.device_calls++;
+        roots_first_calls++;
+        std::vector<size_t> authentic;
+        for (size_t j = 0; j < carriers.size(); j++) {
+          if (v[j]) {
+            authentic.push_back(carriers[j]);
+          } else {
+            verdict[carriers[j]] = 0;  // IsValidValidator failed: nothing below it is looked at
+            forged_now++;
+          }
+        }
+        carriers.swap(authentic);
+        std::vector<size_t> left;
+        for (size_t i : ask)
+          if (verdict[i] < 0) left.push_back(i);
+        ask.swap(left);
+      }
+    }
     if (!carriers.empty()) {
       const uint8_t *w;
       const uint32_t *o;
@@ -1012,6 +1060,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
           if (cv.cls[j] == 0) {
             verdict[carriers[j]] = cv.sender[j] ? 1 : 0;
             cert_rows++;
+            if (!cv.sender[j]) forged_now++;
           }
           MsgPtr &m = msgs[carriers[j]];
           if (!m) continue;
@@ -1047,6 +1096,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       }
     }
   }
+  forged_carriers_ = forged_carriers_ * 0.5 + (double)forged_now;  // (half-life: one batch)
   // (1) messages of the current view with the proposal at hand: judged completely, one set call per type
   std::vector<size_t> rest;
   // (a backend that judges bytes: the GPU always; the loop backend when rows are kept, so that the row path runs without a device)

@@ -234,6 +234,11 @@ class HotPath {
   // backend's rows when the message arrives and is NOT decoded (proto.hpp: RoundChangeMessage::certificate_deferred);
   // handleRoundChangeMessage takes the noted verdict.  rc_from_rows: messages decided that way so far.
   bool use_rc_rows = true;
+  // 0 = the trees of all carriers of a micro-batch are expanded and judged in the one certificate call; 1 = the carriers'
+  // own envelopes are judged first (one more backend call) and only authenticated carriers have their trees expanded;
+  // 2 (default) = 1 while forged carriers keep arriving (a decayed count of carriers whose envelope failed), 0 otherwise.
+  int cert_roots_first = 2;
+  size_t roots_first_calls = 0;
   size_t rc_from_rows = 0;
   double last_ingest_device_ms = 0.0;  // wall time the last IngestFlat spent inside the batch backend's calls
   size_t lean_rows = 0;        // messages ingested as rows so far
@@ -331,6 +336,7 @@ class HotPath {
   // isValidMsgFn of handleRoundChangeMessage for the ROUND_CHANGE message at `row`, from the rows alone (no nested message
   // is decoded): 1 / 0 = the verdict, −1 = not decided here (an irregular shape: the object walk decides)
   int roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row);
+  double forged_carriers_ = 0.0;  // carriers whose own envelope failed, halved every batch
   std::vector<uint64_t> rc_set_;  // scratch: the sender set of one certificate
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);
   void prefetchSenders(const std::vector<const IbftMessage *> &msgs);

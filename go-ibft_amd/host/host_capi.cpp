@@ -616,6 +616,8 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
 void ibft_host_use_rc_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_rc_rows = on != 0; }
 size_t ibft_host_rc_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.rc_from_rows; }
+void ibft_host_cert_roots_first(ibft_host *h, int mode) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.cert_roots_first = mode; }
+size_t ibft_host_roots_first_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.roots_first_calls; }
 double ibft_host_last_ingest_device_ms(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.last_ingest_device_ms; }
 int ibft_host_retain_heap(size_t bytes) {
   // glibc: freed memory at the top of the heap above M_TRIM_THRESHOLD goes back to the kernel, blocks above

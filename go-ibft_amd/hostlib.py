@@ -136,6 +136,8 @@ def lib() -> C.CDLL:
         L.ibft_host_use_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rows.restype = None
         L.ibft_host_retain_heap.argtypes = [C.c_size_t]; L.ibft_host_retain_heap.restype = C.c_int
         L.ibft_host_use_rc_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rc_rows.restype = None
+        L.ibft_host_cert_roots_first.argtypes = [vp, C.c_int]; L.ibft_host_cert_roots_first.restype = None
+        L.ibft_host_roots_first_calls.argtypes = [vp]; L.ibft_host_roots_first_calls.restype = C.c_size_t
         L.ibft_host_last_ingest_device_ms.argtypes = [vp]; L.ibft_host_last_ingest_device_ms.restype = C.c_double
         L.ibft_host_rc_from_rows.argtypes = [vp]; L.ibft_host_rc_from_rows.restype = C.c_size_t
         L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
@@ -483,6 +485,14 @@ class Host:
 
     def last_ingest_device_ms(self) -> float:
         return float(self.L.ibft_host_last_ingest_device_ms(self.h))
+
+    def cert_roots_first(self, mode: int):
+        """0 = never, 1 = always, 2 = while forged carriers keep arriving (default): authenticate carriers before expanding trees"""
+        self.L.ibft_host_cert_roots_first(self.h, mode)
+
+    @property
+    def roots_first_calls(self) -> int:
+        return int(self.L.ibft_host_roots_first_calls(self.h))
 
     def use_rc_rows(self, on: bool):
         """Judge a ROUND_CHANGE message's certificate from the backend's rows on arrival (default) or by the object walk."""

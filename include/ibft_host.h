@@ -194,6 +194,15 @@ void ibft_host_use_certs(ibft_host *h, int on);
  * not judge, type and payload that disagree, hashes that are not 32 bytes, …) are left to the walk over the decoded objects,
  * and so is everything once the validator set changes.  use_rc_rows(0) = decode and walk, as before.  rc_from_rows:
  * ROUND_CHANGE messages decided that way so far.                                                                      */
+/* Who pays for a certificate.  Judging a carrier's whole tree on arrival means that ONE message from anybody — its From is
+ * just a field — buys up to N² signature checks, where the reference spends one IsValidValidator on it.  mode 1: the
+ * envelopes of the carriers of a micro-batch are judged first (one more backend call) and only authenticated carriers have
+ * their trees expanded; mode 0: never (one call, lowest latency); mode 2 (default): mode 1 while forged carriers keep
+ * arriving — a count of carriers whose own envelope failed, halved every batch, at 4 or more — mode 0 otherwise, so honest
+ * traffic keeps its single call and a flood costs the attacker's messages one check each after the first few.  The verdicts
+ * are the same in every mode.  roots_first_calls: how often the extra call was made.                                   */
+void ibft_host_cert_roots_first(ibft_host *h, int mode);
+size_t ibft_host_roots_first_calls(ibft_host *h);
 /* wall time the last ibft_host_ingest_* call spent inside the batch backend (the device calls), in milliseconds */
 double ibft_host_last_ingest_device_ms(ibft_host *h);
 void ibft_host_use_rc_rows(ibft_host *h, int on);

@@ -320,15 +320,17 @@ def test_ingest_wire_through_the_device(gpu_verifier, oracle, sets, rows):
     ref.close(); ing.close()
 
 
-@pytest.mark.parametrize("rc_rows", [True, False])
-def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle, rc_rows):
+@pytest.mark.parametrize("rc_rows,roots_first", [(True, 2), (False, 2), (True, 1)])
+def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle, rc_rows, roots_first):
     """§8f ranks 1 + 2 with the real backend at N = 128: ROUND-CHANGE messages with quorum-sized PreparedCertificates and the
     PREPREPARE whose RoundChangeCertificate is made of them arrive as wire bytes; IngestWire settles every nested signature
     and proposal-hash check in ONE ibft_verify_certificates_wire call per micro-batch (no PayloadNoSig re-marshal of nested
     messages on the host), handleRoundChangeMessage / handlePrePrepare then ask the device nothing — and decide exactly like
     the per-message walks backed by the CPU oracle, Byzantine certificates included.  rc_rows (default): the certificate of a
     ROUND_CHANGE message is judged from the device's rows on arrival (validPC + proposalMatchesCertificate in row form) and
-    never decoded; off: decoded, verdicts noted in the nested objects, the walk over them."""
+    never decoded; off: decoded, verdicts noted in the nested objects, the walk over them.  roots_first = 1: the carriers'
+    envelopes are judged before any tree is expanded (ibft_host_cert_roots_first: one more device call, a forged carrier's
+    tree is never looked at); 2 = the adaptive default, which stays with the single call here."""
     import go_ibft_amd.hostlib as H
     from oracle import wire as W, workload as WL
     n = 128
@@ -381,12 +383,14 @@ def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle,
     ing.attach_gpu(gpu_verifier)
     ing.use_batch(True)
     ing.use_rc_rows(rc_rows)
+    ing.cert_roots_first(roots_first)
     expect = [ref.add_message(x) for x in wires]
     got, rows, hits, calls = ing.ingest_wire(wires)
-    assert [x != 0 for x in got] == [x != 0 for x in expect] and got[-1] == 0 and calls == 1   # ONE device call for the micro-batch
-    assert ing.rc_from_rows == (len(rcs) if rc_rows else 0)                                # (the forged envelope is not stored)
+    extra = 1 if roots_first == 1 else 0
+    assert [x != 0 for x in got] == [x != 0 for x in expect] and got[-1] == 0 and calls == 1 + extra   # ONE device call for the micro-batch
+    assert ing.rc_from_rows == (len(rcs) if rc_rows else 0) and ing.roots_first_calls == extra  # (the forged envelope is not stored)
     c_calls, c_rows, _ = ing.cert_stats()
-    assert c_calls == 1 and c_rows == len(wires) * (1 + quorum)                            # every message of every tree judged
+    assert c_calls == 1 and c_rows == (len(wires) - extra) * (1 + quorum)                  # every message of every (authenticated) tree judged
     for h in (ref, ing):
         h.set_state(1, 1, None)
     a = sorted(ref.handle_round_change(1, 1))

@@ -172,3 +172,54 @@ def test_every_certificate_rule_from_rows(kind):
     assert sorted(hosts["rows"].store_get_valid(height, rnd, 3)) == sorted(wires)
     for h in hosts.values():
         h.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_a_flood_of_forged_carriers_does_not_buy_their_trees(mode):
+    """judging a carrier's tree on arrival lets anybody buy N² signature checks with one message.  With
+    cert_roots_first (2 = adaptive, the default) the carriers' envelopes are judged first while forged carriers keep arriving:
+    the nested messages of a forged carrier are then never looked at.  Same verdicts in every mode."""
+    n = 10
+    w = World(n=n, seed=77)
+    height, rnd, raw = 3, 1, b"the block"
+    honest = [rc_message(w, height, rnd, a, raw=raw, cert=w.certificate(height, 0, raw), cert_round=0) for a in w.addrs]
+    forged = []
+    for k in range(40):                                   # a stranger replays honest certificates under envelopes of its own
+        m = rc_message(w, height, rnd, w.addrs[k % n], raw=raw, cert=w.certificate(height, 0, raw), cert_round=0)
+        m.signature = b"forged-%d" % k
+        w.bad_wires.add(m.encode())
+        forged.append(m)
+    nested_asked = []
+    ver = w.verifier()
+    inner = ver["is_valid_validator"]
+    ver["is_valid_validator"] = lambda wire: (nested_asked.append(wire), inner(wire))[1]
+    stock, fast = w.host(), H.Host()
+    assert fast.vm_init({a: 1 for a in w.addrs})
+    fast.set_verifier(**ver)
+    fast.use_loop_batch(0)
+    fast.use_batch(True)
+    fast.cert_roots_first(mode)
+    for h in (stock, fast):
+        h.set_id(b"someone else")
+        h.set_state(height, rnd, None)
+    batches = [[m.encode() for m in forged[k:k + 8]] for k in range(0, 40, 8)] + [[m.encode() for m in honest]]
+    for wires in batches:
+        assert stock.ingest_wire(wires)[0] == fast.ingest_wire(wires)[0]
+    assert sorted(stock.handle_round_change(height, rnd)) == sorted(fast.handle_round_change(height, rnd))
+    q = 2 * n // 3 + 1
+    per_tree = 1 + q                                       # the carrier, the PREPREPARE, q − 1 PREPAREs
+    everything = (40 + n) * per_tree
+    if mode == 0:
+        assert len(nested_asked) == everything and fast.roots_first_calls == 0
+    elif mode == 1:
+        assert len(nested_asked) == 40 + n + n * per_tree and fast.roots_first_calls == len(batches)
+    else:   # the first batch is expanded in full (nothing was known), from then on forged carriers cost one check each; the
+            # honest batch that follows the flood still pays the extra call, the one after it would not
+        assert len(nested_asked) == 8 * per_tree + 32 + n + n * per_tree and fast.roots_first_calls == len(batches) - 1
+        for _ in range(3):
+            fast.ingest_wire([honest[0].encode()])         # re-deliveries: no carriers asked, the count decays
+        fresh = rc_message(w, height, rnd + 1, w.addrs[0], raw=raw, cert=w.certificate(height, 0, raw), cert_round=0)
+        calls = fast.roots_first_calls
+        fast.ingest_wire([fresh.encode()])
+        assert fast.roots_first_calls == calls             # calm again: one call per micro-batch
+    stock.close(); fast.close()
