@@ -797,7 +797,7 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
 }
 
 bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats,
-                         uint8_t *types) {
+                         uint8_t *types, const std::shared_ptr<const void> &owned) {
   for (size_t i = 0; i < n; i++) results[i] = -1;
   if (types) memset(types, 0xFF, n);
   IngestStats st;
@@ -814,9 +814,10 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   }
   const Proposal *proposal = getProposal();
   syncClosureKey(proposal);
-  // ONE copy of the batch: the buffer every message decoded below points into (and keeps alive)
-  const uint8_t *wire;
-  const std::shared_ptr<const void> backing = make_backing(wire_in, off[n], &wire);
+  // ONE copy of the batch: the buffer every message decoded below points into (and keeps alive) — or none, when the caller
+  // hands over a buffer it shares (`owned`: the receive queue's)
+  const uint8_t *wire = wire_in;
+  const std::shared_ptr<const void> backing = owned ? owned : make_backing(wire_in, off[n], &wire);
   std::vector<MsgPtr> msgs(n);
   std::vector<int8_t> verdict(n, -1);       // −1 unknown, 0 / 1 decided
   std::vector<uint64_t> fp1(n), fp2(n);
@@ -1441,18 +1442,64 @@ bool HotPath::handleLean(const View &view, MessageType type, bool &quorum) {
       quorum = false;
       return true;
     }
-    seals.reserve(left + objects.size());
-    lv = messages.LeanFor(view, type, closure_epoch_, valset_epoch_);
-    if (lv)
-      lv->for_each([&](const LeanRow &row) {
-        CommittedSeal cs{bytes::view((const char *)row.wire + row.from_off, row.from_len),
-                         bytes::view((const char *)row.wire + row.seal_off, row.seal_len), nullptr, lv->buffers[row.buf]};
-        seals.emplace_back(std::move(cs));
-      });
-    committedSeals = std::move(seals);
+    committedSeals = std::move(seals);  // (+ the rows': CommittedSeals() / PackCommittedSeals())
+    committed_as_rows = true;
+    committed_view = view;
     stateName = StateName::fin;
   }
   return true;
+}
+
+// the seals of the last successful handleCommit: the objects' (extracted then) and, when the view held rows, the rows' — read
+// off their bytes now (the seal list keeps the buffers alive)
+const std::vector<std::optional<CommittedSeal>> &HotPath::CommittedSeals() {
+  if (committed_as_rows) {
+    committed_as_rows = false;
+    if (LeanView *lv = messages.LeanFor(committed_view, COMMIT, closure_epoch_, valset_epoch_)) {
+      committedSeals.reserve(committedSeals.size() + lv->size());
+      lv->for_each([&](const LeanRow &row) {
+        CommittedSeal cs{bytes::view((const char *)row.wire + row.from_off, row.from_len),
+                         bytes::view((const char *)row.wire + row.seal_off, row.seal_len), nullptr, lv->buffers[row.buf]};
+        committedSeals.emplace_back(std::move(cs));
+      });
+    }
+  }
+  return committedSeals;
+}
+// the same list in the C API's packing ({u8 present, u32 length + signer, u32 length + signature} per seal), rows straight
+// from their bytes
+size_t HotPath::PackCommittedSeals(bytes &out) {
+  size_t count = 0;
+  auto put = [&](const char *signer, size_t ls, const char *sig, size_t lg) {
+    const uint32_t a = (uint32_t)ls, b = (uint32_t)lg;
+    out.push_back(1);
+    out.append((const char *)&a, 4);
+    out.append(signer, ls);
+    out.append((const char *)&b, 4);
+    out.append(sig, lg);
+    count++;
+  };
+  LeanView *lv = committed_as_rows ? messages.LeanFor(committed_view, COMMIT, closure_epoch_, valset_epoch_) : nullptr;
+  size_t total = 0;
+  for (auto &s : committedSeals) total += 9 + (s ? s->signer.size() + s->signature.size() : 0);
+  if (lv) total += lv->size() * (9 + 20 + 65);
+  out.reserve(out.size() + total);
+  for (auto &s : committedSeals) {
+    if (s) {
+      put(s->signer.data(), s->signer.size(), s->signature.data(), s->signature.size());
+    } else {
+      const uint32_t z = 0;
+      out.push_back(0);
+      out.append((const char *)&z, 4);
+      out.append((const char *)&z, 4);
+      count++;
+    }
+  }
+  if (lv)
+    lv->for_each([&](const LeanRow &row) {
+      put((const char *)row.wire + row.from_off, row.from_len, (const char *)row.wire + row.seal_off, row.seal_len);
+    });
+  return count;
 }
 
 std::vector<bytes> HotPath::PreparedWire() {
@@ -1557,6 +1604,7 @@ bool HotPath::handleCommit(const View &view) {
   std::vector<std::optional<CommittedSeal>> seals;
   if (!extract_committed_seals(commitMessages, seals)) return false;  // safe check, ibft.go:952-958
   committedSeals = std::move(seals);
+  committed_as_rows = false;
   stateName = StateName::fin;
   return true;
 }

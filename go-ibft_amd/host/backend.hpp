@@ -244,6 +244,10 @@ class HotPath {
   size_t lean_rows = 0;        // messages ingested as rows so far
   bool prepared_as_rows = false;  // the last successful handlePrepare ran over rows: PC.PrepareMessages = PreparedWire()
   View prepared_view{};
+  bool committed_as_rows = false;  // the last successful handleCommit ran over rows: their seals are read on demand
+  View committed_view{};
+  const std::vector<std::optional<CommittedSeal>> &CommittedSeals();  // state.getCommittedSeals() after handleCommit
+  size_t PackCommittedSeals(bytes &out);                              // the same, packed for the C API; returns their number
   std::vector<bytes> PreparedWire();  // the prepared messages' wire bytes (rows: as stored; objects: encoded)
   size_t cert_calls = 0, cert_rows = 0;  // certificate-tree calls made by IngestWire, rows they judged
   size_t cert_hits = 0;  // sender verdicts the last certificate walk took from the arrival-time tables
@@ -254,8 +258,10 @@ class HotPath {
   // as they are.  results[i]: −1 undecodable, else AddMessage's 0 / 1 / 2.
   // types (optional, n bytes): IbftMessage.type of every row that decoded (0xFF otherwise) — what a caller needs to turn a
   // result of 2 into the SignalEvent(type, view) of core/ibft.go:1119.
+  // owned: a buffer the rows lie in that the caller SHARES with the mirror (it must stay unchanged for as long as anybody
+  // holds it): the stored messages point into it and keep it alive, and the batch is not copied.
   bool IngestFlat(const uint8_t *wire, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats = nullptr,
-                  uint8_t *types = nullptr);
+                  uint8_t *types = nullptr, const std::shared_ptr<const void> &owned = nullptr);
   // IBFT.AddMessage with IsValidValidator already answered (AddMessageFast when the quorum index is enabled)
   int addWithVerdict(MsgPtr m, bool sender_ok);
   void PruneVerdictCache(uint64_t below_height);

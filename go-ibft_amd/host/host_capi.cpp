@@ -189,11 +189,12 @@ struct ibft_host {
 
 namespace {
 void IngestQueue::loop() {
-  std::vector<uint8_t> wire;
   std::vector<uint32_t> off;
   std::vector<int8_t> res;
   std::vector<uint8_t> types;
   for (;;) {
+    // the bytes that arrived become the buffer the stored messages point into: handed to the mirror, not copied again
+    auto buf = std::make_shared<std::vector<uint8_t>>();
     {
       std::unique_lock<std::mutex> lk(mu_);
       cv_.wait(lk, [&] { return stop_ || off_.size() > 1; });
@@ -205,11 +206,13 @@ void IngestQueue::loop() {
           cv_.wait_for(lk, dl / 4 + std::chrono::microseconds(1));
         if (stop_) return;
       }
-      wire.swap(wire_);
       off.swap(off_);
-      wire_.clear();
       off_.assign(1, 0);
+      buf->swap(wire_);
+      wire_.reserve(buf->size());  // (the next burst is about as large: no regrowth from nothing under the pushers' feet)
     }
+    const std::vector<uint8_t> &wire = *buf;
+    const std::shared_ptr<const void> shared(buf, buf->data());
     const size_t n = off.size() - 1;
     res.assign(n, -1);
     types.assign(n, 0xFF);
@@ -221,7 +224,7 @@ void IngestQueue::loop() {
       // rows [lo, lo + k): offsets rebased by IngestFlat's contract (off[0] may be non-zero: it reads wire[off[i] .. off[i+1]))
       HotPath::IngestStats st;
       const auto t0 = std::chrono::steady_clock::now();
-      h_->hp.IngestFlat(wire.data(), off.data() + lo, k, res.data() + lo, &st, types.data() + lo);
+      h_->hp.IngestFlat(wire.data(), off.data() + lo, k, res.data() + lo, &st, types.data() + lo, shared);
       d.ingest_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       d.device_us += (uint64_t)(st.device_ms * 1e3);
       d.batches++;
@@ -736,7 +739,11 @@ int ibft_host_handle_prepare(ibft_host *h, uint64_t height, uint64_t round, ibft
 int ibft_host_handle_commit(ibft_host *h, uint64_t height, uint64_t round, ibft_host_buf *seals) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   bool q = h->hp.handleCommit(View{height, round, {}});
-  if (seals) seals_to_buf(q ? h->hp.committedSeals : std::vector<std::optional<CommittedSeal>>{}, seals);
+  if (seals) {
+    bytes o;
+    const size_t count = q ? h->hp.PackCommittedSeals(o) : 0;
+    to_buf(o, count, seals);
+  }
   return q ? 1 : 0;
 }
 

@@ -526,6 +526,10 @@ class Host:
         out = unpack(_take(b))
         return out[0] if q and out else None
 
+    def handle_preprepare_quiet(self, height, round_) -> bool:
+        """handlePrePrepare → accepted or not (the message itself stays in the mirror)"""
+        return bool(self.L.ibft_host_handle_preprepare(self.h, height, round_, None))
+
     def use_sets(self, on: bool):
         self.L.ibft_host_use_sets(self.h, 1 if on else 0)
 

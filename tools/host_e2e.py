@@ -219,6 +219,55 @@ def round_change_through_the_mirror(V, H, n: int = 256, reps: int = 10, rc_rows:
     return res
 
 
+def reproposal_through_the_mirror(V, H, n: int = 256, reps: int = 8):
+    """the other half of a round change: the new proposer's PREPREPARE carries the RoundChangeCertificate — Q ROUND_CHANGE
+    messages with their prepared certificates, ONE message of ≈4 MB — and every node validates it (handlePrePrepare →
+    validateProposal, core/ibft.go:683-788, 792-813): ibft_host_ingest_wire of that one message → handlePrePrepare"""
+    import cert_cases as CC
+    from oracle import wire, workload as W
+    r = W.make_round(n, 900 + n, height=5, round_=1, raw_len=1024)
+    q = (2 * n) // 3 + 1
+    pm = CC.preprepare(r, 1, 5, 1)
+    prepares = [CC.prepare(r, j, 5, 1) for j in range(n) if j != 1][: q - 1]
+    pcb = wire.prepared_certificate(pm, prepares)
+    rcs = [CC.round_change(r, i, 5, 2, wire.Proposal(r.raw, 1), pcb) for i in range(q)]
+    pp = CC.preprepare_with_rcc(r, 5, 2, rcs, proposal_round=2).encode()
+    powers = {r.addrs[i].tobytes(): int(r.power[i]) for i in range(n)}
+    packed = H.pack([pp])
+    res = {"validators": n, "message_bytes": len(pp), "signatures": 1 + q * (q + 1)}
+    for name, flags in (("cold", 0), ("warm", V.FLAG_PUBKEY_CACHE)):
+        bv = V.BatchVerifier(flags=flags, max_rows=65536)
+        ing, hpp, dev = [], [], []
+        try:
+            bv.set_validators(5, r.addrs, r.power)
+            for rep in range(reps + 2):
+                host = H.Host()
+                assert host.vm_init(powers)
+                host.set_id(r.addrs[0].tobytes())
+                host.set_round_robin_proposer([r.addrs[i].tobytes() for i in range(n)], use_height=False)
+                host.set_state(5, 2, None)
+                host.attach_gpu(bv)
+                host.use_batch(True)
+                host.enable_quorum_index()
+                t0 = time.perf_counter()
+                rc = host.ingest_packed(packed, 1)
+                t1 = time.perf_counter()
+                ok = host.handle_preprepare_quiet(5, 2)
+                t2 = time.perf_counter()
+                assert set(rc) <= {1, 2} and ok and host.fallbacks() == 0, (rc, ok)
+                dev_ms = host.last_ingest_device_ms()
+                host.close()
+                if rep >= 2:
+                    ing.append((t1 - t0) * 1e3)
+                    hpp.append((t2 - t1) * 1e3)
+                    dev.append(dev_ms)
+        finally:
+            bv.close()
+        res[name] = {"ingest_ms": float(np.median(ing)), "of_which_device_ms": float(np.median(dev)),
+                     "handle_preprepare_ms": float(np.median(hpp)), "total_ms": float(np.median(np.array(ing) + np.array(hpp)))}
+    return res
+
+
 if __name__ == "__main__":
     import go_ibft_amd.hostlib as H
     import go_ibft_amd.verifier as V
@@ -236,5 +285,6 @@ if __name__ == "__main__":
     if "--no-rc" not in sys.argv:
         out["round_change_n256"] = round_change_through_the_mirror(V, H)
         out["round_change_n256_object_walk"] = round_change_through_the_mirror(V, H, rc_rows=False)
+        out["reproposal_n256"] = reproposal_through_the_mirror(V, H)
     out["retain_heap"] = "--no-retain-heap" not in sys.argv
     print(json.dumps(out, indent=1))
