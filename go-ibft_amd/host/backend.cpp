@@ -213,7 +213,7 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
 // messages of a PREPREPARE payload; proposalMessage, then prepareMessages, of a ROUND_CHANGE payload's PreparedCertificate
 static void nested_messages(const IbftMessage &m, std::vector<MsgPtr> &out) {
   out.clear();
-  if (m.kind == PayloadKind::PREPREPARE && m.preprepare().certificate) {
+  if (m.kind == PayloadKind::PREPREPARE && m.preprepare().realise_certificate() && m.preprepare().certificate) {
     out = m.preprepare().certificate->round_change_messages;
   } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().realise_certificate() && m.round_change().latest_prepared_certificate) {
     const PreparedCertificate &pc = *m.round_change().latest_prepared_certificate;
@@ -567,19 +567,21 @@ void HotPath::PruneVerdictCache(uint64_t below_height) {
 // The verdicts of one root row of a certificate call and of everything below it are noted IN the decoded objects, matched
 // by position: a decoded message lists its nested messages in the order the device lists them.  A subtree whose row count
 // differs from the decoded count (the device refused the wrapper as non-canonical) is left to the stock route.
-// validPC (core/ibft.go:1162-1231) ∧ proposalMatchesCertificate (:516-551) for the ROUND_CHANGE message at `row`, read off
-// the backend's rows: view / type / payload kind / From / carried hash of every nested message (ibft_wire_row_t), its
-// IsValidValidator bit and its IsValidProposalHash(lastPreparedProposal, hash) bit.  Only the REGULAR shape is decided here —
-// every nested message judged (class 0), with a view, a From of at most 20 bytes and a 32-byte hash under the payload its
-// type announces; anything else (−1) is left to the walk over the decoded objects, which is the authority for the corner cases.
-int HotPath::roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row) {
+// validPC (core/ibft.go:1162-1231) for the PreparedCertificate of the ROUND_CHANGE message at `row`, read off the backend's
+// rows: view / type / payload kind / From / carried hash of every nested message (ibft_wire_row_t) and its IsValidValidator
+// bit; with match_proposal also proposalMatchesCertificate (:516-551) against the message's own lastPreparedProposal (the
+// IsValidProposalHash bits).  2 = the message carries no certificate, 1 / 0 = the verdict, −1 = not decided here.  Only the
+// REGULAR shape is decided — every nested message judged (class 0), with a view, a From of at most 20 bytes and a 32-byte
+// hash under the payload its type announces; anything else is left to the walk over the decoded objects, which is the
+// authority for the corner cases.
+int HotPath::pcVerdictFromRows(const CertVerdicts &cv, size_t row, uint64_t limit, uint64_t height, bool match_proposal) {
   if (row >= cv.n_rows || cv.rows.size() != cv.n_rows || cv.cls[row] != 0) return -1;
   const ibft_wire_row_t &rc = cv.rows[row];
   const ibft_cert_node_t &nd = cv.nodes[row];
   if (rc.status != IBFT_WIRE_OK || !rc.has_view || rc.type != ROUND_CHANGE || rc.payload_kind != 8) return -1;
   const bool has_proposal = nd.flags & IBFT_CERT_HAS_PROPOSAL, has_cert = nd.flags & IBFT_CERT_HAS_CERTIFICATE;
-  if (!has_cert) return has_proposal ? 0 : 1;  // validPC(nil) is true; a proposal without a certificate does not match
-  if (!has_proposal) return -1;                // IsValidProposalHash(nil, hash): the backend's business
+  if (!has_cert) return 2;
+  if (match_proposal && !has_proposal) return -1;  // IsValidProposalHash(nil, hash): the backend's business
   const size_t lo = nd.first_child, n = nd.n_children;
   if (lo + n > cv.n_rows) return -1;
   if (n == 0) return 0;  // ProposalMessage == nil (and no PREPARE either)
@@ -601,7 +603,7 @@ int HotPath::roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row) {
     if (cv.rows[c].payload_kind != 6 || cv.rows[c].hash_len != 32) return -1;
   // AreValidPCMessages (messages/helpers.go:167-214): one height, one round below the limit, one hash, unique senders;
   // HasQuorum over the sender set (:1184)
-  const uint64_t height = rc.height, limit = rc.round, round = cv.rows[lo].round;
+  const uint64_t round = cv.rows[lo].round;
   size_t slots = 64;
   while (slots < 4 * n) slots <<= 1;
   rc_set_.assign(slots, 0);
@@ -630,14 +632,92 @@ int HotPath::roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row) {
   }
   if (!ok || power < validatorManager.quorum()) return 0;
   // the proposal message comes from the proposer of its view and is validly signed; the PREPAREs are validly signed and
-  // none of them comes from the proposer (:1207-1228); every hash is the hash of the last prepared proposal (:516-551)
+  // none of them comes from the proposer (:1207-1228); with match_proposal every hash is the hash of the last prepared
+  // proposal (:516-551)
   for (size_t c = lo; c < lo + n; c++) {
     const ibft_wire_row_t &w = cv.rows[c];
-    if (!cv.sender[c] || !cv.hash[c]) return 0;
+    if (!cv.sender[c] || (match_proposal && !cv.hash[c])) return 0;
     const bool proposer = verifier && verifier->IsProposer(bytes::view((const char *)w.from, w.from_len), w.height, w.round);
     if (proposer != (c == lo)) return 0;
   }
   return 1;
+}
+
+// handleRoundChangeMessage's isValidMsgFn (core/ibft.go:478-489) for the ROUND_CHANGE message at `row`:
+// validPC(latestPC, view.round, view.height) ∧ proposalMatchesCertificate(lastPreparedProposal, latestPC)
+int HotPath::roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row) {
+  if (row >= cv.n_rows || cv.rows.size() != cv.n_rows) return -1;
+  const int v = pcVerdictFromRows(cv, row, cv.rows[row].round, cv.rows[row].height, true);
+  if (v != 2) return v;
+  // no certificate: validPC(nil) is true; a proposal without a certificate does not match, no proposal either does
+  return (cv.nodes[row].flags & IBFT_CERT_HAS_PROPOSAL) ? 0 : 1;
+}
+
+// validateProposal (core/ibft.go:683-788) as far as it is a function of the PREPREPARE message at `row` and of the
+// validator set: the RoundChangeCertificate has unique senders and a quorum of them, every ROUND_CHANGE message in it is of
+// the proposal's view and validly signed (ok), and the prepared certificates that are valid name a highest round and the
+// hash prepared in it (has_prepared, max_round, hash).  What depends on the node and on the application — the common
+// checks, IsProposer(ID), IsValidProposal, the final IsValidProposalHash — stays with validateProposal.  false = not
+// decided here.
+bool HotPath::proposalVerdictFromRows(const CertVerdicts &cv, size_t row, ProposalVerdict &out) {
+  out = ProposalVerdict();
+  if (row >= cv.n_rows || cv.rows.size() != cv.n_rows || cv.cls[row] != 0) return false;
+  const ibft_wire_row_t &pp = cv.rows[row];
+  const ibft_cert_node_t &nd = cv.nodes[row];
+  if (pp.status != IBFT_WIRE_OK || !pp.has_view || pp.type != PREPREPARE || pp.payload_kind != 5) return false;
+  out.rows = 0;
+  if (!(nd.flags & IBFT_CERT_HAS_CERTIFICATE)) return true;  // rcc == nil: not ok (for a round above 0)
+  const size_t lo = nd.first_child, n = nd.n_children;
+  if (lo + n > cv.n_rows) return false;
+  for (size_t c = lo; c < lo + n; c++) {
+    const ibft_wire_row_t &w = cv.rows[c];
+    if (cv.cls[c] != 0 || w.status != IBFT_WIRE_OK || !w.has_view || w.from_len > 20 || cv.nodes[c].role != IBFT_CERT_ROLE_RCC_MESSAGE)
+      return false;
+    if (w.type == ROUND_CHANGE && w.payload_kind != 8) return false;  // (ExtractLatestPC's type / payload rule: not decided here)
+    out.rows += 1 + cv.nodes[c].n_children;
+  }
+  if (n == 0 || !validatorManager.initialized()) return true;  // HasUniqueSenders of nothing / HasQuorum of anything: false
+  // HasUniqueSenders, hasQuorumByMsgType(ROUND_CHANGE) = HasQuorum over the sender set (:707-716)
+  size_t slots = 64;
+  while (slots < 4 * n) slots <<= 1;
+  std::vector<uint64_t> set(slots, 0);  // (rc_set_ is pcVerdictFromRows' scratch)
+  unsigned __int128 power = 0;
+  for (size_t c = lo; c < lo + n; c++) {
+    const ibft_wire_row_t &w = cv.rows[c];
+    const std::string_view from((const char *)w.from, w.from_len);
+    const uint64_t hk = hash_key(from.data(), from.size());
+    for (size_t sl = hk & (slots - 1);; sl = (sl + 1) & (slots - 1)) {
+      const uint64_t e = set[sl];
+      if (e == 0) {
+        set[sl] = (hk & 0xFFFFFFFF00000000ull) | (uint64_t)(c - lo + 1);
+        break;
+      }
+      if ((e & 0xFFFFFFFF00000000ull) != (hk & 0xFFFFFFFF00000000ull)) continue;
+      const ibft_wire_row_t &o = cv.rows[lo + (size_t)(e & 0xFFFFFFFFull) - 1];
+      if (o.from_len == w.from_len && memcmp(o.from, w.from, w.from_len) == 0) return true;  // the same sender twice: not ok
+    }
+    power += validatorManager.powerOf(from);
+  }
+  if (power < validatorManager.quorum()) return true;
+  // every message is a ROUND_CHANGE of the proposal's view, validly signed (:724-744)
+  for (size_t c = lo; c < lo + n; c++) {
+    const ibft_wire_row_t &w = cv.rows[c];
+    if (w.type != ROUND_CHANGE || w.height != pp.height || w.round != pp.round || !cv.sender[c]) return true;
+  }
+  // the valid prepared certificates: (round, hash) of their proposal messages; the highest round wins, the last one among equals (:746-778)
+  for (size_t c = lo; c < lo + n; c++) {
+    const int v = pcVerdictFromRows(cv, c, pp.round, pp.height, false);
+    if (v < 0) return false;
+    if (v != 1) continue;
+    const ibft_wire_row_t &first = cv.rows[cv.nodes[c].first_child];
+    if (!out.has_prepared || first.round >= out.max_round) {
+      out.max_round = first.round;
+      memcpy(out.hash, first.proposal_hash, 32);
+    }
+    out.has_prepared = true;
+  }
+  out.ok = true;
+  return true;
 }
 
 void HotPath::noteCertificateTree(const CertVerdicts &cv, size_t row, const MsgPtr &root, bool note) {
@@ -940,7 +1020,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   auto decode_all = [&]() {
     for (size_t i : to_decode) {
       auto m = std::make_shared<IbftMessage>();
-      const bool defer = defer_certificates && kinds[i] == (uint8_t)PayloadKind::ROUND_CHANGE;
+      const bool defer = defer_certificates && (kinds[i] == (uint8_t)PayloadKind::ROUND_CHANGE || kinds[i] == (uint8_t)PayloadKind::PREPREPARE);
       if (decode_in(backing, wire + off[i], off[i + 1] - off[i], *m, defer)) msgs[i] = std::move(m);  // else: dropped (results −1)
     }
   };
@@ -1065,7 +1145,8 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
           }
           MsgPtr &m = msgs[carriers[j]];
           if (!m) continue;
-          const bool deferred = m->kind == PayloadKind::ROUND_CHANGE && m->round_change().certificate_deferred;
+          const bool deferred = (m->kind == PayloadKind::ROUND_CHANGE && m->round_change().certificate_deferred) ||
+                                (m->kind == PayloadKind::PREPREPARE && m->preprepare().certificate_deferred);
           if (defer_certificates && cv.cls[j] == 0 && m->kind == PayloadKind::ROUND_CHANGE) {
             vouched[carriers[j]] = 1;  // well-formed and canonical down to the last nested message: may stay undecoded
             const int rc_ok = roundChangeVerdictFromRows(cv, j);
@@ -1083,7 +1164,30 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
               }
             }
           }
-          if (deferred && !m->round_change().realise_certificate()) {
+          if (defer_certificates && cv.cls[j] == 0 && m->kind == PayloadKind::PREPREPARE) {
+            vouched[carriers[j]] = 1;
+            ProposalVerdict pv;
+            if (proposalVerdictFromRows(cv, j, pv)) {
+              if (verdict[carriers[j]] != 0) {
+                m->proposal_verdict.mut() = pv;
+                m->verdicts.pp_epoch = valset_epoch_;
+                // (its own (proposal, proposalHash) bit — validateProposalCommon's question — is a row verdict as well)
+                if (const Proposal *own = extract_proposal(*m)) {
+                  if (extract_proposal_hash(*m) && !(cv.cls[j] & IBFT_CERT_CLASS_PROPOSAL_BY_HOST)) {
+                    m->verdicts.self = cv.self[j] != 0;
+                    m->verdicts.self_of = own;
+                  }
+                }
+                pp_from_rows++;
+              }
+              if (deferred || cv.nodes[j].n_children == 0) {
+                cert_rows += pv.rows;
+                continue;
+              }
+            }
+          }
+          if (deferred && !(m->kind == PayloadKind::ROUND_CHANGE ? m->round_change().realise_certificate()
+                                                                 : m->preprepare().realise_certificate())) {
             m.reset();  // proto.Unmarshal would have failed on this message: dropped (results −1)
             continue;
           }
@@ -1143,8 +1247,11 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   decoded();
   if (defer_certificates)  // certificates nobody vouched for are decoded now; a message whose certificate does not decode is dropped
     for (size_t i : to_decode)
-      if (msgs[i] && !vouched[i] && msgs[i]->kind == PayloadKind::ROUND_CHANGE && msgs[i]->round_change().certificate_deferred &&
-          !msgs[i]->round_change().realise_certificate())
+      if (msgs[i] && !vouched[i] &&
+          ((msgs[i]->kind == PayloadKind::ROUND_CHANGE && msgs[i]->round_change().certificate_deferred &&
+            !msgs[i]->round_change().realise_certificate()) ||
+           (msgs[i]->kind == PayloadKind::PREPREPARE && msgs[i]->preprepare().certificate_deferred &&
+            !msgs[i]->preprepare().realise_certificate())))
         msgs[i].reset();
   if (lean_mode && !wire_sets_done)
     for (size_t i : ask)
@@ -1758,6 +1865,22 @@ MsgPtr HotPath::handlePrePrepare(const View &view) {
 bool HotPath::validateProposal(const IbftMessage &msg, const View &view) {
   const uint64_t height = view.height, round = view.round;
   const Proposal *proposal = extract_proposal(msg);
+  if (use_rc_rows && msg.verdicts.pp_epoch == valset_epoch_ && msg.view && msg.view->height == height && msg.view->round == round) {
+    // everything about the RoundChangeCertificate was decided from the backend's rows when the message arrived
+    // (proposalVerdictFromRows) — the certificate itself was never decoded; what depends on this node and on the
+    // application is asked now
+    const ProposalVerdict &pv = msg.proposal_verdict.get();
+    if (!validateProposalCommon(msg, view)) return false;
+    if (!pv.ok) return false;
+    if (verifier->IsProposer(verifier->ID(), height, round)) return false;
+    cert_hits = pv.rows;
+    if (!pv.has_prepared) return true;
+    Proposal p2;
+    p2.raw_proposal = proposal->raw_proposal;
+    p2.round = pv.max_round;
+    const bytes expected = bytes::view((const char *)pv.hash, 32);
+    return verifier->IsValidProposalHash(&p2, &expected);
+  }
   const RoundChangeCertificate *rcc = extract_round_change_certificate(msg);
   if (!validateProposalCommon(msg, view)) return false;
   if (!rcc) return false;

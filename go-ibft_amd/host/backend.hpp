@@ -240,6 +240,7 @@ class HotPath {
   int cert_roots_first = 2;
   size_t roots_first_calls = 0;
   size_t rc_from_rows = 0;
+  size_t pp_from_rows = 0;  // PREPREPARE messages whose RoundChangeCertificate was judged from rows (and left undecoded)
   double last_ingest_device_ms = 0.0;  // wall time the last IngestFlat spent inside the batch backend's calls
   size_t lean_rows = 0;        // messages ingested as rows so far
   bool prepared_as_rows = false;  // the last successful handlePrepare ran over rows: PC.PrepareMessages = PreparedWire()
@@ -342,6 +343,8 @@ class HotPath {
   // isValidMsgFn of handleRoundChangeMessage for the ROUND_CHANGE message at `row`, from the rows alone (no nested message
   // is decoded): 1 / 0 = the verdict, −1 = not decided here (an irregular shape: the object walk decides)
   int roundChangeVerdictFromRows(const CertVerdicts &cv, size_t row);
+  int pcVerdictFromRows(const CertVerdicts &cv, size_t row, uint64_t limit, uint64_t height, bool match_proposal);
+  bool proposalVerdictFromRows(const CertVerdicts &cv, size_t row, ProposalVerdict &out);
   double forged_carriers_ = 0.0;  // carriers whose own envelope failed, halved every batch
   std::vector<uint64_t> rc_set_;  // scratch: the sender set of one certificate
   bool validPCImpl(const PreparedCertificate *certificate, uint64_t roundLimit, uint64_t height);

@@ -352,7 +352,7 @@ int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *of
     }
     for (size_t k = 0; k < all.size(); k++) {  // breadth first, like the device
       const IbftMessage &m = *all[k];
-      if (m.kind == PayloadKind::PREPREPARE && m.preprepare().certificate) {
+      if (m.kind == PayloadKind::PREPREPARE && m.preprepare().realise_certificate() && m.preprepare().certificate) {
         for (auto &c : m.preprepare().certificate->round_change_messages) all.push_back(c);
       } else if (m.kind == PayloadKind::ROUND_CHANGE && m.round_change().realise_certificate() && m.round_change().latest_prepared_certificate) {
         const PreparedCertificate &pc = *m.round_change().latest_prepared_certificate;
@@ -618,6 +618,7 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
 }
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
 void ibft_host_use_rc_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_rc_rows = on != 0; }
+size_t ibft_host_pp_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.pp_from_rows; }
 size_t ibft_host_rc_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.rc_from_rows; }
 void ibft_host_cert_roots_first(ibft_host *h, int mode) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.cert_roots_first = mode; }
 size_t ibft_host_roots_first_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.roots_first_calls; }

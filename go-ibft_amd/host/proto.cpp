@@ -201,6 +201,13 @@ bool decode_preprepare(const uint8_t *p, size_t n, PrePrepareMessage &o, int dep
       set_bytes(o.proposal_hash, q, l);
     } else if (tag == ((3u << 3) | 2)) {
       if (!r.len_delim(q, l)) return false;
+      if (tl_defer_certificate && depth == 0 && tl_backing && !o.certificate && !o.certificate_deferred) {
+        o.certificate_deferred = true;  // (a second occurrence of the field — never canonical — is merged below)
+        o.certificate_wire = bytes::view((const char *)q, l);
+        o.certificate_backing = *tl_backing;
+        continue;
+      }
+      if (o.certificate_deferred && !o.realise_certificate()) return false;
       if (!o.certificate) o.certificate.emplace();
       if (!decode_rcc(q, l, *o.certificate, depth)) return false;
     } else if ((tag >> 3) >= 1 && (tag >> 3) <= 3) {
@@ -373,7 +380,10 @@ static bytes encode(const PrePrepareMessage &p) {
   bytes o;
   if (p.proposal) put_len_field(o, 1, encode(*p.proposal));
   put_bytes_field(o, 2, p.proposal_hash);
-  if (p.certificate) put_len_field(o, 3, encode(*p.certificate));
+  if (p.certificate_deferred)
+    put_len_field(o, 3, p.certificate_wire);  // (canonical by the condition under which a certificate stays deferred)
+  else if (p.certificate)
+    put_len_field(o, 3, encode(*p.certificate));
   o += p.unknown;
   return o;
 }
@@ -543,6 +553,22 @@ bool RoundChangeMessage::realise_certificate() const {
   if (ok) const_cast<RoundChangeMessage *>(this)->latest_prepared_certificate = std::move(pc);
   return ok;
 }
+bool PrePrepareMessage::realise_certificate() const {
+  if (!certificate_deferred) return true;
+  certificate_deferred = false;
+  const std::shared_ptr<const void> keep = std::move(certificate_backing);
+  const bytes w = std::move(certificate_wire);
+  certificate_backing.reset();
+  certificate_wire = bytes();
+  BackingScope scope(&keep);
+  const bool saved = tl_defer_certificate;
+  tl_defer_certificate = false;
+  RoundChangeCertificate rcc;
+  const bool ok = decode_rcc((const uint8_t *)w.data(), w.size(), rcc, 0);
+  tl_defer_certificate = saved;
+  if (ok) const_cast<PrePrepareMessage *>(this)->certificate = std::move(rcc);
+  return ok;
+}
 bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out, bool defer_certificate) {
   BackingScope scope(&backing);
   struct DeferScope {
@@ -596,6 +622,7 @@ const bytes *extract_proposal_hash(const IbftMessage &m) {
 }
 const RoundChangeCertificate *extract_round_change_certificate(const IbftMessage &m) {
   if (m.type != PREPREPARE || m.kind != PayloadKind::PREPREPARE) return nullptr;
+  if (m.preprepare().certificate_deferred) (void)m.preprepare().realise_certificate();
   return m.preprepare().certificate ? &*m.preprepare().certificate : nullptr;
 }
 const PreparedCertificate *extract_latest_pc(const IbftMessage &m) {

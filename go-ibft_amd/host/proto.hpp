@@ -49,6 +49,11 @@ struct PrePrepareMessage {
   bytes proposal_hash;
   std::optional<RoundChangeCertificate> certificate;
   bytes unknown;
+  // a certificate that has not been decoded yet — see RoundChangeMessage below
+  mutable bool certificate_deferred = false;
+  mutable bytes certificate_wire;
+  mutable std::shared_ptr<const void> certificate_backing;
+  bool realise_certificate() const;
 };
 struct PrepareMessage {
   bytes proposal_hash;
@@ -81,6 +86,16 @@ enum class PayloadKind { NONE, PREPREPARE, PREPARE, COMMIT, ROUND_CHANGE };
 // Verifier predicates are pure functions of the message bytes, the proposal and the validator set, so a verdict computed
 // when the message arrived can sit in the message object itself: it lives exactly as long as the message, needs no side
 // table, and is ignored (epoch mismatch) once the validator set or the proposal it was computed against has changed.
+// validateProposal (core/ibft.go:683-788) as far as it depends only on a PREPREPARE message's RoundChangeCertificate and on the
+// validator set, decided from a batch backend's rows when the message arrived (HotPath::proposalVerdictFromRows)
+struct ProposalVerdict {
+  bool ok = false;            // unique senders, quorum, every ROUND_CHANGE message of the proposal's view and validly signed
+  bool has_prepared = false;  // at least one valid PreparedCertificate: (max_round, hash) = the highest prepared round and its hash
+  uint64_t max_round = 0;
+  uint8_t hash[32] = {0};
+  uint32_t rows = 0;          // the nested messages the verdict covers
+};
+
 struct Verdicts {
   uint32_t sender_epoch = 0;   // validator-set epoch of `sender` (0 = unknown)
   uint32_t closure_epoch = 0;  // proposal epoch of `closure` (0 = unknown)
@@ -94,6 +109,7 @@ struct Verdicts {
   uint32_t rc_epoch = 0;  // validator-set epoch of `rc_ok` (0 = unknown)
   uint32_t rc_rows = 0;
   uint8_t rc_ok = 0;
+  uint32_t pp_epoch = 0;  // validator-set epoch of the message's ProposalVerdict (IbftMessage::proposal_verdict; 0 = none)
 };
 
 // A member most messages never use (the PREPREPARE / ROUND_CHANGE payloads, ≈ 500 bytes of the message object between them):
@@ -138,6 +154,7 @@ struct IbftMessage {
   RoundChangeMessage &round_change_mut() { return round_change_.mut(); }
   Lazy<PrePrepareMessage> preprepare_;
   Lazy<RoundChangeMessage> round_change_;
+  mutable Lazy<ProposalVerdict> proposal_verdict;  // (with verdicts.pp_epoch)
   bytes unknown;
   // the buffer the byte fields of a DECODED message (and of everything nested in it) point into; null for a message
   // that was built field by field
@@ -158,7 +175,8 @@ bytes encode(const RoundChangeCertificate &rcc);
 bool decode(const uint8_t *p, size_t n, IbftMessage &out);
 // The same without copying the wire: [p, p + n) lies inside `backing`, which the message (and every message nested in it)
 // keeps alive; all byte fields are views into it.
-// defer_certificate: the PreparedCertificate of a top-level ROUND_CHANGE payload is not decoded (RoundChangeMessage above).
+// defer_certificate: the PreparedCertificate of a top-level ROUND_CHANGE payload / the RoundChangeCertificate of a top-level
+// PREPREPARE payload is not decoded (RoundChangeMessage, PrePrepareMessage above).
 bool decode_in(const std::shared_ptr<const void> &backing, const uint8_t *p, size_t n, IbftMessage &out,
                bool defer_certificate = false);
 // What the receive side needs to know about a message BEFORE it is decoded (and without allocating anything): whether the

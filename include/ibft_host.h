@@ -207,6 +207,13 @@ size_t ibft_host_roots_first_calls(ibft_host *h);
 double ibft_host_last_ingest_device_ms(ibft_host *h);
 void ibft_host_use_rc_rows(ibft_host *h, int on);
 size_t ibft_host_rc_from_rows(ibft_host *h);
+/* The same switch covers the RoundChangeCertificate of a PREPREPARE message (validateProposal, core/ibft.go:683-788):
+ * unique senders, their quorum, every ROUND_CHANGE message of the proposal's view and validly signed, validPC of every
+ * nested PreparedCertificate and the highest prepared round with its hash are decided from the rows on arrival and the
+ * certificate stays undecoded; handlePrePrepare then asks only what depends on this node and on the application
+ * (the common checks, IsProposer(ID), IsValidProposal, the final IsValidProposalHash).  pp_from_rows: PREPREPARE messages
+ * decided that way so far.                                                                                             */
+size_t ibft_host_pp_from_rows(ibft_host *h);
 /* PROCESS-WIDE, optional: keep up to `bytes` of freed C heap in the process (glibc mallopt: M_TRIM_THRESHOLD, M_TOP_PAD,
  * M_MMAP_THRESHOLD) instead of handing it back to the kernel.  The mirror's memory has the rhythm of the chain — the
  * messages of a height are stored, then pruned — and with the default thresholds every height's buffers are fresh pages

@@ -82,6 +82,7 @@ def test_certificates_on_arrival_equal_stock(seed, mode):
     if mode in ("certs", "certs_objects"):
         assert calls >= 3 and rows > 20 and fast.loop_batch_cert_calls() == calls
         assert fast.rc_from_rows > 5 if mode == "certs" else fast.rc_from_rows == 0
+        assert (fast.pp_from_rows >= 1 or getattr(w, "irregular", False)) if mode == "certs" else fast.pp_from_rows == 0
     else:
         assert calls == 0 and fast.rc_from_rows == 0
     for view_round in (1, 2, 3):
@@ -223,3 +224,70 @@ def test_a_flood_of_forged_carriers_does_not_buy_their_trees(mode):
         fast.ingest_wire([fresh.encode()])
         assert fast.roots_first_calls == calls             # calm again: one call per micro-batch
     stock.close(); fast.close()
+
+
+RCC_SHAPES = ["honest", "duplicate_rc_sender", "rc_of_another_round", "rc_of_another_height", "rc_forged_envelope", "prepare_in_the_rcc",
+              "too_few_rcs", "no_rcc", "one_invalid_pc_is_ignored", "two_prepared_rounds", "highest_round_prepared_another_block",
+              "nobody_prepared_anything", "pc_round_at_the_limit"]
+
+
+@pytest.mark.parametrize("shape", RCC_SHAPES)
+def test_every_proposal_rule_from_rows(shape):
+    """validateProposal (core/ibft.go:683-788) rule by rule: a PREPREPARE of round 2 whose RoundChangeCertificate has ONE
+    property — decided from the backend's rows on arrival (the certificate never decoded), by the walk over decoded objects
+    with arrival-time verdicts, and by the reference's per-message walk: the same answer."""
+    from test_host_roundchange import PR
+    n = 10
+    w = World(n=n, seed=300 + RCC_SHAPES.index(shape))
+    height, rnd, raw = 3, 2, b"the block"
+    q = 2 * n // 3 + 1
+    rcs = []
+    for k, a in enumerate(w.addrs[:q]):
+        cert_round = 0
+        craw = raw
+        if shape == "two_prepared_rounds":
+            cert_round = k % 2                              # rounds 0 and 1: the proposal must carry the hash prepared in round 1
+        if shape == "highest_round_prepared_another_block" and k == 3:
+            cert_round, craw = 1, b"another block"         # the highest prepared round is about another block: the proposal's hash fails
+        if shape == "pc_round_at_the_limit" and k == 3:
+            cert_round, craw = 2, b"another block"         # round ≥ the proposal's round: not a valid PC, so it is ignored
+        if shape == "nobody_prepared_anything":
+            rcs.append(rc_message(w, height, rnd, a))
+            continue
+        kind = "bad_prepare_signature" if (shape == "one_invalid_pc_is_ignored" and k == 2) else None
+        r2 = craw if kind is None else b"9-block|own"
+        rcs.append(rc_message(w, height, rnd, a, raw=r2, cert=w.certificate(height, cert_round, r2, kind), cert_round=cert_round))
+    if shape == "duplicate_rc_sender":
+        rcs.append(rcs[0])
+    elif shape == "rc_of_another_round":
+        rcs[1] = rc_message(w, height, rnd + 1, rcs[1].sender, raw=raw, cert=w.certificate(height, 0, raw), cert_round=0)
+    elif shape == "rc_of_another_height":
+        rcs[1] = rc_message(w, height + 1, rnd, rcs[1].sender, raw=raw, cert=w.certificate(height, 0, raw), cert_round=0)
+    elif shape == "rc_forged_envelope":
+        w.bad_wires.add(rcs[1].encode())
+    elif shape == "prepare_in_the_rcc":
+        rcs[1] = W.IbftMessage(view=W.View(height, rnd), sender=rcs[1].sender, type=PR, signature=b"sig", payload=W.prepare_body(b"h" * 32))
+    elif shape == "too_few_rcs":
+        rcs = rcs[: q - 1]
+    prop = w.proposer(height, rnd)
+    # the block is re-proposed; its hash is that of (block, new round) — the certificate's hashes are those of the prepared rounds
+    pp = W.IbftMessage(view=W.View(height, rnd), sender=prop, type=PP, signature=b"sig-pp-" + prop,
+                       payload=W.preprepare_body(W.Proposal(raw, rnd), fake_hash(raw, rnd),
+                                                 None if shape == "no_rcc" else W.round_change_certificate(rcs)))
+    hosts = {"stock": w.host(), "rows": w.host(), "objects": w.host()}
+    for name, h in hosts.items():
+        h.set_id(b"someone else")
+        h.set_state(height, rnd, None)
+        if name != "stock":
+            h.use_loop_batch(0)
+            h.use_batch(True)
+            h.use_rc_rows(name == "rows")
+    res = {name: h.ingest_wire([pp.encode()])[0] for name, h in hosts.items()}
+    assert res["stock"] == res["rows"] == res["objects"] == [2]
+    out = {name: h.handle_preprepare(height, rnd) for name, h in hosts.items()}
+    assert out["stock"] == out["rows"] == out["objects"]
+    accepted = shape in ("honest", "one_invalid_pc_is_ignored", "two_prepared_rounds", "nobody_prepared_anything", "pc_round_at_the_limit")
+    assert (out["stock"] is not None) == accepted and (out["stock"] in (None, pp.encode()))
+    assert hosts["rows"].pp_from_rows == 1 and hosts["objects"].pp_from_rows == 0
+    for h in hosts.values():
+        h.close()
