@@ -408,5 +408,6 @@ def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle,
         pa, pb = ref.handle_preprepare(1, 1), ing.handle_preprepare(1, 1)
         assert pa == pb and (pb is not None) == ok
         assert ing.last_cert_batch()[0] == 0
+    assert ing.pp_from_rows == (2 if rc_rows else 0)       # validateProposal's certificate rules: from the rows, or by the object walk
     assert ing.fallbacks() == 0
     ref.close(); ing.close()
