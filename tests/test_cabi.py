@@ -117,3 +117,20 @@ def test_wire_row_struct_matches_the_header():
     names = re.findall(r"\b(height|round|status|type|payload_kind|has_view|hash_len|seal_len|from_len|sig_len|from|proposal_hash|pad)\b(?=[,;\[])", body)
     assert names == list(V.WIRE_ROW.names)
     assert V.WIRE_ROW.itemsize == 80 and V.WIRE_ROW.fields["from"][1] == 24 and V.WIRE_ROW.fields["proposal_hash"][1] == 44
+
+
+def test_host_keccak_entry_needs_no_device(lib):
+    """ibft_keccak256(a ‖ b) — the library's HOST Keccak (what hashes proposals and messages too long for one wavefront's sponge;
+    compiled for BMI1/2 where the core has them, plain otherwise): block boundaries, two-part inputs, against the oracle."""
+    import ctypes as C
+    import numpy as np
+    from oracle import binding as B
+    f = lib.ibft_keccak256
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 280)) + [407, 408, 409, 1000, 4096, 100_000]:
+        a = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        b = rng.integers(0, 256, n % 11, dtype=np.uint8).tobytes()
+        out = (C.c_uint8 * 32)()
+        assert f(a, len(a), b, len(b), out) == 0
+        assert bytes(out) == B.keccak256(a + b), n
