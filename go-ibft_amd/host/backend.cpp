@@ -597,6 +597,7 @@ void HotPath::EnableQuorumIndex() { index_enabled_ = true; }
 
 void HotPath::PruneVerdictCache(uint64_t below_height) {
   for (auto it = seen_.begin(); it != seen_.end();) it = it->second.height < below_height ? seen_.erase(it) : std::next(it);
+  if (seen_.empty()) seen_has_votes_ = false;
 }
 
 // The verdicts of one root row of a certificate call and of everything below it are noted IN the decoded objects, matched
@@ -979,26 +980,59 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     stored_rows[PREPARE] = messages.LeanFor(cur, PREPARE, closure_epoch_, valset_epoch_);
     stored_rows[COMMIT] = messages.LeanFor(cur, COMMIT, closure_epoch_, valset_epoch_);
   }
+  // A row candidate needs its fingerprint only for the two tables it could be in: the rejected ones, and seen_ when that holds
+  // PREPARE / COMMIT objects at all (its own re-deliveries are found in the store, its repeats inside the batch by sender)
+  const bool cand_fp = !seen_rejected_.empty() || seen_has_votes_;
+  std::vector<uint8_t> have_fp(n, 0);
+  auto ensure_fp = [&](size_t i) {
+    if (!have_fp[i]) {
+      fingerprint(wire + off[i], off[i + 1] - off[i], fp_seed_, fp1[i], fp2[i]);
+      have_fp[i] = 1;
+    }
+  };
+  std::vector<uint32_t> cand_tab;  // repeats of row candidates inside the batch: by sender, then byte for byte
+  size_t cand_mask = 0;
+  auto first_cand_in_batch = [&](size_t i, const uint8_t *row, size_t len, uint64_t from_hash) -> int32_t {
+    if (cand_tab.empty()) {
+      cand_mask = fib_mask;
+      cand_tab.assign(cand_mask + 1, 0);
+    }
+    for (size_t sl = from_hash & cand_mask;; sl = (sl + 1) & cand_mask) {
+      const uint32_t e = cand_tab[sl];
+      if (e == 0) {
+        cand_tab[sl] = (uint32_t)i + 1;
+        return -1;
+      }
+      const size_t f = e - 1;
+      if (off[f + 1] - off[f] == len && memcmp(wire + off[f], row, len) == 0) return (int32_t)f;
+    }
+  };
   for (size_t i = 0; i < n; i++) {
     const uint8_t *row = wire + off[i];
     const size_t len = off[i + 1] - off[i];
-    fingerprint(row, len, fp_seed_, fp1[i], fp2[i]);
-    if (!seen_.empty()) {
-      auto hit = seen_.find(fp1[i]);
-      if (hit != seen_.end() && hit->second.fp2 == fp2[i] && hit->second.len == len && memcmp(hit->second.wire, row, len) == 0) {
-        msgs[i] = hit->second.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
-        verdict[i] = 1;
-        st.cache_hits++;
-        continue;
+    // A look at the message without decoding it (see below)
+    const Peek pk = peek(row, len);
+    const bool is_cand = pk.ok && lean_mode && pk.simple && pk.from_len && pk.has_view && pk.height == height && pk.round == round &&
+                         ((pk.type == PREPARE && pk.kind == PayloadKind::PREPARE) || (pk.type == COMMIT && pk.kind == PayloadKind::COMMIT));
+    if (!is_cand || cand_fp) {
+      ensure_fp(i);
+      if (!seen_.empty()) {
+        auto hit = seen_.find(fp1[i]);
+        if (hit != seen_.end() && hit->second.fp2 == fp2[i] && hit->second.len == len && memcmp(hit->second.wire, row, len) == 0) {
+          msgs[i] = hit->second.msg;  // the stored object, with everything noted in it: no decode, nothing to ask
+          verdict[i] = 1;
+          st.cache_hits++;
+          continue;
+        }
       }
-    }
-    if (!seen_rejected_.empty()) {
-      auto rej = seen_rejected_.find(fp1[i]);
-      if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
-        verdict[i] = 0;  // rejected before (the reference would judge it again — and reject it again)
-        st.cache_hits++;
-        results[i] = 0;
-        continue;
+      if (!seen_rejected_.empty()) {
+        auto rej = seen_rejected_.find(fp1[i]);
+        if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
+          verdict[i] = 0;  // rejected before (the reference would judge it again — and reject it again)
+          st.cache_hits++;
+          results[i] = 0;
+          continue;
+        }
       }
     }
     // A look at the message without decoding it: rows whose top-level walk fails are dropped (proto.Unmarshal error:
@@ -1006,13 +1040,13 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     // ROUND_CHANGE, no expansion of its certificates): a nil view or a view below the state's cannot pass
     // isAcceptableMessage (core/ibft.go:1133-1148).  (Membership of From is the Backend's business — a mock accepts anybody
     // — so it is NOT pre-judged here; the device rejects a non-member like any other bad signature.)
-    const Peek pk = peek(row, len);
-    if (pk.ok && lean_mode && pk.simple && pk.from_len && pk.has_view && pk.height == height && pk.round == round &&
-        ((pk.type == PREPARE && pk.kind == PayloadKind::PREPARE) || (pk.type == COMMIT && pk.kind == PayloadKind::COMMIT))) {
+    if (is_cand) {
       kinds[i] = (uint8_t)pk.kind;
       ptype[i] = (uint8_t)pk.type;
+      const std::string_view from((const char *)row + pk.from_off, pk.from_len);
+      const uint64_t from_hash = hash_key(from.data(), from.size());
       if (const LeanView *lv = stored_rows[pk.type]) {
-        const LeanRow *was = lv->find(std::string_view((const char *)row + pk.from_off, pk.from_len));
+        const LeanRow *was = lv->find(from, from_hash);
         if (was && was->len == len && memcmp(was->wire, row, len) == 0) {
           // a stored row delivered again: stored again below, in arrival order (its sender's row is overwritten by itself)
           st.cache_hits++;
@@ -1022,7 +1056,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
           continue;
         }
       }
-      if ((dup_of[i] = first_in_batch(i, row, len)) >= 0) continue;
+      if ((dup_of[i] = have_fp[i] ? first_in_batch(i, row, len) : first_cand_in_batch(i, row, len, from_hash)) >= 0) continue;
       cand[i] = 1;
       LeanRow &lr = lrow[i];
       lr.wire = row;
@@ -1030,6 +1064,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       lr.from_off = pk.from_off; lr.from_len = pk.from_len;
       lr.hash_off = pk.hash_off; lr.hash_len = pk.hash_len;
       lr.seal_off = pk.seal_off; lr.seal_len = pk.seal_len;
+      lr.sender_hash = from_hash;
       ask.push_back(i);
       continue;
     }
@@ -1365,6 +1400,7 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
   }
   st.device_rows = asked.size();
   auto remember_rejected = [&](size_t i) {
+    ensure_fp(i);
     if (rejected_fifo_.size() < rejected_cap) {
       rejected_fifo_.push_back(fp1[i]);
     } else if (rejected_cap) {
@@ -1421,8 +1457,13 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     results[i] = (int8_t)addWithVerdict(msgs[i], verdict[i] == 1);
     if (!fresh) continue;
     if (results[i] > 0) {
-      if (seen_.size() >= seen_cap) seen_.clear();
+      if (seen_.size() >= seen_cap) {
+        seen_.clear();
+        seen_has_votes_ = false;
+      }
       const IbftMessage &m = *msgs[i];
+      ensure_fp(i);
+      if (m.type == PREPARE || m.type == COMMIT) seen_has_votes_ = true;
       seen_[fp1[i]] = Seen{fp2[i], msgs[i], wire + off[i], off[i + 1] - off[i], m.view ? m.view->height : 0};
     } else if (verdict[i] == 0) {
       remember_rejected(i);
@@ -1511,7 +1552,7 @@ void HotPath::addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows
       [&](size_t k, bool fresh, const LeanView &lv) {
         if (fresh) {
           const std::string_view from = rows[k]->from();
-          const uint64_t w = validatorManager.powerOf(from);
+          const uint64_t w = rows[k]->sender_hash ? validatorManager.powerOf(from, rows[k]->sender_hash) : validatorManager.powerOf(from);
           power += w;
           dpower += w;
           dcount++;

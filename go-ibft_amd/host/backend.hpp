@@ -182,6 +182,7 @@ class HotPath {
     quorumIndex.Invalidate();
     valset_epoch_++;   // every sender verdict noted in a message object was computed against the old set: ignored from now on
     seen_.clear();
+    seen_has_votes_ = false;
     seen_rejected_.clear();
   }
   QuorumIndex quorumIndex;
@@ -335,6 +336,7 @@ class HotPath {
   int quorumProbe(uint32_t type, const View &view);  // the 1 / 2 of AddMessageFast, from the quorum index
   bool handleLean(const View &view, MessageType type, bool &quorum);  // true = the view was held as rows and is handled
   std::unordered_map<uint64_t, Seen> seen_;
+  bool seen_has_votes_ = false;  // seen_ holds (or held, since it was last empty) PREPARE / COMMIT objects
   std::unordered_map<uint64_t, uint64_t> seen_rejected_;  // fp1 → fp2
   std::vector<uint64_t> rejected_fifo_;
   size_t rejected_head_ = 0;

@@ -683,6 +683,15 @@ int ibft_host_peek_vs_decode(const uint8_t *wire, size_t len, uint64_t out[12]) 
   out[9] = (ok && m.view) ? m.view->round : 0; out[10] = ok ? m.type : 0; out[11] = ok ? (uint64_t)m.kind : 0;
   return 0;
 }
+int ibft_host_peek_shortcut_agrees(const uint8_t *wire, size_t len) {
+  const Peek a = peek(wire, len), b = peek_general(wire, len);
+  const bool same = a.ok == b.ok && (!a.ok || (a.has_view == b.has_view && a.height == b.height && a.round == b.round && a.type == b.type &&
+                                               a.kind == b.kind && a.simple == b.simple &&
+                                               (!a.simple || (a.from_off == b.from_off && a.from_len == b.from_len && a.sig_off == b.sig_off &&
+                                                              a.sig_len == b.sig_len && a.hash_off == b.hash_off && a.hash_len == b.hash_len &&
+                                                              a.seal_off == b.seal_off && a.seal_len == b.seal_len))));
+  return same ? (a.ok && a.simple ? 2 : 1) : 0;
+}
 int ibft_host_set_round_robin_proposer(ibft_host *h, const uint8_t *packed_addrs, size_t len, int use_height) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   std::vector<bytes> a;

@@ -121,6 +121,8 @@ struct LeanRow {
   uint32_t len = 0, buf = 0;
   uint32_t from_off = 0, from_len = 0, hash_off = 0, hash_len = 0, seal_off = 0, seal_len = 0;
   uint8_t closure = 0;            // handlePrepare's / handleCommit's closure verdict (against the view's closure epoch)
+  uint8_t dead = 0;               // (the store's: pruned)
+  uint64_t sender_hash = 0;       // hash_key(from()); 0 = not computed yet
   std::string_view from() const { return std::string_view((const char *)wire + from_off, from_len); }
 };
 class LeanView {
@@ -132,12 +134,13 @@ class LeanView {
   bool erase(std::string_view from) {
     const size_t at = locate(from);
     if (at == npos) return false;
-    dead_[at] = 1;
+    rows_[at].dead = 1;
     live_--;
     return true;
   }
-  const LeanRow *find(std::string_view from) const {
-    const size_t at = locate(from);
+  const LeanRow *find(std::string_view from) const { return find(from, hash_key(from.data(), from.size())); }
+  const LeanRow *find(std::string_view from, uint64_t hash) const {
+    const size_t at = locate(from, hash);
     return at == npos ? nullptr : &rows_[at];
   }
   // insert, or replace the row of the same sender; true = a new sender
@@ -145,7 +148,9 @@ class LeanView {
     if (buffers.empty() || buffers.back() != backing) buffers.push_back(backing);
     row.buf = (uint32_t)buffers.size() - 1;
     const std::string_view from = row.from();
-    const uint64_t h = hash_key(from.data(), from.size());
+    if (row.sender_hash == 0) row.sender_hash = hash_key(from.data(), from.size());
+    const uint64_t h = row.sender_hash;
+    row.dead = 0;
     const size_t at = locate(from, h);
     if (at != npos) {
       rows_[at] = row;
@@ -153,8 +158,6 @@ class LeanView {
     }
     if ((rows_.size() + 1) * 2 > index_.size()) rebuild(std::max<size_t>(64, (rows_.size() + 1) * 4));
     rows_.push_back(row);
-    hash_.push_back(h);
-    dead_.push_back(0);
     link(rows_.size() - 1, h);
     live_++;
     return true;
@@ -162,15 +165,15 @@ class LeanView {
   template <class F>
   void filter(F &&f) {  // f(const LeanRow &) → false erases the row
     for (size_t i = 0; i < rows_.size(); i++)
-      if (!dead_[i] && !f(rows_[i])) {
-        dead_[i] = 1;
+      if (!rows_[i].dead && !f(rows_[i])) {
+        rows_[i].dead = 1;
         live_--;
       }
   }
   template <class F>
   void for_each(F &&f) const {
     for (size_t i = 0; i < rows_.size(); i++)
-      if (!dead_[i]) f(rows_[i]);
+      if (!rows_[i].dead) f(rows_[i]);
   }
 
  private:
@@ -187,7 +190,7 @@ class LeanView {
       if (e == 0) return npos;
       if ((e & 0xFFFFFFFF00000000ull) != tag) continue;
       const size_t at = (size_t)(e & 0xFFFFFFFFull) - 1;
-      if (!dead_[at] && rows_[at].from() == from) return at;
+      if (!rows_[at].dead && rows_[at].from() == from) return at;
     }
   }
   void link(size_t i, uint64_t h) {
@@ -201,11 +204,9 @@ class LeanView {
     while (n < slots) n <<= 1;
     index_.assign(n, 0);
     for (size_t i = 0; i < rows_.size(); i++)
-      if (!dead_[i]) link(i, hash_[i]);
+      if (!rows_[i].dead) link(i, rows_[i].sender_hash);
   }
   std::vector<LeanRow> rows_;
-  std::vector<uint64_t> hash_;  // hash_key of each row's sender
-  std::vector<uint8_t> dead_;
   std::vector<uint64_t> index_;
   size_t live_ = 0;
 };
@@ -299,8 +300,9 @@ class ValidatorManager {
   const std::map<bytes, uint64_t> &powers() const { return power_; }
   // O(1): voting power of `from` (0 for a non-member) and membership
   uint64_t powerOf(const bytes &from) const { return powerOf(std::string_view(from.data(), from.size())); }
-  uint64_t powerOf(std::string_view from) const {
-    const int64_t at = seat(from);
+  uint64_t powerOf(std::string_view from) const { return powerOf(from, hash_key(from.data(), from.size())); }
+  uint64_t powerOf(std::string_view from, uint64_t hash) const {  // hash = hash_key(from)
+    const int64_t at = seat(from, hash);
     return at < 0 ? 0 : seat_power_[(size_t)at];
   }
   bool isValidator(const bytes &from) const { return seat(std::string_view(from.data(), from.size())) >= 0; }
@@ -312,10 +314,11 @@ class ValidatorManager {
   std::vector<uint64_t> seat_slot_;
   std::vector<bytes> seat_addr_;
   std::vector<uint64_t> seat_power_;
-  int64_t seat(std::string_view from) const {
+  int64_t seat(std::string_view from) const { return seat(from, hash_key(from.data(), from.size())); }
+  int64_t seat(std::string_view from, uint64_t h) const {
     if (seat_slot_.empty()) return -1;
     const size_t mask = seat_slot_.size() - 1;
-    const uint64_t h = hash_key(from.data(), from.size()), tag = h & 0xFFFFFFFF00000000ull;
+    const uint64_t tag = h & 0xFFFFFFFF00000000ull;
     for (size_t s = h & mask;; s = (s + 1) & mask) {
       const uint64_t e = seat_slot_[s];
       if (e == 0) return -1;

@@ -428,7 +428,86 @@ bytes encode(const IbftMessage &m, bool with_signature) {
   return o;
 }
 
+// The shape every honest PREPARE / COMMIT has — View{height, round}, From, Signature, type, PrepareMessage{hash} or
+// CommitMessage{hash, seal}, each once, in field order, one-byte lengths except the payload's — recognised without the
+// general walk; anything else (false) goes to it.  Same Peek as peek_general() on what it accepts
+// (tests/test_host_semantics.py).
+static bool peek_regular(const uint8_t *p, size_t n, Peek &out) {
+  size_t i = 0;
+  auto varint = [&](uint64_t &v) {
+    v = 0;
+    for (int sh = 0; sh < 64 && i < n; sh += 7) {
+      const uint8_t b = p[i++];
+      v |= (uint64_t)(b & 0x7F) << sh;
+      if (!(b & 0x80)) return sh < 63 || b <= 1;
+    }
+    return false;
+  };
+  if (n < 8 || p[0] != 0x0A || p[1] >= 0x80) return false;
+  const size_t view_end = 2 + p[1];
+  if (view_end > n) return false;
+  i = 2;
+  uint64_t height = 0, round = 0;
+  if (i < view_end && p[i] == 0x08) {
+    i++;
+    if (!varint(height) || i > view_end) return false;
+  }
+  if (i < view_end && p[i] == 0x10) {
+    i++;
+    if (!varint(round) || i > view_end) return false;
+  }
+  if (i != view_end) return false;
+  if (i + 2 > n || p[i] != 0x12 || p[i + 1] >= 0x80 || p[i + 1] == 0) return false;
+  const uint32_t from_off = (uint32_t)i + 2, from_len = p[i + 1];
+  i += 2 + from_len;
+  if (i + 2 > n || p[i] != 0x1A || p[i + 1] >= 0x80 || p[i + 1] == 0) return false;
+  const uint32_t sig_off = (uint32_t)i + 2, sig_len = p[i + 1];
+  i += 2 + sig_len;
+  if (i + 2 > n || p[i] != 0x20 || (p[i + 1] != PREPARE && p[i + 1] != COMMIT)) return false;
+  const uint32_t type = p[i + 1];
+  i += 2;
+  if (i + 2 > n || p[i] != (type == PREPARE ? 0x32 : 0x3A)) return false;
+  i++;
+  uint64_t plen;
+  if (!varint(plen) || plen != n - i) return false;
+  // PrepareMessage {1: proposalHash} / CommitMessage {1: proposalHash, 2: committedSeal}
+  uint32_t hash_off = 0, hash_len = 0, seal_off = 0, seal_len = 0;
+  if (i < n && p[i] == 0x0A) {
+    if (i + 2 > n || p[i + 1] >= 0x80 || p[i + 1] == 0) return false;
+    hash_off = (uint32_t)i + 2;
+    hash_len = p[i + 1];
+    i += 2 + hash_len;
+  }
+  if (type == COMMIT && i < n && p[i] == 0x12) {
+    if (i + 2 > n || p[i + 1] >= 0x80 || p[i + 1] == 0) return false;
+    seal_off = (uint32_t)i + 2;
+    seal_len = p[i + 1];
+    i += 2 + seal_len;
+  }
+  if (i != n) return false;
+  out.ok = true;
+  out.has_view = true;
+  out.height = height;
+  out.round = round;
+  out.type = type;
+  out.kind = type == PREPARE ? PayloadKind::PREPARE : PayloadKind::COMMIT;
+  out.from_off = from_off; out.from_len = from_len;
+  out.sig_off = sig_off; out.sig_len = sig_len;
+  out.hash_off = hash_off; out.hash_len = hash_len;
+  out.seal_off = seal_off; out.seal_len = seal_len;
+  out.simple = true;
+  return true;
+}
+
 Peek peek(const uint8_t *p, size_t n) {
+  {
+    Peek fast;
+    if (peek_regular(p, n, fast)) return fast;
+  }
+  return peek_general(p, n);
+}
+
+Peek peek_general(const uint8_t *p, size_t n) {
   Peek out;
   bool repeated = false, payload_plain = true, seen_twice[9] = {false};
   int views = 0;

@@ -195,6 +195,7 @@ struct Peek {
   bool simple = false;
 };
 Peek peek(const uint8_t *p, size_t n);
+Peek peek_general(const uint8_t *p, size_t n);  // the field walk without the shortcut for the regular PREPARE / COMMIT shape
 // a heap copy of [p, p + n) to decode into (one allocation)
 std::shared_ptr<const void> make_backing(const uint8_t *p, size_t n, const uint8_t **copy);
 bool decode(const uint8_t *p, size_t n, PreparedCertificate &out);

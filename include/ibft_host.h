@@ -127,6 +127,9 @@ int ibft_host_ingest_flat(ibft_host *h, const uint8_t *wire, const uint32_t *off
  * payload kind}, out[6..11] = the same six from the full decoder; the look must succeed whenever the decoder does and agree
  * with it.                                                                                                            */
 int ibft_host_peek_vs_decode(const uint8_t *wire, size_t len, uint64_t out[12]);
+/* Test hook: the look has a shortcut for the shape every honest PREPARE / COMMIT has; 0 = shortcut and general walk
+ * disagree about this message (a bug), 1 = they agree, 2 = they agree and the message is a row candidate (`simple`).   */
+int ibft_host_peek_shortcut_agrees(const uint8_t *wire, size_t len);
 /* The receive-side queue: transport threads PUSH what arrives (rows back to back + offsets, copied,
  * never blocks on an ingest in progress); one worker per mirror takes everything pending and ingests it as ONE batch
  * (ibft_host_ingest_flat on at most max_rows rows at a time).  The batch size adapts to the load by itself: arrivals pile up
