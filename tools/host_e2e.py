@@ -279,6 +279,9 @@ if __name__ == "__main__":
            "config3_warm": host_mirror_from_wire(V, H, fx, V.FLAG_PUBKEY_CACHE, 30),
            "config3_queue_cold": host_mirror_queue(V, H, fx, 0, 30),
            "config3_queue_warm": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30),
+           # a 50 µs linger (ibft_host_queue_start): the worker waits until nothing has arrived for 50 µs, so a burst is ONE batch per phase
+           "config3_queue_cold_linger50": host_mirror_queue(V, H, fx, 0, 30, linger_us=50),
+           "config3_queue_warm_linger50": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30, linger_us=50),
            # the same with every message decoded into an object on arrival (ibft_host_use_rows(0)): what the rows save
            "config3_cold_objects": host_mirror_from_wire(V, H, fx, 0, 30, rows=False),
            "config3_queue_warm_objects": host_mirror_queue(V, H, fx, V.FLAG_PUBKEY_CACHE, 30, rows=False)}
