@@ -637,6 +637,8 @@ def main():
                   "micro_batches_warm": E.host_mirror_from_wire(V, HL, fx, V.FLAG_PUBKEY_CACHE, 20),
                   "queue_cold": E.host_mirror_queue(V, HL, fx, 0, 20),
                   "queue_warm": E.host_mirror_queue(V, HL, fx, V.FLAG_PUBKEY_CACHE, 20),
+                  "queue_cold_linger50us": E.host_mirror_queue(V, HL, fx, 0, 20, linger_us=50),
+                  "queue_warm_linger50us": E.host_mirror_queue(V, HL, fx, V.FLAG_PUBKEY_CACHE, 20, linger_us=50),
                   "round_change_n256": E.round_change_through_the_mirror(V, HL, 256, 6),
                   "reproposal_n256": E.reproposal_through_the_mirror(V, HL, 256, 4)}
             rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = hm
