@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libibftgpu.so")
-SOURCES = ["ibftgpu.hip", "host_keccak_x86.cpp", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "cert_wave_dev.h", "modinv_dev.h",
+SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "cert_wave_dev.h", "modinv_dev.h",
            "sign_dev.h", "secp256k1_dev.h", "keccak_dev.h", os.path.join("..", "..", "include", "ibftgpu.h")]
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
@@ -41,12 +41,12 @@ def _mark(target: str, deps: list[str], extra: str = "") -> None:
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", LIB, os.path.join(CSRC, "ibftgpu.hip"), os.path.join(CSRC, "host_keccak_x86.cpp"), "-ldl"]
-    if force or _stale(LIB, SOURCES, " ".join(cmd[:-4])):
+           "-o", LIB, os.path.join(CSRC, "ibftgpu.hip"), "-ldl"]
+    if force or _stale(LIB, SOURCES, " ".join(cmd[:-3])):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)
-        _mark(LIB, SOURCES, " ".join(cmd[:-4]))
+        _mark(LIB, SOURCES, " ".join(cmd[:-3]))
     return LIB
 
 

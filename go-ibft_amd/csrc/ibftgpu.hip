@@ -601,8 +601,6 @@ bool note_proposal(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t rou
 // Keccak-256 of a ‖ b on the HOST, with the device code's own permutation (keccak_dev.h compiles for both sides).
 // Keccak is a sequential sponge: one host core absorbs ≈340–360 MB/s here, ≈600 MB/s on the GPU box's cores (3.6 µs for 1 KiB, ≈3 ms for 1 MiB) where the one
 // wavefront that can work on a message absorbs 25 MB/s (profiles/r02_a1_sizes_v2.json: 41 ms for 1 MiB).
-// host_keccak_x86.cpp: whole 136-byte blocks absorbed with an AVX-512 permutation (1 = done, 0 = no such core)
-extern "C" int ibftk_host_keccak_absorb_x86(uint64_t s[25], const uint8_t *p, size_t blocks);
 // the permutation for a host that has BMI1/BMI2 (andn, rorx: every x86-64 core since 2013): the same code, compiled for them
 __attribute__((target("bmi,bmi2"), noinline)) static void f1600_bmi(uint64_t s[25]) { keccak::f1600(s); }
 static void f1600_plain(uint64_t s[25]) { keccak::f1600(s); }
@@ -614,14 +612,6 @@ void host_keccak256(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, ui
   size_t fill = 0;
   auto absorb = [&](const uint8_t *p, size_t n) {
     while (n) {
-      if (fill == 0 && n >= 4 * 136) {  // a long run of whole blocks: the vector permutation, where the core has one
-        const size_t blocks = n / 136;
-        if (ibftk_host_keccak_absorb_x86(s, p, blocks)) {
-          p += blocks * 136;
-          n -= blocks * 136;
-          continue;
-        }
-      }
       if (fill == 0 && n >= 136) {  // whole blocks straight from the source
         for (int i = 0; i < 17; i++) {
           uint64_t w;
