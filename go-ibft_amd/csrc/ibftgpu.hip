@@ -2661,4 +2661,100 @@ int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint
   return group_exchange(g, n, plan, out_sender_mask, out_valid_mask, tally);
 }
 
+// Certificates sharded by CARRIER: every device expands and judges the trees of its own contiguous range of the call's
+// messages (ibft_verify_certificates_wire on its context, all devices at once); nothing has to be exchanged — the verdicts
+// are per row and no tally is taken — so the only work here is the renumbering: the merged rows are in the breadth-first
+// order ONE call over all n messages would produce (level by level, within a level rank by rank, which is message order).
+int ibft_group_verify_certificates_wire(ibft_group *g, const uint8_t *wire_bytes, const uint32_t *off, size_t n, size_t rows_cap,
+                                        size_t *out_n_rows, ibft_cert_node_t *out_nodes, ibft_wire_row_t *out_rows,
+                                        uint8_t *out_class, uint64_t *out_sender_mask, uint64_t *out_hash_mask,
+                                        uint64_t *out_self_mask) {
+  if (!g || !out_n_rows || (n && (!off || !out_sender_mask))) return IBFT_E_INVAL;
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return IBFT_E_INVAL;
+  *out_n_rows = 0;
+  if (n == 0) return IBFT_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  const uint32_t world = (uint32_t)g->ctx.size();
+  const size_t per = (n + world - 1) / world;
+  struct Part {
+    size_t lo = 0, hi = 0, rows = 0;
+    std::vector<uint32_t> off;
+    std::vector<ibft_cert_node_t> nodes;
+    std::vector<ibft_wire_row_t> wrows;
+    std::vector<uint8_t> cls;
+    std::vector<uint64_t> ms, mh, mself;
+  };
+  std::vector<Part> part(world);
+  int rc = g->each([&](uint32_t i) {
+    Part &p = part[i];
+    p.lo = std::min(n, (size_t)i * per);
+    p.hi = std::min(n, p.lo + per);
+    if (p.hi == p.lo) return (int)IBFT_OK;
+    ibft_ctx *c = g->ctx[i];
+    const size_t cap = std::min<size_t>(rows_cap, c->max_rows), words = (cap + 63) / 64;
+    p.off.resize(p.hi - p.lo + 1);
+    for (size_t k = p.lo; k <= p.hi; k++) p.off[k - p.lo] = off[k] - off[p.lo];
+    p.nodes.resize(cap);
+    if (out_rows) p.wrows.resize(cap);
+    p.cls.assign(cap, 0);
+    p.ms.assign(words, 0);
+    p.mh.assign(words, 0);
+    p.mself.assign(words, 0);
+    return ibft_verify_certificates_wire(c, wire_bytes + off[p.lo], p.off.data(), p.hi - p.lo, cap, &p.rows, p.nodes.data(),
+                                         out_rows ? p.wrows.data() : nullptr, p.cls.data(), p.ms.data(), p.mh.data(), p.mself.data());
+  });
+  if (rc) return rc;
+  // rows per (rank, level); a rank's rows are breadth first, so its levels are contiguous blocks
+  size_t total = 0, levels = 1;
+  for (Part &p : part) {
+    total += p.rows;
+    for (size_t j = 0; j < p.rows; j++) levels = std::max<size_t>(levels, (size_t)p.nodes[j].level + 1);
+  }
+  if (total > rows_cap) return IBFT_E_TOOBIG;
+  std::vector<std::vector<size_t>> count(world, std::vector<size_t>(levels + 2, 0)), start(world, std::vector<size_t>(levels + 2, 0)),
+      dest(world, std::vector<size_t>(levels + 2, 0));
+  for (uint32_t r = 0; r < world; r++) {
+    for (size_t j = 0; j < part[r].rows; j++) count[r][part[r].nodes[j].level]++;
+    for (size_t l = 1; l < levels + 2; l++) start[r][l] = start[r][l - 1] + count[r][l - 1];
+  }
+  size_t base = 0;
+  for (size_t l = 0; l < levels + 2; l++)
+    for (uint32_t r = 0; r < world; r++) {
+      dest[r][l] = base;
+      base += count[r][l];
+    }
+  const size_t words = (total + 63) / 64;
+  memset(out_sender_mask, 0, words * 8);
+  if (out_hash_mask) memset(out_hash_mask, 0, words * 8);
+  if (out_self_mask) memset(out_self_mask, 0, words * 8);
+  for (uint32_t r = 0; r < world; r++) {
+    const Part &p = part[r];
+    const uint32_t byte_base = p.rows ? off[p.lo] : 0;
+    auto global = [&](size_t local, size_t level) { return dest[r][level] + (local - start[r][level]); };
+    for (size_t j = 0; j < p.rows; j++) {
+      const size_t level = p.nodes[j].level, at = global(j, level);
+      if (out_nodes) {
+        ibft_cert_node_t nd = p.nodes[j];
+        nd.off += byte_base;
+        if (nd.raw_len) nd.raw_off += byte_base;
+        if (nd.parent == IBFT_CERT_NO_PARENT)
+          nd.ordinal += (uint32_t)p.lo;  // its number among the call's messages
+        else
+          nd.parent = (uint32_t)global(nd.parent, level - 1);
+        nd.first_child = (uint32_t)global(nd.first_child, level + 1);
+        out_nodes[at] = nd;
+      }
+      if (out_rows) out_rows[at] = p.wrows[j];
+      if (out_class) out_class[at] = p.cls[j];
+      const uint64_t bit = 1ull << (at & 63);
+      if ((p.ms[j >> 6] >> (j & 63)) & 1) out_sender_mask[at >> 6] |= bit;
+      if (out_hash_mask && ((p.mh[j >> 6] >> (j & 63)) & 1)) out_hash_mask[at >> 6] |= bit;
+      if (out_self_mask && ((p.mself[j >> 6] >> (j & 63)) & 1)) out_self_mask[at >> 6] |= bit;
+    }
+  }
+  *out_n_rows = total;
+  return IBFT_OK;
+}
+
 }  // extern "C"

@@ -36,7 +36,7 @@ EXPORTS = [
     "ibft_shard_range", "ibft_exchange_layout", "ibft_comm_unique_id", "ibft_comm_init", "ibft_comm_destroy",
     "ibft_seals_exchange", "ibft_seals_fetch_merged", "ibft_seals_run", "ibft_verify_hashes_digest", "ibft_set_kernel_timing",
     "ibft_group_create", "ibft_group_destroy", "ibft_group_size", "ibft_group_ctx", "ibft_group_set_validators",
-    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages",
+    "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages", "ibft_group_verify_certificates_wire",
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
     "ibft_cache_memory",
@@ -172,6 +172,7 @@ def load_library() -> C.CDLL:
     L.ibft_group_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_group_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp,
                                              vp, vp, C.POINTER(Tally)]
+    L.ibft_group_verify_certificates_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.ibft_group_is_local.argtypes = [vp]
     L.ibft_keccak256.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
     L.ibft_cache_memory.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -670,6 +671,26 @@ class DeviceGroup:
         self._chk(self._L.ibft_group_verify_senders(self._g, _p(pl), _p(off), _p(s), _p(f), _p(pre), n, _p(mask), C.byref(t)),
                   "ibft_group_verify_senders")
         return mask_to_bool(mask, n), t
+
+    def verify_certificates_wire(self, wire, off, rows_cap: int = 65536, want_rows: bool = True):
+        """ibft_group_verify_certificates_wire: the trees sharded by carrier over the group's devices, rows numbered as ONE
+        call over all messages numbers them; same tuple as BatchVerifier.verify_certificates_wire"""
+        wb = _bytes_col(wire)
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        n = len(off) - 1
+        cap = int(rows_cap)
+        words = (cap + 63) // 64 or 1
+        nodes = np.zeros(max(cap, 1), dtype=CERT_NODE)
+        rows = np.zeros(max(cap, 1), dtype=WIRE_ROW) if want_rows else None
+        cls = np.zeros(max(cap, 1), dtype=np.uint8)
+        ms, mh, mself = (np.zeros(words, dtype=np.uint64) for _ in range(3))
+        n_rows = C.c_size_t(0)
+        self._chk(self._L.ibft_group_verify_certificates_wire(self._g, _p(wb), _p(off), n, cap, C.byref(n_rows), _p(nodes),
+                                                              _p(rows) if want_rows else None, _p(cls), _p(ms), _p(mh), _p(mself)),
+                  "ibft_group_verify_certificates_wire")
+        k = int(n_rows.value)
+        return (k, nodes[:k], rows[:k] if want_rows else None, cls[:k], mask_to_bool(ms, k), mask_to_bool(mh, k),
+                mask_to_bool(mself, k))
 
     def verify_messages(self, payload: bytes, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None,
                         valid_pre=None, raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):

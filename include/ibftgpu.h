@@ -523,6 +523,14 @@ int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint
                                const uint8_t *seal65, const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n,
                                const uint8_t *raw, size_t raw_len, uint64_t round, const uint8_t *digest32,
                                uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally);
+/* Certificate trees sharded by CARRIER: device k expands and judges the trees of its own contiguous range of the call's n
+ * messages, all devices at once; ibft_verify_certificates_wire's arguments and results, the rows numbered as ONE call over
+ * all n messages numbers them (breadth first).  Verdicts are per row and no tally is taken, so the devices exchange
+ * nothing.  rows_cap bounds the merged tree and each device's share of it.                                          */
+int ibft_group_verify_certificates_wire(ibft_group *g, const uint8_t *wire, const uint32_t *off, size_t n, size_t rows_cap,
+                                        size_t *out_n_rows, ibft_cert_node_t *out_nodes, ibft_wire_row_t *out_rows,
+                                        uint8_t *out_class, uint64_t *out_sender_mask, uint64_t *out_hash_mask,
+                                        uint64_t *out_self_mask);
 
 #ifdef __cplusplus
 }

@@ -139,3 +139,44 @@ def test_certificate_calls_feed_the_key_cache():
         assert tables >= q and warm >= 1, (tables, warm, cold)       # every signer of the tree has a table; a warm pass ran
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_certificates_sharded_by_carrier_equal_one_call(world):
+    """ibft_group_verify_certificates_wire: the trees of a batch split by carrier over `world` contexts (here all on device 0,
+    each with its own stream), judged at once, and renumbered — n_rows, every node field (offsets into the WHOLE wire, parents,
+    first children, ordinals), the parsed rows, classes and the three masks equal those of ONE call over the whole batch;
+    and the oracle's tree.  Batches with fewer carriers than contexts, deep trees (PREPREPARE → ROUND_CHANGE → PREPARE) and
+    non-canonical messages included."""
+    import go_ibft_amd.verifier as V
+    r = W.make_round(8, 811, height=5, round_=1)
+    bv = V.BatchVerifier(max_rows=4096)
+    g = V.DeviceGroup([0] * world, max_rows_total=4096 * world)
+    try:
+        bv.set_validators(5, r.addrs, r.power)
+        g.set_validators(5, r.addrs, r.power)
+        batches = [msgs for _, msgs in CC.handmade(r)] + list(CC.fuzz_batches(r, 60, 77))
+        honest = [m.encode() for m in CC.honest_round_change_set(r)]
+        batches += [honest, honest[:1], honest + [CC.preprepare_with_rcc(r).encode()] + honest[:3]]
+        checked = 0
+        for k, msgs in enumerate(batches):
+            buf, off = CC.pack(msgs)
+            if WC.expected_tree(msgs, r.addrs, rows_cap=4096) is None:
+                continue
+            one = bv.verify_certificates_wire(buf, off, rows_cap=4096)
+            many = g.verify_certificates_wire(buf, off, rows_cap=4096)
+            assert one[0] == many[0], k
+            for name in one[1].dtype.names:
+                if name != "pad":
+                    assert (one[1][name] == many[1][name]).all(), (k, name)
+            assert one[2].tobytes() == many[2].tobytes(), k
+            for a, b in zip(one[3:], many[3:]):
+                assert (a == b).all(), k
+            CC.compare(f"sharded {k}", WC.expected_tree(msgs, r.addrs, rows_cap=4096), *many)
+            checked += 1
+        assert checked > 40
+        with pytest.raises(RuntimeError, match="-7"):              # the merged tree must fit rows_cap
+            g.verify_certificates_wire(*CC.pack(honest), rows_cap=55)
+    finally:
+        g.close()
+        bv.close()
