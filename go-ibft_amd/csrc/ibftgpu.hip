@@ -2679,6 +2679,7 @@ int ibft_group_verify_certificates_wire(ibft_group *g, const uint8_t *wire_bytes
   const size_t per = (n + world - 1) / world;
   struct Part {
     size_t lo = 0, hi = 0, rows = 0;
+    uint32_t shift = 0;  // bytes in front of the shard's first message in the buffer its device sees
     std::vector<uint32_t> off;
     std::vector<ibft_cert_node_t> nodes;
     std::vector<ibft_wire_row_t> wrows;
@@ -2693,15 +2694,18 @@ int ibft_group_verify_certificates_wire(ibft_group *g, const uint8_t *wire_bytes
     if (p.hi == p.lo) return (int)IBFT_OK;
     ibft_ctx *c = g->ctx[i];
     const size_t cap = std::min<size_t>(rows_cap, c->max_rows), words = (cap + 63) / 64;
+    // (a shard that does not start the buffer keeps a few bytes in front of it: no message of it lies at offset 0, so a
+    // node's raw_off of 0 can only mean "not parsed" and the offsets can be moved back into the whole buffer below)
+    p.shift = std::min<uint32_t>(off[p.lo], 64u);
     p.off.resize(p.hi - p.lo + 1);
-    for (size_t k = p.lo; k <= p.hi; k++) p.off[k - p.lo] = off[k] - off[p.lo];
+    for (size_t k = p.lo; k <= p.hi; k++) p.off[k - p.lo] = off[k] - off[p.lo] + p.shift;
     p.nodes.resize(cap);
     if (out_rows) p.wrows.resize(cap);
     p.cls.assign(cap, 0);
     p.ms.assign(words, 0);
     p.mh.assign(words, 0);
     p.mself.assign(words, 0);
-    return ibft_verify_certificates_wire(c, wire_bytes + off[p.lo], p.off.data(), p.hi - p.lo, cap, &p.rows, p.nodes.data(),
+    return ibft_verify_certificates_wire(c, wire_bytes + off[p.lo] - p.shift, p.off.data(), p.hi - p.lo, cap, &p.rows, p.nodes.data(),
                                          out_rows ? p.wrows.data() : nullptr, p.cls.data(), p.ms.data(), p.mh.data(), p.mself.data());
   });
   if (rc) return rc;
@@ -2730,14 +2734,14 @@ int ibft_group_verify_certificates_wire(ibft_group *g, const uint8_t *wire_bytes
   if (out_self_mask) memset(out_self_mask, 0, words * 8);
   for (uint32_t r = 0; r < world; r++) {
     const Part &p = part[r];
-    const uint32_t byte_base = p.rows ? off[p.lo] : 0;
+    const uint32_t byte_base = p.rows ? off[p.lo] - p.shift : 0;
     auto global = [&](size_t local, size_t level) { return dest[r][level] + (local - start[r][level]); };
     for (size_t j = 0; j < p.rows; j++) {
       const size_t level = p.nodes[j].level, at = global(j, level);
       if (out_nodes) {
         ibft_cert_node_t nd = p.nodes[j];
         nd.off += byte_base;
-        if (nd.raw_len) nd.raw_off += byte_base;
+        if (nd.raw_off) nd.raw_off += byte_base;
         if (nd.parent == IBFT_CERT_NO_PARENT)
           nd.ordinal += (uint32_t)p.lo;  // its number among the call's messages
         else
