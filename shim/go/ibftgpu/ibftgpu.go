@@ -419,6 +419,24 @@ func (g *Group) VerifyMessages(payload []byte, off []uint32, msgSig65, from20, h
 	return senders, valid, tally(ct), nil
 }
 
+// VerifyCertificatesWire judges the certificate trees of raw PREPREPARE / ROUND_CHANGE messages sharded by carrier over the
+// group's devices (Ctx.VerifyCertificatesWire's arguments and results; the rows are numbered as one call over all messages
+// numbers them).  No tally is taken and the devices exchange nothing.
+func (g *Group) VerifyCertificatesWire(wire []byte, off []uint32, rowsCap int) (nodes []CertNode, class []byte, sender, hash, self []uint64, err error) {
+	n := len(off) - 1
+	nodes = make([]CertNode, rowsCap+1)
+	class = make([]byte, rowsCap+1)
+	sender, hash, self = make([]uint64, (rowsCap+63)/64+1), make([]uint64, (rowsCap+63)/64+1), make([]uint64, (rowsCap+63)/64+1)
+	var rows C.size_t
+	rc := C.ibft_group_verify_certificates_wire(g.g, ptr8(wire), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(n), C.size_t(rowsCap), &rows,
+		(*C.ibft_cert_node_t)(unsafe.Pointer(&nodes[0])), nil, ptr8(class), (*C.uint64_t)(unsafe.Pointer(&sender[0])),
+		(*C.uint64_t)(unsafe.Pointer(&hash[0])), (*C.uint64_t)(unsafe.Pointer(&self[0])))
+	if rc != C.IBFT_OK {
+		return nil, nil, nil, nil, nil, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
+	}
+	return nodes[:int(rows)], class[:int(rows)], sender, hash, self, nil
+}
+
 func tally(t C.ibft_tally_t) Tally {
 	return Tally{uint64(t.quorum_lo), uint64(t.quorum_hi), uint64(t.power_lo), uint64(t.power_hi),
 		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0, uint32(t.shard_overlap)}
