@@ -9,6 +9,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libibftgpu.so")
 SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wave_fe_dev.h", "wire_dev.h", "cert_wave_dev.h", "modinv_dev.h",
            "sign_dev.h", "secp256k1_dev.h", "keccak_dev.h", os.path.join("..", "..", "include", "ibftgpu.h")]
+# Code-generation flags of the product library (part of its build stamp).  max-ilp: the verdict kernels run ONE wavefront per
+# SIMD at the sizes that matter (N ≤ 4 096), where every hazard s_nop is a lost issue slot — scheduling for instruction-level
+# parallelism instead of register pressure takes the s_nops of ecrecover_rows_kernel from 399 to 114 (133 → 174 VGPRs, still
+# two wavefronts per SIMD) and the kernels 3–4.6 % down at N = 64 … 4 096, nothing lost at 16 384 / 65 536
+# (profiles/r03r_*).  IBFT_HIPCC_FLAGS adds to them for experiments.
+CODEGEN_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+EXTRA_FLAGS = CODEGEN_FLAGS + os.environ.get("IBFT_HIPCC_FLAGS", "").split()
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
 CERT_WAVE_HARNESS = os.path.join(CSRC, "libdev_cert_wave_host.so")
@@ -40,7 +47,7 @@ def _mark(target: str, deps: list[str], extra: str = "") -> None:
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS, "-shared", "-fPIC",
            "-o", LIB, os.path.join(CSRC, "ibftgpu.hip"), "-ldl"]
     if force or _stale(LIB, SOURCES, " ".join(cmd[:-3])):
         if verbose:

@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 want = sys.argv[1] if len(sys.argv) > 1 else "ecrecover_rows_kernelILi0"
 with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "k.s")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w", "-o", out,
+    sys.path.insert(0, ROOT)
+    from go_ibft_amd.build import EXTRA_FLAGS      # the product's own code-generation flags
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS, "--cuda-device-only", "-S", "-w", "-o", out,
                            os.path.join(ROOT, "go-ibft_amd", "csrc", "ibftgpu.hip")], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^[^\s.;]\S*" + re.escape(want) + r"\S*:", l))
