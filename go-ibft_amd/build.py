@@ -13,9 +13,10 @@ SOURCES = ["ibftgpu.hip", "kernels.hip.h", "recover_dev.h", "verify_dev.h", "wav
 # SIMD at the sizes that matter (N ≤ 4 096), where every hazard s_nop is a lost issue slot — scheduling for instruction-level
 # parallelism instead of register pressure takes the s_nops of ecrecover_rows_kernel from 399 to 114 (133 → 174 VGPRs, still
 # two wavefronts per SIMD) and the kernels 3–4.6 % down at N = 64 … 4 096, nothing lost at 16 384 / 65 536
-# (profiles/r03r_*).  IBFT_HIPCC_FLAGS adds to them for experiments.
+# (profiles/r03r_*).  IBFT_HIPCC_FLAGS adds to them for experiments, IBFT_NO_CODEGEN_FLAGS=1 drops them (the A/B of
+# profiles/r03r_sched_ab.txt).
 CODEGEN_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-EXTRA_FLAGS = CODEGEN_FLAGS + os.environ.get("IBFT_HIPCC_FLAGS", "").split()
+EXTRA_FLAGS = ([] if os.environ.get("IBFT_NO_CODEGEN_FLAGS") == "1" else CODEGEN_FLAGS) + os.environ.get("IBFT_HIPCC_FLAGS", "").split()
 HOST_HARNESS = os.path.join(CSRC, "libdev_arith_host.so")
 WAVE_HARNESS = os.path.join(CSRC, "libdev_wave_host.so")
 CERT_WAVE_HARNESS = os.path.join(CSRC, "libdev_cert_wave_host.so")
