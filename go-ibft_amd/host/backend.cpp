@@ -912,6 +912,18 @@ bool HotPath::IngestWire(const std::vector<bytes> &raw, std::vector<int> &result
   return ok;
 }
 
+// IngestFlat, stage by stage (go-ibft_amd/host/DESIGN.md has the reasons):
+//   look     every row: field walk (peek), fingerprint where a table could hold it → re-deliveries of stored objects /
+//            stored rows / rejected messages answered at once, repeats inside the batch folded, stale views rejected,
+//            PREPARE / COMMIT of the current view marked as row candidates (not decoded), the rest queued for decoding
+//   decode   the non-candidates, top level only for certificate carriers — on a helper thread while the device works
+//   (0)      certificate carriers → ONE VerifyCertificatesWire (after a roots-first call while forged carriers keep arriving):
+//            envelope verdicts, ROUND_CHANGE / PREPREPARE certificate rules from the rows, certificates left undecoded
+//   (1)      everything else that is undecided → ONE VerifyMessagesWire: sender verdicts, closures of the current view's
+//            PREPARE / COMMIT; judged candidates become rows, the others are decoded after all
+//   (2)      what no byte-judging call covered → the sender batch / the per-message verifier
+//   store    IBFT.AddMessage per message in arrival order (rows in runs under one lock), results 0 / 1 / 2 / −1, memory of
+//            stored objects and of rejected fingerprints updated
 bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, int8_t *results, IngestStats *stats,
                          uint8_t *types, const std::shared_ptr<const void> &owned) {
   for (size_t i = 0; i < n; i++) results[i] = -1;
