@@ -1229,6 +1229,16 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
           if (!m) continue;
           const bool deferred = (m->kind == PayloadKind::ROUND_CHANGE && m->round_change().certificate_deferred) ||
                                 (m->kind == PayloadKind::PREPREPARE && m->preprepare().certificate_deferred);
+          if (defer_certificates && cv.cls[j] == 0 && verdict[carriers[j]] == 0 && deferred) {
+            // a forged carrier: rejected whatever its certificate says — nothing below it is looked at, nothing decoded
+            vouched[carriers[j]] = 1;
+            size_t below = cv.nodes[j].n_children;
+            if (m->kind == PayloadKind::PREPREPARE)
+              for (size_t c = cv.nodes[j].first_child, e = c + cv.nodes[j].n_children; c < e && c < cv.n_rows; c++)
+                below += cv.nodes[c].n_children;
+            cert_rows += below;  // rows the device judged (counted whether or not the carrier turns out to be storable)
+            continue;
+          }
           if (defer_certificates && cv.cls[j] == 0 && m->kind == PayloadKind::ROUND_CHANGE) {
             vouched[carriers[j]] = 1;  // well-formed and canonical down to the last nested message: may stay undecoded
             const int rc_ok = roundChangeVerdictFromRows(cv, j);

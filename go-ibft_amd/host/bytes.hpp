@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <functional>
 #include <string>
 #include <string_view>
@@ -190,9 +191,18 @@ class bytes {
   char inl_[kInline];
 };
 
-// hash of a short key (an address): 8 bytes at a time, multiply-fold
+// hash of a short key (an address): 8 bytes at a time, multiply-fold, keyed per process — the keys are attacker-chosen
+// bytes (the From of any message, of any message nested in a certificate), and an unkeyed hash would let colliding keys be
+// prepared offline to turn every open-addressing table here into a linear list
+inline uint64_t hash_seed() noexcept {
+  static const uint64_t seed = [] {
+    std::random_device rd;
+    return ((uint64_t)rd() << 32 | rd()) | 1;
+  }();
+  return seed;
+}
 inline uint64_t hash_key(const char *p, size_t n) noexcept {
-  uint64_t h = (uint64_t)n * 0x9E3779B97F4A7C15ull;
+  uint64_t h = ((uint64_t)n * 0x9E3779B97F4A7C15ull) ^ hash_seed();
   while (n >= 8) {
     uint64_t w;
     memcpy(&w, p, 8);
