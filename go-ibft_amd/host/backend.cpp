@@ -1492,6 +1492,23 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
     }
   }
   flush_run();
+  // A large batch of which little was stored (a flood of rejected messages around a few honest ones): the stored rows must
+  // not keep the whole buffer — everybody's rejected bytes — alive until the height is pruned.  They move into a buffer of
+  // their own; objects stored from such a batch (few: carriers, odd encodings) still hold it.
+  if (lean_mode && off[n] >= repack_min_bytes) {
+    size_t kept = 0, objects = 0;
+    for (size_t i = 0; i < n; i++) {
+      if (results[i] <= 0) continue;
+      kept += off[i + 1] - off[i];
+      if (msgs[i]) objects++;
+    }
+    if (objects == 0 && kept * 4 < off[n]) {
+      View cur;
+      cur.height = height;
+      cur.round = round;
+      repacked_bytes += messages.RepackLean(cur, PREPARE, backing) + messages.RepackLean(cur, COMMIT, backing);
+    }
+  }
   last_ingest_device_ms = st.device_ms;
   if (stats) *stats = st;
   return true;

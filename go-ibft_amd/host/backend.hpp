@@ -241,6 +241,8 @@ class HotPath {
   int cert_roots_first = 2;
   size_t roots_first_calls = 0;
   size_t rc_from_rows = 0;
+  size_t repack_min_bytes = 256 << 10;  // batches of at least this size are checked for a low stored share (< 1/4 of the bytes)
+  size_t repacked_bytes = 0;            // bytes of stored rows moved out of such batches' buffers
   size_t pp_from_rows = 0;  // PREPREPARE messages whose RoundChangeCertificate was judged from rows (and left undecoded)
   double last_ingest_device_ms = 0.0;  // wall time the last IngestFlat spent inside the batch backend's calls
   size_t lean_rows = 0;        // messages ingested as rows so far

@@ -618,6 +618,8 @@ void ibft_host_set_seen_caps(ibft_host *h, size_t stored_cap, size_t rejected_ca
 }
 void ibft_host_use_sets(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_sets = on != 0; }
 void ibft_host_use_rc_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_rc_rows = on != 0; }
+size_t ibft_host_repacked_bytes(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.repacked_bytes; }
+void ibft_host_set_repack_min_bytes(ibft_host *h, size_t bytes) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.repack_min_bytes = bytes; }
 size_t ibft_host_pp_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.pp_from_rows; }
 size_t ibft_host_rc_from_rows(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.rc_from_rows; }
 void ibft_host_cert_roots_first(ibft_host *h, int mode) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.cert_roots_first = mode; }

@@ -276,6 +276,14 @@ size_t Messages::FilterLean(const View &view, MessageType type, const std::funct
   return it->second.size();
 }
 
+size_t Messages::RepackLean(const View &view, MessageType type, const std::shared_ptr<const void> &backing) {
+  int s = slot(type);
+  if (s < 0) return 0;
+  std::unique_lock lk(mux_[s]);
+  auto it = lean_[s].find({view.height, view.round});
+  return it == lean_[s].end() ? 0 : it->second.repack(backing);
+}
+
 void Messages::MaterializeAll() {
   for (int s : {(int)PREPARE, (int)COMMIT}) {
     std::unique_lock lk(mux_[s]);

@@ -11,6 +11,7 @@
 // returned messages; this mirror iterates in the senders' arrival order (deterministic).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -162,6 +163,27 @@ class LeanView {
     live_++;
     return true;
   }
+  // The rows that point into `backing` get a buffer of their own (their bytes, back to back) and `backing` is let go: for a
+  // batch of which little was stored — the rest of its buffer is other people's rejected bytes.  Returns the bytes copied.
+  size_t repack(const std::shared_ptr<const void> &backing) {
+    size_t idx = buffers.size();
+    for (size_t b = 0; b < buffers.size(); b++)
+      if (buffers[b] == backing) idx = b;
+    if (idx == buffers.size()) return 0;
+    size_t total = 0;
+    for (const LeanRow &r : rows_)
+      if (r.buf == idx) total += r.len;  // (pruned rows too: their slots may still be compared against)
+    uint8_t *mem = static_cast<uint8_t *>(malloc(total ? total : 1));
+    size_t at = 0;
+    for (LeanRow &r : rows_)
+      if (r.buf == idx) {
+        memcpy(mem + at, r.wire, r.len);
+        r.wire = mem + at;
+        at += r.len;
+      }
+    buffers[idx] = std::shared_ptr<const void>(mem, free);
+    return total;
+  }
   template <class F>
   void filter(F &&f) {  // f(const LeanRow &) → false erases the row
     for (size_t i = 0; i < rows_.size(); i++)
@@ -262,6 +284,8 @@ class Messages {
   LeanView *LeanFor(const View &view, MessageType type, uint32_t closure_epoch, uint32_t valset_epoch);
   // prune the rows f rejects (hooks fire, as for GetValidMessages); returns the survivors' count
   size_t FilterLean(const View &view, MessageType type, const std::function<bool(const LeanRow &)> &f);
+  // a batch buffer of which little was stored: the view's rows that point into it move into a buffer of their own
+  size_t RepackLean(const View &view, MessageType type, const std::shared_ptr<const void> &backing);
   void MaterializeAll();  // every view held as rows becomes objects (validator set changed: the rows' verdicts are void)
   std::vector<bytes> SendersOf(const View &view, MessageType type);  // distinct senders of a view, rows or objects
 

@@ -141,6 +141,8 @@ def lib() -> C.CDLL:
         L.ibft_host_last_ingest_device_ms.argtypes = [vp]; L.ibft_host_last_ingest_device_ms.restype = C.c_double
         L.ibft_host_rc_from_rows.argtypes = [vp]; L.ibft_host_rc_from_rows.restype = C.c_size_t
         L.ibft_host_pp_from_rows.argtypes = [vp]; L.ibft_host_pp_from_rows.restype = C.c_size_t
+        L.ibft_host_repacked_bytes.argtypes = [vp]; L.ibft_host_repacked_bytes.restype = C.c_size_t
+        L.ibft_host_set_repack_min_bytes.argtypes = [vp, C.c_size_t]; L.ibft_host_set_repack_min_bytes.restype = None
         L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
         L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
         L.ibft_host_handle_preprepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
@@ -506,6 +508,13 @@ class Host:
     @property
     def pp_from_rows(self) -> int:
         return int(self.L.ibft_host_pp_from_rows(self.h))
+
+    def set_repack_min_bytes(self, nbytes: int):
+        self.L.ibft_host_set_repack_min_bytes(self.h, nbytes)
+
+    @property
+    def repacked_bytes(self) -> int:
+        return int(self.L.ibft_host_repacked_bytes(self.h))
 
     def use_rows(self, on: bool):
         """Keep the PREPARE / COMMIT messages a batch backend judged from their bytes as rows (default) or as objects."""

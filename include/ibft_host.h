@@ -224,6 +224,12 @@ size_t ibft_host_pp_from_rows(ibft_host *h);
  * once at start-up if the C heap of the process is yours to tune (in a Go node it is: the Go heap is not malloc's).
  * 0 = set, −1 = the C library refused a value.                                                                        */
 int ibft_host_retain_heap(size_t bytes);
+/* Rows point into the buffer of the batch they arrived in and keep it alive.  When less than a quarter of the bytes of a
+ * batch of at least repack_min_bytes (default 256 KiB) was stored — a flood of rejected messages around a few honest ones
+ * — the stored rows are moved into a buffer of their own and the batch's buffer is let go, so that rejected bytes are not
+ * held until the height is pruned.  repacked_bytes: bytes moved that way so far.                                      */
+void ibft_host_set_repack_min_bytes(ibft_host *h, size_t bytes);
+size_t ibft_host_repacked_bytes(ibft_host *h);
 void ibft_host_use_rows(ibft_host *h, int on);
 size_t ibft_host_rows_kept(ibft_host *h);
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits);

@@ -215,3 +215,29 @@ def test_a_view_may_hold_rows_and_objects(seed):
     _same_answers(rows, stock, fresh=False)
     for h in (rows, objs, stock):
         h.close()
+
+
+def test_rows_do_not_pin_a_flood():
+    """Rows point into the buffer of the batch they arrived in.  A large batch of which little is stored — rejected bulk around a
+    few honest messages — must not stay alive for them: the stored rows move into a buffer of their own."""
+    w, ver, proposal, prepares, commits = _world(13, 9, bad_hash=(), forged=(), bad_seal=())
+    rows, objs = _host(w, ver, proposal, True), _host(w, ver, proposal, False)
+    junk = []
+    for k in range(40):                                     # forged COMMITs with 10 KB seals: rejected, 400 KB of them
+        m = W.IbftMessage(view=W.View(1, 0), sender=w.addrs[k % 13], type=CM, signature=b"junk-%d" % k,
+                          payload=W.commit_body(b"j" * 32, bytes([k]) * 10_000))
+        w.bad_wires.add(m.encode())
+        junk.append(m.encode())
+    honest = [m.encode() for m in commits[:3]]
+    batch = junk[:20] + honest + junk[20:]
+    ra, rb = rows.ingest_wire(batch)[0], objs.ingest_wire(batch)[0]
+    assert ra == rb and ra.count(0) == 40 and rows.rows_kept == 3
+    assert rows.repacked_bytes == sum(len(x) for x in honest) and objs.repacked_bytes == 0
+    # the rows live on in their own buffer: re-delivery is still recognised, the walks answer as before
+    again = rows.ingest_wire(honest)
+    assert again[0] == [1, 1, 1] and again[2] == 3          # three hits, nothing asked
+    rest = [m.encode() for m in prepares + commits[3:]]
+    assert rows.ingest_wire(rest)[0] == objs.ingest_wire(rest)[0]
+    assert rows.repacked_bytes == sum(len(x) for x in honest)   # (an ordinary batch is left where it is)
+    _same_answers(rows, objs)
+    rows.close(); objs.close()
