@@ -416,12 +416,14 @@ def main():
             bv.seals_launch(1); bv.seals_fetch(); bv.seals_launch(1); bv.seals_fetch()
             assert bv.cache_stats()[0] == len(np.unique(rd["signer20"], axis=0)) or byzantine
         assert V.shard_range(n_total, rank, world) == (lo, hi) == S.shard_range(n_total, rank, world)
+        comm_info = None
         if dist:
             # the data-path collective lives in libibftgpu.so (RCCL all-reduce of verdict words + tally pieces);
             # torch.distributed only carries the 128-byte communicator id and the timing fences
             uid = [V.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0, device=dev)
             bv.comm_init(uid[0], rank, world)
+            comm_info = bv.comm_info()   # what the communicator itself reports: (ranks, this rank, device)
 
         def step():  # N = 1: one synchronous pass, results on the host when it returns
             return bv.seals_run()
@@ -520,6 +522,7 @@ def main():
             bv.cache_stats()
             warm_lanes = bv.lanes_per_signature
         res = {"n_total": n_total, "rows": rows, "elapsed": elapsed, "steps": steps, "lat": lat, "lat_h2d": lat_h2d,
+               "rccl": comm_info,
                "kernel_ms": kernel_ms, "kernel_launches": kernel_launches, "kname": kernel_name(path, cold_lanes, warm_lanes),
                "src": rd["src"], "rd": rd, "tables": bv.cache_stats()[0] if path == "warm" else 0, "input_generation_s": t_gen,
                "valid_fraction": float(verdict.mean())}
@@ -573,6 +576,8 @@ def main():
                                  "the bound that applies (DESIGN.md §5)"},
         }
         rec["quorum_latency_ms_p50"] = rec["step_latency_ms_p50"]   # replaced by the sequence below at N=1
+        if m["rccl"] is not None:   # N > 1 (or forced): the collective is the library's ncclAllReduce over this communicator
+            rec["rccl_nranks"], rec["rccl_rank0_device"] = m["rccl"][0], m["rccl"][2]
         if long_leg is not None:
             L = long_leg
             lk = (L["kernel_ms"] / 1e3) / max(L["kernel_launches"], 1)
@@ -644,12 +649,17 @@ def main():
             rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = hm
         except Exception as e:  # noqa: BLE001
             rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = {"error": repr(e)}
-    if world == 8 and os.environ.get("IBFT_BENCH_SKIP_CONFIG5") != "1":
-        # BASELINE config #5: 65 536 validators, 8 × 8192 rows, 20 % Byzantine seals, parity vs the CPU oracle
+    if (world == 8 or (dist is not None and os.environ.get("IBFT_BENCH_CONFIG5") == "1")) and \
+            os.environ.get("IBFT_BENCH_SKIP_CONFIG5") != "1":
+        # BASELINE config #5: 65 536 validators, 8 × 8192 rows, 20 % Byzantine seals, parity vs the CPU oracle.
+        # IBFT_BENCH_CONFIG5=1 runs the same leg at any world size that divides 65 536 (with IBFT_BENCH_FORCE_DIST=1 on one
+        # GPU: the whole set as ONE shard through the sharded code path and a real one-rank RCCL communicator — what
+        # profiles/r04_forcedist_config5.json holds)
         try:
-            c5 = run_config(8192, True, max(10, args.steps // 4), 3, "cold")
+            c5 = run_config(65536 // world, True, max(10, args.steps // 4), 3, "cold")
             if rank == 0:
-                rec["config5"] = {"validators": c5["n_total"], "rows_per_gpu": 8192, "byzantine_fraction": 0.2,
+                rec["config5"] = {"validators": c5["n_total"], "rows_per_gpu": 65536 // world, "byzantine_fraction": 0.2,
+                                  "rccl_nranks": c5["rccl"][0] if c5["rccl"] else None,
                                   "value": c5["n_total"] * c5["steps"] / c5["elapsed"], "unit": "verifies/s",
                                   "ms_per_step": c5["elapsed"] / c5["steps"] * 1e3, "kernel": c5["kname"],
                                   "valid_fraction": c5["valid_fraction"],

@@ -112,6 +112,13 @@ struct ibft_ctx {
   DevBuf d_seen, d_acc, d_quorum;                    // tally: distinct-sender bitmap, launch-wide sums + ticket, quorum words
   uint64_t last_wide[ibftk::TALLY_SUM_WORDS] = {0};  // full-width power of the last fetched tally
   uint64_t height = 0;
+  std::vector<uint32_t> h_vtab;  // host copy of the validator table (6 dwords per slot): the proposer's seat is looked up here
+  // HasPrepareQuorum: set by an entry point that was given a proposer, consumed by the next tally it enqueues
+  bool next_prop_on = false;
+  int32_t next_prop_vidx = -1;
+  bool last_prop_on = false;     // … of the last tally enqueued (what a sharded batch's unpack step applies)
+  int32_t last_prop_vidx = -1;
+  uint32_t last_proposer_rows = 0;
 
   // multi-GPU exchange (ibft_comm_*): rows of a batch sharded over `xworld` contexts, one all-reduce merges them
   ncclComm_t comm = nullptr;
@@ -122,6 +129,7 @@ struct ibft_ctx {
   DevBuf d_seen_out;    // the last tally's distinct-sender bitmap (⌈n_validators/64⌉ u64 words): what the ranks exchange
   hipEvent_t ev_xpack = nullptr;  // local collective: this rank's buffer is packed / the summed buffers are back
   uint32_t x_K[2] = {1, 1};       // verdict arrays of the exchange in each slot (1: seal / sender batch, 2: message set)
+  bool x_prop_on[2] = {false, false};
   uint32_t set_n = 0;             // rows of the last message set (its words are in d_set)
   uint64_t *h_xres[2] = {nullptr, nullptr}, *dh_xres[2] = {nullptr, nullptr};
   size_t h_xres_words = 0;
@@ -136,6 +144,7 @@ struct ibft_ctx {
   uint32_t warm_passes = 0, cold_passes = 0, last_group = 0, last_cold_group = 1;
   bool cold_group_auto = true;
   uint32_t cold_group_force = 0;  // IBFT_COLD_LANES=1|2|4|8|64 (experiments: pin the cold kernel variant)
+  uint32_t warm_group_force = 0;  // IBFT_WARM_LANES=1|2|…|64 (experiments: pin the warm kernel variant)
   uint32_t rows_kernel_max = 8192;  // AUTO: a DPP row per signature above wave_rows_max up to this many rows
                                     // (4 096 rows: 0.55 ms vs 0.84 ms for the 8-lane kernel; 8 192: 0.84 vs 0.86)
   uint32_t wave_rows_max = 2048;  // AUTO: one wavefront per signature up to this many rows (two per SIMD: 0.45 ms); the
@@ -343,7 +352,9 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     a.warm_done = (uint8_t *)c->d_warm_done.p + row_base;
     // lanes per signature: ≈ one wavefront per SIMD (1024 SIMDs × 64 lanes / n rows), a power of two
     uint32_t G = 1;
-    if (c->kernel == IBFT_KERNEL_WAVE) {
+    if (c->warm_group_force) {
+      G = c->warm_group_force;
+    } else if (c->kernel == IBFT_KERNEL_WAVE) {
       G = 64;
     } else if (c->kernel != IBFT_KERNEL_LANE) {
       while (G < 64 && (uint64_t)n * (G * 2) <= 65536ull) G *= 2;
@@ -499,6 +510,15 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
   t.host_tally = c->dh_tally;
   t.set_on = set ? 1u : 0u;
   if (set) t.set = *set;
+  // HasPrepareQuorum: on one device the proposer's seat joins the bitmap here; a rank of a sharded batch only counts the
+  // proposer's rows and leaves the seat to the merge (exchange_unpack_kernel)
+  t.prop_on = c->next_prop_on ? 1u : 0u;
+  t.prop_vidx = c->next_prop_vidx;
+  t.prop_seat = (c->comm || c->xlocal) ? 0u : 1u;
+  c->last_prop_on = c->next_prop_on;
+  c->last_prop_vidx = c->next_prop_vidx;
+  c->next_prop_on = false;
+  c->next_prop_vidx = -1;
   if (c->cache_on) t.learned_src = (const uint64_t *)c->dev->d_learned.p;
   if (c->comm || c->xlocal) {  // a rank of a sharded batch: the bitmap of this launch is what the exchange merges
     const size_t bytes = (size_t)((c->n_validators + 63) / 64) * 8;
@@ -544,7 +564,7 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
                                c->stream));
     // d_tally holds {power_lo, power_hi, counts, has_quorum, learned|any_validator, power in full}: one copy
     if (tally && have_tally)
-      HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, (size_t)(ibftk::TALLY_OUT_WIDE + ibftk::TALLY_SUM_WORDS) * 8,
+      HIPCHK(c, hipMemcpyAsync(c->h_tally, c->d_tally.p, (size_t)(ibftk::TALLY_OUT_PROPOSER_ROWS + 1) * 8,
                                hipMemcpyDeviceToHost, c->stream));
     // {keys learned, a learned slot}: the device-wide counter itself (a tally kernel passes it on in word 4 of its results;
     // calls without a tally — the certificate tree, plain hash batches — read it here)
@@ -574,9 +594,30 @@ int fetch_results(ibft_ctx *c, uint32_t n, uint64_t *out_mask, ibft_tally_t *tal
       tally->valid_rows = (uint32_t)(c->h_tally[2] & 0xFFFFFFFFull);
       tally->distinct_senders = (uint32_t)(c->h_tally[2] >> 32);
       tally->has_quorum = (uint32_t)c->h_tally[3];
+      tally->proposer_rows = (uint32_t)c->h_tally[ibftk::TALLY_OUT_PROPOSER_ROWS];
     }
   }
   return IBFT_OK;
+}
+
+// validator index of an address in the current set (−1: no validator) — the device's open-addressing table, on the host
+int32_t host_lookup(const ibft_ctx *c, const uint8_t addr20[20]) {
+  if (c->h_vtab.empty()) return -1;
+  uint32_t a[5];
+  memcpy(a, addr20, 20);
+  uint32_t s = ibftk::addr_hash(a) & c->vslot_mask;
+  for (uint32_t probe = 0; probe <= c->vslot_mask; probe++) {
+    const uint32_t *e = &c->h_vtab[(size_t)s * 6];
+    if (e[5] == 0) return -1;
+    if (memcmp(e, a, 20) == 0) return (int32_t)e[5] - 1;
+    s = (s + 1) & c->vslot_mask;
+  }
+  return -1;
+}
+// the next tally this context enqueues is HasPrepareQuorum with this proposer (null: plain HasQuorum)
+void note_proposer(ibft_ctx *c, const uint8_t *proposer20) {
+  c->next_prop_on = proposer20 != nullptr;
+  c->next_prop_vidx = proposer20 ? host_lookup(c, proposer20) : -1;
 }
 
 int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes);
@@ -809,6 +850,9 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(ncclComm_t, int *) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -829,6 +873,9 @@ RcclApi *rccl() {
     IBFT_SYM(CommInitRank, "ncclCommInitRank");
     IBFT_SYM(CommDestroy, "ncclCommDestroy");
     IBFT_SYM(AllReduce, "ncclAllReduce");
+    IBFT_SYM(CommCount, "ncclCommCount");
+    IBFT_SYM(CommUserRank, "ncclCommUserRank");
+    IBFT_SYM(CommCuDevice, "ncclCommCuDevice");
     IBFT_SYM(GroupStart, "ncclGroupStart");
     IBFT_SYM(GroupEnd, "ncclGroupEnd");
     IBFT_SYM(GetErrorString, "ncclGetErrorString");
@@ -1000,6 +1047,8 @@ int exchange_post(ibft_ctx *c, uint64_t n_total, const xplan &x) {
   ua.seen_words = x.seen_words;
   ua.n_pieces = x.n_pieces;
   ua.n_validators = c->n_validators;
+  ua.prop_on = c->last_prop_on ? 1u : 0u;  // (the tally of this batch was the last one this context enqueued)
+  ua.prop_vidx = c->last_prop_vidx;
   const uint32_t copy_blocks = (x.K * x.total_words + ibftk::XUNPACK_THREADS - 1) / ibftk::XUNPACK_THREADS;
   hipLaunchKernelGGL(ibftk::exchange_unpack_kernel, dim3(copy_blocks + 1), dim3(ibftk::XUNPACK_THREADS), 0, c->xstream, ua);
   HIPCHK(c, hipGetLastError());
@@ -1043,6 +1092,7 @@ int fetch_merged_locked(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally, ui
     tally->distinct_senders = (uint32_t)(t[2] >> 32);
     tally->has_quorum = (uint32_t)t[3];
     tally->shard_overlap = (uint32_t)t[4 + ibftk::TALLY_SUM_WORDS];
+    tally->proposer_rows = (uint32_t)t[5 + ibftk::TALLY_SUM_WORDS];
   }
   return IBFT_OK;
 }
@@ -1133,7 +1183,7 @@ extern "C" {
 
 static void key_cache_unmap(ibft_ctx *c);
 
-int ibft_version(void) { return 1; }
+int ibft_version(void) { return 2; }  // 2: ibft_tally_t.proposer_rows, proposer20 arguments, ibft_tally_prepare, ibft_comm_info
 
 const char *ibft_strerror(int code) {
   switch (code) {
@@ -1177,6 +1227,10 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   if (const char *e = getenv("IBFT_COLD_LANES")) {
     const int g = atoi(e);
     if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64) c->cold_group_force = (uint32_t)g;
+  }
+  if (const char *e = getenv("IBFT_WARM_LANES")) {
+    const int g = atoi(e);
+    if (g >= 1 && g <= 64 && (g & (g - 1)) == 0) c->warm_group_force = (uint32_t)g;
   }
   if (const char *e = getenv("IBFT_NO_EVENTS"))
     if (atoi(e) == 1) c->time_every = 0;
@@ -1514,6 +1568,7 @@ static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addr
     c->cache_on = key_cache_map(c, vaddr) == IBFT_OK;
   }
   c->valset_addrs.assign(addrs20, addrs20 + n * 20);
+  c->h_vtab = std::move(tab);
   c->vslot_mask = slots - 1;
   c->n_validators = (uint32_t)nv;
   c->power_words = pw;
@@ -1862,8 +1917,9 @@ static int messages_launch_locked(ibft_ctx *c, const uint8_t *payload, const uin
   }
   if (n == 0) {
     if (hash_needed && (rc = launch_proposal_hash(c))) return rc;
-    // an empty shard of a sharded set still contributes (zero) words, an empty bitmap and a zero count to the exchange
-    if (c->comm || c->xlocal) return enqueue_tally(c, 0);
+    // an empty shard of a sharded set still contributes (zero) words, an empty bitmap and a zero count to the exchange;
+    // HasPrepareQuorum of no messages is still a question (the proposer alone may be a quorum: validator_manager.go:109-126)
+    if (c->comm || c->xlocal || c->next_prop_on) return enqueue_tally(c, 0);
     return IBFT_OK;
   }
   uint8_t *d_hash = (uint8_t *)c->d_hash.p, *d_sig = (uint8_t *)c->d_sig.p, *d_signer = (uint8_t *)c->d_signer.p,
@@ -1921,13 +1977,17 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
                          const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
                          const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw, size_t raw_len,
                          uint64_t round,
-                         const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally) {
+                         const uint8_t *digest32, const uint8_t *proposer20, uint64_t *out_sender_mask,
+                         uint64_t *out_valid_mask, ibft_tally_t *tally) {
   if (!c || (n && (!out_sender_mask || !out_valid_mask))) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
+  note_proposer(c, proposer20);
   int rc = messages_launch_locked(c, payload, off, msg_sig65, from20, hash32, hash_len, seal65, sender_pre, valid_pre, n, raw,
                                   raw_len, round, digest32);
+  c->next_prop_on = false;  // (an error in front of the tally must not leave the proposer to a later call)
   if (rc) return rc;
   if (n == 0) {
+    if (proposer20) return fetch_results(c, 0, nullptr, tally, true);
     if (tally) {
       memset(tally, 0, sizeof *tally);
       tally->quorum_lo = c->quorum_w[0];
@@ -2082,7 +2142,7 @@ int ibft_verify_senders_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint3
 int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint32_t *off, size_t n, uint64_t height,
                               uint64_t round, const uint8_t *raw, size_t raw_len, uint64_t proposal_round,
                               const uint8_t *digest32, uint64_t *out_sender_mask, uint64_t *out_valid_mask,
-                              uint8_t *out_class, ibft_wire_row_t *out_rows, ibft_tally_t *tally) {
+                              uint8_t *out_class, ibft_wire_row_t *out_rows, const uint8_t *proposer20, ibft_tally_t *tally) {
   if (!c || (n && (!off || !out_sender_mask || !out_valid_mask))) return IBFT_E_INVAL;
   if ((raw_len && !raw) || raw_len > (1ull << 31)) return IBFT_E_INVAL;
   for (size_t i = 0; i < n; i++)
@@ -2109,6 +2169,11 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   }
   if (n == 0) {
     if (hash_needed && (rc = launch_proposal_hash(c))) return rc;
+    if (proposer20) {  // HasPrepareQuorum of no messages: the proposer alone
+      note_proposer(c, proposer20);
+      if ((rc = enqueue_tally(c, 0))) return rc;
+      return fetch_results(c, 0, nullptr, tally, true);
+    }
     if (tally) {
       memset(tally, 0, sizeof *tally);
       tally->quorum_lo = c->quorum_w[0];
@@ -2162,6 +2227,7 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   // the verdict launch above did not need the proposal's hash, the combine step does: hashed on the side stream meanwhile
   if (hash_needed && (rc = launch_proposal_hash(c))) return rc;
   if ((rc = wait_proposal_hash(c))) return rc;
+  note_proposer(c, proposer20);
   if ((rc = enqueue_tally(c, (uint32_t)n, &sa))) return rc;
   c->mask_dirty_words = 0;
   if (!c->dh_set)
@@ -2363,7 +2429,18 @@ int ibft_wire_stage_seals(ibft_ctx *c) {
   return IBFT_OK;
 }
 
+static int tally_impl(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, const uint8_t *proposer20,
+                      ibft_tally_t *tally);
 int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, ibft_tally_t *tally) {
+  return tally_impl(c, sender20, mask, n, nullptr, tally);
+}
+int ibft_tally_prepare(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, const uint8_t proposer20[20],
+                       ibft_tally_t *tally) {
+  if (!proposer20) return IBFT_E_INVAL;
+  return tally_impl(c, sender20, mask, n, proposer20, tally);
+}
+static int tally_impl(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, const uint8_t *proposer20,
+                      ibft_tally_t *tally) {
   if (!c || !tally || (n && (!sender20 || !mask))) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
@@ -2375,12 +2452,18 @@ int ibft_tally(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_
   if ((rc = upload(c, c->d_signer, sender20, n * 20))) return rc;
   c->mask_dirty_words = std::max(c->mask_dirty_words, (uint32_t)mask_words(n));
   if ((rc = upload(c, c->d_mask, mask, (size_t)mask_words(n) * 8))) return rc;
+  ibftk::lookup_proposer lp{};
+  if (proposer20) {
+    lp.on = 1;
+    memcpy(lp.a, proposer20, 20);
+  }
   if (n) {
     hipLaunchKernelGGL(ibftk::lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                        (const uint8_t *)c->d_signer.p, (const uint32_t *)c->d_vtab.p, c->vslot_mask,
-                       (uint32_t)n, (int32_t *)c->d_vidx.p);
+                       (uint32_t)n, (int32_t *)c->d_vidx.p, lp);
     HIPCHK(c, hipGetLastError());
   }
+  note_proposer(c, proposer20);
   if ((rc = enqueue_tally(c, (uint32_t)n))) return rc;
   return fetch_results(c, (uint32_t)n, nullptr, tally, true);
 }
@@ -2450,6 +2533,21 @@ int ibft_seals_exchange(ibft_ctx *c, uint64_t n_total) {
   if ((rc = exchange_pre(c, n_total, x))) return rc;
   if ((rc = exchange_collective(c, api, x))) return rc;
   return exchange_post(c, n_total, x);
+}
+
+int ibft_comm_info(ibft_ctx *c, uint32_t *rccl_nranks, uint32_t *rccl_rank, int32_t *rccl_device) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  RcclApi *api = rccl();
+  if (!c->comm || !api || !api->CommCount || !api->CommUserRank || !api->CommCuDevice) return IBFT_E_INVAL;
+  int n = 0, r = 0, d = 0;
+  NCCLCHK(c, api, api->CommCount(c->comm, &n));
+  NCCLCHK(c, api, api->CommUserRank(c->comm, &r));
+  NCCLCHK(c, api, api->CommCuDevice(c->comm, &d));
+  if (rccl_nranks) *rccl_nranks = (uint32_t)n;
+  if (rccl_rank) *rccl_rank = (uint32_t)r;
+  if (rccl_device) *rccl_device = d;
+  return IBFT_OK;
 }
 
 int ibft_seals_fetch_merged(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
@@ -2628,8 +2726,8 @@ int ibft_group_verify_senders(ibft_group *g, const uint8_t *payload, const uint3
 int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint32_t *off, const uint8_t *msg_sig65,
                                const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len, const uint8_t *seal65,
                                const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n, const uint8_t *raw,
-                               size_t raw_len, uint64_t round, const uint8_t *digest32, uint64_t *out_sender_mask,
-                               uint64_t *out_valid_mask, ibft_tally_t *tally) {
+                               size_t raw_len, uint64_t round, const uint8_t *digest32, const uint8_t *proposer20,
+                               uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally) {
   if (!g || (n && (!off || !msg_sig65 || !from20 || !hash32 || !hash_len || !out_sender_mask || !out_valid_mask)))
     return IBFT_E_INVAL;
   for (size_t i = 0; i < n; i++)
@@ -2647,10 +2745,12 @@ int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint
     uint64_t lo, hi;
     (void)ibft_shard_range(n, i, world, &lo, &hi);
     if (n) shard_offsets(off, lo, hi, loff[i]);
+    note_proposer(c, proposer20);
     int r = messages_launch_locked(c, n ? payload + off[lo] : nullptr, n ? loff[i].data() : nullptr, msg_sig65 + 65 * lo,
                                    from20 + 20 * lo, hash32 + 32 * lo, hash_len + lo, seal65 ? seal65 + 65 * lo : nullptr,
                                    sender_pre ? sender_pre + lo : nullptr, valid_pre ? valid_pre + lo : nullptr,
                                    (size_t)(hi - lo), raw, raw_len, round, digest32);
+    c->next_prop_on = false;
     if (r) return r;
     return exchange_pre(c, n, plan[i], 2);
   });

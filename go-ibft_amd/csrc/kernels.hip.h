@@ -1236,6 +1236,7 @@ __global__ void __launch_bounds__(256) cert_compare_kernel(const wire::node_info
 //   GetVotingPowers returns *big.Int, validator_manager.go:17-31).  Sums are TALLY_SUM_WORDS wide.
 // out[] (u64 words): [0..1] low 128 bits of the power, [2] valid_rows | distinct << 32, [3] has_quorum,
 //   [4] keys learned | a learned validator (written by the recover kernels), [5..9] the power in full,
+//   [10] valid rows sent by the proposer (prop_on: any such row voids the quorum, validator_manager.go:114-121),
 //   [16..16+2·PW) the raw 32-bit piece sums (what the multi-GPU exchange adds across ranks).
 constexpr int TALLY_THREADS = 1024;
 constexpr int TALLY_ROWS_PER_BLOCK = 4096;
@@ -1244,7 +1245,9 @@ constexpr int TALLY_MAX_PIECES = 8;      // 2·PW 32-bit pieces
 constexpr int TALLY_OUT_WIDE = 5;        // out[5..10)
 constexpr int TALLY_OUT_PIECES = 16;     // out[16..24)
 constexpr int TALLY_OUT_WORDS = 24;
-constexpr int TALLY_ACC_WORDS = TALLY_MAX_PIECES + 3;  // pieces, valid, distinct, ticket
+constexpr int TALLY_ACC_WORDS = TALLY_MAX_PIECES + 4;  // pieces, valid, distinct, ticket, rows sent by the proposer
+constexpr int TALLY_OUT_PROPOSER_ROWS = 10;            // out[10]: valid rows whose sender is the proposer (HasPrepareQuorum)
+constexpr int32_t VIDX_PROPOSER_OUTSIDER = -2;         // lookup_kernel: sender == proposer and the proposer is no validator
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -1348,6 +1351,12 @@ struct tally_args {
   uint32_t *seen_out;       // or null: the launch's distinct-sender bitmap is left here (⌈n_validators/32⌉ words) — what a
                             // sharded batch exchanges, because the SET of senders merges across shards and sums do not
   uint32_t set_on;          // a message set: the verdict words are combined here first (set_combine_word)
+  // HasPrepareQuorum (/root/reference/core/validator_manager.go:99-127): the proposer's address joins the sender set
+  // (prop_vidx = its validator index, −1 when it is no validator: it then adds nothing, :88-92) and a valid row sent BY
+  // the proposer voids the quorum (:114-121).  prop_seat = 0: a rank of a sharded batch only counts the proposer's rows —
+  // the seat is added where the shards' bitmaps are merged (exchange_unpack_kernel).
+  uint32_t prop_on, prop_seat;
+  int32_t prop_vidx;
   set_args set;
 };
 
@@ -1361,7 +1370,7 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   constexpr int RPT = TALLY_ROWS_PER_BLOCK / TALLY_THREADS;
   extern __shared__ uint32_t lseen[];  // ⌈n_validators/32⌉ words when a.lds_bitmap
   __shared__ uint64_t wds[TALLY_ROWS_PER_BLOCK / 64];
-  __shared__ uint64_t part[NP + 1][TALLY_THREADS / 64];
+  __shared__ uint64_t part[NP + 2][TALLY_THREADS / 64];
   __shared__ uint32_t last_flag;
   const uint32_t tid = threadIdx.x;
   const uint32_t row0 = blockIdx.x * (uint32_t)TALLY_ROWS_PER_BLOCK;
@@ -1430,18 +1439,27 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   __syncthreads();
   bool first[RPT];
   uint64_t valid = 0, distinct = 0;
+  uint32_t by_proposer = 0;
 #pragma unroll
   for (int j = 0; j < RPT; j++) {
     const uint32_t lr = (uint32_t)j * TALLY_THREADS + tid;
     const bool bit = row0 + lr < a.n && ((wds[lr >> 6] >> (lr & 63)) & 1ull);
     valid += bit;
     first[j] = false;
+    if (a.prop_on && bit && ((a.prop_vidx >= 0 && vi[j] == a.prop_vidx) || vi[j] == VIDX_PROPOSER_OUTSIDER)) by_proposer++;
     if (bit && vi[j] >= 0) {  // unknown senders contribute 0 (validator_manager.go:88-92)
       const uint32_t m = 1u << (vi[j] & 31);
       const uint32_t old = a.lds_bitmap ? atomicOr(&lseen[vi[j] >> 5], m)
                                         : atomicOr(&a.seen[vi[j] >> 5], m);  // device scope (huge sets only)
       first[j] = !(old & m);  // distinct-sender set (validator_manager.go:147-155)
     }
+  }
+  // the proposer's seat in the sender set: one more "row" of thread 0 of the first workgroup
+  bool pfirst = false;
+  if (a.prop_on && a.prop_seat && a.prop_vidx >= 0 && blockIdx.x == 0 && tid == 0) {
+    const uint32_t m = 1u << (a.prop_vidx & 31);
+    const uint32_t old = a.lds_bitmap ? atomicOr(&lseen[a.prop_vidx >> 5], m) : atomicOr(&a.seen[a.prop_vidx >> 5], m);
+    pfirst = !(old & m);
   }
   if (MULTI && a.lds_bitmap) {
     // Several workgroups: the set is shared through a bitmap in HBM, but device-scope atomics on one cache line
@@ -1460,10 +1478,16 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
       const uint32_t v = first[j] ? (uint32_t)vi[j] : 0u;  // (first[j] implies vi[j] ≥ 0)
       first[j] = first[j] && ((lseen[v >> 5] >> (v & 31)) & 1u);
     }
+    if (pfirst) pfirst = (lseen[a.prop_vidx >> 5] >> (a.prop_vidx & 31)) & 1u;
   }
   uint64_t p[NP];
 #pragma unroll
   for (int k = 0; k < NP; k++) p[k] = 0;
+  if (pfirst) {
+    distinct++;
+#pragma unroll
+    for (int k = 0; k < NP; k++) p[k] += a.vpower32[(size_t)a.prop_vidx * NP + k];
+  }
 #pragma unroll
   for (int j = 0; j < RPT; j++) {
     if (!first[j]) continue;
@@ -1480,16 +1504,20 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
   {
     const uint64_t cnt = wave_sum_u64(valid | (distinct << 32));
     if (lane == 0) part[NP][wave] = cnt;
+    const uint64_t bp = a.prop_on ? wave_sum_u64((uint64_t)by_proposer) : 0ull;  // (prop_on is launch-uniform)
+    if (lane == 0) part[NP + 1][wave] = bp;
   }
   __syncthreads();
   uint64_t piece[TALLY_MAX_PIECES];
-  uint64_t v = 0, d = 0;
+  uint64_t v = 0, d = 0, proposer_rows = 0;
   if (MULTI) {
-    if (tid <= NP) {  // thread k adds piece k (thread NP: the two counters) of this workgroup to the launch-wide sums
+    if (tid <= NP + 1) {  // thread k adds piece k (thread NP: the two counters, NP + 1: the proposer's rows) of this workgroup to the launch-wide sums
       uint64_t sum = 0;
       for (int w = 0; w < TALLY_THREADS / 64; w++) sum += part[tid][w];
       if (tid < NP) {
         if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + tid), (unsigned long long)sum);
+      } else if (tid == NP + 1) {
+        if (sum) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 3), (unsigned long long)sum);
       } else {
         if (sum & 0xFFFFFFFFull) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), (unsigned long long)(sum & 0xFFFFFFFFull));
         if (sum >> 32) atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), (unsigned long long)(sum >> 32));
@@ -1516,6 +1544,7 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
       piece[k] = k < NP ? (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + k), 0ull) : 0ull;
     v = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES), 0ull);
     d = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 1), 0ull);
+    proposer_rows = (uint64_t)atomicAdd(reinterpret_cast<unsigned long long *>(a.acc + TALLY_MAX_PIECES + 3), 0ull);
 #pragma unroll
     for (int k = 0; k < TALLY_ACC_WORDS; k++)
       __hip_atomic_store(a.acc + k, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1530,13 +1559,17 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
         for (int w = 0; w < TALLY_THREADS / 64; w++) piece[k] += part[k][w];
     }
     uint64_t c = 0;
-    for (int w = 0; w < TALLY_THREADS / 64; w++) c += part[NP][w];
+    for (int w = 0; w < TALLY_THREADS / 64; w++) {
+      c += part[NP][w];
+      proposer_rows += part[NP + 1][w];
+    }
     v = c & 0xFFFFFFFFull;
     d = c >> 32;
   }
   uint64_t w[TALLY_SUM_WORDS];
   pieces_to_words(piece, NP, w);
-  const uint64_t hq = words_ge(w, a.quorum) ? 1 : 0;
+  // a PREPARE from the proposer among the valid ones: no quorum, whatever the power (validator_manager.go:114-121)
+  const uint64_t hq = (words_ge(w, a.quorum) && proposer_rows == 0) ? 1 : 0;
   const uint64_t c = (v & 0xFFFFFFFFull) | (d << 32);
   a.out[0] = w[0];
   a.out[1] = w[1];
@@ -1547,7 +1580,9 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
 #pragma unroll
   for (int k = 0; k < TALLY_MAX_PIECES; k++) a.out[TALLY_OUT_PIECES + k] = piece[k];
   if (a.learned_src) a.out[4] = *a.learned_src;
+  a.out[TALLY_OUT_PROPOSER_ROWS] = proposer_rows;
   if (a.host_tally) {
+    a.host_tally[TALLY_OUT_PROPOSER_ROWS] = proposer_rows;
     a.host_tally[0] = w[0];
     a.host_tally[1] = w[1];
     a.host_tally[2] = c;
@@ -1585,8 +1620,8 @@ __global__ void exchange_pack_kernel(exchange_pack_args a) {
   } else if (i < cnt) {
     const uint32_t r = (i - seen_base) / a.seen_words, j = (i - seen_base) - r * a.seen_words;
     a.xbuf[i] = r == a.rank ? ((uint64_t)a.seen[2 * j] | ((uint64_t)a.seen[2 * j + 1] << 32)) : 0ull;
-  } else if (i == cnt) {
-    a.xbuf[i] = a.tally_out[2] & 0xFFFFFFFFull;
+  } else if (i == cnt) {  // valid rows | valid rows sent by the proposer << 32 (both sum across ranks)
+    a.xbuf[i] = (a.tally_out[2] & 0xFFFFFFFFull) | (a.tally_out[TALLY_OUT_PROPOSER_ROWS] << 32);
   }
 }
 
@@ -1615,6 +1650,8 @@ struct exchange_unpack_args {
   const uint64_t *quorum;
   uint64_t *dst, *host_dst;
   uint32_t K, world, words_per_rank, seen_words, n_pieces, n_validators;
+  uint32_t prop_on;    // HasPrepareQuorum: the proposer's seat joins the MERGED bitmap, a valid row of his in any shard voids
+  int32_t prop_vidx;
 };
 __global__ void __launch_bounds__(XUNPACK_THREADS) exchange_unpack_kernel(exchange_unpack_args a) {
   const uint32_t total_words = a.words_per_rank * a.world;
@@ -1640,6 +1677,11 @@ __global__ void __launch_bounds__(XUNPACK_THREADS) exchange_unpack_kernel(exchan
       const uint64_t s = a.xbuf[seen_base + r * a.seen_words + j];
       m |= s;
       per_rank += (uint64_t)__popcll(s);
+    }
+    if (a.prop_on && a.prop_vidx >= 0 && (uint32_t)a.prop_vidx / 64u == j) {  // the proposer's seat
+      const uint64_t seat = 1ull << ((uint32_t)a.prop_vidx & 63u);
+      if (!(m & seat)) per_rank++;  // (not an overlap: keep per_rank − popcount(m) what it was)
+      m |= seat;
     }
     const uint64_t here = (uint64_t)__popcll(m);
     distinct += here;
@@ -1683,30 +1725,41 @@ __global__ void __launch_bounds__(XUNPACK_THREADS) exchange_unpack_kernel(exchan
   }
   uint64_t w[TALLY_SUM_WORDS];
   pieces_to_words(piece, TALLY_MAX_PIECES, w);
-  uint64_t t[5 + TALLY_SUM_WORDS];
+  uint64_t t[6 + TALLY_SUM_WORDS];
+  const uint64_t counts = a.xbuf[seen_base + a.world * a.seen_words];
+  const uint64_t proposer_rows = a.prop_on ? counts >> 32 : 0ull;
   t[0] = w[0];
   t[1] = w[1];
-  t[2] = (a.xbuf[seen_base + a.world * a.seen_words] & 0xFFFFFFFFull) | (d << 32);
-  t[3] = words_ge(w, a.quorum) ? 1 : 0;
+  t[2] = (counts & 0xFFFFFFFFull) | (d << 32);
+  t[3] = (words_ge(w, a.quorum) && proposer_rows == 0) ? 1 : 0;
 #pragma unroll
   for (int k = 0; k < TALLY_SUM_WORDS; k++) t[4 + k] = w[k];
   t[4 + TALLY_SUM_WORDS] = o;
+  t[5 + TALLY_SUM_WORDS] = proposer_rows;
 #pragma unroll
-  for (int k = 0; k < 5 + TALLY_SUM_WORDS; k++) {
+  for (int k = 0; k < 6 + TALLY_SUM_WORDS; k++) {
     a.dst[seen_base + k] = t[k];
     if (a.host_dst) a.host_dst[seen_base + k] = t[k];
   }
 }
 
 // sender -> validator index, for ibft_tally() on a caller-supplied mask
+// proposer5 (or null): HasPrepareQuorum compares From with the proposer's address byte for byte, member or not
+// (validator_manager.go:114-115) — a row of a proposer who is no validator is marked VIDX_PROPOSER_OUTSIDER
+struct lookup_proposer {
+  uint32_t on, a[5];
+};
 __global__ void lookup_kernel(const uint8_t *__restrict__ signer20, const uint32_t *__restrict__ vtab,
-                              uint32_t slot_mask, uint32_t n, int32_t *__restrict__ vidx) {
+                              uint32_t slot_mask, uint32_t n, int32_t *__restrict__ vidx, lookup_proposer prop) {
   uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   uint32_t a[5];
   const uint32_t *p = reinterpret_cast<const uint32_t *>(signer20 + 20ull * row);
   for (int i = 0; i < 5; i++) a[i] = p[i];
-  vidx[row] = valset_lookup(vtab, slot_mask, a);
+  int v = valset_lookup(vtab, slot_mask, a);
+  if (prop.on && v < 0 && a[0] == prop.a[0] && a[1] == prop.a[1] && a[2] == prop.a[2] && a[3] == prop.a[3] && a[4] == prop.a[4])
+    v = VIDX_PROPOSER_OUTSIDER;
+  vidx[row] = v;
 }
 
 }  // namespace ibftk

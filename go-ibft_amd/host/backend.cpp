@@ -8,6 +8,7 @@
 #include <cstring>
 #include <random>
 #include <thread>
+#include <unordered_set>
 
 namespace ibft {
 
@@ -108,6 +109,21 @@ bool GpuBackend::VerifyCommitBatch(const Proposal *proposal, const std::vector<M
   return true;
 }
 
+int GpuBackend::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) {
+  if (proposer && proposer->size() != 20) return -1;
+  std::vector<uint8_t> col(senders.size() * 20);
+  for (size_t i = 0; i < senders.size(); i++) {
+    if (senders[i].size() != 20) return -1;  // no validator address has another length; the host's byte compare decides
+    memcpy(&col[20 * i], senders[i].data(), 20);
+  }
+  std::vector<uint64_t> mask((senders.size() + 63) / 64 + 1, ~0ull);
+  ibft_tally_t t{};
+  last_rc = proposer ? ibft_tally_prepare(ctx_, col.data(), mask.data(), senders.size(), (const uint8_t *)proposer->data(), &t)
+                     : ibft_tally(ctx_, col.data(), mask.data(), senders.size(), &t);
+  if (last_rc != IBFT_OK) return -1;
+  return t.has_quorum ? 1 : 0;
+}
+
 bool GpuBackend::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &verdict) {
   verdict.assign(msgs.size(), 0);
   if (msgs.empty()) return true;
@@ -136,7 +152,7 @@ bool GpuBackend::VerifyMessageSet(const Proposal *proposal, MessageType type, co
                                  cc.hash_len.data(), type == COMMIT ? cc.sig65.data() : nullptr, sc.pre_flags.data(),
                                  type == COMMIT ? cc.pre_flags.data() : nullptr, sc.n,
                                  (const uint8_t *)proposal->raw_proposal.data(), proposal->raw_proposal.size(),
-                                 proposal->round, nullptr, ms.data(), mv.data(), nullptr);
+                                 proposal->round, nullptr, nullptr, ms.data(), mv.data(), nullptr);
   if (last_rc != IBFT_OK) return false;
   unpack_mask(ms, sc.n, sender);
   unpack_mask(mv, sc.n, closure);
@@ -185,7 +201,7 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
   std::vector<uint8_t> cls(n, 0);
   last_rc = ibft_verify_messages_wire(ctx_, wire, off, n, height, round, (const uint8_t *)proposal.raw_proposal.data(),
                                       proposal.raw_proposal.size(), proposal.round, nullptr, ms.data(), mv.data(), cls.data(),
-                                      nullptr, nullptr);
+                                      nullptr, nullptr, nullptr);
   if (last_rc != IBFT_OK) return false;
   unpack_mask(ms, n, sender);
   unpack_mask(mv, n, closure);
@@ -467,6 +483,22 @@ bool LoopBatch::VerifyCommitBatch(const Proposal *proposal, const std::vector<Ms
   }
   return true;
 }
+int LoopBatch::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) {
+  if (!quorum_vm || fail_quorum || !quorum_vm->initialized()) return -1;
+  quorum_calls++;
+  std::unordered_set<std::string> set;
+  if (proposer) set.emplace(proposer->data(), proposer->size());
+  bool voided = false;
+  for (const bytes &s : senders) {
+    if (proposer && s.size() == proposer->size() && memcmp(s.data(), proposer->data(), s.size()) == 0) voided = true;
+    set.emplace(s.data(), s.size());
+  }
+  unsigned __int128 sum = 0;
+  for (const std::string &a : set) sum += quorum_vm->powerOf(std::string_view(a));
+  const bool q = !voided && sum >= quorum_vm->quorum();
+  return (q != wrong_quorum) ? 1 : 0;
+}
+
 bool LoopBatch::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
   if (fail_senders) return false;
   calls++;
@@ -548,7 +580,23 @@ bool HotPath::hasQuorumByMsgType(const std::vector<MsgPtr> &msgs, uint32_t type)
 // hasQuorumByMsgType for the messages a GetValidMessages walk just returned: they are ALL the stored messages of the view
 // (the walk pruned the rest), one per sender — so with the quorum index on, Σ power of the view is already known (the
 // store's hooks kept it through the prunes) and no sender set has to be rebuilt.
+// The decision itself, optionally from the device: `host_answer` is what the mirror's own rule says for these senders
+bool HotPath::quorumDecision(uint32_t type, const std::vector<bytes> &senders, bool host_answer) {
+  if (!device_quorum || !batch || (type != PREPARE && type != COMMIT && type != ROUND_CHANGE)) return host_answer;
+  if (type == PREPARE && !proposalMessage) return host_answer;  // HasPrepareQuorum: nil proposal → false without asking (:101-110)
+  const int q = batch->QuorumOfSenders(senders, type == PREPARE ? &proposalMessage->from : nullptr);
+  if (q < 0) return host_answer;
+  device_quorum_calls++;
+  if ((q != 0) != host_answer) device_quorum_mismatches++;
+  return q != 0;
+}
+
 bool HotPath::hasQuorumOfStoredView(const View &view, uint32_t type, const std::vector<MsgPtr> &msgs) {
+  if (device_quorum && batch && validatorManager.initialized()) {
+    std::vector<bytes> senders;
+    for (auto &x : msgs) senders.push_back(x->from);
+    return quorumDecision(type, senders, hasQuorumByMsgType(msgs, type));
+  }
   if (!index_enabled_ || !validatorManager.initialized()) return hasQuorumByMsgType(msgs, type);
   auto rebuild = [&]() {
     std::vector<bytes> senders;
@@ -1649,6 +1697,7 @@ bool HotPath::handleLean(const View &view, MessageType type, bool &quorum) {
     } else {
       quorum = pc.first >= validatorManager.quorum();
     }
+    if (device_quorum) quorum = quorumDecision(type, messages.SendersOf(view, type), quorum);
   }
   if (!quorum) return true;
   if (type == PREPARE) {

@@ -74,6 +74,10 @@ struct BatchVerifier {
                                   std::vector<uint8_t> & /*closure*/, std::vector<uint8_t> & /*judged*/) {
     return false;
   }
+  // a8 on the device (include/ibftgpu.h: ibft_tally / ibft_tally_prepare): ValidatorManager.HasQuorum over the sender set
+  // (proposer == nullptr) or HasPrepareQuorum with proposalMessage.From = *proposer (validator_manager.go:77-127).
+  // 1 / 0 = the decision, −1 = not offered / device unavailable / an address that is not 20 bytes (the host decides).
+  virtual int QuorumOfSenders(const std::vector<bytes> & /*senders*/, const bytes * /*proposer*/) { return -1; }
 };
 
 // SoA columns handed to the C ABI (plain bytes, no pointers inside: cgo-safe layout)
@@ -119,6 +123,7 @@ class GpuBackend : public BatchVerifier {
                           const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
                           std::vector<uint8_t> &judged) override;
   bool VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off, size_t n, CertVerdicts &out) override;
+  int QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) override;
   size_t cert_rows_cap = 65536;  // rows one certificate call may expand to (the context's max_rows bounds it too)
   int last_rc = 0;
 
@@ -144,6 +149,13 @@ class LoopBatch : public BatchVerifier {
   bool VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
                           const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
                           std::vector<uint8_t> &judged) override;
+  // a8 without a device: HasQuorum / HasPrepareQuorum restated from scratch over `quorum_vm`'s powers (a set of addresses,
+  // the proposer's seat, a sender equal to the proposer voids) — the CPU-side stand-in for ibft_tally[_prepare]; fail_quorum
+  // makes it report "device unavailable", wrong_quorum inverts the answer (the mirror must count the mismatch)
+  int QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) override;
+  const ValidatorManager *quorum_vm = nullptr;
+  bool fail_quorum = false, wrong_quorum = false;
+  size_t quorum_calls = 0;
   bool fail_hashes = false, fail_seals = false, fail_senders = false, fail_sets = false, fail_certs = false;
   size_t calls = 0;      // batch calls answered
   size_t set_calls = 0;  // of which message-set calls
@@ -219,6 +231,13 @@ class HotPath {
     double device_ms = 0.0;  // wall time inside the batch backend's calls (the rest of an ingest is the mirror's own work)
   };
   bool use_sets = true;
+  // device_quorum: the quorum decision of handlePrepare / handleCommit is the DEVICE's (BatchVerifier::QuorumOfSenders →
+  // ibft_tally_prepare / ibft_tally over the senders that survived the walk) — hasQuorumByMsgType computed by tally_kernel,
+  // HasPrepareQuorum's proposer rule included; the quorum index's answer is kept as a cross-check (mismatches counted, the
+  // device's answer taken).  Off by default: the index answers in O(1) without a device call.
+  bool device_quorum = false;
+  size_t device_quorum_calls = 0, device_quorum_mismatches = 0;
+  bool quorumDecision(uint32_t type, const std::vector<bytes> &senders, bool host_answer);
   size_t closure_hits = 0;  // messages of the last handlePrepare / handleCommit whose closure verdict was already known
   // With use_certs (default) the PREPREPARE / ROUND_CHANGE messages of a micro-batch go to the device as they arrived
   // (VerifyCertificatesWire): their own IsValidValidator AND every IsValidValidator / IsValidProposalHash that

@@ -634,6 +634,12 @@ int ibft_host_retain_heap(size_t bytes) {
   ok &= mallopt(M_MMAP_THRESHOLD, (int)(cap > ((size_t)32 << 20) ? ((size_t)32 << 20) : cap));
   return ok ? 0 : -1;
 }
+void ibft_host_use_device_quorum(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.device_quorum = on != 0; }
+void ibft_host_device_quorum_stats(ibft_host *h, size_t *calls, size_t *mismatches) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  if (calls) *calls = h->hp.device_quorum_calls;
+  if (mismatches) *mismatches = h->hp.device_quorum_mismatches;
+}
 void ibft_host_use_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_lean = on != 0; }
 size_t ibft_host_rows_kept(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.lean_rows; }
 void ibft_host_use_certs(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_certs = on != 0; }
@@ -657,11 +663,14 @@ size_t ibft_host_loop_batch_set_calls(ibft_host *h) { std::lock_guard<std::recur
 void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   h->loop.reset(new LoopBatch(&h->cbv));
+  h->loop->quorum_vm = &h->hp.validatorManager;
   h->loop->fail_hashes = (fail_mask & 1) != 0;
   h->loop->fail_seals = (fail_mask & 2) != 0;
   h->loop->fail_senders = (fail_mask & 4) != 0;
   h->loop->fail_sets = (fail_mask & 8) != 0;
   h->loop->fail_certs = (fail_mask & 16) != 0;
+  h->loop->fail_quorum = (fail_mask & 32) != 0;
+  h->loop->wrong_quorum = (fail_mask & 64) != 0;
   h->hp.batch = h->loop.get();
 }
 size_t ibft_host_loop_batch_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->loop ? h->loop->calls : 0; }

@@ -134,6 +134,9 @@ def lib() -> C.CDLL:
             getattr(L, nm).argtypes = [vp]; getattr(L, nm).restype = C.c_size_t
         L.ibft_host_use_certs.argtypes = [vp, C.c_int]; L.ibft_host_use_certs.restype = None
         L.ibft_host_use_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rows.restype = None
+        L.ibft_host_use_device_quorum.argtypes = [vp, C.c_int]; L.ibft_host_use_device_quorum.restype = None
+        L.ibft_host_device_quorum_stats.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ibft_host_device_quorum_stats.restype = None
         L.ibft_host_retain_heap.argtypes = [C.c_size_t]; L.ibft_host_retain_heap.restype = C.c_int
         L.ibft_host_use_rc_rows.argtypes = [vp, C.c_int]; L.ibft_host_use_rc_rows.restype = None
         L.ibft_host_cert_roots_first.argtypes = [vp, C.c_int]; L.ibft_host_cert_roots_first.restype = None
@@ -515,6 +518,16 @@ class Host:
     @property
     def repacked_bytes(self) -> int:
         return int(self.L.ibft_host_repacked_bytes(self.h))
+
+    def use_device_quorum(self, on: bool):
+        """handlePrepare / handleCommit take the quorum decision from the batch backend (ibft_tally_prepare / ibft_tally)"""
+        self.L.ibft_host_use_device_quorum(self.h, 1 if on else 0)
+
+    def device_quorum_stats(self):
+        """(decisions the backend took, decisions on which the mirror's quorum index disagreed — must be 0)"""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self.L.ibft_host_device_quorum_stats(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def use_rows(self, on: bool):
         """Keep the PREPARE / COMMIT messages a batch backend judged from their bytes as rows (default) or as objects."""

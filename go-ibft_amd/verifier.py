@@ -39,7 +39,7 @@ EXPORTS = [
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages", "ibft_group_verify_certificates_wire",
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
-    "ibft_cache_memory",
+    "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -73,7 +73,8 @@ class Tally(C.Structure):
     _fields_ = [("quorum_lo", C.c_uint64), ("quorum_hi", C.c_uint64),
                 ("power_lo", C.c_uint64), ("power_hi", C.c_uint64),
                 ("valid_rows", C.c_uint32), ("distinct_senders", C.c_uint32),
-                ("has_quorum", C.c_uint32), ("shard_overlap", C.c_uint32)]
+                ("has_quorum", C.c_uint32), ("shard_overlap", C.c_uint32),
+                ("proposer_rows", C.c_uint32), ("reserved", C.c_uint32)]
 
     @property
     def power(self) -> int:
@@ -128,18 +129,20 @@ def load_library() -> C.CDLL:
     L.ibft_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_tally.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(Tally)]
+    L.ibft_tally_prepare.argtypes = [vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
+    L.ibft_comm_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.ibft_seals_stage.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.ibft_seals_launch.argtypes = [vp, C.c_uint32]
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp,
-                                            C.POINTER(Tally)]
+                                            vp, C.POINTER(Tally)]
     L.ibft_forget_proposal.argtypes = [vp]
     L.ibft_pinned_alloc.argtypes = [C.c_size_t]; L.ibft_pinned_alloc.restype = vp
     L.ibft_pinned_free.argtypes = [vp]; L.ibft_pinned_free.restype = None
     L.ibft_column_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
-    L.ibft_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp, vp, vp,
+    L.ibft_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp,
                                        C.POINTER(Tally)]
     L.ibft_seals_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.ibft_seals_export.argtypes = [vp, vp, vp]
@@ -171,7 +174,7 @@ def load_library() -> C.CDLL:
     L.ibft_group_verify_seals.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_group_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_group_verify_messages.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp,
-                                             vp, vp, C.POINTER(Tally)]
+                                             vp, vp, vp, C.POINTER(Tally)]
     L.ibft_group_verify_certificates_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.ibft_group_is_local.argtypes = [vp]
     L.ibft_keccak256.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
@@ -376,8 +379,10 @@ class BatchVerifier:
 
     # a whole PREPARE / COMMIT set in one call: IsValidValidator ∧ IsValidProposalHash (∧ IsValidCommittedSeal)
     def verify_messages(self, payload: bytes, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None, valid_pre=None,
-                        raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
-        """→ (sender bool[n], valid bool[n], Tally over sender ∧ valid); seal65=None for a PREPARE set"""
+                        raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None, proposer: bytes | None = None):
+        """→ (sender bool[n], valid bool[n], Tally over sender ∧ valid); seal65=None for a PREPARE set; proposer (20 bytes):
+        the tally is ValidatorManager.HasPrepareQuorum with that proposer instead of HasQuorum"""
+        pr = None if proposer is None else np.frombuffer(bytes(proposer), dtype=np.uint8)
         pl = _bytes_col(payload)
         off = np.ascontiguousarray(off, dtype=np.uint32)
         s = _u8(msg_sig65, (-1, 65)); f = _u8(from20, (-1, 20)); h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
@@ -391,12 +396,12 @@ class BatchVerifier:
         mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
         t = Tally()
         self._chk(self._L.ibft_verify_messages(self._h, _p(pl), _p(off), _p(s), _p(f), _p(h), _p(hl), _p(sl), _p(spre), _p(vpre), n,
-                                               _p(rawb), 0 if raw is None else len(raw), round_, _p(dg), _p(ms), _p(mv),
+                                               _p(rawb), 0 if raw is None else len(raw), round_, _p(dg), _p(pr), _p(ms), _p(mv),
                                                C.byref(t)), "ibft_verify_messages")
         return mask_to_bool(ms, n), mask_to_bool(mv, n), t
 
     def prepare_messages(self, payload, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None, valid_pre=None,
-                         raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
+                         raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None, proposer: bytes | None = None):
         """verify_messages with the argument marshalling done ONCE: for a caller whose columns live in fixed buffers that
         are refilled every round (what the integration prescribes).  Returns run() → (sender words u64[⌈n/64⌉], valid words,
         Tally); the word arrays are reused between calls.  Decode with mask_to_bool(words, n)."""
@@ -412,9 +417,10 @@ class BatchVerifier:
         ms = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
         mv = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
         t = Tally()
-        keep = (pl, off, s, f, h, hl, sl, spre, vpre, rawb, dg)      # the pointers below stay valid while these live
+        pr = None if proposer is None else np.frombuffer(bytes(proposer), dtype=np.uint8)
+        keep = (pl, off, s, f, h, hl, sl, spre, vpre, rawb, dg, pr)  # the pointers below stay valid while these live
         args = (self._h, _p(pl), _p(off), _p(s), _p(f), _p(h), _p(hl), _p(sl), _p(spre), _p(vpre), n, _p(rawb),
-                0 if raw is None else len(raw), round_, _p(dg), _p(ms), _p(mv), C.byref(t))
+                0 if raw is None else len(raw), round_, _p(dg), _p(pr), _p(ms), _p(mv), C.byref(t))
         fn, chk = self._L.ibft_verify_messages, self._chk
 
         def run(_keep=keep):
@@ -438,7 +444,7 @@ class BatchVerifier:
         return mask_to_bool(mask, n), rows, t
 
     def verify_messages_wire(self, wire, off, height: int, round_: int, raw: bytes | None = None, proposal_round: int | None = None,
-                             digest32: bytes | None = None, want_rows: bool = True):
+                             digest32: bytes | None = None, want_rows: bool = True, proposer: bytes | None = None):
         """raw messages judged completely → (sender bool[n], valid bool[n], rows or class bytes, Tally): rows = the full
         parse results (want_rows) or the one routing byte per row (CLASS_* bits); see include/ibftgpu.h"""
         wb = _bytes_col(wire)
@@ -454,7 +460,9 @@ class BatchVerifier:
         self._chk(self._L.ibft_verify_messages_wire(self._h, _p(wb), _p(off), n, height, round_, _p(rawb),
                                                     0 if raw is None else len(raw),
                                                     round_ if proposal_round is None else proposal_round, _p(dg), _p(ms), _p(mv),
-                                                    _p(cls), _p(rows) if (n and want_rows) else None, C.byref(t)),
+                                                    _p(cls), _p(rows) if (n and want_rows) else None,
+                                                    _p(None if proposer is None else np.frombuffer(bytes(proposer), dtype=np.uint8)),
+                                                    C.byref(t)),
                   "ibft_verify_messages_wire")
         self._last_class = cls[:n]
         return mask_to_bool(ms, n), mask_to_bool(mv, n), (rows if want_rows else cls[:n]), t
@@ -491,6 +499,22 @@ class BatchVerifier:
         t = Tally()
         self._chk(self._L.ibft_tally(self._h, _p(f), _p(m), len(f), C.byref(t)), "ibft_tally")
         return t
+
+    # ValidatorManager.HasPrepareQuorum (core/validator_manager.go:99-127) over a caller-supplied verdict array
+    def has_prepare_quorum(self, sender20, verdict, proposer: bytes) -> Tally:
+        f = _u8(sender20, (-1, 20))
+        m = bool_to_mask(np.asarray(verdict, dtype=bool))
+        pr = np.frombuffer(bytes(proposer), dtype=np.uint8)
+        assert len(pr) == 20
+        t = Tally()
+        self._chk(self._L.ibft_tally_prepare(self._h, _p(f), _p(m), len(f), _p(pr), C.byref(t)), "ibft_tally_prepare")
+        return t
+
+    def comm_info(self):
+        """(ranks, this rank, device) as the RCCL communicator itself reports them"""
+        n, r, d = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+        self._chk(self._L.ibft_comm_info(self._h, C.byref(n), C.byref(r), C.byref(d)), "ibft_comm_info")
+        return int(n.value), int(r.value), int(d.value)
 
     # staged / device-resident form of a2 (bench.py, multi-GPU)
     def seals_stage(self, hash32, sig65, signer20, pre_flags=None) -> int:
@@ -693,8 +717,10 @@ class DeviceGroup:
                 mask_to_bool(mself, k))
 
     def verify_messages(self, payload: bytes, off, msg_sig65, from20, hash32, hash_len, seal65=None, sender_pre=None,
-                        valid_pre=None, raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None):
+                        valid_pre=None, raw: bytes | None = None, round_: int = 0, digest32: bytes | None = None,
+                        proposer: bytes | None = None):
         """a whole PREPARE / COMMIT set sharded by message → (sender bool[n], valid bool[n], merged Tally)"""
+        pr = None if proposer is None else np.frombuffer(bytes(proposer), dtype=np.uint8)
         pl = _bytes_col(payload)
         off = np.ascontiguousarray(off, dtype=np.uint32)
         s = _u8(msg_sig65, (-1, 65)); f = _u8(from20, (-1, 20)); h = _u8(hash32, (-1, 32)); hl = _u8(hash_len)
@@ -709,7 +735,7 @@ class DeviceGroup:
         t = Tally()
         self._chk(self._L.ibft_group_verify_messages(self._g, _p(pl), _p(off), _p(s), _p(f), _p(h), _p(hl), _p(sl), _p(spre),
                                                      _p(vpre), n, _p(rawb), 0 if raw is None else len(raw), round_, _p(dg),
-                                                     _p(ms), _p(mv), C.byref(t)), "ibft_group_verify_messages")
+                                                     _p(pr), _p(ms), _p(mv), C.byref(t)), "ibft_group_verify_messages")
         return mask_to_bool(ms, n), mask_to_bool(mv, n), t
 
     @property

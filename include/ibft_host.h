@@ -230,6 +230,12 @@ int ibft_host_retain_heap(size_t bytes);
  * held until the height is pruned.  repacked_bytes: bytes moved that way so far.                                      */
 void ibft_host_set_repack_min_bytes(ibft_host *h, size_t bytes);
 size_t ibft_host_repacked_bytes(ibft_host *h);
+/* a8 on the device: handlePrepare / handleCommit take the quorum decision from ibft_tally_prepare / ibft_tally (tally_kernel:
+ * HasPrepareQuorum's proposer rule included, /root/reference/core/validator_manager.go:77-127) over the senders that survived
+ * the walk, instead of the mirror's quorum index; the index's answer is kept as a cross-check — `mismatches` counts the
+ * decisions on which the two differed (must stay 0), `calls` the decisions the device took.  Off by default.               */
+void ibft_host_use_device_quorum(ibft_host *h, int on);
+void ibft_host_device_quorum_stats(ibft_host *h, size_t *calls, size_t *mismatches);
 void ibft_host_use_rows(ibft_host *h, int on);
 size_t ibft_host_rows_kept(ibft_host *h);
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits);
@@ -245,7 +251,8 @@ int ibft_host_cert_routes(ibft_ctx *ctx, const uint8_t *wire, const uint32_t *of
                           size_t *rows, size_t *valid, double *host_ms, double *total_ms);
 /* A batch backend that loops over the callback Verifier (no device): the batch control flow — one call per walk,
  * verdict tables, fallback — for CPU-side tests.  fail_mask bits: 1 hash batches, 2 seal batches, 4 sender
- * batches, 8 message-set calls, 16 certificate-tree calls report "device unavailable".                                            */
+ * batches, 8 message-set calls, 16 certificate-tree calls report "device unavailable"; 32: so does the quorum call
+ * (ibft_host_use_device_quorum), 64: the quorum call answers the OPPOSITE (the mirror then counts a mismatch).                       */
 void ibft_host_use_loop_batch(ibft_host *h, int fail_mask);
 size_t ibft_host_loop_batch_calls(ibft_host *h);
 /* batches that fell back to the per-message verifier because the batch backend reported failure            */

@@ -23,6 +23,9 @@
  *   ibft_tally (+ the ibft_tally_t filled by the verify calls)
  *                        <- ValidatorManager.HasQuorum
  *                           /root/reference/core/validator_manager.go:77-96
+ *   ibft_tally_prepare (+ the proposer20 argument of the message-set calls)
+ *                        <- ValidatorManager.HasPrepareQuorum — the decision hasQuorumByMsgType takes for PREPARE
+ *                           /root/reference/core/validator_manager.go:99-127, core/ibft.go:1273-1284
  *   ibft_verify_messages, ibft_verify_messages_wire
  *                        <- all of the above for a whole PREPARE / COMMIT set in ONE call (from SoA columns / from the
  *                           transport's bytes): IsValidValidator on arrival (core/ibft.go:1128) and the closure of
@@ -134,6 +137,9 @@ typedef struct {
   uint32_t shard_overlap;        /* sharded calls (ibft_seals_fetch_merged, ibft_group_*): Σ over validators of (shards in which
                                     the validator has a valid row) − 1.  Such a validator is counted ONCE in power and
                                     distinct_senders, like everywhere else; 0 from the single-device calls             */
+  uint32_t proposer_rows;        /* HasPrepareQuorum calls (a proposer20 was given): valid rows whose sender IS the proposer —
+                                    any such row forces has_quorum = 0 (validator_manager.go:114-121); 0 otherwise     */
+  uint32_t reserved;
 } ibft_tally_t;
 
 int ibft_version(void);
@@ -243,6 +249,19 @@ int ibft_wire_stage_seals(ibft_ctx *ctx);
 /* a8 alone: HasQuorum over the rows whose bit is set in mask.                      */
 int ibft_tally(ibft_ctx *ctx, const uint8_t *sender20, const uint64_t *mask, size_t n,
                ibft_tally_t *tally);
+/* a8, the PREPARE form: ValidatorManager.HasPrepareQuorum(state, proposalMessage, msgs)
+ * (/root/reference/core/validator_manager.go:99-127 — what hasQuorumByMsgType asks for PREPARE messages,
+ * core/ibft.go:1273-1284).  proposer20 = proposalMessage.From.  The proposer's address JOINS the sender set before the
+ * powers are summed (it counts once, and only if it is a validator: unknown addresses add nothing, :88-92), and a
+ * row of the mask whose sender equals the proposer byte for byte — validator or not — voids the result:
+ * has_quorum = 0 whatever the power, tally->proposer_rows = the number of such rows (:114-121 "proposer is among
+ * signers but it is not expected to be").  distinct_senders then counts the proposer's seat too.  With n = 0 the
+ * answer is whether the proposer alone is a quorum (one validator of all the power).  The caller keeps the one case
+ * the device cannot see: proposalMessage == nil → false without asking (:101-110).  The same rule is applied by
+ * ibft_verify_messages / ibft_verify_messages_wire / ibft_group_verify_messages when their proposer20 argument is
+ * not NULL, and by the sharded merge (the seat joins the MERGED bitmap; a proposer row in any shard voids).     */
+int ibft_tally_prepare(ibft_ctx *ctx, const uint8_t *sender20, const uint64_t *mask, size_t n,
+                       const uint8_t proposer20[20], ibft_tally_t *tally);
 
 /* The context remembers the last (raw proposal, round) it hashed: ibft_verify_hashes / ibft_verify_messages
  * with the same proposal do not hash it again.  ibft_forget_proposal drops that memory (the next call hashes);
@@ -325,7 +344,9 @@ int ibft_column_stats(ibft_ctx *ctx, uint32_t *gather_batches);
  *                           ∧ (seal65 == NULL ∨ IsValidCommittedSeal(hash32[i], {from20[i], seal65[i]}))
  *                         — what the handle* closure would return for it;
  *   tally                 = ValidatorManager.HasQuorum over the rows with both bits (hasQuorumByMsgType of
- *                           the messages that were stored AND survive the closure).
+ *                           the messages that were stored AND survive the closure); with proposer20 != NULL
+ *                           (a PREPARE set: proposer20 = the accepted proposal message's From) the tally is
+ *                           ValidatorManager.HasPrepareQuorum — see ibft_tally_prepare.
  * payload / off / msg_sig65 / from20 / sender_pre are ibft_verify_senders' columns (sender_pre = its pre_flags),
  * hash32 / hash_len are ibft_verify_hashes', seal65 / valid_pre are ibft_verify_seals' sig65 / pre_flags
  * (seal65 NULL for a PREPARE set; the seal's signer is the message's From, messages/helpers.go:22-35).  The proposal is given as raw bytes + round (hashed on the
@@ -338,7 +359,8 @@ int ibft_verify_messages(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *
                          const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len,
                          const uint8_t *seal65, const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n,
                          const uint8_t *raw, size_t raw_len, uint64_t round, const uint8_t *digest32,
-                         uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally);
+                         const uint8_t *proposer20, uint64_t *out_sender_mask, uint64_t *out_valid_mask,
+                         ibft_tally_t *tally);
 
 /* The same for a batch of messages AS THE TRANSPORT DELIVERED THEM (ibft_verify_senders_wire's input): the
  * device walks the bytes, and every canonical PREPARE / COMMIT message of the view (height, round) is judged
@@ -351,7 +373,8 @@ int ibft_verify_messages(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *
  *                           and, for a COMMIT, whose committed seal verifies for From: the handlePrepare /
  *                           handleCommit closure (core/ibft.go:856-862, :932-944).  Messages of other views or
  *                           kinds have bit 0 here and are judged when their view is handled;
- *   tally                 = HasQuorum over the rows with both bits (meaningful for a batch of one type);
+ *   tally                 = HasQuorum over the rows with both bits (meaningful for a batch of one type) —
+ *                           HasPrepareQuorum when proposer20 != NULL (a batch of PREPAREs of the asked view);
  *   out_class[i] (n bytes, may be NULL) = what the caller needs to route row i: IBFT_WIRE_CLASS_NEEDS_HOST — not
  *                           judged here, stock route; IBFT_WIRE_CLASS_CLOSURE — a PREPARE / COMMIT of the asked
  *                           view: its valid bit IS the closure's verdict; bits 4..7 = IbftMessage.type.  One byte
@@ -365,7 +388,7 @@ int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const ui
                               uint64_t height, uint64_t round, const uint8_t *raw, size_t raw_len,
                               uint64_t proposal_round, const uint8_t *digest32, uint64_t *out_sender_mask,
                               uint64_t *out_valid_mask, uint8_t *out_class, ibft_wire_row_t *out_rows,
-                              ibft_tally_t *tally);
+                              const uint8_t *proposer20, ibft_tally_t *tally);
 
 /* ---- SURVEY.md §8f rank 2 from the transport's bytes: certificates --------------------------------------------
  * A PREPREPARE message carries a RoundChangeCertificate, a ROUND_CHANGE message a PreparedCertificate
@@ -490,6 +513,9 @@ int ibft_comm_destroy(ibft_ctx *ctx);
 int ibft_seals_exchange(ibft_ctx *ctx, uint64_t n_total);
 /* out_mask: ⌈n_total/64⌉ words (bit g = verdict of global row g); either pointer may be NULL */
 int ibft_seals_fetch_merged(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
+/* What the communicator itself says about this rank (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): lets a
+ * benchmark line state that the collective really spans `nranks` devices.  IBFT_E_INVAL without a communicator.  */
+int ibft_comm_info(ibft_ctx *ctx, uint32_t *rccl_nranks, uint32_t *rccl_rank, int32_t *rccl_device);
 
 typedef struct ibft_group ibft_group;
 /* One context per listed device + the collective over them; max_rows_total = largest n (0 = 65536 per device).
@@ -522,7 +548,8 @@ int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint
                                const uint8_t *from20, const uint8_t *hash32, const uint8_t *hash_len,
                                const uint8_t *seal65, const uint8_t *sender_pre, const uint8_t *valid_pre, size_t n,
                                const uint8_t *raw, size_t raw_len, uint64_t round, const uint8_t *digest32,
-                               uint64_t *out_sender_mask, uint64_t *out_valid_mask, ibft_tally_t *tally);
+                               const uint8_t *proposer20, uint64_t *out_sender_mask, uint64_t *out_valid_mask,
+                               ibft_tally_t *tally);
 /* Certificate trees sharded by CARRIER: device k expands and judges the trees of its own contiguous range of the call's n
  * messages, all devices at once; ibft_verify_certificates_wire's arguments and results, the rows numbered as ONE call over
  * all n messages numbers them (breadth first).  Verdicts are per row and no tally is taken, so the devices exchange

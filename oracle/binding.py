@@ -202,13 +202,26 @@ def verify_seals(vs: ValSet, hash32, sig65, signer20, pre_flags=None, flags: int
 
 
 def verify_senders(vs: ValSet, payload: bytes, off: np.ndarray, sig65, from20, pre_flags=None,
-                   flags: int = 0) -> np.ndarray:
+                   flags: int = 0, nthreads: int = 1) -> np.ndarray:
     pl = np.frombuffer(bytes(payload) or b"\0", dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint32)
     sig65 = _u8(sig65, (-1, 65)); from20 = _u8(from20, (-1, 20))
     n = len(sig65)
     pre = None if pre_flags is None else _u8(pre_flags)
     out = np.zeros(n, dtype=np.uint8)
+    if nthreads > 1 and n >= 4 * nthreads:
+        # rows are independent and the offsets are absolute: every thread takes a contiguous range of rows over the
+        # same payload buffer (the C loop runs without the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [n * k // nthreads for k in range(nthreads + 1)]
+
+        def part(k):
+            lo, hi = cuts[k], cuts[k + 1]
+            lib().orc_verify_senders(vs.h, _p(pl), _p(off[lo:hi + 1]), _p(sig65[lo:hi]), _p(from20[lo:hi]),
+                                     _p(pre[lo:hi]) if pre is not None else None, hi - lo, flags, _p(out[lo:hi]))
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            list(ex.map(part, range(nthreads)))
+        return out
     lib().orc_verify_senders(vs.h, _p(pl), _p(off), _p(sig65), _p(from20), _p(pre), n, flags, _p(out))
     return out
 

@@ -52,6 +52,9 @@ type Tally struct {
 	HasQuorum          bool
 	// sharded calls: how often a validator had valid rows in more than one shard (it is counted once)
 	ShardOverlap uint32
+	// HasPrepareQuorum calls (a proposer was given): valid rows sent BY the proposer — any such row makes HasQuorum false
+	// (core/validator_manager.go:114-121)
+	ProposerRows uint32
 }
 
 // Ctx owns one ibft_ctx (one HIP stream, resident columns on one GPU).  Use one Ctx per
@@ -183,15 +186,17 @@ func (c *Ctx) VerifySenders(payload []byte, off []uint32, sig65, from20, preFlag
 
 // VerifyMessages = a whole PREPARE / COMMIT set in one call (ibft_verify_messages): senderMask bit i is
 // IsValidValidator(message i), validMask bit i the handlePrepare / handleCommit closure for it, the tally is
-// HasQuorum over the rows with both bits.  seal65 == nil for a PREPARE set; senderPre / validPre may be nil.
+// HasQuorum over the rows with both bits — ValidatorManager.HasPrepareQuorum (core/validator_manager.go:99-127) when
+// proposer20 (the accepted proposal message's From) is not nil.  seal65 == nil for a PREPARE set; senderPre / validPre
+// may be nil.
 func (c *Ctx) VerifyMessages(payload []byte, off []uint32, msgSig65, from20, hash32, hashLen, seal65, senderPre, validPre,
-	raw []byte, round uint64) (senderMask, validMask []uint64, t Tally, err error) {
+	raw []byte, round uint64, proposer20 []byte) (senderMask, validMask []uint64, t Tally, err error) {
 	n := len(off) - 1
 	senderMask, validMask = make([]uint64, (n+63)/64+1), make([]uint64, (n+63)/64+1)
 	var ct C.ibft_tally_t
 	rc := C.ibft_verify_messages(c.h, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0])), ptr8(msgSig65), ptr8(from20),
 		ptr8(hash32), ptr8(hashLen), ptr8(seal65), ptr8(senderPre), ptr8(validPre), C.size_t(n), ptr8(raw),
-		C.size_t(len(raw)), C.uint64_t(round), nil, (*C.uint64_t)(unsafe.Pointer(&senderMask[0])),
+		C.size_t(len(raw)), C.uint64_t(round), nil, ptr8(proposer20), (*C.uint64_t)(unsafe.Pointer(&senderMask[0])),
 		(*C.uint64_t)(unsafe.Pointer(&validMask[0])), &ct)
 	return senderMask, validMask, tally(ct), c.check(rc)
 }
@@ -204,15 +209,17 @@ const (
 
 // VerifyMessagesWire = raw messages judged completely (ibft_verify_messages_wire): the device walks the bytes and
 // verifies both signatures of every PREPARE / COMMIT of the view (height, round) in one launch.
-func (c *Ctx) VerifyMessagesWire(wire []byte, off []uint32, height, round uint64, raw []byte, proposalRound uint64) (
-	senderMask, validMask []uint64, class []byte, t Tally, err error) {
+// proposer20 != nil (a batch of PREPAREs of the view): the tally is HasPrepareQuorum.
+func (c *Ctx) VerifyMessagesWire(wire []byte, off []uint32, height, round uint64, raw []byte, proposalRound uint64,
+	proposer20 []byte) (senderMask, validMask []uint64, class []byte, t Tally, err error) {
 	n := len(off) - 1
 	senderMask, validMask = make([]uint64, (n+63)/64+1), make([]uint64, (n+63)/64+1)
 	class = make([]byte, n+1)
 	var ct C.ibft_tally_t
 	rc := C.ibft_verify_messages_wire(c.h, ptr8(wire), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(n), C.uint64_t(height),
 		C.uint64_t(round), ptr8(raw), C.size_t(len(raw)), C.uint64_t(proposalRound), nil,
-		(*C.uint64_t)(unsafe.Pointer(&senderMask[0])), (*C.uint64_t)(unsafe.Pointer(&validMask[0])), ptr8(class), nil, &ct)
+		(*C.uint64_t)(unsafe.Pointer(&senderMask[0])), (*C.uint64_t)(unsafe.Pointer(&validMask[0])), ptr8(class), nil,
+		ptr8(proposer20), &ct)
 	return senderMask, validMask, class[:n], tally(ct), c.check(rc)
 }
 
@@ -404,14 +411,14 @@ func (g *Group) VerifySenders(payload []byte, off []uint32, sig65, from20, preFl
 // VerifyMessages judges a whole PREPARE / COMMIT set sharded by message (Ctx.VerifyMessages' columns and
 // results; seal65 nil for a PREPARE set; digest32 nil to have raw ‖ BE64(round) hashed on the devices).
 func (g *Group) VerifyMessages(payload []byte, off []uint32, msgSig65, from20, hash32, hashLen, seal65,
-	senderPre, validPre, raw []byte, round uint64, digest32 []byte) (senders, valid []uint64, t Tally, err error) {
+	senderPre, validPre, raw []byte, round uint64, digest32, proposer20 []byte) (senders, valid []uint64, t Tally, err error) {
 	n := len(msgSig65) / 65
 	senders = make([]uint64, (n+63)/64+1)
 	valid = make([]uint64, (n+63)/64+1)
 	var ct C.ibft_tally_t
 	rc := C.ibft_group_verify_messages(g.g, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0])), ptr8(msgSig65),
 		ptr8(from20), ptr8(hash32), ptr8(hashLen), ptr8(seal65), ptr8(senderPre), ptr8(validPre), C.size_t(n),
-		ptr8(raw), C.size_t(len(raw)), C.uint64_t(round), ptr8(digest32),
+		ptr8(raw), C.size_t(len(raw)), C.uint64_t(round), ptr8(digest32), ptr8(proposer20),
 		(*C.uint64_t)(unsafe.Pointer(&senders[0])), (*C.uint64_t)(unsafe.Pointer(&valid[0])), &ct)
 	if rc != C.IBFT_OK {
 		return nil, nil, Tally{}, fmt.Errorf("%w: %s", ErrFallback, C.GoString(C.ibft_strerror(rc)))
@@ -439,7 +446,7 @@ func (g *Group) VerifyCertificatesWire(wire []byte, off []uint32, rowsCap int) (
 
 func tally(t C.ibft_tally_t) Tally {
 	return Tally{uint64(t.quorum_lo), uint64(t.quorum_hi), uint64(t.power_lo), uint64(t.power_hi),
-		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0, uint32(t.shard_overlap)}
+		uint32(t.valid_rows), uint32(t.distinct_senders), t.has_quorum != 0, uint32(t.shard_overlap), uint32(t.proposer_rows)}
 }
 
 // Bit reports row i's verdict.

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.ibft_version() == 1
+    assert lib.ibft_version() == 2
     assert lib.ibft_strerror(0) == b"ok"
     assert b"device" in lib.ibft_strerror(-2)
 
@@ -78,8 +78,10 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.ibft_sign_seals(null, b, b, 1, b, None, None),
         lambda: lib.ibft_column_stats(null, None),
         lambda: lib.ibft_forget_proposal(null),
-        lambda: lib.ibft_verify_messages_wire(null, b, off, 1, 0, 0, b, 1, 0, None, m, m, None, None, C.byref(t)),
-        lambda: lib.ibft_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, m, m, C.byref(t)),
+        lambda: lib.ibft_verify_messages_wire(null, b, off, 1, 0, 0, b, 1, 0, None, m, m, None, None, None, C.byref(t)),
+        lambda: lib.ibft_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, None, m, m, C.byref(t)),
+        lambda: lib.ibft_tally_prepare(null, b, m, 1, b, C.byref(t)),
+        lambda: lib.ibft_comm_info(null, None, None, None),
         lambda: lib.ibft_verify_certificates_wire(null, b, off, 1, 8, C.byref(C.c_size_t()), None, None, None, m, m, m),
         lambda: lib.ibft_seals_launch(null, 1),
         lambda: lib.ibft_seals_fetch(null, m, C.byref(t)),
@@ -89,12 +91,26 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.ibft_seals_fetch_merged(null, m, C.byref(t)),
         lambda: lib.ibft_group_verify_seals(null, b, b, b, None, 1, m, C.byref(t)),
         lambda: lib.ibft_group_verify_senders(null, b, off, b, b, None, 1, m, C.byref(t)),
-        lambda: lib.ibft_group_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, m, m, C.byref(t)),
+        lambda: lib.ibft_group_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, None, m, m, C.byref(t)),
         lambda: lib.ibft_group_set_validators(null, 1, b, b, 1),
         lambda: lib.ibft_group_is_local(null),
     ]
     for i, call in enumerate(calls):
         assert call() == -1, i
+
+
+def test_tally_struct_matches_the_header():
+    """ibft_tally_t: 56 bytes, field order as in include/ibftgpu.h (the ctypes struct and the Go struct mirror it)"""
+    import ctypes as C
+    import go_ibft_amd.verifier as V
+    hdr = open(os.path.join(ROOT, "include", "ibftgpu.h")).read()
+    body = hdr[hdr.index("typedef struct {\n  uint64_t quorum_lo, quorum_hi;"):hdr.index("} ibft_tally_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(quorum_lo|quorum_hi|power_lo|power_hi|valid_rows|distinct_senders|has_quorum|shard_overlap|proposer_rows|reserved)\b(?=[,;])", body)
+    assert names == [f[0] for f in V.Tally._fields_]
+    assert C.sizeof(V.Tally) == 56 and V.Tally.proposer_rows.offset == 48
+    go = open(os.path.join(ROOT, "shim", "go", "ibftgpu", "ibftgpu.go")).read()
+    assert "uint32(t.proposer_rows)" in go and "ProposerRows" in go
 
 
 def test_cert_node_struct_matches_the_header():

@@ -277,3 +277,106 @@ def test_group_senders_and_message_sets_on_one_device(oracle, gpu_verifier, worl
         assert (t.power, t.valid_rows, t.has_quorum) == (te.power, te.valid_rows, te.has_quorum)
     finally:
         g.close()
+
+
+# ---- BASELINE configs #4 and #5 at their stated sizes, on one device -------------------------------------------------
+# (round-3 review, "missing" #1: N = 16 384 × 4 and N = 65 536 × 8 with 20 % bad seals existed only in bench.py's
+# world == 8 leg, which no box had ever executed)
+
+_BIG = {}
+
+
+def _big_round(n, world, byzantine, envelopes):
+    key = (n, world, byzantine, envelopes)
+    if key not in _BIG:
+        _BIG.clear()                               # one large round alive at a time
+        if byzantine:
+            _BIG[key] = _dup_round(n, 7000 + n + world, world, envelopes=envelopes)
+        else:
+            from oracle import workload as W
+            _BIG[key] = W.make_round(n, 7000 + n + world, weighted=True, with_envelopes=envelopes)
+    return _BIG[key]
+
+
+@pytest.mark.parametrize("world,n,byzantine", [(4, 16384, False), (4, 16384, True), (8, 65536, True)])
+def test_baseline_config_4_and_5_seals_at_size(oracle, gpu_verifier, world, n, byzantine):
+    """config #4: 16 384 validators sharded 4 ways (honest, then the Byzantine mix); config #5: 65 536 validators, 8
+    shards of 8 192 rows, 20 % bad seals cycling over all twelve corruption kinds (core/byzantine_test.go:258-290
+    is the behaviour to hold), the rows before every seam repeated behind it.  Merged mask / power / distinct senders /
+    has_quorum ≡ ibft_verify_seals on the whole batch ≡ the CPU oracle; u64 powers, then 256-bit powers
+    (quorum over the address SET: core/validator_manager.go:77-96, 147-155)."""
+    import go_ibft_amd.verifier as V
+    from oracle.semantics import ValidatorManager
+    from oracle import workload as W
+    r = _big_round(n, world, byzantine, False)
+    if byzantine:
+        assert {k for k in r.kinds if k} == set(W.CORRUPTIONS)
+        assert 0.15 < sum(1 for k in r.kinds if k) / n < 0.25
+    vs = oracle.ValSet(r.addrs, r.power)
+    exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=16).astype(bool)
+    te = oracle.tally(vs, r.signer20, exp.astype(np.uint8))
+    assert exp.all() if not byzantine else (0.7 < exp.mean() < 0.9)
+    gpu_verifier.set_validators(1, r.addrs, r.power)
+    one, t1 = gpu_verifier.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+    assert (one == exp).all()
+    assert (t1.power, t1.valid_rows, t1.distinct_senders, t1.has_quorum, t1.quorum) == \
+           (te.power, te.valid_rows, te.distinct_senders, te.has_quorum, te.quorum)
+    g = V.DeviceGroup([0] * world, max_rows_total=n)
+    try:
+        assert g.size == world and g.is_local
+        g.set_validators(1, r.addrs, r.power)
+        for rep in range(2):
+            got, t = g.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+            assert (got == exp).all(), np.flatnonzero(got != exp)[:8]
+            assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum, t.quorum) == \
+                   (te.power, te.valid_rows, te.distinct_senders, te.has_quorum, te.quorum)
+        assert (t.shard_overlap > 0) == byzantine  # (_dup_round repeats valid rows across every seam)
+        # 256-bit powers: the merged power is re-summed from 32-bit pieces over the OR of the W bitmap segments
+        stakes = [(1 + int(p)) * 10**21 * (2**64 if i % 3 == 0 else 1) for i, p in enumerate(r.power)]
+        vm = ValidatorManager()
+        assert vm.init({bytes(r.addrs[i]): stakes[i] for i in range(n)})
+        g.set_validators_u256(1, r.addrs, stakes)
+        got, t = g.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+        assert (got == exp).all()
+        w = g.last_tally_wide()
+        members = {bytes(a) for a in r.addrs}
+        senders = {bytes(a) for a in r.signer20[exp]} & members
+        assert w.power == sum(vm.power[a] for a in senders) and w.quorum == vm.quorum
+        assert bool(t.has_quorum) == (w.power >= w.quorum) and t.distinct_senders == len(senders)
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("world,n", [(4, 16384), (8, 65536)])
+def test_baseline_config_4_and_5_message_sets_at_size(oracle, gpu_verifier, world, n):
+    """the same two shapes as COMMIT message sets (ibft_group_verify_messages: envelope signatures + committed seals of
+    every shard in one verdict launch per rank, K = 2 verdict arrays in the exchange), Byzantine seals plus forged
+    envelopes ≡ ibft_verify_messages on one device ≡ the oracle's three separate predicates"""
+    import go_ibft_amd.verifier as V
+    r = _big_round(n, world, True, True)
+    sig = r.msg_sig65.copy()
+    for j, i in enumerate(np.random.default_rng(n).choice(n, size=n // 13, replace=False)):
+        sig[i, j % 64] ^= 0x20
+    vs = oracle.ValSet(r.addrs, r.power)
+    senders = oracle.verify_senders(vs, r.payload, r.off, sig, r.signer20, nthreads=16).astype(bool)
+    hashes = oracle.verify_hashes(r.raw, r.round, r.hash32, r.hash_len).astype(bool)
+    seals = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=16).astype(bool)
+    te = oracle.tally(vs, r.signer20, (senders & hashes & seals).astype(np.uint8))
+    gpu_verifier.set_validators(r.height, r.addrs, r.power)
+    s1, v1, t1 = gpu_verifier.verify_messages(r.payload, r.off, sig, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                              valid_pre=r.pre_flags, raw=r.raw, round_=r.round)
+    assert (s1 == senders).all() and (v1 == (hashes & seals)).all()
+    g = V.DeviceGroup([0] * world, max_rows_total=n)
+    try:
+        g.set_validators(r.height, r.addrs, r.power)
+        for rep in range(2):
+            s, v, t = g.verify_messages(r.payload, r.off, sig, r.signer20, r.hash32, r.hash_len, r.seal65,
+                                        valid_pre=r.pre_flags, raw=r.raw, round_=r.round)
+            assert (s == senders).all(), np.flatnonzero(s != senders)[:16]
+            assert (v == (hashes & seals)).all(), np.flatnonzero(v != (hashes & seals))[:16]
+            assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == \
+                   (te.power, te.valid_rows, te.distinct_senders, te.has_quorum) == \
+                   (t1.power, t1.valid_rows, t1.distinct_senders, t1.has_quorum)
+    finally:
+        g.close()
+    _BIG.clear()

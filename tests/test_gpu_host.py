@@ -411,3 +411,58 @@ def test_certificates_judged_on_arrival_through_the_device(gpu_verifier, oracle,
     assert ing.pp_from_rows == (2 if rc_rows else 0)       # validateProposal's certificate rules: from the rows, or by the object walk
     assert ing.fallbacks() == 0
     ref.close(); ing.close()
+
+
+@pytest.mark.parametrize("rows", [False, True])
+@pytest.mark.parametrize("scenario", ["all", "short_by_one", "proposer_prepares", "weighted"])
+def test_quorum_decision_taken_from_the_device(gpu_verifier, oracle, rows, scenario):
+    """a8 through the mirror (ibft_host_use_device_quorum): handlePrepare asks ibft_tally_prepare — HasPrepareQuorum with
+    proposalMessage.From, core/validator_manager.go:99-127 — and handleCommit ibft_tally over the senders that survived the
+    walk; the decision equals the stock mirror's (hasQuorumByMsgType with the oracle-backed verifier), object mode and row
+    mode, and the mirror's own quorum index never disagrees."""
+    import go_ibft_amd.hostlib as H
+    from oracle import wire as W
+    n = 40
+    r, proposal, prepares, commits = _build_round(oracle, n, 5150, False)
+    power = r.power.copy()
+    if scenario == "weighted":
+        power[:] = 1
+        power[3] = 60                              # one heavy validator …
+    gpu_verifier.set_validators(r.height, r.addrs, power)
+    powers = {r.addrs[i].tobytes(): int(power[i]) for i in range(n)}
+    quorum = 2 * int(power.sum()) // 3 + 1
+    if scenario == "short_by_one":                # PREPAREs + the proposer's seat = quorum − 1; COMMITs = quorum − 1
+        prepares, commits = prepares[: quorum - 2], commits[: quorum - 1]
+    elif scenario == "proposer_prepares":         # a (correctly signed) PREPARE of the proposer among the others
+        p = W.IbftMessage(view=W.View(r.height, r.round), sender=r.addrs[0].tobytes(), type=W.PREPARE,
+                          payload=W.prepare_body(r.proposal_hash))
+        p.signature = oracle.sign(r.sks[0], oracle.keccak256(p.payload_no_sig()))
+        prepares = prepares + [p]
+    elif scenario == "weighted":                  # … who stays silent: 39 of 99 < 67
+        prepares = [m for m in prepares if m.sender != r.addrs[3].tobytes()]
+        commits = [m for m in commits if m.sender != r.addrs[3].tobytes()]
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    wires = [m.encode() for m in prepares + commits]
+    ref, dev = H.Host(), H.Host()
+    for h in (ref, dev):
+        assert h.vm_init(powers)
+        h.set_state(r.height, r.round, proposal.encode())
+        h.set_verifier(f1, f2, f3)
+    dev.attach_gpu(gpu_verifier)
+    dev.use_batch(True)
+    dev.use_rows(rows)
+    dev.enable_quorum_index()
+    dev.use_device_quorum(True)
+    for x in wires:
+        ref.add_message(x)
+    dev.ingest_wire(wires)
+    assert (dev.rows_kept > 0) == rows
+    okp, prepared = ref.handle_prepare(r.height, r.round)
+    okp2, prepared2 = dev.handle_prepare(r.height, r.round)
+    okc, seals = ref.handle_commit(r.height, r.round)
+    okc2, seals2 = dev.handle_commit(r.height, r.round)
+    assert (okp, sorted(prepared), okc, sorted(seals)) == (okp2, sorted(prepared2), okc2, sorted(seals2))
+    assert (okp, okc) == {"all": (True, True), "short_by_one": (False, False), "proposer_prepares": (False, True),
+                          "weighted": (False, False)}[scenario]
+    assert dev.device_quorum_stats() == (2, 0)
+    ref.close(); dev.close()
