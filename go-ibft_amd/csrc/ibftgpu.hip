@@ -2846,7 +2846,9 @@ int ibft_group_verify_certificates_wire(ibft_group *g, const uint8_t *wire_bytes
           nd.ordinal += (uint32_t)p.lo;  // its number among the call's messages
         else
           nd.parent = (uint32_t)global(nd.parent, level - 1);
-        nd.first_child = (uint32_t)global(nd.first_child, level + 1);
+        // a leaf's first_child is whatever the walk left there: only a node WITH children has a range to renumber (round-3
+        // advice: the subtraction underflowed for leaves and consumers that test the bounds first took the slow route)
+        nd.first_child = nd.n_children ? (uint32_t)global(nd.first_child, level + 1) : (uint32_t)at;
         out_nodes[at] = nd;
       }
       if (out_rows) out_rows[at] = p.wrows[j];

@@ -486,7 +486,7 @@ bool LoopBatch::VerifyCommitBatch(const Proposal *proposal, const std::vector<Ms
 int LoopBatch::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) {
   if (!quorum_vm || fail_quorum || !quorum_vm->initialized()) return -1;
   quorum_calls++;
-  std::unordered_set<std::string> set;
+  std::unordered_set<std::string_view, sv_hash> set;
   if (proposer) set.emplace(proposer->data(), proposer->size());
   bool voided = false;
   for (const bytes &s : senders) {
@@ -494,7 +494,7 @@ int LoopBatch::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *p
     set.emplace(s.data(), s.size());
   }
   unsigned __int128 sum = 0;
-  for (const std::string &a : set) sum += quorum_vm->powerOf(std::string_view(a));
+  for (std::string_view a : set) sum += quorum_vm->powerOf(a);
   const bool q = !voided && sum >= quorum_vm->quorum();
   return (q != wrong_quorum) ? 1 : 0;
 }
@@ -667,8 +667,8 @@ int HotPath::pcVerdictFromRows(const CertVerdicts &cv, size_t row, uint64_t limi
   if (!has_cert) return 2;
   if (match_proposal && !has_proposal) return -1;  // IsValidProposalHash(nil, hash): the backend's business
   const size_t lo = nd.first_child, n = nd.n_children;
+  if (n == 0) return 0;  // ProposalMessage == nil (and no PREPARE either) — before the bounds: a leaf's first_child means nothing
   if (lo + n > cv.n_rows) return -1;
-  if (n == 0) return 0;  // ProposalMessage == nil (and no PREPARE either)
   if (cv.nodes[lo].role != IBFT_CERT_ROLE_PC_PROPOSAL) return 0;  // ProposalMessage == nil
   if (n == 1) return 0;                                            // PrepareMessages == nil
   for (size_t c = lo; c < lo + n; c++) {
@@ -752,7 +752,7 @@ bool HotPath::proposalVerdictFromRows(const CertVerdicts &cv, size_t row, Propos
   out.rows = 0;
   if (!(nd.flags & IBFT_CERT_HAS_CERTIFICATE)) return true;  // rcc == nil: not ok (for a round above 0)
   const size_t lo = nd.first_child, n = nd.n_children;
-  if (lo + n > cv.n_rows) return false;
+  if (n && lo + n > cv.n_rows) return false;
   for (size_t c = lo; c < lo + n; c++) {
     const ibft_wire_row_t &w = cv.rows[c];
     if (cv.cls[c] != 0 || w.status != IBFT_WIRE_OK || !w.has_view || w.from_len > 20 || cv.nodes[c].role != IBFT_CERT_ROLE_RCC_MESSAGE)
@@ -899,7 +899,9 @@ inline uint64_t mix64(uint64_t a, uint64_t b) {
   const unsigned __int128 r = (unsigned __int128)a * b;
   return (uint64_t)r ^ (uint64_t)(r >> 64);
 }
-// keyed 128-bit fingerprint of a message's bytes (the key is per mirror: collisions cannot be prepared offline)
+// seeded 128-bit fingerprint of a message's bytes: a fast filter in front of a byte compare (stored messages) or a Keccak
+// compare (rejected ones).  NOT collision resistant whatever the seed — mix64(x, 0) == 0, so a block that equals one of
+// the multiplier constants zeroes a lane — and never the only evidence for a decision.
 inline void fingerprint(const uint8_t *p, size_t n, uint64_t seed, uint64_t &f1, uint64_t &f2) {
   uint64_t a = seed ^ 0x9E3779B97F4A7C15ull, b = (seed * 0xD6E8FEB86659FD93ull) ^ (uint64_t)n;
   if (n >= 256) {  // a long message (certificates inside): eight independent chains over 64-byte strides — the multiplies of
@@ -1087,11 +1089,17 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       }
       if (!seen_rejected_.empty()) {
         auto rej = seen_rejected_.find(fp1[i]);
-        if (rej != seen_rejected_.end() && rej->second == fp2[i]) {
-          verdict[i] = 0;  // rejected before (the reference would judge it again — and reject it again)
-          st.cache_hits++;
-          results[i] = 0;
-          continue;
+        if (rej != seen_rejected_.end() && rej->second.fp2 == fp2[i]) {
+          uint8_t dg[32];
+          (void)ibft_keccak256(row, len, nullptr, 0, dg);
+          if (memcmp(dg, rej->second.digest, 32) == 0) {
+            verdict[i] = 0;  // THESE bytes were rejected before (the reference would judge them again — and reject them again)
+            st.cache_hits++;
+            results[i] = 0;
+            continue;
+          }
+          // another message under the same fingerprint (an honest message somebody prepared a colliding forgery for):
+          // judged like any other
         }
       }
     }
@@ -1478,7 +1486,11 @@ bool HotPath::IngestFlat(const uint8_t *wire_in, const uint32_t *off, size_t n, 
       rejected_fifo_[rejected_head_] = fp1[i];
       rejected_head_ = (rejected_head_ + 1) % rejected_cap;
     }
-    if (rejected_cap) seen_rejected_[fp1[i]] = fp2[i];
+    if (rejected_cap) {
+      Rejected &rj = seen_rejected_[fp1[i]];
+      rj.fp2 = fp2[i];
+      (void)ibft_keccak256(wire + off[i], off[i + 1] - off[i], nullptr, 0, rj.digest);
+    }
   };
   // IBFT.AddMessage per message, in arrival order, with the verdict attached; what was stored is remembered for its
   // re-deliveries, what was rejected by its fingerprint
@@ -1636,7 +1648,7 @@ void HotPath::addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows
   int proposer_prepared = -1;  // not looked at yet
   const size_t taken = messages.AddLeanRun(
       type, height, round, rows.data(), rows.size(), backing, closure_epoch_, valset_epoch_,
-      [&](size_t k, bool fresh, const LeanView &lv) {
+      [&](size_t k, bool fresh, const LeanView &lv, const SenderMap *objs) {
         if (fresh) {
           const std::string_view from = rows[k]->from();
           const uint64_t w = rows[k]->sender_hash ? validatorManager.powerOf(from, rows[k]->sender_hash) : validatorManager.powerOf(from);
@@ -1649,7 +1661,10 @@ void HotPath::addLeanRun(uint32_t type, const std::vector<const LeanRow *> &rows
         if (type == COMMIT) {
           q = vm_ok && power >= quorum;
         } else if (proposalMessage && vm_ok && power + w_proposer >= quorum) {
-          if (proposer_prepared < 0) proposer_prepared = lv.contains(proposer) ? 1 : 0;
+          // messages.Has: the proposer's PREPARE may be held as a row or as an object (round-3 advice: rows only gave a
+          // spurious quorum signal, which handlePrepare then took back)
+          if (proposer_prepared < 0)
+            proposer_prepared = (lv.contains(proposer) || (objs && objs->contains(bytes::view(proposer.data(), proposer.size())))) ? 1 : 0;
           q = proposer_prepared == 0;
         }
         results[at[k]] = q ? 2 : 1;

@@ -339,9 +339,12 @@ class HotPath {
   }
   // the handle* walks: arrival-time verdicts first, one batch call for the rest, per-message closure when that fails
   std::vector<uint8_t> closureVerdicts(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &all);
-  // Messages seen before, by a keyed 128-bit fingerprint of their wire bytes: a byte-identical re-delivery (gossip) of a
-  // STORED message is answered with the stored object (compared byte for byte on a hit) — no decode, no device work; a
-  // re-delivery of a rejected one by its fingerprint alone, from a bounded FIFO.
+  // Messages seen before, found by a seeded 128-bit fingerprint of their wire bytes.  The fingerprint is a FILTER, not an
+  // identity — multiply-fold mixing has seed-independent collisions (a 16-byte block that zeroes a multiplicand, round-3
+  // advice), so nothing is decided on it alone: a byte-identical re-delivery (gossip) of a STORED message is answered
+  // with the stored object after a byte-for-byte compare; a re-delivery of a REJECTED one is recognised by the Keccak-256 of
+  // its bytes (computed when it was rejected, and again only for a message whose fingerprint hits), from a bounded FIFO.  A
+  // message that merely collides with a rejected forgery is judged like any other.
   struct Seen {
     uint64_t fp2;
     MsgPtr msg;           // the stored message (keeps its bytes: wire / len point into its backing)
@@ -358,7 +361,11 @@ class HotPath {
   bool handleLean(const View &view, MessageType type, bool &quorum);  // true = the view was held as rows and is handled
   std::unordered_map<uint64_t, Seen> seen_;
   bool seen_has_votes_ = false;  // seen_ holds (or held, since it was last empty) PREPARE / COMMIT objects
-  std::unordered_map<uint64_t, uint64_t> seen_rejected_;  // fp1 → fp2
+  struct Rejected {
+    uint64_t fp2;
+    uint8_t digest[32];  // keccak256 of the rejected bytes
+  };
+  std::unordered_map<uint64_t, Rejected> seen_rejected_;  // fp1 → the rejected message's identity
   std::vector<uint64_t> rejected_fifo_;
   size_t rejected_head_ = 0;
   uint64_t fp_seed_;

@@ -191,34 +191,60 @@ class bytes {
   char inl_[kInline];
 };
 
-// hash of a short key (an address): 8 bytes at a time, multiply-fold, keyed per process — the keys are attacker-chosen
-// bytes (the From of any message, of any message nested in a certificate), and an unkeyed hash would let colliding keys be
-// prepared offline to turn every open-addressing table here into a linear list
-inline uint64_t hash_seed() noexcept {
-  static const uint64_t seed = [] {
+// Hash of a short key (an address): SipHash-1-3 under a 128-bit per-process key.  The keys are attacker-chosen bytes (the
+// From of any message, of any message nested in a certificate) and they index every open-addressing table here (SenderMap,
+// LeanView, the validator seats, the certificate walks' sender sets): a multiply / xor-shift hash has differentials that do
+// not depend on its seed (round-3 advice: keys (w1, w2) and (w1 ^ 2^63, w2 ^ (2^63 | 2^31)) collided under every seed),
+// so colliding keys could be prepared offline whatever the seed and the tables pushed towards linear probing.  SipHash is a
+// PRF: without the key no collision can be prepared.  A 20-byte address costs three compression rounds + three final ones.
+struct SipKey {
+  uint64_t k0, k1;
+};
+inline const SipKey &hash_seed() noexcept {
+  static const SipKey key = [] {
     std::random_device rd;
-    return ((uint64_t)rd() << 32 | rd()) | 1;
+    return SipKey{(uint64_t)rd() << 32 | rd(), (uint64_t)rd() << 32 | rd()};
   }();
-  return seed;
+  return key;
 }
-inline uint64_t hash_key(const char *p, size_t n) noexcept {
-  uint64_t h = ((uint64_t)n * 0x9E3779B97F4A7C15ull) ^ hash_seed();
+inline uint64_t siphash13(const char *p, size_t n, const SipKey &key) noexcept {
+  uint64_t v0 = key.k0 ^ 0x736f6d6570736575ull, v1 = key.k1 ^ 0x646f72616e646f6dull, v2 = key.k0 ^ 0x6c7967656e657261ull,
+           v3 = key.k1 ^ 0x7465646279746573ull;
+  auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+  auto round = [&]() {
+    v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+    v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+  };
+  uint64_t b = (uint64_t)n << 56;
   while (n >= 8) {
     uint64_t w;
     memcpy(&w, p, 8);
-    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
-    h ^= h >> 32;
+    v3 ^= w;
+    round();
+    v0 ^= w;
     p += 8;
     n -= 8;
   }
   if (n) {
     uint64_t w = 0;
     memcpy(&w, p, n);
-    h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
-    h ^= h >> 29;
+    b |= w;
   }
-  return h;
+  v3 ^= b;
+  round();
+  v0 ^= b;
+  v2 ^= 0xff;
+  round();
+  round();
+  round();
+  return v0 ^ v1 ^ v2 ^ v3;
 }
+inline uint64_t hash_key(const char *p, size_t n) noexcept { return siphash13(p, n, hash_seed()); }
+struct sv_hash {  // the same keyed hash for std:: containers of address views
+  size_t operator()(std::string_view s) const noexcept { return (size_t)hash_key(s.data(), s.size()); }
+};
 struct bytes_hash {
   size_t operator()(const bytes &b) const noexcept { return (size_t)hash_key(b.data(), b.size()); }
 };

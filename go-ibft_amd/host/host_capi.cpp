@@ -126,12 +126,25 @@ class IngestQueue {
       stop_ = true;
     }
     cv_.notify_all();
+    space_cv_.notify_all();
     th_.join();
   }
-  void push(const uint8_t *wire, const uint32_t *off, size_t n) {
-    if (!n) return;
+  // Bounded: the pending bytes are offsets of 32 bits and memory of the process.  A pusher that would take the queue past
+  // its caps WAITS for the worker to take what is pending (the reference's AddMessage is synchronous: a transport thread that
+  // delivers faster than messages are verified is slowed down, not buffered without end — round-3 advice); a single push
+  // that could never fit is refused (−2), nothing of it queued.
+  int push(const uint8_t *wire, const uint32_t *off, size_t n) {
+    if (!n) return 0;
+    const size_t bytes = (size_t)off[n] - off[0];
+    if (bytes > cap_bytes_ || n > cap_rows_) return -2;
     {
-      std::lock_guard<std::mutex> lk(mu_);
+      std::unique_lock<std::mutex> lk(mu_);
+      if (wire_.size() + bytes > cap_bytes_ || off_.size() - 1 + n > cap_rows_) {
+        backpressure_waits_++;
+        cv_.notify_all();
+        space_cv_.wait(lk, [&] { return stop_ || (wire_.size() + bytes <= cap_bytes_ && off_.size() - 1 + n <= cap_rows_); });
+        if (stop_) return -1;
+      }
       const uint32_t base = (uint32_t)wire_.size();
       wire_.insert(wire_.end(), wire + off[0], wire + off[n]);
       for (size_t i = 1; i <= n; i++) off_.push_back(base + (off[i] - off[0]));
@@ -139,6 +152,17 @@ class IngestQueue {
       last_push_ = std::chrono::steady_clock::now();
     }
     cv_.notify_all();
+    return 0;
+  }
+  void set_caps(size_t cap_bytes, size_t cap_rows) {
+    std::lock_guard<std::mutex> lk(mu_);
+    cap_bytes_ = std::min<size_t>(cap_bytes ? cap_bytes : kDefaultCapBytes, kMaxCapBytes);
+    cap_rows_ = cap_rows ? cap_rows : kDefaultCapRows;
+    space_cv_.notify_all();
+  }
+  uint64_t backpressure_waits() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return backpressure_waits_;
   }
   void drain(ibft_host_queue_stats *out) {
     std::unique_lock<std::mutex> lk(mu_);
@@ -161,7 +185,10 @@ class IngestQueue {
   size_t max_rows_;
   uint32_t linger_us_;
   std::mutex mu_;
-  std::condition_variable cv_, done_cv_;
+  std::condition_variable cv_, done_cv_, space_cv_;
+  static constexpr size_t kDefaultCapBytes = (size_t)256 << 20, kMaxCapBytes = 0xFFFF0000u, kDefaultCapRows = (size_t)1 << 20;
+  size_t cap_bytes_ = kDefaultCapBytes, cap_rows_ = kDefaultCapRows;  // pending, not yet taken by the worker
+  uint64_t backpressure_waits_ = 0;
   std::vector<uint8_t> wire_;
   std::vector<uint32_t> off_{0};
   uint64_t pushed_ = 0;
@@ -210,6 +237,7 @@ void IngestQueue::loop() {
       off_.assign(1, 0);
       buf->swap(wire_);
       wire_.reserve(buf->size());  // (the next burst is about as large: no regrowth from nothing under the pushers' feet)
+      space_cv_.notify_all();      // pushers that waited for room
     }
     const std::vector<uint8_t> &wire = *buf;
     const std::shared_ptr<const void> shared(buf, buf->data());
@@ -594,9 +622,12 @@ int ibft_host_queue_push(ibft_host *h, const uint8_t *wire, const uint32_t *off,
   if (!h->queue || (n && (!wire || !off))) return -1;  // (no mirror lock: pushing never waits for an ingest in progress)
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return -1;
-  h->queue->push(wire, off, n);
-  return 0;
+  return h->queue->push(wire, off, n);
 }
+void ibft_host_queue_set_caps(ibft_host *h, size_t max_pending_bytes, size_t max_pending_rows) {
+  if (h->queue) h->queue->set_caps(max_pending_bytes, max_pending_rows);
+}
+uint64_t ibft_host_queue_backpressure_waits(ibft_host *h) { return h->queue ? h->queue->backpressure_waits() : 0; }
 int ibft_host_queue_drain(ibft_host *h, ibft_host_queue_stats *out) {
   if (!h->queue) return -1;
   h->queue->drain(out);
@@ -641,6 +672,10 @@ void ibft_host_device_quorum_stats(ibft_host *h, size_t *calls, size_t *mismatch
   if (mismatches) *mismatches = h->hp.device_quorum_mismatches;
 }
 void ibft_host_use_rows(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_lean = on != 0; }
+void ibft_host_lean_stats(ibft_host *h, uint64_t height, uint64_t round, uint32_t type, size_t *live, size_t *slots, size_t *buffers) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  h->hp.messages.LeanStats(View{height, round, {}}, (MessageType)type, live, slots, buffers);
+}
 size_t ibft_host_rows_kept(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.lean_rows; }
 void ibft_host_use_certs(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_certs = on != 0; }
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits) {

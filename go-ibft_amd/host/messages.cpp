@@ -218,7 +218,7 @@ SenderMap *Messages::objects_of(int s, uint64_t height, uint64_t round) {
 
 size_t Messages::AddLeanRun(uint32_t type, uint64_t height, uint64_t round, const LeanRow *const *rows, size_t n,
                             const std::shared_ptr<const void> &backing, uint32_t closure_epoch, uint32_t valset_epoch,
-                            const std::function<void(size_t, bool, const LeanView &)> &after) {
+                            const std::function<void(size_t, bool, const LeanView &, const SenderMap *)> &after) {
   int s = slot(type);
   if (s != PREPARE && s != COMMIT) return 0;
   std::unique_lock lk(mux_[s]);
@@ -241,7 +241,7 @@ size_t Messages::AddLeanRun(uint32_t type, uint64_t height, uint64_t round, cons
       had_object = objs->erase(bytes::view(f.data(), f.size()));
     }
     const bool fresh = lv.put(*rows[k], backing) && !had_object;
-    after(k, fresh, lv);
+    after(k, fresh, lv, objs);  // (objs: the view's OBJECTS — a sender may be held as either)
   }
   return n;
 }
@@ -292,6 +292,23 @@ void Messages::MaterializeAll() {
       materialize_locked(s, key.first, key.second);
     }
   }
+}
+
+void Messages::LeanStats(const View &view, MessageType type, size_t *live, size_t *slots, size_t *buffers) {
+  size_t a = 0, b = 0, c = 0;
+  int s = slot(type);
+  if (s >= 0) {
+    std::shared_lock lk(mux_[s]);
+    auto lv = lean_[s].find({view.height, view.round});
+    if (lv != lean_[s].end()) {
+      a = lv->second.size();
+      b = lv->second.slots();
+      c = lv->second.buffers_held();
+    }
+  }
+  if (live) *live = a;
+  if (slots) *slots = b;
+  if (buffers) *buffers = c;
 }
 
 std::vector<bytes> Messages::SendersOf(const View &view, MessageType type) {
@@ -349,7 +366,7 @@ bool ValidatorManager::HasQuorum(const std::set<bytes> &senders) const {
 // senders, each counted once — a flat hash set of views instead of one tree node per sender.
 bool ValidatorManager::HasQuorumOf(const std::vector<MsgPtr> &msgs, const bytes *extra) const {
   if (!initialized_) return false;
-  std::unordered_set<std::string_view> seen;
+  std::unordered_set<std::string_view, sv_hash> seen;  // (keyed: the senders are the network's choice)
   seen.reserve(msgs.size() * 2 + 2);
   unsigned __int128 sum = 0;
   if (extra && seen.insert(std::string_view(extra->data(), extra->size())).second) sum += powerOf(*extra);

@@ -129,14 +129,22 @@ struct LeanRow {
 class LeanView {
  public:
   uint32_t closure_epoch = 0, valset_epoch = 0;  // what the rows' verdicts were computed against
+  // buffers[b] keeps the bytes of the rows with buf == b alive; it is let go (null) as soon as no LIVE row points into it —
+  // a batch buffer also holds other senders' rejected bytes, and a sender that keeps replacing its message (canonical /
+  // re-encoded variants, round-3 advice) must not pin one whole batch per replacement until the height is pruned
   std::vector<std::shared_ptr<const void>> buffers;
   size_t size() const { return live_; }
+  size_t slots() const { return rows_.size(); }           // rows held, dead ones included (bounded: ≤ 2·live + 32)
+  size_t buffers_held() const {
+    size_t k = 0;
+    for (const auto &b : buffers) k += b != nullptr;
+    return k;
+  }
   bool contains(std::string_view from) const { return locate(from) != npos; }
   bool erase(std::string_view from) {
     const size_t at = locate(from);
     if (at == npos) return false;
-    rows_[at].dead = 1;
-    live_--;
+    row_died(at);
     return true;
   }
   const LeanRow *find(std::string_view from) const { return find(from, hash_key(from.data(), from.size())); }
@@ -144,17 +152,21 @@ class LeanView {
     const size_t at = locate(from, hash);
     return at == npos ? nullptr : &rows_[at];
   }
-  // insert, or replace the row of the same sender; true = a new sender
+  // insert, or replace the row of the same sender; true = a new sender.  (Pointers into the view — find() — do not survive
+  // a put: rows may move.)
   bool put(LeanRow row, const std::shared_ptr<const void> &backing) {
-    if (buffers.empty() || buffers.back() != backing) buffers.push_back(backing);
-    row.buf = (uint32_t)buffers.size() - 1;
     const std::string_view from = row.from();
     if (row.sender_hash == 0) row.sender_hash = hash_key(from.data(), from.size());
     const uint64_t h = row.sender_hash;
     row.dead = 0;
+    if ((dead_ > live_ && dead_ >= 32) || null_bufs_ >= 64) compact();  // (before any index is taken: compaction renumbers)
     const size_t at = locate(from, h);
+    row.buf = buffer_index(backing);
+    buf_live_[row.buf]++;
     if (at != npos) {
+      const uint32_t old = rows_[at].buf;
       rows_[at] = row;
+      unref(old);
       return false;
     }
     if ((rows_.size() + 1) * 2 > index_.size()) rebuild(std::max<size_t>(64, (rows_.size() + 1) * 4));
@@ -166,31 +178,29 @@ class LeanView {
   // The rows that point into `backing` get a buffer of their own (their bytes, back to back) and `backing` is let go: for a
   // batch of which little was stored — the rest of its buffer is other people's rejected bytes.  Returns the bytes copied.
   size_t repack(const std::shared_ptr<const void> &backing) {
-    size_t idx = buffers.size();
-    for (size_t b = 0; b < buffers.size(); b++)
-      if (buffers[b] == backing) idx = b;
-    if (idx == buffers.size()) return 0;
     size_t total = 0;
-    for (const LeanRow &r : rows_)
-      if (r.buf == idx) total += r.len;  // (pruned rows too: their slots may still be compared against)
-    uint8_t *mem = static_cast<uint8_t *>(malloc(total ? total : 1));
-    size_t at = 0;
-    for (LeanRow &r : rows_)
-      if (r.buf == idx) {
-        memcpy(mem + at, r.wire, r.len);
-        r.wire = mem + at;
-        at += r.len;
-      }
-    buffers[idx] = std::shared_ptr<const void>(mem, free);
+    for (size_t idx = 0; idx < buffers.size(); idx++) {
+      if (!buffers[idx] || buffers[idx] != backing) continue;
+      size_t bytes = 0;
+      for (const LeanRow &r : rows_)
+        if (!r.dead && r.buf == idx) bytes += r.len;
+      uint8_t *mem = static_cast<uint8_t *>(malloc(bytes ? bytes : 1));
+      size_t at = 0;
+      for (LeanRow &r : rows_)
+        if (!r.dead && r.buf == idx) {
+          memcpy(mem + at, r.wire, r.len);
+          r.wire = mem + at;
+          at += r.len;
+        }
+      buffers[idx] = std::shared_ptr<const void>(mem, free);
+      total += bytes;
+    }
     return total;
   }
   template <class F>
   void filter(F &&f) {  // f(const LeanRow &) → false erases the row
     for (size_t i = 0; i < rows_.size(); i++)
-      if (!rows_[i].dead && !f(rows_[i])) {
-        rows_[i].dead = 1;
-        live_--;
-      }
+      if (!rows_[i].dead && !f(rows_[i])) row_died(i);
   }
   template <class F>
   void for_each(F &&f) const {
@@ -202,7 +212,8 @@ class LeanView {
   static constexpr size_t npos = (size_t)-1;
   size_t locate(std::string_view from) const { return locate(from, hash_key(from.data(), from.size())); }
   // index entry: the key's hash (upper half) next to the row number + 1 (lower half) — a probe that lands on another
-  // sender's slot is told apart without touching that sender's bytes
+  // sender's slot is told apart without touching that sender's bytes.  A dead row's bytes are never read (its buffer may
+  // be gone).
   size_t locate(std::string_view from, uint64_t h) const {
     if (index_.empty()) return npos;
     const size_t mask = index_.size() - 1;
@@ -228,9 +239,59 @@ class LeanView {
     for (size_t i = 0; i < rows_.size(); i++)
       if (!rows_[i].dead) link(i, rows_[i].sender_hash);
   }
+  // a batch arrives as runs of rows over ONE backing: the last buffer first, then the few others (a re-delivery from an
+  // older batch must find its buffer again instead of pinning it a second time)
+  uint32_t buffer_index(const std::shared_ptr<const void> &backing) {
+    for (size_t b = buffers.size(); b-- > 0;)
+      if (buffers[b] == backing) return (uint32_t)b;
+    buffers.push_back(backing);
+    buf_live_.push_back(0);
+    return (uint32_t)buffers.size() - 1;
+  }
+  void unref(uint32_t b) {
+    if (--buf_live_[b] == 0) {
+      buffers[b].reset();
+      null_bufs_++;
+    }
+  }
+  void row_died(size_t at) {
+    rows_[at].dead = 1;
+    rows_[at].wire = nullptr;
+    live_--;
+    dead_++;
+    unref(rows_[at].buf);
+  }
+  // dead rows outnumber the live ones: drop them and the buffers nobody points into, renumber, re-index
+  void compact() {
+    std::vector<uint32_t> remap(buffers.size(), 0);
+    size_t nb = 0;
+    for (size_t b = 0; b < buffers.size(); b++)
+      if (buffers[b]) {
+        remap[b] = (uint32_t)nb;
+        if (nb != b) {
+          buffers[nb] = std::move(buffers[b]);
+          buf_live_[nb] = buf_live_[b];
+        }
+        nb++;
+      }
+    buffers.resize(nb);
+    buf_live_.resize(nb);
+    size_t k = 0;
+    for (size_t i = 0; i < rows_.size(); i++)
+      if (!rows_[i].dead) {
+        rows_[i].buf = remap[rows_[i].buf];
+        if (k != i) rows_[k] = rows_[i];
+        k++;
+      }
+    rows_.resize(k);
+    dead_ = 0;
+    null_bufs_ = 0;
+    rebuild(std::max<size_t>(64, (k + 1) * 4));
+  }
   std::vector<LeanRow> rows_;
   std::vector<uint64_t> index_;
-  size_t live_ = 0;
+  std::vector<uint32_t> buf_live_;  // live rows per buffer
+  size_t live_ = 0, dead_ = 0, null_bufs_ = 0;
 };
 
 class Messages {
@@ -278,7 +339,7 @@ class Messages {
   // (they become objects; the caller stores these messages one by one).
   size_t AddLeanRun(uint32_t type, uint64_t height, uint64_t round, const LeanRow *const *rows, size_t n,
                     const std::shared_ptr<const void> &backing, uint32_t closure_epoch, uint32_t valset_epoch,
-                    const std::function<void(size_t, bool, const LeanView &)> &after);
+                    const std::function<void(size_t, bool, const LeanView &, const SenderMap *)> &after);
   // the view's rows when it is held as rows AND they were judged against these epochs; otherwise the rows (if any) are
   // materialised and nullptr is returned.  The pointer is valid until the next call that touches the view.
   LeanView *LeanFor(const View &view, MessageType type, uint32_t closure_epoch, uint32_t valset_epoch);
@@ -288,6 +349,8 @@ class Messages {
   size_t RepackLean(const View &view, MessageType type, const std::shared_ptr<const void> &backing);
   void MaterializeAll();  // every view held as rows becomes objects (validator set changed: the rows' verdicts are void)
   std::vector<bytes> SendersOf(const View &view, MessageType type);  // distinct senders of a view, rows or objects
+  // what a view's rows hold: live rows, row slots (dead ones included), batch buffers still referenced
+  void LeanStats(const View &view, MessageType type, size_t *live, size_t *slots, size_t *buffers);
 
  private:
   using protoMessages = SenderMap;                           // sender -> message

@@ -729,7 +729,7 @@ bool extract_committed_seals(const std::vector<MsgPtr> &msgs, std::vector<std::o
 
 bool has_unique_senders(const std::vector<MsgPtr> &msgs) {
   if (msgs.empty()) return false;
-  std::unordered_set<std::string_view> seen;
+  std::unordered_set<std::string_view, sv_hash> seen;
   seen.reserve(msgs.size() * 2);
   for (const auto &m : msgs)
     if (!seen.insert(std::string_view(m->from.data(), m->from.size())).second) return false;
@@ -746,7 +746,7 @@ bool are_valid_pc_messages(const std::vector<MsgPtr> &msgs, uint64_t height, uin
   // messages[0].View.Round: a nil View would panic in the reference; treat as invalid
   if (!msgs[0]->view) return false;
   const uint64_t round = msgs[0]->view->round;
-  std::unordered_set<std::string_view> senders;
+  std::unordered_set<std::string_view, sv_hash> senders;
   senders.reserve(msgs.size() * 2);
   const bytes *hash = nullptr;
   for (const auto &m : msgs) {

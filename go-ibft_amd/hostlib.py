@@ -121,6 +121,8 @@ def lib() -> C.CDLL:
         L.ibft_host_queue_start.argtypes = [vp, C.c_size_t, C.c_uint32]
         L.ibft_host_queue_push.argtypes = [vp, vp, vp, C.c_size_t]
         L.ibft_host_queue_drain.argtypes = [vp, C.POINTER(QueueStats)]
+        L.ibft_host_queue_set_caps.argtypes = [vp, C.c_size_t, C.c_size_t]; L.ibft_host_queue_set_caps.restype = None
+        L.ibft_host_queue_backpressure_waits.argtypes = [vp]; L.ibft_host_queue_backpressure_waits.restype = C.c_uint64
         L.ibft_host_queue_stop.argtypes = [vp]; L.ibft_host_queue_stop.restype = None
         L.ibft_host_queue_on_signal.argtypes = [vp, SIGNAL_FN, vp]; L.ibft_host_queue_on_signal.restype = None
         L.ibft_host_seen_entries.argtypes = [vp]; L.ibft_host_seen_entries.restype = C.c_size_t
@@ -147,6 +149,8 @@ def lib() -> C.CDLL:
         L.ibft_host_repacked_bytes.argtypes = [vp]; L.ibft_host_repacked_bytes.restype = C.c_size_t
         L.ibft_host_set_repack_min_bytes.argtypes = [vp, C.c_size_t]; L.ibft_host_set_repack_min_bytes.restype = None
         L.ibft_host_rows_kept.argtypes = [vp]; L.ibft_host_rows_kept.restype = C.c_size_t
+        L.ibft_host_lean_stats.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32] + [C.POINTER(C.c_size_t)] * 3
+        L.ibft_host_lean_stats.restype = None
         L.ibft_host_cert_stats.argtypes = [vp] + [C.POINTER(C.c_size_t)] * 3; L.ibft_host_cert_stats.restype = None
         L.ibft_host_handle_preprepare.argtypes = [vp, C.c_uint64, C.c_uint64, bp]
         _lib = L
@@ -451,6 +455,17 @@ class Host:
         if self.L.ibft_host_queue_push(self.h, wire.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(off) - 1) != 0:
             raise RuntimeError("ibft_host_queue_push")
 
+    def queue_set_caps(self, max_pending_bytes: int = 0, max_pending_rows: int = 0):
+        self.L.ibft_host_queue_set_caps(self.h, max_pending_bytes, max_pending_rows)
+
+    def queue_try_push(self, wire, off) -> int:
+        """ibft_host_queue_push's own return code (0 queued, −2 larger than the queue's caps)"""
+        return self.L.ibft_host_queue_push(self.h, wire.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(off) - 1)
+
+    @property
+    def queue_backpressure_waits(self) -> int:
+        return int(self.L.ibft_host_queue_backpressure_waits(self.h))
+
     def queue_drain(self) -> QueueStats:
         st = QueueStats()
         if self.L.ibft_host_queue_drain(self.h, C.byref(st)) != 0:
@@ -532,6 +547,12 @@ class Host:
     def use_rows(self, on: bool):
         """Keep the PREPARE / COMMIT messages a batch backend judged from their bytes as rows (default) or as objects."""
         self.L.ibft_host_use_rows(self.h, 1 if on else 0)
+
+    def lean_stats(self, height, round_, type_):
+        """(live rows, row slots, batch buffers still referenced) of one view's rows"""
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self.L.ibft_host_lean_stats(self.h, height, round_, type_, C.byref(a), C.byref(b), C.byref(c))
+        return int(a.value), int(b.value), int(c.value)
 
     @property
     def rows_kept(self) -> int:

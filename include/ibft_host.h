@@ -149,6 +149,12 @@ typedef void (*ibft_host_signal_fn)(void *user, uint32_t type, uint64_t height, 
 int ibft_host_queue_start(ibft_host *h, size_t max_rows, uint32_t linger_us);
 void ibft_host_queue_on_signal(ibft_host *h, ibft_host_signal_fn fn, void *user);
 int ibft_host_queue_push(ibft_host *h, const uint8_t *wire, const uint32_t *off, size_t n);
+/* The queue is BOUNDED (defaults: 256 MiB / 1 Mi messages pending, i.e. pushed and not yet taken by the worker; the byte cap
+ * never exceeds 4 GiB − 64 KiB: pending offsets are 32 bits wide): a push that would take it past a cap waits until the
+ * worker has taken what is pending — the back-pressure the reference's synchronous AddMessage applies to a transport thread
+ * (core/ibft.go:1101-1123) — and a single push larger than a cap returns −2 with nothing queued.  0 = default.          */
+void ibft_host_queue_set_caps(ibft_host *h, size_t max_pending_bytes, size_t max_pending_rows);
+uint64_t ibft_host_queue_backpressure_waits(ibft_host *h);
 int ibft_host_queue_drain(ibft_host *h, ibft_host_queue_stats *out);
 void ibft_host_queue_stop(ibft_host *h);
 /* Receive-side memory (bounded): messages remembered for byte-identical re-deliveries — only messages that AddMessage
@@ -238,6 +244,11 @@ void ibft_host_use_device_quorum(ibft_host *h, int on);
 void ibft_host_device_quorum_stats(ibft_host *h, size_t *calls, size_t *mismatches);
 void ibft_host_use_rows(ibft_host *h, int on);
 size_t ibft_host_rows_kept(ibft_host *h);
+/* What the rows of one view hold: live rows, row slots (replaced / pruned ones included until the next compaction:
+ * ≤ 2·live + 32) and batch buffers still referenced — a buffer is let go when its last live row is replaced or pruned,
+ * so a sender that keeps replacing its message pins one batch, not one per replacement.                                */
+void ibft_host_lean_stats(ibft_host *h, uint64_t height, uint64_t round, uint32_t type, size_t *live, size_t *slots,
+                          size_t *buffers);
 void ibft_host_cert_stats(ibft_host *h, size_t *calls, size_t *rows, size_t *hits);
 size_t ibft_host_loop_batch_cert_calls(ibft_host *h);
 /* handlePrePrepare (core/ibft.go:792-813): 1 = a stored PREPREPARE of (height, round) passes validateProposal0 (round 0) /

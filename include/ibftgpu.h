@@ -441,7 +441,8 @@ int ibft_verify_messages_wire(ibft_ctx *ctx, const uint8_t *wire_bytes, const ui
 typedef struct {
   uint32_t off, len;                /* the message's bytes in `wire`                                             */
   uint32_t parent, ordinal;         /* containing row (IBFT_CERT_NO_PARENT for level 0), position among its children */
-  uint32_t first_child, n_children; /* its nested messages are rows [first_child, first_child + n_children)       */
+  uint32_t first_child, n_children; /* its nested messages are rows [first_child, first_child + n_children);
+                                       first_child means nothing when n_children == 0 (test n_children first)   */
   uint32_t raw_off, raw_len;        /* Proposal.rawProposal it carries (PREPREPARE: proposal; ROUND_CHANGE:
                                        lastPreparedProposal), in `wire`                                          */
   uint64_t proposal_round;          /* Proposal.round                                                            */

@@ -416,3 +416,85 @@ def test_ingest_queue_adaptive_batches_equal_direct_ingest():
     q.queue_push(np.frombuffer(wires[0], dtype=np.uint8), np.array([0, len(wires[0])], dtype=np.uint32))
     assert q.queue_drain().ingested == 1
     ref.close(); q.close()                                   # close() stops the worker
+
+
+def test_a_forgery_prepared_to_collide_with_an_honest_message_does_not_silence_it():
+    """Round-3 advice (medium): the receive side used to drop a message as "rejected before" on a match of its 128-bit
+    fingerprint alone, and the fingerprint's multiply-fold mixing has a seed-independent collision: a 16-byte block equal to
+    the two multiplier constants zeroes both lanes, whatever came before it.  An honest message that carries that block (a
+    transaction inside the raw proposal) and a forgery that differs from it in an EARLIER byte then share a fingerprint under
+    every seed; the forgery, sent first, is rejected — and the honest message was then dropped without being judged (the
+    reference judges every delivery: core/ibft.go:1101-1123).  Rejections are now identified by Keccak-256 of the bytes."""
+    import struct
+    w = World(4, 11)
+    block = struct.pack("<QQ", 0xE7037ED1A0B428DB, 0xA0761D6478BD642F)
+    for filler in range(0, 16):                          # put the block at a 16-aligned offset of the message's bytes
+        raw = b"t" * filler + block + b"tail of the block"
+        hsh = fake_hash(raw, 0)
+        m = W.IbftMessage(view=W.View(1, 0), sender=w.proposer(1, 0), type=PP, signature=b"sig-pp",
+                          payload=W.preprepare_body(W.Proposal(raw, 0), hsh, None))
+        honest = m.encode()
+        at = honest.index(block)
+        if at % 16 == 0:
+            break
+    assert at % 16 == 0 and len(honest) < 256
+    forged = bytearray(honest)
+    forged[honest.index(b"sig-pp") + 1] ^= 0x01          # one byte in front of the block: another message, same fingerprint
+    forged = bytes(forged)
+    w.bad_wires.add(forged)                              # its signature does not verify
+    for first_forged in (True, False):
+        h = w.host()
+        h.set_state(1, 0, None)
+        h.use_loop_batch(0)
+        h.use_batch(True)
+        if first_forged:
+            assert h.ingest_wire([forged])[0] == [0]     # rejected, remembered
+            res, asked, hits, calls = h.ingest_wire([forged])
+            assert res == [0] and hits == 1 and asked == 0   # the SAME bytes again: answered from the memory
+        res, asked, hits, calls = h.ingest_wire([honest])
+        assert res[0] > 0 and hits == 0, "the honest message was not judged"
+        assert h.store_num(1, 0, PP) == 1
+        h.close()
+
+
+def test_ingest_queue_is_bounded_and_applies_back_pressure():
+    """Round-3 advice: the receive queue grew for as long as the worker was inside a device call (32-bit offsets, memory).
+    Now: a push that would pass the caps WAITS until the worker has taken what is pending; a push that can never fit is
+    refused.  A slow verifier stands in for a stalled device."""
+    import threading
+    import time
+    import numpy as np
+    w, proposal, prepares, commits = _commit_world(n=30, bad=())
+    ver = w.verifier()
+    slow = ver["is_valid_validator"]
+
+    def slow_validator(wire):
+        time.sleep(0.002)
+        return slow(wire)
+    ver["is_valid_validator"] = slow_validator
+    q = H.Host()
+    assert q.vm_init({a: 1 for a in w.addrs})
+    q.set_verifier(**ver)
+    q.set_state(1, 0, proposal.encode())
+    q.queue_start(max_rows=8)
+    wires = [m.encode() for m in prepares + commits]
+    one = max(len(x) for x in wires)
+    q.queue_set_caps(max_pending_bytes=4 * one, max_pending_rows=4)
+    big = np.frombuffer(b"".join(wires[:6]), dtype=np.uint8)
+    assert q.queue_try_push(big, np.concatenate([[0], np.cumsum([len(x) for x in wires[:6]])]).astype(np.uint32)) == -2
+    t0 = time.perf_counter()
+
+    def producer(chunk):
+        for x in chunk:
+            q.queue_push(np.frombuffer(x, dtype=np.uint8), np.array([0, len(x)], dtype=np.uint32))
+    threads = [threading.Thread(target=producer, args=(wires[i::2],)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    pushed_in = time.perf_counter() - t0
+    st = q.queue_drain()
+    assert st.pushed == st.ingested == len(wires) and st.stored == len(wires)
+    assert st.max_batch_rows <= 4                            # never more pending than the cap
+    assert q.queue_backpressure_waits > 0 and pushed_in > 0.002 * (len(wires) - 8)   # the pushers were held back
+    q.close()

@@ -241,3 +241,35 @@ def test_rows_do_not_pin_a_flood():
     assert rows.repacked_bytes == sum(len(x) for x in honest)   # (an ordinary batch is left where it is)
     _same_answers(rows, objs)
     rows.close(); objs.close()
+
+
+def test_a_sender_that_keeps_replacing_its_message_pins_one_batch_not_all_of_them():
+    """Round-3 advice: a Byzantine validator alternates two encodings-that-verify of its COMMIT (here: two seals the mock
+    accepts), one per batch, each batch padded with other people's rejected bytes.  The reference keeps ONE message per
+    sender per view (messages/messages.go:54-65); the row store must not keep every batch buffer alive behind the one live
+    row, nor grow a row slot per replacement."""
+    w, ver, proposal, prepares, commits = _world(13, 21, bad_hash=(), forged=(), bad_seal=())
+    rows, objs = _host(w, ver, proposal, True), _host(w, ver, proposal, False)
+    for h in (rows, objs):
+        h.set_repack_min_bytes(1 << 30)                     # (the low-yield repack would hide the effect: off)
+    base = [m.encode() for m in commits[1:4]]
+    assert rows.ingest_wire(base)[0] == objs.ingest_wire(base)[0]
+    who = w.addrs[0]
+    for k in range(200):
+        variant = W.IbftMessage(view=W.View(1, 0), sender=who, type=CM, signature=b"sig-%d" % k,
+                                payload=W.commit_body(fake_hash(b"the block 21", 0), b"seal-%d-" % (k % 2) + who)).encode()
+        junk = W.IbftMessage(view=W.View(1, 0), sender=w.addrs[5], type=CM, signature=b"junk-%d" % k,
+                             payload=W.commit_body(b"j" * 32, bytes([k % 251]) * 2000)).encode()
+        w.bad_wires.add(junk)
+        ra, rb = rows.ingest_wire([junk, variant])[0], objs.ingest_wire([junk, variant])[0]
+        assert ra == rb == [0, 1]
+    live, slots, buffers = rows.lean_stats(1, 0, CM)
+    assert live == 4 and slots == 4 and buffers == 2        # the first batch (three rows) + the LAST variant's batch
+    assert rows.store_num(1, 0, CM) == objs.store_num(1, 0, CM) == 4
+    # senders that come and go (pruned by a walk, then back): dead slots are compacted away
+    rest = [m.encode() for m in prepares + commits[4:]]
+    assert rows.ingest_wire(rest)[0] == objs.ingest_wire(rest)[0]
+    _same_answers(rows, objs)
+    live, slots, buffers = rows.lean_stats(1, 0, CM)
+    assert slots <= 2 * live + 32 and buffers <= 3
+    rows.close(); objs.close()
