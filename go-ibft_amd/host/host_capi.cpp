@@ -455,6 +455,27 @@ int ibft_host_store_get_extended_rcc(ibft_host *h, uint64_t height, ibft_host_ms
   msgs_to_buf(msgs, out);
   return 0;
 }
+int ibft_host_store_get_extended_rcc_msgs(ibft_host *h, uint64_t height, ibft_host_msg_pred pred,
+                                          ibft_host_rcc_msgs_pred rcc_pred, void *user, ibft_host_buf *out) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  auto msgs = h->hp.messages.GetExtendedRCC(
+      height,
+      [&](const IbftMessage &m) {
+        if (!pred) return true;
+        bytes w = encode(m);
+        return pred(user, (const uint8_t *)w.data(), w.size()) != 0;
+      },
+      [&](uint64_t round, const std::vector<MsgPtr> &v) {
+        if (!rcc_pred) return true;
+        ibft_host_buf b{};
+        msgs_to_buf(v, &b);
+        const int r = rcc_pred(user, round, b.data, b.len, b.count);
+        ibft_host_buf_free(&b);
+        return r != 0;
+      });
+  msgs_to_buf(msgs, out);
+  return 0;
+}
 int ibft_host_store_get_most_rc(ibft_host *h, uint64_t min_round, uint64_t height, ibft_host_buf *out) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   msgs_to_buf(h->hp.messages.GetMostRoundChangeMessages(min_round, height), out);

@@ -75,6 +75,11 @@ int ibft_host_store_get_valid(ibft_host *h, uint64_t height, uint64_t round, uin
                               ibft_host_msg_pred pred, void *user, ibft_host_buf *out);
 int ibft_host_store_get_extended_rcc(ibft_host *h, uint64_t height, ibft_host_msg_pred pred,
                                      ibft_host_rcc_pred rcc_pred, void *user, ibft_host_buf *out);
+/* The same with the candidate set handed to the RCC predicate as packed messages — what isValidRCC(round, msgs) of
+ * messages/messages.go:202-245 receives (core/ibft.go:487-495 takes HasQuorum over their senders).                    */
+typedef int (*ibft_host_rcc_msgs_pred)(void *user, uint64_t round, const uint8_t *packed, size_t len, size_t n_messages);
+int ibft_host_store_get_extended_rcc_msgs(ibft_host *h, uint64_t height, ibft_host_msg_pred pred,
+                                          ibft_host_rcc_msgs_pred rcc_pred, void *user, ibft_host_buf *out);
 int ibft_host_store_get_most_rc(ibft_host *h, uint64_t min_round, uint64_t height, ibft_host_buf *out);
 
 /* messages/helpers.go */

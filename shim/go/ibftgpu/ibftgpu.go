@@ -98,6 +98,26 @@ func (c *Ctx) Close() {
 	}
 }
 
+// Handle is the ibft_ctx pointer for another cgo package of this module (hoststore attaches it to the host mirror:
+// ibft_host_attach_gpu); the context stays owned by c.
+func (c *Ctx) Handle() unsafe.Pointer { return unsafe.Pointer(c.h) }
+
+// HasQuorum = ValidatorManager.HasQuorum over the rows of `mask` (ibft_tally, core/validator_manager.go:77-96).
+func (c *Ctx) HasQuorum(sender20 []byte, mask []uint64) (Tally, error) {
+	var t C.ibft_tally_t
+	rc := C.ibft_tally(c.h, ptr8(sender20), (*C.uint64_t)(unsafe.Pointer(&mask[0])), C.size_t(len(sender20)/20), &t)
+	return tally(t), c.check(rc)
+}
+
+// HasPrepareQuorum = ValidatorManager.HasPrepareQuorum (ibft_tally_prepare, core/validator_manager.go:99-127): proposer20
+// is proposalMessage.From; the caller answers false itself when there is no proposal message (:101-110).
+func (c *Ctx) HasPrepareQuorum(sender20 []byte, mask []uint64, proposer20 []byte) (Tally, error) {
+	var t C.ibft_tally_t
+	rc := C.ibft_tally_prepare(c.h, ptr8(sender20), (*C.uint64_t)(unsafe.Pointer(&mask[0])), C.size_t(len(sender20)/20),
+		ptr8(proposer20), &t)
+	return tally(t), c.check(rc)
+}
+
 func ptr8(b []byte) *C.uint8_t {
 	if len(b) == 0 {
 		return nil

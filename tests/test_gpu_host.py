@@ -466,3 +466,45 @@ def test_quorum_decision_taken_from_the_device(gpu_verifier, oracle, rows, scena
                           "weighted": (False, False)}[scenario]
     assert dev.device_quorum_stats() == (2, 0)
     ref.close(); dev.close()
+
+
+@pytest.mark.parametrize("device_quorum", [False, True])
+def test_go_hoststore_call_sequence_with_the_device_attached(gpu_verifier, oracle, device_quorum):
+    """shim/go/hoststore's C call sequence (read from the Go file, tests/test_hoststore_sequence.py) replayed with the real
+    backend: New (ibft_host_attach_gpu) → SetValidators → SetState → AddWireMessages × k → Drain → HandlePrepare →
+    HandleCommit ≡ the stock mirror with the oracle-backed per-message Verifier, on a Byzantine round with real signatures."""
+    import go_ibft_amd.hostlib as H
+    from test_hoststore_sequence import Replay
+    r, proposal, prepares, commits = _build_round(oracle, 200, 606, True)
+    gpu_verifier.set_validators(r.height, r.addrs, r.power)
+    powers = {r.addrs[i].tobytes(): int(r.power[i]) for i in range(r.n)}
+    f1, f2, f3 = _oracle_verifier(oracle, r)
+    stock = H.Host()
+    assert stock.vm_init(powers)
+    stock.set_state(r.height, r.round, proposal.encode())
+    stock.set_verifier(f1, f2, f3)
+    wires = [m.encode() for m in prepares + commits]
+    expect = [stock.add_message(x) for x in wires]
+    rp = Replay(None, None, gpu=gpu_verifier)
+    rp.run("New", device_quorum=device_quorum, max_rows=0, linger_us=50)
+    rp.run("SetValidators", powers=powers)
+    rp.run("SetState", height=r.height, round=r.round, proposal=proposal.encode())
+    for k in range(0, len(wires), 64):
+        rp.run("AddWireMessages", raw=wires[k:k + 64])
+    rp.run("Drain")
+    assert rp.stats.ingested == len(wires) and rp.stats.stored == sum(1 for x in expect if x > 0)
+    assert rp.stats.device_calls >= 1 and rp.stats.device_calls <= rp.stats.batches + 2
+    rp.run("HandlePrepare", height=r.height, round=r.round)
+    okp, prepared = stock.handle_prepare(r.height, r.round)
+    assert rp.results[("HandlePrepare", "ibft_host_handle_prepare")] == int(okp) == 1
+    assert sorted(H.unpack(rp.taken)) == sorted(prepared)
+    rp.run("HandleCommit", height=r.height, round=r.round)
+    okc, seals = stock.handle_commit(r.height, r.round)
+    assert rp.results[("HandleCommit", "ibft_host_handle_commit")] == int(okc) == 1
+    assert sorted(H.unpack_seals(rp.taken)) == sorted(seals)
+    rp.run("RowsKept")
+    assert rp.results[("RowsKept", "ibft_host_rows_kept")] > 0
+    rp.run("DeviceQuorumStats")
+    assert rp.dq == ((2, 0) if device_quorum else (0, 0))
+    rp.run("Close")
+    stock.close()

@@ -6,7 +6,10 @@ DEFINED somewhere a Go compiler would find it —
   i.state.<m>( / i.messages.<m>( / i.backend.<m>(   the reference's state / Messages interface / Backend
   ibftgpu.<Symbol>       exported by shim/go/ibftgpu
   messages.<Func>, proto.<Type>                     shim/go/messages or the reference packages
-  C.<name>               declared in include/ibftgpu.h
+  C.<name>               declared in include/ibftgpu.h / include/ibft_host.h / the file's own cgo preamble, and every
+                         C.<function>(...) call passes as many arguments as the prototype has parameters
+  hoststore              *Store has every method of core.Messages and of core.hostStore; the "C call sequence" each method
+                         documents is the one its body makes (tests/test_hoststore_sequence.py replays those sequences)
   import paths           the overlay layout documented in shim/go/ibftgpu/ibftgpu.go
 
 Exit code 0 = consistent.  The reference checks are skipped (with a note) when /root/reference is absent."""
@@ -21,6 +24,90 @@ REF = "/root/reference"
 
 def read(paths):
     return "\n".join(open(p, errors="ignore").read() for p in paths)
+
+
+def _split_args(text: str) -> int:
+    """number of top-level comma-separated items in an argument / parameter list"""
+    text = text.strip()
+    if not text or text == "void":
+        return 0
+    depth, n = 0, 1
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        elif ch == "," and depth == 0:
+            n += 1
+    return n
+
+
+def _matching(text: str, open_at: int) -> int:
+    depth = 0
+    for k in range(open_at, len(text)):
+        if text[k] == "(":
+            depth += 1
+        elif text[k] == ")":
+            depth -= 1
+            if depth == 0:
+                return k
+    return -1
+
+
+def c_prototypes(header: str) -> dict:
+    """function name → parameter count, for every prototype / inline definition in C text"""
+    text = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    text = "\n".join(l.split("//")[0] for l in text.splitlines() if not l.lstrip().startswith("#"))
+    out = {}
+    for m in re.finditer(r"\b(\w+)\s*\(", text):
+        name = m.group(1)
+        if name in ("if", "for", "while", "return", "sizeof", "switch") or text[max(0, m.start() - 2):m.start()].endswith("(*"):
+            continue
+        before = text[:m.start()].rstrip()
+        if not before or before[-1] in "=(,!&|+-*/<>?:" and not before.endswith("*"):   # a call, not a declaration
+            continue
+        end = _matching(text, m.end() - 1)
+        if end < 0:
+            continue
+        after = text[end + 1:end + 40].lstrip()
+        if not (after.startswith(";") or after.startswith("{")):
+            continue
+        if re.search(r"typedef[^;]*$", before):   # function-pointer typedef
+            continue
+        out.setdefault(name, _split_args(text[m.end():end]))
+    return out
+
+
+def go_c_calls(code: str):
+    """(name, argument count) of every C.<name>(...) call in Go text (type conversions included: one argument)"""
+    out = []
+    for m in re.finditer(r"\bC\.(\w+)\(", code):
+        end = _matching(code, m.end() - 1)
+        if end > 0:
+            out.append((m.group(1), _split_args(code[m.end():end])))
+    return out
+
+
+def go_functions_with_doc(src: str):
+    """(name, doc comment, body) of every top-level func of a Go file"""
+    out = []
+    for m in re.finditer(r"((?:^//[^\n]*\n)*)^func (?:\([^)]*\) )?(\w+)\(", src, re.M):
+        brace = src.find("{", _matching(src, m.end() - 1))   # (the result list may be parenthesised too: the body's brace follows it)
+        line_end = src.find("\n", brace)
+        if src.count("(", _matching(src, m.end() - 1) + 1, brace) != src.count(")", _matching(src, m.end() - 1) + 1, brace):
+            brace = src.find("{", line_end)
+        depth, k = 0, brace
+        while k < len(src):
+            if src[k] == "{":
+                depth += 1
+            elif src[k] == "}":
+                depth -= 1
+                if depth == 0:
+                    break
+            k += 1
+        doc = "\n".join(l[2:].strip() for l in m.group(1).splitlines())
+        out.append((m.group(2), doc, src[brace:k + 1]))
+    return out
 
 
 def main(shim_root: str | None = None) -> int:
@@ -71,13 +158,57 @@ def main(shim_root: str | None = None) -> int:
     for name in sorted(set(re.findall(r"(?<![\w.])proto\.(\w+)", all_shim))):
         if have_ref and not re.search(r"\b%s\b" % name, ref_proto):
             errors.append(f"proto.{name} not found in messages/proto")
-    # C symbols
-    cnames = set(re.findall(r"\bC\.(\w+)", gpu_shim))
-    for name in sorted(cnames):
-        if name in ("int", "size_t", "uint8_t", "uint32_t", "uint64_t", "int32_t", "GoString"):
+    # C symbols: every C.<name> of a cgo file must be declared in the headers its preamble includes (or in the preamble
+    # itself), and every C.<function>(...) call must pass as many arguments as the prototype has parameters — the part of a
+    # type check that can be done without a compiler
+    host_hdr = open(os.path.join(ROOT, "include", "ibft_host.h")).read()
+    protos = c_prototypes(hdr + "\n" + host_hdr)
+    builtin = {"int", "size_t", "uint8_t", "uint32_t", "uint64_t", "int32_t", "uintptr_t", "GoString", "free", "char", "double"}
+    for path, text in shim.items():
+        if 'import "C"' not in text:
             continue
-        if not re.search(r"\b%s\b" % name, hdr):
-            errors.append(f"C.{name} is not declared in include/ibftgpu.h")
+        raw = open(path).read()
+        preamble = raw[raw.index("/*"):raw.index('import "C"')] if "/*" in raw.split('import "C"')[0] else ""
+        visible = hdr + (host_hdr if "ibft_host.h" in preamble else "") + preamble
+        local = c_prototypes(preamble)
+        rel = os.path.relpath(path, ROOT)
+        for name in sorted(set(re.findall(r"\bC\.(\w+)", text))):
+            if name in builtin:
+                continue
+            if not re.search(r"\b%s\b" % name, visible):
+                errors.append(f"{rel}: C.{name} is not declared in the headers / preamble of this file")
+        for name, argc in go_c_calls(text):
+            want = local.get(name, protos.get(name))
+            if want is not None and want != argc:
+                errors.append(f"{rel}: C.{name} called with {argc} arguments, the prototype has {want}")
+    # the optional interfaces of package core that another package of the overlay implements
+    hs = "\n".join(v for p_, v in shim.items() if os.sep + "hoststore" + os.sep in p_)
+    m_if = re.search(r"type hostStore interface \{(.*?)\n\}", core_shim, re.S)
+    if m_if and hs:
+        for name in re.findall(r"^\s*(\w+)\(", m_if.group(1), re.M):
+            if not defined_method("Store", name, hs):
+                errors.append(f"core.hostStore.{name} is not a method of *hoststore.Store")
+    for name in ("AddMessage", "PruneByHeight", "GetValidMessages", "GetExtendedRCC", "GetMostRoundChangeMessages"):
+        if hs and not defined_method("Store", name, hs):   # core.Messages (core/ibft.go:23-46); the subscription half is embedded
+            errors.append(f"*hoststore.Store lacks {name} of core.Messages")
+    if hs and "*messages.Messages" not in hs:
+        errors.append("*hoststore.Store does not embed *messages.Messages (Subscribe / Unsubscribe / SignalEvent)")
+    # the documented C call sequence of every method is the one its body makes (tests/test_hoststore_sequence.py replays it)
+    hs_path = os.path.join(shim_root, "hoststore", "hoststore.go")
+    hs_src = open(hs_path).read() if os.path.exists(hs_path) else ""
+    for fn, doc, body in go_functions_with_doc(hs_src):
+        m_seq = re.search(r"C call sequence:\s*(.*?)\.\s*$", doc, re.S)
+        made = [n for n, _ in go_c_calls(body) if n.startswith("ibft_host_")]
+        for helper, _, hbody in go_functions_with_doc(hs_src):   # one level of helpers of the same file
+            if helper != fn and re.search(r"\b%s\(" % helper, body):
+                made += [n for n, _ in go_c_calls(hbody) if n.startswith("ibft_host_")]
+        if m_seq is None:
+            if made:
+                errors.append(f"hoststore.{fn}: calls {made} but documents no C call sequence")
+            continue
+        documented = re.findall(r"ibft_host_\w+", m_seq.group(1))   # ("… (on failure: x, y)" counts too)
+        if sorted(set(documented)) != sorted(set(made)):
+            errors.append(f"hoststore.{fn}: documented sequence {documented} != calls made {made}")
     # methods on shim types used by the shim itself (ctx.X / g.X)
     for name in sorted(set(re.findall(r"\(\*Ctx\)\.(\w+)", all_shim))):
         if not defined_method("Ctx", name, gpu_shim):
