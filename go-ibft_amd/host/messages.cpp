@@ -385,6 +385,7 @@ bool ValidatorManager::HasPrepareQuorum(const IbftMessage *proposal, const std::
 void QuorumIndex::OnSender(uint32_t type, uint64_t height, uint64_t round, const bytes &from, int delta,
                            const ValidatorManager &vm) {
   std::lock_guard<std::mutex> lk(mu_);
+  changes_++;
   Entry *e = find(type, height, round);
   if (!e || !e->valid || e->epoch != epoch_) return;  // stale: rebuilt on demand
   const unsigned __int128 w = vm.powerOf(from);       // unknown senders contribute 0
@@ -399,6 +400,7 @@ void QuorumIndex::OnSender(uint32_t type, uint64_t height, uint64_t round, const
 
 void QuorumIndex::Add(uint32_t type, uint64_t height, uint64_t round, unsigned __int128 dpower, size_t dcount) {
   std::lock_guard<std::mutex> lk(mu_);
+  changes_++;
   Entry *e = find(type, height, round);
   if (!e || !e->valid || e->epoch != epoch_) return;  // stale: rebuilt on demand
   e->power += dpower;
@@ -406,6 +408,7 @@ void QuorumIndex::Add(uint32_t type, uint64_t height, uint64_t round, unsigned _
 }
 void QuorumIndex::OnPrune(uint64_t below_height) {
   std::lock_guard<std::mutex> lk(mu_);
+  changes_++;
   for (auto it = e_.begin(); it != e_.end();)
     it = std::get<1>(it->first) < below_height ? e_.erase(it) : std::next(it);
   last_ = nullptr;
@@ -414,24 +417,35 @@ void QuorumIndex::OnPrune(uint64_t below_height) {
 std::pair<unsigned __int128, size_t> QuorumIndex::Get(uint32_t type, uint64_t height, uint64_t round,
                                                       const std::function<std::vector<bytes>()> &rebuild,
                                                       const ValidatorManager &vm) {
-  std::lock_guard<std::mutex> lk(mu_);
-  Entry *pe = find(type, height, round);
-  if (!pe) {
-    pe = &e_[{type, height, round}];
-    last_key_ = {type, height, round};
-    last_ = pe;
-  }
-  Entry &e = *pe;
-  if (!e.valid || e.epoch != epoch_) {
-    e = Entry{};
+  // Lock order: the store's hooks call OnSender / OnPrune UNDER the store's per-type lock, so this index's lock is always
+  // the inner one — `rebuild` (which takes the store's lock to list the view's senders) therefore runs with this lock
+  // RELEASED (ThreadSanitizer: lock-order inversion, round 4).  Whatever changed meanwhile bumped `changes_`: list again.
+  std::unique_lock<std::mutex> lk(mu_);
+  for (;;) {
+    Entry *pe = find(type, height, round);
+    if (pe && pe->valid && pe->epoch == epoch_) return {pe->power, pe->count};
+    const uint64_t seen = changes_, epoch = epoch_;
+    lk.unlock();
+    unsigned __int128 power = 0;
+    size_t count = 0;
     for (const bytes &from : rebuild()) {
-      e.power += vm.powerOf(from);
-      e.count++;
+      power += vm.powerOf(from);
+      count++;
     }
-    e.valid = true;
-    e.epoch = epoch_;
+    lk.lock();
+    if (changes_ != seen || epoch_ != epoch) continue;
+    pe = find(type, height, round);
+    if (!pe) {
+      pe = &e_[{type, height, round}];
+      last_key_ = {type, height, round};
+      last_ = pe;
+    }
+    pe->power = power;
+    pe->count = count;
+    pe->valid = true;
+    pe->epoch = epoch;
+    return {power, count};
   }
-  return {e.power, e.count};
 }
 
 std::set<bytes> convertMessageToAddressSet(const std::vector<MsgPtr> &msgs) {

@@ -430,7 +430,10 @@ class QuorumIndex {
   // the counters of a view moved by (Δpower, Δsenders) — a run of rows stored without the per-sender hook
   void Add(uint32_t type, uint64_t height, uint64_t round, unsigned __int128 dpower, size_t dcount);
   void OnPrune(uint64_t below_height);
-  void Invalidate() { epoch_++; }  // validator set changed: sums are recomputed on next use
+  void Invalidate() {  // validator set changed: sums are recomputed on next use
+    std::lock_guard<std::mutex> lk(mu_);
+    epoch_++;
+  }
   // (Σ power, number of stored senders); `rebuild` lists the view's senders when the entry is stale
   std::pair<unsigned __int128, size_t> Get(uint32_t type, uint64_t height, uint64_t round,
                                            const std::function<std::vector<bytes>()> &rebuild,
@@ -456,6 +459,7 @@ class QuorumIndex {
     return last_;
   }
   uint64_t epoch_ = 1;
+  uint64_t changes_ = 0;  // every hook call: a Get that listed the view with the lock released sees whether it must list again
   std::mutex mu_;
 };
 

@@ -31,6 +31,19 @@ def build_host(force: bool = False) -> str:
     return HOST_LIB
 
 
+SANITIZERS = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "tsan": ["-fsanitize=thread"]}
+
+
+def build_host_sanitized(kind: str, out_dir: str) -> str:
+    """TEST-ONLY: the mirror compiled with AddressSanitizer + UBSan ("asan") or ThreadSanitizer ("tsan") into out_dir
+    (tests/test_host_sanitize.py loads it through IBFT_HOST_LIB under LD_PRELOAD of the sanitizer runtime)"""
+    build_lib()
+    out = os.path.join(out_dir, f"libibft_host_{kind}.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-fno-omit-frame-pointer", *SANITIZERS[kind], "-std=c++17", "-fPIC", "-shared",
+                           "-o", out, *HOST_SRCS, "-L" + CSRC, "-libftgpu", "-Wl,-rpath," + CSRC], cwd=HOST_DIR)
+    return out
+
+
 class Buf(C.Structure):
     _fields_ = [("data", C.POINTER(C.c_uint8)), ("len", C.c_size_t), ("count", C.c_size_t)]
 
@@ -74,7 +87,7 @@ def retain_heap(nbytes: int = 256 << 20) -> bool:
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        L = C.CDLL(build_host())
+        L = C.CDLL(os.environ.get("IBFT_HOST_LIB") or build_host())   # IBFT_HOST_LIB: a sanitizer build (tests)
         vp, bp = C.c_void_p, C.POINTER(Buf)
         L.ibft_host_new.restype = vp
         L.ibft_host_free.argtypes = [vp]
