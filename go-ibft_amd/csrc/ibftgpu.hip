@@ -112,6 +112,10 @@ struct ibft_ctx {
   DevBuf d_seen, d_acc, d_quorum;                    // tally: distinct-sender bitmap, launch-wide sums + ticket, quorum words
   uint64_t last_wide[ibftk::TALLY_SUM_WORDS] = {0};  // full-width power of the last fetched tally
   uint64_t height = 0;
+  // the seal-digest convention of the embedding Backend (ibft_set_seal_digest): 0 = the proposalHash itself
+  uint32_t seal_digest_mode = 0;
+  uint64_t seal_suffix_words[9] = {0};
+  DevBuf d_hash_copy;            // message sets under a non-identity convention: the carried hashes a1 compares
   std::vector<uint32_t> h_vtab;  // host copy of the validator table (6 dwords per slot): the proposer's seat is looked up here
   // HasPrepareQuorum: set by an entry point that was given a proposer, consumed by the next tally it enqueues
   bool next_prop_on = false;
@@ -621,6 +625,24 @@ void note_proposer(ibft_ctx *c, const uint8_t *proposer20) {
 }
 
 int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes);
+
+// rows [row0, row0 + n) of the hash column: carried proposalHash → the digest the seal signs (no-op under the identity
+// convention); keep_copy: the carried hashes stay available in d_hash_copy (rows [0, n)) for the a1 compare
+int apply_seal_digest(ibft_ctx *c, uint32_t row0, uint32_t n, bool keep_copy) {
+  if (c->seal_digest_mode == 0 || n == 0) return IBFT_OK;
+  ibftk::seal_digest_args a{};
+  a.hash32 = (uint8_t *)c->d_hash.p + 32ull * row0;
+  if (keep_copy) {
+    int rc = ensure(c, c->d_hash_copy, (size_t)n * 32);
+    if (rc) return rc;
+    a.copy32 = (uint8_t *)c->d_hash_copy.p;
+  }
+  a.n = n;
+  memcpy(a.suffix_words, c->seal_suffix_words, sizeof a.suffix_words);
+  hipLaunchKernelGGL(ibftk::seal_digest_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  return IBFT_OK;
+}
 
 // d_H ← keccak256(raw ‖ BE64(round)) unless it already holds exactly that (enqueued on the context's stream)
 // d_H ← keccak256(raw ‖ BE64(round)) unless it already holds exactly that.  Two steps so that a message set can put the
@@ -1311,7 +1333,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
                     &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
                     &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total,
-                    &c->d_cert_slot, &c->d_cert_tiles})
+                    &c->d_cert_slot, &c->d_cert_tiles, &c->d_hash_copy, &c->d_seen_out})
     release(*b);
   if (c->dev) {
     {
@@ -1709,6 +1731,7 @@ static int seals_stage_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t 
   cc.add(c->d_signer.p, signer20, n * 20);
   if (pre_flags) cc.add(c->d_pre.p, pre_flags, n);
   if ((rc = cc.flush(c))) return rc;
+  if ((rc = apply_seal_digest(c, 0, (uint32_t)n, false))) return rc;
   // ibft_seals_stage promises the caller its buffers back; the one-shot call waits once, at the end
   if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));
   c->staged_n = (uint32_t)n;
@@ -1948,13 +1971,16 @@ static int messages_launch_locked(ibft_ctx *c, const uint8_t *payload, const uin
                        (const uint8_t *)c->d_payload.p, (const uint32_t *)c->d_off.p, (uint32_t)n, d_hash);
     HIPCHK(c, hipGetLastError());
   }
+  // the seals sign digest(carried hash) under a non-identity convention; a1 still compares the carried hashes (the copy)
+  const bool converted = seal65 && c->seal_digest_mode != 0;
+  if (converted && (rc = apply_seal_digest(c, half, (uint32_t)n, true))) return rc;
   c->ev_used = 0;
   const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
   if ((rc = enqueue_recover(c, rows, false, 0, time_it))) return rc;
   ibftk::set_args sa{};
   sa.sender_pre = sender_pre ? d_pre : nullptr;
   sa.valid_pre = valid_pre ? d_pre + half : nullptr;
-  sa.hash32 = d_hash + 32ull * half;
+  sa.hash32 = converted ? (const uint8_t *)c->d_hash_copy.p : d_hash + 32ull * half;
   sa.hash_len = (const uint8_t *)c->d_hash_len.p;
   sa.H4 = (const uint64_t *)c->d_H.p;
   sa.n = (uint32_t)n;
@@ -2019,6 +2045,7 @@ int ibft_sign_seals(ibft_ctx *c, const uint8_t *sk32, const uint8_t *hash32, siz
   int rc;
   if ((rc = upload(c, c->d_payload, sk32, n * 32))) return rc;  // the sender-payload column is free during a seal batch
   if ((rc = upload(c, c->d_hash, hash32, n * 32))) return rc;
+  if ((rc = apply_seal_digest(c, 0, (uint32_t)n, false))) return rc;  // a seal signs what the convention says it signs
   ibftk::sign_args a;
   a.gtab = (const uint32_t *)c->dev->d_gtab.p;
   a.sk32 = (const uint8_t *)c->d_payload.p;
@@ -2206,12 +2233,14 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
     HIPCHK(c, hipMemsetAsync(d_sig + 65ull * n, 0, 65ull * (half - n), c->stream));
     HIPCHK(c, hipMemsetAsync(d_pre + n, 1, half - n, c->stream));
   }
+  const bool converted = c->seal_digest_mode != 0;
+  if (converted && (rc = apply_seal_digest(c, half, (uint32_t)n, true))) return rc;
   c->ev_used = 0;
   const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
   // with the pre column: wavefronts whose rows are all dead (the seal rows of PREPAREs, other views, odd encodings) exit at once
   if ((rc = enqueue_recover(c, half + (uint32_t)n, true, 0, time_it))) return rc;
   ibftk::set_args sa{};
-  sa.hash32 = d_hash + 32ull * half;
+  sa.hash32 = converted ? (const uint8_t *)c->d_hash_copy.p : d_hash + 32ull * half;
   sa.hash_len = (const uint8_t *)c->d_hash_len.p;
   sa.H4 = (const uint64_t *)c->d_H.p;
   sa.sender_pre = d_pre;  // not canonical here, or From / Signature of a length no signature check can pass
@@ -2424,6 +2453,8 @@ int ibft_wire_stage_seals(ibft_ctx *c) {
                        (const wire::row_info *)c->d_wire_rows.p, (const uint8_t *)c->d_seal.p, n,
                        (uint8_t *)c->d_hash.p, (uint8_t *)c->d_sig.p, (uint8_t *)c->d_pre.p);
     HIPCHK(c, hipGetLastError());
+    int rc = apply_seal_digest(c, 0, n, false);
+    if (rc) return rc;
   }
   c->staged_pre = true;
   return IBFT_OK;
@@ -2626,6 +2657,30 @@ int ibft_group_is_local(const ibft_group *g) { return g ? (g->local ? 1 : 0) : I
 
 uint32_t ibft_group_size(const ibft_group *g) { return g ? (uint32_t)g->ctx.size() : 0; }
 ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i) { return (g && i < g->ctx.size()) ? g->ctx[i] : nullptr; }
+
+int ibft_set_seal_digest(ibft_ctx *c, uint32_t mode, const uint8_t *suffix, size_t suffix_len) {
+  if (!c || mode > IBFT_SEAL_DIGEST_KECCAK_SUFFIX || (suffix_len && !suffix) || suffix_len > IBFT_SEAL_SUFFIX_MAX) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  uint8_t block[72] = {0};
+  if (mode == IBFT_SEAL_DIGEST_KECCAK_SUFFIX) {
+    if (suffix_len) memcpy(block, suffix, suffix_len);
+    block[suffix_len] = 0x01;  // pad10*1 starts right behind the message
+  }
+  c->seal_digest_mode = mode;
+  memcpy(c->seal_suffix_words, block, sizeof block);
+  c->staged_n = 0;  // a resident batch was staged under the previous convention
+  c->wire_valid = false;
+  return IBFT_OK;
+}
+int ibft_group_set_seal_digest(ibft_group *g, uint32_t mode, const uint8_t *suffix, size_t suffix_len) {
+  if (!g) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (ibft_ctx *c : g->ctx) {
+    int rc = ibft_set_seal_digest(c, mode, suffix, suffix_len);
+    if (rc) return rc;
+  }
+  return IBFT_OK;
+}
 
 int ibft_group_set_validators(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n) {
   if (!g) return IBFT_E_INVAL;

@@ -1743,6 +1743,42 @@ __global__ void __launch_bounds__(XUNPACK_THREADS) exchange_unpack_kernel(exchan
   }
 }
 
+// ---- the seal-digest convention (ibft_set_seal_digest) --------------------------------------------------
+// Backend.IsValidCommittedSeal is "the signature for the proposal hash in the committed seal" (core/backend.go:53-55);
+// WHAT is signed is the embedding Backend's business — the 32-byte proposalHash itself (default), or
+// keccak256(proposalHash ‖ suffix) (e.g. a COMMIT-type byte appended before hashing).  One lane per row: the carried hash
+// is kept (copy32: what a1 compares) and the row's digest replaces it in the column the verdict kernels read.
+struct seal_digest_args {
+  uint8_t *hash32;        // n × 32: carried hashes in, digests out
+  uint8_t *copy32;        // or null: the carried hashes, unchanged
+  uint32_t n;
+  uint64_t suffix_words[9];  // suffix ‖ 0x01 ‖ 0… as little-endian words (bytes 32..103 of the one Keccak block)
+};
+__global__ void seal_digest_kernel(seal_digest_args a) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.n) return;
+  uint4 *p = reinterpret_cast<uint4 *>(a.hash32 + 32ull * row);
+  const uint4 x = p[0], y = p[1];
+  if (a.copy32) {
+    uint4 *q = reinterpret_cast<uint4 *>(a.copy32 + 32ull * row);
+    q[0] = x;
+    q[1] = y;
+  }
+  uint64_t s[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) s[i] = 0;
+  s[0] = (uint64_t)x.x | ((uint64_t)x.y << 32);
+  s[1] = (uint64_t)x.z | ((uint64_t)x.w << 32);
+  s[2] = (uint64_t)y.x | ((uint64_t)y.y << 32);
+  s[3] = (uint64_t)y.z | ((uint64_t)y.w << 32);
+#pragma unroll
+  for (int j = 0; j < 9; j++) s[4 + j] = a.suffix_words[j];
+  s[16] ^= 0x8000000000000000ull;  // pad10*1: the last bit of the 136-byte rate
+  keccak::f1600(s);
+  p[0] = make_uint4((uint32_t)s[0], (uint32_t)(s[0] >> 32), (uint32_t)s[1], (uint32_t)(s[1] >> 32));
+  p[1] = make_uint4((uint32_t)s[2], (uint32_t)(s[2] >> 32), (uint32_t)s[3], (uint32_t)(s[3] >> 32));
+}
+
 // sender -> validator index, for ibft_tally() on a caller-supplied mask
 // proposer5 (or null): HasPrepareQuorum compares From with the proposer's address byte for byte, member or not
 // (validator_manager.go:114-115) — a row of a proposer who is no validator is marked VIDX_PROPOSER_OUTSIDER

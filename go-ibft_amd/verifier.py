@@ -39,7 +39,7 @@ EXPORTS = [
     "ibft_group_set_validators_u256", "ibft_group_verify_seals", "ibft_group_verify_senders", "ibft_group_verify_messages", "ibft_group_verify_certificates_wire",
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
-    "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info",
+    "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info", "ibft_set_seal_digest", "ibft_group_set_seal_digest",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -130,6 +130,8 @@ def load_library() -> C.CDLL:
     L.ibft_verify_senders.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
     L.ibft_tally.argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(Tally)]
     L.ibft_tally_prepare.argtypes = [vp, vp, vp, C.c_size_t, vp, C.POINTER(Tally)]
+    L.ibft_set_seal_digest.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+    L.ibft_group_set_seal_digest.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
     L.ibft_comm_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]
     L.ibft_seals_stage.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.ibft_seals_launch.argtypes = [vp, C.c_uint32]
@@ -322,6 +324,14 @@ class BatchVerifier:
         t = TallyWide()
         self._chk(self._L.ibft_last_tally_wide(self._h, C.byref(t)), "ibft_last_tally_wide")
         return t
+
+    def set_seal_digest(self, suffix: bytes | None) -> None:
+        """the embedding Backend's seal convention: None = the seal signs the proposalHash itself (default),
+        bytes = it signs keccak256(proposalHash ‖ suffix)  (include/ibftgpu.h: ibft_set_seal_digest)"""
+        b = None if not suffix else np.frombuffer(bytes(suffix), dtype=np.uint8)
+        self._chk(self._L.ibft_set_seal_digest(self._h, 0 if suffix is None else 1, _p(b), len(suffix or b"")),
+                  "ibft_set_seal_digest")
+        self._staged = 0
 
     def try_set_validators(self, height: int, addrs20, power) -> int:
         a = _u8(addrs20, (-1, 20)); p = np.ascontiguousarray(power, dtype=np.uint64)
@@ -656,6 +666,11 @@ class DeviceGroup:
             self._g = C.c_void_p()
 
     __del__ = close
+
+    def set_seal_digest(self, suffix: bytes | None) -> None:
+        b = None if not suffix else np.frombuffer(bytes(suffix), dtype=np.uint8)
+        self._chk(self._L.ibft_group_set_seal_digest(self._g, 0 if suffix is None else 1, _p(b), len(suffix or b"")),
+                  "ibft_group_set_seal_digest")
 
     def _chk(self, rc, what):
         if rc != 0:

@@ -45,7 +45,7 @@
  * Ethereum-style ones an IBFT backend uses, stated once, obeyed by CPU oracle and
  * GPU alike):
  *   proposal hash = keccak256(RawProposal ‖ BE64(Round));  seal digest = the 32-byte
- *   proposalHash itself;  sender digest = keccak256(PayloadNoSig)
+ *   proposalHash itself (or keccak256(proposalHash ‖ suffix): ibft_set_seal_digest);  sender digest = keccak256(PayloadNoSig)
  *   (/root/reference/messages/proto/helper.go:12-27);  signature = 65 B r‖s‖v with
  *   r,s big-endian in [1,n-1] and v∈{0,1};  address = keccak256(X‖Y)[12:32].
  *   Recovery-id policy: v is the parity of R.y and nothing else — R.x = r always.  The second candidate
@@ -172,6 +172,21 @@ typedef struct {
 } ibft_tally_wide_t;
 /* full-width result of the last tally this context delivered (verify / fetch / fetch_merged call)  */
 int ibft_last_tally_wide(ibft_ctx *ctx, ibft_tally_wide_t *out);
+
+/* ---- the seal-digest convention ---------------------------------------------------------------------------
+ * "IsValidCommittedSeal checks if signature for proposal hash in committed seal is signed by a validator"
+ * (/root/reference/core/backend.go:53-55): WHICH bytes the seal signs is the embedding Backend's choice.  Default
+ * (IDENTITY): the 32-byte proposalHash itself.  KECCAK_SUFFIX: keccak256(proposalHash ‖ suffix), suffix ≤ 64 bytes —
+ * e.g. a Backend that appends the COMMIT message type before hashing passes suffix = {0x02}.  The convention applies to
+ * every a2 evaluation of the context: ibft_verify_seals / ibft_seals_stage (the hash32 column still carries the
+ * proposalHash each row's message carries; the digest is derived on the device), ibft_wire_stage_seals, the seal half of
+ * ibft_verify_messages / ibft_verify_messages_wire (a1 keeps comparing the CARRIED hash with the proposal's), the group
+ * calls (ibft_group_set_seal_digest), and ibft_sign_seals (a simulator's seals sign what its verifiers check).  It does
+ * not touch a3: an envelope signs keccak256(PayloadNoSig).  Changing it drops a resident staged batch.            */
+#define IBFT_SEAL_DIGEST_IDENTITY 0u
+#define IBFT_SEAL_DIGEST_KECCAK_SUFFIX 1u
+#define IBFT_SEAL_SUFFIX_MAX 64u
+int ibft_set_seal_digest(ibft_ctx *ctx, uint32_t mode, const uint8_t *suffix, size_t suffix_len);
 
 /* a1.  raw/raw_len/round: the proposal all rows are checked against.  hash32 is
  * n×32 (zero-filled where absent), hash_len[i] the real byte length (0 = nil).    */
@@ -534,6 +549,7 @@ ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i); /* the i-th device's contex
 int ibft_group_set_validators(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint64_t *power, size_t n);
 int ibft_group_set_validators_u256(ibft_group *g, uint64_t height, const uint8_t *addrs20, const uint8_t *power_be32,
                                    size_t n);
+int ibft_group_set_seal_digest(ibft_group *g, uint32_t mode, const uint8_t *suffix, size_t suffix_len);
 /* IsValidCommittedSeal + HasQuorum for n rows sharded over the group's devices: same arguments and results as
  * ibft_verify_seals, out_mask / tally are the merged (global) ones — identical to ibft_verify_seals on the whole
  * batch whatever the rows contain (duplicated senders across shards included).                              */

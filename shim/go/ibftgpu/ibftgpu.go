@@ -98,6 +98,18 @@ func (c *Ctx) Close() {
 	}
 }
 
+// SetSealDigest tells the context WHAT a committed seal signs in this Backend (core/backend.go:53-55 leaves it open):
+// suffix == nil: the 32-byte proposalHash itself (the default); otherwise keccak256(proposalHash ‖ suffix) — e.g. a Backend
+// that appends byte(proto.MessageType_COMMIT) before hashing passes []byte{2}.  Every a2 route of the context follows
+// (seal batches, the seal half of message sets — a1 keeps comparing the carried hash — and the batch signer).
+func (c *Ctx) SetSealDigest(suffix []byte) error {
+	mode := C.uint32_t(C.IBFT_SEAL_DIGEST_IDENTITY)
+	if suffix != nil {
+		mode = C.IBFT_SEAL_DIGEST_KECCAK_SUFFIX
+	}
+	return c.check(C.ibft_set_seal_digest(c.h, mode, ptr8(suffix), C.size_t(len(suffix))))
+}
+
 // Handle is the ibft_ctx pointer for another cgo package of this module (hoststore attaches it to the host mirror:
 // ibft_host_attach_gpu); the context stays owned by c.
 func (c *Ctx) Handle() unsafe.Pointer { return unsafe.Pointer(c.h) }

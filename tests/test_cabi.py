@@ -82,6 +82,8 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.ibft_verify_messages(null, b, off, b, b, b, b, None, None, None, 1, b, 1, 0, None, None, m, m, C.byref(t)),
         lambda: lib.ibft_tally_prepare(null, b, m, 1, b, C.byref(t)),
         lambda: lib.ibft_comm_info(null, None, None, None),
+        lambda: lib.ibft_set_seal_digest(null, 1, b, 1),
+        lambda: lib.ibft_group_set_seal_digest(null, 1, b, 1),
         lambda: lib.ibft_verify_certificates_wire(null, b, off, 1, 8, C.byref(C.c_size_t()), None, None, None, m, m, m),
         lambda: lib.ibft_seals_launch(null, 1),
         lambda: lib.ibft_seals_fetch(null, m, C.byref(t)),
