@@ -135,11 +135,101 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
                       f"{el:.1f} s, {cores} pthreads); 1 thread: {single:.0f} verifies/s"}
 
 
+# wall ns per wave-instruction per SIMD by instruction class, measured with tools/ubench_wave.hip (profiles/r02a_ubench_wave.txt):
+# one / two / four resident wavefronts per SIMD
+ISSUE_NS = {1: {"plain": 2.07, "dpp": 2.22, "mad": 2.50}, 2: {"plain": 1.11, "dpp": 1.93, "mad": 2.19},
+            4: {"plain": 0.99, "dpp": 1.86, "mad": 2.13}}
+LANES_OF = {"ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 1, "ecrecover_rows_kernel": 16, "ecrecover_wave_kernel": 64,
+            "verify_known_wave_kernel": 64}
+# wavefronts a SIMD can hold (512 registers per lane: go-ibft_amd/csrc resource usage, tools/occupancy.py)
+RESIDENT_CAP = {"ecrecover_lane_kernel": 2, "verify_known_lane_kernel": 2, "ecrecover_rows_kernel": 2, "ecrecover_wave_kernel": 2,
+                "verify_known_wave_kernel": 2, "ecrecover_group_kernel": 1, "verify_known_group_kernel": 2}
+
+
+def _static_mix(kname: str):
+    """(v_mad_u64_u32 share, DPP share, s_nop per VALU) of a kernel's hot loops from the newest profiles/r*_static_mix.txt"""
+    base = kname.split("<")[0]
+    args = re.findall(r"\d+", kname.split("<")[1]) if "<" in kname else []
+    mangled = base + "ILi" + "ELi".join(args) + "E" if args else base
+    for sp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_static_mix.txt")), reverse=True):
+        st = open(sp).read()
+        for sec in st.split("# kernel ")[1:]:
+            if mangled in sec.splitlines()[0]:
+                try:
+                    f_mad = float(re.search(r"v_mad_u64_u32 share of VALU[^:]*: ([0-9.]+)", sec).group(1))
+                    f_dpp = float(re.search(r"DPP share of VALU[^:]*: ([0-9.]+)", sec).group(1))
+                    nop = float(re.search(r"s_nop per VALU instruction[^:]*: ([0-9.]+)", sec).group(1))
+                except AttributeError:
+                    continue
+                if f_mad > 0:
+                    return f_mad, f_dpp, nop, os.path.relpath(sp, ROOT)
+    if "wave_kernel" in kname:      # the one-wavefront-per-signature kernels run the row-layout code (wfe_mul) inside calls
+        return _static_mix("ecrecover_rows_kernel<0>")
+    return None
+
+
+def valu_issue(kname: str, rows: int, avg_kernel_s: float):
+    """The bound that applies to this path (integer VALU issue), per launch: VALU wave-instructions from the newest
+    profiles/r*_pmc_instruction_mix.txt that holds this kernel (rocprofv3 --pmc SQ_INSTS_VALU of this same command on the
+    builder's box — a file attachment: PMCs cannot be read in-process — scaled by rows when the file's batch size differs:
+    the count per signature does not depend on the batch), priced against
+      * the guide's issue peak: 1 024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz;
+      * the mix-weighted ceiling at FULL occupancy (4 wavefronts per SIMD) for this kernel's instruction mix;
+      * the mix-weighted ceiling at the occupancy THIS launch reaches (wavefronts offered per SIMD, capped by registers)."""
+    base = kname.split("<")[0]
+    kshort = re.escape(base) + r"<[^>]*>" if "<" in kname else re.escape(base)
+    exact = re.escape(kname.replace(",", ", ")) if "group" in kname else kshort
+    insts = salu = None
+    src = scaled = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instruction_mix.txt")), reverse=True):
+        try:
+            text = open(path).read()
+        except OSError:
+            continue
+        m = re.search(exact + r"\s+SQ_INSTS_VALU\s+([0-9.]+) per launch", text)
+        if not m:
+            continue
+        m_rows = re.search(r"^# rows per launch: (\d+)", text, re.M)
+        file_rows = int(m_rows.group(1)) if m_rows else 1024
+        if insts is not None and file_rows != rows:
+            continue                                  # an exact-size file wins over the newest one
+        ms = re.search(exact + r"\s+SQ_INSTS_SALU\s+([0-9.]+) per launch", text)
+        insts, salu = float(m.group(1)) * rows / file_rows, (float(ms.group(1)) if ms else 0.0) * rows / file_rows
+        src, scaled = os.path.relpath(path, ROOT), (None if file_rows == rows else file_rows)
+        if file_rows == rows:
+            break
+    mix = _static_mix(kname)
+    if insts is None or mix is None:
+        return None
+    f_mad, f_dpp, nop, mix_src = mix
+    lanes = LANES_OF.get(base) or int(re.findall(r"\d+", kname)[-1])
+    offered = rows * lanes / 64 / 1024
+    resident = max(1, min(RESIDENT_CAP.get(base, 2), int(offered + 0.999)))
+
+    def ceiling(waves):
+        t = ISSUE_NS[waves]
+        return 1024 / ((f_mad * t["mad"] + f_dpp * t["dpp"] + (1.0 - f_mad - f_dpp) * t["plain"]) * 1e-9)
+    ach = insts / avg_kernel_s
+    peak_guide = 1024 * 2.4e9 / 2.0
+    full, here = ceiling(4), ceiling(1 if resident < 2 else 2)
+    return {"wave_insts_per_launch": insts, "salu_insts_per_launch": salu, "achieved_ginst_s": ach / 1e9,
+            "peak_guide_ginst_s": peak_guide / 1e9, "frac_of_guide_peak": ach / peak_guide,
+            "ceiling_full_occupancy_ginst_s": full / 1e9, "frac_of_full_occupancy_ceiling": ach / full,
+            "ceiling_at_this_occupancy_ginst_s": here / 1e9, "frac_of_ceiling_at_this_occupancy": ach / here,
+            "wavefronts_offered_per_simd": offered, "wavefronts_resident_per_simd": resident,
+            "mad_share": f_mad, "dpp_share": f_dpp, "s_nop_per_valu": nop,
+            "note": "peak_guide = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); the "
+                    "ceilings price THIS kernel's instruction mix with the measured issue times of profiles/r02a_ubench_wave.txt "
+                    "(v_mad_u64_u32 2.50 / 2.19 / 2.13 ns, DPP 2.22 / 1.93 / 1.86 ns, plain VALU 2.07 / 1.11 / 0.99 ns per "
+                    "instruction per SIMD at 1 / 2 / 4 resident wavefronts)",
+            "source": src, "instruction_count_scaled_from_rows": scaled, "mix_source": mix_src}
+
+
 def profile_attachments(kname: str, rows: int, avg_kernel_s: float):
     """PMC counters cannot be read from inside this process: the per-launch values measured with rocprofv3
     (separate passes of this same command: tools/profile.sh → profiles/r*_traffic.json, tools/pmc_wave.sh →
     profiles/r*_pmc_instruction_mix.txt) are attached when kernel and batch size match."""
-    traffic, valu = None, None
+    traffic = None
     try:
         needle = "ibftk::" + kname.replace(",", ", ")
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
@@ -150,46 +240,9 @@ def profile_attachments(kname: str, rows: int, avg_kernel_s: float):
     except (OSError, ValueError):
         pass
     try:
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instruction_mix.txt")), reverse=True):
-            text = open(path).read()
-            m_rows = re.search(r"^# rows per launch: (\d+)", text, re.M)
-            file_rows = int(m_rows.group(1)) if m_rows else 1024
-            kshort = re.escape(kname.split("<")[0]) + r"<[^>]*>"
-            m = re.search(kshort + r"\s+SQ_INSTS_VALU\s+([0-9.]+) per launch", text)
-            if not (m and file_rows == rows):
-                continue
-            insts = float(m.group(1))
-            ms = re.search(kshort + r"\s+SQ_INSTS_SALU\s+([0-9.]+) per launch", text)
-            salu = float(ms.group(1)) if ms else 0.0
-            # static mix of the hot loops (tools/static_mix.py) and the measured issue time of each class
-            # (tools/ubench_wave.hip → profiles/r02a_ubench_wave.txt, wall ns per wave-instruction per SIMD)
-            f_mad, f_dpp, nop_per_valu = 15.0 / 72.0, 0.38, 0.065
-            for sp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_static_mix.txt")), reverse=True):
-                st = open(sp).read()
-                if kname.split("<")[0] in st:
-                    f_mad = float(re.search(r"v_mad_u64_u32 share of VALU[^:]*: ([0-9.]+)", st).group(1))
-                    f_dpp = float(re.search(r"DPP share of VALU[^:]*: ([0-9.]+)", st).group(1))
-                    nop_per_valu = float(re.search(r"s_nop per VALU instruction[^:]*: ([0-9.]+)", st).group(1))
-                    break
-            waves_per_simd = max(1.0, rows * 16 / 64 / 1024) if "rows_kernel" in kname else 1.0
-            # ns per wave-instruction per SIMD: plain VALU / DPP / v_mad_u64_u32 at 1 and at 2 wavefronts per SIMD
-            t_plain, t_dpp, t_mad = (2.07, 2.22, 2.50) if waves_per_simd < 1.5 else (1.11, 1.93, 2.19)
-            ns_per_valu = f_mad * t_mad + (f_dpp - 0.0) * t_dpp + (1.0 - f_mad - f_dpp) * t_plain
-            peak_measured = 1024 / (ns_per_valu * 1e-9)            # VALU wave-instructions per second, whole chip
-            peak_guide = 1024 * 2.4e9 / 2.0                        # the guide: a wave64 VALU instruction issues over 2 cycles
-            ach = insts / avg_kernel_s
-            valu = {"wave_insts_per_launch": insts, "salu_insts_per_launch": salu, "achieved_ginst_s": ach / 1e9,
-                    "peak_ginst_s": peak_guide / 1e9, "frac": ach / peak_guide,
-                    "peak_at_this_occupancy_ginst_s": peak_measured / 1e9, "frac_of_peak_at_this_occupancy": ach / peak_measured,
-                    "waves_per_simd": waves_per_simd, "mad_share": f_mad, "dpp_share": f_dpp, "s_nop_per_valu": nop_per_valu,
-                    "note": "peak_ginst_s = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (the guide); "
-                            "peak_at_this_occupancy = 1024 SIMDs / (mix-weighted issue time of ONE resident wavefront per SIMD: "
-                            "2.07 ns plain, 2.22 ns DPP, 2.50 ns v_mad_u64_u32 — profiles/r02a_ubench_wave.txt): this batch size "
-                            "gives the row-per-signature kernel exactly one wavefront per SIMD, so that is its ceiling",
-                    "source": os.path.relpath(path, ROOT)}
-            break
-    except (OSError, ValueError, AttributeError):
-        pass
+        valu = valu_issue(kname, rows, avg_kernel_s)
+    except (OSError, ValueError, AttributeError, IndexError):
+        valu = None
     return traffic, valu
 
 
@@ -290,10 +343,18 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
                     warm_l = bv.lanes_per_signature
                 kern = kms / max(kl, 1) / 1e3
                 ent = out[i] if path == "warm" else {"validators": n}
+                kn = kernel_name(path, cold_l, warm_l)
+                try:
+                    vi = valu_issue(kn, n, kern)
+                except (OSError, ValueError, AttributeError, IndexError):
+                    vi = None
+                if vi:   # the sweep keeps the numbers, the headline object the prose
+                    vi = {k: v for k, v in vi.items() if k not in ("note",)}
                 ent[path] = {"verifies_per_s": n * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": kern * 1e3,
-                             "kernel": kernel_name(path, cold_l, warm_l),
+                             "kernel": kn,
                              "hbm_gb_s": n * ALGO_BYTES_PER_VERIFY / kern / 1e9,
-                             "hbm_frac": n * ALGO_BYTES_PER_VERIFY / kern / 1e9 / HBM_PEAK_GBS}
+                             "hbm_frac": n * ALGO_BYTES_PER_VERIFY / kern / 1e9 / HBM_PEAK_GBS,
+                             "valu_issue": vi}
                 if path == "cold":
                     out.append(ent)
         finally:

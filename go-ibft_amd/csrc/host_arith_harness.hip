@@ -78,6 +78,25 @@ int dev_ecmult_var(const uint8_t *k, const uint8_t *p64, uint8_t *out64) {
   return ok ? 1 : 0;
 }
 
+// the same through round 1's form (unsigned 4-bit windows, 15 Jacobian multiples, full additions): the cross-check of the
+// signed-window / common-Z form above
+int dev_ecmult_var_v1(const uint8_t *k, const uint8_t *p64, uint8_t *out64) {
+  ibftk::aff P;
+  P.x = fin(p64);
+  P.y = fin(p64 + 32);
+  ibftk::jac q = ibftk::ecmult_var_v1(P, secp::from_be32(k));
+  ibftk::aff a;
+  bool ok = secp::jac_to_aff(a, q);
+  secp::to_be32(out64, secp::l26_to_u256(a.x));
+  secp::to_be32(out64 + 32, secp::l26_to_u256(a.y));
+  return ok ? 1 : 0;
+}
+// signed digits of a 128-bit scalar as ecmult_var recodes them: out[i] = digit i + 8 (33 bytes)
+void dev_window_digits(const uint8_t *k, uint8_t *out33) {
+  const secp::u256 b = ibftk::window_bias(secp::from_be32(k));
+  for (int i = 0; i < ibftk::WINDOW_DIGITS; i++) out33[i] = (uint8_t)secp::nibble(b, i);
+}
+
 // affine x of k1·G + k2·G through jac_add (via_aff = 0) or jac_add_aff (1); returns 0 for infinity
 int dev_point_add_case(const uint8_t *k1, const uint8_t *k2, int via_aff, uint8_t *out32) {
   ibftk::aff g = secp::generator();

@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
       entry = a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt);
     }
     aff pt = load_affine(entry);
-    jac sum = secp::jac_add_aff(acc, pt);
+    jac sum = secp::jac_add_aff_t<true>(acc, pt);  // (the one inlined copy of the mixed addition: secp256k1_dev.h)
     acc = secp::jac_select(has && dgt != 0, sum, acc);
   }
 #pragma unroll 1
@@ -649,24 +649,29 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
       acc = secp::jac_select(dg != 0, sum, acc);
     }
   } else {
-    jac tab[16];
-    tab[0] = secp::jac_inf();
-    tab[1] = base;
-    tab[2] = secp::jac_dbl(base);
+    // signed radix-16 windows over a table of the multiples 1…8 of this lane's base brought to one common Z (recover_dev.h:
+    // ecmult_table).  The base is Jacobian (X, Y, Z) — the AFFINE point (X, Y) of the isomorphic curve y² = x³ + 7·Z⁶, on
+    // which the table is built and the loop runs; Z·Zc goes back into the accumulator's Z at the end.  The λ half uses the
+    // entries' β·X, the sign of a digit is a negation of Y.  Digit j of a piece = nibble(k + Σ 8·16^i, piece·NIBS + j) − 8;
+    // the half's 33rd digit (the carry, 0 or 1) belongs to its top piece — the other pieces see a zero digit there.
+    aff b1;
+    b1.x = base.x;
+    b1.y = base.y;
+    wtab wt;
+    ecmult_table(b1, wt);
+    const u256 kb = window_bias(kk);
 #pragma unroll 1
-    for (int i = 3; i < 16; i++) tab[i] = secp::jac_add(tab[i - 1], base);
+    for (int nib = NIBS; nib >= 0; nib--) {
+      if (nib != NIBS) {
 #pragma unroll 1
-    for (int nib = NIBS - 1; nib >= 0; nib--) {
-#pragma unroll 1
-      for (int d = 0; d < 4; d++) acc = secp::jac_dbl(acc);
-      const uint32_t dg = secp::nibble(kk, (int)(piece * NIBS) + nib);
-      jac q = tab[dg];
-      secp::fe bx = secp::fe_mul(q.x, beta);
-      q.x = secp::l26_select(half != 0, bx, q.x);
-      q.y = secp::l26_select(flip, secp::fe_neg(q.y, 1), q.y);
-      jac sum = secp::jac_add(acc, q);
-      acc = secp::jac_select(dg != 0, sum, acc);
+        for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+      }
+      const int at = (int)(piece * NIBS) + nib;
+      const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
+      const int e = mine ? (int)secp::nibble(kb, at) - 8 : 0;
+      acc = window_add(acc, wt, e, half != 0, flip);
     }
+    acc.z = secp::fe_mul(acc.z, secp::fe_mul(wt.zc, base.z));
   }
   // u1·G: the fixed-base windows are dealt to the lanes of the group
 #pragma unroll 1

@@ -71,8 +71,10 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
   }
 }
 
-// u1*G from the fixed-base table (GTAB_WINDOWS mixed adds, no doublings)
+// u1*G from the fixed-base table (GTAB_WINDOWS mixed adds, no doublings); one inlined copy of the mixed addition
+// in a rolled loop (secp256k1_dev.h: the INL code shape)
 __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ gtab, const u256 &k, jac acc) {
+#pragma unroll 1
   for (int w = 0; w < GTAB_WINDOWS; w++) {
     uint32_t dgt = (k.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
     const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
@@ -83,16 +85,104 @@ __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ 
     q.x.n[8] = t2.x; q.x.n[9] = t2.y; q.y.n[0] = t2.z; q.y.n[1] = t2.w;
     q.y.n[2] = t3.x; q.y.n[3] = t3.y; q.y.n[4] = t3.z; q.y.n[5] = t3.w;
     q.y.n[6] = t4.x; q.y.n[7] = t4.y; q.y.n[8] = t4.z; q.y.n[9] = t4.w;
-    jac sum = secp::jac_add_aff(acc, q);
-    if (dgt != 0) acc = sum;
+    jac sum = secp::jac_add_aff_t<true>(acc, q);
+    acc = secp::jac_select(dgt != 0, sum, acc);
   }
   return acc;
 }
 
-// u2*R through the GLV split: u2 = k1 + k2·λ with 128-bit |k1|, |k2|, so 128 doublings instead
-// of 256.  One per-lane table of j·(±R), j = 1..15; the λ-multiple of an entry is (β·X, Y, Z),
-// its sign is folded into Y.  4-bit fixed windows, MSB first, both scalars share the doublings.
+// ---- u2·R: GLV split, signed radix-16 windows, a window table with ONE common Z (round 4) -----------------------
+// u2 = k1 + k2·λ with 128-bit |k1|, |k2| (128 doublings instead of 256).  Each half is recoded into 33 signed digits
+// e_i ∈ [−8, 7] without a carry chain: with C = Σ_{i<33} 8·16^i, digit i of k is nibble_i(k + C) − 8 — so the table
+// holds the multiples 1…8 of ±R only (the sign of a digit is a negation of Y) instead of 1…15.
+// The eight multiples are brought to ONE common Z ("effective affine"): with Zc = z₂·…·z₈ and s_i = Zc / z_i
+// (prefix / suffix products, no inversion) entry i becomes (x_i·s_i², y_i·s_i³) — the AFFINE point of i·R on the
+// isomorphic curve y² = x³ + 7·Zc⁶.  The a = 0 formulas never read the curve constant, so the main loop runs on that
+// curve with MIXED additions (7M + 4S instead of 11M + 5S, 66 times), the λ-multiples are the same entries with X·β
+// (computed once per entry instead of once per addition), and Zc is multiplied into the accumulator's Z once at the end.
+// Round 1's form (15 Jacobian multiples, full additions, β per addition) is kept below for the CPU cross-check.
+struct wtab {
+  secp::fe x[9], y[9], bx[9];  // entries 1…8 (0 unused); bx = β·x
+  secp::fe zc;
+};
+__host__ __device__ __forceinline__ void ecmult_table(const aff &R1, wtab &t) {
+  jac m[9];
+  m[1] = secp::jac_from_aff(R1);
+  m[2] = secp::jac_dbl(m[1]);
+  m[3] = secp::jac_add_aff(m[2], R1);
+  m[4] = secp::jac_dbl(m[2]);
+  m[5] = secp::jac_add_aff(m[4], R1);
+  m[6] = secp::jac_dbl(m[3]);
+  m[7] = secp::jac_add_aff(m[6], R1);
+  m[8] = secp::jac_dbl(m[4]);
+  secp::fe pre[9], suf[10];  // pre[i] = z₂·…·z_i, suf[i] = z_i·…·z₈
+  pre[1] = secp::fe_one();
+  pre[2] = m[2].z;
+#pragma unroll 1
+  for (int i = 3; i <= 8; i++) pre[i] = secp::fe_mul(pre[i - 1], m[i].z);
+  suf[9] = secp::fe_one();
+  suf[8] = m[8].z;
+#pragma unroll 1
+  for (int i = 7; i >= 2; i--) suf[i] = secp::fe_mul(suf[i + 1], m[i].z);
+  t.zc = pre[8];
+  const secp::fe beta = secp::GLV_CONST(1);
+#pragma unroll 1
+  for (int i = 1; i <= 8; i++) {
+    const secp::fe s = i == 1 ? pre[8] : secp::fe_mul(pre[i - 1], suf[i + 1]);  // Zc / z_i  (z₁ = 1)
+    const secp::fe s2 = secp::fe_sqr(s);
+    t.x[i] = secp::fe_mul(m[i].x, s2);
+    t.y[i] = secp::fe_mul(m[i].y, secp::fe_mul(s2, s));
+    t.bx[i] = secp::fe_mul(t.x[i], beta);
+  }
+}
+// k + Σ_{i<33} 8·16^i (k < 2^128): nibble i of the sum, minus 8, is the signed digit i of k
+__host__ __device__ __forceinline__ u256 window_bias(const u256 &k) {
+  u256 r = secp::zero256();
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++) r.v[i] = secp::addc(i < 4 ? k.v[i] : 0u, i < 4 ? 0x88888888u : 0x8u, c);
+  return r;
+}
+constexpr int WINDOW_DIGITS = 33;
+// one signed-window addition: acc ± entry |e| of the table (X or β·X), nothing for e = 0; the INL code shape
+__host__ __device__ __forceinline__ jac window_add(const jac &acc, const wtab &t, int e, bool lambda, bool flip) {
+  const uint32_t mag = (uint32_t)(e < 0 ? -e : e);
+  const uint32_t idx = mag ? mag : 1u;  // (a dummy operand for e = 0: the sum is computed and dropped)
+  aff q;
+  q.x = secp::l26_select(lambda, t.bx[idx], t.x[idx]);
+  const secp::fe y = t.y[idx];
+  q.y = secp::l26_select((e < 0) != flip, secp::fe_neg(y, 1), y);  // magnitude ≤ 2
+  const jac sum = secp::jac_add_aff_t<true>(acc, q);
+  return secp::jac_select(mag != 0, sum, acc);
+}
 __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) {
+  secp::glv_split sp = secp::sc_split_lambda(k);
+  aff R1 = R;
+  R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
+  const bool flip2 = sp.neg1 != sp.neg2;
+  wtab t;
+  ecmult_table(R1, t);
+  const u256 k1 = window_bias(sp.k1), k2 = window_bias(sp.k2);
+  jac acc = secp::jac_inf();
+#pragma unroll 1
+  for (int i = WINDOW_DIGITS - 1; i >= 0; i--) {
+    if (i != WINDOW_DIGITS - 1) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+      const int e = (int)(h ? secp::nibble(k2, i) : secp::nibble(k1, i)) - 8;
+      acc = window_add(acc, t, e, h != 0, h != 0 && flip2);
+    }
+  }
+  acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve
+  return acc;
+}
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Round 1's u2·R (4-bit unsigned windows over 15 Jacobian multiples, full additions): host builds only — the CPU
+// harness checks the new form against it on random and adversarial scalars (tests/test_dev_arith_host.py)
+__host__ __device__ __forceinline__ jac ecmult_var_v1(const aff &R, const u256 &k) {
   secp::glv_split sp = secp::sc_split_lambda(k);
   aff R1 = R;
   R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
@@ -117,6 +207,7 @@ __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) 
   }
   return acc;
 }
+#endif
 
 // Recover the signer address of (digest z, r, s, v); returns false if the signature
 // is rejected (same rejection list as oracle/secp256k1.c:orc_ecrecover).

@@ -766,25 +766,48 @@ HD jac jac_from_aff(const aff &a) {
   r.inf = false;
   return r;
 }
+// The point formulas exist in two code shapes (template parameter INL):
+//   false  every field multiplication is a CALL of fe_mul_fn / fe_sqr_fn (≈30 instructions of argument moves and
+//          s_swappc per call, small code) — everything that runs a handful of times per signature;
+//   true   the multiplications are INLINED into the formula (no call overhead, ≈1.5–2.5 k instructions per formula) —
+//          for the ONE copy of the doubling and of the mixed addition inside a rolled main loop, where ≈3/4 of a
+//          recovery's multiplications are (round 4; the fully inlined kernel of round 1 was 53 k instructions and
+//          instruction fetch set its time — one inlined copy per loop stays far inside the 64 KB instruction cache).
+template <bool INL>
+HD fe fe_mul_t(const fe &a, const fe &b) {
+  if constexpr (INL)
+    return fe_mul_inl(a, b);
+  else
+    return fe_mul(a, b);
+}
+template <bool INL>
+HD fe fe_sqr_t(const fe &a) {
+  if constexpr (INL)
+    return fe_sqr_inl(a);
+  else
+    return fe_sqr(a);
+}
 // dbl-2009-l: 2M + 5S.  Magnitudes in comments.
-HD jac jac_dbl(const jac &p) {
-  fe A = fe_sqr(p.x);                                   // 1
-  fe B = fe_sqr(p.y);                                   // 1
-  fe C = fe_sqr(B);                                     // 1
-  fe t = fe_sqr(fe_add(p.x, B));                        // in 2 -> 1
+template <bool INL>
+HD jac jac_dbl_t(const jac &p) {
+  fe A = fe_sqr_t<INL>(p.x);                            // 1
+  fe B = fe_sqr_t<INL>(p.y);                            // 1
+  fe C = fe_sqr_t<INL>(B);                              // 1
+  fe t = fe_sqr_t<INL>(fe_add(p.x, B));                 // in 2 -> 1
   t = fe_add(fe_add(t, fe_neg(A, 1)), fe_neg(C, 1));    // 1+2+2 = 5
   fe D = fe_normalize_weak(fe_mul_int(t, 2));           // 10 -> 1
   fe E = fe_mul_int(A, 3);                              // 3
-  fe F = fe_sqr(E);                                     // 1
+  fe F = fe_sqr_t<INL>(E);                              // 1
   jac r;
   r.x = fe_normalize_weak(fe_add(F, fe_neg(fe_mul_int(D, 2), 2)));       // 1 + 3 = 4 -> 1
   fe C8 = fe_mul_int(C, 8);                                              // 8
-  fe y3 = fe_add(fe_mul(E, fe_add(D, fe_neg(r.x, 1))), fe_neg(C8, 8));   // E:3, D−X3: 1+2=3; 1 + 9 = 10
+  fe y3 = fe_add(fe_mul_t<INL>(E, fe_add(D, fe_neg(r.x, 1))), fe_neg(C8, 8));   // E:3, D−X3: 1+2=3; 1 + 9 = 10
   r.y = fe_normalize_weak(y3);
-  r.z = fe_mul(fe_mul_int(p.y, 2), p.z);                                 // in 2,1 -> 1
+  r.z = fe_mul_t<INL>(fe_mul_int(p.y, 2), p.z);                          // in 2,1 -> 1
   r.inf = p.inf;  // no point of order 2 on this curve: y = 0 cannot occur for on-curve input
   return r;
 }
+HD jac jac_dbl(const jac &p) { return jac_dbl_t<false>(p); }
 // add-2007-bl: 11M + 5S, exceptional cases handled (rare, divergent)
 HD jac jac_add(const jac &p, const jac &q) {
   fe z1z1 = fe_sqr(p.z);
@@ -821,33 +844,35 @@ HD jac jac_add(const jac &p, const jac &q) {
   return r;
 }
 // madd-2007-bl: 7M + 4S (q affine, never infinity)
-HD jac jac_add_aff(const jac &p, const aff &q) {
-  fe z1z1 = fe_sqr(p.z);
-  fe u2 = fe_mul(q.x, z1z1);
-  fe s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
+template <bool INL>
+HD jac jac_add_aff_t(const jac &p, const aff &q) {
+  fe z1z1 = fe_sqr_t<INL>(p.z);
+  fe u2 = fe_mul_t<INL>(q.x, z1z1);
+  fe s2 = fe_mul_t<INL>(fe_mul_t<INL>(q.y, p.z), z1z1);
   fe h = fe_add(u2, fe_neg(p.x, 1));   // 3
   fe rr = fe_add(s2, fe_neg(p.y, 1));  // 3
-  fe hh = fe_sqr(h);                   // 1
+  fe hh = fe_sqr_t<INL>(h);            // 1
   fe i = fe_mul_int(hh, 4);            // 4
-  fe j = fe_mul(h, i);                 // 1
+  fe j = fe_mul_t<INL>(h, i);          // 1
   fe r2 = fe_mul_int(rr, 2);           // 6
-  fe v = fe_mul(p.x, i);               // 1
+  fe v = fe_mul_t<INL>(p.x, i);        // 1
   jac r;
-  r.x = fe_normalize_weak(fe_add(fe_add(fe_sqr(r2), fe_neg(j, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // 6 -> 1
-  fe y1j2 = fe_mul_int(fe_mul(p.y, j), 2);                                                         // 2
-  r.y = fe_normalize_weak(fe_add(fe_mul(r2, fe_add(v, fe_neg(r.x, 1))), fe_neg(y1j2, 2)));         // 4 -> 1
+  r.x = fe_normalize_weak(fe_add(fe_add(fe_sqr_t<INL>(r2), fe_neg(j, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // 6 -> 1
+  fe y1j2 = fe_mul_int(fe_mul_t<INL>(p.y, j), 2);                                                         // 2
+  r.y = fe_normalize_weak(fe_add(fe_mul_t<INL>(r2, fe_add(v, fe_neg(r.x, 1))), fe_neg(y1j2, 2)));         // 4 -> 1
   // Z3 = (Z1+H)² − Z1Z1 − HH
-  r.z = fe_normalize_weak(fe_add(fe_add(fe_sqr(fe_add(p.z, h)), fe_neg(z1z1, 1)), fe_neg(hh, 1)));  // in 4; 5 -> 1
+  r.z = fe_normalize_weak(fe_add(fe_add(fe_sqr_t<INL>(fe_add(p.z, h)), fe_neg(z1z1, 1)), fe_neg(hh, 1)));  // in 4; 5 -> 1
   r.inf = false;
   const bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
   const bool same = !p.inf && hz && rz;
   const bool opposite = !p.inf && hz && !rz;
   const jac qj = jac_from_aff(q);
-  if (wave_any(same)) r = jac_select(same, jac_dbl(qj), r);
+  if (wave_any(same)) r = jac_select(same, jac_dbl_t<false>(qj), r);  // (rare: the call shape keeps the loop body small)
   r = jac_select(opposite, jac_inf(), r);
   r = jac_select(p.inf, qj, r);
   return r;
 }
+HD jac jac_add_aff(const jac &p, const aff &q) { return jac_add_aff_t<false>(p, q); }
 // returns false if p is infinity; r.x / r.y are canonical (fully normalised)
 HD bool jac_to_aff(aff &r, const jac &p) {
   fe zi = fe_inv(p.z);

@@ -85,13 +85,23 @@ __host__ __device__ __forceinline__ bool verify_known(const uint32_t *__restrict
   u256 u1, u2;
   verify_scalars(z_raw, r, s, u1, u2);
   jac acc = secp::jac_inf();
-  for (int w = 0; w < QTAB_WINDOWS; w++) {
-    uint32_t dgt = (u2.v[w >> 2] >> (8 * (w & 3))) & 255u;
-    aff q = load_affine(qtab_v + (size_t)GTAB_ENTRY_DWORDS * (w * QTAB_ENTRIES + dgt));
-    jac sum = secp::jac_add_aff(acc, q);
+  // ONE rolled loop over the 32 + GTAB_WINDOWS table points (one inlined copy of the mixed addition: secp256k1_dev.h)
+#pragma unroll 1
+  for (int w = 0; w < QTAB_WINDOWS + GTAB_WINDOWS; w++) {
+    uint32_t dgt;
+    const uint32_t *entry;
+    if (w < QTAB_WINDOWS) {
+      dgt = (u2.v[w >> 2] >> (8 * (w & 3))) & 255u;
+      entry = qtab_v + (size_t)GTAB_ENTRY_DWORDS * (w * QTAB_ENTRIES + dgt);
+    } else {
+      const int g = w - QTAB_WINDOWS;
+      dgt = (u1.v[(g * GTAB_BITS) >> 5] >> ((g * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+      entry = gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)g * GTAB_ENTRIES + dgt);
+    }
+    aff q = load_affine(entry);
+    jac sum = secp::jac_add_aff_t<true>(acc, q);
     acc = secp::jac_select(dgt != 0, sum, acc);
   }
-  acc = ecmult_gen(gtab, u1, acc);
   return verify_finish(acc, r, v) && ok;
 }
 

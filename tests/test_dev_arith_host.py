@@ -128,6 +128,38 @@ def test_glv_split_and_variable_base_mult(dev):
             assert o.raw == R.pub_bytes(exp)
 
 
+def test_signed_window_form_of_the_variable_base_multiplication(dev):
+    """round 4: ecmult_var recodes each GLV half into 33 signed radix-16 digits (digit i = nibble_i(k + Σ 8·16^i) − 8, no carry
+    chain), uses a table of the multiples 1…8 brought to ONE common Z (mixed additions on the isomorphic curve) and multiplies
+    the common Z back in at the end.  (1) the digits reconstruct the scalar and stay in [−8, 7]; (2) the result equals round
+    1's form (unsigned windows, 15 Jacobian multiples, full additions) and the big-int reference on random scalars and on
+    scalars whose halves are all-0 / all-7 / all-8 / all-F nibbles, powers of 16 and their neighbours — every digit value,
+    the carry into digit 32, additions that hit the point at infinity."""
+    rng = np.random.default_rng(17)
+    halves = [0, 1, 7, 8, 9, 15, 16, 2**128 - 1, 2**127, 2**127 - 1, int("7" * 32, 16), int("8" * 32, 16), int("f" * 32, 16),
+              int("78" * 16, 16), int("87" * 16, 16), 8 * 16**31, 8 * 16**31 - 1, 16**31] + \
+             [int.from_bytes(rng.bytes(16), "big") for _ in range(200)]
+    for h in halves:
+        o = C.create_string_buffer(33)
+        dev.dev_window_digits(b32(h), o)
+        digits = [b - 8 for b in o.raw]
+        assert all(-8 <= d <= 7 for d in digits) and digits[32] in (0, 1)
+        assert sum(d * 16**i for i, d in enumerate(digits)) == h
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    special = [0, 1, 2, 7, 8, 9, 15, 16, 17, 2**128 - 1, 2**128, 2**128 + 1, N - 1, N - 8, N - 9, lam, lam + 1, (8 * lam) % N, (lam * 15 + 8) % N,
+               int("8" * 32, 16), (int("8" * 32, 16) * lam + int("7" * 32, 16)) % N, (int("f" * 32, 16) * lam + int("f" * 32, 16)) % N]
+    ks = special + [int.from_bytes(rng.bytes(32), "big") % N for _ in range(40)]
+    pts = [R.G] + [R.pt_mul(int.from_bytes(rng.bytes(24), "big") + 1, R.G) for _ in range(3)]
+    for j, k in enumerate(ks):
+        pt = pts[j % len(pts)]
+        a, b = C.create_string_buffer(64), C.create_string_buffer(64)
+        oa, ob = dev.dev_ecmult_var(b32(k), R.pub_bytes(pt), a), dev.dev_ecmult_var_v1(b32(k), R.pub_bytes(pt), b)
+        exp = R.pt_mul(k, pt)
+        assert bool(oa) == bool(ob) == (exp is not None), hex(k)
+        if exp is not None:
+            assert a.raw == b.raw == R.pub_bytes(exp), hex(k)
+
+
 def _point_add_cases():
     rng = np.random.default_rng(21)
     ks = [int.from_bytes(rng.bytes(32), "big") % N for _ in range(6)] + [1, 2, N - 1]
