@@ -447,10 +447,24 @@ HD fe fe_one() {
   r.n[0] = 1;
   return r;
 }
+// n squarings in a row (the √ and inversion chains: 253 of a recovery's ≈266 √-chain operations).  On the device ONE
+// outlined function holds a rolled loop around the INLINED squaring: a run of n squarings costs one call instead of n
+// (round 4: the argument moves and register traffic around a call cost more than the ≈30 instructions they look like).
+// n must be wave-uniform (it always is a constant of the chain).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __attribute__((noinline)) fe fe_sqr_n_fn(SECP_ARGS10(a), int n) {
+  fe a = SECP_PACK10(a);
+#pragma unroll 1
+  for (int i = 0; i < n; i++) a = fe_sqr_inl(a);
+  return a;
+}
+HD fe fe_sqr_n(fe a, int n) { return fe_sqr_n_fn(SECP_PASS10(a), n); }
+#else
 HD fe fe_sqr_n(fe a, int n) {
   for (int i = 0; i < n; i++) a = fe_sqr(a);
   return a;
 }
+#endif
 // shared prefix of the p−2 and (p+1)/4 addition chains: x223 = a^(2^223 − 1) etc.
 struct fe_chain {
   fe x2, x3, x22, x223;
