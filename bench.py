@@ -53,7 +53,7 @@ FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 
 def kernel_name(path: str, cold_lanes: int, warm_lanes: int) -> str:
     if path == "cold":
-        return {1: "ecrecover_lane_kernel<0>", 64: "ecrecover_wave_kernel<0>",
+        return {1: "ecrecover_lane_kernel<0>", 64: "ecrecover_wave_kernel<0>", 128: "ecrecover_wave2_kernel<0>",
                 16: "ecrecover_rows_kernel<0>"}.get(cold_lanes, f"ecrecover_group_kernel<0,{cold_lanes}>")
     return {64: "verify_known_wave_kernel<0>", 1: "verify_known_lane_kernel<0>"}.get(
         warm_lanes, f"verify_known_group_kernel<0,{warm_lanes}>")
@@ -139,7 +139,7 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
 # one / two / four resident wavefronts per SIMD
 ISSUE_NS = {1: {"plain": 2.07, "dpp": 2.22, "mad": 2.50}, 2: {"plain": 1.11, "dpp": 1.93, "mad": 2.19},
             4: {"plain": 0.99, "dpp": 1.86, "mad": 2.13}}
-LANES_OF = {"ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 1, "ecrecover_rows_kernel": 16, "ecrecover_wave_kernel": 64,
+LANES_OF = {"ecrecover_wave2_kernel": 128, "ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 1, "ecrecover_rows_kernel": 16, "ecrecover_wave_kernel": 64,
             "verify_known_wave_kernel": 64}
 # wavefronts a SIMD can hold (512 registers per lane: go-ibft_amd/csrc resource usage, tools/occupancy.py)
 RESIDENT_CAP = {"ecrecover_lane_kernel": 2, "verify_known_lane_kernel": 2, "ecrecover_rows_kernel": 2, "ecrecover_wave_kernel": 2,
@@ -163,7 +163,7 @@ def _static_mix(kname: str):
                     continue
                 if f_mad > 0:
                     return f_mad, f_dpp, nop, os.path.relpath(sp, ROOT)
-    if "wave_kernel" in kname:      # the one-wavefront-per-signature kernels run the row-layout code (wfe_mul) inside calls
+    if "wave_kernel" in kname or "wave2_kernel" in kname:      # the one- / two-wavefront-per-signature kernels run the row-layout code (wfe_mul) inside calls
         return _static_mix("ecrecover_rows_kernel<0>")
     return None
 

@@ -93,6 +93,30 @@ void lane_rec(void *vp) {
   j->ok[l] = ok ? 1 : 0;
 }
 
+// the two-wavefront form: the helper's half, then the main half, on one emulated wavefront each, `sh` in plain memory
+struct rec2_job {
+  const uint8_t *hash32, *sig65;
+  uint32_t flags;
+  uint8_t *addr20;
+  int *ok;
+  wv::pair_shared *sh;
+};
+void lane_rec2_helper(void *vp) {
+  rec2_job *j = (rec2_job *)vp;
+  u256 z = secp::from_be32(j->hash32), r = secp::from_be32(j->sig65), s = secp::from_be32(j->sig65 + 32);
+  wv::recover_helper_wave(g_gtab.data(), z, r, s, j->sh, wv::no_sync());
+}
+void lane_rec2_main(void *vp) {
+  rec2_job *j = (rec2_job *)vp;
+  u256 z = secp::from_be32(j->hash32), r = secp::from_be32(j->sig65), s = secp::from_be32(j->sig65 + 32);
+  uint32_t a[5];
+  secp::aff Q;
+  bool ok = wv::recover_pubkey_wave<99, true>(g_gtab.data(), z, r, s, j->sig65[64], j->flags, a, Q, j->sh, wv::no_sync());
+  const int l = wave_emul::lane();
+  memcpy(j->addr20 + 20 * l, a, 20);
+  j->ok[l] = ok ? 1 : 0;
+}
+
 struct pre_job {
   const uint32_t *x;  // [10]
   uint32_t *out;      // [4][16] PX, then PY, PZ, yc : 4 × 64
@@ -202,6 +226,14 @@ void wvh_pt_op(int op, const uint32_t *p, const uint32_t *q, uint32_t *out) {
 void wvh_recover(const uint8_t *hash32, const uint8_t *sig65, uint32_t flags, uint8_t *addr64x20, int *ok64) {
   rec_job j{hash32, sig65, flags, addr64x20, ok64};
   wave_emul::run(lane_rec, &j);
+}
+// two wavefronts per signature: helper (scalars, u1·G) then main, sharing `sh` — sequential here, concurrent on the device
+void wvh_recover2(const uint8_t *hash32, const uint8_t *sig65, uint32_t flags, uint8_t *addr64x20, int *ok64) {
+  wv::pair_shared sh;
+  memset(&sh, 0xA5, sizeof sh);  // (nothing may be read before the helper wrote it)
+  rec2_job j{hash32, sig65, flags, addr64x20, ok64, &sh};
+  wave_emul::run(lane_rec2_helper, &j);
+  wave_emul::run(lane_rec2_main, &j);
 }
 uint32_t wvh_neg_limb(int which, int i) { return wv::wneg_limb(which, i); }
 

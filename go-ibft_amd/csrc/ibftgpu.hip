@@ -151,6 +151,8 @@ struct ibft_ctx {
   uint32_t warm_group_force = 0;  // IBFT_WARM_LANES=1|2|…|64 (experiments: pin the warm kernel variant)
   uint32_t rows_kernel_max = 8192;  // AUTO: a DPP row per signature above wave_rows_max up to this many rows
                                     // (4 096 rows: 0.55 ms vs 0.84 ms for the 8-lane kernel; 8 192: 0.84 vs 0.86)
+  uint32_t pair_rows_max = 512;   // AUTO: TWO wavefronts per signature up to this many rows (≤ one wavefront per SIMD in all;
+                                  // IBFT_PAIR_ROWS_MAX=0 turns the form off)
   uint32_t wave_rows_max = 2048;  // AUTO: one wavefront per signature up to this many rows (two per SIMD: 0.45 ms); the
                                   // row-per-signature kernel (0.55 ms up to 4 096 rows) wins from there
 
@@ -413,7 +415,8 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
   if (c->cold_group_force) {
     CG = c->cold_group_force;
   } else if (c->cold_group_auto) {
-    if ((uint64_t)n <= c->wave_rows_max) CG = 64;
+    if ((uint64_t)n <= c->pair_rows_max) CG = 128;
+    else if ((uint64_t)n <= c->wave_rows_max) CG = 64;
     else if ((uint64_t)n <= c->rows_kernel_max) CG = 16;
     else if ((uint64_t)n * 8 <= 65536ull) CG = 8;
     else if ((uint64_t)n * 4 <= 65536ull) CG = 4;
@@ -427,6 +430,13 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
       hipLaunchKernelGGL(ibftk::ecrecover_rows_kernel<0>, rgrid, rblock, 0, c->stream, a);
     else
       hipLaunchKernelGGL(ibftk::ecrecover_rows_kernel<1>, rgrid, rblock, 0, c->stream, a);
+  } else if (CG == 128) {
+    if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
+    const dim3 pgrid((n + ibftk::PAIRS_PER_BLOCK - 1) / ibftk::PAIRS_PER_BLOCK), pblock(128 * ibftk::PAIRS_PER_BLOCK);
+    if (mode == 0)
+      hipLaunchKernelGGL(ibftk::ecrecover_wave2_kernel<0>, pgrid, pblock, 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(ibftk::ecrecover_wave2_kernel<1>, pgrid, pblock, 0, c->stream, a);
   } else if (CG == 64) {
     if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     if (mode == 0)
@@ -1248,7 +1258,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
   if (const char *e = getenv("IBFT_COLD_LANES")) {
     const int g = atoi(e);
-    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64) c->cold_group_force = (uint32_t)g;
+    if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64 || g == 128) c->cold_group_force = (uint32_t)g;
   }
   if (const char *e = getenv("IBFT_WARM_LANES")) {
     const int g = atoi(e);
@@ -1261,6 +1271,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   if (const char *e = getenv("IBFT_CERT_OVERLAP")) c->cert_overlap = atoi(e) != 0;
   if (getenv("IBFT_DIGEST_FUSION")) c->digest_in_gather = true;
   if (const char *e = getenv("IBFT_WAVE_ROWS_MAX")) c->wave_rows_max = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("IBFT_PAIR_ROWS_MAX")) c->pair_rows_max = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("IBFT_ROWS_KERNEL_MAX")) c->rows_kernel_max = (uint32_t)strtoul(e, nullptr, 10);
   int rc = IBFT_OK;
   do {

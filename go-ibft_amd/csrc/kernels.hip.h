@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
 #pragma unroll 1
   for (int off = G / 2; off >= 1; off >>= 1) {
     jac other = shfl_xor_jac(acc, off);
-    acc = secp::jac_add(acc, other);
+    acc = secp::jac_add_t<true>(acc, other);  // (one inlined copy in the rolled butterfly)
   }
   ok = verify_finish(acc, r, v) && ok && crypto;
   if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
 #pragma unroll 1
   for (int off = G / 2; off >= 1; off >>= 1) {
     jac other = shfl_xor_jac(acc, off);
-    acc = secp::jac_add(acc, other);
+    acc = secp::jac_add_t<true>(acc, other);  // (one inlined copy in the rolled butterfly)
   }
   aff Qa;
   ok = secp::jac_to_aff_fast(Qa, acc) && ok;
@@ -738,6 +738,63 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) ecrecover_wave_kernel(
   uint32_t got[5];
   aff Qa;
   bool ok = wv::recover_pubkey_wave(a.gtab, z, r, s, v, a.flags, got, Qa);
+#pragma unroll
+  for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
+  if (lane == 0 && ok) {
+    learn_key(a, vi, Qa);
+    atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
+  }
+}
+
+// ---- cold path, TWO WAVEFRONTS PER SIGNATURE (n ≤ 512: round 4) ----------------------------------------------------
+// Half of the chip's SIMDs idle when n ≤ 512 signatures run one wavefront each.  A workgroup here is PAIRS_PER_BLOCK = 2 pairs
+// — four wavefronts, which land on the four SIMDs of ONE compute unit, so 512 rows are exactly one wavefront per SIMD of
+// the chip by construction: wavefront w < 2 is the MAIN wavefront of signature slot w (prefix doublings with √, table, main
+// loop, joins, Z⁻¹, Keccak), wavefront 2 + w its HELPER (r⁻¹ mod n, u₁, u₂, GLV split; then u₁·G) — the two meet in LDS at two
+// workgroup barriers (wave_fe_dev.h: recover_pubkey_wave<…, PAIR>, recover_helper_wave).  Every wavefront of the workgroup
+// passes both barriers, whatever its row turns out to be: a pair with nothing to do only synchronises.
+constexpr int PAIRS_PER_BLOCK = 2;
+template <int MODE>
+__global__ void __launch_bounds__(128 * PAIRS_PER_BLOCK) ecrecover_wave2_kernel(recover_args a) {
+  __shared__ wv::pair_shared sh[PAIRS_PER_BLOCK];
+  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t slot = w % PAIRS_PER_BLOCK;
+  const bool helper = w >= PAIRS_PER_BLOCK;
+  const uint32_t row_raw = blockIdx.x * PAIRS_PER_BLOCK + slot;
+  const bool live = row_raw < a.n;
+  const uint32_t row = live ? row_raw : a.n - 1;
+  const bool done = a.warm_done && a.warm_done[row] != 0;
+  uint32_t want[5];
+#pragma unroll
+  for (int i = 0; i < 5; i++) want[i] = reinterpret_cast<const uint32_t *>(a.signer20 + 20ull * row)[i];
+  const int vi = valset_lookup(a.vtab, a.vslot_mask, want);
+  const bool pre = a.pre_flags && a.pre_flags[row] != 0;
+  if (!helper && lane == 0 && live && !done) a.vidx[row] = vi;
+  const bool active = live && !done && !pre && vi >= 0;  // the same for both wavefronts of the pair
+  auto sync = [] { __syncthreads(); };
+  if (!active) {  // (wave-uniform) nothing to recover: keep the workgroup's barrier count
+    sync();
+    sync();
+    return;
+  }
+  const u256 r = secp::from_be32(a.sig65 + 65ull * row);
+  const u256 s = secp::from_be32(a.sig65 + 65ull * row + 32);
+  const uint32_t v = a.sig65[65ull * row + 64];
+  u256 z;
+  if (MODE == 0) {
+    z = secp::from_be32(a.hash32 + 32ull * row);
+  } else {
+    uint64_t d[4];
+    hash_range_dwords(a.payload + a.off[row], a.off[row + 1] - a.off[row], d);
+    keccak::digest_to_limbs(d, z.v);
+  }
+  if (helper) {
+    wv::recover_helper_wave(a.gtab, z, r, s, &sh[slot], sync);
+    return;
+  }
+  uint32_t got[5];
+  aff Qa;
+  bool ok = wv::recover_pubkey_wave<99, true>(a.gtab, z, r, s, v, a.flags, got, Qa, &sh[slot], sync);
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == want[i]);
   if (lane == 0 && ok) {

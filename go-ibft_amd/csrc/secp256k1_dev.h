@@ -823,40 +823,42 @@ HD jac jac_dbl_t(const jac &p) {
 }
 HD jac jac_dbl(const jac &p) { return jac_dbl_t<false>(p); }
 // add-2007-bl: 11M + 5S, exceptional cases handled (rare, divergent)
-HD jac jac_add(const jac &p, const jac &q) {
-  fe z1z1 = fe_sqr(p.z);
-  fe z2z2 = fe_sqr(q.z);
-  fe u1 = fe_mul(p.x, z2z2);
-  fe u2 = fe_mul(q.x, z1z1);
-  fe s1 = fe_mul(fe_mul(p.y, q.z), z2z2);
-  fe s2 = fe_mul(fe_mul(q.y, p.z), z1z1);
+template <bool INL>
+HD jac jac_add_t(const jac &p, const jac &q) {
+  fe z1z1 = fe_sqr_t<INL>(p.z);
+  fe z2z2 = fe_sqr_t<INL>(q.z);
+  fe u1 = fe_mul_t<INL>(p.x, z2z2);
+  fe u2 = fe_mul_t<INL>(q.x, z1z1);
+  fe s1 = fe_mul_t<INL>(fe_mul_t<INL>(p.y, q.z), z2z2);
+  fe s2 = fe_mul_t<INL>(fe_mul_t<INL>(q.y, p.z), z1z1);
   fe h = fe_add(u2, fe_neg(u1, 1));    // 3
   fe rr = fe_add(s2, fe_neg(s1, 1));   // 3
-  fe i = fe_sqr(fe_mul_int(h, 2));     // in 6 -> 1
-  fe j = fe_mul(h, i);                 // 1
+  fe i = fe_sqr_t<INL>(fe_mul_int(h, 2));  // in 6 -> 1
+  fe j = fe_mul_t<INL>(h, i);          // 1
   fe r2 = fe_mul_int(rr, 2);           // 6
-  fe v = fe_mul(u1, i);                // 1
+  fe v = fe_mul_t<INL>(u1, i);         // 1
   jac r;
   // X3 = r2² − J − 2V
-  r.x = fe_normalize_weak(fe_add(fe_add(fe_sqr(r2), fe_neg(j, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // 1+2+3 = 6 -> 1
+  r.x = fe_normalize_weak(fe_add(fe_add(fe_sqr_t<INL>(r2), fe_neg(j, 1)), fe_neg(fe_mul_int(v, 2), 2)));  // 1+2+3 = 6 -> 1
   // Y3 = r2·(V − X3) − 2·S1·J
-  fe s1j2 = fe_mul_int(fe_mul(s1, j), 2);                                                          // 2
-  r.y = fe_normalize_weak(fe_add(fe_mul(r2, fe_add(v, fe_neg(r.x, 1))), fe_neg(s1j2, 2)));         // 1 + 3 -> 1
+  fe s1j2 = fe_mul_int(fe_mul_t<INL>(s1, j), 2);                                                          // 2
+  r.y = fe_normalize_weak(fe_add(fe_mul_t<INL>(r2, fe_add(v, fe_neg(r.x, 1))), fe_neg(s1j2, 2)));         // 1 + 3 -> 1
   // Z3 = ((Z1+Z2)² − Z1Z1 − Z2Z2)·H
-  fe zz = fe_add(fe_add(fe_sqr(fe_add(p.z, q.z)), fe_neg(z1z1, 1)), fe_neg(z2z2, 1));              // 5
-  r.z = fe_mul(zz, h);                                                                             // in 5,3 -> 1
+  fe zz = fe_add(fe_add(fe_sqr_t<INL>(fe_add(p.z, q.z)), fe_neg(z1z1, 1)), fe_neg(z2z2, 1));              // 5
+  r.z = fe_mul_t<INL>(zz, h);                                                                             // in 5,3 -> 1
   r.inf = false;
   // exceptional cases, branch-free per lane; the doubling runs for the whole wave if any lane needs it
   const bool both = !p.inf && !q.inf;
   const bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
   const bool same = both && hz && rz;       // P == Q
   const bool opposite = both && hz && !rz;  // P == −Q
-  if (wave_any(same)) r = jac_select(same, jac_dbl(p), r);
+  if (wave_any(same)) r = jac_select(same, jac_dbl_t<false>(p), r);
   r = jac_select(opposite, jac_inf(), r);
   r = jac_select(q.inf, p, r);
   r = jac_select(p.inf, q, r);
   return r;
 }
+HD jac jac_add(const jac &p, const jac &q) { return jac_add_t<false>(p, q); }
 // madd-2007-bl: 7M + 4S (q affine, never infinity)
 template <bool INL>
 HD jac jac_add_aff_t(const jac &p, const aff &q) {

@@ -761,6 +761,24 @@ WVF bool wjac_to_aff(aff &r, const wjac &p, const wk &k) {
   return !(p.inf || secp::fe_is_zero(zf));
 }
 
+// u1·G summed into acc: the GTAB_WINDOWS fixed-base windows dealt to the four rows (rows hold partial sums: the caller joins)
+WVF wjac gen_windows_wave(const uint32_t *__restrict__ gtab, const u256 &u1, wjac acc, const wk &k) {
+  constexpr int WPR = ibftk::GTAB_WINDOWS / 4;
+#pragma unroll 1
+  for (int t = 0; t < WPR; t++) {
+    const int win = (int)k.row * WPR + t;
+    const int bit = win * ibftk::GTAB_BITS;
+    const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    const uint32_t *e = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt);
+    const uint32_t ld = k.li < 10 ? k.li : 0u;
+    waff pt;
+    pt.x = e[ld] & k.act;
+    pt.y = e[10 + ld] & k.act;
+    const wjac sum = wjac_add_aff(acc, pt, k);  // (called multiply: four iterations do not pay for 6 KB of code)
+    acc = wjac_select(dgt != 0, sum, acc);
+  }
+  return acc;
+}
 // ---- the recover, one signature per wavefront -------------------------------------------------------
 // Same contract and rejection list as ibftk::recover_pubkey (recover_dev.h); every lane of the
 // wavefront passes the same (z, r, s, v) and gets the same answer.
@@ -774,9 +792,27 @@ WVF bool wjac_to_aff(aff &r, const wjac &p, const wk &k) {
 // the G additions runs on (w·x, w², 1) — the isomorphic curve y² = x³ + 7w³ — and the accumulator's Z
 // is multiplied by y once the chain (computed by row 3 during the prefix doublings) has delivered it.
 // STOP < 99 cuts the function short after a stage (devtest timing breakdown only; addr then holds junk).
-template <int STOP = 99>
+//
+// TWO WAVEFRONTS PER SIGNATURE (round 4, n ≤ 512 — at most half of the chip's SIMDs would otherwise work): PAIR = true is
+// the MAIN wavefront of a pair.  Everything on its critical path stays (√ riding on the prefix doublings, table, the 64
+// doublings of the main loop, joins, Z⁻¹, Keccak); what does not depend on the curve work — r⁻¹ mod n, u₁, u₂, the GLV split,
+// and the sixteen fixed-base additions of u₁·G with their two joins — is done by the HELPER wavefront (recover_helper_wave)
+// meanwhile and handed over through `sh` (LDS on the device) at two workgroup barriers (`sync`): the split scalars before the
+// table is built, the point u₁·G before the last addition.  Same verdicts: point addition is associative, and the rare cases
+// (∞, equal or opposite operands) are handled by wjac_add wherever they fall.
+struct pair_shared {
+  uint32_t k1[4], k2[4];            // |k1|, |k2| of the GLV split of u₂ (128 bits each)
+  uint32_t neg;                     // bit 0: k1 negative, bit 1: k2 negative
+  uint32_t ginf;                    // u₁·G is the point at infinity (u₁ = 0)
+  uint32_t gx[16], gy[16], gz[16];  // u₁·G, Jacobian, limb i in slot i (slots 10…15 zero: the row layout's idle lanes)
+};
+struct no_sync {
+  HD void operator()() const {}
+};
+template <int STOP = 99, bool PAIR = false, class SYNC = no_sync>
 WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
-                            uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa) {
+                            uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa, const pair_shared *sh = nullptr,
+                            SYNC sync = SYNC()) {
 #define WV_STAGE(n, keep)     \
   if (STOP == (n)) {          \
     addr[0] = (keep);         \
@@ -793,11 +829,25 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   uint32_t PX = X0, PY = Y0, PZ, yc;
   prefix_and_sqrt(PX, PY, PZ, yc, w, 64, k);
   WV_STAGE(1, PX ^ PY ^ PZ ^ yc)
-  // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
-  const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
-  const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
-  const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
-  const secp::glv_split sp = secp::sc_split_lambda(u2);
+  // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ — computed here, or (PAIR) by the helper wavefront while the prefix ran
+  u256 u1 = secp::zero256();
+  secp::glv_split sp;
+  if constexpr (PAIR) {
+    sync();  // barrier 1: the helper has written the split scalars
+    sp.k1 = sp.k2 = secp::zero256();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      sp.k1.v[i] = sh->k1[i];
+      sp.k2.v[i] = sh->k2[i];
+    }
+    sp.neg1 = (sh->neg & 1u) != 0;
+    sp.neg2 = (sh->neg & 2u) != 0;
+  } else {
+    const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
+    u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
+    const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+    sp = secp::sc_split_lambda(u2);
+  }
   WV_STAGE(2, PX ^ PY ^ PZ ^ yc ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
   const bool half = (k.row & 1u) != 0, upper = (k.row & 2u) != 0;
   // signed radix-16 digits of this row's |k|: k + 0x88…8 has nibbles d_j + 8, bit 128 is the top digit
@@ -854,23 +904,19 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   fe y = secp::fe_normalize(gather(yc));
   y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
   acc.z = wfe_mul(acc.z, scatter(y, k), k);
-  // u1·G: the fixed-base windows are dealt to the rows
-  constexpr int WPR = ibftk::GTAB_WINDOWS / 4;
-#pragma unroll 1
-  for (int t = 0; t < WPR; t++) {
-    const int win = (int)k.row * WPR + t;
-    const int bit = win * ibftk::GTAB_BITS;
-    const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
-    const uint32_t *e = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt);
-    const uint32_t ld = k.li < 10 ? k.li : 0u;
-    waff pt;
-    pt.x = e[ld] & k.act;
-    pt.y = e[10 + ld] & k.act;
-    const wjac sum = wjac_add_aff(acc, pt, k);  // (called multiply: four iterations do not pay for 6 KB of code)
-    acc = wjac_select(dgt != 0, sum, acc);
-  }
+  // u1·G: the fixed-base windows are dealt to the rows (PAIR: the helper wavefront has summed them meanwhile)
+  if constexpr (!PAIR) acc = gen_windows_wave(gtab, u1, acc, k);
   acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
   acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
+  if constexpr (PAIR) {
+    sync();  // barrier 2: u₁·G is in `sh`
+    wjac g;
+    g.x = sh->gx[k.li];
+    g.y = sh->gy[k.li];
+    g.z = sh->gz[k.li];
+    g.inf = sh->ginf != 0;
+    acc = wjac_add(acc, g, k);
+  }
   WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
   const jac Q = wjac_gather(acc);
   ok = jac_to_aff_wave(Qa, Q, k) && ok;  // every row holds the same point after the joins
@@ -879,6 +925,37 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
 #undef WV_STAGE
+}
+
+// The HELPER wavefront of a pair (see recover_pubkey_wave<…, PAIR = true>): r⁻¹ mod n, u₁ = −z/r, u₂ = s/r, the GLV split of
+// u₂ → `sh`, barrier 1; then u₁·G (sixteen table additions over the four rows, two joins) → `sh`, barrier 2.
+template <class SYNC>
+WVF void recover_helper_wave(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s, pair_shared *sh,
+                             SYNC sync) {
+  const wk k = wk_init();
+  const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
+  const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
+  const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+  const secp::glv_split sp = secp::sc_split_lambda(u2);
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      sh->k1[i] = sp.k1.v[i];
+      sh->k2[i] = sp.k2.v[i];
+    }
+    sh->neg = (sp.neg1 ? 1u : 0u) | (sp.neg2 ? 2u : 0u);
+  }
+  sync();  // barrier 1
+  wjac acc = gen_windows_wave(gtab, u1, wjac_inf(), k);
+  acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
+  acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);  // every row holds u₁·G now
+  if (lane_id() < 16) {
+    sh->gx[k.li] = acc.x;
+    sh->gy[k.li] = acc.y;
+    sh->gz[k.li] = acc.z;
+  }
+  if (lane_id() == 0) sh->ginf = acc.inf ? 1u : 0u;
+  sync();  // barrier 2
 }
 
 WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {

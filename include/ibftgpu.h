@@ -105,16 +105,17 @@ extern "C" {
 #define IBFT_ROW_HASH_BAD 0x04u
 
 /* cfg.kernel: how many lanes work on one signature.  The verdicts never depend on it.
- *   AUTO  cold path (recover): one wavefront per signature up to 2048 rows, one DPP row (16 lanes) per
+ *   AUTO  cold path (recover): TWO wavefronts per signature up to 512 rows (a helper wavefront takes r⁻¹, the scalar split
+ *         and u1·G off the critical path), one wavefront per signature up to 2048 rows, one DPP row (16 lanes) per
  *         signature up to 8192 rows, then 4 / 2 lanes per signature while rows*lanes <= 65536, one
  *         lane beyond (the 8-lane form remains selectable);
  *         warm path (known keys): G = 64,32,...,2 lanes per signature so that a batch gives about
  *         one wavefront per SIMD (64 up to 1024 rows), one lane from 65536 rows.
  *   LANE  always one lane per signature (throughput form, both paths).
  *   WAVE  warm path pinned to one wavefront per signature.
- * Experiments only: the environment variable IBFT_COLD_LANES = 1|2|4|8|16|64 pins the cold variant,
- * IBFT_WAVE_ROWS_MAX / IBFT_ROWS_KERNEL_MAX move the AUTO thresholds of the one-wavefront and the
- * row-per-signature forms (read at ibft_ctx_create). */
+ * Experiments only: the environment variable IBFT_COLD_LANES = 1|2|4|8|16|64|128 pins the cold variant (128 = two
+ * wavefronts per signature), IBFT_PAIR_ROWS_MAX / IBFT_WAVE_ROWS_MAX / IBFT_ROWS_KERNEL_MAX move the AUTO thresholds of
+ * the two-wavefront, the one-wavefront and the row-per-signature forms (read at ibft_ctx_create). */
 #define IBFT_KERNEL_AUTO 0u
 #define IBFT_KERNEL_LANE 1u
 #define IBFT_KERNEL_WAVE 2u
@@ -330,7 +331,8 @@ int ibft_cache_stats(ibft_ctx *ctx, uint32_t *tables, uint32_t *warm_passes, uin
 int ibft_cache_memory(ibft_ctx *ctx, uint64_t *device_bytes, uint32_t *slots_in_use, uint32_t *slots_allocated,
                       uint32_t *contexts_sharing);
 /* Lanes per signature used by the last verdict pass: cold kernel (1 = ecrecover_lane_kernel,
- * 2/4/8 = ecrecover_group_kernel) and warm kernel (0 = none ran, 1 = lane, 2..64 = group).     */
+ * 2/4/8 = ecrecover_group_kernel, 16 = ecrecover_rows_kernel, 64 = ecrecover_wave_kernel, 128 = ecrecover_wave2_kernel)
+ * and warm kernel (0 = none ran, 1 = lane, 2..64 = group).                                        */
 int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);
 /* ---- pinned column buffers -------------------------------------------------------------------------
  * Every entry point accepts ordinary (pageable) host memory for its columns; the runtime then stages each

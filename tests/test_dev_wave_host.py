@@ -229,3 +229,65 @@ def test_byzantine_rows_through_both_emulated_recovers(wh, oracle):
             assert bool(ok[16 * row]) == (w is not None), r.kinds[i]
             if w is not None:
                 assert addr[16 * row].tobytes() == w, r.kinds[i]
+
+
+# ---- two wavefronts per signature (round 4): helper (scalars, u1·G) + main, `sh` shared ------------------------------------
+
+def _recover2(wh, h, sig, flags=0):
+    addr = np.zeros((64, 20), dtype=np.uint8)
+    ok = np.zeros(64, dtype=np.int32)
+    wh.wvh_recover2(h, sig, flags, addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+    assert (ok == ok[0]).all() and (addr == addr[0]).all(), "lanes of the main wavefront disagree"
+    return bool(ok[0]), addr[0].tobytes()
+
+
+def test_pair_recover_matches_oracle(wh, oracle):
+    """the main / helper split of the one-wavefront recover (recover_pubkey_wave<…, PAIR = true> + recover_helper_wave): the
+    same case list as the single-wavefront form — public vectors, random signatures, every rejection"""
+    wh.wvh_init_gtab()
+    WC.check_full_recover_matches_oracle(lambda h, sig, flags=0: _recover2(wh, h, sig, flags), oracle)
+
+
+def test_pair_recover_with_crafted_scalars_and_byzantine_rows(wh, oracle):
+    """the exceptional paths moved: u1·G = ∞ (zero digest) now meets the accumulator in ONE addition behind the joins, the
+    accumulator may be ∞ there (tiny u2), G-part and accumulator may be equal or opposite points"""
+    from oracle import pyref, workload as W
+    wh.wvh_init_gtab()
+    n = pyref.N
+    rng = np.random.default_rng(199)
+    for i, t in enumerate([1, 16, 2**64 - 1, 2**64, 2**128 - 1, n - 1, n - 2**64, int("8" * 64, 16) % n]):
+        k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        x, _ = pyref.pt_mul(k, pyref.G)
+        r = x % n
+        z = 0 if i < 2 else int.from_bytes(rng.bytes(32), "big")
+        sig = r.to_bytes(32, "big") + ((t * r) % n).to_bytes(32, "big") + bytes([i & 1])
+        h = z.to_bytes(32, "big")
+        got = _recover2(wh, h, sig)
+        want = oracle.recover_address(h, sig)
+        assert want is not None and got == (True, want), hex(t)
+    # u1·G = −u2·R (the recovered key is the point at infinity: rejected) and u1·G = u2·R (a doubling in the last addition):
+    # R = k·G, choose s, z with u1 = −z/r = ∓ u2·k = ∓ (s/r)·k  ⇔  z = ± s·k
+    for sign in (1, -1):
+        k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        x, y = pyref.pt_mul(k, pyref.G)
+        r, s = x % n, int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        z = (sign * s * k) % n
+        sig = r.to_bytes(32, "big") + s.to_bytes(32, "big") + bytes([y & 1])
+        h = z.to_bytes(32, "big")
+        want = oracle.recover_address(h, sig)
+        ok, addr = _recover2(wh, h, sig)
+        assert ok == (want is not None) and (want is None or addr == want), sign
+        addr1 = np.zeros((64, 20), dtype=np.uint8)
+        ok1 = np.zeros(64, dtype=np.int32)
+        wh.wvh_recover(h, sig, 0, addr1.ctypes.data_as(ctypes.c_void_p), ok1.ctypes.data_as(ctypes.c_void_p))
+        assert bool(ok1[0]) == ok                      # … and the single-wavefront form agrees
+    rr = W.make_round(64, 4242, byzantine=True)
+    seen = set()
+    for i, kind in enumerate(rr.kinds):
+        if kind in seen or rr.pre_flags[i]:
+            continue
+        seen.add(kind)
+        w = oracle.recover_address(rr.hash32[i].tobytes(), rr.seal65[i].tobytes())
+        ok, addr = _recover2(wh, rr.hash32[i].tobytes(), rr.seal65[i].tobytes())
+        assert ok == (w is not None) and (w is None or addr == w), kind
+    assert len(seen) >= 8

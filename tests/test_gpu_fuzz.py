@@ -65,7 +65,7 @@ def test_fuzz_rows_vs_oracle(oracle, flags, kernel, n_rows):
         bv.close()
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64, 128])
 def test_crafted_scalars_all_variants(oracle, lanes, monkeypatch):
     """Signatures built so that u2 = s/r (and u1 = −z/r) take extreme shapes: tiny, ±1 around 2^64 and
     2^128 (the piece boundaries of the lane groups and of the one-wavefront kernel), n − small, all-ones
@@ -110,7 +110,7 @@ def test_crafted_scalars_all_variants(oracle, lanes, monkeypatch):
         bv.close()
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64, 128])
 def test_recovery_id_policy_r_plus_n_candidate_is_never_tried(oracle, lanes, monkeypatch):
     """include/ibftgpu.h, conventions: v is the parity of R.y and nothing else — R.x = r always.  SEC 1 §4.1.6's
     second candidate R.x = r + n exists only for r < p − n (≈ 2^128.4); a signature whose TRUE nonce point has

@@ -114,7 +114,7 @@ def test_pre_columns_empty_set_and_interleaving_with_other_calls(oracle):
         bv.close()
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64, 128])
 def test_payload_lengths_around_the_keccak_rate_at_every_alignment(oracle, lanes, monkeypatch):
     """PayloadNoSig rows of every length around the 136-byte Keccak rate (empty, one block exactly, one byte over,
     several blocks), packed back to back so that rows start at every byte alignment: the kernels hash them with

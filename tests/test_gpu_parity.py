@@ -59,10 +59,11 @@ def test_ragged_sizes_vs_oracle(gpu_verifier, gpu_verifier_lane, oracle, n):
         assert (senders == oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20).astype(bool)).all()
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64, 128])
 def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
     """IBFT_COLD_LANES pins the cold kernel: lane kernel, 2/4/8-lane groups, one DPP row per
-    signature (16), one wavefront per signature (64).  Same Byzantine round, seals and senders, strict-low-s on and off."""
+    signature (16), one wavefront per signature (64), TWO wavefronts per signature (128: main + helper).  Same Byzantine
+    round, seals and senders, strict-low-s on and off."""
     import go_ibft_amd.verifier as V
     from oracle import workload as W
     monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
@@ -83,14 +84,15 @@ def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
             bv.close()
 
 
-@pytest.mark.parametrize("n,expect_group", [(1500, 64), (3000, 16), (5000, 16), (8192, 16), (12000, 4), (20000, 2), (40000, 1)])
+@pytest.mark.parametrize("n,expect_group", [(1, 128), (61, 128), (512, 128), (513, 64), (1500, 64), (3000, 16), (5000, 16), (8192, 16),
+                                            (12000, 4), (20000, 2), (40000, 1)])
 def test_cold_group_sizes(oracle, n, expect_group):
-    """AUTO picks one wavefront per signature up to 2 048 rows, one DPP row per signature up to 8 192,
+    """AUTO picks two wavefronts per signature up to 512 rows, one up to 2 048, one DPP row per signature up to 8 192,
     then 4/2/1 lanes per signature so
     that n·G/64 ≤ 1024 wavefronts; each choice is compared with the oracle on a Byzantine round."""
     import go_ibft_amd.verifier as V
     from oracle import workload as W
-    assert (64 if n <= 2048 else 16 if n <= 8192 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
+    assert (128 if n <= 512 else 64 if n <= 2048 else 16 if n <= 8192 else 4 if n * 4 <= 65536 else 2 if n * 2 <= 65536 else 1) == expect_group
     r = W.make_round(n, 3000 + n, byzantine=True)
     bv = V.BatchVerifier(max_rows=65536)
     try:
@@ -233,7 +235,7 @@ def test_large_n_properties(gpu_verifier, oracle):
     assert (again == got).all() and t3.power == t.power
 
 
-@pytest.mark.parametrize("lanes", [1, 8, 16, 64])
+@pytest.mark.parametrize("lanes", [1, 8, 16, 64, 128])
 def test_public_recover_vectors_on_gpu(lanes, monkeypatch):
     """The third-party recover vectors of tests/golden/kats.json (go-ethereum's signature test triple, the
     ecrecover-precompile example, five RFC 6979 secp256k1 vectors of the bitcoin test suites) through the cold

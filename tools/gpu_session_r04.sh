@@ -21,6 +21,11 @@ for PART in "$@"; do
         --no-cpu-baseline --no-sequence --no-warm --no-sweep --no-certificates --no-host-mirror --extended-steps 0 \
         > gpurun_out/profiles/r04_forcedist_config5.json 2> gpurun_out/r04_forcedist_config5.err
       echo "config5 rc=$?"; tail -c 1500 gpurun_out/profiles/r04_forcedist_config5.json; tail -3 gpurun_out/r04_forcedist_config5.err ;;
+    pair)
+      timeout 600 python tools/pair_ab.py > gpurun_out/profiles/r04_pair_ab.txt 2> gpurun_out/r04_pair_ab.err
+      echo "pair rc=$?"; cat gpurun_out/profiles/r04_pair_ab.txt; tail -3 gpurun_out/r04_pair_ab.err
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_message_set.py tests/test_gpu_arith.py -m gpu -x -q > gpurun_out/r04_pytest_pair.log 2>&1
+      echo "pairtests rc=$?"; tail -4 gpurun_out/r04_pytest_pair.log ;;
     alltests)
       timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r04_pytest_gpu.log 2>&1
       echo "alltests rc=$?"; tail -5 gpurun_out/r04_pytest_gpu.log ;;
