@@ -135,6 +135,7 @@ class Cluster:
         self.mode, self.build, self.micro_batch, self.lockstep = mode, build, micro_batch, lockstep
         # Backend.BuildProposal (core/backend.go:60-62) for a round > 0 without a previous proposal: node → raw bytes
         self.build_proposal = build_proposal
+        self.censor = None
         self.nodes = [Node(i, a, self) for i, a in enumerate(addresses)]
         powers = powers or {a: 1 for a in addresses}
         for nd in self.nodes:
@@ -158,7 +159,11 @@ class Cluster:
         return (height + round_) % len(self.nodes)     # core/helpers_test.go:214-225
 
     # -- Transport.Multicast: every node, the sender included (core/helpers_test.go:227-231)
-    def multicast(self, type_: int, wire: bytes):
+    def multicast(self, type_: int, wire: bytes, frm: "Node" = None):
+        # censor(node, type, (height, round)) → True: the node's Transport drops the message (a silent Byzantine node,
+        # core/rapid_test.go:227-236 — it still builds and accepts what it would have sent)
+        if frm is not None and self.censor is not None and self.censor(frm, type_, (frm.height, frm.round)):
+            return
         for nd in self.nodes:
             if not nd.offline:
                 nd.inbox.append((type_, wire))
@@ -191,7 +196,7 @@ class Cluster:
             pp = self.build(nd, PP, view)                          # BuildPrePrepareMessage(raw, rcc, view)
             nd.accepted = pp
             h.set_state(nd.height, nd.round, pp)                   # acceptProposal
-            self.multicast(PP, pp)
+            self.multicast(PP, pp, nd)
             nd.state = "prepare"
             if not self.lockstep:
                 self._wake(nd)
@@ -202,7 +207,7 @@ class Cluster:
                 return
             nd.accepted = msg
             h.set_state(nd.height, nd.round, msg)                  # acceptProposal
-            self.multicast(PR, self.build(nd, PR, view))           # sendPrepareMessage
+            self.multicast(PR, self.build(nd, PR, view), nd)           # sendPrepareMessage
             nd.state = "prepare"
             if not self.lockstep:
                 self._wake(nd)                                     # subscribe() probes what is already stored
@@ -214,7 +219,7 @@ class Cluster:
             nd.latest_pc = (nd.accepted, sorted(prepared))         # … latestPC / latestPreparedProposal (core/state.go:209-222)
             nd.latest_prepared = (raw_proposal_of(nd.accepted), nd.round)
             if not nd.withhold_commit:
-                self.multicast(CM, self.build(nd, CM, view))       # sendCommitMessage
+                self.multicast(CM, self.build(nd, CM, view), nd)       # sendCommitMessage
             nd.state = "commit"
             if not self.lockstep:
                 self._wake(nd)
@@ -235,7 +240,7 @@ class Cluster:
             nd.state, nd.accepted, nd.prepared = "newRound", None, None
             nd.pending.clear()
             nd.host.set_state(nd.height, nd.round, None)
-            self.multicast(RC, self.build(nd, RC, (nd.height, nd.round)))   # sendRoundChangeMessage(latestPreparedProposal, latestPC)
+            self.multicast(RC, self.build(nd, RC, (nd.height, nd.round)), nd)   # sendRoundChangeMessage(latestPreparedProposal, latestPC)
         return self._pump(max_rounds)
 
     def run_height(self, height: int, max_rounds: int = 100000):
@@ -249,7 +254,7 @@ class Cluster:
             pp = self.build(p, PP, view)
             p.accepted = pp
             p.host.set_state(height, 0, pp)
-            self.multicast(PP, pp)
+            self.multicast(PP, pp, p)
             p.state = "prepare"
         return self._pump(max_rounds)
 

@@ -14,7 +14,7 @@ for PART in "$@"; do
       timeout 900 python tools/occupancy.py --steps 30 > gpurun_out/profiles/r04_occupancy.txt 2> gpurun_out/r04_occupancy.err
       echo "occupancy rc=$?"; cat gpurun_out/profiles/r04_occupancy.txt; tail -3 gpurun_out/r04_occupancy.err ;;
     profsizes)
-      timeout 1500 bash tools/profile_sizes.sh r04 1024 16384 65536 > gpurun_out/r04_profile_sizes.log 2>&1
+      timeout 1500 bash tools/profile_sizes.sh r04 ${IBFT_PROF_SIZES:-512 1024 16384 65536} > gpurun_out/r04_profile_sizes.log 2>&1
       echo "profsizes rc=$?"; tail -40 gpurun_out/r04_profile_sizes.log ;;
     config5)
       IBFT_BENCH_FORCE_DIST=1 IBFT_BENCH_CONFIG5=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 timeout 600 python bench.py --steps 20 --warmup 5 \
@@ -26,6 +26,9 @@ for PART in "$@"; do
       echo "pair rc=$?"; cat gpurun_out/profiles/r04_pair_ab.txt; tail -3 gpurun_out/r04_pair_ab.err
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_message_set.py tests/test_gpu_arith.py -m gpu -x -q > gpurun_out/r04_pytest_pair.log 2>&1
       echo "pairtests rc=$?"; tail -4 gpurun_out/r04_pytest_pair.log ;;
+    soak)
+      timeout 1200 python tools/soak.py > gpurun_out/profiles/r04_soak.json 2> gpurun_out/r04_soak.err
+      echo "soak rc=$?"; tail -c 600 gpurun_out/profiles/r04_soak.json; tail -3 gpurun_out/r04_soak.err ;;
     alltests)
       timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r04_pytest_gpu.log 2>&1
       echo "alltests rc=$?"; tail -5 gpurun_out/r04_pytest_gpu.log ;;
