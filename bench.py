@@ -364,6 +364,38 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
             "sizes": out}
 
 
+def set_change_leg(V, n: int = 4096, reps: int = 3, passes: int = 5):
+    """the key cache's cost model (warm numbers assume a learned set): wall time of the first `passes` synchronous COMMIT
+    passes after ibft_set_validators installs n validators the device has never seen — pass 1 recovers every row and
+    learns the keys, pass 2 builds the per-validator tables (qtab_build_kernel) and verifies with them, later passes are
+    warm — and what the tables hold in HBM; median over `reps` fresh sets."""
+    import go_ibft_amd.simulate as SIM
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=n)
+    try:
+        ms = np.empty((reps, passes))
+        b0, u0 = bv.cache_memory()[:2]
+        for k in range(reps):
+            r = SIM.make_round(bv, n, 7000 + 13 * k)
+            bv.set_validators(1, r.addrs, r.power)
+            bv.seals_stage(r.hash32, r.seal65, r.signer20, None)
+            bv.sync()
+            for j in range(passes):
+                t0 = time.perf_counter()
+                verdict, t = bv.seals_run()
+                ms[k, j] = (time.perf_counter() - t0) * 1e3
+                assert verdict.all() and t.has_quorum == 1
+        held, used, alloc, _ = bv.cache_memory()
+        tables, warm_p, cold_p = bv.cache_stats()
+    finally:
+        bv.close()
+    return {"definition": "ms of each of the first passes over one resident COMMIT batch after a full validator-set change "
+                          "(no key known): pass 1 = recover + learn, pass 2 = build tables + warm verify, then warm",
+            "validators": n, "pass_ms": [float(x) for x in np.median(ms, axis=0)], "fresh_sets": reps,
+            "table_bytes_per_validator": int((held - b0) // (used - u0)) if used > u0 and held > b0 else None,
+            "cache_bytes_held": int(held), "slots_in_use": int(used), "slots_allocated": int(alloc),
+            "warm_passes": int(warm_p), "cold_passes": int(cold_p)}
+
+
 def certificates_leg(V, n: int = 256, reps: int = 30):
     """§8f rank 2: the ROUND-CHANGE messages of one round change at n validators — Q = ⌊2n/3⌋+1 messages, each with a
     PreparedCertificate of Q messages: Q·(Q+1) signatures — as the transport's bytes → the verdict of every nested
@@ -681,6 +713,11 @@ def main():
             rec["sweep"] = sweep_sizes(V)
         except Exception as e:  # noqa: BLE001 — an extra leg must never take the headline line down
             rec["sweep"] = {"error": repr(e)}
+    if world == 1 and rank == 0 and not args.no_sweep:
+        try:
+            rec["set_change"] = set_change_leg(V)
+        except Exception as e:  # noqa: BLE001
+            rec["set_change"] = {"error": repr(e)}
     if world == 1 and rank == 0 and not args.no_certificates:
         try:
             rec["certificates"] = certificates_leg(V)

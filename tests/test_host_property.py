@@ -9,7 +9,7 @@ inserted; and before the last round nobody inserted.  On top of the reference: t
 (per-message Verifier, one batch call per walk, micro-batched wire ingest + quorum index) agree node by node — inserted
 block AND the seal set handed to InsertProposal — and a rejected Byzantine seal never appears in that set.
 
-The reference draws 4..30 nodes and 5..20 heights under rapid's shrinker; the ranges here are cut (4..13 nodes, 1..3
+The reference draws 4..30 nodes and 5..20 heights under rapid's shrinker; the heights are cut (4..30 nodes as there, 1..5
 heights) so that the CPU suite stays inside its few minutes; the round timer is cluster_sim's tick()."""
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -34,8 +34,8 @@ def quorum(n):                                         # core/consensus_test.go:
 @st.composite
 def setups(draw):
     """generatePropertyTestEvent: {nodes, events[height] = [(silent, bad) per round]}, heights numbered from 1"""
-    n = draw(st.integers(4, 13))
-    heights = draw(st.integers(1, 3))
+    n = draw(st.integers(4, 30))
+    heights = draw(st.integers(1, 5))
     events = []
     for h in range(1, heights + 1):
         rounds, r = [], 0
