@@ -211,12 +211,14 @@ def valu_issue(kname: str, rows: int, avg_kernel_s: float):
         return 1024 / ((f_mad * t["mad"] + f_dpp * t["dpp"] + (1.0 - f_mad - f_dpp) * t["plain"]) * 1e-9)
     ach = insts / avg_kernel_s
     peak_guide = 1024 * 2.4e9 / 2.0
-    full, here = ceiling(4), ceiling(1 if resident < 2 else 2)
+    # fewer wavefronts than SIMDs (small sets): only the SIMDs that hold one can issue
+    full, here = ceiling(4), ceiling(1 if resident < 2 else 2) * min(1.0, offered)
     return {"wave_insts_per_launch": insts, "salu_insts_per_launch": salu, "achieved_ginst_s": ach / 1e9,
             "peak_guide_ginst_s": peak_guide / 1e9, "frac_of_guide_peak": ach / peak_guide,
             "ceiling_full_occupancy_ginst_s": full / 1e9, "frac_of_full_occupancy_ceiling": ach / full,
             "ceiling_at_this_occupancy_ginst_s": here / 1e9, "frac_of_ceiling_at_this_occupancy": ach / here,
             "wavefronts_offered_per_simd": offered, "wavefronts_resident_per_simd": resident,
+            "simds_with_a_wavefront": int(min(1024, round(offered * 1024))),
             "mad_share": f_mad, "dpp_share": f_dpp, "s_nop_per_valu": nop,
             "note": "peak_guide = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); the "
                     "ceilings price THIS kernel's instruction mix with the measured issue times of profiles/r02a_ubench_wave.txt "
