@@ -47,6 +47,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 ROWS_PER_GPU = 4096          # BASELINE configs #3 (1 GPU) and #4 (4 GPUs × 4096)
 SEQ_ROUNDS = 1000            # latency p50 over ≥1000 rounds
 PREWARM_STEPS = 150         # untimed passes in front of the W warm-up steps of the headline legs (see run_config)
+CONFIG5_TIMEOUT_S = 240     # the N = 8 extra leg (config #5) is abandoned after this long; the headline line goes out regardless
 KERNEL_TIMING_EVERY = 4      # HIP-event pair around the verdict kernel of every 4th timed pass (≥ 50 samples at --steps 200)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 
@@ -755,8 +756,23 @@ def main():
         # IBFT_BENCH_CONFIG5=1 runs the same leg at any world size that divides 65 536 (with IBFT_BENCH_FORCE_DIST=1 on one
         # GPU: the whole set as ONE shard through the sharded code path and a real one-rank RCCL communicator — what
         # profiles/r04_forcedist_config5.json holds)
+        # This leg has never met a multi-GPU node before the driver's run: should a rank stall in it (a collective one rank
+        # never reaches), the headline line — complete by now — must still go out.  A timer on every rank ends the process;
+        # rank 0 prints the line first, with the stall recorded.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                rec["config5"] = {"error": f"no result within {CONFIG5_TIMEOUT_S} s (leg abandoned, headline unaffected)"}
+                sys.stdout.flush()
+                print(json.dumps(rec), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(CONFIG5_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             c5 = run_config(65536 // world, True, max(10, args.steps // 4), 3, "cold")
+            watchdog.cancel()
             if rank == 0:
                 rec["config5"] = {"validators": c5["n_total"], "rows_per_gpu": 65536 // world, "byzantine_fraction": 0.2,
                                   "rccl_nranks": c5["rccl"][0] if c5["rccl"] else None,
@@ -766,6 +782,7 @@ def main():
                                   "parity": "every rank's shard of the merged verdict mask equals the CPU oracle's verdicts; "
                                             "merged quorum flag recomputed from the merged power"}
         except Exception as e:  # noqa: BLE001 — the extra leg must never take the headline line down
+            watchdog.cancel()
             if rank == 0:
                 rec["config5"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

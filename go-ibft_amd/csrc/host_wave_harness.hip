@@ -167,6 +167,14 @@ void lane_inv(void *vp) {
   secp::to_be32(j->out + 32 * wave_emul::lane(), r);
 }
 
+void lane_inv_rows(void *vp) {
+  inv_job *j = (inv_job *)vp;
+  const wv::wk k = wv::wk_init();
+  const u256 x = secp::from_be32(j->x32 + 32 * (wave_emul::lane() >> 4));
+  const u256 r = j->which == 0 ? wv::modinv_wave<secp::ModP>(x, k) : wv::modinv_wave<secp::ModN>(x, k);
+  secp::to_be32(j->out + 32 * wave_emul::lane(), r);
+}
+
 struct vk_job {
   const uint32_t *qtab;
   const uint8_t *hash32, *sig65;
@@ -198,6 +206,11 @@ void wvh_recover4(const uint8_t *hash32x4, const uint8_t *sig65x4, uint8_t *addr
 void wvh_modinv(int which, const uint8_t *x32, uint8_t *out64x32) {
   inv_job j{x32, out64x32, which};
   wave_emul::run(lane_inv, &j);
+}
+// four DIFFERENT values, one per DPP row (what the row-per-signature recover does): x4x32 = 4 × 32 bytes
+void wvh_modinv_rows(int which, const uint8_t *x4x32, uint8_t *out64x32) {
+  inv_job j{x4x32, out64x32, which};
+  wave_emul::run(lane_inv_rows, &j);
 }
 void wvh_verify_known(const uint32_t *qtab, const uint8_t *hash32, const uint8_t *sig65, uint32_t flags, int *ok64) {
   vk_job j{qtab, hash32, sig65, flags, ok64};

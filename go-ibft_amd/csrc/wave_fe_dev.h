@@ -140,7 +140,7 @@ struct wk {
   uint32_t li;    // lane within the row
   uint32_t row;   // 0..3
   uint32_t act;   // all ones on limb lanes (li < 10)
-  uint32_t m3;    // li < 3 ? M26 : all ones
+  uint32_t m3;    // li < 3 ? M26 : (li < 10 ? all ones : 0): the last AND of wfe_reduce (clears the idle lanes too)
   uint32_t lt3;   // all ones for li < 3
   uint32_t lt9;   // all ones for li < 9
   uint32_t kr;    // 2^260 mod p as limbs: 0x3D10 in lane 0, 0x400 in lane 1
@@ -152,7 +152,7 @@ HD wk wk_init() {
   k.li = l & 15u;
   k.row = l >> 4;
   k.act = k.li < 10 ? 0xFFFFFFFFu : 0u;
-  k.m3 = k.li < 3 ? M26 : 0xFFFFFFFFu;
+  k.m3 = k.li < 3 ? M26 : (k.li < 10 ? 0xFFFFFFFFu : 0u);
   k.lt3 = k.li < 3 ? 0xFFFFFFFFu : 0u;
   k.lt9 = k.li < 9 ? 0xFFFFFFFFu : 0u;
   k.kr = k.li == 0 ? 0x3D10u : (k.li == 1 ? 0x400u : 0u);
@@ -200,24 +200,50 @@ HD void wfe_prod(uint32_t a, uint32_t b, uint64_t &lo, uint64_t &hi) {
   wfe_mul_step<8>(a, b, lo, hi);
   wfe_mul_step<9>(a, b, lo, hi);
 }
-// 64-bit column sums (each < 2^64) → magnitude 1 (< 2^26 + 2^16), idle lanes zero
-HD uint32_t wfe_reduce(uint64_t lo, uint64_t hi, uint32_t act, uint32_t m3, uint32_t lt3) {
+// Code-generation hints (device build only; the host build computes the same integers without them).
+//   fence_v: an empty asm that redefines a VGPR value.  Between two additions it keeps instruction selection from
+//     fusing them into v_add3_u32 — whose operands cannot carry a DPP modifier, so each shifted summand then costs a
+//     v_mov_b32_dpp of its own — and lets the DPP combiner fold every shifted summand into a v_add_u32_dpp.
+//   opaque_s: a wave-uniform constant the optimiser cannot see through.  ·0x400 would otherwise be strength-reduced to
+//     v_lshlrev_b64 + v_lshl_add_u64 (two issue slots) where one v_mad_u64_u32 does it.
+// One wavefront per SIMD issues one instruction every ≈4 cycles whatever it is: instructions are the cost.
+HD uint32_t fence_v(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(v));
+#endif
+  return v;
+}
+HD uint32_t opaque_s(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+s"(v));
+#endif
+  return v;
+}
+// 64-bit column sums (each < 2^64) → magnitude 1 (< 2^26 + 2^16), idle lanes zero.
+// m3z: M26 in lanes 0..2, all ones in lanes 3..9, ZERO in the idle lanes (wk::m3z) — the last AND also clears what the
+// second fold leaves in lanes 10, 11.
+HD uint32_t wfe_reduce(uint64_t lo, uint64_t hi, uint32_t act, uint32_t m3z, uint32_t lt3) {
+  const uint32_t c400 = opaque_s(0x400u);
   // cut into 26-bit chunks
   const uint32_t c0 = (uint32_t)lo & M26, c1 = (uint32_t)(lo >> 26) & M26, c2 = (uint32_t)(lo >> 52);
   const uint32_t h0 = (uint32_t)hi & M26, h1 = (uint32_t)(hi >> 26) & M26, h2 = (uint32_t)(hi >> 52);
   // S: positions 0..15, T: positions 16..20 (lane j = position 16 + j)
-  const uint32_t S = c0 + row_shr<1>(c1) + row_shr<2>(c2);
-  const uint32_t T = h0 + row_shr<1>(h1) + row_shr<2>(h2) + row_shl<15>(c1) + row_shl<14>(c2);
+  uint32_t S = fence_v(c0 + row_shr<1>(c1));
+  S = S + row_shr<2>(c2);
+  uint32_t T = fence_v(h0 + row_shr<1>(h1));
+  T = fence_v(T + row_shr<2>(h2));
+  T = fence_v(T + row_shl<15>(c1));
+  T = T + row_shl<14>(c2);
   // H: lane j = position 10 + j (j = 0..10); fold with 2^260 ≡ 0x3D10 + 0x400·2^26
   const uint32_t H = row_shl<10>(S) + row_shr<6>(T);
   uint64_t V = mad64(H, 0x3D10u, (uint64_t)(S & act));
-  V = mad64(row_shr<1>(H), 0x400u, V);  // < 2^42 in lanes 0..11
+  V = mad64(row_shr<1>(H), c400, V);  // < 2^42 in lanes 0..11
   const uint32_t U = ((uint32_t)V & M26) + row_shr<1>((uint32_t)(V >> 26));  // positions 0..11
-  // positions 10, 11 once more
+  // positions 10, 11 once more (lanes 10, 11 of U itself stay in V2 and are cleared by m3z)
   const uint32_t H2 = row_shl<10>(U);  // lanes 0, 1
-  uint64_t V2 = mad64(H2, 0x3D10u, (uint64_t)(U & act));
-  V2 = mad64(row_shr<1>(H2), 0x400u, V2);  // lanes 0..2 < 2^41, lanes 3..9 = U
-  return ((uint32_t)V2 & m3) + row_shr<1>((uint32_t)(V2 >> 26) & lt3);
+  uint64_t V2 = mad64(H2, 0x3D10u, (uint64_t)U);
+  V2 = mad64(row_shr<1>(H2), c400, V2);  // lanes 0..2 < 2^41, lanes 3..9 = U
+  return ((uint32_t)V2 & m3z) + row_shr<1>((uint32_t)(V2 >> 26) & lt3);
 }
 // both inputs of magnitude ≤ 15 with zero idle lanes; result magnitude 1 (< 2^26 + 2^16), idle lanes zero
 HD uint32_t wfe_mul_body(uint32_t a, uint32_t b, uint32_t act, uint32_t m3, uint32_t lt3) {
@@ -595,35 +621,59 @@ WVF void prefix_and_sqrt(uint32_t &X, uint32_t &Y, uint32_t &Z, uint32_t &root, 
 // Carries are not rippled: column c_i = lo30 + 2^30·hi gives limb_j = lo_{j+1} + hi_j, one more
 // parallel pass leaves limbs in [−4, 2^30 + 4) (top limb unmasked) — bounded, not canonical, which is
 // all the next batch needs (only f, g mod 2^30 and the sign of the top limbs of d, e are read).
-// 30 divsteps on the low words, variable time (zero runs stripped with one ctz), written so that the DPP rows of
-// a wavefront may hold DIFFERENT values (the row-per-signature recover): the add/subtract half has no branch —
-// with an if/else every row pays for both sides plus the EXEC-mask bookkeeping (r⁻¹ mod n took 0.034 ms of the
-// 0.47 ms row kernel that way) — and only the loop exit is a wave-wide vote; rows that are done idle through the
-// remaining rounds (z = 0, nothing selected).  ζ < 0: (ζ, f, g, u, v, q, r) ← (−ζ − 1, g, g − f, q, r, q − u, r − v);
-// otherwise g, q, r += f, u, v.  Same transition matrix and ζ as secp::divsteps_30 (tests/test_dev_wave_host.py).
+// 30 divsteps on the low words, variable time, written so that the DPP rows of a wavefront may hold DIFFERENT values
+// (the row-per-signature recover): no branch but the loop's own vote; rows that are done idle through the remaining
+// rounds (nothing selected, a zero multiplier).  One round =
+//   strip the zero run of g with one ctz (a sentinel bit bounds it by the steps that are left): those steps only halve;
+//   ζ < 0 (g is odd now): the swap of the divstep, (ζ, f, g, u, v, q, r) ← (−ζ − 1, g, −f, q, r, −u, −v) — its
+//     subtraction is left to the next line (−f + 1·g);
+//   ζ ≥ 0 everywhere now, so the next min(ζ + 1, steps left) steps cannot swap: each adds f to g when g is odd, and
+//     halves.  Up to SIX of them are taken at once (round 4): w = −g/f mod 2^L makes g + w·f ≡ 0 (mod 2^L), and
+//     (g, q, r) += w·(f, u, v) is exactly what those L steps add — Σ b_j·2^j·(f, u, v) with b_j the parities they
+//     would have met — the halvings follow as the next zero run.  −1/f mod 64 = f·(f² − 2)  (f·that = (f² − 1)² − 1,
+//     and f² − 1 ≡ 0 mod 8).  Four rows in lockstep need 231 rounds per inversion this way, 311 one step at a time.
+// Same transition matrix and ζ as secp::divsteps_30, step for step (tests/test_dev_wave_host.py).
 WVF int32_t divsteps_30_rows(int32_t zeta, uint32_t f0, uint32_t g0, secp::trans2x2 &t) {
   uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
   int i = 30;
-  for (;;) {
-    const uint32_t m = g | (1u << i);
-    const int z = __builtin_ctz(m);
-    g >>= z;
-    u <<= z;
-    v <<= z;
-    zeta -= z;
-    i -= z;
-    if (!any(i != 0)) break;
-    const uint32_t live = i != 0 ? 0xFFFFFFFFu : 0u;
-    const uint32_t c = (uint32_t)(zeta >> 31) & live;  // all ones: swap and subtract
-    const uint32_t og = g, oq = q, orr = r;
-    g += ((f ^ c) - c) & live;
-    q += ((u ^ c) - c) & live;
-    r += ((v ^ c) - c) & live;
-    f = (og & c) | (f & ~c);
-    u = (oq & c) | (u & ~c);
-    v = (orr & c) | (v & ~c);
-    zeta = (int32_t)((uint32_t)zeta ^ c);  // −ζ − 1 = ~ζ
+#define WV_STRIP_ZEROS()                         \
+  {                                              \
+    const uint32_t m = g | (1u << i);            \
+    const int z = __builtin_ctz(m);              \
+    g >>= z;                                     \
+    u <<= z;                                     \
+    v <<= z;                                     \
+    zeta -= z;                                   \
+    i -= z;                                      \
   }
+  // "strip; do { round; strip; } while (vote)": the loop closes with ONE vote and ONE branch (a round with no row live
+  // changes nothing, so entering it unasked is harmless)
+  WV_STRIP_ZEROS()
+  do {
+    // (the optimiser must not see a boolean in the mask: it would turn the bit-selects below into compares +
+    // conditional moves; as a plain mask each is one v_bfi_b32)
+    const uint32_t c = fence_v((uint32_t)(zeta >> 31) & (i != 0 ? 0xFFFFFFFFu : 0u));
+    const uint32_t nf = 0u - f, nu = 0u - u, nv = 0u - v;
+    const uint32_t f2 = (g & c) | (f & ~c), u2 = (q & c) | (u & ~c), v2 = (r & c) | (v & ~c);
+    g = (nf & c) | (g & ~c);
+    q = (nu & c) | (q & ~c);
+    r = (nv & c) | (r & ~c);
+    f = f2;
+    u = u2;
+    v = v2;
+    zeta = (int32_t)((uint32_t)zeta ^ c);  // −ζ − 1 = ~ζ
+    // L = min(ζ + 1, steps left, 6); a finished row has no steps left: L = 0, w = 0
+    const int cap = i < 6 ? i : 6;
+    int L = zeta + 1;
+    L = L < 0 ? 0 : L;
+    L = L > cap ? cap : L;
+    const uint32_t w = mul24(mul24(mul24(f, f) - 2u, f), g) & ((1u << L) - 1u);  // only bits 0..5 matter
+    g += w * f;
+    q += w * u;
+    r += w * v;
+    WV_STRIP_ZEROS()
+  } while (any(i != 0));
+#undef WV_STRIP_ZEROS
   t.u = (int32_t)u;
   t.v = (int32_t)v;
   t.q = (int32_t)q;
@@ -692,30 +742,46 @@ WVF u256 modinv_wave_body(const u256 &x, bool is_p, uint32_t li) {
   D.v[7] = (int32_t)row_bcast<7>((uint32_t)d);
   D.v[8] = (int32_t)row_bcast<8>((uint32_t)d);
   const bool fneg = (row_bcast<0>((uint32_t)f) & 3u) == 3u;
+  // D → [0, M), negated first when f = −1 (secp::normalize_30 with the modulus at run time).
+  // Range of D: (−2M − ε, M + ε), NOT (−2M, M).  The batches decide "d < 0" from the top limb of a carry-save form
+  // (limbs in [−4, 2^30 + 4)), which calls a value in [0, 4·2^210) negative when its top limb is −1 under a limb 7 of
+  // 2^30 + c; such a d gets one M too many.  A row that is done (g = 0) while other rows of the wavefront still work
+  // goes through the remaining batches with the matrix (2^30, 0; 0, 1) and keeps exactly that surplus: 1/1 came out
+  // as M + 1 (tests/test_dev_wave_host.py::test_modular_inverse_of_four_different_values_in_lockstep).  So: add M
+  // while negative (twice after the negation), then take M off once if the value reached it.
+  auto ripple = [&]() {
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    D.v[i + 1] += D.v[i] >> 30;
-    D.v[i] &= secp::M30;
-  }
-  // D in (−2M, M) → [0, M), negated first when f = −1 (secp::normalize_30 with the modulus at run time)
-  int32_t add = D.v[8] >> 31;
+    for (int i = 0; i < 8; i++) {
+      D.v[i + 1] += D.v[i] >> 30;
+      D.v[i] &= secp::M30;
+    }
+  };
+  auto add_m_if_negative = [&]() {
+    const int32_t neg = D.v[8] >> 31;
 #pragma unroll
-  for (int i = 0; i < 9; i++) D.v[i] += mod[i] & add;
+    for (int i = 0; i < 9; i++) D.v[i] += mod[i] & neg;
+    ripple();
+  };
+  ripple();
+  add_m_if_negative();  // (−M − ε, M + ε)
   const int32_t nm = fneg ? -1 : 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) D.v[i] = (D.v[i] ^ nm) - nm;
+  ripple();
+  add_m_if_negative();  // (−ε, M + ε)
+  add_m_if_negative();  // [0, M + ε)
+  {
+    secp::s30 E = D;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    D.v[i + 1] += D.v[i] >> 30;
-    D.v[i] &= secp::M30;
-  }
-  add = D.v[8] >> 31;
+    for (int i = 0; i < 9; i++) E.v[i] -= mod[i];
 #pragma unroll
-  for (int i = 0; i < 9; i++) D.v[i] += mod[i] & add;
+    for (int i = 0; i < 8; i++) {
+      E.v[i + 1] += E.v[i] >> 30;
+      E.v[i] &= secp::M30;
+    }
+    const int32_t keep = E.v[8] >> 31;  // D − M < 0: D was below M already
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    D.v[i + 1] += D.v[i] >> 30;
-    D.v[i] &= secp::M30;
+    for (int i = 0; i < 9; i++) D.v[i] = (D.v[i] & keep) | (E.v[i] & ~keep);
   }
   return secp::s30_to_u256(D);
 }

@@ -134,6 +134,25 @@ def test_lane_parallel_modular_inverse(wh):
             assert int.from_bytes(out[0].tobytes(), "big") == (pow(x, -1, m) if x else 0), (which, hex(x))
 
 
+def test_modular_inverse_of_four_different_values_in_lockstep(wh):
+    """the row-per-signature kernels invert a different value in every DPP row of a wavefront: the rounds of the divsteps
+    (zero runs, swaps, up to six steps cancelled at once) are taken in lockstep, rows that finish a batch early idle"""
+    import random
+    from oracle import pyref
+    rng = random.Random(77)
+    for which, m in ((0, pyref.P), (1, pyref.N)):
+        special = [1, 2, 3, m - 1, m - 2, (m + 1) // 2, 2**30, 2**30 + 1, 2**60 - 1, 2**255 % m, 0, 2**128]
+        for t in range(40):
+            xs = [rng.choice(special) if rng.random() < 0.3 else (rng.randrange(m) >> rng.choice([0, 0, 0, 64, 128, 200]))
+                  for _ in range(4)]
+            buf = b"".join(x.to_bytes(32, "big") for x in xs)
+            out = np.zeros((64, 32), dtype=np.uint8)
+            wh.wvh_modinv_rows(which, buf, out.ctypes.data_as(ctypes.c_void_p))
+            for row, x in enumerate(xs):
+                assert (out[16 * row:16 * row + 16] == out[16 * row]).all()
+                assert int.from_bytes(out[16 * row].tobytes(), "big") == (pow(x, -1, m) if x else 0), (which, row, hex(x))
+
+
 def test_full_recover_with_crafted_scalars(wh, oracle):
     """u2 = s/r of extreme shapes (tiny, around 2^64 / 2^128, n − small) and a zero digest through the
     emulated one-wavefront recover: mostly-zero digit strings, accumulators at infinity, top digits."""
