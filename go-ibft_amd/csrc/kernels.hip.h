@@ -483,7 +483,19 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
 
   bool ok = sig_in_range(r, s, v, a.flags);
   u256 u1, u2;
-  verify_scalars(z, r, s, u1, u2);
+  // G ≥ 16: a signature owns whole DPP rows, and all their lanes hold the same (z, r, s) — the two inversions (s⁻¹ mod n
+  // here, Z⁻¹ mod p at the end) run with the limbs of d, e, f, g over the lanes of the row (wave_fe_dev.h:modinv_wave,
+  // ≈9.5 k issue slots) instead of every lane running the whole constant-time safegcd on its own copy (≈15 k): they were
+  // 43 % of this kernel at N = 4 096.  Smaller groups share a row between signatures and keep the lane form.
+  constexpr bool ROW_INV = G >= 16;
+  const wv::wk wkc = wv::wk_init();
+  if (ROW_INV) {
+    const secp::sc sinv = secp::sc_from_u256(wv::modinv_wave<secp::ModN>(s, wkc));
+    u1 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z), sinv));
+    u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(r), sinv));
+  } else {
+    verify_scalars(z, r, s, u1, u2);
+  }
   const uint32_t *qt = a.qtab + QTAB_DWORDS_PER_VALIDATOR * (crypto ? (uint32_t)sl : a.dummy_validator);
   jac acc = secp::jac_inf();
 #pragma unroll 1
@@ -510,7 +522,25 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
     jac other = shfl_xor_jac(acc, off);
     acc = secp::jac_add_t<true>(acc, other);  // (one inlined copy in the rolled butterfly)
   }
-  ok = verify_finish(acc, r, v) && ok && crypto;
+  if (ROW_INV) {
+    // The butterfly left the SUM in every lane of the group, but not one REPRESENTATION of it: P + Q and Q + P come out
+    // with Z of opposite sign, so the lanes of a group hold (λ²X, λ³Y, λZ) for different λ.  The row-layout inversion
+    // takes its limbs from all lanes of a row: give every lane the Z of the group's first lane; that lane then holds a
+    // consistent (X, Y, Z) and is the one that reports.
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+      acc.z.n[i] = G == 16 ? wv::row_bcast<0>(acc.z.n[i]) : (uint32_t)__shfl((int)acc.z.n[i], (int)(lane & ~(uint32_t)(G - 1)), 64);
+    acc.inf = __shfl(acc.inf ? 1 : 0, (int)(lane & ~(uint32_t)(G - 1)), 64) != 0;
+    aff A;
+    const bool fin = wv::jac_to_aff_wave(A, acc, wkc);
+    const secp::fe rx = secp::fe_from_u256(r);  // r < n < p: canonical limbs
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) diff |= A.x.n[i] ^ rx.n[i];
+    ok = fin && diff == 0 && (A.y.n[0] & 1u) == v && ok && crypto;
+  } else {
+    ok = verify_finish(acc, r, v) && ok && crypto;
+  }
   if (sub == 0 && ok) atomicOr(reinterpret_cast<unsigned long long *>(a.mask + (row >> 6)), 1ull << (row & 63));
 }
 

@@ -228,12 +228,11 @@ HD uint32_t wfe_reduce(uint64_t lo, uint64_t hi, uint32_t act, uint32_t m3z, uin
   const uint32_t c0 = (uint32_t)lo & M26, c1 = (uint32_t)(lo >> 26) & M26, c2 = (uint32_t)(lo >> 52);
   const uint32_t h0 = (uint32_t)hi & M26, h1 = (uint32_t)(hi >> 26) & M26, h2 = (uint32_t)(hi >> 52);
   // S: positions 0..15, T: positions 16..20 (lane j = position 16 + j)
-  uint32_t S = fence_v(c0 + row_shr<1>(c1));
-  S = S + row_shr<2>(c2);
-  uint32_t T = fence_v(h0 + row_shr<1>(h1));
-  T = fence_v(T + row_shr<2>(h2));
-  T = fence_v(T + row_shl<15>(c1));
-  T = T + row_shl<14>(c2);
+  // (nested so that every addition has ONE shifted summand — shr2 = shr1∘shr1, shl15 = shl14∘shl1, zero-filling all —
+  // and folds it as a DPP operand; only the last one needs the fence)
+  const uint32_t S = c0 + row_shr<1>(c1 + row_shr<1>(c2));
+  const uint32_t T0 = h0 + row_shr<1>(h1 + row_shr<1>(h2));
+  const uint32_t T = fence_v(T0) + row_shl<14>(c2 + row_shl<1>(c1));
   // H: lane j = position 10 + j (j = 0..10); fold with 2^260 ≡ 0x3D10 + 0x400·2^26
   const uint32_t H = row_shl<10>(S) + row_shr<6>(T);
   uint64_t V = mad64(H, 0x3D10u, (uint64_t)(S & act));
