@@ -55,7 +55,10 @@ void dev_fe_inv_safegcd(const uint8_t *a, uint8_t *out) { fout(out, secp::fe_inv
 int dev_divsteps_agree(int32_t zeta, uint32_t f0, uint32_t g0) {
   secp::trans2x2 a, b;
   int32_t za = secp::divsteps_30(zeta, f0, g0, a), zb = secp::divsteps_30_var(zeta, f0, g0, b);
-  return za == zb && a.u == b.u && a.v == b.v && a.q == b.q && a.r == b.r;
+  secp::trans2x2 c;  // the lockstep form (up to six steps cancelled per round): what every verification kernel runs
+  const int32_t zc = secp::divsteps_30_lockstep(zeta, f0, g0, c);
+  return za == zb && a.u == b.u && a.v == b.v && a.q == b.q && a.r == b.r &&
+         za == zc && a.u == c.u && a.v == c.v && a.q == c.q && a.r == c.r;
 }
 void dev_sc_inv_safegcd(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_inv_safegcd(sin_(a))); }
 // GLV split: out = k1(32 BE) ‖ k2(32 BE), returns neg1 | neg2<<1

@@ -105,6 +105,104 @@ HD int32_t divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, trans2x2 &t) {
   return zeta;
 }
 
+// (helpers of divsteps_30_lockstep)  opaque_mask: the optimiser must not see a boolean in a select mask;
+// mul24_lo: a product of which only the low bits are used — v_mul_u32_u24 on the device (it reads the low 24 bits of its
+// operands), the plain product elsewhere.
+HD uint32_t opaque_mask(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm("" : "+v"(v));
+#endif
+  return v;
+}
+// the loop's vote: every lane of the wavefront (device), every coroutine of the emulated wavefront (tests: the rounds are
+// then really taken in lockstep, finished lanes idling), or just this value (plain host code)
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(IBFT_WAVE_EMUL)
+}  // namespace secp
+namespace wave_emul {
+inline uint64_t ballot(bool c);  // wave_emul.h
+inline int lane();               // −1 outside an emulated wavefront (the harness also calls plain host code)
+}
+namespace secp {
+#endif
+HD bool lockstep_any(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __any(c ? 1 : 0) != 0;
+#elif defined(IBFT_WAVE_EMUL)
+  return wave_emul::lane() < 0 ? c : wave_emul::ballot(c) != 0;
+#else
+  return c;
+#endif
+}
+HD uint32_t mul24_lo(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return a * b;
+#endif
+}
+// ---- variable-time divsteps for lanes in lockstep -------------------------------------------------------
+// 30 divsteps on the low words, variable time, written so that the lanes of a wavefront (or the DPP rows of the
+// row-per-signature recover, wave_fe_dev.h) may hold DIFFERENT values: no branch but the loop's own vote; lanes that are
+// done idle through the remaining rounds (nothing selected, a zero multiplier).  One round =
+//   strip the zero run of g with one ctz (a sentinel bit bounds it by the steps that are left): those steps only halve;
+//   ζ < 0 (g is odd now): the swap of the divstep, (ζ, f, g, u, v, q, r) ← (−ζ − 1, g, −f, q, r, −u, −v) — its
+//     subtraction is left to the next line (−f + 1·g);
+//   ζ ≥ 0 everywhere now, so the next min(ζ + 1, steps left) steps cannot swap: each adds f to g when g is odd, and
+//     halves.  Up to SIX of them are taken at once (round 4): w = −g/f mod 2^L makes g + w·f ≡ 0 (mod 2^L), and
+//     (g, q, r) += w·(f, u, v) is exactly what those L steps add — Σ b_j·2^j·(f, u, v) with b_j the parities they
+//     would have met — the halvings follow as the next zero run.  −1/f mod 64 = f·(f² − 2)  (f·that = (f² − 1)² − 1,
+//     and f² − 1 ≡ 0 mod 8).  Four rows in lockstep need 231 rounds per inversion this way, 311 one step at a time.
+// Same transition matrix and ζ as divsteps_30, step for step (tests/test_dev_arith_host.py, tests/test_dev_wave_host.py).
+
+HD int32_t divsteps_30_lockstep(int32_t zeta, uint32_t f0, uint32_t g0, trans2x2 &t) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+  int i = 30;
+#define WV_STRIP_ZEROS()                         \
+  {                                              \
+    const uint32_t m = g | (1u << i);            \
+    const int z = __builtin_ctz(m);              \
+    g >>= z;                                     \
+    u <<= z;                                     \
+    v <<= z;                                     \
+    zeta -= z;                                   \
+    i -= z;                                      \
+  }
+  // "strip; do { round; strip; } while (vote)": the loop closes with ONE vote and ONE branch (a round with no row live
+  // changes nothing, so entering it unasked is harmless)
+  WV_STRIP_ZEROS()
+  do {
+    // (the optimiser must not see a boolean in the mask: it would turn the bit-selects below into compares +
+    // conditional moves; as a plain mask each is one v_bfi_b32)
+    const uint32_t c = opaque_mask((uint32_t)(zeta >> 31) & (i != 0 ? 0xFFFFFFFFu : 0u));
+    const uint32_t nf = 0u - f, nu = 0u - u, nv = 0u - v;
+    const uint32_t f2 = (g & c) | (f & ~c), u2 = (q & c) | (u & ~c), v2 = (r & c) | (v & ~c);
+    g = (nf & c) | (g & ~c);
+    q = (nu & c) | (q & ~c);
+    r = (nv & c) | (r & ~c);
+    f = f2;
+    u = u2;
+    v = v2;
+    zeta = (int32_t)((uint32_t)zeta ^ c);  // −ζ − 1 = ~ζ
+    // L = min(ζ + 1, steps left, 6); a finished row has no steps left: L = 0, w = 0
+    const int cap = i < 6 ? i : 6;
+    int L = zeta + 1;
+    L = L < 0 ? 0 : L;
+    L = L > cap ? cap : L;
+    const uint32_t w = mul24_lo(mul24_lo(mul24_lo(f, f) - 2u, f), g) & ((1u << L) - 1u);  // only bits 0..5 matter
+    g += w * f;
+    q += w * u;
+    r += w * v;
+    WV_STRIP_ZEROS()
+  } while (lockstep_any(i != 0));
+#undef WV_STRIP_ZEROS
+  t.u = (int32_t)u;
+  t.v = (int32_t)v;
+  t.q = (int32_t)q;
+  t.r = (int32_t)r;
+  return zeta;
+}
+
+
 // (f, g) ← t·(f, g) / 2^30  (exact)
 HD void update_fg_30(s30 &f, s30 &g, const trans2x2 &t) {
   const int64_t u = t.u, v = t.v, q = t.q, r = t.r;
@@ -179,7 +277,11 @@ HD void normalize_30(s30 &r, bool neg) {
   }
 }
 
-// x⁻¹ mod M for canonical x in [0, M); 0 maps to 0 (like the Fermat chain)
+// x⁻¹ mod M for canonical x in [0, M); 0 maps to 0 (like the Fermat chain).
+// Constant-time batches.  (Round 4 tried divsteps_30_lockstep here too: with 64 different values in lockstep a batch
+// needs ≈14 rounds of 33 instructions instead of 30 × 20, but the loop inside the 20 batches pushes the lane / group
+// kernels past 256 registers or into spills — N = 16 384 unchanged, N = 65 536 cold +0.5 %, warm +3.7 % slower,
+// profiles/r04f_lockstep_lane_ab.txt.  The lockstep form stays where a value owns a DPP row: wave_fe_dev.h.)
 template <class MOD>
 HD u256 modinv(const u256 &x) {
   s30 d, e, f, g = s30_from_u256(x);

@@ -620,64 +620,10 @@ WVF void prefix_and_sqrt(uint32_t &X, uint32_t &Y, uint32_t &Z, uint32_t &root, 
 // Carries are not rippled: column c_i = lo30 + 2^30·hi gives limb_j = lo_{j+1} + hi_j, one more
 // parallel pass leaves limbs in [−4, 2^30 + 4) (top limb unmasked) — bounded, not canonical, which is
 // all the next batch needs (only f, g mod 2^30 and the sign of the top limbs of d, e are read).
-// 30 divsteps on the low words, variable time, written so that the DPP rows of a wavefront may hold DIFFERENT values
-// (the row-per-signature recover): no branch but the loop's own vote; rows that are done idle through the remaining
-// rounds (nothing selected, a zero multiplier).  One round =
-//   strip the zero run of g with one ctz (a sentinel bit bounds it by the steps that are left): those steps only halve;
-//   ζ < 0 (g is odd now): the swap of the divstep, (ζ, f, g, u, v, q, r) ← (−ζ − 1, g, −f, q, r, −u, −v) — its
-//     subtraction is left to the next line (−f + 1·g);
-//   ζ ≥ 0 everywhere now, so the next min(ζ + 1, steps left) steps cannot swap: each adds f to g when g is odd, and
-//     halves.  Up to SIX of them are taken at once (round 4): w = −g/f mod 2^L makes g + w·f ≡ 0 (mod 2^L), and
-//     (g, q, r) += w·(f, u, v) is exactly what those L steps add — Σ b_j·2^j·(f, u, v) with b_j the parities they
-//     would have met — the halvings follow as the next zero run.  −1/f mod 64 = f·(f² − 2)  (f·that = (f² − 1)² − 1,
-//     and f² − 1 ≡ 0 mod 8).  Four rows in lockstep need 231 rounds per inversion this way, 311 one step at a time.
-// Same transition matrix and ζ as secp::divsteps_30, step for step (tests/test_dev_wave_host.py).
+// The 30 divsteps of a batch: secp::divsteps_30_lockstep (modinv_dev.h) — written for lanes / rows that hold
+// DIFFERENT values and advance in lockstep, which is what the row-per-signature recover needs.
 WVF int32_t divsteps_30_rows(int32_t zeta, uint32_t f0, uint32_t g0, secp::trans2x2 &t) {
-  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
-  int i = 30;
-#define WV_STRIP_ZEROS()                         \
-  {                                              \
-    const uint32_t m = g | (1u << i);            \
-    const int z = __builtin_ctz(m);              \
-    g >>= z;                                     \
-    u <<= z;                                     \
-    v <<= z;                                     \
-    zeta -= z;                                   \
-    i -= z;                                      \
-  }
-  // "strip; do { round; strip; } while (vote)": the loop closes with ONE vote and ONE branch (a round with no row live
-  // changes nothing, so entering it unasked is harmless)
-  WV_STRIP_ZEROS()
-  do {
-    // (the optimiser must not see a boolean in the mask: it would turn the bit-selects below into compares +
-    // conditional moves; as a plain mask each is one v_bfi_b32)
-    const uint32_t c = fence_v((uint32_t)(zeta >> 31) & (i != 0 ? 0xFFFFFFFFu : 0u));
-    const uint32_t nf = 0u - f, nu = 0u - u, nv = 0u - v;
-    const uint32_t f2 = (g & c) | (f & ~c), u2 = (q & c) | (u & ~c), v2 = (r & c) | (v & ~c);
-    g = (nf & c) | (g & ~c);
-    q = (nu & c) | (q & ~c);
-    r = (nv & c) | (r & ~c);
-    f = f2;
-    u = u2;
-    v = v2;
-    zeta = (int32_t)((uint32_t)zeta ^ c);  // −ζ − 1 = ~ζ
-    // L = min(ζ + 1, steps left, 6); a finished row has no steps left: L = 0, w = 0
-    const int cap = i < 6 ? i : 6;
-    int L = zeta + 1;
-    L = L < 0 ? 0 : L;
-    L = L > cap ? cap : L;
-    const uint32_t w = mul24(mul24(mul24(f, f) - 2u, f), g) & ((1u << L) - 1u);  // only bits 0..5 matter
-    g += w * f;
-    q += w * u;
-    r += w * v;
-    WV_STRIP_ZEROS()
-  } while (any(i != 0));
-#undef WV_STRIP_ZEROS
-  t.u = (int32_t)u;
-  t.v = (int32_t)v;
-  t.q = (int32_t)q;
-  t.r = (int32_t)r;
-  return zeta;
+  return secp::divsteps_30_lockstep(zeta, f0, g0, t);
 }
 
 template <int WITH_MOD>

@@ -246,13 +246,20 @@ def test_recover_address_matches_oracle(dev, oracle):
 
 
 def test_variable_time_divsteps_match_constant_time(dev):
-    """divsteps_30_var strips runs of even g with one ctz; batch by batch it must produce the same
-    ζ and transition matrix as the constant-time form (all the update code is shared)."""
+    """divsteps_30_var strips runs of even g with one ctz, divsteps_30_lockstep also cancels up to six steps of an odd
+    run with one multiplication; batch by batch both must produce the same ζ and transition matrix as the constant-time
+    form (all the update code is shared)."""
     rng = np.random.default_rng(77)
     dev.dev_divsteps_agree.argtypes = [C.c_int32, C.c_uint32, C.c_uint32]
     cases = [(-1, 1, 0), (-1, 0xFFFFFC2F, 0), (5, 3, 2**31), (-7, 0xFFFFFFFF, 0xFFFFFFFF), (0, 1, 1), (-1, 1, 2**30)]
     for _ in range(4000):
         cases.append((int(rng.integers(-40, 40)), int(rng.integers(0, 2**32)) | 1, int(rng.integers(0, 2**32))))
+    for _ in range(2000):   # long odd runs (g ≡ −f mod 2^k), long even runs, ζ around the swap
+        f0 = int(rng.integers(0, 2**32)) | 1
+        k = int(rng.integers(1, 31))
+        g0 = ((-f0 * int(rng.integers(1, 2**16) | 1)) % 2**k + (int(rng.integers(0, 2**32)) << k)) % 2**32
+        cases.append((int(rng.integers(-3, 4)), f0, g0))
+        cases.append((int(rng.integers(-700, -500)), f0, g0 << int(rng.integers(0, 8)) & 0xFFFFFFFF))
     for zeta, f0, g0 in cases:
         assert dev.dev_divsteps_agree(zeta, f0, g0) == 1, (zeta, f0, g0)
 
