@@ -156,6 +156,7 @@ __global__ void __launch_bounds__(64) devtest_wave_fe_kernel(int op, const uint3
     case 5: r = wv::wfe_sqrt_candidate(x, k); break;
     case 6: r = wv::scatter(wv::gather(x), k); break;
     case 7: r = wv::wfe_is_zero(x) ? 1u : 0u; break;
+    case 8: r = wv::wfe_z_maybe_zero(wv::wfe_mul(x, y, k)) ? 1u : 0u; break;  // the additions' filter on Z3
   }
   out[64 * blockIdx.x + threadIdx.x] = r;
 }

@@ -45,6 +45,14 @@ void dev_fe_lazy(const uint8_t *a, const uint8_t *b, const uint8_t *c, uint32_t 
   secp::fe u = secp::fe_sub(A, B, 1);                                                       // 3
   fout(out, secp::fe_mul(secp::fe_sqr(t), u));
 }
+// the additions' filter: Z3 = 2·z·(a − b) as madd-2007-bl forms it; bit 0 = fe_z_maybe_zero(Z3), bit 1 = fe_is_zero(Z3),
+// bit 2 = the same through a squaring-shaped product and fe_normalize_weak (the other producers of a Z3)
+int dev_fe_zero_filter(const uint8_t *a, const uint8_t *b, const uint8_t *z) {
+  const secp::fe h = secp::fe_sub(fin(a), fin(b), 1);  // magnitude 3, ≡ 0 iff a ≡ b
+  const secp::fe z3 = secp::fe_mul(secp::fe_mul_int(fin(z), 2), h);
+  const secp::fe zs = secp::fe_normalize_weak(secp::fe_add(secp::fe_sqr(h), secp::fe_mul_int(z3, 3)));
+  return (secp::fe_z_maybe_zero(z3) ? 1 : 0) | (secp::fe_is_zero(z3) ? 2 : 0) | (secp::fe_z_maybe_zero(zs) ? 4 : 0);
+}
 int dev_fe_equal(const uint8_t *a, const uint8_t *b) { return secp::fe_equal(fin(a), fin(b), 1) ? 1 : 0; }
 void dev_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *out) { sout(out, secp::sc_mul(sin_(a), sin_(b))); }
 void dev_sc_sqr(const uint8_t *a, uint8_t *out) { sout(out, secp::sc_sqr(sin_(a))); }

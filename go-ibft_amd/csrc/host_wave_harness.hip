@@ -39,6 +39,7 @@ void lane_mul(void *p) {
     case 5: r = wv::wfe_sqrt_candidate(a, k); break;
     case 6: r = wv::scatter(wv::gather(a), k); break;
     case 7: r = wv::wfe_is_zero(a) ? 1u : 0u; break;
+    case 8: r = wv::wfe_z_maybe_zero(wv::wfe_mul(a, b, k)) ? 1u : 0u; break;  // the additions' filter on Z3
   }
   j->out[k.row * 16 + k.li] = r;
 }

@@ -432,6 +432,11 @@ HD bool fe_is_zero(const fe &a) {  // a of magnitude ≤ 32: value ≡ 0 (mod p)
   }
   return z0 == 0 || z1 == 0;
 }
+// Cheap NECESSARY condition for z ≡ 0 (mod p), z an output of fe_mul / fe_sqr / fe_normalize_weak: limb 0 is then exactly
+// z mod 2^26 and the value is below 2^256 + 2^240 < 2p, so a multiple of p is 0 or p itself and limb 0 is 0 or P26(0).
+// Never misses a zero; says "maybe" for one non-zero z in 2^25.  The point additions use it on Z3 (= 2·Z1·H or
+// 2·Z1·Z2·H) in place of the full fe_is_zero(H) — ≈60 instructions per addition that decided nothing.
+HD bool fe_z_maybe_zero(const fe &z) { return z.n[0] == 0u || z.n[0] == P26(0); }
 HD bool fe_equal(const fe &a, const fe &b, uint32_t mb) { return fe_is_zero(fe_sub(a, b, mb)); }
 HD bool fe_is_odd(const fe &a_normalized) { return (a_normalized.n[0] & 1u) != 0; }
 HD fe fe_from_u256(const u256 &a) { return l26_from_u256(a); }     // a < p assumed by callers
@@ -847,13 +852,17 @@ HD jac jac_add_t(const jac &p, const jac &q) {
   fe zz = fe_add(fe_add(fe_sqr_t<INL>(fe_add(p.z, q.z)), fe_neg(z1z1, 1)), fe_neg(z2z2, 1));              // 5
   r.z = fe_mul_t<INL>(zz, h);                                                                             // in 5,3 -> 1
   r.inf = false;
-  // exceptional cases, branch-free per lane; the doubling runs for the whole wave if any lane needs it
+  // exceptional cases (P = ±Q ⇔ H ≡ 0): Z1·Z2 ≢ 0 for finite points, so H ≡ 0 ⇔ Z3 ≡ 0, and fe_z_maybe_zero(Z3) never
+  // misses it — the exact tests run once in 2^25 additions, for the whole wave if any lane asks
   const bool both = !p.inf && !q.inf;
-  const bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
-  const bool same = both && hz && rz;       // P == Q
-  const bool opposite = both && hz && !rz;  // P == −Q
-  if (wave_any(same)) r = jac_select(same, jac_dbl_t<false>(p), r);
-  r = jac_select(opposite, jac_inf(), r);
+  const bool maybe = both && fe_z_maybe_zero(r.z);
+  if (__builtin_expect(wave_any(maybe), false)) {  // (the rare path is laid out of line: the common one falls through)
+    const bool hz = maybe && fe_is_zero(h), rz = fe_is_zero(rr);
+    const bool same = hz && rz;       // P == Q
+    const bool opposite = hz && !rz;  // P == −Q
+    if (wave_any(same)) r = jac_select(same, jac_dbl_t<false>(p), r);
+    r = jac_select(opposite, jac_inf(), r);
+  }
   r = jac_select(q.inf, p, r);
   r = jac_select(p.inf, q, r);
   return r;
@@ -879,12 +888,15 @@ HD jac jac_add_aff_t(const jac &p, const aff &q) {
   // Z3 = (Z1+H)² − Z1Z1 − HH
   r.z = fe_normalize_weak(fe_add(fe_add(fe_sqr_t<INL>(fe_add(p.z, h)), fe_neg(z1z1, 1)), fe_neg(hh, 1)));  // in 4; 5 -> 1
   r.inf = false;
-  const bool hz = fe_is_zero(h), rz = fe_is_zero(rr);
-  const bool same = !p.inf && hz && rz;
-  const bool opposite = !p.inf && hz && !rz;
   const jac qj = jac_from_aff(q);
-  if (wave_any(same)) r = jac_select(same, jac_dbl_t<false>(qj), r);  // (rare: the call shape keeps the loop body small)
-  r = jac_select(opposite, jac_inf(), r);
+  const bool maybe = !p.inf && fe_z_maybe_zero(r.z);  // Z3 = 2·Z1·H: H ≡ 0 ⇒ Z3 ∈ {0, p} (see fe_z_maybe_zero)
+  if (__builtin_expect(wave_any(maybe), false)) {  // (the rare path is laid out of line: the common one falls through)
+    const bool hz = maybe && fe_is_zero(h), rz = fe_is_zero(rr);
+    const bool same = hz && rz;
+    const bool opposite = hz && !rz;
+    if (wave_any(same)) r = jac_select(same, jac_dbl_t<false>(qj), r);  // (rare: the call shape keeps the loop body small)
+    r = jac_select(opposite, jac_inf(), r);
+  }
   r = jac_select(p.inf, qj, r);
   return r;
 }

@@ -169,6 +169,28 @@ def _point_add_cases():
     return cases + [(0, 0)]
 
 
+def test_zero_filter_of_the_additions_never_misses(dev):
+    """fe_z_maybe_zero(Z3) stands in for fe_is_zero(H) in jac_add / jac_add_aff: it must say "maybe" whenever H ≡ 0,
+    whatever the encodings (a, a + p), and hardly ever otherwise."""
+    rng = np.random.default_rng(23)
+    xs = [0, 1, 2**32 + 976, 2**32 + 977, 5, P - 1] + [int.from_bytes(rng.bytes(32), "big") % P for _ in range(300)]
+    for x in xs:
+        z = int.from_bytes(rng.bytes(32), "big") % P or 1
+        for a, b in ((x, x), (x + P, x), (x, x + P)):
+            if max(a, b) >= 2**256:
+                continue
+            assert dev.dev_fe_zero_filter(b32(a), b32(b), b32(z)) == 7, (x, a, b)
+    flagged = 0
+    for _ in range(2000):
+        a, b, z = (int.from_bytes(rng.bytes(32), "big") % P for _ in range(3))
+        if a == b or z == 0:
+            continue
+        f = dev.dev_fe_zero_filter(b32(a), b32(b), b32(z))
+        assert not f & 2
+        flagged += f & 1
+    assert flagged <= 1   # 2^-25 each
+
+
 def test_exceptional_point_additions(dev):
     """P+P, P+(−P), ∞+P, P+∞ through jac_add and jac_add_aff (wave-uniform exceptional paths)."""
     for k1, k2 in _point_add_cases():

@@ -41,7 +41,7 @@ def test_neg_constants(wh):
 
 
 @pytest.mark.parametrize("case", ["mul_matches_bigint_at_every_magnitude", "weak_normalise_and_negate",
-                                  "gather_scatter_and_is_zero", "sqrt_chain", "point_double_add_madd",
+                                  "gather_scatter_and_is_zero", "zero_filter_never_misses", "sqrt_chain", "point_double_add_madd",
                                   "point_exceptional_cases_mixed_over_rows"])
 def test_wave_arithmetic(wh, case):
     getattr(WC, "check_" + case)(*_ops(wh))

@@ -88,6 +88,55 @@ def check_gather_scatter_and_is_zero(fe_op, pt_op):
     assert [int(out[r, 0]) for r in range(4)] == [1, 1, 1, 0]
 
 
+def check_zero_filter_never_misses(fe_op, pt_op):
+    """wfe_z_maybe_zero on a product (what the point additions test Z3 = 2·Z1·H with): a product ≡ 0 (mod p) is flagged
+    whatever the representation of its zero factor (magnitudes up to 15: the lazily reduced H), and almost nothing else is."""
+    rng = random.Random(16)
+    s = sum(1 << (26 * i) for i in range(10))
+
+    def noncanon(x, hi):
+        """another limb pattern of the same integer: borrow 2^26 from limb i + 1 into limb i here and there (limbs ≤ hi)"""
+        l = limbs(x)
+        for i in range(9):
+            if l[i + 1] >= 1 and l[i] + 2**26 <= hi and rng.randrange(2):
+                l[i] += 2**26
+                l[i + 1] -= 1
+        return l
+
+    def zero_rep(m):
+        """limbs ≤ (m + 1)·U + 2^26 of a value ≡ 0 (mod p)"""
+        mode = rng.randrange(4)
+        if mode == 0:
+            return limbs(0)
+        if mode == 1:
+            j = rng.randrange(1, m + 1)
+            return [j * v for v in limbs(P)]                                   # j·p, unreduced limbs
+        if mode == 2:                                                          # u2 + (K_m − x1), u2 ≡ x1: the additions' H
+            x = rng.randrange(P)
+            x1 = noncanon(x, m * U)
+            u2 = noncanon(x + P if x + P < 2**260 and rng.randrange(2) else x, U + 2**16)
+            k = [m * U + d for d in limbs((-m * U * s) % P)]
+            return [a + (b - c) for a, b, c in zip(u2, k, x1)]
+        return limbs(rng.randrange(1, 16) * P)                                  # m·p < 2^260, canonical limbs
+    for it in range(150):
+        m = rng.choice([1, 2, 3, 8, 12])
+        za = [zero_rep(m) for _ in range(4)]
+        assert all(value(z) % P == 0 and all(0 <= v <= 15 * U for v in z) for z in za)
+        other = [rand_limbs(rng, rng.choice([1, 2, 6, 15])) for _ in range(4)]
+        for a, b in ((za, other), (other, za)):
+            out = fe_op(8, a, b)
+            assert (out[:, :16] == 1).all(), (it, m)
+    flagged = 0
+    for it in range(100):
+        a = [limbs(rng.randrange(1, P)) for _ in range(4)]
+        b = [limbs(rng.randrange(1, P)) for _ in range(4)]
+        out = fe_op(8, a, b)
+        for r in range(4):
+            assert len(set(int(v) for v in out[r, :16])) == 1   # row-uniform
+            flagged += int(out[r, 0])
+    assert flagged <= 2   # expected 400 · 2.3e-4
+
+
 def check_sqrt_chain(fe_op, pt_op):
     rng = random.Random(14)
     xs = [rng.randrange(P) for _ in range(4)]
