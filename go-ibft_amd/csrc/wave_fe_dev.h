@@ -490,26 +490,32 @@ WVF uint32_t wfe_sqrt_candidate(uint32_t a, const wk &k) {
 }
 
 // The same chain as ONE doubly nested loop around a single pasted multiplication: 14 segments of
-// "n squarings, then × a saved power" (the last one: two squarings).  The row-per-signature recover has no spare
-// row to hide the chain on, so it pays for every instruction of it: no call / return / argument moves per step
-// (≈15 of ≈90 instructions with the outlined multiply), and one 600-byte body instead of thirteen call sites.
-WVF uint32_t wfe_sqrt_candidate_rolled(uint32_t a, const wk &k) {
-  //                         x2 x3 x6 x9 x11 x22 x44 x88 x176 x220 x223  t   t  (2 squarings)
-  const uint8_t NSQ[14] = {1, 1, 3, 3, 2, 11, 22, 44, 88, 44, 3, 23, 6, 1};
+// "n squarings, then × a saved power".  The row-per-signature recover has no spare row to hide the chain on, so it pays
+// for every instruction of it: no call / return / argument moves per step (≈15 of ≈90 instructions with the outlined
+// multiply), and one 600-byte body instead of thirteen call sites.
+//   INVSQRT = false: a^((p+1)/4), the square-root candidate (exponent bits 223 ones, 0, 22 ones, 00001100);
+//   INVSQRT = true:  a^((p−3)/4) = a^((p+1)/4) / a (bits 223 ones, 0, 22 ones, 00001011) — for a square a this is
+//                    ±1/√a, the one exponentiation that gives recover_pubkey_row BOTH √(x³ + 7) and the inverse of the
+//                    final Z (see there).
+template <bool INVSQRT>
+WVF uint32_t wfe_pow_chain_rolled(uint32_t a, const wk &k) {
+  //                                 x2 x3 x6 x9 x11 x22 x44 x88 x176 x220 x223  t   t   t
+  const uint8_t NSQ_SQRT[14] = {1, 1, 3, 3, 2, 11, 22, 44, 88, 44, 3, 23, 6, 1};   // last segment: two bare squarings
+  const uint8_t NSQ_INV[14] = {1, 1, 3, 3, 2, 11, 22, 44, 88, 44, 3, 23, 5, 3};    // … ·2^5·a, then ·2^3·x2
   uint32_t cur = a, x2 = 0, x3 = 0, x11 = 0, x22 = 0, x44 = 0, x88 = 0;
 #pragma unroll 1
   for (int seg = 0; seg < 14; seg++) {
-    uint32_t opnd = a;                        // segments 0, 1
+    uint32_t opnd = a;                        // segments 0, 1 (and 12 of the inverse square root)
     opnd = (seg == 2 || seg == 3 || seg == 10) ? x3 : opnd;
-    opnd = (seg == 4 || seg == 12) ? x2 : opnd;
+    opnd = (seg == 4 || seg == (INVSQRT ? 13 : 12)) ? x2 : opnd;
     opnd = seg == 5 ? x11 : opnd;
     opnd = (seg == 6 || seg == 11) ? x22 : opnd;
     opnd = (seg == 7 || seg == 9) ? x44 : opnd;
     opnd = seg == 8 ? x88 : opnd;
-    const int nsq = NSQ[seg];
+    const int nsq = INVSQRT ? NSQ_INV[seg] : NSQ_SQRT[seg];
 #pragma unroll 1
     for (int i = 0; i <= nsq; i++) {
-      const uint32_t b = (i < nsq || seg == 13) ? cur : opnd;  // wave-uniform choice
+      const uint32_t b = (i < nsq || (!INVSQRT && seg == 13)) ? cur : opnd;  // wave-uniform choice
       cur = wfe_mul<true>(cur, b, k);
     }
     x2 = seg == 0 ? cur : x2;
@@ -521,6 +527,7 @@ WVF uint32_t wfe_sqrt_candidate_rolled(uint32_t a, const wk &k) {
   }
   return cur;
 }
+WVF uint32_t wfe_sqrt_candidate_rolled(uint32_t a, const wk &k) { return wfe_pow_chain_rolled<false>(a, k); }
 
 // ---- √ on a spare row ------------------------------------------------------------------------------
 // The a^((p+1)/4) chain (secp::fe_sqrt_candidate) is 266 dependent multiplications — but it needs
@@ -991,6 +998,73 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
   pt.y = e20[10 + ld] & k.act;
   return pt;
 }
+// ---- the end of the row-per-signature recover: ONE exponentiation for √(x³ + 7) AND the final inversion ------------
+// The rows run u2·R without knowing R's y: with t = x³ + 7 the point R′ = (x·t, t²) lies on y² = x³ + 7t³, which is the
+// curve itself seen through (x, y) → (x·u², y·u³), u = y_R = √t, and the a = 0 formulas never look at the constant.  A
+// Jacobian result (X′, Y′, Z′) there is the point (X′, Y′, Z′·u) here.  Its sum with P1 = u1·G (kept in an accumulator of
+// its own) can be written down with u as a symbol, because u² = t is known:
+//     U1 = X1·Z′²t   U2 = X′·Z1²   S2 = Y′·Z1³   S1 = ŝ·u, ŝ = Y1·Z′³t   H = U2 − U1   V = U1·H²
+//     X3 = A + B·u    A = S2² + ŝ²t − H³ − 2V            B = −2·S2·ŝ
+//     Y3 = C + D·u    C = S2·(V − A) + ŝ·B·t             D = −S2·B − ŝ·(V − A + H³)
+//     Z3 = m·u        m = Z1·Z′·H
+// and the affine point is x = (A + B·u)/(m²t), y = (C·u + D·t)/(m³t²).  With q = t·m² and I = q^((p−3)/4) = ±1/(u·m):
+//     I² = 1/(m²t)        ±u = I·m·t        1/(m³t²) = I⁴·m
+// — the square root and the inverse come out of the SAME 254-squaring chain; the sign of u is fixed by the recovery id
+// exactly as before (y_R has parity v), and I enters only through I², I⁴ and I·(the sign that is being fixed).  What this
+// replaces: a √ chain at the start AND a safegcd inversion of Z at the end (≈9 k issue slots) for ≈35 multiplications.
+// t not a square (r is no x coordinate): (I·m·t)² = −t ≠ t, the row is rejected like before.
+// Rare rows — P1 or the u2·R′ result at infinity, or H = 0 (u1·G = ±u2·R) — take the textbook route for the whole
+// wavefront: √t by the same chain, the accumulator moved to the curve, a complete addition, an inversion.
+WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t t, uint32_t v, const wk &k) {
+  const uint32_t z2s = wfe_mul(wfe_sqr(p2.z, k), t, k);  // Z2² = Z′²·t
+  const uint32_t z1s = wfe_sqr(p1.z, k);
+  const uint32_t U1 = wfe_mul(p1.x, z2s, k), U2 = wfe_mul(p2.x, z1s, k);
+  const uint32_t S2 = wfe_mul(p2.y, wfe_mul(z1s, p1.z, k), k);
+  const uint32_t sh = wfe_mul(p1.y, wfe_mul(z2s, p2.z, k), k);  // ŝ
+  const uint32_t H = U2 + wfe_neg1(U1, k);                      // 3
+  const uint32_t HH = wfe_sqr(H, k);
+  const uint32_t HHH = wfe_mul(HH, H, k);
+  const uint32_t V = wfe_mul(U1, HH, k);
+  // A = S2² + ŝ²·t − H³ − 2V: one reduction for the two products (1·1 + 1·2), then 1 + 2 + 3 → 1
+  const uint32_t A = wfe_weak(wfe_mul2(S2, S2, wfe_sqr(sh, k), t, k) + wfe_neg1(HHH, k) + wfe_neg2(2u * V, k), k);
+  const uint32_t Bn = wfe_mul(2u * S2, sh, k);                  // −B
+  const uint32_t VA = V + wfe_neg1(A, k);                       // 3
+  const uint32_t C = wfe_mul2(S2, VA, wfe_neg1(wfe_mul(sh, t, k), k), Bn, k);   // 1·3 + 2·1
+  const uint32_t D = wfe_mul2(S2, Bn, wfe_neg1(sh, k), VA + HHH, k);             // 1·1 + 2·4
+  const uint32_t m = wfe_mul(wfe_mul(p1.z, p2.z, k), H, k);
+  // H ≡ 0 ⇔ m ≡ 0 (finite points have Z ≢ 0).  The cheap filter says "maybe" for one row in 4 000 — once per launch of
+  // 4 096 rows, and a launch lasts as long as its slowest wavefront: the exact test (75 instructions) decides before the
+  // rare route (≈35 k) is taken.
+  const bool mz = wfe_z_maybe_zero(m);  // (cross-lane: every lane evaluates it)
+  bool hz = false;
+  if (any(mz)) hz = wfe_is_zero(m) && mz;
+  const bool rare = p1.inf || p2.inf || hz;
+  const uint32_t I = wfe_pow_chain_rolled<true>(wfe_mul(wfe_sqr(m, k), t, k), k);
+  const uint32_t I2 = wfe_sqr(I, k);
+  const uint32_t ut = wfe_mul(I, wfe_mul(m, t, k), k);          // ±√t
+  bool ok = wfe_is_zero(wfe_sqr(ut, k) + wfe_neg2(t, k));       // t is a square: (x, ·) is on the curve
+  const fe un = secp::fe_normalize(gather(ut));
+  const uint32_t u = ((un.n[0] & 1u) != v) ? wfe_neg1(ut, k) : ut;               // y_R: parity v (magnitude ≤ 2)
+  const uint32_t xq = wfe_mul(A + wfe_neg1(wfe_mul(Bn, u, k), k), I2, k);         // (A + B·u)·I²
+  const uint32_t yq = wfe_mul(wfe_mul2(C, u, D, t, k), wfe_mul(wfe_sqr(I2, k), m, k), k);  // (C·u + D·t)·I⁴·m
+  Qa.x = secp::fe_normalize(gather(xq));
+  Qa.y = secp::fe_normalize(gather(yq));
+  if (any(rare)) {
+    const uint32_t ys = wfe_mul(wfe_pow_chain_rolled<true>(t, k), t, k);          // t^((p+1)/4)
+    const bool onc = wfe_is_zero(wfe_sqr(ys, k) + wfe_neg2(t, k));
+    const fe yn = secp::fe_normalize(gather(ys));
+    const uint32_t yr = ((yn.n[0] & 1u) != v) ? wfe_neg1(ys, k) : ys;
+    wjac pe = p2;
+    pe.z = wfe_mul(p2.z, yr, k);
+    aff Qs;
+    const bool fin = wjac_to_aff(Qs, wjac_add(p1, pe, k), k);
+    Qa.x = secp::l26_select(rare, Qs.x, Qa.x);
+    Qa.y = secp::l26_select(rare, Qs.y, Qa.y);
+    ok = rare ? (onc && fin) : ok;
+  }
+  return ok;
+}
+
 // ---- sixteen lanes per signature: every ROW of the wavefront recovers its own signature -------------------
 // For batches between the one-wavefront form (n ≤ 2 048) and the point where eight lanes per signature
 // fill the chip (n = 8 192): four signatures per wavefront, so n = 4 096 is again one wavefront per SIMD.
@@ -1004,6 +1078,9 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
 // wtab[slot·64 + lane]; a lane only ever touches its own column, so no barrier is involved.
 #ifndef IBFT_ROWS_VARIANT
 #define IBFT_ROWS_VARIANT 2  // 1: table in registers, straight-line build (kept for A/B timing); 2: table in LDS, rolled loops
+#endif
+#ifndef IBFT_ROWS_DEFER_SQRT
+#define IBFT_ROWS_DEFER_SQRT 1  // 1: √ and the final inversion from one exponentiation at the end (rows_finish_deferred); 0: √ first, safegcd last (A/B)
 #endif
 constexpr int ROW_TAB_SLOTS = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products
 template <int STOP = 99>
@@ -1019,21 +1096,30 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   const fe rx = secp::fe_from_u256(r);
   const uint32_t x = scatter(rx, k);
   const uint32_t one = k.li == 0 ? 1u : 0u;
-  const uint32_t rhs = wfe_mul(wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u);  // magnitude 2
+  const uint32_t rhs = wfe_mul(wfe_sqr(x, k), x, k) + (k.li == 0 ? 7u : 0u);  // t = x³ + 7, magnitude 2
+#if IBFT_ROWS_DEFER_SQRT
+  // y = √t is not computed here: R′ = (x·t, t²) on the isomorphic curve stands in for R until the very end, where ONE
+  // exponentiation yields both √t and the inverse of the final Z (rows_finish_deferred)
+  const waff R1 = waff{wfe_mul(x, rhs, k), wfe_sqr(rhs, k)};
+  const uint32_t skeep = R1.x ^ R1.y;
+#else
   const uint32_t yc = wfe_sqrt_candidate_rolled(rhs, k);
   const bool on_curve = wfe_is_zero(wfe_sqr(yc, k) + wfe_neg2(rhs, k));  // cross-lane: every row evaluates it
   ok = ok && on_curve;
   fe y = secp::fe_normalize(gather(yc));
   y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
-  WV_STAGE(1, y.n[0] ^ y.n[3])
+  const waff R1 = waff{x, scatter(y, k)};
+  const uint32_t skeep = y.n[0] ^ y.n[3];
+#endif
+  WV_STAGE(1, skeep)
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ
   const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
-  WV_STAGE(21, y.n[0] ^ rinv.n[0] ^ rinv.n[9])
+  WV_STAGE(21, skeep ^ rinv.n[0] ^ rinv.n[9])
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
-  WV_STAGE(22, y.n[0] ^ u1.v[0] ^ u2.v[3])
+  WV_STAGE(22, skeep ^ u1.v[0] ^ u2.v[3])
   const secp::glv_split sp = secp::sc_split_lambda(u2);
-  WV_STAGE(2, y.n[0] ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
+  WV_STAGE(2, skeep ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
   // signed radix-16 digits of |k1|, |k2|: k + 0x88…8 has nibbles d_j + 8, bit 128 is digit 32
   uint32_t w1[5], w2[5];
   {
@@ -1048,7 +1134,6 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   }
 #if IBFT_ROWS_VARIANT == 1
   // tables 1..8 of R (affine start: mixed additions) and, through X·β, of λR
-  const waff R1 = waff{x, scatter(y, k)};
   wjac T[9];
   T[1] = wjac_from_aff(R1, k);
   T[2] = wjac_dbl(T[1], k);
@@ -1126,7 +1211,6 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   //   66 times) and Zc is multiplied into the accumulator's Z once, before the G additions.
   const uint32_t lane_ = lane_id();
 #define WT(slot) wtab[(slot) * 64 + lane_]
-  const waff R1 = waff{x, scatter(y, k)};
   {
     wjac cur = wjac_from_aff(R1, k);
     WT(0) = cur.x;
@@ -1200,17 +1284,27 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
 #endif
   acc.z = wfe_mul(acc.z, Zc, k);  // back from the isomorphic curve (an accumulator at infinity keeps its flag)
   WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
-  // u1·G: all the fixed-base windows in this row
+  // u1·G: all the fixed-base windows in this row — into the accumulator itself, or (deferred √) into one of its own: the
+  // table points are points of the curve, the accumulator still lives on the isomorphic one
+#if IBFT_ROWS_DEFER_SQRT
+  wjac accg = wjac_inf();
+#else
+  wjac &accg = acc;
+#endif
 #pragma unroll 1
   for (int win = 0; win < ibftk::GTAB_WINDOWS; win++) {
     const int bit = win * ibftk::GTAB_BITS;
     const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
     const waff pt = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt), k);
-    const wjac sum = wjac_add_aff<true>(acc, pt, k);
-    acc = wjac_select(dgt != 0, sum, acc);
+    const wjac sum = wjac_add_aff<true>(accg, pt, k);
+    accg = wjac_select(dgt != 0, sum, accg);
   }
-  WV_STAGE(5, acc.x ^ acc.y ^ acc.z)
+  WV_STAGE(5, acc.x ^ acc.y ^ acc.z ^ accg.x ^ accg.z)
+#if IBFT_ROWS_DEFER_SQRT
+  ok = rows_finish_deferred(Qa, accg, acc, rhs, v, k) && ok;
+#else
   ok = wjac_to_aff(Qa, acc, k) && ok;
+#endif
   WV_STAGE(6, Qa.x.n[0] ^ Qa.y.n[1])
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);

@@ -216,6 +216,41 @@ def test_row_per_signature_recover(wh, oracle):
         assert ok[16 * row] == 1 and addr[16 * row].tobytes() == oracle.recover_address(hs[row], sigs[row]), row
 
 
+def test_row_recover_when_the_last_addition_is_exceptional(wh, oracle):
+    """recover_pubkey_row adds u1·G to the u2·R accumulator in ONE symbolic addition at the very end (the square root of
+    x³ + 7 is still unknown there): u1·G = u2·R (the key is a doubling), u1·G = −u2·R (the key would be ∞: rejected),
+    u1 = 0, next to an ordinary row in the same wavefront — the rare route runs for all four rows, every row keeps its own answer."""
+    from oracle import pyref
+    wh.wvh_init_gtab()
+    rng = np.random.default_rng(515)
+    n = pyref.N
+    for trial in range(2):
+        hs, sigs = [], []
+        for sign in (1, -1):
+            k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+            x, y = pyref.pt_mul(k, pyref.G)
+            r, s = x % n, int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+            hs.append(((sign * s * k) % n).to_bytes(32, "big"))
+            sigs.append(r.to_bytes(32, "big") + s.to_bytes(32, "big") + bytes([(y & 1) ^ trial]))   # trial 1: the other root
+        ski = (int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1).to_bytes(32, "big")
+        hi = rng.bytes(32)
+        hs.append(hi); sigs.append(oracle.sign(ski, hi))
+        hs.append(bytes(32)); sigs.append(oracle.sign(ski, bytes(32)))
+        order = [0, 1, 2, 3] if trial == 0 else [2, 0, 3, 1]
+        hs, sigs = [hs[i] for i in order], [sigs[i] for i in order]
+        addr = np.zeros((64, 20), dtype=np.uint8)
+        ok = np.zeros(64, dtype=np.int32)
+        wh.wvh_recover4(b"".join(hs), b"".join(sigs), addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+        wants = [oracle.recover_address(h, sg) for h, sg in zip(hs, sigs)]
+        assert sum(w is None for w in wants) == (1 if trial == 0 else 0) or trial == 1
+        for row in range(4):
+            lanes = slice(16 * row, 16 * row + 16)
+            assert (ok[lanes] == ok[16 * row]).all() and (addr[lanes] == addr[16 * row]).all()
+            assert bool(ok[16 * row]) == (wants[row] is not None), (trial, row)
+            if wants[row] is not None:
+                assert addr[16 * row].tobytes() == wants[row], (trial, row)
+
+
 def test_byzantine_rows_through_both_emulated_recovers(wh, oracle):
     """One row of every corruption kind of the synthetic workload (random bytes, r = 0, s ≥ n, v = 2, stolen
     seal, …) plus honest rows through the one-wavefront recover and, four at a time, through the

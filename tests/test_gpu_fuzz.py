@@ -111,6 +111,52 @@ def test_crafted_scalars_all_variants(oracle, lanes, monkeypatch):
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64, 128])
+def test_last_addition_exceptional_all_variants(oracle, lanes, monkeypatch):
+    """u1·G = ±u2·R: the addition that joins the fixed-base part and the variable-base part meets equal or opposite points
+    (a doubling / the point at infinity — the latter is no key: rejected).  R = k·G, z = ±s·k; with the recovery id of the
+    other root too (then it is an ordinary addition).  Mixed with ordinary rows so that the rare route of the
+    row-per-signature kernel (which joins the two parts symbolically, before it knows √(x³+7)) runs next to common rows.
+    Every kernel variant, cold then warm, must agree with the oracle row by row."""
+    import go_ibft_amd.verifier as V
+    from oracle import pyref
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    n = pyref.N
+    rng = np.random.default_rng(909)
+    hs, sigs, signer, want = [], [], [], []
+    for i in range(24):
+        k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        x, y = pyref.pt_mul(k, pyref.G)
+        r, s = x % n, int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        if r != x:
+            continue
+        sign = 1 if i % 2 == 0 else -1
+        h = ((sign * s * k) % n).to_bytes(32, "big")
+        sig = r.to_bytes(32, "big") + s.to_bytes(32, "big") + bytes([(y & 1) ^ (1 if i % 3 == 2 else 0)])
+        a = oracle.recover_address(h, sig)
+        assert a == pyref.recover_address(h, sig)
+        hs.append(h); sigs.append(sig); want.append(a is not None)
+        signer.append(a if a is not None else bytes([i + 1]) * 20)
+    for i in range(8):                                # ordinary rows in between
+        ski = (int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1).to_bytes(32, "big")
+        h = rng.bytes(32)
+        sg = oracle.sign(ski, h)
+        hs.insert(3 * i, h); sigs.insert(3 * i, sg); want.insert(3 * i, True)
+        signer.insert(3 * i, oracle.recover_address(h, sg))
+    assert 4 <= want.count(False) <= 16
+    hs = np.array([np.frombuffer(h, dtype=np.uint8) for h in hs])
+    sigs = np.array([np.frombuffer(x, dtype=np.uint8) for x in sigs])
+    signer = np.array([np.frombuffer(a, dtype=np.uint8) for a in signer])
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=1024)
+    try:
+        bv.set_validators(1, np.unique(signer, axis=0), np.ones(len(np.unique(signer, axis=0)), dtype=np.uint64))
+        for _ in range(2):
+            got, _ = bv.is_valid_committed_seal(hs, sigs, signer)
+            assert got.tolist() == want
+    finally:
+        bv.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 64, 128])
 def test_recovery_id_policy_r_plus_n_candidate_is_never_tried(oracle, lanes, monkeypatch):
     """include/ibftgpu.h, conventions: v is the parity of R.y and nothing else — R.x = r always.  SEC 1 §4.1.6's
     second candidate R.x = r + n exists only for r < p − n (≈ 2^128.4); a signature whose TRUE nonce point has
