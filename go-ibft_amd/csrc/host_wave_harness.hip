@@ -155,6 +155,30 @@ void lane_rec4(void *vp) {
   j->ok[l] = ok ? 1 : 0;
 }
 
+// rows_finish_deferred on its own: per row P1 (on the curve), P2′ (on y² = x³ + 7t³), t and the recovery id
+struct fin_job {
+  const uint32_t *p1, *p2;  // [4][31] each
+  const uint32_t *t;        // [4][10]
+  const uint32_t *v;        // [4]
+  uint32_t *out;            // [4][21]: canonical x[10], y[10], ok
+};
+void lane_fin(void *vp) {
+  fin_job *j = (fin_job *)vp;
+  const wv::wk k = wv::wk_init();
+  const wv::wjac p1 = load_pt(j->p1, k), p2 = load_pt(j->p2, k);
+  const uint32_t t = k.li < 10 ? j->t[k.row * 10 + k.li] : 0u;
+  secp::aff Q;
+  const bool ok = wv::rows_finish_deferred(Q, p1, p2, t, j->v[k.row], k);
+  if (k.li == 0) {
+    uint32_t *o = j->out + 21 * k.row;
+    for (int i = 0; i < 10; i++) {
+      o[i] = Q.x.n[i];
+      o[10 + i] = Q.y.n[i];
+    }
+    o[20] = ok ? 1u : 0u;
+  }
+}
+
 struct inv_job {
   const uint8_t *x32;
   uint8_t *out;  // [64][32]
@@ -236,6 +260,10 @@ void wvh_fe_op(int op, const uint32_t *a, const uint32_t *b, uint32_t *out64) {
 void wvh_pt_op(int op, const uint32_t *p, const uint32_t *q, uint32_t *out) {
   pt_job j{p, q, out, op};
   wave_emul::run(lane_pt, &j);
+}
+void wvh_rows_finish(const uint32_t *p1, const uint32_t *p2, const uint32_t *t, const uint32_t *v, uint32_t *out) {
+  fin_job j{p1, p2, t, v, out};
+  wave_emul::run(lane_fin, &j);
 }
 void wvh_recover(const uint8_t *hash32, const uint8_t *sig65, uint32_t flags, uint8_t *addr64x20, int *ok64) {
   rec_job j{hash32, sig65, flags, addr64x20, ok64};

@@ -5,6 +5,8 @@ The exact device source is compiled for the host with the cross-lane primitives 
 Python big-int arithmetic and the oracle.  Test infrastructure only.
 """
 import ctypes
+import random
+
 import numpy as np
 import pytest
 
@@ -249,6 +251,74 @@ def test_row_recover_when_the_last_addition_is_exceptional(wh, oracle):
             assert bool(ok[16 * row]) == (wants[row] is not None), (trial, row)
             if wants[row] is not None:
                 assert addr[16 * row].tobytes() == wants[row], (trial, row)
+
+
+def test_rows_finish_deferred_against_big_integers(wh):
+    """The closing step of recover_pubkey_row on its own (wave_fe_dev.h: rows_finish_deferred): P1 on the curve, P2′ on the
+    isomorphic curve y² = x³ + 7t³ (the image of a point P2 under (x, y) → (x·u², y·u³), u = √t of parity v), both in
+    Jacobian coordinates with random Z.  Expected: the affine sum P1 + P2 — through the common route (ONE exponentiation
+    gives √t and the inverse) and through the rare one (P1 = ±P2, a part at infinity), mixed over the rows of a wavefront;
+    t not a square: rejected.  Big-integer arithmetic is the judge."""
+    import wave_cases as W2
+    from oracle import pyref
+    rng = random.Random(77)
+    P, n = W2.P, pyref.N
+
+    def image(pt, u, z):          # P2 → Jacobian point of the isomorphic curve with Z = z
+        x, y = pt
+        xi, yi = x * u * u % P, y * pow(u, 3, P) % P
+        return (xi * z * z % P, yi * pow(z, 3, P) % P, z, False)
+
+    def jac(pt, z):
+        return (pt[0] * z * z % P, pt[1] * pow(z, 3, P) % P, z, False)
+
+    def case(kind):
+        xr, yr = pyref.pt_mul(rng.randrange(1, n), pyref.G)
+        t, u = (xr ** 3 + 7) % P, (yr if rng.randrange(2) else P - yr)
+        k1 = rng.randrange(1, n)
+        p1 = pyref.pt_mul(k1, pyref.G)
+        p2 = pyref.pt_mul(rng.randrange(1, n), pyref.G)
+        if kind == "same":
+            p2 = p1
+        elif kind == "opposite":
+            p2 = (p1[0], P - p1[1])
+        want = pyref.pt_add(p1, p2)
+        j1, j2 = jac(p1, rng.randrange(1, P)), image(p2, u, rng.randrange(1, P))
+        v = u & 1
+        if kind == "p1_inf":
+            j1, want = (0, 0, 0, True), p2
+        elif kind == "p2_inf":
+            j2, want = (0, 0, 0, True), p1
+        elif kind == "both_inf":
+            j1 = j2 = (0, 0, 0, True)
+            want = None
+        elif kind == "not_square":
+            while pow(t, (P - 1) // 2, P) == 1:
+                t = rng.randrange(2, P)
+            want = None
+        elif kind == "other_root":          # the recovery id names −u: P2′ then stands for −P2
+            v ^= 1
+            want = pyref.pt_add(p1, (p2[0], P - p2[1]))
+        return j1, j2, t, v, want
+    kinds = ["common"] * 6 + ["same", "opposite", "p1_inf", "p2_inf", "both_inf", "not_square", "other_root"]
+    for it in range(14):
+        row_kinds = [kinds[(it * 4 + r) % len(kinds)] if it < 10 else "common" for r in range(4)]
+        if it == 10:
+            row_kinds = ["same", "common", "opposite", "common"]
+        cs = [case(kd) for kd in row_kinds]
+        p1 = W2.jac_rows([c[0] for c in cs]); p2 = W2.jac_rows([c[1] for c in cs])
+        t = np.array([W2.limbs(c[2]) for c in cs], dtype=np.uint32)
+        t[:, 0] += 0   # (canonical limbs: magnitude 1)
+        v = np.array([c[3] for c in cs], dtype=np.uint32)
+        out = np.zeros((4, 21), dtype=np.uint32)
+        wh.wvh_rows_finish(p1.ctypes.data_as(ctypes.c_void_p), p2.ctypes.data_as(ctypes.c_void_p), t.ctypes.data_as(ctypes.c_void_p),
+                           v.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        for r in range(4):
+            want = cs[r][4]
+            assert bool(out[r, 20]) == (want is not None), (it, r, row_kinds[r])
+            if want is not None:
+                assert (W2.value(out[r, :10]), W2.value(out[r, 10:20])) == want, (it, r, row_kinds[r])
+                assert all(int(x) < 2**26 for x in out[r, :20])
 
 
 def test_byzantine_rows_through_both_emulated_recovers(wh, oracle):
