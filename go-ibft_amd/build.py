@@ -46,15 +46,51 @@ def _mark(target: str, deps: list[str], extra: str = "") -> None:
         f.write(_digest(deps, extra) + "\n")
 
 
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+PHASE_ALIGN = os.environ.get("IBFT_NO_PHASE_ALIGN") != "1"
+
+
+def _build_lib_phase_aligned(verbose: bool) -> None:
+    """hipcc's own steps, taken apart so that the device assembly passes through go-ibft_amd/phase_align.py (8-byte
+    instructions on 8-byte boundaries: profiles/r04o_*): device code → assembly → aligned assembly → code object →
+    fat binary → host compile with that fat binary embedded → libibftgpu.so."""
+    import tempfile
+    from . import phase_align
+    src = os.path.join(CSRC, "ibftgpu.hip")
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS]
+    with tempfile.TemporaryDirectory(prefix="ibftgpu_build_") as d:
+        dev_s, al_s, dev_o, dev_out, fb = (os.path.join(d, n) for n in ("dev.s", "dev.aligned.s", "dev.o", "dev.out", "dev.hipfb"))
+        run = lambda cmd: subprocess.check_call(cmd, cwd=CSRC, stderr=None if verbose else subprocess.DEVNULL)
+        run(["hipcc", *common, "--cuda-device-only", "-S", "-o", dev_s, src])
+        phase_align.align_file(dev_s, al_s, dev_o, verbose=verbose)
+        run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_out, dev_o])
+        run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+             "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={dev_out}", f"-output={fb}"])
+        run(["hipcc", *common, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-shared", "-fPIC",
+             "-o", LIB, src, "-ldl"])
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS, "-shared", "-fPIC",
            "-o", LIB, os.path.join(CSRC, "ibftgpu.hip"), "-ldl"]
-    if force or _stale(LIB, SOURCES, " ".join(cmd[:-3])):
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd, cwd=CSRC)
-        _mark(LIB, SOURCES, " ".join(cmd[:-3]))
+    stamp_extra = " ".join(cmd[:-3]) + (" +phase_align" if PHASE_ALIGN else "")
+    deps = SOURCES + ([os.path.join("..", "phase_align.py")] if PHASE_ALIGN else [])
+    if force or _stale(LIB, deps, stamp_extra):
+        done = False
+        if PHASE_ALIGN:
+            try:
+                if verbose:
+                    print(" ".join(cmd), "  (+ phase_align.py between device assembly and code object)", flush=True)
+                _build_lib_phase_aligned(verbose)
+                done = True
+            except Exception as e:  # the one-shot build below is the same library without the alignment step
+                print(f"build: phase-aligned build failed ({e}); building with hipcc in one step", flush=True)
+        if not done:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
+        _mark(LIB, deps, stamp_extra)
     return LIB
 
 

@@ -1013,8 +1013,8 @@ WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
 // exactly as before (y_R has parity v), and I enters only through I², I⁴ and I·(the sign that is being fixed).  What this
 // replaces: a √ chain at the start AND a safegcd inversion of Z at the end (≈9 k issue slots) for ≈35 multiplications.
 // t not a square (r is no x coordinate): (I·m·t)² = −t ≠ t, the row is rejected like before.
-// Rare rows — P1 or the u2·R′ result at infinity, or H = 0 (u1·G = ±u2·R) — take the textbook route for the whole
-// wavefront: √t by the same chain, the accumulator moved to the curve, a complete addition, an inversion.
+// Rare rows — P1 or the u2·R′ result at infinity, or H = 0 (u1·G = ±u2·R) — go through the same chain with other inputs
+// (in the function).
 WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t t, uint32_t v, const wk &k) {
   const uint32_t z2s = wfe_mul(wfe_sqr(p2.z, k), t, k);  // Z2² = Z′²·t
   const uint32_t z1s = wfe_sqr(p1.z, k);
@@ -1026,43 +1026,54 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
   const uint32_t HHH = wfe_mul(HH, H, k);
   const uint32_t V = wfe_mul(U1, HH, k);
   // A = S2² + ŝ²·t − H³ − 2V: one reduction for the two products (1·1 + 1·2), then 1 + 2 + 3 → 1
-  const uint32_t A = wfe_weak(wfe_mul2(S2, S2, wfe_sqr(sh, k), t, k) + wfe_neg1(HHH, k) + wfe_neg2(2u * V, k), k);
-  const uint32_t Bn = wfe_mul(2u * S2, sh, k);                  // −B
+  uint32_t A = wfe_weak(wfe_mul2(S2, S2, wfe_sqr(sh, k), t, k) + wfe_neg1(HHH, k) + wfe_neg2(2u * V, k), k);
+  uint32_t Bn = wfe_mul(2u * S2, sh, k);                        // −B
   const uint32_t VA = V + wfe_neg1(A, k);                       // 3
-  const uint32_t C = wfe_mul2(S2, VA, wfe_neg1(wfe_mul(sh, t, k), k), Bn, k);   // 1·3 + 2·1
-  const uint32_t D = wfe_mul2(S2, Bn, wfe_neg1(sh, k), VA + HHH, k);             // 1·1 + 2·4
-  const uint32_t m = wfe_mul(wfe_mul(p1.z, p2.z, k), H, k);
+  uint32_t C = wfe_mul2(S2, VA, wfe_neg1(wfe_mul(sh, t, k), k), Bn, k);   // 1·3 + 2·1
+  uint32_t D = wfe_mul2(S2, Bn, wfe_neg1(sh, k), VA + HHH, k);            // 1·1 + 2·4
+  uint32_t m = wfe_mul(wfe_mul(p1.z, p2.z, k), H, k);
   // H ≡ 0 ⇔ m ≡ 0 (finite points have Z ≢ 0).  The cheap filter says "maybe" for one row in 4 000 — once per launch of
-  // 4 096 rows, and a launch lasts as long as its slowest wavefront: the exact test (75 instructions) decides before the
-  // rare route (≈35 k) is taken.
+  // 4 096 rows — so the exact test decides.
   const bool mz = wfe_z_maybe_zero(m);  // (cross-lane: every lane evaluates it)
   bool hz = false;
   if (any(mz)) hz = wfe_is_zero(m) && mz;
-  const bool rare = p1.inf || p2.inf || hz;
+  // The rare rows ride the SAME exponentiation with other (A, B, C, D, m) — a launch lasts as long as its slowest wavefront,
+  // and a validator can make any of these cases on purpose (z = ±s·k, z = 0), so none of them may cost a second chain
+  // or an inversion (the first version's textbook route did: +20 % for the whole launch):
+  //   P1 = ∞ (u1 = 0):           the sum is P2:      x = X′/(Z′²t), y = Y′·u/(Z′³t²)     →  (X′, 0, Y′, 0, Z′)
+  //   H = 0 (P2 = ±P1):          tentatively 2·P1 =: S, a point of the curve itself: x = X_S/Z_S², y = Y_S/Z_S³
+  //                                                                                     →  (X_S·t, 0, 0, Y_S·t, Z_S)
+  //                              and P2 = +P1 ⇔ S2 = ŝ·u is checked once u is known; P2 = −P1: the key would be ∞, rejected
+  //   P2′ = ∞ (cannot be the outcome of a valid row): S := P1, the same shape;   both ∞: rejected.
+  bool chk = false, rej = false;
+  if (any(p1.inf || p2.inf || hz)) {
+    const wjac d1 = wjac_dbl(p1, k);
+    const bool only1 = !p1.inf && (p2.inf || hz);  // the answer is a point S of the curve itself
+    const uint32_t xs = p2.inf ? p1.x : d1.x, ys = p2.inf ? p1.y : d1.y, zs = p2.inf ? p1.z : d1.z;
+    const uint32_t as = wfe_mul(xs, t, k), ds = wfe_mul(ys, t, k);
+    A = only1 ? as : (p1.inf ? p2.x : A);
+    Bn = (only1 || p1.inf) ? 0u : Bn;
+    C = only1 ? 0u : (p1.inf ? p2.y : C);
+    D = only1 ? ds : (p1.inf ? 0u : D);
+    m = only1 ? zs : (p1.inf ? p2.z : m);
+    chk = hz && !p1.inf && !p2.inf;
+    rej = p1.inf && p2.inf;
+  }
   const uint32_t I = wfe_pow_chain_rolled<true>(wfe_mul(wfe_sqr(m, k), t, k), k);
   const uint32_t I2 = wfe_sqr(I, k);
   const uint32_t ut = wfe_mul(I, wfe_mul(m, t, k), k);          // ±√t
   bool ok = wfe_is_zero(wfe_sqr(ut, k) + wfe_neg2(t, k));       // t is a square: (x, ·) is on the curve
   const fe un = secp::fe_normalize(gather(ut));
   const uint32_t u = ((un.n[0] & 1u) != v) ? wfe_neg1(ut, k) : ut;               // y_R: parity v (magnitude ≤ 2)
+  if (any(chk)) {
+    const bool same = wfe_is_zero(S2 + wfe_neg1(wfe_mul(sh, u, k), k));           // S1 = ŝ·u = S2: P2 = P1, the doubling stands
+    ok = ok && (!chk || same);
+  }
   const uint32_t xq = wfe_mul(A + wfe_neg1(wfe_mul(Bn, u, k), k), I2, k);         // (A + B·u)·I²
   const uint32_t yq = wfe_mul(wfe_mul2(C, u, D, t, k), wfe_mul(wfe_sqr(I2, k), m, k), k);  // (C·u + D·t)·I⁴·m
   Qa.x = secp::fe_normalize(gather(xq));
   Qa.y = secp::fe_normalize(gather(yq));
-  if (any(rare)) {
-    const uint32_t ys = wfe_mul(wfe_pow_chain_rolled<true>(t, k), t, k);          // t^((p+1)/4)
-    const bool onc = wfe_is_zero(wfe_sqr(ys, k) + wfe_neg2(t, k));
-    const fe yn = secp::fe_normalize(gather(ys));
-    const uint32_t yr = ((yn.n[0] & 1u) != v) ? wfe_neg1(ys, k) : ys;
-    wjac pe = p2;
-    pe.z = wfe_mul(p2.z, yr, k);
-    aff Qs;
-    const bool fin = wjac_to_aff(Qs, wjac_add(p1, pe, k), k);
-    Qa.x = secp::l26_select(rare, Qs.x, Qa.x);
-    Qa.y = secp::l26_select(rare, Qs.y, Qa.y);
-    ok = rare ? (onc && fin) : ok;
-  }
-  return ok;
+  return ok && !rej;
 }
 
 // ---- sixteen lanes per signature: every ROW of the wavefront recovers its own signature -------------------
@@ -1092,6 +1103,11 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     return ok;                \
   }
   const wk k = wk_init();
+#if defined(__HIP_DEVICE_COMPILE__) && defined(IBFT_ROWS_PAD_DWORDS)
+  // code-placement experiment (profiles/r04n_*): every instruction behind this point moves by 4·IBFT_ROWS_PAD_DWORDS bytes
+#pragma unroll
+  for (int pad_ = 0; pad_ < IBFT_ROWS_PAD_DWORDS; pad_++) asm volatile("s_nop 0");
+#endif
   bool ok = ibftk::sig_in_range(r, s, v, flags);
   const fe rx = secp::fe_from_u256(r);
   const uint32_t x = scatter(rx, k);

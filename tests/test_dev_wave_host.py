@@ -278,9 +278,9 @@ def test_rows_finish_deferred_against_big_integers(wh):
         k1 = rng.randrange(1, n)
         p1 = pyref.pt_mul(k1, pyref.G)
         p2 = pyref.pt_mul(rng.randrange(1, n), pyref.G)
-        if kind == "same":
+        if kind in ("same", "same_other_root"):
             p2 = p1
-        elif kind == "opposite":
+        elif kind in ("opposite", "opposite_other_root"):
             p2 = (p1[0], P - p1[1])
         want = pyref.pt_add(p1, p2)
         j1, j2 = jac(p1, rng.randrange(1, P)), image(p2, u, rng.randrange(1, P))
@@ -296,14 +296,14 @@ def test_rows_finish_deferred_against_big_integers(wh):
             while pow(t, (P - 1) // 2, P) == 1:
                 t = rng.randrange(2, P)
             want = None
-        elif kind == "other_root":          # the recovery id names −u: P2′ then stands for −P2
+        elif kind in ("other_root", "same_other_root", "opposite_other_root"):   # the recovery id names −u: P2′ then stands for −P2
             v ^= 1
             want = pyref.pt_add(p1, (p2[0], P - p2[1]))
         return j1, j2, t, v, want
-    kinds = ["common"] * 6 + ["same", "opposite", "p1_inf", "p2_inf", "both_inf", "not_square", "other_root"]
-    for it in range(14):
-        row_kinds = [kinds[(it * 4 + r) % len(kinds)] if it < 10 else "common" for r in range(4)]
-        if it == 10:
+    kinds = ["common"] * 6 + ["same", "opposite", "p1_inf", "p2_inf", "both_inf", "not_square", "other_root", "same_other_root", "opposite_other_root"]
+    for it in range(16):
+        row_kinds = [kinds[(it * 4 + r) % len(kinds)] if it < 12 else "common" for r in range(4)]
+        if it == 12:
             row_kinds = ["same", "common", "opposite", "common"]
         cs = [case(kd) for kd in row_kinds]
         p1 = W2.jac_rows([c[0] for c in cs]); p2 = W2.jac_rows([c[1] for c in cs])
