@@ -55,7 +55,13 @@ def _build_lib_phase_aligned(verbose: bool) -> None:
     instructions on 8-byte boundaries: profiles/r04o_*): device code → assembly → aligned assembly → code object →
     fat binary → host compile with that fat binary embedded → libibftgpu.so."""
     import tempfile
-    from . import phase_align
+    try:
+        from . import phase_align
+    except ImportError:  # (run as a script: python go-ibft_amd/build.py)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("phase_align", os.path.join(HERE, "phase_align.py"))
+        phase_align = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(phase_align)
     src = os.path.join(CSRC, "ibftgpu.hip")
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS]
     with tempfile.TemporaryDirectory(prefix="ibftgpu_build_") as d:
