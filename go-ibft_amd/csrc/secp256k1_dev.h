@@ -719,22 +719,53 @@ struct glv_split {
   u256 k1, k2;  // magnitudes, < 2^128
   bool neg1, neg2;
 };
+// low 256 bits of c·w for c < 2^128 (a mul_shift_384 result: limbs 5..9 are zero) and a constant w < 2^130 (five 26-bit limbs)
+HD u256 mul_c_by_const(const sc &c, const uint32_t (&w)[5]) {
+  uint64_t E[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) E[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int j = 0; j < 5; j++) E[i + j] += (uint64_t)c.n[i] * w[j];  // < 5·2^53
+  l26 r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    r.n[k] = (uint32_t)E[k] & M26;
+    E[k + 1] += E[k] >> 26;
+  }
+  r.n[8] = (uint32_t)E[8] & M26;
+  r.n[9] = (uint32_t)(E[8] >> 26) & M22;  // (bits ≥ 256 are dropped: the caller works modulo 2^256)
+  return l26_to_u256(r);
+}
+// Round 4: the split in EXACT INTEGERS.  With c1 = round(k·g1/2^384), c2 = round(k·g2/2^384) the halves are
+//   k1 = k − c1·a1 − c2·a2      k2 = −c1·b1 − c2·b2 = c1·|b1| − c2·a1        (b2 = a1)
+// and both lie in (−2^128, 2^128): computed modulo 2^256 in two's complement they are exact, the sign is bit 255.  Four
+// 128 × 130-bit products instead of three multiplications modulo n with their four-round reductions, three
+// canonicalisations and two modular additions (the same k1, k2: k1 + k2·λ ≡ k and the bounds are what the tests check).
 HD glv_split sc_split_lambda(const u256 &k) {  // k in [0, n)
-  sc ks = sc_from_u256(k);
-  sc c1 = sc_mul(mul_shift_384(ks, GLV_CONST(4)), GLV_CONST(2));
-  sc c2 = sc_mul(mul_shift_384(ks, GLV_CONST(5)), GLV_CONST(3));
-  u256 r2 = add_mod_n(sc_canon(c1), sc_canon(c2));
-  u256 t = sc_canon(sc_mul(sc_from_u256(r2), GLV_CONST(0)));
-  u256 r1 = add_mod_n(k, sc_neg_canon(t));
+  const uint32_t A1[5] = {0x284EB15u, 0x3243924u, 0x2BCDE86u, 0x0869F51u, 0x03086D2u};   // a1 = b2
+  const uint32_t B1M[5] = {0x2BFE4C3u, 0x11FEA42u, 0x08286F5u, 0x358043Au, 0x0E4437Eu};  // −b1
+  const uint32_t A2[5] = {0x144CFD8u, 0x0442367u, 0x33F657Cu, 0x3DEA38Bu, 0x114CA50u};   // a2 (129 bits)
+  const sc ks = sc_from_u256(k);
+  const sc c1 = mul_shift_384(ks, GLV_CONST(4)), c2 = mul_shift_384(ks, GLV_CONST(5));
+  u256 k2w, t, k1w;
+  sub256(k2w, mul_c_by_const(c1, B1M), mul_c_by_const(c2, A1));
+  {
+    const u256 p = mul_c_by_const(c1, A1), q = mul_c_by_const(c2, A2);
+    uint32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t.v[i] = addc(p.v[i], q.v[i], cy);
+  }
+  sub256(k1w, k, t);
   glv_split s;
-  // a "negative" residue is one above (n−1)/2: x − 1 ≥ (n−1)/2  ⇔  x > (n−1)/2
-  u256 m1;
-  sub256(m1, r1, one256());
-  s.neg1 = !is_zero(r1) && geq_const(m1, NHL());
-  sub256(m1, r2, one256());
-  s.neg2 = !is_zero(r2) && geq_const(m1, NHL());
-  s.k1 = select(s.neg1, sc_neg_canon(r1), r1);
-  s.k2 = select(s.neg2, sc_neg_canon(r2), r2);
+  s.neg1 = (k1w.v[7] >> 31) != 0;
+  s.neg2 = (k2w.v[7] >> 31) != 0;
+  u256 n1, n2;
+  sub256(n1, zero256(), k1w);
+  sub256(n2, zero256(), k2w);
+  s.k1 = select(s.neg1, n1, k1w);
+  s.k2 = select(s.neg2, n2, k2w);
   return s;
 }
 
