@@ -230,7 +230,11 @@ void IngestQueue::loop() {
         // a short wait for a burst to finish arriving, as long as messages keep coming
         const auto dl = std::chrono::microseconds(linger_us_);
         while (!stop_ && off_.size() - 1 < max_rows_ && std::chrono::steady_clock::now() - last_push_ < dl)
-          cv_.wait_for(lk, dl / 4 + std::chrono::microseconds(1));
+          // (a system_clock deadline: pthread_cond_timedwait.  wait_for goes through pthread_cond_clockwait, which GCC 11's
+          // ThreadSanitizer does not intercept — it then misses the unlock / relock inside the wait and reports "double lock"
+          // and races on everything this mutex guards: tests/test_host_sanitize.py, flaky exactly when this line waited.  The
+          // loop re-reads the steady clock, so a wall-clock step only ends one 13 µs nap early or late.)
+          cv_.wait_until(lk, std::chrono::system_clock::now() + dl / 4 + std::chrono::microseconds(1));
         if (stop_) return;
       }
       off.swap(off_);
