@@ -114,6 +114,69 @@ HD uint32_t lane_perm(uint32_t v, uint32_t src) {
   return v + src;
 #endif
 }
+// gfx950's row swaps (v_permlane16_swap_b32 / v_permlane32_swap_b32): VALU instructions that exchange whole DPP rows
+// between TWO registers — no LDS round trip, unlike ds_bpermute (which a lone wavefront per SIMD waits out in full).
+// With d = [d0 d1 d2 d3], s = [s0 s1 s2 s3] (one letter per row of sixteen lanes):
+//   rows_swap16(d, s): a = [d0 s0 d2 s2], b = [d1 s1 d3 s3]     (odd rows of d ↔ even rows of s)
+//   rows_swap32(d, s): a = [d0 d1 s0 s1], b = [d2 d3 s2 s3]     (upper half of d ↔ lower half of s)
+// so rows_swap16(v, v) followed by rows_swap32 of a result with itself broadcasts one row to all four.
+struct u32x2 {
+  uint32_t a, b;
+};
+#ifndef IBFT_ROW_SWAPS
+#define IBFT_ROW_SWAPS 1  // 0: the same exchanges through ds_bpermute (A/B timing)
+#endif
+HD u32x2 rows_swap16(uint32_t d, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if IBFT_ROW_SWAPS
+  const auto r = __builtin_amdgcn_permlane16_swap(d, s, false, false);
+  return u32x2{r[0], r[1]};
+#else
+  const uint32_t l = __lane_id();
+  const uint32_t sd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l - 16u) << 2), (int)s);
+  const uint32_t du = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l + 16u) << 2), (int)d);
+  return u32x2{(l & 16u) ? sd : d, (l & 16u) ? s : du};
+#endif
+#elif defined(IBFT_WAVE_EMUL)
+  const int l = wave_emul::lane();
+  const bool odd = (l & 16) != 0;
+  const uint32_t sd = wave_emul::xchg(s, odd ? l - 16 : l, 0x610u);
+  const uint32_t du = wave_emul::xchg(d, odd ? l : l + 16, 0x611u);
+  return u32x2{odd ? sd : d, odd ? s : du};
+#else
+  return u32x2{d, s};
+#endif
+}
+HD u32x2 rows_swap32(uint32_t d, uint32_t s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#if IBFT_ROW_SWAPS
+  const auto r = __builtin_amdgcn_permlane32_swap(d, s, false, false);
+  return u32x2{r[0], r[1]};
+#else
+  const uint32_t l = __lane_id();
+  const uint32_t sd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l - 32u) << 2), (int)s);
+  const uint32_t du = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l + 32u) << 2), (int)d);
+  return u32x2{(l & 32u) ? sd : d, (l & 32u) ? s : du};
+#endif
+#elif defined(IBFT_WAVE_EMUL)
+  const int l = wave_emul::lane();
+  const bool up = (l & 32) != 0;
+  const uint32_t sd = wave_emul::xchg(s, up ? l - 32 : l, 0x620u);
+  const uint32_t du = wave_emul::xchg(d, up ? l : l + 32, 0x621u);
+  return u32x2{up ? sd : d, up ? s : du};
+#else
+  return u32x2{d, s};
+#endif
+}
+// the value the same lane of the row 16 / 32 lanes away holds (lane ^ 16, lane ^ 32)
+HD uint32_t row_partner16(uint32_t v) {
+  const u32x2 r = rows_swap16(v, v);  // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
+  return (lane_id() & 16u) ? r.a : r.b;
+}
+HD uint32_t row_partner32(uint32_t v) {
+  const u32x2 r = rows_swap32(v, v);  // a = [v0 v1 v0 v1], b = [v2 v3 v2 v3]
+  return (lane_id() & 32u) ? r.a : r.b;
+}
 HD bool any(bool c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __any(c ? 1 : 0) != 0;
@@ -456,10 +519,22 @@ WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
 }
 HD wjac wjac_lane_xor(const wjac &p, int off) {
   wjac r;
-  r.x = lane_xor(p.x, off);
-  r.y = lane_xor(p.y, off);
-  r.z = lane_xor(p.z, off);
-  r.inf = lane_xor(p.inf ? 1u : 0u, off) != 0;
+  if (off == 16) {
+    r.x = row_partner16(p.x);
+    r.y = row_partner16(p.y);
+    r.z = row_partner16(p.z);
+    r.inf = row_partner16(p.inf ? 1u : 0u) != 0;
+  } else if (off == 32) {
+    r.x = row_partner32(p.x);
+    r.y = row_partner32(p.y);
+    r.z = row_partner32(p.z);
+    r.inf = row_partner32(p.inf ? 1u : 0u) != 0;
+  } else {
+    r.x = lane_xor(p.x, off);
+    r.y = lane_xor(p.y, off);
+    r.z = lane_xor(p.z, off);
+    r.inf = lane_xor(p.inf ? 1u : 0u, off) != 0;
+  }
   return r;
 }
 HD jac wjac_gather(const wjac &p) {
@@ -592,20 +667,25 @@ WVF uint32_t sqrt_side_tail(const sqrt_side &sd, const wk &k) {
 
 // ---- prefix doublings with the three rows working on ONE point ----------------------------------------
 // dbl-2009-l has three dependent levels of multiplications: {X², Y², 2Y·Z} → {B², (X+B)², (3A)²} →
-// {E·(D − X3)}.  Rows 0..2 take one product each, ds_bpermute moves the results between rows: three
-// wfe_mul per doubling instead of seven.  In: X, Y valid in rows 0..2 (replicated), Z valid in row 2.
+// {E·(D − X3)}.  Rows 0..2 take one product each, row swaps move the results between rows (five swaps a doubling;
+// ds_bpermute, two LDS round trips a doubling, is what this replaced): three wfe_mul per doubling instead of seven.  In: X, Y valid in rows 0..2 (replicated), Z valid in row 2.
 template <bool SPECIAL>
 WVF void prefix_dbl(uint32_t &X, uint32_t &Y, uint32_t &Z, sqrt_side &sd, int i, const wk &k) {
   const bool r0 = k.row == 0, r1 = k.row == 1, r2 = k.row == 2;
   // level 1: row 0: A = X², row 1: B = Y², row 2: Z3 = 2Y·Z
   const uint32_t m1 = mul_with_side<0, SPECIAL>(r0 ? X : (r2 ? 2u * Y : Y), r0 ? X : (r2 ? Z : Y), sd, i, k);
-  // row 0 ← B (row 1), row 2 ← A (row 0)
-  const uint32_t v1 = lane_perm(m1, ((r0 ? 1u : (r2 ? 0u : k.row)) << 4) | k.li);
+  // rows 0, 1 ← B (row 1), every row ← A (row 0): m1 = [A B Z3 ·] → [A A Z3 Z3], [B B · ·] → [A A A A]
+  const u32x2 e1 = rows_swap16(m1, m1);
+  const uint32_t A = rows_swap32(e1.a, e1.a).a;
+  const uint32_t v1 = r2 ? A : e1.b;
   // level 2: row 0: C = B², row 1: (X + B)², row 2: F = (3A)²
   const uint32_t o2 = r1 ? X + v1 : (r2 ? 3u * v1 : v1);  // magnitudes 1, 2, 3
   const uint32_t m2 = mul_with_side<1, SPECIAL>(o2, o2, sd, i, k);
-  const uint32_t A = lane_perm(m1, k.li), C = lane_perm(m2, k.li);
-  const uint32_t T = lane_perm(m2, 16u | k.li), F = lane_perm(m2, 32u | k.li);
+  // m2 = [C T F ·] → [C C F F], [T T · ·] → [C C C C], [F F F F] and [T T T T]
+  const u32x2 e2 = rows_swap16(m2, m2);
+  const u32x2 cf = rows_swap32(e2.a, e2.a);
+  const uint32_t C = cf.a, F = cf.b;
+  const uint32_t T = rows_swap32(e2.b, e2.b).a;
   const uint32_t t = T + wfe_neg1(A, k) + wfe_neg1(C, k);    // 5
   const uint32_t D = wfe_weak(2u * t, k);                    // 10 → 1
   const uint32_t X3 = wfe_weak(F + wfe_neg2(2u * D, k), k);  // 4 → 1
@@ -1090,6 +1170,9 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
 #ifndef IBFT_ROWS_VARIANT
 #define IBFT_ROWS_VARIANT 2  // 1: table in registers, straight-line build (kept for A/B timing); 2: table in LDS, rolled loops
 #endif
+#ifndef IBFT_ROWS_PEEL
+#define IBFT_ROWS_PEEL 1  // 1: the first digit of the main loop and the first G window are choices, not additions (A/B: 0)
+#endif
 #ifndef IBFT_ROWS_DEFER_SQRT
 #define IBFT_ROWS_DEFER_SQRT 1  // 1: √ and the final inversion from one exponentiation at the end (rows_finish_deferred); 0: √ first, safegcd last (A/B)
 #endif
@@ -1276,8 +1359,24 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   }
   WV_STAGE(3, WT(0) ^ WT(7) ^ WT(23) ^ u1.v[0] ^ w1[0] ^ w2[1] ^ Zc)
   wjac acc = wjac_inf();
+#if IBFT_ROWS_PEEL
+  // Digit 32 (the carry bit of the recoding, 0 or 1, never negative) outside the loop: the accumulator is still at
+  // infinity, so k1's digit is a choice between T[1] and infinity, not an addition, and k2's is ONE addition that runs
+  // once per signature (outlined multiply: its code is fetched, not executed).
+  {
+    const uint32_t y1 = WT(1);
+    const uint32_t yn = wfe_neg1(y1, k);  // magnitude 2
+    const wjac first = wjac_from_aff(waff{WT(0), sp.neg1 ? yn : y1}, k);
+    acc = wjac_select((w1[4] & 1u) != 0, first, acc);
+    const wjac s2 = wjac_add_aff(acc, waff{WT(2), sp.neg2 ? yn : y1}, k);
+    acc = wjac_select((w2[4] & 1u) != 0, s2, acc);
+  }
+#pragma unroll 1
+  for (int jd = 31; jd >= 0; jd--) {
+#else
 #pragma unroll 1
   for (int jd = 32; jd >= 0; jd--) {
+#endif
     // digit jd of both scalars (digit 32 is the carry bit, never negative); the table reads are issued before the
     // doublings that hide their latency
     const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
@@ -1307,8 +1406,19 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
 #else
   wjac &accg = acc;
 #endif
+#if IBFT_ROWS_PEEL && IBFT_ROWS_DEFER_SQRT
+  // window 0 into an accumulator at infinity is the table point itself (or still infinity for a zero digit)
+  {
+    const uint32_t dgt = u1.v[0] & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    const waff pt = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * (size_t)dgt, k);
+    accg = wjac_select(dgt != 0, wjac_from_aff(pt, k), accg);
+  }
+#pragma unroll 1
+  for (int win = 1; win < ibftk::GTAB_WINDOWS; win++) {
+#else
 #pragma unroll 1
   for (int win = 0; win < ibftk::GTAB_WINDOWS; win++) {
+#endif
     const int bit = win * ibftk::GTAB_BITS;
     const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
     const waff pt = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt), k);

@@ -218,6 +218,69 @@ def test_row_per_signature_recover(wh, oracle):
         assert ok[16 * row] == 1 and addr[16 * row].tobytes() == oracle.recover_address(hs[row], sigs[row]), row
 
 
+def _glv_split_exact(k):
+    """k = k1 + k2·λ (mod n) by rounding to the lattice basis (a1, b1), (a2, b2) — the decomposition every GLV
+    implementation of this curve returns away from rounding ties (secp::sc_split_lambda in integers)."""
+    from oracle import pyref
+    n = pyref.N
+    a1, b1 = 0x3086D221A7D46BCDE86C90E49284EB15, -0xE4437ED6010E88286F547FA90ABFE4C3
+    a2, b2 = 0x114CA50F7A8E2F3F657C1108D9D44CFD8, 0x3086D221A7D46BCDE86C90E49284EB15
+    c1 = (b2 * k + n // 2) // n
+    c2 = (-b1 * k + n // 2) // n
+    return k - c1 * a1 - c2 * a2, -c1 * b1 - c2 * b2
+
+
+def test_row_recover_first_digits_outside_the_loops(wh, oracle):
+    """recover_pubkey_row takes digit 32 of the signed radix-16 recoding (the carry of |k| + 0x88…8 out of bit 127) and the
+    first fixed-base window outside their loops — a choice between a table point and ∞, not an addition.  The three
+    combinations of the two carries that the split can produce (its range is a parallelogram: |k1| and |k2| are never both
+    above 0x77…78), each with a zero and a non-zero first window of u1, both signs of k1 / k2 among them, and u1 = 0
+    next to a carry: every row answers as the oracle does."""
+    from oracle import pyref
+    wh.wvh_init_gtab()
+    n = pyref.N
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    rng = np.random.default_rng(3232)
+    carry = lambda k: int(abs(k) + int("8" * 32, 16) >= 1 << 128)
+    found = {}
+    signs = set()
+    while len(found) < 3:
+        u2 = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+        k1, k2 = _glv_split_exact(u2)
+        assert (k1 + k2 * lam - u2) % n == 0 and abs(k1) < 1 << 128 and abs(k2) < 1 << 128
+        key = (carry(k1), carry(k2))
+        if key not in found:
+            found[key] = u2
+            signs.add((k1 < 0, k2 < 0))
+    assert len(signs) >= 2
+    rows = []
+    for key in sorted(found):
+        for zero_window in (False, True):
+            u1 = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+            if zero_window:
+                u1 &= ~0xFFFF
+            rows.append((u1, found[key]))
+    assert sorted(found) == [(0, 0), (0, 1), (1, 0)]
+    rows += [(0, found[(1, 0)]), (1 << 16, found[(0, 1)])]
+    for base in range(0, len(rows), 4):
+        hs, sigs = [], []
+        for u1, u2 in rows[base:base + 4]:
+            k = int.from_bytes(rng.bytes(32), "big") % (n - 1) + 1
+            x, y = pyref.pt_mul(k, pyref.G)
+            r = x % n
+            hs.append(((-u1 * r) % n).to_bytes(32, "big"))          # u1 = −z/r
+            sigs.append(r.to_bytes(32, "big") + ((u2 * r) % n).to_bytes(32, "big") + bytes([y & 1]))   # u2 = s/r
+        addr = np.zeros((64, 20), dtype=np.uint8)
+        ok = np.zeros(64, dtype=np.int32)
+        wh.wvh_recover4(b"".join(hs), b"".join(sigs), addr.ctypes.data_as(ctypes.c_void_p), ok.ctypes.data_as(ctypes.c_void_p))
+        for row in range(4):
+            want = oracle.recover_address(hs[row], sigs[row])
+            lanes = slice(16 * row, 16 * row + 16)
+            assert want is not None
+            assert (ok[lanes] == 1).all() and (addr[lanes] == addr[16 * row]).all(), (base, row)
+            assert addr[16 * row].tobytes() == want, (base, row)
+
+
 def test_row_recover_when_the_last_addition_is_exceptional(wh, oracle):
     """recover_pubkey_row adds u1·G to the u2·R accumulator in ONE symbolic addition at the very end (the square root of
     x³ + 7 is still unknown there): u1·G = u2·R (the key is a doubling), u1·G = −u2·R (the key would be ∞: rejected),
