@@ -892,6 +892,9 @@ WVF wjac gen_windows_wave(const uint32_t *__restrict__ gtab, const u256 &u1, wja
   }
   return acc;
 }
+#ifndef IBFT_WAVE_COMMON_Z
+#define IBFT_WAVE_COMMON_Z 1  // 1: the one-wavefront recover brings each row's table to one common Z (mixed additions); 0: A/B
+#endif
 // ---- the recover, one signature per wavefront -------------------------------------------------------
 // Same contract and rejection list as ibftk::recover_pubkey (recover_dev.h); every lane of the
 // wavefront passes the same (z, r, s, v) and gets the same answer.
@@ -995,6 +998,49 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   T[6] = wjac_dbl(T[3], k);
   T[7] = wjac_add(T[6], T[1], k);
   T[8] = wjac_dbl(T[4], k);
+#if IBFT_WAVE_COMMON_Z
+  // ONE common Z for the row's table, as in the row-per-signature recover: with Zc = z1·…·z8 and s_i = Zc / z_i entry i
+  // is the affine point (x_i·s_i², y_i·s_i³) of an isomorphic curve, the sixteen additions of the main loop are MIXED
+  // (10.5 multiplications instead of 16) and Zc goes into the accumulator's Z once behind the loop: 51 multiplications
+  // spent, 88 saved per row.  pre[i] = z1·…·z_i forward, suf = z_{i+1}·…·z8 while walking down.
+  uint32_t AX[9], AY[9], Zc;
+  {
+    uint32_t pre[8];
+    pre[1] = T[1].z;
+#pragma unroll
+    for (int i = 2; i <= 7; i++) pre[i] = wfe_mul(pre[i - 1], T[i].z, k);
+    uint32_t suf = one;
+#pragma unroll
+    for (int i = 8; i >= 1; i--) {
+      const uint32_t sc = i == 8 ? pre[7] : (i == 1 ? suf : wfe_mul(pre[i - 1], suf, k));
+      const uint32_t s2 = wfe_sqr(sc, k);
+      AX[i] = wfe_mul(T[i].x, s2, k);
+      AY[i] = wfe_mul(T[i].y, wfe_mul(s2, sc, k), k);
+      suf = i == 8 ? T[8].z : wfe_mul(suf, T[i].z, k);
+    }
+    Zc = suf;
+  }
+  WV_STAGE(3, AX[3] ^ AY[5] ^ AX[6] ^ AX[7] ^ AY[8] ^ Zc ^ yc ^ u1.v[0])
+  wjac acc = wjac_select(top, wjac_from_aff(waff{AX[1], AY[1]}, k), wjac_inf());
+#pragma unroll 1
+  for (int jd = 15; jd >= 0; jd--) {
+#pragma unroll 1
+    for (int d = 0; d < 4; d++) acc = wjac_dbl<true>(acc, k);
+    const uint32_t word = jd >= 8 ? d_hi : d_lo;
+    const int dg = (int)((word >> (4 * (jd & 7))) & 15u) - 8;
+    const uint32_t mag = (uint32_t)(dg < 0 ? -dg : dg);
+    waff q = waff{AX[1], AY[1]};
+#pragma unroll
+    for (int e = 2; e <= 8; e++) {
+      q.x = mag == (uint32_t)e ? AX[e] : q.x;
+      q.y = mag == (uint32_t)e ? AY[e] : q.y;
+    }
+    q.y = dg < 0 ? wfe_neg1(q.y, k) : q.y;  // magnitude ≤ 2
+    const wjac sum = wjac_add_aff<true>(acc, q, k);
+    acc = wjac_select(mag != 0, sum, acc);
+  }
+  acc.z = wfe_mul(acc.z, Zc, k);  // back from the table's curve (an accumulator at infinity keeps its flag)
+#else
   WV_STAGE(3, T[3].x ^ T[5].y ^ T[6].z ^ T[7].x ^ T[8].y ^ yc ^ u1.v[0])
   wjac acc = wjac_select(top, T[1], wjac_inf());
 #pragma unroll 1
@@ -1011,6 +1057,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
     const wjac sum = wjac_add<true>(acc, q, k);
     acc = wjac_select(mag != 0, sum, acc);
   }
+#endif
   WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ yc ^ u1.v[0])
   // back to the real curve: y² = w ?  parity(y) = v; Z ← Z·y
   ok = ok && wfe_is_zero(wfe_sqr(yc, k) + wfe_neg1(w, k));
