@@ -144,7 +144,7 @@ ISSUE_NS = {1: {"plain": 2.07, "dpp": 2.22, "mad": 2.50}, 2: {"plain": 1.11, "dp
 LANES_OF = {"ecrecover_wave2_kernel": 128, "ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 1, "ecrecover_rows_kernel": 16, "ecrecover_wave_kernel": 64,
             "verify_known_wave_kernel": 64}
 # wavefronts a SIMD can hold (512 registers per lane: go-ibft_amd/csrc resource usage, tools/occupancy.py)
-RESIDENT_CAP = {"ecrecover_lane_kernel": 2, "verify_known_lane_kernel": 2, "ecrecover_rows_kernel": 2, "ecrecover_wave_kernel": 2,
+RESIDENT_CAP = {"ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 2, "ecrecover_rows_kernel": 2, "ecrecover_wave_kernel": 2,
                 "verify_known_wave_kernel": 2, "ecrecover_group_kernel": 1, "verify_known_group_kernel": 2}
 
 

@@ -692,14 +692,21 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
     const u256 kb = window_bias(kk);
 #pragma unroll 1
     for (int nib = NIBS; nib >= 0; nib--) {
+      const int at = (int)(piece * NIBS) + nib;
+      const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
+      const int e = mine ? (int)secp::nibble(kb, at) - 8 : 0;
+#if IBFT_WINDOW_PREFETCH
+      const aff q = window_operand(wt, e, half != 0, flip);  // read in front of the doublings that cover its latency
+#endif
       if (nib != NIBS) {
 #pragma unroll 1
         for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
       }
-      const int at = (int)(piece * NIBS) + nib;
-      const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
-      const int e = mine ? (int)secp::nibble(kb, at) - 8 : 0;
+#if IBFT_WINDOW_PREFETCH
+      acc = window_add_q(acc, q, e);
+#else
       acc = window_add(acc, wt, e, half != 0, flip);
+#endif
     }
     acc.z = secp::fe_mul(acc.z, secp::fe_mul(wt.zc, base.z));
   }

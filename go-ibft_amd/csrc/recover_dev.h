@@ -144,16 +144,29 @@ __host__ __device__ __forceinline__ u256 window_bias(const u256 &k) {
   return r;
 }
 constexpr int WINDOW_DIGITS = 33;
-// one signed-window addition: acc ± entry |e| of the table (X or β·X), nothing for e = 0; the INL code shape
-__host__ __device__ __forceinline__ jac window_add(const jac &acc, const wtab &t, int e, bool lambda, bool flip) {
+// one signed-window addition: acc ± entry |e| of the table (X or β·X), nothing for e = 0; the INL code shape.
+// In two halves, because the table lives in the lane's private segment: window_operand READS the entry — the callers issue
+// it in front of the four doublings of the window, whose ≈520 instructions then cover the latency of the scratch loads (a
+// lone wavefront per SIMD otherwise waits it out, 66 times per signature; hosts differ in how fast scratch is served:
+// DESIGN.md §5.1) — and window_add_q adds it.
+#ifndef IBFT_WINDOW_PREFETCH
+#define IBFT_WINDOW_PREFETCH 1  // 0: the entry is read where it is used, behind the doublings (A/B)
+#endif
+__host__ __device__ __forceinline__ aff window_operand(const wtab &t, int e, bool lambda, bool flip) {
   const uint32_t mag = (uint32_t)(e < 0 ? -e : e);
   const uint32_t idx = mag ? mag : 1u;  // (a dummy operand for e = 0: the sum is computed and dropped)
   aff q;
   q.x = secp::l26_select(lambda, t.bx[idx], t.x[idx]);
   const secp::fe y = t.y[idx];
   q.y = secp::l26_select((e < 0) != flip, secp::fe_neg(y, 1), y);  // magnitude ≤ 2
+  return q;
+}
+__host__ __device__ __forceinline__ jac window_add_q(const jac &acc, const aff &q, int e) {
   const jac sum = secp::jac_add_aff_t<true>(acc, q);
-  return secp::jac_select(mag != 0, sum, acc);
+  return secp::jac_select(e != 0, sum, acc);
+}
+__host__ __device__ __forceinline__ jac window_add(const jac &acc, const wtab &t, int e, bool lambda, bool flip) {
+  return window_add_q(acc, window_operand(t, e, lambda, flip), e);
 }
 __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) {
   secp::glv_split sp = secp::sc_split_lambda(k);
@@ -166,14 +179,25 @@ __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) 
   jac acc = secp::jac_inf();
 #pragma unroll 1
   for (int i = WINDOW_DIGITS - 1; i >= 0; i--) {
+#if IBFT_WINDOW_PREFETCH
+    const int e1 = (int)secp::nibble(k1, i) - 8, e2 = (int)secp::nibble(k2, i) - 8;
+    const aff q1 = window_operand(t, e1, false, false), q2 = window_operand(t, e2, true, flip2);
+#endif
     if (i != WINDOW_DIGITS - 1) {
 #pragma unroll 1
       for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
     }
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {
+#if IBFT_WINDOW_PREFETCH
+      aff q;  // (one inlined copy of the mixed addition: the operand is chosen, not the code)
+      q.x = secp::l26_select(h != 0, q2.x, q1.x);
+      q.y = secp::l26_select(h != 0, q2.y, q1.y);
+      acc = window_add_q(acc, q, h ? e2 : e1);
+#else
       const int e = (int)(h ? secp::nibble(k2, i) : secp::nibble(k1, i)) - 8;
       acc = window_add(acc, t, e, h != 0, h != 0 && flip2);
+#endif
     }
   }
   acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve
