@@ -73,7 +73,8 @@ def _worker(rank, world, port, n_total, seed, out_dir, dup):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_total,dup", [(2, 200, False), (2, 128, True), (3, 500, True), (2, 200, True)])
+@pytest.mark.parametrize("world,n_total,dup", [(2, 200, False), (2, 128, True), (3, 500, True), (2, 200, True), (4, 700, True),
+                                                (8, 1100, True)])   # the driver's scaling run: 1, 2, 4, 8 ranks
 def test_sharded_verify_and_allreduce_merge(tmp_path, world, n_total, dup):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_total, 77 + n_total, str(tmp_path), dup), nprocs=world, join=True)
