@@ -148,6 +148,29 @@ RESIDENT_CAP = {"ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 2, "ecre
                 "verify_known_wave_kernel": 2, "ecrecover_group_kernel": 1, "verify_known_group_kernel": 2}
 
 
+LIVE_TAG = None   # set by --profile: the counter files of THIS run's rocprofv3 sub-steps (gpurun_out/profiles/LIVE_TAG_*)
+
+
+def _attachment_files(suffix: str):
+    """counter summaries to read, best first: this run's own (--profile), then the committed ones, newest first"""
+    live = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "profiles", f"{LIVE_TAG}_{suffix}"))) if LIVE_TAG else []
+    return live + sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}")), reverse=True)
+
+
+def collect_live_counters(rows: int) -> str:
+    """--profile: the rocprofv3 passes of tools/profile.sh (kernel stats, FETCH_SIZE, WRITE_SIZE: separate runs) and
+    tools/pmc_wave.sh (instruction counters, one counter set per run) as sub-steps of this run, over the same command line
+    they always use; their summaries land in gpurun_out/profiles/live_n<rows>_* and are what this line then attaches."""
+    tag = f"live_n{rows}"
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+    for cmd in (["bash", os.path.join(ROOT, "tools", "profile.sh"), tag, str(rows)],
+                ["bash", os.path.join(ROOT, "tools", "pmc_wave.sh"), str(rows), tag]):
+        rc = subprocess.call(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if rc != 0:
+            print(f"bench: {' '.join(cmd[1:])} returned {rc}; attaching the committed counters", file=sys.stderr)
+    return tag
+
+
 def _static_mix(kname: str):
     """(v_mad_u64_u32 share, DPP share, s_nop per VALU) of a kernel's hot loops from the newest profiles/r*_static_mix.txt"""
     base = kname.split("<")[0]
@@ -183,7 +206,7 @@ def valu_issue(kname: str, rows: int, avg_kernel_s: float):
     exact = re.escape(kname.replace(",", ", ")) if "group" in kname else kshort
     insts = salu = None
     src = scaled = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_instruction_mix.txt")), reverse=True):
+    for path in _attachment_files("pmc_instruction_mix.txt"):
         try:
             text = open(path).read()
         except OSError:
@@ -236,7 +259,7 @@ def profile_attachments(kname: str, rows: int, avg_kernel_s: float):
     traffic = None
     try:
         needle = "ibftk::" + kname.replace(",", ", ")
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        for path in _attachment_files("traffic.json"):
             ent = next((v for k, v in json.load(open(path)).items() if needle in k), None)
             if ent and ent.get("rows") == rows:
                 traffic = ent["hbm_bytes_per_launch"]
@@ -454,12 +477,16 @@ def relaunch(args) -> int:
 
 
 def main():
+    global LIVE_TAG
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows (validators) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="N = 1: collect roofline.traffic / valu_issue with rocprofv3 sub-steps of this run (tools/profile.sh, "
+                         "tools/pmc_wave.sh; ≈2 minutes) instead of attaching the committed profiles/ files")
     ap.add_argument("--no-sequence", action="store_true", help="skip the config-#3 sequence latency legs")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm-path leg")
     ap.add_argument("--seq-rounds", type=int, default=SEQ_ROUNDS)
@@ -655,6 +682,8 @@ def main():
         value = n_total * m["steps"] / m["elapsed"]
         avg_kernel_s = (m["kernel_ms"] / 1e3) / max(m["kernel_launches"], 1)
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
+        if args.profile and world == 1 and dist is None:
+            LIVE_TAG = collect_live_counters(rows)        # (behind the timed legs: the sub-steps are processes of their own)
         traffic, valu = profile_attachments(m["kname"], rows, avg_kernel_s)
         workload = (f"BASELINE config #3: N={n_total} validators, 1xMI355X — value: one round of COMMIT seals per step "
                     f"(ECDSA recover+compare+membership+quorum tally); quorum_latency_ms_p50: the full PREPARE+COMMIT "
@@ -678,6 +707,9 @@ def main():
                                           f"{KERNEL_TIMING_EVERY if world == 1 else 1}th timed pass ({m['kernel_launches']} samples)",
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
                          "valu_issue": valu,
+                         "counters": ("rocprofv3 sub-steps of this run (--profile): gpurun_out/profiles/" + LIVE_TAG + "_*") if LIVE_TAG
+                                     else "attached: the newest committed profiles/ file of this kernel and batch size "
+                                          "(valu_issue.source names it; --profile collects them in this run instead)",
                          "note": "integer-VALU-bound path: HBM fraction is reported as required; valu_issue is "
                                  "the bound that applies (DESIGN.md §5)"},
         }
