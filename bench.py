@@ -22,7 +22,9 @@ Inputs are resident in HBM when the timed region starts.
         CPU oracle outside the timed region.
   `python bench.py --gpus N` from a bare shell re-launches itself under torch.distributed.run.
 
-Prints ONE JSON line on rank 0.
+Rank 0 prints TWO JSON lines: first the detail record ({"bench_detail": …}: sweep with counters, sequence forms, host-mirror
+legs, certificates — also written to gpurun_out/bench_detail.json), then, LAST on stdout and under 6 KB, the headline line the
+driver parses (metric, value, config, quorum latency, roofline with the VALU-issue bound, cpu_baseline).
 """
 from __future__ import annotations
 
@@ -53,6 +55,41 @@ KERNEL_TIMING_EVERY = 4      # HIP-event pair around the verdict kernel of every
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 
 
+# IBFT_BENCH_DRYRUN=1 (tests/test_bench_line.py): the rank / world plumbing of this file on CPU ranks over gloo with
+# tests/bench_stub.py in place of the verifier — no measurement comes out of it, the record says dry_run
+DRY_RUN = os.environ.get("IBFT_BENCH_DRYRUN") == "1"
+COMM_INIT_TIMEOUT_S = 180   # ncclCommInitRank blocks until every rank has joined: a rank that never arrives must not hang the job
+
+
+def bv_module_round(n_total: int):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench_stub
+    return bench_stub.make_round(n_total)
+
+
+def comm_init_or_die(bv, uid, rank: int, world: int) -> None:
+    """ibft_comm_init with a deadline: on a hang every rank prints what it was waiting for and the process ends non-zero
+    (the driver then sees an error line instead of a job that never returns)."""
+    import threading
+    done = threading.Event()
+
+    def give_up():
+        if not done.is_set():
+            print(f"bench: rank {rank}/{world}: ibft_comm_init (ncclCommInitRank) has not returned after {COMM_INIT_TIMEOUT_S} s — "
+                  f"a rank is missing or the ranks cannot reach each other (HSA_ENABLE_IPC_MODE_LEGACY="
+                  f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}, MASTER_ADDR={os.environ.get('MASTER_ADDR')}); giving up",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+    t = threading.Timer(COMM_INIT_TIMEOUT_S, give_up)
+    t.daemon = True
+    t.start()
+    try:
+        bv.comm_init(uid, rank, world)
+    finally:
+        done.set()
+        t.cancel()
+
+
 def kernel_name(path: str, cold_lanes: int, warm_lanes: int) -> str:
     if path == "cold":
         return {1: "ecrecover_lane_kernel<0>", 64: "ecrecover_wave_kernel<0>", 128: "ecrecover_wave2_kernel<0>",
@@ -66,6 +103,11 @@ def load_round(bv, n_total: int, lo: int, hi: int, byzantine: bool = False):
     RANK'S DEVICE by the library's batch signer (go_ibft_amd/simulate.py → ibft_sign_seals: the whole validator table of
     a 65 536-validator round in milliseconds — no rank signs with host code at bench time, nothing of the oracle is on the
     path).  Rows [lo, hi) are this rank's shard."""
+    if DRY_RUN:
+        r = bv_module_round(n_total)
+        return {"addrs": r.addrs, "power": r.power, "hash32": r.hash32[lo:hi], "seal65": r.seal65[lo:hi],
+                "signer20": r.signer20[lo:hi], "pre": None, "src": "DRY RUN: unsigned rows, stub verifier", "fx": None,
+                "expect": None}
     if n_total == 4096 and not byzantine and os.path.exists(FIXTURE):
         with np.load(FIXTURE) as z:
             g = {k: z[k] for k in z.files}   # materialised once: an NpzFile re-reads the archive on every g[k]
@@ -466,6 +508,92 @@ def certificates_leg(V, n: int = 256, reps: int = 30):
     return res
 
 
+LINE_LIMIT = 6144   # the driver keeps the last 8 081 bytes of stdout: the LAST line must parse on its own (round-4 review)
+DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_ms", "kernel_samples",
+                  "algorithmic_bytes_per_launch", "counters")
+_VALU_KEYS = ("wave_insts_per_launch", "achieved_ginst_s", "peak_guide_ginst_s", "frac_of_guide_peak",
+              "frac_of_full_occupancy_ceiling", "frac_of_ceiling_at_this_occupancy", "wavefronts_resident_per_simd", "source")
+
+
+def _r(x, nd=6):
+    """floats of the headline line at 6 significant digits: the line is for reading and parsing, the detail file keeps all"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def headline_record(rec: dict) -> dict:
+    """The driver's line: SURVEY §8d's quantities and nothing else — metric / value / config, quorum latency, the roofline of the
+    dominant kernel with the VALU-issue bound that applies, the CPU baseline; one number per sweep size.  Everything else
+    (sweep with counters, extended sample, sequence forms, set change, certificates, host-mirror legs, prose) is the DETAIL
+    record: gpurun_out/bench_detail.json and an EARLIER stdout line."""
+    out = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                               "scaling", "vs_baseline", "dtype", "data") if k in rec}
+    cfg = rec.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "validators", "rows_per_gpu", "path", "prewarm_steps", "kernel",
+                                         "parallelism") if k in cfg}
+    for k in ("quorum_latency_ms_p50", "step_latency_ms_p50", "step_latency_ms_p50_incl_h2d", "rccl_nranks", "rccl_rank0_device"):
+        if k in rec:
+            out[k] = rec[k]
+    rf = rec.get("roofline") or {}
+    out["roofline"] = {k: rf[k] for k in _ROOFLINE_KEYS if k in rf}
+    if rf.get("valu_issue"):
+        out["roofline"]["valu_issue"] = {k: rf["valu_issue"][k] for k in _VALU_KEYS if k in rf["valu_issue"]}
+    cb = rec.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "os_cpu_count") if k in cb}
+    ql = rec.get("quorum_latency") or {}
+    if "message_sets_warm" in ql:
+        out["quorum_latency_warm_ms_p50"] = ql["message_sets_warm"].get("p50_ms")
+    if "warm_path" in rec:
+        out["warm_path"] = {k: rec["warm_path"][k] for k in ("value", "ms_per_step", "kernel_ms", "kernel") if k in rec["warm_path"]}
+    if "sustained_incl_h2d" in rec:
+        out["sustained_incl_h2d"] = {k: rec["sustained_incl_h2d"][k] for k in ("value", "ms_per_step", "slots", "vs_resident")
+                                     if k in rec["sustained_incl_h2d"]}
+    sw = (rec.get("sweep") or {}).get("sizes")
+    if sw:   # one row per size: [N, cold verifies/s, cold kernel ms, warm verifies/s, warm kernel ms]
+        out["sweep"] = [[e["validators"], e.get("cold", {}).get("verifies_per_s"), e.get("cold", {}).get("kernel_ms"),
+                         e.get("warm", {}).get("verifies_per_s"), e.get("warm", {}).get("kernel_ms")] for e in sw]
+        out["sweep_columns"] = "N, cold verifies/s, cold kernel ms, warm verifies/s, warm kernel ms"
+    if "config5" in rec:
+        c5 = rec["config5"]
+        out["config5"] = {k: c5[k] for k in ("validators", "rows_per_gpu", "byzantine_fraction", "rccl_nranks", "value",
+                                             "ms_per_step", "kernel", "valid_fraction", "error") if k in c5}
+    if "build" in rec:
+        out["build"] = rec["build"]
+    if rec.get("dry_run"):
+        out["dry_run"] = True
+    out["parity"] = "numerics unpinned by the reference (DESIGN.md §3): verdicts checked against the CPU oracle"
+    out["detail"] = "gpurun_out/bench_detail.json (also the previous stdout line)"
+    out = _r(out)
+    # never let an extra take the line over the limit: drop optional objects, widest first
+    for k in ("sweep", "sweep_columns", "warm_path", "config5", "sustained_incl_h2d", "build", "parity"):
+        if len(json.dumps(out)) < LINE_LIMIT:
+            break
+        out.pop(k, None)
+    return out
+
+
+def emit(rec: dict) -> str:
+    """detail record → gpurun_out/bench_detail.json + one stdout line; then the headline line, LAST on stdout"""
+    try:
+        os.makedirs(os.path.dirname(DETAIL_PATH), exist_ok=True)
+        with open(DETAIL_PATH, "w") as f:
+            json.dump(rec, f)
+    except OSError:
+        pass
+    line = json.dumps(headline_record(rec))
+    assert len(line) < LINE_LIMIT, len(line)
+    print(json.dumps({"bench_detail": rec}), flush=True)
+    print(line, flush=True)
+    return line
+
+
 def relaunch(args) -> int:
     """`python bench.py --gpus N` from a bare shell: become N ranks under torch.distributed.run."""
     port = 29500 + (os.getpid() % 2000)
@@ -504,7 +632,11 @@ def main():
         sys.exit(relaunch(args))
 
     import torch
-    import go_ibft_amd.verifier as V
+    if DRY_RUN:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import bench_stub as V
+    else:
+        import go_ibft_amd.verifier as V
     # one RCCL per process: the library dlopen()s librccl on first use — point it at the copy torch has loaded
     os.environ.setdefault("IBFT_RCCL_LIB", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
 
@@ -516,13 +648,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if DRY_RUN:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         if world != args.gpus:
             raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    else:
+    elif not DRY_RUN:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cpu") if DRY_RUN else torch.device("cuda", local)
 
     import go_ibft_amd.shard as S
 
@@ -553,7 +688,7 @@ def main():
             # torch.distributed only carries the 128-byte communicator id and the timing fences
             uid = [V.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0, device=dev)
-            bv.comm_init(uid[0], rank, world)
+            comm_init_or_die(bv, uid[0], rank, world)
             comm_info = bv.comm_info()   # what the communicator itself reports: (ranks, this rank, device)
 
         def step():  # N = 1: one synchronous pass, results on the host when it returns
@@ -575,7 +710,8 @@ def main():
         def fence():
             if dist is not None:
                 dist.barrier()
-            torch.cuda.synchronize()
+            if not DRY_RUN:
+                torch.cuda.synchronize()
             bv.sync()
 
         # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed loop costs ≈40 ms.
@@ -682,7 +818,7 @@ def main():
         value = n_total * m["steps"] / m["elapsed"]
         avg_kernel_s = (m["kernel_ms"] / 1e3) / max(m["kernel_launches"], 1)
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
-        if args.profile and world == 1 and dist is None:
+        if args.profile and world == 1 and dist is None and not DRY_RUN:
             LIVE_TAG = collect_live_counters(rows)        # (behind the timed legs: the sub-steps are processes of their own)
         traffic, valu = profile_attachments(m["kname"], rows, avg_kernel_s)
         workload = (f"BASELINE config #3: N={n_total} validators, 1xMI355X — value: one round of COMMIT seals per step "
@@ -702,7 +838,7 @@ def main():
             "step_latency_ms_p50_incl_h2d": float(np.median(m["lat_h2d"]) * 1e3) if m["lat_h2d"] else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": m["kname"], "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": m["kname"], "avg_kernel_ms": avg_kernel_s * 1e3, "kernel_samples": m["kernel_launches"],
                          "kernel_timing": f"HIP events on the library's stream around the verdict kernel of every "
                                           f"{KERNEL_TIMING_EVERY if world == 1 else 1}th timed pass ({m['kernel_launches']} samples)",
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
@@ -714,6 +850,15 @@ def main():
                                  "the bound that applies (DESIGN.md §5)"},
         }
         rec["quorum_latency_ms_p50"] = rec["step_latency_ms_p50"]   # replaced by the sequence below at N=1
+        if DRY_RUN:
+            rec["dry_run"] = True
+            rec["data"] = "DRY RUN (IBFT_BENCH_DRYRUN=1): CPU ranks, stub verifier — plumbing only, NOT a measurement"
+        try:
+            import go_ibft_amd.build as BLD
+            bi = BLD.build_info()
+            rec["build"] = {"libibftgpu": bi["flavour"], "intact": bi["intact"], "sha256_12": (bi["sha256"] or "")[:12]}
+        except Exception:  # noqa: BLE001
+            pass
         if m["rccl"] is not None:   # N > 1 (or forced): the collective is the library's ncclAllReduce over this communicator
             rec["rccl_nranks"], rec["rccl_rank0_device"] = m["rccl"][0], m["rccl"][2]
         if long_leg is not None:
@@ -725,6 +870,8 @@ def main():
                                "hbm_frac": rows * ALGO_BYTES_PER_VERIFY / lk / 1e9 / HBM_PEAK_GBS,
                                "step_latency_ms_p10_p50_p90": [float(x) for x in np.percentile(np.array(L["lat"]) * 1e3, [10, 50, 90])]}
 
+    if DRY_RUN:   # the extra legs all need the device
+        args.no_warm = args.no_sequence = args.no_sweep = args.no_certificates = args.no_host_mirror = args.no_cpu_baseline = True
     if world == 1 and args.path == "cold" and not args.no_warm:
         # extra, NOT the headline: the same batch once every validator's key is known (steady state)
         w = run_config(args.rows, False, args.steps, args.warmup, "warm")
@@ -807,7 +954,7 @@ def main():
             if rank == 0:
                 rec["config5"] = {"error": f"no result within {CONFIG5_TIMEOUT_S} s (leg abandoned, headline unaffected)"}
                 sys.stdout.flush()
-                print(json.dumps(rec), flush=True)
+                emit(rec)
             os._exit(0)
         watchdog = threading.Timer(CONFIG5_TIMEOUT_S, give_up)
         watchdog.daemon = True
@@ -838,7 +985,7 @@ def main():
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(rec), flush=True)
+        emit(rec)
 
 
 if __name__ == "__main__":

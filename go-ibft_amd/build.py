@@ -31,19 +31,48 @@ def _digest(deps: list[str], extra: str = "") -> str:
     return h.hexdigest()
 
 
+def _file_sha256(path: str) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _read_stamp(target: str) -> list[str]:
+    try:
+        with open(target + ".stamp") as f:
+            return f.read().split("\n")
+    except OSError:
+        return []
+
+
 def _stale(target: str, deps: list[str], extra: str = "") -> bool:
-    """A target is current when the digest of its sources (+ the compile command) equals the one recorded
-    next to it when it was built — modification times say nothing after a checkout or a copy to another box."""
-    stamp = target + ".stamp"
-    if not (os.path.exists(target) and os.path.exists(stamp)):
+    """A target is current when (1) the digest of its sources (+ the compile command) equals the one recorded next to it
+    when it was built — modification times say nothing after a checkout or a copy to another box — and (2) the target's OWN
+    sha256 equals the one recorded: a binary that something rewrote after the build (round-4 review: objcopy, in place) is
+    rebuilt, never shipped."""
+    st = _read_stamp(target)
+    if not os.path.exists(target) or len(st) < 2:
         return True
-    with open(stamp) as f:
-        return f.read().strip() != _digest(deps, extra)
+    return st[0].strip() != _digest(deps, extra) or st[1].strip() != _file_sha256(target)
 
 
-def _mark(target: str, deps: list[str], extra: str = "") -> None:
+def _mark(target: str, deps: list[str], extra: str = "", flavour: str = "") -> None:
+    """stamp = source digest, the built file's sha256, how it was built (line 3: what bench.py / build_info() report)"""
     with open(target + ".stamp", "w") as f:
-        f.write(_digest(deps, extra) + "\n")
+        f.write(_digest(deps, extra) + "\n" + _file_sha256(target) + "\n" + flavour + "\n")
+
+
+def build_info(target: str | None = None) -> dict:
+    """what the stamp says about a built target: {"flavour": "phase_align" | "phase_align_failed: …" | "one_step", "sha256": …,
+    "intact": the file still is what the build wrote}"""
+    target = target or LIB
+    st = _read_stamp(target)
+    if len(st) < 3 or not os.path.exists(target):
+        return {"flavour": None, "sha256": None, "intact": False}
+    return {"flavour": st[2].strip(), "sha256": st[1].strip(), "intact": st[1].strip() == _file_sha256(target)}
 
 
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"
@@ -66,7 +95,12 @@ def _build_lib_phase_aligned(verbose: bool) -> None:
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", *EXTRA_FLAGS]
     with tempfile.TemporaryDirectory(prefix="ibftgpu_build_") as d:
         dev_s, al_s, dev_o, dev_out, fb = (os.path.join(d, n) for n in ("dev.s", "dev.aligned.s", "dev.o", "dev.out", "dev.hipfb"))
-        run = lambda cmd: subprocess.check_call(cmd, cwd=CSRC, stderr=None if verbose else subprocess.DEVNULL)
+        def run(cmd):   # stderr is kept: a failing sub-step must say why
+            p = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+            if verbose and p.stderr:
+                print(p.stderr, end="", flush=True)
+            if p.returncode != 0:
+                raise RuntimeError(f"{os.path.basename(cmd[0])} returned {p.returncode}: {p.stderr[-2000:]}")
         run(["hipcc", *common, "--cuda-device-only", "-S", "-o", dev_s, src])
         phase_align.align_file(dev_s, al_s, dev_o, verbose=verbose)
         run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_out, dev_o])
@@ -82,21 +116,26 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
            "-o", LIB, os.path.join(CSRC, "ibftgpu.hip"), "-ldl"]
     stamp_extra = " ".join(cmd[:-3]) + (" +phase_align" if PHASE_ALIGN else "")
     deps = SOURCES + ([os.path.join("..", "phase_align.py")] if PHASE_ALIGN else [])
-    if force or _stale(LIB, deps, stamp_extra):
+    # a stamp that records a FAILED alignment step is retried (the fallback library is the same code without the step)
+    retry = PHASE_ALIGN and (build_info(LIB)["flavour"] or "").startswith("phase_align_failed")
+    if force or retry or _stale(LIB, deps, stamp_extra):
         done = False
+        flavour = "one_step"
         if PHASE_ALIGN:
             try:
                 if verbose:
                     print(" ".join(cmd), "  (+ phase_align.py between device assembly and code object)", flush=True)
                 _build_lib_phase_aligned(verbose)
                 done = True
+                flavour = "phase_align"
             except Exception as e:  # the one-shot build below is the same library without the alignment step
                 print(f"build: phase-aligned build failed ({e}); building with hipcc in one step", flush=True)
+                flavour = "phase_align_failed: " + " ".join(str(e).split())[:300]
         if not done:
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd, cwd=CSRC)
-        _mark(LIB, deps, stamp_extra)
+        _mark(LIB, deps, stamp_extra, flavour)
     return LIB
 
 

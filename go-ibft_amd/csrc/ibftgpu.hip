@@ -120,8 +120,11 @@ struct ibft_ctx {
   // HasPrepareQuorum: set by an entry point that was given a proposer, consumed by the next tally it enqueues
   bool next_prop_on = false;
   int32_t next_prop_vidx = -1;
-  bool last_prop_on = false;     // … of the last tally enqueued (what a sharded batch's unpack step applies)
-  int32_t last_prop_vidx = -1;
+  // … and that tally is ONE SHARD's share of a sharded PREPARE set whose exchange follows in the same call (set by
+  // ibft_group_verify_messages only): the proposer's seat is then left to the merge.  Every other tally — ibft_tally_prepare,
+  // a one-shot ibft_verify_messages[_wire] — adds the seat itself, also on a context that is a member of a group or of a
+  // communicator (round-4 advice: the seat was dropped by membership, and HasPrepareQuorum under-counted there).
+  bool next_shard = false;
   uint32_t last_proposer_rows = 0;
 
   // multi-GPU exchange (ibft_comm_*): rows of a batch sharded over `xworld` contexts, one all-reduce merges them
@@ -133,7 +136,6 @@ struct ibft_ctx {
   DevBuf d_seen_out;    // the last tally's distinct-sender bitmap (⌈n_validators/64⌉ u64 words): what the ranks exchange
   hipEvent_t ev_xpack = nullptr;  // local collective: this rank's buffer is packed / the summed buffers are back
   uint32_t x_K[2] = {1, 1};       // verdict arrays of the exchange in each slot (1: seal / sender batch, 2: message set)
-  bool x_prop_on[2] = {false, false};
   uint32_t set_n = 0;             // rows of the last message set (its words are in d_set)
   uint64_t *h_xres[2] = {nullptr, nullptr}, *dh_xres[2] = {nullptr, nullptr};
   size_t h_xres_words = 0;
@@ -528,11 +530,10 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
   // proposer's rows and leaves the seat to the merge (exchange_unpack_kernel)
   t.prop_on = c->next_prop_on ? 1u : 0u;
   t.prop_vidx = c->next_prop_vidx;
-  t.prop_seat = (c->comm || c->xlocal) ? 0u : 1u;
-  c->last_prop_on = c->next_prop_on;
-  c->last_prop_vidx = c->next_prop_vidx;
+  t.prop_seat = c->next_shard ? 0u : 1u;
   c->next_prop_on = false;
   c->next_prop_vidx = -1;
+  c->next_shard = false;
   if (c->cache_on) t.learned_src = (const uint64_t *)c->dev->d_learned.p;
   if (c->comm || c->xlocal) {  // a rank of a sharded batch: the bitmap of this launch is what the exchange merges
     const size_t bytes = (size_t)((c->n_validators + 63) / 64) * 8;
@@ -629,9 +630,10 @@ int32_t host_lookup(const ibft_ctx *c, const uint8_t addr20[20]) {
   return -1;
 }
 // the next tally this context enqueues is HasPrepareQuorum with this proposer (null: plain HasQuorum)
-void note_proposer(ibft_ctx *c, const uint8_t *proposer20) {
+void note_proposer(ibft_ctx *c, const uint8_t *proposer20, bool shard = false) {
   c->next_prop_on = proposer20 != nullptr;
   c->next_prop_vidx = proposer20 ? host_lookup(c, proposer20) : -1;
+  c->next_shard = shard && proposer20 != nullptr;
 }
 
 int upload(ibft_ctx *c, DevBuf &b, const void *src, size_t bytes);
@@ -962,6 +964,10 @@ int ensure_handoff_events(ibft_ctx *c) {
 
 struct xplan {
   uint32_t slot, w, total_words, seen_words, n_pieces, slots, my_words, K;
+  // HasPrepareQuorum of THIS exchange (fixed when the plan is made: a tally some other call enqueues on the context between
+  // pack and unpack must not change what the merge applies)
+  bool prop_on;
+  int32_t prop_vidx;
 };
 // u64 slots of the exchange buffer: K verdict arrays, one bitmap segment per rank, the count of valid rows
 uint32_t exchange_slots(uint32_t K, uint32_t words_per_rank, uint32_t world, uint32_t n_validators) {
@@ -969,7 +975,7 @@ uint32_t exchange_slots(uint32_t K, uint32_t words_per_rank, uint32_t world, uin
 }
 // before the collective: order behind the tally, pack this rank's words + its sender bitmap into the exchange buffer.
 // n_local rows of this rank (seal batch: the staged one; message set: the last set), K verdict arrays.
-int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x, uint32_t K = 1) {
+int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x, uint32_t K = 1, const uint8_t *proposer20 = nullptr) {
   if (!(c->comm || c->xlocal) || !c->have_valset) return (c->comm || c->xlocal) ? IBFT_E_NOVALSET : IBFT_E_INVAL;
   if (c->x_issued - c->x_fetched >= 2) {
     c->last_error = "two exchanges already in flight: call ibft_seals_fetch_merged first";
@@ -979,6 +985,8 @@ int exchange_pre(ibft_ctx *c, uint64_t n_total, xplan &x, uint32_t K = 1) {
   const uint64_t per = shard_rows_per_rank(n_total, c->xworld);
   const uint32_t n_local = K == 2 ? c->set_n : c->staged_n;
   x.K = K;
+  x.prop_on = proposer20 != nullptr;
+  x.prop_vidx = proposer20 ? host_lookup(c, proposer20) : -1;
   x.slot = c->x_issued & 1u;
   x.w = (uint32_t)(per / 64);
   x.total_words = x.w * c->xworld;
@@ -1079,8 +1087,8 @@ int exchange_post(ibft_ctx *c, uint64_t n_total, const xplan &x) {
   ua.seen_words = x.seen_words;
   ua.n_pieces = x.n_pieces;
   ua.n_validators = c->n_validators;
-  ua.prop_on = c->last_prop_on ? 1u : 0u;  // (the tally of this batch was the last one this context enqueued)
-  ua.prop_vidx = c->last_prop_vidx;
+  ua.prop_on = x.prop_on ? 1u : 0u;
+  ua.prop_vidx = x.prop_vidx;
   const uint32_t copy_blocks = (x.K * x.total_words + ibftk::XUNPACK_THREADS - 1) / ibftk::XUNPACK_THREADS;
   hipLaunchKernelGGL(ibftk::exchange_unpack_kernel, dim3(copy_blocks + 1), dim3(ibftk::XUNPACK_THREADS), 0, c->xstream, ua);
   HIPCHK(c, hipGetLastError());
@@ -2021,7 +2029,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
   note_proposer(c, proposer20);
   int rc = messages_launch_locked(c, payload, off, msg_sig65, from20, hash32, hash_len, seal65, sender_pre, valid_pre, n, raw,
                                   raw_len, round, digest32);
-  c->next_prop_on = false;  // (an error in front of the tally must not leave the proposer to a later call)
+  c->next_prop_on = c->next_shard = false;  // (an error in front of the tally must not leave the proposer to a later call)
   if (rc) return rc;
   if (n == 0) {
     if (proposer20) return fetch_results(c, 0, nullptr, tally, true);
@@ -2811,14 +2819,14 @@ int ibft_group_verify_messages(ibft_group *g, const uint8_t *payload, const uint
     uint64_t lo, hi;
     (void)ibft_shard_range(n, i, world, &lo, &hi);
     if (n) shard_offsets(off, lo, hi, loff[i]);
-    note_proposer(c, proposer20);
+    note_proposer(c, proposer20, /*shard=*/true);
     int r = messages_launch_locked(c, n ? payload + off[lo] : nullptr, n ? loff[i].data() : nullptr, msg_sig65 + 65 * lo,
                                    from20 + 20 * lo, hash32 + 32 * lo, hash_len + lo, seal65 ? seal65 + 65 * lo : nullptr,
                                    sender_pre ? sender_pre + lo : nullptr, valid_pre ? valid_pre + lo : nullptr,
                                    (size_t)(hi - lo), raw, raw_len, round, digest32);
-    c->next_prop_on = false;
+    c->next_prop_on = c->next_shard = false;
     if (r) return r;
-    return exchange_pre(c, n, plan[i], 2);
+    return exchange_pre(c, n, plan[i], 2, proposer20);
   });
   if (rc) {
     for (ibft_ctx *c : g->ctx) c->have_H = false;

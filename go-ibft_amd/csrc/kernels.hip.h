@@ -1545,7 +1545,12 @@ __global__ void __launch_bounds__(TALLY_THREADS) tally_kernel(tally_args a) {
     const bool bit = row0 + lr < a.n && ((wds[lr >> 6] >> (lr & 63)) & 1ull);
     valid += bit;
     first[j] = false;
-    if (a.prop_on && bit && ((a.prop_vidx >= 0 && vi[j] == a.prop_vidx) || vi[j] == VIDX_PROPOSER_OUTSIDER)) by_proposer++;
+    if (a.prop_on && bit && ((a.prop_vidx >= 0 && vi[j] == a.prop_vidx) || vi[j] == VIDX_PROPOSER_OUTSIDER)) {
+      // HasPrepareQuorum walks PREPARE messages (core/ibft.go:864-871 hands it the PREPAREs of the view): in a batch of raw
+      // messages of both types (the wire form marks its PREPAREs: no_seal) a COMMIT of the proposer is no PREPARE of his
+      const bool is_prepare = !(a.set_on && a.set.no_seal) || a.set.no_seal[row0 + lr] != 0;
+      if (is_prepare) by_proposer++;
+    }
     if (bit && vi[j] >= 0) {  // unknown senders contribute 0 (validator_manager.go:88-92)
       const uint32_t m = 1u << (vi[j] & 31);
       const uint32_t old = a.lds_bitmap ? atomicOr(&lseen[vi[j] >> 5], m)

@@ -136,14 +136,20 @@ class IngestQueue {
   int push(const uint8_t *wire, const uint32_t *off, size_t n) {
     if (!n) return 0;
     const size_t bytes = (size_t)off[n] - off[0];
-    if (bytes > cap_bytes_ || n > cap_rows_) return -2;
     {
       std::unique_lock<std::mutex> lk(mu_);
+      // "could never fit" is judged under the lock, and again whenever the waiter wakes: set_caps may lower the caps while
+      // a pusher waits, and a push larger than the NEW caps would otherwise wait for ever on an empty queue (round-4 advice)
+      auto never = [&] { return bytes > cap_bytes_ || n > cap_rows_; };
+      if (never()) return -2;
       if (wire_.size() + bytes > cap_bytes_ || off_.size() - 1 + n > cap_rows_) {
         backpressure_waits_++;
         cv_.notify_all();
-        space_cv_.wait(lk, [&] { return stop_ || (wire_.size() + bytes <= cap_bytes_ && off_.size() - 1 + n <= cap_rows_); });
+        space_cv_.wait(lk, [&] {
+          return stop_ || never() || (wire_.size() + bytes <= cap_bytes_ && off_.size() - 1 + n <= cap_rows_);
+        });
         if (stop_) return -1;
+        if (never()) return -2;
       }
       const uint32_t base = (uint32_t)wire_.size();
       wire_.insert(wire_.end(), wire + off[0], wire + off[n]);

@@ -105,6 +105,7 @@ def powers_be32(powers) -> np.ndarray:
 
 
 _lib = None
+ABI_VERSION = 2   # include/ibftgpu.h: ibft_version()
 
 
 def load_library() -> C.CDLL:
@@ -118,6 +119,8 @@ def load_library() -> C.CDLL:
     L = C.CDLL(lib_path)
     vp = C.c_void_p
     L.ibft_version.restype = C.c_int
+    if L.ibft_version() < ABI_VERSION:   # a stale .so writes past the caller's ibft_tally_t (48 → 56 bytes at version 2)
+        raise GpuUnavailable(f"{lib_path}: ibft_version() = {L.ibft_version()}, this binding needs >= {ABI_VERSION} — rebuild")
     L.ibft_strerror.argtypes = [C.c_int]; L.ibft_strerror.restype = C.c_char_p
     L.ibft_last_error.argtypes = [vp]; L.ibft_last_error.restype = C.c_char_p
     L.ibft_ctx_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]

@@ -391,7 +391,9 @@ int ibft_verify_messages(ibft_ctx *ctx, const uint8_t *payload, const uint32_t *
  *                           handleCommit closure (core/ibft.go:856-862, :932-944).  Messages of other views or
  *                           kinds have bit 0 here and are judged when their view is handled;
  *   tally                 = HasQuorum over the rows with both bits (meaningful for a batch of one type) —
- *                           HasPrepareQuorum when proposer20 != NULL (a batch of PREPAREs of the asked view);
+ *                           HasPrepareQuorum when proposer20 != NULL (a batch of PREPAREs of the asked view; in a
+ *                           batch of both types only a PREPARE of the proposer counts in proposer_rows and voids
+ *                           the quorum — his COMMIT is no PREPARE of his, validator_manager.go:114-121);
  *   out_class[i] (n bytes, may be NULL) = what the caller needs to route row i: IBFT_WIRE_CLASS_NEEDS_HOST — not
  *                           judged here, stock route; IBFT_WIRE_CLASS_CLOSURE — a PREPARE / COMMIT of the asked
  *                           view: its valid bit IS the closure's verdict; bits 4..7 = IbftMessage.type.  One byte

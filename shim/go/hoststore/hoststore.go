@@ -94,13 +94,18 @@ func New(gpu *ibftgpu.Ctx, o Options) (*Store, error) {
 	return s, nil
 }
 
-// Close stops the worker and frees the mirror.  C call sequence: ibft_host_queue_stop, ibft_host_free.
+// Close stops the worker, frees the mirror and closes the embedded reference store (messages/messages.go:75: its event
+// manager and subscriptions — this method shadows the promoted one, so it has to call it).
+// C call sequence: ibft_host_queue_stop, ibft_host_free.
 func (s *Store) Close() {
 	if s.h != nil {
 		C.ibft_host_queue_stop(s.h)
 		C.ibft_host_free(s.h)
 		s.h = nil
 		s.self.Delete()
+	}
+	if s.Messages != nil {
+		s.Messages.Close()
 	}
 }
 
@@ -157,6 +162,8 @@ func (s *Store) SetState(height, round uint64, proposalMessage *proto.IbftMessag
 	return nil
 }
 
+const maxPushBytes = 0xFFFF0000 // kMaxCapBytes of the queue (go-ibft_amd/host/host_capi.cpp)
+
 // AddWireMessages is the transport's entry point: the messages as they arrived, never unmarshalled in Go.  The bytes
 // are copied into the queue; one worker ingests everything pending as one batch (one ibft_verify_messages_wire call:
 // IsValidValidator + the handle* closure of every PREPARE / COMMIT of the view), stores the survivors as rows and
@@ -169,6 +176,17 @@ func (s *Store) AddWireMessages(raw [][]byte) error {
 	total := 0
 	for _, m := range raw {
 		total += len(m)
+	}
+	// offsets are 32 bits on the C side: a batch past that is split in two pushes (a single message that large is
+	// refused — the queue's own byte cap, ibft_host_queue_set_caps, is far below it)
+	if uint64(total) > maxPushBytes {
+		if len(raw) == 1 {
+			return ErrUnavailable
+		}
+		if err := s.AddWireMessages(raw[:len(raw)/2]); err != nil {
+			return err
+		}
+		return s.AddWireMessages(raw[len(raw)/2:])
 	}
 	wire := make([]byte, 0, total)
 	off := make([]uint32, 1, len(raw)+1)

@@ -74,7 +74,14 @@ type Options struct {
 	KeyCache   bool
 }
 
+// abiVersion is what this binding was written against (include/ibftgpu.h: ibft_version; 2 = ibft_tally_t with
+// proposer_rows, 56 bytes): an older library would write a shorter struct, a binding older than the library a longer one.
+const abiVersion = 2
+
 func New(o Options) (*Ctx, error) {
+	if v := int(C.ibft_version()); v < abiVersion {
+		return nil, fmt.Errorf("%w: libibftgpu ABI version %d, binding needs >= %d", ErrFallback, v, abiVersion)
+	}
 	cfg := C.ibft_cfg{device: C.int32_t(o.Device), max_rows: C.uint32_t(o.MaxRows)}
 	if o.StrictLowS {
 		cfg.flags |= C.IBFT_FLAG_STRICT_LOW_S

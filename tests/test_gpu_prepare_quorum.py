@@ -303,3 +303,73 @@ def test_sharded_prepare_set_with_the_proposer_rule(oracle, world, n):
     finally:
         g.close()
         one.close()
+
+
+def test_tally_prepare_on_a_group_member_context_keeps_the_seat():
+    """round-4 advice (medium): a context that is a member of a group (or of a communicator) dropped the proposer's seat in
+    EVERY tally, also in ibft_tally_prepare and the one-shot set calls that no exchange follows — HasPrepareQuorum then
+    under-counted against validator_manager.go:111-126 (3f+1 equal validators, f silent: the PREPARE quorum never came).
+    The seat is left to the merge only by the sharded call itself."""
+    import ctypes as C
+    import go_ibft_amd.verifier as V
+    from oracle.semantics import ValidatorManager
+    names = ['A', 'B', 'C', 'D']
+    vm = ValidatorManager()
+    assert vm.init({_addr(n): 1 for n in names})
+    g = V.DeviceGroup([0, 0], max_rows_total=256)
+    try:
+        g.set_validators(1, _col(names), [1, 1, 1, 1])
+        L = g._L
+        for rank in range(2):
+            ctx = L.ibft_group_ctx(g._g, rank)
+            for signers in (['B', 'C'], ['B'], ['A', 'B', 'C'], []):
+                send = _col(signers)
+                ones = np.ones(len(signers), bool)
+                want, power, distinct, prows = _expect(vm, _addr('A'), [bytes(s) for s in send], ones)
+                m = V.bool_to_mask(ones)
+                pr = np.frombuffer(_addr('A'), np.uint8)
+                t = V.Tally()
+                assert L.ibft_tally_prepare(ctx, V._p(np.ascontiguousarray(send)), V._p(m), len(signers), V._p(pr), C.byref(t)) == 0
+                assert (bool(t.has_quorum), t.power, t.distinct_senders, t.proposer_rows) == (want, power, distinct, prows), \
+                    (rank, signers)
+        # the sharded call on the same group still merges the seat exactly once
+        r, rows, chunks, sigs = _prepare_set(130, 4711, 1)
+        g.set_validators(r.height, r.addrs, r.power)
+        payload, off = _pack(chunks)
+        m = len(chunks)
+        h = np.tile(np.frombuffer(r.proposal_hash, np.uint8), (m, 1))
+        s, v, t = g.verify_messages(payload, off, np.array(sigs).reshape(-1, 65), np.array([r.addrs[i] for i in rows]).reshape(-1, 20),
+                                    h, np.full(m, 32, np.uint8), raw=r.raw, round_=r.round, proposer=r.addrs[1].tobytes())
+        assert s.all() and v.all() and (t.has_quorum, t.power, t.distinct_senders, t.proposer_rows) == (1, int(r.power.sum()), 130, 0)
+    finally:
+        g.close()
+
+
+def test_wire_batch_of_both_types_only_a_prepare_of_the_proposer_voids(oracle):
+    """ibft_verify_messages_wire(proposer20) over raw PREPAREs AND the proposer's own COMMIT: HasPrepareQuorum walks PREPARE
+    messages, so the COMMIT is no PREPARE of his — proposer_rows stays 0 (round-4 advice, low)"""
+    import go_ibft_amd.verifier as V
+    from oracle import wire, binding as B
+    n, p = 16, 3
+    r, rows, chunks, sigs = _prepare_set(n, 4800, p)
+    proposer = r.addrs[p].tobytes()
+
+    def raw(i, type_, body):
+        m = wire.IbftMessage(view=wire.View(r.height, r.round), sender=r.addrs[i].tobytes(), type=type_, payload=body)
+        m.signature = B.sign(r.sks[i], B.keccak256(m.payload_no_sig()))
+        return m.encode()
+    prepares = [raw(i, wire.PREPARE, wire.prepare_body(r.proposal_hash)) for i in rows]
+    commit_p = raw(p, wire.COMMIT, wire.commit_body(r.proposal_hash, B.sign(r.sks[p], r.proposal_hash)))
+    prepare_p = raw(p, wire.PREPARE, wire.prepare_body(r.proposal_hash))
+    bv = V.BatchVerifier(max_rows=256)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        buf, off = _pack(prepares + [commit_p])
+        s, v, cls, t = bv.verify_messages_wire(buf, off, r.height, r.round, raw=r.raw, want_rows=False, proposer=proposer)
+        assert s.all() and v.all()
+        assert (t.has_quorum, t.proposer_rows, t.distinct_senders) == (1, 0, n)
+        buf, off = _pack(prepares + [commit_p, prepare_p])
+        s, v, cls, t = bv.verify_messages_wire(buf, off, r.height, r.round, raw=r.raw, want_rows=False, proposer=proposer)
+        assert s.all() and v.all() and (t.has_quorum, t.proposer_rows) == (0, 1)
+    finally:
+        bv.close()

@@ -48,9 +48,29 @@ def test_hot_loops_of_the_built_library_are_aligned():
     if not B.PHASE_ALIGN or not os.path.exists(B.LIB):
         pytest.skip("library not built with the alignment step")
     import code_phase as CP
+    before = B._file_sha256(B.LIB)
     ins = list(CP.disassemble(B.LIB, "ecrecover_rows_kernelILi0").values())[0]
+    # round-4 review: objcopy with one file operand rewrote the product library in place (while it was mapped: the suite ended
+    # in SIGSEGV, and the rewritten binary travelled to the GPU box) — the tool reads a private copy now
+    assert B._file_sha256(B.LIB) == before and B.build_info()["intact"]
     big = [(lo, hi) for lo, hi in set(CP.loops(ins)) if sum(1 for x in ins if lo <= x[0] <= hi) > 400]
     assert big
     for lo, hi in big:
         n, n8, mis = CP.stats([x for x in ins if lo <= x[0] <= hi])
         assert n8 > 0.7 * n and mis < 0.15 * n8, (hex(lo), n, n8, mis)
+
+
+def test_a_rewritten_library_is_stale(tmp_path, monkeypatch):
+    """the stamp records the built file's own sha256: a binary that something modified after the build is rebuilt, not shipped"""
+    import go_ibft_amd.build as B
+    t = tmp_path / "lib.so"
+    dep = "keccak_dev.h"
+    t.write_bytes(b"built")
+    B._mark(str(t), [dep], "cmd", "phase_align")
+    assert not B._stale(str(t), [dep], "cmd") and B.build_info(str(t)) == {"flavour": "phase_align", "sha256": B._file_sha256(str(t)), "intact": True}
+    t.write_bytes(b"rewritten")
+    assert B._stale(str(t), [dep], "cmd") and not B.build_info(str(t))["intact"]
+    t.write_bytes(b"built")
+    assert not B._stale(str(t), [dep], "cmd") and B._stale(str(t), [dep], "other cmd")
+    (tmp_path / "lib.so.stamp").write_text("0123\n")            # a stamp of the old one-line format: rebuilt
+    assert B._stale(str(t), [dep], "cmd")

@@ -11,7 +11,11 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def disassemble(lib, sym_substr):
     d = tempfile.mkdtemp()
-    subprocess.check_call(["objcopy", "--dump-section", f".hip_fatbin={d}/fat.bin", lib], stderr=subprocess.DEVNULL)
+    # objcopy with ONE file operand rewrites that file in place (round-4 review: the CPU suite replaced the product library
+    # while it was mapped): work on a private copy and send objcopy's output to /dev/null
+    import shutil
+    shutil.copyfile(lib, f"{d}/lib.so")
+    subprocess.check_call(["objcopy", "--dump-section", f".hip_fatbin={d}/fat.bin", f"{d}/lib.so", "/dev/null"], stderr=subprocess.DEVNULL)
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={d}/fat.bin",
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={d}/k.co"])
     syms = subprocess.check_output([f"{LLVM}/llvm-readelf", "-sW", f"{d}/k.co"], text=True)
