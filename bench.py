@@ -21,6 +21,10 @@ Inputs are resident in HBM when the timed region starts.
         `config5`: 65 536 validators, 8192 rows per GPU, 20 % Byzantine seals, checked against the
         CPU oracle outside the timed region.
   `python bench.py --gpus N` from a bare shell re-launches itself under torch.distributed.run.
+  torch is imported only for N > 1 and only as torch.distributed over gloo (communicator id, barriers, max over ranks): the
+  kernels run on the image's ROCm 7.2 HIP runtime, not on the 7.0.2 runtime bundled with torch (3.5 % slower for the same
+  code object, profiles/r05b_harness_ab.txt); the fences around the timed region are the library's own stream syncs
+  (ibft_sync: verdict, exchange and copy streams) — torch's streams never carried any of this work.
 
 Rank 0 prints TWO JSON lines: first the detail record ({"bench_detail": …}: sweep with counters, sequence forms, host-mirror
 legs, certificates — also written to gpurun_out/bench_detail.json), then, LAST on stdout and under 6 KB, the headline line the
@@ -179,10 +183,36 @@ def cpu_baseline(addrs, power, hash32, seal65, signer20, budget_s: float = 12.0)
                       f"{el:.1f} s, {cores} pthreads); 1 thread: {single:.0f} verifies/s"}
 
 
-# wall ns per wave-instruction per SIMD by instruction class, measured with tools/ubench_wave.hip (profiles/r02a_ubench_wave.txt):
-# one / two / four resident wavefronts per SIMD
-ISSUE_NS = {1: {"plain": 2.07, "dpp": 2.22, "mad": 2.50}, 2: {"plain": 1.11, "dpp": 1.93, "mad": 2.19},
-            4: {"plain": 0.99, "dpp": 1.86, "mad": 2.13}}
+# wall ns per wave-instruction per SIMD by instruction class at one / two / four resident wavefronts per SIMD, measured with
+# tools/ubench_wave.hip — round 5's run (0.25 ms kernels behind 30 ms of untimed launches, median of 7, instructions on 8-byte
+# boundaries as go-ibft_amd/phase_align.py leaves them): profiles/r05a_ubench_wave.txt.  Round 2's numbers (2.07 / 2.22 / 2.50 at
+# one wavefront) came from 34 µs kernels and carried the launch ramp: the kernels BEAT the ceilings priced with them.
+ISSUE_NS = {1: {"plain": 1.79, "dpp": 1.79, "mad": 1.80}, 2: {"plain": 0.89, "dpp": 1.74, "mad": 1.75},
+            4: {"plain": 0.89, "dpp": 1.70, "mad": 1.73}}
+ISSUE_NS_SOURCE = "built-in (profiles/r05a_ubench_wave.txt)"
+
+
+def _load_issue_ns():
+    """the class times of the newest committed profiles/r*_ubench_wave.txt that has the round-5 class lines"""
+    global ISSUE_NS, ISSUE_NS_SOURCE
+    names = {"class 4-byte": "plain", "class DPP aligned": "dpp", "class mad aligned": "mad"}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench_wave.txt")), reverse=True):
+        got = {}
+        try:
+            for line in open(path):
+                for pre, cls in names.items():
+                    if line.startswith(pre):
+                        m = re.search(r"waves/SIMD=(\d+).*wall: ([0-9.]+) ns per inst per SIMD", line)
+                        if m:
+                            got.setdefault(int(m.group(1)), {})[cls] = float(m.group(2))
+        except OSError:
+            continue
+        if all(len(got.get(w, {})) == 3 for w in (1, 2, 4)):
+            ISSUE_NS, ISSUE_NS_SOURCE = got, os.path.relpath(path, ROOT)
+            return
+
+
+_load_issue_ns()
 LANES_OF = {"ecrecover_wave2_kernel": 128, "ecrecover_lane_kernel": 1, "verify_known_lane_kernel": 1, "ecrecover_rows_kernel": 16, "ecrecover_wave_kernel": 64,
             "verify_known_wave_kernel": 64}
 # wavefronts a SIMD can hold (512 registers per lane: go-ibft_amd/csrc resource usage, tools/occupancy.py)
@@ -288,9 +318,9 @@ def valu_issue(kname: str, rows: int, avg_kernel_s: float):
             "simds_with_a_wavefront": int(min(1024, round(offered * 1024))),
             "mad_share": f_mad, "dpp_share": f_dpp, "s_nop_per_valu": nop,
             "note": "peak_guide = 1024 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md); the "
-                    "ceilings price THIS kernel's instruction mix with the measured issue times of profiles/r02a_ubench_wave.txt "
-                    "(v_mad_u64_u32 2.50 / 2.19 / 2.13 ns, DPP 2.22 / 1.93 / 1.86 ns, plain VALU 2.07 / 1.11 / 0.99 ns per "
-                    "instruction per SIMD at 1 / 2 / 4 resident wavefronts)",
+                    "ceilings price THIS kernel's instruction mix with the issue times tools/ubench_wave.hip measured per class "
+                    f"(ns per instruction per SIMD at 1 / 2 / 4 resident wavefronts: {ISSUE_NS}; {ISSUE_NS_SOURCE})",
+            "issue_ns_source": ISSUE_NS_SOURCE,
             "source": src, "instruction_count_scaled_from_rows": scaled, "mix_source": mix_src}
 
 
@@ -438,6 +468,66 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
             "results host-visible), inputs signed on the device; hbm_* = 118 B x N / verdict-kernel time (HIP events, every pass); "
             f"every entry behind >= {SWEEP_PREWARM_MIN_PASSES} untimed passes / {SWEEP_PREWARM_MIN_S} s (clock ramp)",
             "sizes": out}
+
+
+def sustained_leg(V, rd, steps: int = 400, sizes=(4096, 65536)):
+    """Round-4 review, item 7: the headline is "inputs resident in HBM"; a node gets NEW messages at every wake-up
+    (core/ibft.go:931-946), so a sustained stream pays an upload per batch.  With the context's two staging slots
+    (ibft_seals_stage_next / ibft_seals_swap) the copy of batch k+1 runs on a copy stream while the kernels of batch k work:
+    per step launch(k) → stage_next(k+1) → fetch(k) → swap, a FRESH host batch (pinned columns) every step — two batches
+    alternate, the second with one seal corrupted so that every step's tally proves whose results it is.  Reported next to
+    the resident-batch rate of the SAME context measured right before it (same box, same clocks)."""
+    import go_ibft_amd.simulate as SIM
+    out = {"definition": "verifies/s with a fresh host batch every step (H2D of the 117 B/row columns included, overlapped "
+                         "through the second staging slot); resident = the same context re-running one resident batch",
+           "sizes": []}
+    for n in sizes:
+        bv = V.BatchVerifier(flags=0, max_rows=max(n, 1024))
+        try:
+            if n == len(rd["seal65"]) and rd.get("pre") is None:
+                addrs, power, h, s, f = rd["addrs"], rd["power"], rd["hash32"], rd["seal65"], rd["signer20"]
+            else:
+                r = SIM.make_round(bv, n, 300 + n)
+                addrs, power, h, s, f = r.addrs, r.power, r.hash32, r.seal65, r.signer20
+            bv.set_validators(1, addrs, power)
+            s_bad = np.array(s, copy=True)
+            s_bad[n // 2, 5] ^= 0x40                                     # batch B: one forged seal
+            A = tuple(V.pinned_copy(x) for x in (h, s, f))
+            Bt = tuple(V.pinned_copy(x) for x in (np.roll(h, 1, axis=0), np.roll(s_bad, 1, axis=0), np.roll(f, 1, axis=0)))
+            host, expect = (A, Bt), (n, n - 1)
+            bv.seals_stage(*A)
+            for _ in range(PREWARM_STEPS):
+                bv.seals_run()
+            gc.collect(); gc.disable()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                bv.seals_run()
+            resident = time.perf_counter() - t0
+            # the stream: two untimed rounds to create the copy stream and the spare columns, then the timed steps
+            k = 0
+            for _ in range(4):
+                bv.seals_launch(1); bv.seals_stage_next(*host[(k + 1) & 1]); _, t = bv.seals_fetch(); bv.seals_swap(); k += 1
+            ok = True
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                bv.seals_launch(1)
+                bv.seals_stage_next(*host[(k + 1) & 1])
+                _, t = bv.seals_fetch()
+                ok &= t.valid_rows == expect[k & 1] and t.has_quorum == 1
+                bv.seals_swap()
+                k += 1
+            stream = time.perf_counter() - t0
+            gc.enable()
+            assert ok, "a step of the stream delivered another batch's tally"
+            out["sizes"].append({"validators": n, "steps": steps, "value": n * steps / stream, "ms_per_step": stream / steps * 1e3,
+                                 "resident_value": n * steps / resident, "resident_ms_per_step": resident / steps * 1e3,
+                                 "vs_resident": resident / stream, "h2d_bytes_per_step": int(n * 117), "slots": 2})
+        finally:
+            bv.close()
+    head = out["sizes"][0]
+    out.update({k: head[k] for k in ("value", "ms_per_step", "vs_resident", "slots")})
+    out["unit"] = "verifies/s"
+    return out
 
 
 def set_change_leg(V, n: int = 4096, reps: int = 3, passes: int = 5):
@@ -619,6 +709,7 @@ def main():
     ap.add_argument("--no-warm", action="store_true", help="skip the warm-path leg")
     ap.add_argument("--seq-rounds", type=int, default=SEQ_ROUNDS)
     ap.add_argument("--no-sweep", action="store_true", help="skip the N = 64 … 65 536 sweep")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the fresh-host-batch-every-step leg (two staging slots)")
     ap.add_argument("--no-certificates", action="store_true", help="skip the round-change certificate leg")
     ap.add_argument("--no-host-mirror", action="store_true", help="skip the end-to-end legs through include/ibft_host.h")
     ap.add_argument("--extended-steps", type=int, default=400,
@@ -631,33 +722,51 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(args))
 
-    import torch
+    # WHICH HIP RUNTIME THE KERNELS RUN ON (round 5, profiles/r05b_harness_ab.txt): torch 2.10+rocm7.0 bundles its own
+    # libamdhip64 / libhsa-runtime64 (ROCm 7.0.2) and a process that imports torch first binds libibftgpu.so to THAT runtime —
+    # the same code object then runs the headline kernel in 0.3449 ms instead of the 0.3330 ms it takes on the image's ROCm 7.2
+    # runtime the library was built for (same box, alternating processes).  So the library is loaded FIRST, and torch comes in
+    # only where the contract needs torch.distributed (N > 1): as the carrier of the 128-byte communicator id and of the timing
+    # fences over a gloo group — CPU tensors, torch.cuda is never initialised (two HIP runtimes cannot share a process: with the
+    # library's runtime up, torch.cuda finds no device).  The data-path collective is the library's own ncclAllReduce on the
+    # image's librccl either way.  torch_first = the previous order (torch's runtime, nccl process group, torch.cuda fences).
+    torch_first = os.environ.get("IBFT_BENCH_TORCH_FIRST") == "1" and not DRY_RUN
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    want_dist = world > 1 or os.environ.get("IBFT_BENCH_FORCE_DIST") == "1"
+    torch = None
+    if torch_first:
+        import torch
+        os.environ.setdefault("IBFT_RCCL_LIB", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
     if DRY_RUN:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import bench_stub as V
     else:
         import go_ibft_amd.verifier as V
-    # one RCCL per process: the library dlopen()s librccl on first use — point it at the copy torch has loaded
-    os.environ.setdefault("IBFT_RCCL_LIB", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+        V.load_library()                                  # binds the process to /opt/rocm's HIP runtime (unless torch_first)
+        if want_dist and not torch_first:
+            # … and to /opt/rocm's librccl, BEFORE torch comes in: libtorch_hip needs "librccl.so.1" too, and whichever copy is
+            # mapped first serves both (same SONAME) — torch's RCCL (built for ROCm 7.0) on the 7.2 HIP runtime fails in
+            # ncclCommInitRank ("unhandled cuda error", profiles/r05c: the first forced-dist run of this order)
+            V.comm_unique_id()
     dist = None
-    if world > 1 or os.environ.get("IBFT_BENCH_FORCE_DIST") == "1":
+    if want_dist:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if DRY_RUN:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
+        if torch_first:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the container's hostname may not resolve
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         if world != args.gpus:
             raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    elif not DRY_RUN:
+    elif torch_first:
         torch.cuda.set_device(0)
-    dev = torch.device("cpu") if DRY_RUN else torch.device("cuda", local)
+    dev = torch.device("cuda", local) if torch_first else (torch.device("cpu") if torch is not None else None)
 
     import go_ibft_amd.shard as S
 
@@ -687,7 +796,7 @@ def main():
             # the data-path collective lives in libibftgpu.so (RCCL all-reduce of verdict words + tally pieces);
             # torch.distributed only carries the 128-byte communicator id and the timing fences
             uid = [V.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0, device=dev)
+            dist.broadcast_object_list(uid, src=0, device=dev)        # (gloo: dev = cpu)
             comm_init_or_die(bv, uid[0], rank, world)
             comm_info = bv.comm_info()   # what the communicator itself reports: (ranks, this rank, device)
 
@@ -710,9 +819,9 @@ def main():
         def fence():
             if dist is not None:
                 dist.barrier()
-            if not DRY_RUN:
-                torch.cuda.synchronize()
-            bv.sync()
+            if torch_first:
+                torch.cuda.synchronize()      # (torch's streams carry none of this work: the library's own streams are what counts)
+            bv.sync()                         # hipStreamSynchronize of the context's verdict and exchange streams
 
         # torch's import leaves ~10^6 tracked objects: a generation-2 collection in the middle of a timed loop costs ≈40 ms.
         # Collect BEFORE the warm-up (not between warm-up and timing: 40 ms of idle device is enough for its clocks to fall,
@@ -872,6 +981,7 @@ def main():
 
     if DRY_RUN:   # the extra legs all need the device
         args.no_warm = args.no_sequence = args.no_sweep = args.no_certificates = args.no_host_mirror = args.no_cpu_baseline = True
+        args.no_sustained = True
     if world == 1 and args.path == "cold" and not args.no_warm:
         # extra, NOT the headline: the same batch once every validator's key is known (steady state)
         w = run_config(args.rows, False, args.steps, args.warmup, "warm")
@@ -905,6 +1015,11 @@ def main():
             rec["sweep"] = sweep_sizes(V)
         except Exception as e:  # noqa: BLE001 — an extra leg must never take the headline line down
             rec["sweep"] = {"error": repr(e)}
+    if world == 1 and rank == 0 and not args.no_sustained and args.path == "cold":
+        try:
+            rec["sustained_incl_h2d"] = sustained_leg(V, main_leg["rd"])
+        except Exception as e:  # noqa: BLE001
+            rec["sustained_incl_h2d"] = {"error": repr(e)}
     if world == 1 and rank == 0 and not args.no_sweep:
         try:
             rec["set_change"] = set_change_leg(V)

@@ -92,6 +92,14 @@ struct ibft_ctx {
 
   // columns in HBM
   DevBuf d_hash, d_sig, d_signer, d_pre, d_hash_len, d_payload, d_off, d_raw;
+  // the SECOND staging slot of the seal columns (ibft_seals_stage_next / ibft_seals_swap): batch k+1 is copied here on a
+  // copy stream of its own while the verdict kernels read batch k from the columns above; a swap exchanges the two sets
+  DevBuf d_hash_nx, d_sig_nx, d_signer_nx, d_pre_nx;
+  hipStream_t cstream = nullptr;
+  hipEvent_t ev_staged = nullptr, ev_cols_read = nullptr;  // the copy into the spare slot is done / the spare slot's last reader is
+  uint32_t next_n = 0;
+  bool next_pre = false, next_valid = false;
+  uint32_t launched_n = 0;  // rows of the last ibft_seals_launch: what ibft_seals_fetch delivers (a swap may have changed staged_n since)
   DevBuf d_mask, d_vidx, d_tally, d_H;
   DevBuf d_mask_out;        // verdict words after the tally consumed d_mask (what fetch / export read)
   // d_mask words [0, mask_dirty_words) may hold bits; 0 = the whole work mask is zero (the tally left it so)
@@ -1352,8 +1360,15 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_warm_done, &c->d_seen, &c->d_acc, &c->d_quorum, &c->d_wire_rows, &c->d_seal,
                     &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
                     &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total,
-                    &c->d_cert_slot, &c->d_cert_tiles, &c->d_hash_copy, &c->d_seen_out})
+                    &c->d_cert_slot, &c->d_cert_tiles, &c->d_hash_copy, &c->d_seen_out, &c->d_hash_nx, &c->d_sig_nx,
+                    &c->d_signer_nx, &c->d_pre_nx})
     release(*b);
+  if (c->cstream) {
+    (void)hipStreamSynchronize(c->cstream);
+    (void)hipStreamDestroy(c->cstream);
+  }
+  if (c->ev_staged) (void)hipEventDestroy(c->ev_staged);
+  if (c->ev_cols_read) (void)hipEventDestroy(c->ev_cols_read);
   if (c->dev) {
     {
       std::lock_guard<std::mutex> dlk(c->dev->mu);
@@ -1765,11 +1780,72 @@ int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, c
   return seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n, true);
 }
 
+// Double-buffered staging: the copy of batch k+1 overlaps the verdict kernels of batch k.
+int ibft_seals_stage_next(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
+                          const uint8_t *pre_flags, size_t n) {
+  if (!c || (n && (!hash32 || !sig65 || !signer20))) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (n > c->max_rows) return IBFT_E_TOOBIG;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->cstream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_cols_read, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_cols_read, c->stream));
+  }
+  int rc;
+  const size_t m = std::max<size_t>(c->max_rows, c->row_cap);
+  if ((rc = ensure(c, c->d_hash_nx, m * 32))) return rc;
+  if ((rc = ensure(c, c->d_sig_nx, m * 65 + 64))) return rc;
+  if ((rc = ensure(c, c->d_signer_nx, m * 20))) return rc;
+  if ((rc = ensure(c, c->d_pre_nx, m))) return rc;
+  // the spare slot was the resident one until the last swap: kernels enqueued before that swap may still read it
+  HIPCHK(c, hipStreamWaitEvent(c->cstream, c->ev_cols_read, 0));
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(c->d_hash_nx.p, hash32, n * 32, hipMemcpyHostToDevice, c->cstream));
+    HIPCHK(c, hipMemcpyAsync(c->d_sig_nx.p, sig65, n * 65, hipMemcpyHostToDevice, c->cstream));
+    HIPCHK(c, hipMemcpyAsync(c->d_signer_nx.p, signer20, n * 20, hipMemcpyHostToDevice, c->cstream));
+    if (pre_flags) HIPCHK(c, hipMemcpyAsync(c->d_pre_nx.p, pre_flags, n, hipMemcpyHostToDevice, c->cstream));
+  }
+  HIPCHK(c, hipEventRecord(c->ev_staged, c->cstream));
+  c->next_n = (uint32_t)n;
+  c->next_pre = pre_flags != nullptr;
+  c->next_valid = true;
+  return IBFT_OK;
+}
+
+int ibft_seals_swap(ibft_ctx *c, int wait_for_copy) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->next_valid) {
+    c->last_error = "ibft_seals_swap without a batch staged by ibft_seals_stage_next";
+    return IBFT_E_INVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  // everything enqueued so far read the columns that become the spare slot now; what is enqueued from here on reads the
+  // other set, once its copy has landed (a device-side wait: the host does not block unless asked to)
+  HIPCHK(c, hipEventRecord(c->ev_cols_read, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_staged, 0));
+  std::swap(c->d_hash, c->d_hash_nx);
+  std::swap(c->d_sig, c->d_sig_nx);
+  std::swap(c->d_signer, c->d_signer_nx);
+  std::swap(c->d_pre, c->d_pre_nx);
+  c->staged_n = c->next_n;
+  c->staged_pre = c->next_pre;
+  c->next_valid = false;
+  c->wire_valid = false;
+  int rc;
+  if ((rc = apply_seal_digest(c, 0, c->staged_n, false))) return rc;
+  if (wait_for_copy) HIPCHK(c, hipEventSynchronize(c->ev_staged));  // the caller's source buffers are free again
+  return IBFT_OK;
+}
+
 static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
   if (c->ev_used >= 4096) c->ev_used = 0;  // event pairs accumulate until ibft_last_kernel_ms reads (and resets) them
   if (repeat == 0) repeat = 1;
+  c->launched_n = c->staged_n;
   for (uint32_t k = 0; k < repeat; k++) {
     int rc;
     const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
@@ -1789,7 +1865,7 @@ int ibft_seals_fetch(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c) return IBFT_E_INVAL;
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
-  return fetch_results(c, c->staged_n, out_mask, tally, true);
+  return fetch_results(c, c->launched_n, out_mask, tally, true);
 }
 
 int ibft_seals_run(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
@@ -2093,6 +2169,8 @@ int ibft_sync(ibft_ctx *c) {
   std::lock_guard<std::mutex> lk(c->mu);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->xstream) HIPCHK(c, hipStreamSynchronize(c->xstream));  // exchanges in flight (ibft_seals_exchange)
+  if (c->cstream) HIPCHK(c, hipStreamSynchronize(c->cstream));  // a batch on its way into the spare slot (ibft_seals_stage_next)
   return IBFT_OK;
 }
 

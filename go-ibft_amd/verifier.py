@@ -40,6 +40,7 @@ EXPORTS = [
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
     "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info", "ibft_set_seal_digest", "ibft_group_set_seal_digest",
+    "ibft_seals_stage_next", "ibft_seals_swap",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -140,6 +141,8 @@ def load_library() -> C.CDLL:
     L.ibft_seals_launch.argtypes = [vp, C.c_uint32]
     L.ibft_seals_fetch.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
+    L.ibft_seals_stage_next.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
+    L.ibft_seals_swap.argtypes = [vp, C.c_int]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp,
                                             vp, C.POINTER(Tally)]
@@ -537,11 +540,27 @@ class BatchVerifier:
         self._staged = len(s)
         return len(s)
 
+    def seals_stage_next(self, hash32, sig65, signer20, pre_flags=None) -> int:
+        """the NEXT batch into the spare column set, asynchronously on the context's copy stream (the arrays are kept alive
+        here until the swap; pass ibft_pinned_alloc memory — pinned_copy() — for the copy to overlap the kernels)"""
+        h = _u8(hash32, (-1, 32)); s = _u8(sig65, (-1, 65)); f = _u8(signer20, (-1, 20))
+        pre = None if pre_flags is None else _u8(pre_flags)
+        self._next_cols = (h, s, f, pre)
+        self._chk(self._L.ibft_seals_stage_next(self._h, _p(h), _p(s), _p(f), _p(pre), len(s)), "ibft_seals_stage_next")
+        return len(s)
+
+    def seals_swap(self, wait_for_copy: bool = True) -> None:
+        """the staged batch becomes the resident one; per step of a stream: launch(k), stage_next(k+1), fetch(k), swap"""
+        self._chk(self._L.ibft_seals_swap(self._h, 1 if wait_for_copy else 0), "ibft_seals_swap")
+        self._staged = len(self._next_cols[1])
+        self._held_cols, self._next_cols = self._next_cols, None   # (with wait_for_copy=0 the copy may still read them)
+
     def seals_launch(self, repeat: int = 1) -> None:
         self._chk(self._L.ibft_seals_launch(self._h, repeat), "ibft_seals_launch")
+        self._launched = self._staged
 
     def seals_fetch(self):
-        n = self._staged
+        n = getattr(self, "_launched", self._staged)   # the batch of the last launch (a swap may have come in between)
         mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
         t = Tally()
         self._chk(self._L.ibft_seals_fetch(self._h, _p(mask), C.byref(t)), "ibft_seals_fetch")

@@ -296,6 +296,20 @@ int ibft_seals_launch(ibft_ctx *ctx, uint32_t repeat);
 int ibft_seals_fetch(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
 /* launch(1) + fetch in one call: one more pass over the resident batch, results on return.      */
 int ibft_seals_run(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
+/* Two staging slots (round 5): the reference hands handleCommit NEW messages at every wake-up
+ * (core/ibft.go:931-946: one GetValidMessages walk per wake-up), so a sustained stream of batches pays an upload per
+ * batch; with one column set the upload of batch k+1 could not start before the verdict of batch k.
+ *   ibft_seals_stage_next: copy the NEXT batch into the context's spare column set on a copy stream of its own,
+ *       asynchronously — the source buffers must stay untouched until ibft_seals_swap(ctx, 1) returns (or, with
+ *       wait_for_copy = 0, until the next fetch of that batch); for the copy to overlap they must be page-locked
+ *       (ibft_pinned_alloc);
+ *   ibft_seals_swap: the staged batch becomes the resident one (launch / run / fetch then work on it), the previous one
+ *       becomes the spare slot; kernels already enqueued keep reading the columns they were launched on, the ones
+ *       enqueued afterwards wait ON THE DEVICE for the copy.  IBFT_E_INVAL without a staged batch.
+ * Per step of a sustained stream:  launch(k) → stage_next(k+1) → fetch(k) → swap.                                   */
+int ibft_seals_stage_next(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
+                          const uint8_t *signer20, const uint8_t *pre_flags, size_t n);
+int ibft_seals_swap(ibft_ctx *ctx, int wait_for_copy);
 /* Device address of the resident verdict mask (⌈n/64⌉ u64 words) and of the two
  * u64 tally accumulators {power, valid_rows|distinct<<32}: lets the caller run an
  * RCCL all-reduce over validator shards without a host round trip.                 */

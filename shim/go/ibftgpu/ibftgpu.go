@@ -360,6 +360,19 @@ func (c *Ctx) SealsRun(n int) ([]uint64, Tally, error) {
 	return mask, tally(t), c.check(rc)
 }
 
+// SealsStageNext copies the NEXT seal batch into the context's spare column set on a copy stream of its own while the
+// kernels of the resident batch run; SealsSwap makes it the resident batch.  Per step of a sustained stream of COMMIT
+// sets (one GetValidMessages walk per wake-up, core/ibft.go:931-946): SealsLaunch(k) → SealsStageNext(k+1) →
+// SealsFetch(k) → SealsSwap.  The columns must stay untouched until SealsSwap returns (it waits for the copy); allocate
+// them with PinnedAlloc for the copy to overlap.
+func (c *Ctx) SealsStageNext(hash32, sig65, signer20, preFlags []byte) error {
+	n := len(sig65) / 65
+	return c.check(C.ibft_seals_stage_next(c.h, ptr8(hash32), ptr8(sig65), ptr8(signer20), ptr8(preFlags), C.size_t(n)))
+}
+
+// SealsSwap: see SealsStageNext.
+func (c *Ctx) SealsSwap() error { return c.check(C.ibft_seals_swap(c.h, 1)) }
+
 // SignSeals = n × Backend.BuildCommitMessage's committed seal (core/backend.go:12-34) for a SIMULATOR that plays
 // n validators in one process: sk and hashes are n×32 bytes; returns the n×65 seals, the n×20 signer addresses
 // and ok[i] == 0 for a key outside [1, n).  Leaves the batch resident: SealsRun(n) verifies it without an upload.

@@ -1,0 +1,83 @@
+"""GPU: two staging slots per context (ibft_seals_stage_next / ibft_seals_swap, include/ibftgpu.h) — a sustained stream of COMMIT
+sets, a new batch at every wake-up (/root/reference/core/ibft.go:931-946): the copy of batch k+1 overlaps the verdict
+kernels of batch k.  Parity: alternating batches of different content and different sizes, every verdict / tally equal to the
+CPU oracle's for THAT batch — nothing of batch k leaks into k+1, kernels already enqueued keep reading the columns they were
+launched on."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(n_validators):
+    from oracle import workload as W, binding as B
+    r = W.make_round(n_validators, 9100 + n_validators, byzantine=True, weighted=True)
+    vs = B.ValSet(r.addrs, r.power)
+    cols = (r.hash32, r.seal65, r.signer20, r.pre_flags)
+    out = []
+    for k, (lo, hi, rev) in enumerate([(0, n_validators, False), (0, n_validators // 2, False), (n_validators // 3, n_validators, True),
+                                       (0, 1, False), (5, n_validators - 7, True)]):
+        sel = np.arange(lo, hi)[::-1] if rev else np.arange(lo, hi)
+        h, s, f, p = (np.ascontiguousarray(c[sel]) for c in cols)
+        if k == 2:
+            p = None                                        # a batch without pre-flags behind one with them
+            e = B.verify_seals(vs, h, s, f, None)
+        else:
+            e = B.verify_seals(vs, h, s, f, p)
+        out.append((h, s, f, p, e.astype(bool), B.tally(vs, f, e)))
+    return r, out
+
+
+@pytest.mark.parametrize("n,pinned", [(300, True), (4096, True), (4096, False), (9000, True)])
+def test_stream_of_batches_through_two_slots_equals_the_oracle(oracle, n, pinned):
+    import go_ibft_amd.verifier as V
+    r, batches = _batches(n)
+    col = (lambda a: None if a is None else V.pinned_copy(a)) if pinned else (lambda a: a)
+    host = [(col(h), col(s), col(f), col(p)) for h, s, f, p, _, _ in batches]
+    bv = V.BatchVerifier(max_rows=max(n, 1024))
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        bv.seals_stage(*host[0])
+        order = [0, 1, 2, 3, 4, 0, 2, 1, 4, 4, 3, 0]
+        for step, (cur, nxt) in enumerate(zip(order, order[1:] + [0])):
+            bv.seals_launch(1)                    # batch `cur` is resident
+            bv.seals_stage_next(*host[nxt])       # its successor travels meanwhile
+            verdict, t = bv.seals_fetch()
+            _, _, _, _, want, wt = batches[cur]
+            assert len(verdict) == len(want) and (verdict == want).all(), (step, cur)
+            assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == (wt.power, wt.valid_rows, wt.distinct_senders, wt.has_quorum)
+            bv.seals_swap()
+        # the resident batch after the last swap is batch 0 again; the one-shot call still works on the same context
+        verdict, t = bv.seals_run()
+        assert (verdict == batches[0][4]).all()
+        h, s, f, p, want, wt = batches[1]
+        v2, t2 = bv.is_valid_committed_seal(h, s, f, p)
+        assert (v2 == want).all() and t2.power == wt.power
+    finally:
+        bv.close()
+
+
+def test_a_kernel_enqueued_before_the_swap_keeps_its_columns_and_the_swap_needs_a_staged_batch(oracle):
+    import go_ibft_amd.verifier as V
+    r, batches = _batches(2048)
+    a, b = batches[0], batches[2]
+    bv = V.BatchVerifier(max_rows=2048)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        with pytest.raises(RuntimeError):
+            bv.seals_swap()                       # nothing staged
+        bv.seals_stage(*a[:4])
+        pa = [V.pinned_copy(x) for x in b[:3]]
+        for _ in range(5):
+            bv.seals_launch(1)                    # reads slot A … (not fetched yet)
+            bv.seals_stage_next(pa[0], pa[1], pa[2], None)
+            bv.seals_swap(wait_for_copy=False)    # … while the swap already points the context at slot B
+            va, ta = bv.seals_fetch()
+            assert (va == a[4]).all() and ta.power == a[5].power
+            vb, tb = bv.seals_run()
+            assert (vb == b[4]).all() and tb.power == b[5].power
+            # and back: A through the spare slot
+            bv.seals_stage_next(*a[:4])
+            bv.seals_swap()
+    finally:
+        bv.close()

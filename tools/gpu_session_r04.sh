@@ -18,7 +18,7 @@ for PART in "$@"; do
       echo "profsizes rc=$?"; tail -40 gpurun_out/r04_profile_sizes.log ;;
     config5)
       IBFT_BENCH_FORCE_DIST=1 IBFT_BENCH_CONFIG5=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29571 timeout 600 python bench.py --steps 20 --warmup 5 \
-        --no-cpu-baseline --no-sequence --no-warm --no-sweep --no-certificates --no-host-mirror --extended-steps 0 \
+        --no-cpu-baseline --no-sequence --no-warm --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0 \
         > gpurun_out/profiles/r04_forcedist_config5.json 2> gpurun_out/r04_forcedist_config5.err
       echo "config5 rc=$?"; tail -c 1500 gpurun_out/profiles/r04_forcedist_config5.json; tail -3 gpurun_out/r04_forcedist_config5.err ;;
     pair)

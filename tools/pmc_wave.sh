@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 cd /tmp
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_IFETCH" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | tr ' ' '_')
-  timeout 300 rocprofv3 --pmc $set -d "$OUT/$tag" -o p --output-format csv -- python $ROOT/bench.py --rows $ROWS --steps 20 --warmup 3 --no-cpu-baseline --no-sequence --no-sweep --no-certificates --no-host-mirror --extended-steps 0 > "$OUT/$tag.log" 2>&1
+  timeout 300 rocprofv3 --pmc $set -d "$OUT/$tag" -o p --output-format csv -- python $ROOT/bench.py --rows $ROWS --steps 20 --warmup 3 --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0 > "$OUT/$tag.log" 2>&1
 done
 cd "$ROOT"
 ROWS=$ROWS OUTDIR=$OUT python - > "$SUM/${TAG}_pmc_instruction_mix.txt" <<'PY'

@@ -15,9 +15,9 @@ mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 # the headline leg only: the sequence legs launch the same kernel over 8 192 rows (a COMMIT set), which would mix two
 # launch shapes into one per-kernel average; their kernels are summarised by a second stats pass (…_seq_kernel_stats.csv)
-CMD="python $ROOT/bench.py --rows $ROWS --steps 50 --warmup 5 --no-cpu-baseline --no-sequence --no-sweep --no-certificates --no-host-mirror --extended-steps 0"
-SEQ="python $ROOT/bench.py --rows $ROWS --steps 10 --warmup 2 --no-cpu-baseline --no-warm --seq-rounds 30 --no-sweep --no-certificates --no-host-mirror --extended-steps 0"
-PMC="python $ROOT/bench.py --rows $ROWS --steps 30 --warmup 3 --no-cpu-baseline --no-sequence --no-sweep --no-certificates --no-host-mirror --extended-steps 0"
+CMD="python $ROOT/bench.py --rows $ROWS --steps 50 --warmup 5 --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0"
+SEQ="python $ROOT/bench.py --rows $ROWS --steps 10 --warmup 2 --no-cpu-baseline --no-warm --seq-rounds 30 --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0"
+PMC="python $ROOT/bench.py --rows $ROWS --steps 30 --warmup 3 --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- $CMD > "$OUT/stats.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats_seq" -o q --output-format csv -- $SEQ > "$OUT/stats_seq.log" 2>&1
