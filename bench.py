@@ -22,9 +22,10 @@ Inputs are resident in HBM when the timed region starts.
         CPU oracle outside the timed region.
   `python bench.py --gpus N` from a bare shell re-launches itself under torch.distributed.run.
   torch is imported only for N > 1 and only as torch.distributed over gloo (communicator id, barriers, max over ranks): the
-  kernels run on the image's ROCm 7.2 HIP runtime, not on the 7.0.2 runtime bundled with torch (3.5 % slower for the same
-  code object, profiles/r05b_harness_ab.txt); the fences around the timed region are the library's own stream syncs
-  (ibft_sync: verdict, exchange and copy streams) — torch's streams never carried any of this work.
+  process runs ONE HIP runtime and ONE RCCL, the image's ROCm 7.2 ones the library was built for (torch 2.10+rocm7.0 bundles
+  its own 7.0.2 copies, and a process that imports torch first binds the library to those); the fences around the timed
+  region are the library's own stream syncs (ibft_sync: verdict, exchange and copy streams) — torch's streams never carried
+  any of this work.  Every rank pins itself to its GPU's NUMA node first (go_ibft_amd/numa.py: 0.333 vs 0.345 ms per kernel).
 
 Rank 0 prints TWO JSON lines: first the detail record ({"bench_detail": …}: sweep with counters, sequence forms, host-mirror
 legs, certificates — also written to gpurun_out/bench_detail.json), then, LAST on stdout and under 6 KB, the headline line the
@@ -626,7 +627,7 @@ def headline_record(rec: dict) -> dict:
                                "scaling", "vs_baseline", "dtype", "data") if k in rec}
     cfg = rec.get("config", {})
     out["config"] = {k: cfg[k] for k in ("workload", "validators", "rows_per_gpu", "path", "prewarm_steps", "kernel",
-                                         "parallelism") if k in cfg}
+                                         "parallelism", "numa_pin") if k in cfg}
     for k in ("quorum_latency_ms_p50", "step_latency_ms_p50", "step_latency_ms_p50_incl_h2d", "rccl_nranks", "rccl_rank0_device"):
         if k in rec:
             out[k] = rec[k]
@@ -722,18 +723,23 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch(args))
 
-    # WHICH HIP RUNTIME THE KERNELS RUN ON (round 5, profiles/r05b_harness_ab.txt): torch 2.10+rocm7.0 bundles its own
-    # libamdhip64 / libhsa-runtime64 (ROCm 7.0.2) and a process that imports torch first binds libibftgpu.so to THAT runtime —
-    # the same code object then runs the headline kernel in 0.3449 ms instead of the 0.3330 ms it takes on the image's ROCm 7.2
-    # runtime the library was built for (same box, alternating processes).  So the library is loaded FIRST, and torch comes in
-    # only where the contract needs torch.distributed (N > 1): as the carrier of the 128-byte communicator id and of the timing
-    # fences over a gloo group — CPU tensors, torch.cuda is never initialised (two HIP runtimes cannot share a process: with the
-    # library's runtime up, torch.cuda finds no device).  The data-path collective is the library's own ncclAllReduce on the
-    # image's librccl either way.  torch_first = the previous order (torch's runtime, nccl process group, torch.cuda fences).
+    # WHICH HIP RUNTIME THE PROCESS RUNS: torch 2.10+rocm7.0 bundles its own libamdhip64 / libhsa-runtime64 / librccl (ROCm
+    # 7.0.2), and a process that imports torch first binds libibftgpu.so — built against the image's ROCm 7.2 — to THOSE.  The
+    # library is loaded FIRST instead, and torch comes in only where the contract needs torch.distributed (N > 1): as the carrier
+    # of the 128-byte communicator id and of the timing fences over a gloo group — CPU tensors, torch.cuda never initialised,
+    # no minute-long torch import at N = 1.  The data-path collective is the library's own ncclAllReduce either way.  (Speed is
+    # NOT the reason: with the process held on one socket both runtimes run the kernel in the same time, profiles/r05g_*.)
+    # torch_first = the previous order (torch's runtime, nccl process group, torch.cuda fences).
     torch_first = os.environ.get("IBFT_BENCH_TORCH_FIRST") == "1" and not DRY_RUN
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # … and WHERE THE PROCESS RUNS: on the GPU's own NUMA node the same kernel takes 0.333 ms, on the other socket 0.345 ms
+    # (profiles/r05g_harness_ab.txt, r05h_numa_pin_ab.txt — the runtime makes no difference once the socket is held fixed; what
+    # looked like one in r05b was the scheduler's choice of socket).  Every rank pins itself to its device's node before the
+    # first HIP call (go_ibft_amd/numa.py: sysfs only); a Go host does the same with numactl.
+    import go_ibft_amd.numa as NUMA
+    numa_pin = {"pinned": False, "why": "dry run"} if DRY_RUN else NUMA.pin_to_device_node(local)
     want_dist = world > 1 or os.environ.get("IBFT_BENCH_FORCE_DIST") == "1"
     torch = None
     if torch_first:
@@ -761,6 +767,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node: the container's hostname may not resolve
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")    # RCCL's bootstrap likewise (data moves over xGMI / P2P)
             dist.init_process_group("gloo", rank=rank, world_size=world)
         if world != args.gpus:
             raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
@@ -942,7 +949,8 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": f"synthetic ({m['src']})",
             "config": {"workload": workload, "validators": n_total, "rows_per_gpu": rows, "path": args.path,
                        "prewarm_steps": PREWARM_STEPS if (carry is not None or world > 1 or dist is not None) else 0,
-                       "kernel": m["kname"], "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU"},
+                       "kernel": m["kname"], "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU",
+                       "numa_pin": numa_pin},
             "step_latency_ms_p50": float(np.median(m["lat"]) * 1e3),
             "step_latency_ms_p50_incl_h2d": float(np.median(m["lat_h2d"]) * 1e3) if m["lat_h2d"] else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,0 +1,95 @@
+"""Pin the calling process to the CPUs of the NUMA node a GPU hangs off — before the HIP runtime comes up.
+
+Measured on the MI355X boxes of this pool (2 × EPYC 9575F, four GPUs per socket; profiles/r05g_harness_ab.txt, r05h_*): the
+SAME verdict kernel on the SAME inputs runs 0.333 ms when the process that drives the device lives on the GPU's own NUMA node
+and 0.345 ms when it lives on the other socket — whichever HIP runtime is loaded, wherever the kernel arguments are placed
+(what round 4 had put down to "two classes of boxes" and round 5 at first to the runtime bundled with torch was the
+scheduler's choice of socket for the process).  The runtime creates its queues, signals and helper threads where the creating
+thread runs, so the pinning has to happen first.
+
+No HIP call is made here: the device → PCI function → local CPU list mapping is read from the KFD topology in sysfs
+(/sys/class/kfd/kfd/topology/nodes/*/properties: drm_render_minor → /sys/class/drm/renderD<minor>/device/local_cpulist), with
+ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES applied the way the runtime applies them.  Anything unexpected → no pinning.
+A Go host does the same with numactl / cpuset at process start."""
+from __future__ import annotations
+
+import glob
+import os
+
+
+def _visible(var: str, n: int, base: list[int]) -> list[int]:
+    v = os.environ.get(var)
+    if v is None or v.strip() == "":
+        return base
+    out = []
+    for tok in v.split(","):
+        tok = tok.strip()
+        if not tok.isdigit() or int(tok) >= len(base):   # (UUID forms and out-of-range entries end the list, as in the runtime)
+            break
+        out.append(base[int(tok)])
+    return out
+
+
+def kfd_gpu_nodes() -> list[dict]:
+    """the GPU agents of the KFD topology in node order: {node, gpu_id, drm_render_minor, location_id, domain}"""
+    nodes = []
+    for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda p: int(os.path.basename(p))):
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(path, "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) == 0:       # a CPU agent
+            continue
+        nodes.append({"node": int(os.path.basename(path)), "drm_render_minor": int(props.get("drm_render_minor", "-1")),
+                      "location_id": int(props.get("location_id", "0")), "domain": int(props.get("domain", "0"))})
+    return nodes
+
+
+def device_cpulist(device: int = 0) -> tuple[str, int] | None:
+    """(CPU list, NUMA node) of HIP device `device`, or None"""
+    gpus = kfd_gpu_nodes()
+    idx = _visible("HIP_VISIBLE_DEVICES", len(gpus), _visible("ROCR_VISIBLE_DEVICES", len(gpus), list(range(len(gpus)))))
+    if device >= len(idx):
+        return None
+    g = gpus[idx[device]]
+    dev = f"/sys/class/drm/renderD{g['drm_render_minor']}/device"
+    try:
+        cpus = open(os.path.join(dev, "local_cpulist")).read().strip()
+        node = int(open(os.path.join(dev, "numa_node")).read())
+    except (OSError, ValueError):
+        return None
+    return (cpus, node) if cpus else None
+
+
+def parse_cpulist(s: str) -> set[int]:
+    out = set()
+    for part in s.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            out.update(range(int(a), int(b) + 1))
+        elif part.strip():
+            out.add(int(part))
+    return out
+
+
+def pin_to_device_node(device: int = 0) -> dict:
+    """sched_setaffinity(this process) to the CPUs local to `device` (∩ the CPUs it may already use); returns what was done.
+    Call BEFORE the first HIP call of the process (before go_ibft_amd.verifier.load_library())."""
+    info = {"pinned": False, "device": device}
+    if os.environ.get("IBFT_NO_NUMA_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        info["why"] = "disabled"
+        return info
+    try:
+        got = device_cpulist(device)
+        if got is None:
+            info["why"] = "no topology"
+            return info
+        cpus = parse_cpulist(got[0]) & os.sched_getaffinity(0)
+        if not cpus:
+            info["why"] = "local CPUs not in the affinity mask"
+            return info
+        os.sched_setaffinity(0, cpus)
+        info.update(pinned=True, numa_node=got[1], cpus=got[0])
+    except (OSError, ValueError) as e:
+        info["why"] = repr(e)
+    return info

@@ -11,8 +11,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import go_ibft_amd  # noqa: F401
 mode = sys.argv[1] if len(sys.argv) > 1 else "none"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+pin = None
+if os.environ.get("IBFT_PIN") == "1":       # go_ibft_amd/numa.py: onto the GPU's own NUMA node, before any HIP call
+    import go_ibft_amd.numa as NUMA
+    pin = NUMA.pin_to_device_node(0)
 if mode == "torch_first":
     import torch
     torch.cuda.set_device(0)
@@ -39,5 +44,7 @@ el = time.perf_counter() - t0
 ms, k = bv.last_kernel_ms()
 assert verdict.all() and t.has_quorum == 1
 libs = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l or "libhsa-runtime" in l})
+if pin is not None:
+    print("pin:", pin, end="  ")
 print(f"{mode:12s} kernel {ms / k:.4f} ms  step {el / steps * 1e3:.4f} ms  ({k} samples)  hip runtime: {', '.join(libs)}")
 bv.close()

@@ -11,6 +11,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("IBFT_TORCH_FIRST") == "1":   # the HIP runtime bundled with torch (ROCm 7.0.2) instead of the image's 7.2
+    import torch
+    torch.cuda.set_device(0)
 import go_ibft_amd.verifier as V  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
