@@ -95,10 +95,13 @@ def comm_init_or_die(bv, uid, rank: int, world: int) -> None:
         t.cancel()
 
 
-def kernel_name(path: str, cold_lanes: int, warm_lanes: int) -> str:
+def kernel_name(path: str, cold_lanes: int, warm_lanes: int, cold_table: int = 1) -> str:
+    """the kernel's name as rocprofv3 prints it (without spaces); cold_table: ibft_last_cold_table (1 LDS → template
+    argument 0, 3 private → 1, 2 private + prefetch → 2)"""
     if path == "cold":
-        return {1: "ecrecover_lane_kernel<0>", 64: "ecrecover_wave_kernel<0>", 128: "ecrecover_wave2_kernel<0>",
-                16: "ecrecover_rows_kernel<0>"}.get(cold_lanes, f"ecrecover_group_kernel<0,{cold_lanes}>")
+        tab = {1: 0, 3: 1, 2: 2}.get(cold_table, 0)
+        return {1: f"ecrecover_lane_kernel<0,{tab}>", 64: "ecrecover_wave_kernel<0>", 128: "ecrecover_wave2_kernel<0>",
+                16: "ecrecover_rows_kernel<0>"}.get(cold_lanes, f"ecrecover_group_kernel<0,{cold_lanes},{tab}>")
     return {64: "verify_known_wave_kernel<0>", 1: "verify_known_lane_kernel<0>"}.get(
         warm_lanes, f"verify_known_group_kernel<0,{warm_lanes}>")
 
@@ -276,7 +279,7 @@ def valu_issue(kname: str, rows: int, avg_kernel_s: float):
       * the mix-weighted ceiling at the occupancy THIS launch reaches (wavefronts offered per SIMD, capped by registers)."""
     base = kname.split("<")[0]
     kshort = re.escape(base) + r"<[^>]*>" if "<" in kname else re.escape(base)
-    exact = re.escape(kname.replace(",", ", ")) if "group" in kname else kshort
+    exact = re.escape(kname.replace(",", ", ")) if ("group" in kname or "lane_kernel" in kname) else kshort
     insts = salu = None
     src = scaled = None
     for path in _attachment_files("pmc_instruction_mix.txt"):
@@ -300,9 +303,10 @@ def valu_issue(kname: str, rows: int, avg_kernel_s: float):
     if insts is None or mix is None:
         return None
     f_mad, f_dpp, nop, mix_src = mix
-    lanes = LANES_OF.get(base) or int(re.findall(r"\d+", kname)[-1])
+    lanes = LANES_OF.get(base) or int(re.findall(r"\d+", kname)[1])
     offered = rows * lanes / 64 / 1024
-    resident = max(1, min(RESIDENT_CAP.get(base, 2), int(offered + 0.999)))
+    cap = 2 if kname.replace(" ", "").startswith("ecrecover_lane_kernel<0,1") else RESIDENT_CAP.get(base, 2)   # (table in the private segment, no prefetch: 256 registers)
+    resident = max(1, min(cap, int(offered + 0.999)))
 
     def ceiling(waves):
         t = ISSUE_NS[waves]
@@ -449,7 +453,7 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
                     warm_l = bv.lanes_per_signature
                 kern = kms / max(kl, 1) / 1e3
                 ent = out[i] if path == "warm" else {"validators": n}
-                kn = kernel_name(path, cold_l, warm_l)
+                kn = kernel_name(path, cold_l, warm_l, bv.last_cold_table())
                 try:
                     vi = valu_issue(kn, n, kern)
                 except (OSError, ValueError, AttributeError, IndexError):
@@ -908,7 +912,8 @@ def main():
             warm_lanes = bv.lanes_per_signature
         res = {"n_total": n_total, "rows": rows, "elapsed": elapsed, "steps": steps, "lat": lat, "lat_h2d": lat_h2d,
                "rccl": comm_info,
-               "kernel_ms": kernel_ms, "kernel_launches": kernel_launches, "kname": kernel_name(path, cold_lanes, warm_lanes),
+               "kernel_ms": kernel_ms, "kernel_launches": kernel_launches,
+               "kname": kernel_name(path, cold_lanes, warm_lanes, bv.last_cold_table()),
                "src": rd["src"], "rd": rd, "tables": bv.cache_stats()[0] if path == "warm" else 0, "input_generation_s": t_gen,
                "valid_fraction": float(verdict.mean())}
         if dist:

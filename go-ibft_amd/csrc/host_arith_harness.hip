@@ -89,6 +89,25 @@ int dev_ecmult_var(const uint8_t *k, const uint8_t *p64, uint8_t *out64) {
   return ok ? 1 : 0;
 }
 
+// the same with the window table in "LDS" (round 5: recover_dev.h ltab) — here a heap block that stands for the columns of TPB = 3
+// lanes of a workgroup, this call being lane `lane` of them (the other columns must stay untouched: returned in guard_ok)
+int dev_ecmult_var_lds(const uint8_t *k, const uint8_t *p64, uint8_t *out64, int lane, int *guard_ok) {
+  ibftk::aff P;
+  P.x = fin(p64);
+  P.y = fin(p64 + 32);
+  std::vector<uint32_t> mem((size_t)ibftk::LTAB_WORDS * 3, 0xA5A5A5A5u);
+  ibftk::jac q = ibftk::ecmult_var_lds<3>(P, secp::from_be32(k), mem.data() + lane);
+  int ok_guard = 1;
+  for (size_t i = 0; i < mem.size(); i++)
+    if ((int)(i % 3) != lane && mem[i] != 0xA5A5A5A5u) ok_guard = 0;
+  if (guard_ok) *guard_ok = ok_guard;
+  ibftk::aff a;
+  bool ok = secp::jac_to_aff(a, q);
+  secp::to_be32(out64, secp::l26_to_u256(a.x));
+  secp::to_be32(out64 + 32, secp::l26_to_u256(a.y));
+  return ok ? 1 : 0;
+}
+
 // the same through round 1's form (unsigned 4-bit windows, 15 Jacobian multiples, full additions): the cross-check of the
 // signed-window / common-Z form above
 int dev_ecmult_var_v1(const uint8_t *k, const uint8_t *p64, uint8_t *out64) {

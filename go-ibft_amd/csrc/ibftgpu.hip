@@ -158,6 +158,9 @@ struct ibft_ctx {
   uint32_t warm_passes = 0, cold_passes = 0, last_group = 0, last_cold_group = 1;
   bool cold_group_auto = true;
   uint32_t cold_group_force = 0;  // IBFT_COLD_LANES=1|2|4|8|64 (experiments: pin the cold kernel variant)
+  // IBFT_COLD_TABLE=lds|private|private2 pins where the lane / group cold kernels keep their window tables: 1 LDS, 2 private
+  // segment with the prefetch (round 4's form), 3 private segment without it (two resident wavefronts; lane kernel only)
+  uint32_t cold_table_force = 0, last_cold_table = 0;
   uint32_t warm_group_force = 0;  // IBFT_WARM_LANES=1|2|…|64 (experiments: pin the warm kernel variant)
   uint32_t rows_kernel_max = 8192;  // AUTO: a DPP row per signature above wave_rows_max up to this many rows
                                     // (4 096 rows: 0.55 ms vs 0.84 ms for the 8-lane kernel; 8 192: 0.84 vs 0.86)
@@ -459,23 +462,41 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
     if (!warm && (rc_clean = clean_mask(c))) return rc_clean;
     const uint32_t rows_per_wave = 64 / CG;
     dim3 cgrid((n + rows_per_wave - 1) / rows_per_wave), cblock(64);
-#define IBFT_LAUNCH_COLD(GG)                                                                         \
-  if (mode == 0)                                                                                     \
-    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<0, GG>), cgrid, cblock, 0, c->stream, a);      \
-  else                                                                                               \
-    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<1, GG>), cgrid, cblock, 0, c->stream, a);
+    // the lanes' window tables: LDS (no private segment) unless pinned otherwise (IBFT_COLD_TABLE=private: round 4's form, A/B)
+    const bool lds_tab = c->cold_table_force != 2;
+#define IBFT_LAUNCH_COLD(GG)                                                                                          \
+  if (mode == 0 && lds_tab)                                                                                           \
+    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<0, GG, ibftk::TAB_LDS>), cgrid, cblock, 0, c->stream, a);       \
+  else if (mode == 0)                                                                                                 \
+    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<0, GG, ibftk::TAB_PRIVATE_PREFETCH>), cgrid, cblock, 0, c->stream, a); \
+  else if (lds_tab)                                                                                                   \
+    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<1, GG, ibftk::TAB_LDS>), cgrid, cblock, 0, c->stream, a);       \
+  else                                                                                                                \
+    hipLaunchKernelGGL((ibftk::ecrecover_group_kernel<1, GG, ibftk::TAB_PRIVATE_PREFETCH>), cgrid, cblock, 0, c->stream, a);
     switch (CG) {
       case 8: IBFT_LAUNCH_COLD(8) break;
       case 4: IBFT_LAUNCH_COLD(4) break;
       default: IBFT_LAUNCH_COLD(2) break;
     }
 #undef IBFT_LAUNCH_COLD
+    c->last_cold_table = lds_tab ? 1 : 2;
   } else {
     dim3 grid((n + ibftk::ROWS_PER_BLOCK - 1) / ibftk::ROWS_PER_BLOCK), block(ibftk::ROWS_PER_BLOCK);
-    if (mode == 0)
-      hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<0>, grid, block, 0, c->stream, a);
-    else
-      hipLaunchKernelGGL(ibftk::ecrecover_lane_kernel<1>, grid, block, 0, c->stream, a);
+    // one lane per signature: up to one wavefront per SIMD offered (n ≤ 65 536) the table lives in LDS; beyond, in the private
+    // segment WITHOUT the prefetch — 256 registers, two resident wavefronts per SIMD (15 against 18 ns per verify)
+    const uint32_t tab = c->cold_table_force ? c->cold_table_force : ((uint64_t)n <= 65536ull ? 1u : 3u);
+#define IBFT_LAUNCH_LANE(TT)                                                                       \
+  if (mode == 0)                                                                                   \
+    hipLaunchKernelGGL((ibftk::ecrecover_lane_kernel<0, TT>), grid, block, 0, c->stream, a);       \
+  else                                                                                             \
+    hipLaunchKernelGGL((ibftk::ecrecover_lane_kernel<1, TT>), grid, block, 0, c->stream, a);
+    switch (tab) {
+      case 1: IBFT_LAUNCH_LANE(ibftk::TAB_LDS) break;
+      case 2: IBFT_LAUNCH_LANE(ibftk::TAB_PRIVATE_PREFETCH) break;
+      default: IBFT_LAUNCH_LANE(ibftk::TAB_PRIVATE) break;
+    }
+#undef IBFT_LAUNCH_LANE
+    c->last_cold_table = tab;
   }
   c->last_cold_group = CG;
   HIPCHK(c, hipGetLastError());
@@ -1272,6 +1293,11 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->max_rows = (cfg && cfg->max_rows) ? cfg->max_rows : DEFAULT_MAX_ROWS;
   c->kernel = cfg ? cfg->kernel : IBFT_KERNEL_AUTO;
   c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
+  if (const char *e = getenv("IBFT_COLD_TABLE")) {
+    if (!strcmp(e, "lds")) c->cold_table_force = 1;
+    else if (!strcmp(e, "private")) c->cold_table_force = 2;
+    else if (!strcmp(e, "private2")) c->cold_table_force = 3;
+  }
   if (const char *e = getenv("IBFT_COLD_LANES")) {
     const int g = atoi(e);
     if (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64 || g == 128) c->cold_group_force = (uint32_t)g;
@@ -1971,6 +1997,13 @@ int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) 
   std::lock_guard<std::mutex> lk(c->mu);
   if (cold_lanes) *cold_lanes = c->last_cold_group;
   if (warm_lanes) *warm_lanes = c->last_group;
+  return IBFT_OK;
+}
+
+int ibft_last_cold_table(ibft_ctx *c, uint32_t *table) {
+  if (!c || !table) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  *table = (c->last_cold_group == 1 || c->last_cold_group == 2 || c->last_cold_group == 4) ? c->last_cold_table : 0u;
   return IBFT_OK;
 }
 

@@ -372,9 +372,22 @@ __device__ __forceinline__ row_regs stage_rows(const recover_args &a, uint8_t *l
 }
 
 // MODE 0: seals (digest = hash32 row).  MODE 1: senders (digest = keccak256(payload row)).
-template <int MODE>
+// TAB: where the per-lane window table of u2·R lives (recover_dev.h) —
+//   TAB_LDS      in the workgroup's LDS (640 B per lane: one wavefront per SIMD, what a batch of ≤ 65 536 rows offers anyway);
+//                no private segment at all: the launch moves the rows, the G-table lines and nothing else through HBM;
+//   TAB_PRIVATE  in the private segment, read where it is used: 256 registers, TWO resident wavefronts per SIMD — the form for
+//                batches that offer more than one wavefront per SIMD (n > 65 536: 15 instead of 18 ns per verify);
+//   TAB_PRIVATE_PREFETCH  round 4's form (entries read in front of the doublings, one resident wavefront): kept for the A/B.
+constexpr int TAB_LDS = 0, TAB_PRIVATE = 1, TAB_PRIVATE_PREFETCH = 2;
+constexpr int STAGE_BYTES = ROWS_PER_BLOCK * (65 + 32 + 20);
+template <int MODE, int TAB>
 __global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_args a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS_PER_BLOCK * (65 + 32 + 20)];
+  // one block of LDS words: first the staging area of the rows, then (TAB_LDS) the window tables — the block is ONE wavefront
+  // (ROWS_PER_BLOCK = 64) and its LDS operations execute in order, so the table may overwrite rows already read into registers
+  constexpr int LDS_WORDS = TAB == TAB_LDS ? LTAB_WORDS * ROWS_PER_BLOCK : (STAGE_BYTES + 3) / 4;
+  static_assert(LTAB_WORDS * ROWS_PER_BLOCK * 4 >= STAGE_BYTES && ROWS_PER_BLOCK == 64, "the table area holds the staging area");
+  __shared__ __attribute__((aligned(16))) uint32_t ldsw[LDS_WORDS];
+  uint8_t *lds = reinterpret_cast<uint8_t *>(ldsw);
   row_regs q = stage_rows<MODE>(a, lds);
   const uint32_t lane = threadIdx.x;
   // rows the warm kernel already decided keep their bit; a wavefront with nothing left exits
@@ -384,7 +397,11 @@ __global__ void __launch_bounds__(ROWS_PER_BLOCK) ecrecover_lane_kernel(recover_
 
   uint32_t got[5];
   aff Qa;
-  bool rec = recover_pubkey(a.gtab, q.z, q.r, q.s, q.v, a.flags, got, Qa);
+  bool rec;
+  if (TAB == TAB_LDS)
+    rec = recover_pubkey_with(a.gtab, q.z, q.r, q.s, q.v, a.flags, got, Qa, var_mult_lds<ROWS_PER_BLOCK>{ldsw + lane});
+  else
+    rec = recover_pubkey_with(a.gtab, q.z, q.r, q.s, q.v, a.flags, got, Qa, var_mult_private<TAB == TAB_PRIVATE_PREFETCH>{});
   bool ok = need && !q.pre && rec;
 #pragma unroll
   for (int i = 0; i < 5; i++) ok = ok && (got[i] == q.want[i]);
@@ -591,8 +608,9 @@ __global__ void __launch_bounds__(64 * WAVE_KERNEL_WAVES) verify_known_wave_kern
 // replicated across the group, so the critical path shrinks from ≈676 k to ≈520 k (G = 2),
 // ≈440 k (G = 4), ≈410 k (G = 8) VALU instructions: worth it exactly when the batch is too small
 // to fill the chip (host picks G so that n·G/64 ≤ 1024 wavefronts).
-template <int MODE, int G>
+template <int MODE, int G, int TAB = TAB_LDS>
 __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
+  __shared__ uint32_t ldsw[(TAB == TAB_LDS && G != 8) ? LTAB_WORDS * 64 : 1];  // the lanes' window tables (4-bit windows: G = 2, 4)
   constexpr int ROWS = 64 / G;
   constexpr int P = G / 2;            // pieces per GLV half
   constexpr int PIECE_BITS = 128 / P; // 128, 64 or 32 ... (G = 2, 4, 8)
@@ -687,28 +705,44 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
     aff b1;
     b1.x = base.x;
     b1.y = base.y;
-    wtab wt;
-    ecmult_table(b1, wt);
     const u256 kb = window_bias(kk);
+    if (TAB == TAB_LDS) {
+      // the table in LDS (recover_dev.h: ltab): 640 B per lane, β·X multiplied at use — for every lane, the λ half selects it
+      // (half differs from lane to lane: no call under divergent control flow)
+      ltab<64> lt;
+      lt.col = ldsw + lane;
+      ecmult_table_lds<64>(b1, lt);
 #pragma unroll 1
-    for (int nib = NIBS; nib >= 0; nib--) {
-      const int at = (int)(piece * NIBS) + nib;
-      const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
-      const int e = mine ? (int)secp::nibble(kb, at) - 8 : 0;
-#if IBFT_WINDOW_PREFETCH
-      const aff q = window_operand(wt, e, half != 0, flip);  // read in front of the doublings that cover its latency
-#endif
-      if (nib != NIBS) {
+      for (int nib = NIBS; nib >= 0; nib--) {
+        const int at = (int)(piece * NIBS) + nib;
+        const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
+        const int e = mine ? (int)secp::nibble5(kb, at) - 8 : 0;
+        if (nib != NIBS) {
 #pragma unroll 1
-        for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+          for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+        }
+        aff q = window_operand_lds<64>(lt, e, flip);
+        q.x = secp::l26_select(half != 0, secp::fe_mul(q.x, beta), q.x);
+        acc = window_add_q(acc, q, e);
       }
-#if IBFT_WINDOW_PREFETCH
-      acc = window_add_q(acc, q, e);
-#else
-      acc = window_add(acc, wt, e, half != 0, flip);
-#endif
+      acc.z = secp::fe_mul(acc.z, secp::fe_mul(lt.zc, base.z));
+    } else {
+      wtab wt;
+      ecmult_table(b1, wt);
+#pragma unroll 1
+      for (int nib = NIBS; nib >= 0; nib--) {
+        const int at = (int)(piece * NIBS) + nib;
+        const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
+        const int e = mine ? (int)secp::nibble(kb, at) - 8 : 0;
+        const aff q = window_operand(wt, e, half != 0, flip);  // read in front of the doublings that cover its latency
+        if (nib != NIBS) {
+#pragma unroll 1
+          for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+        }
+        acc = window_add_q(acc, q, e);
+      }
+      acc.z = secp::fe_mul(acc.z, secp::fe_mul(wt.zc, base.z));
     }
-    acc.z = secp::fe_mul(acc.z, secp::fe_mul(wt.zc, base.z));
   }
   // u1·G: the fixed-base windows are dealt to the lanes of the group
 #pragma unroll 1
@@ -716,7 +750,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
     const int w = it * G + (int)sub;
     const bool has = w < GTAB_WINDOWS;
     const int ww = has ? w : 0;
-    const uint32_t dg = (u1.v[(ww * GTAB_BITS) >> 5] >> ((ww * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+    const uint32_t dg = (secp::word_sel<8>(u1, (uint32_t)(ww * GTAB_BITS) >> 5) >> ((ww * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
     aff pt = load_affine(a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)ww * GTAB_ENTRIES + dg));
     jac sum = secp::jac_add_aff(acc, pt);
     acc = secp::jac_select(has && dg != 0, sum, acc);

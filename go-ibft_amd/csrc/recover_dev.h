@@ -76,7 +76,7 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
 __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ gtab, const u256 &k, jac acc) {
 #pragma unroll 1
   for (int w = 0; w < GTAB_WINDOWS; w++) {
-    uint32_t dgt = (k.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+    uint32_t dgt = (secp::word_sel<8>(k, (uint32_t)(w * GTAB_BITS) >> 5) >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
     const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
     uint4 t0 = e[0], t1 = e[1], t2 = e[2], t3 = e[3], t4 = e[4];
     aff q;
@@ -168,7 +168,8 @@ __host__ __device__ __forceinline__ jac window_add_q(const jac &acc, const aff &
 __host__ __device__ __forceinline__ jac window_add(const jac &acc, const wtab &t, int e, bool lambda, bool flip) {
   return window_add_q(acc, window_operand(t, e, lambda, flip), e);
 }
-__host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) {
+template <bool PREFETCH>
+__host__ __device__ __forceinline__ jac ecmult_var_t(const aff &R, const u256 &k) {
   secp::glv_split sp = secp::sc_split_lambda(k);
   aff R1 = R;
   R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
@@ -179,25 +180,135 @@ __host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) 
   jac acc = secp::jac_inf();
 #pragma unroll 1
   for (int i = WINDOW_DIGITS - 1; i >= 0; i--) {
-#if IBFT_WINDOW_PREFETCH
     const int e1 = (int)secp::nibble(k1, i) - 8, e2 = (int)secp::nibble(k2, i) - 8;
-    const aff q1 = window_operand(t, e1, false, false), q2 = window_operand(t, e2, true, flip2);
-#endif
+    aff q1, q2;
+    if (PREFETCH) {
+      q1 = window_operand(t, e1, false, false);
+      q2 = window_operand(t, e2, true, flip2);
+    }
     if (i != WINDOW_DIGITS - 1) {
 #pragma unroll 1
       for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
     }
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {
-#if IBFT_WINDOW_PREFETCH
-      aff q;  // (one inlined copy of the mixed addition: the operand is chosen, not the code)
-      q.x = secp::l26_select(h != 0, q2.x, q1.x);
-      q.y = secp::l26_select(h != 0, q2.y, q1.y);
-      acc = window_add_q(acc, q, h ? e2 : e1);
-#else
-      const int e = (int)(h ? secp::nibble(k2, i) : secp::nibble(k1, i)) - 8;
-      acc = window_add(acc, t, e, h != 0, h != 0 && flip2);
-#endif
+      if (PREFETCH) {
+        aff q;  // (one inlined copy of the mixed addition: the operand is chosen, not the code)
+        q.x = secp::l26_select(h != 0, q2.x, q1.x);
+        q.y = secp::l26_select(h != 0, q2.y, q1.y);
+        acc = window_add_q(acc, q, h ? e2 : e1);
+      } else {
+        acc = window_add(acc, t, h ? e2 : e1, h != 0, h != 0 && flip2);
+      }
+    }
+  }
+  acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve
+  return acc;
+}
+__host__ __device__ __forceinline__ jac ecmult_var(const aff &R, const u256 &k) { return ecmult_var_t<IBFT_WINDOW_PREFETCH != 0>(R, k); }
+
+// ---- the same multiplication with the window table in LDS (round 5) -------------------------------------------------
+// The private-segment table above costs 3 056 B of scratch per lane — 1.3 GB of HBM traffic per N = 65 536 launch, 172 × the
+// algorithmic bytes (profiles/r04x_n65536_traffic.json), served at a speed that differs by 12–19 % between hosts.  Here the
+// eight (x, y) pairs of the common-Z table live in the workgroup's LDS: 16 field elements = 640 B per lane, exactly what 160 KB
+// give four wavefronts of a compute unit (one per SIMD: the occupancy these kernels have anyway).  Element slot s of lane
+// `tid` of a TPB-lane workgroup: words col[(10·s + w)·TPB], col = lds + tid — a lane touches its own column only (no barrier),
+// consecutive lanes hit consecutive banks whatever entry each of them asks for (no conflict).  What does not fit is dropped:
+// β·X is multiplied at use (one product per λ-window, +1.5 % instructions), the Z's and prefix products of the build live in
+// registers (the build is straight-line code over outlined multiplications; z₁ = 1).
+constexpr int LTAB_SLOTS = 16;
+constexpr int LTAB_WORDS = LTAB_SLOTS * 10;  // 32-bit words per lane
+template <int TPB>
+struct ltab {
+  uint32_t *col;
+  secp::fe zc;
+};
+template <int TPB>
+__host__ __device__ __forceinline__ void ltab_put(const ltab<TPB> &t, int s, const secp::fe &v) {
+#pragma unroll
+  for (int w = 0; w < 10; w++) t.col[(size_t)(10 * s + w) * TPB] = v.n[w];
+}
+template <int TPB>
+__host__ __device__ __forceinline__ secp::fe ltab_get(const ltab<TPB> &t, int s) {
+  secp::fe v;
+#pragma unroll
+  for (int w = 0; w < 10; w++) v.n[w] = t.col[(size_t)(10 * s + w) * TPB];
+  return v;
+}
+// entry e (1…8): x in slot 2(e−1), y in slot 2(e−1)+1
+template <int TPB>
+__host__ __device__ __forceinline__ void ecmult_table_lds(const aff &R1, ltab<TPB> &t) {
+  secp::fe z[9];
+  ltab_put(t, 0, R1.x);
+  ltab_put(t, 1, R1.y);
+  {
+    const jac m2 = secp::jac_dbl(secp::jac_from_aff(R1));
+    ltab_put(t, 2, m2.x); ltab_put(t, 3, m2.y); z[2] = m2.z;
+    const jac m3 = secp::jac_add_aff(m2, R1);
+    ltab_put(t, 4, m3.x); ltab_put(t, 5, m3.y); z[3] = m3.z;
+    const jac m4 = secp::jac_dbl(m2);
+    ltab_put(t, 6, m4.x); ltab_put(t, 7, m4.y); z[4] = m4.z;
+    const jac m6 = secp::jac_dbl(m3);
+    ltab_put(t, 10, m6.x); ltab_put(t, 11, m6.y); z[6] = m6.z;
+    const jac m5 = secp::jac_add_aff(m4, R1);
+    ltab_put(t, 8, m5.x); ltab_put(t, 9, m5.y); z[5] = m5.z;
+    const jac m8 = secp::jac_dbl(m4);
+    ltab_put(t, 14, m8.x); ltab_put(t, 15, m8.y); z[8] = m8.z;
+    const jac m7 = secp::jac_add_aff(m6, R1);
+    ltab_put(t, 12, m7.x); ltab_put(t, 13, m7.y); z[7] = m7.z;
+  }
+  // Zc = z₂·…·z₈, s_i = Zc / z_i = (z₂…z_{i−1})·(z_{i+1}…z₈): prefix products forward, the suffix product while walking down
+  secp::fe pre[8];  // pre[i] = z₂·…·z_i
+  pre[2] = z[2];
+#pragma unroll
+  for (int i = 3; i <= 7; i++) pre[i] = secp::fe_mul(pre[i - 1], z[i]);
+  secp::fe suf = z[8];  // z_{i+1}·…·z₈ on entry of step i (set for i = 7 here; step 8 has an empty suffix)
+#pragma unroll
+  for (int i = 8; i >= 1; i--) {
+    const secp::fe sc = i == 8 ? pre[7] : (i <= 2 ? suf : secp::fe_mul(pre[i - 1], suf));
+    const secp::fe s2 = secp::fe_sqr(sc);
+    const int sl = 2 * (i - 1);
+    ltab_put(t, sl, secp::fe_mul(ltab_get(t, sl), s2));
+    ltab_put(t, sl + 1, secp::fe_mul(ltab_get(t, sl + 1), secp::fe_mul(s2, sc)));
+    if (i <= 7 && i >= 2) suf = secp::fe_mul(suf, z[i]);  // after step i: z_i·…·z₈ — what step i − 1 needs; after step 2: Zc
+  }
+  t.zc = suf;
+}
+template <int TPB>
+__host__ __device__ __forceinline__ aff window_operand_lds(const ltab<TPB> &t, int e, bool flip) {
+  const uint32_t mag = (uint32_t)(e < 0 ? -e : e);
+  const int sl = 2 * (int)((mag ? mag : 1u) - 1u);  // (a dummy operand for e = 0: the sum is computed and dropped)
+  aff q;
+  q.x = ltab_get(t, sl);
+  const secp::fe y = ltab_get(t, sl + 1);
+  q.y = secp::l26_select((e < 0) != flip, secp::fe_neg(y, 1), y);  // magnitude ≤ 2
+  return q;
+}
+template <int TPB>
+__host__ __device__ __forceinline__ jac ecmult_var_lds(const aff &R, const u256 &k, uint32_t *col) {
+  secp::glv_split sp = secp::sc_split_lambda(k);
+  aff R1 = R;
+  R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
+  const bool flip2 = sp.neg1 != sp.neg2;
+  ltab<TPB> t;
+  t.col = col;
+  ecmult_table_lds<TPB>(R1, t);
+  const u256 k1 = window_bias(sp.k1), k2 = window_bias(sp.k2);
+  const secp::fe beta = secp::GLV_CONST(1);
+  jac acc = secp::jac_inf();
+#pragma unroll 1
+  for (int i = WINDOW_DIGITS - 1; i >= 0; i--) {
+    if (i != WINDOW_DIGITS - 1) {
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+    }
+    const int e1 = (int)secp::nibble5(k1, i) - 8, e2 = (int)secp::nibble5(k2, i) - 8;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {  // (one inlined copy of the mixed addition; h is uniform: the β product is no divergent call)
+      const int e = h ? e2 : e1;
+      aff q = window_operand_lds<TPB>(t, e, h != 0 && flip2);
+      if (h) q.x = secp::fe_mul(q.x, beta);
+      acc = window_add_q(acc, q, e);
     }
   }
   acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve
@@ -235,9 +346,21 @@ __host__ __device__ __forceinline__ jac ecmult_var_v1(const aff &R, const u256 &
 
 // Recover the signer address of (digest z, r, s, v); returns false if the signature
 // is rejected (same rejection list as oracle/secp256k1.c:orc_ecrecover).
-__host__ __device__ __forceinline__ bool recover_pubkey(const uint32_t *__restrict__ gtab, const u256 &z_raw,
-                                                        const u256 &r, const u256 &s, uint32_t v,
-                                                        uint32_t flags, uint32_t addr[5], aff &Qa) {
+// how u2·R is computed: the table in the private segment (PREFETCH: its entries read in front of the doublings — one resident
+// wavefront per SIMD; without: two) or in the workgroup's LDS
+template <bool PREFETCH>
+struct var_mult_private {
+  __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k) const { return ecmult_var_t<PREFETCH>(R, k); }
+};
+template <int TPB>
+struct var_mult_lds {
+  uint32_t *col;
+  __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k) const { return ecmult_var_lds<TPB>(R, k, col); }
+};
+template <class VARMULT>
+__host__ __device__ __forceinline__ bool recover_pubkey_with(const uint32_t *__restrict__ gtab, const u256 &z_raw,
+                                                             const u256 &r, const u256 &s, uint32_t v,
+                                                             uint32_t flags, uint32_t addr[5], aff &Qa, const VARMULT &var_mult) {
   bool ok = v <= 1;
   ok = ok && !secp::is_zero(r) && !secp::geq_const(r, secp::NL());
   ok = ok && !secp::is_zero(s) && !secp::geq_const(s, secp::NL());
@@ -263,12 +386,17 @@ __host__ __device__ __forceinline__ bool recover_pubkey(const uint32_t *__restri
   secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));  // r is canonical, in [1, n)
   u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
-  jac Q = ecmult_var(R, u2);
+  jac Q = var_mult(R, u2);
   Q = ecmult_gen(gtab, u1, Q);
   ok = secp::jac_to_aff_fast(Qa, Q) && ok;
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);
   return ok;
+}
+__host__ __device__ __forceinline__ bool recover_pubkey(const uint32_t *__restrict__ gtab, const u256 &z_raw,
+                                                        const u256 &r, const u256 &s, uint32_t v,
+                                                        uint32_t flags, uint32_t addr[5], aff &Qa) {
+  return recover_pubkey_with(gtab, z_raw, r, s, v, flags, addr, Qa, var_mult_private<IBFT_WINDOW_PREFETCH != 0>{});
 }
 __host__ __device__ __forceinline__ bool recover_address(const uint32_t *__restrict__ gtab, const u256 &z_raw,
                                                          const u256 &r, const u256 &s, uint32_t v,

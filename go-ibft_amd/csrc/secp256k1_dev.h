@@ -141,6 +141,18 @@ HD uint32_t sub256(u256 &r, const u256 &a, const u256 &b) {
 HD uint32_t nibble(const u256 &k, int idx) {  // idx 0 = least significant 4 bits
   return (k.v[idx >> 3] >> (4 * (idx & 7))) & 15u;
 }
+// word `w` of k picked by a chain of selects: a dynamically indexed k.v[w] sends the whole array to the private segment (the
+// last 64–112 B of scratch per lane the lane / group kernels still had once their window tables had moved to LDS)
+template <int WORDS = 8>
+HD uint32_t word_sel(const u256 &k, uint32_t w) {
+  uint32_t r = k.v[0];
+#pragma unroll
+  for (int i = 1; i < WORDS; i++) r = w == (uint32_t)i ? k.v[i] : r;
+  return r;
+}
+HD uint32_t nibble5(const u256 &k, int idx) {  // nibble idx of a value below 2^160 (a biased 128-bit scalar: 33 digits)
+  return (word_sel<5>(k, (uint32_t)idx >> 3) >> (4 * (idx & 7))) & 15u;
+}
 
 // ------------------------------------------------------------------ 10×26 limbs
 constexpr uint32_t M26 = 0x3FFFFFFu;

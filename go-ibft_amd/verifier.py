@@ -40,7 +40,7 @@ EXPORTS = [
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
     "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info", "ibft_set_seal_digest", "ibft_group_set_seal_digest",
-    "ibft_seals_stage_next", "ibft_seals_swap",
+    "ibft_seals_stage_next", "ibft_seals_swap", "ibft_last_cold_table",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -143,6 +143,7 @@ def load_library() -> C.CDLL:
     L.ibft_seals_run.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_seals_stage_next.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.ibft_seals_swap.argtypes = [vp, C.c_int]
+    L.ibft_last_cold_table.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp,
                                             vp, C.POINTER(Tally)]
@@ -663,6 +664,12 @@ class BatchVerifier:
         a, b = C.c_uint32(), C.c_uint32()
         self._chk(self._L.ibft_last_dispatch(self._h, C.byref(a), C.byref(b)), "ibft_last_dispatch")
         return a.value, b.value
+
+    def last_cold_table(self) -> int:
+        """where the last lane / group cold kernel kept its window tables: 0 none ran, 1 LDS, 2 private + prefetch, 3 private"""
+        t = C.c_uint32()
+        self._chk(self._L.ibft_last_cold_table(self._h, C.byref(t)), "ibft_last_cold_table")
+        return t.value
 
     def sync(self):
         self._chk(self._L.ibft_sync(self._h), "ibft_sync")

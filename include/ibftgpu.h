@@ -348,6 +348,11 @@ int ibft_cache_memory(ibft_ctx *ctx, uint64_t *device_bytes, uint32_t *slots_in_
  * 2/4/8 = ecrecover_group_kernel, 16 = ecrecover_rows_kernel, 64 = ecrecover_wave_kernel, 128 = ecrecover_wave2_kernel)
  * and warm kernel (0 = none ran, 1 = lane, 2..64 = group).                                        */
 int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);
+/* Where the last lane / group cold kernel kept the per-lane window table of u2·R: 0 = no such kernel ran, 1 = the
+ * workgroup's LDS (default up to one wavefront per SIMD: no private segment), 2 = private segment with the entries read in
+ * front of the doublings (round 4's form; IBFT_COLD_TABLE=private), 3 = private segment without that prefetch — two
+ * resident wavefronts per SIMD, the lane kernel's form beyond 65 536 rows.                                              */
+int ibft_last_cold_table(ibft_ctx *ctx, uint32_t *table);
 /* ---- pinned column buffers -------------------------------------------------------------------------
  * Every entry point accepts ordinary (pageable) host memory for its columns; the runtime then stages each
  * column through its own bounce buffer — measured at ≈8.5 GB/s, 0.15 ms for the 1.3 MB of a 4 096-message

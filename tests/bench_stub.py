@@ -120,6 +120,9 @@ class BatchVerifier:
     def last_dispatch(self):
         return 16, 16
 
+    def last_cold_table(self):
+        return 0
+
     def cache_stats(self):
         return 0, 0, 0
 

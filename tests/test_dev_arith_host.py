@@ -160,6 +160,29 @@ def test_signed_window_form_of_the_variable_base_multiplication(dev):
             assert a.raw == b.raw == R.pub_bytes(exp), hex(k)
 
 
+def test_window_table_in_lds_equals_the_private_segment_form(dev):
+    """round 5: ecmult_var_lds keeps the eight (x, y) pairs of the common-Z table in the workgroup's LDS (640 B per lane, β·X
+    multiplied at use, the build's Z's in registers) — same result as the private-segment form and the big-int reference on the
+    special scalars of the signed-window test and random ones; every lane writes its own column only (a 3-lane "workgroup")."""
+    rng = np.random.default_rng(29)
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    special = [0, 1, 2, 7, 8, 9, 15, 16, 17, 2**128 - 1, 2**128, 2**128 + 1, N - 1, N - 8, N - 9, lam, lam + 1, (8 * lam) % N, (lam * 15 + 8) % N,
+               int("8" * 32, 16), (int("8" * 32, 16) * lam + int("7" * 32, 16)) % N, (int("f" * 32, 16) * lam + int("f" * 32, 16)) % N]
+    ks = special + [int.from_bytes(rng.bytes(32), "big") % N for _ in range(60)]
+    pts = [R.G] + [R.pt_mul(int.from_bytes(rng.bytes(24), "big") + 1, R.G) for _ in range(4)]
+    for j, k in enumerate(ks):
+        pt = pts[j % len(pts)]
+        a, b = C.create_string_buffer(64), C.create_string_buffer(64)
+        guard = C.c_int(0)
+        oa = dev.dev_ecmult_var(b32(k), R.pub_bytes(pt), a)
+        ob = dev.dev_ecmult_var_lds(b32(k), R.pub_bytes(pt), b, j % 3, C.byref(guard))
+        exp = R.pt_mul(k, pt)
+        assert guard.value == 1, "a lane wrote outside its column"
+        assert bool(oa) == bool(ob) == (exp is not None), hex(k)
+        if exp is not None:
+            assert a.raw == b.raw == R.pub_bytes(exp), hex(k)
+
+
 def _point_add_cases():
     rng = np.random.default_rng(21)
     ks = [int.from_bytes(rng.bytes(32), "big") % N for _ in range(6)] + [1, 2, N - 1]

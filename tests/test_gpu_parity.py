@@ -84,6 +84,67 @@ def test_every_cold_variant_pinned(oracle, lanes, monkeypatch):
             bv.close()
 
 
+@pytest.mark.parametrize("lanes,table", [(1, "lds"), (1, "private"), (1, "private2"), (2, "lds"), (2, "private"), (4, "lds"), (4, "private")])
+def test_every_table_placement_of_the_lane_and_group_kernels(oracle, lanes, table, monkeypatch):
+    """round 5: IBFT_COLD_TABLE pins where the lane / group cold kernels keep the window table of u2·R — the workgroup's LDS
+    (default: no private segment), the private segment with the entries read in front of the doublings (round 4's form), or
+    without that prefetch (two resident wavefronts per SIMD: the lane kernel's form beyond 65 536 rows).  Same Byzantine round,
+    seals and senders, both low-s modes, every placement against the oracle; then the public recover vectors."""
+    import json
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    monkeypatch.setenv("IBFT_COLD_LANES", str(lanes))
+    monkeypatch.setenv("IBFT_COLD_TABLE", table)
+    r = W.make_round(500, 5100 + lanes, byzantine=True, weighted=True, with_envelopes=True)
+    vs = oracle.ValSet(r.addrs, r.power)
+    for flags in (0, V.FLAG_STRICT_LOW_S):
+        bv = V.BatchVerifier(flags=flags, max_rows=4096)
+        try:
+            bv.set_validators(1, r.addrs, r.power)
+            got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+            assert bv.last_dispatch() == (lanes, 0)
+            exp = oracle.verify_seals(vs, r.hash32, r.seal65, r.signer20, r.pre_flags, flags=flags).astype(bool)
+            assert (got == exp).all(), np.nonzero(got != exp)[0][:10]
+            te = oracle.tally(vs, r.signer20, exp.astype(np.uint8))
+            assert (t.power, t.has_quorum) == (te.power, te.has_quorum)
+            senders, _ = bv.is_valid_validator(r.payload, r.off, r.msg_sig65, r.signer20)
+            exp = oracle.verify_senders(vs, r.payload, r.off, r.msg_sig65, r.signer20, flags=flags).astype(bool)
+            assert (senders == exp).all()
+        finally:
+            bv.close()
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))["public_recover_vectors"]
+    addrs = np.array([np.frombuffer(bytes.fromhex(v["address"]), dtype=np.uint8) for v in k])
+    other = addrs.copy()
+    other[:, 19] ^= 1
+    h = np.array([np.frombuffer(bytes.fromhex(v["digest"]), dtype=np.uint8) for v in k] * 2)
+    s = np.array([np.frombuffer(bytes.fromhex(v["sig65"]), dtype=np.uint8) for v in k] * 2)
+    bv = V.BatchVerifier(max_rows=1024)
+    try:
+        bv.set_validators(1, np.concatenate([addrs, other]), np.ones(2 * len(k), dtype=np.uint64))
+        got, _ = bv.is_valid_committed_seal(h, s, np.concatenate([addrs, other]))
+        assert got.tolist() == [True] * len(k) + [False] * len(k)
+    finally:
+        bv.close()
+
+
+def test_lane_kernel_beyond_one_wavefront_per_simd_takes_the_two_resident_form(oracle):
+    """n > 65 536: the lane kernel with the table in the private segment and no prefetch (256 registers, two resident wavefronts
+    per SIMD) — verdicts at 70 000 rows with 20 % Byzantine seals against the oracle (16 host threads)"""
+    import go_ibft_amd.verifier as V
+    import go_ibft_amd.simulate as SIM
+    n = 70000
+    bv = V.BatchVerifier(max_rows=n)
+    try:
+        r = SIM.make_round(bv, n, 77, byzantine=True)
+        bv.set_validators(1, r.addrs, r.power)
+        got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
+        assert bv.last_dispatch() == (1, 0)
+        exp = oracle.verify_seals(oracle.ValSet(r.addrs, r.power), r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=16).astype(bool)
+        assert (got == exp).all() and (exp == r.expect).all()
+    finally:
+        bv.close()
+
+
 @pytest.mark.parametrize("n,expect_group", [(1, 128), (61, 128), (512, 128), (513, 64), (1500, 64), (3000, 16), (5000, 16), (8192, 16),
                                             (12000, 4), (20000, 2), (40000, 1)])
 def test_cold_group_sizes(oracle, n, expect_group):

@@ -7,6 +7,9 @@
 #   profile  python bench.py --profile (rocprofv3 sub-steps of the same run; the line and its counter files kept)
 #   forcedist IBFT_BENCH_FORCE_DIST=1 IBFT_BENCH_CONFIG5=1 bench (one-rank RCCL communicator)
 #   newtests  the GPU tests added this round
+#   tables   tools/table_ab.py (LDS / private-segment window tables)
+#   soak     tools/soak.py (10 300 Byzantine rounds against the oracle)
+#   stages   tools/rows_stages.py
 #   sizes    tools/profile_sizes.sh for 16384 65536 (stats + traffic + counters)
 set -u
 TAG=${1:-r05a}
@@ -59,6 +62,17 @@ fi
 if has newtests; then
   timeout 900 python -m pytest tests/test_gpu_stream.py tests/test_gpu_prepare_quorum.py tests/test_gpu_comm.py -m gpu -x -q > gpurun_out/profiles/${TAG}_pytest_new.log 2>&1
   echo "new tests rc=$?"; tail -3 gpurun_out/profiles/${TAG}_pytest_new.log
+fi
+if has tables; then
+  timeout 600 python tools/table_ab.py > gpurun_out/profiles/${TAG}_table_ab.txt 2> gpurun_out/${TAG}_table_ab.err; echo "table A/B rc=$?"
+  cat gpurun_out/profiles/${TAG}_table_ab.txt
+fi
+if has soak; then
+  timeout 1500 python tools/soak.py > gpurun_out/profiles/${TAG}_soak.json 2> gpurun_out/${TAG}_soak.err
+  echo "soak rc=$?"; tail -c 500 gpurun_out/profiles/${TAG}_soak.json; tail -2 gpurun_out/${TAG}_soak.err
+fi
+if has stages; then
+  timeout 300 python tools/rows_stages.py 4096 > gpurun_out/profiles/${TAG}_rows_stage_ms.txt 2>&1; echo "stages rc=$?"
 fi
 if has sizes; then
   timeout 1500 bash tools/profile_sizes.sh $TAG ${IBFT_PROF_SIZES:-16384 65536} > gpurun_out/${TAG}_profile_sizes.log 2>&1
