@@ -443,8 +443,11 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
                 bv.set_kernel_timing(1)
                 bv.last_kernel_ms()
                 t0 = time.perf_counter()
-                for _ in range(steps):
-                    bv.seals_run()
+                bv.seals_submit()                        # one pass kept in flight, as in the headline leg
+                for _ in range(steps - 1):
+                    bv.seals_submit()
+                    bv.seals_collect()
+                bv.seals_collect()
                 el = time.perf_counter() - t0
                 kms, kl = bv.last_kernel_ms()
                 cold_l, warm_l = bv.last_dispatch()
@@ -470,7 +473,7 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
         finally:
             bv.close()
     return {"steps_per_size": steps, "definition": "one resident COMMIT batch of N seals per step (recover/verify + tally, "
-            "results host-visible), inputs signed on the device; hbm_* = 118 B x N / verdict-kernel time (HIP events, every pass); "
+            "results host-visible, one pass kept in flight), inputs signed on the device; hbm_* = 118 B x N / verdict-kernel time (HIP events, every pass); "
             f"every entry behind >= {SWEEP_PREWARM_MIN_PASSES} untimed passes / {SWEEP_PREWARM_MIN_S} s (clock ramp)",
             "sizes": out}
 
@@ -631,7 +634,7 @@ def headline_record(rec: dict) -> dict:
                                "scaling", "vs_baseline", "dtype", "data") if k in rec}
     cfg = rec.get("config", {})
     out["config"] = {k: cfg[k] for k in ("workload", "validators", "rows_per_gpu", "path", "prewarm_steps", "kernel",
-                                         "parallelism", "numa_pin") if k in cfg}
+                                         "parallelism", "pipeline", "numa_pin") if k in cfg}
     for k in ("quorum_latency_ms_p50", "step_latency_ms_p50", "step_latency_ms_p50_incl_h2d", "rccl_nranks", "rccl_rank0_device"):
         if k in rec:
             out[k] = rec[k]
@@ -759,7 +762,7 @@ def main():
             # … and to /opt/rocm's librccl, BEFORE torch comes in: libtorch_hip needs "librccl.so.1" too, and whichever copy is
             # mapped first serves both (same SONAME) — torch's RCCL (built for ROCm 7.0) on the 7.2 HIP runtime fails in
             # ncclCommInitRank ("unhandled cuda error", profiles/r05c: the first forced-dist run of this order)
-            V.comm_unique_id()
+            V.comm_preload()
     dist = None
     if want_dist:
         import torch
@@ -811,8 +814,28 @@ def main():
             comm_init_or_die(bv, uid[0], rank, world)
             comm_info = bv.comm_info()   # what the communicator itself reports: (ranks, this rank, device)
 
-        def step():  # N = 1: one synchronous pass, results on the host when it returns
+        def step():  # one synchronous pass, results on the host when it returns (latency legs, warm-up)
             return bv.seals_run()
+
+        def run_pipelined(k_steps, lat_out=None):
+            """N = 1: k_steps passes with ONE kept in flight (ibft_seals_submit / ibft_seals_collect: two host-visible result
+            slots, the collect waits for the oldest pass only) — every pass's verdict words and tally are delivered to the host
+            and looked at; the launch of pass k+1 overlaps the completion and delivery of pass k, so the device runs back to
+            back.  The same depth-1 pipeline as the sharded form below (exchange k overlaps the kernels of pass k+1): `value` has
+            ONE definition at every N.  The synchronous round trip of a single pass is reported as step_latency_ms_p50."""
+            bv.seals_submit()
+            res, s0 = None, time.perf_counter()
+            for _ in range(k_steps - 1):
+                bv.seals_submit()
+                res = bv.seals_collect()
+                if lat_out is not None:
+                    s1 = time.perf_counter()
+                    lat_out.append(s1 - s0)
+                    s0 = s1
+            res = bv.seals_collect()
+            if lat_out is not None:
+                lat_out.append(time.perf_counter() - s0)
+            return res
 
         def run_sharded(k_steps):
             """the exchange of pass k (own stream, behind the tally) overlaps with the kernels of pass k+1; the
@@ -845,8 +868,8 @@ def main():
             # steps the caller asked for and are reported in the line (config.prewarm_steps).
             for _ in range(PREWARM_STEPS if (keep is not None or path == "warm") else 0):
                 step()
-            for _ in range(warmup):
-                step()
+            if warmup:
+                run_pipelined(warmup)
         else:
             run_sharded(PREWARM_STEPS)                        # (the same untimed passes in front of a sharded leg)
             if warmup:
@@ -857,10 +880,8 @@ def main():
         if dist is None:
             bv.set_kernel_timing(KERNEL_TIMING_EVERY)         # an event pair costs ≈5 µs of a step: sample the passes
             bv.last_kernel_ms()                               # reset: the HIP-event pairs of the timed passes accumulate
-            for _ in range(steps):
-                s0 = time.perf_counter()
-                out = step()
-                lat.append(time.perf_counter() - s0)
+            intervals = []
+            out = run_pipelined(steps, intervals)
         else:
             out = run_sharded(steps)
         fence()
@@ -878,6 +899,12 @@ def main():
                 bv.seals_launch(1)
                 bv.seals_exchange(n_total)
                 bv.seals_fetch_merged()
+                lat.append(time.perf_counter() - s0)
+        # the synchronous round trip of ONE pass (launch → verdict kernel → tally → results on the host), outside the timed region
+        if dist is None:
+            for _ in range(min(max(steps, 20), 100)):
+                s0 = time.perf_counter()
+                step()
                 lat.append(time.perf_counter() - s0)
         # quorum latency of this one call including the host→device copies
         lat_h2d = []
@@ -911,6 +938,7 @@ def main():
             bv.cache_stats()
             warm_lanes = bv.lanes_per_signature
         res = {"n_total": n_total, "rows": rows, "elapsed": elapsed, "steps": steps, "lat": lat, "lat_h2d": lat_h2d,
+               "intervals": intervals if dist is None else [],
                "rccl": comm_info,
                "kernel_ms": kernel_ms, "kernel_launches": kernel_launches,
                "kname": kernel_name(path, cold_lanes, warm_lanes, bv.last_cold_table()),
@@ -955,6 +983,8 @@ def main():
             "config": {"workload": workload, "validators": n_total, "rows_per_gpu": rows, "path": args.path,
                        "prewarm_steps": PREWARM_STEPS if (carry is not None or world > 1 or dist is not None) else 0,
                        "kernel": m["kname"], "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU",
+                       "pipeline": "one pass kept in flight, every pass's results delivered to the host (N = 1: ibft_seals_submit / "
+                                   "_collect; N > 1: exchange k overlaps the kernels of pass k+1); step_latency_ms_p50 = one synchronous pass",
                        "numa_pin": numa_pin},
             "step_latency_ms_p50": float(np.median(m["lat"]) * 1e3),
             "step_latency_ms_p50_incl_h2d": float(np.median(m["lat_h2d"]) * 1e3) if m["lat_h2d"] else None,
@@ -990,6 +1020,8 @@ def main():
                                "ms_per_step": L["elapsed"] / L["steps"] * 1e3, "avg_kernel_ms": lk * 1e3,
                                "kernel_samples": L["kernel_launches"],
                                "hbm_frac": rows * ALGO_BYTES_PER_VERIFY / lk / 1e9 / HBM_PEAK_GBS,
+                               "step_interval_ms_p10_p50_p90": ([float(x) for x in np.percentile(np.array(L["intervals"]) * 1e3, [10, 50, 90])]
+                                                                if L["intervals"] else None),
                                "step_latency_ms_p10_p50_p90": [float(x) for x in np.percentile(np.array(L["lat"]) * 1e3, [10, 50, 90])]}
 
     if DRY_RUN:   # the extra legs all need the device

@@ -99,6 +99,11 @@ struct ibft_ctx {
   hipEvent_t ev_staged = nullptr, ev_cols_read = nullptr;  // the copy into the spare slot is done / the spare slot's last reader is
   uint32_t next_n = 0;
   bool next_pre = false, next_valid = false;
+  // pipelined passes (ibft_seals_submit / ibft_seals_collect): two host-visible result slots, an event behind each pass's tally
+  uint64_t *p_mask[2] = {nullptr, nullptr}, *p_tally[2] = {nullptr, nullptr}, *dp_mask[2] = {nullptr, nullptr}, *dp_tally[2] = {nullptr, nullptr};
+  hipEvent_t ev_pass[2] = {nullptr, nullptr};
+  uint32_t pass_issued = 0, pass_collected = 0, pass_n[2] = {0, 0};
+  int tally_slot = -1;      // ≥ 0: the next tally delivers into pipeline slot `tally_slot` instead of h_mask / h_tally
   uint32_t launched_n = 0;  // rows of the last ibft_seals_launch: what ibft_seals_fetch delivers (a swap may have changed staged_n since)
   DevBuf d_mask, d_vidx, d_tally, d_H;
   DevBuf d_mask_out;        // verdict words after the tally consumed d_mask (what fetch / export read)
@@ -551,8 +556,8 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
   t.acc = (uint64_t *)c->d_acc.p;
   t.quorum = (const uint64_t *)c->d_quorum.p;
   t.out = (uint64_t *)c->d_tally.p;
-  t.host_mask = c->dh_mask;
-  t.host_tally = c->dh_tally;
+  t.host_mask = c->tally_slot >= 0 ? c->dp_mask[c->tally_slot] : c->dh_mask;
+  t.host_tally = c->tally_slot >= 0 ? c->dp_tally[c->tally_slot] : c->dh_tally;
   t.set_on = set ? 1u : 0u;
   if (set) t.set = *set;
   // HasPrepareQuorum: on one device the proposer's seat joins the bitmap here; a rank of a sharded batch only counts the
@@ -593,7 +598,7 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
       hipLaunchKernelGGL((ibftk::tally_kernel<4, true>), grid, block, dyn, c->stream, t);
   }
   HIPCHK(c, hipGetLastError());
-  c->host_direct = c->dh_mask != nullptr;  // results of THIS tally are on their way to h_mask / h_tally
+  c->host_direct = c->dh_mask != nullptr && c->tally_slot < 0;  // results of THIS tally are on their way to h_mask / h_tally
   if ((uint32_t)mask_words(n) >= c->mask_dirty_words) c->mask_dirty_words = 0;  // ... and it zeroed every word that held bits
   return IBFT_OK;
 }
@@ -1413,6 +1418,11 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   comm_release(c);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_read) (void)hipEventDestroy(c->ev_read);
+  for (int i = 0; i < 2; i++) {
+    if (c->p_mask[i]) (void)hipHostFree(c->p_mask[i]);
+    if (c->p_tally[i]) (void)hipHostFree(c->p_tally[i]);
+    if (c->ev_pass[i]) (void)hipEventDestroy(c->ev_pass[i]);
+  }
   if (c->h_mask) (void)hipHostFree(c->h_mask);
   if (c->h_tally) (void)hipHostFree(c->h_tally);
   if (c->h_digest) (void)hipHostFree(c->h_digest);
@@ -1877,6 +1887,83 @@ static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
     const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
     if ((rc = enqueue_recover(c, c->staged_n, c->staged_pre, 0, time_it))) return rc;
     if ((rc = enqueue_tally(c, c->staged_n))) return rc;
+  }
+  return IBFT_OK;
+}
+
+// Pipelined passes over the resident batch: submit enqueues one pass whose results go to one of two host-visible slots,
+// collect waits for the OLDEST submitted pass only (the event behind its tally, not the stream).
+int ibft_seals_submit(ibft_ctx *c) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (!c->have_valset) return IBFT_E_NOVALSET;
+  if (c->pass_issued - c->pass_collected >= 2) {
+    c->last_error = "two passes already in flight: call ibft_seals_collect first";
+    return IBFT_E_INVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t s = c->pass_issued & 1u;
+  if (!c->p_mask[s]) {  // mapped result slots (the tally kernel writes them itself) and the pass events, on first use
+    for (int i = 0; i < 2; i++) {
+      if (hipHostMalloc((void **)&c->p_mask[i], (size_t)mask_words(std::max<size_t>(c->max_rows, c->row_cap)) * 8 + 64) != hipSuccess ||
+          hipHostMalloc((void **)&c->p_tally[i], 128) != hipSuccess)
+        return IBFT_E_NOMEM;
+      void *dm = nullptr, *dt = nullptr;
+      if (hipHostGetDevicePointer(&dm, c->p_mask[i], 0) != hipSuccess || hipHostGetDevicePointer(&dt, c->p_tally[i], 0) != hipSuccess)
+        return IBFT_E_HIP;
+      c->dp_mask[i] = (uint64_t *)dm;
+      c->dp_tally[i] = (uint64_t *)dt;
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_pass[i], hipEventDisableTiming));
+    }
+  }
+  if (c->ev_used >= 4096) c->ev_used = 0;
+  const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
+  int rc;
+  if ((rc = enqueue_recover(c, c->staged_n, c->staged_pre, 0, time_it))) return rc;
+  c->tally_slot = (int)s;
+  rc = enqueue_tally(c, c->staged_n);
+  c->tally_slot = -1;
+  if (rc) return rc;
+  HIPCHK(c, hipEventRecord(c->ev_pass[s], c->stream));
+  c->pass_n[s] = c->staged_n;
+  c->pass_issued++;
+  return IBFT_OK;
+}
+
+int ibft_seals_collect(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->pass_collected == c->pass_issued) {
+    c->last_error = "ibft_seals_collect without a submitted pass";
+    return IBFT_E_INVAL;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t s = c->pass_collected & 1u;
+  HIPCHK(c, hipEventSynchronize(c->ev_pass[s]));
+  c->pass_collected++;
+  const uint64_t *hm = c->p_mask[s], *ht = c->p_tally[s];
+  if (c->cache_on) {  // keys this pass taught the device (passed on by its tally kernel) → tables
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(ht + 4);
+    int rcb = build_new_tables(c, lw[0], lw[1]);
+    if (rcb) return rcb;
+  }
+  const uint32_t n = c->pass_n[s];
+  const size_t mw = (size_t)mask_words(n);
+  if (out_mask && mw) {
+    memcpy(out_mask, hm, mw * 8);
+    if (n & 63) out_mask[mw - 1] &= (~0ull) >> (64 - (n & 63));
+  }
+  for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) c->last_wide[i] = ht[ibftk::TALLY_OUT_WIDE + i];
+  if (tally) {
+    memset(tally, 0, sizeof *tally);
+    tally->quorum_lo = c->quorum_w[0];
+    tally->quorum_hi = c->quorum_w[1];
+    tally->power_lo = ht[0];
+    tally->power_hi = ht[1];
+    tally->valid_rows = (uint32_t)(ht[2] & 0xFFFFFFFFull);
+    tally->distinct_senders = (uint32_t)(ht[2] >> 32);
+    tally->has_quorum = (uint32_t)ht[3];
+    tally->proposer_rows = (uint32_t)ht[ibftk::TALLY_OUT_PROPOSER_ROWS];
   }
   return IBFT_OK;
 }
@@ -2648,6 +2735,8 @@ int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t n_validators
   if (slots) *slots = exchange_slots(n_masks, (uint32_t)w, world, n_validators);
   return IBFT_OK;
 }
+
+int ibft_comm_preload(void) { return rccl() ? IBFT_OK : IBFT_E_RCCL; }
 
 int ibft_comm_unique_id(uint8_t id[IBFT_COMM_ID_BYTES]) {
   static_assert(IBFT_COMM_ID_BYTES == sizeof(ncclUniqueId), "ABI");

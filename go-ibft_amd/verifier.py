@@ -40,7 +40,8 @@ EXPORTS = [
     "ibft_group_is_local", "ibft_sign_seals", "ibft_verify_messages", "ibft_pinned_alloc", "ibft_pinned_free", "ibft_column_stats",
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
     "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info", "ibft_set_seal_digest", "ibft_group_set_seal_digest",
-    "ibft_seals_stage_next", "ibft_seals_swap", "ibft_last_cold_table",
+    "ibft_seals_stage_next", "ibft_seals_swap", "ibft_last_cold_table", "ibft_seals_submit", "ibft_seals_collect",
+    "ibft_comm_preload",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -144,6 +145,8 @@ def load_library() -> C.CDLL:
     L.ibft_seals_stage_next.argtypes = [vp, vp, vp, vp, vp, C.c_size_t]
     L.ibft_seals_swap.argtypes = [vp, C.c_int]
     L.ibft_last_cold_table.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.ibft_seals_submit.argtypes = [vp]
+    L.ibft_seals_collect.argtypes = [vp, vp, C.POINTER(Tally)]
     L.ibft_sign_seals.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.ibft_verify_messages_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_uint64, C.c_uint64, vp, C.c_size_t, C.c_uint64, vp, vp, vp, vp, vp,
                                             vp, C.POINTER(Tally)]
@@ -260,6 +263,13 @@ def keccak256(a: bytes, b: bytes = b"") -> bytes:
     if rc:
         raise ValueError(f"ibft_keccak256: {rc}")
     return out.raw
+
+
+def comm_preload() -> None:
+    """ibft_comm_preload: map librccl now (before anything else in the process maps another copy under the same SONAME)"""
+    rc = load_library().ibft_comm_preload()
+    if rc != 0:
+        raise GpuUnavailable(f"ibft_comm_preload: {load_library().ibft_strerror(rc).decode()} ({rc})")
 
 
 def comm_unique_id() -> bytes:
@@ -555,6 +565,20 @@ class BatchVerifier:
         self._chk(self._L.ibft_seals_swap(self._h, 1 if wait_for_copy else 0), "ibft_seals_swap")
         self._staged = len(self._next_cols[1])
         self._held_cols, self._next_cols = self._next_cols, None   # (with wait_for_copy=0 the copy may still read them)
+
+    def seals_submit(self) -> None:
+        """one more pass over the resident batch, asynchronously (at most two in flight); results through seals_collect"""
+        self._chk(self._L.ibft_seals_submit(self._h), "ibft_seals_submit")
+        self._submitted = getattr(self, "_submitted", []) + [self._staged]
+
+    def seals_collect(self):
+        """the OLDEST submitted pass → (verdict bool[n], Tally); waits for that pass only"""
+        n = self._submitted[0] if getattr(self, "_submitted", None) else 0
+        mask = np.zeros((n + 63) // 64 or 1, dtype=np.uint64)
+        t = Tally()
+        self._chk(self._L.ibft_seals_collect(self._h, _p(mask), C.byref(t)), "ibft_seals_collect")
+        self._submitted.pop(0)
+        return mask_to_bool(mask, n), t
 
     def seals_launch(self, repeat: int = 1) -> None:
         self._chk(self._L.ibft_seals_launch(self._h, repeat), "ibft_seals_launch")

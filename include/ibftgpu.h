@@ -307,6 +307,16 @@ int ibft_seals_run(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
  *       becomes the spare slot; kernels already enqueued keep reading the columns they were launched on, the ones
  *       enqueued afterwards wait ON THE DEVICE for the copy.  IBFT_E_INVAL without a staged batch.
  * Per step of a sustained stream:  launch(k) → stage_next(k+1) → fetch(k) → swap.                                   */
+/* Pipelined passes (round 5): ibft_seals_submit enqueues ONE pass over the resident batch (verdict kernel + tally) whose
+ * results go to one of two host-visible result slots, and returns at once; ibft_seals_collect waits for the OLDEST
+ * submitted pass — the event behind its tally, not the whole stream — and delivers its verdict words and tally.  At most
+ * two passes in flight (IBFT_E_INVAL beyond; IBFT_E_INVAL on a collect with nothing submitted).  With one pass kept in
+ * flight the launch of pass k+1 overlaps the completion, result delivery and host handling of pass k: the device runs
+ * back to back, as a node's does when batches arrive faster than one host round trip (and as a rank's does in the
+ * sharded form, where exchange k overlaps the kernels of pass k+1).  Combines with the staging slots:
+ * submit(k) → stage_next(k+1) → collect(k−1) → swap.                                                                  */
+int ibft_seals_submit(ibft_ctx *ctx);
+int ibft_seals_collect(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
 int ibft_seals_stage_next(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
                           const uint8_t *signer20, const uint8_t *pre_flags, size_t n);
 int ibft_seals_swap(ibft_ctx *ctx, int wait_for_copy);
@@ -546,6 +556,10 @@ int ibft_shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t *
  * n_masks = K above.  Any out pointer may be NULL.                                                        */
 int ibft_exchange_layout(uint64_t n_total, uint32_t world, uint32_t n_validators, uint32_t n_masks,
                          uint32_t *words_per_rank, uint32_t *seen_words, uint32_t *slots);
+/* Load librccl now (IBFT_RCCL_LIB, librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1 — first that opens) instead of at the
+ * first ibft_comm_* call: a process that will ALSO load another copy of RCCL under the same SONAME (importing torch does)
+ * calls this first, so that the library and the HIP runtime it was built for stay a pair.  IBFT_E_RCCL if none opens.     */
+int ibft_comm_preload(void);
 int ibft_comm_unique_id(uint8_t id[IBFT_COMM_ID_BYTES]);
 int ibft_comm_init(ibft_ctx *ctx, const uint8_t id[IBFT_COMM_ID_BYTES], uint32_t rank, uint32_t world);
 int ibft_comm_destroy(ibft_ctx *ctx);

@@ -370,6 +370,19 @@ func (c *Ctx) SealsStageNext(hash32, sig65, signer20, preFlags []byte) error {
 	return c.check(C.ibft_seals_stage_next(c.h, ptr8(hash32), ptr8(sig65), ptr8(signer20), ptr8(preFlags), C.size_t(n)))
 }
 
+// SealsSubmit enqueues one more pass over the resident seal batch and returns at once (at most two in flight);
+// SealsCollect waits for the OLDEST submitted pass only and returns its verdict words and tally.  Keeping one pass in flight
+// lets the device run back to back while Go handles the previous pass's result (ibft_seals_submit / ibft_seals_collect).
+func (c *Ctx) SealsSubmit() error { return c.check(C.ibft_seals_submit(c.h)) }
+
+// SealsCollect: see SealsSubmit.  n = rows of the batch that pass ran over.
+func (c *Ctx) SealsCollect(n int) ([]uint64, Tally, error) {
+	mask := make([]uint64, (n+63)/64+1)
+	var t C.ibft_tally_t
+	rc := C.ibft_seals_collect(c.h, (*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
+	return mask, tally(t), c.check(rc)
+}
+
 // SealsSwap: see SealsStageNext.
 func (c *Ctx) SealsSwap() error { return c.check(C.ibft_seals_swap(c.h, 1)) }
 

@@ -75,6 +75,14 @@ class BatchVerifier:
         self.seals_launch()
         return self.seals_fetch()
 
+    def seals_submit(self):
+        self.seals_launch()
+        self._inflight = getattr(self, "_inflight", []) + [(self._verdict.copy(), self._t)]
+        assert len(self._inflight) <= 2
+
+    def seals_collect(self):
+        return self._inflight.pop(0)
+
     def is_valid_committed_seal(self, hash32, seal65, signer20, pre=None):
         self.seals_stage(hash32, seal65, signer20, pre)
         return self.seals_run()

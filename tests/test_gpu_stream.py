@@ -81,3 +81,54 @@ def test_a_kernel_enqueued_before_the_swap_keeps_its_columns_and_the_swap_needs_
             bv.seals_swap()
     finally:
         bv.close()
+
+
+def test_pipelined_passes_deliver_every_pass_in_order_through_two_result_slots(oracle):
+    """ibft_seals_submit / ibft_seals_collect: one pass kept in flight, every collect returns the OLDEST pass — over batches that
+    change under the pipeline (stage_next / swap between submits) every pass's verdict words and tally are those of the batch it
+    ran over; three submits are refused, a collect with nothing submitted too."""
+    import go_ibft_amd.verifier as V
+    r, batches = _batches(4096)
+    host = [tuple(None if a is None else V.pinned_copy(a) for a in b[:4]) for b in batches]
+    bv = V.BatchVerifier(max_rows=4096)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        with pytest.raises(RuntimeError):
+            bv.seals_collect()
+        order = [0, 1, 2, 4, 3, 0, 2, 2, 1, 4]
+        bv.seals_stage(*host[order[0]])
+        expected = []
+        for i, cur in enumerate(order):
+            bv.seals_submit()                                  # pass over batch `cur`
+            expected.append(cur)
+            if i + 1 < len(order):
+                bv.seals_stage_next(*host[order[i + 1]])
+            if len(expected) == 2:
+                with pytest.raises(RuntimeError):
+                    bv.seals_submit()                          # a third pass in flight is refused
+                verdict, t = bv.seals_collect()
+                want, wt = batches[expected.pop(0)][4:6]
+                assert len(verdict) == len(want) and (verdict == want).all(), i
+                assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == (wt.power, wt.valid_rows, wt.distinct_senders, wt.has_quorum)
+            if i + 1 < len(order):
+                bv.seals_swap()
+        verdict, t = bv.seals_collect()
+        want, wt = batches[expected.pop(0)][4:6]
+        assert (verdict == want).all() and t.power == wt.power
+        # the synchronous calls still work next to the pipeline, warm path included
+        verdict, t = bv.seals_run()
+        assert (verdict == batches[order[-1]][4]).all()
+    finally:
+        bv.close()
+    wv = V.BatchVerifier(max_rows=4096, flags=V.FLAG_PUBKEY_CACHE)
+    try:
+        wv.set_validators(r.height, r.addrs, r.power)
+        wv.seals_stage(*[x for x in batches[0][:4]])
+        for _ in range(3):                                     # learn, build, warm — through the pipeline
+            wv.seals_submit(); wv.seals_submit()
+            for _ in range(2):
+                verdict, t = wv.seals_collect()
+                assert (verdict == batches[0][4]).all() and t.power == batches[0][5].power
+        assert wv.cache_stats()[0] > 0
+    finally:
+        wv.close()
