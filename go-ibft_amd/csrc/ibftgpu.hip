@@ -1903,18 +1903,21 @@ int ibft_seals_submit(ibft_ctx *c) {
   }
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t s = c->pass_issued & 1u;
-  if (!c->p_mask[s]) {  // mapped result slots (the tally kernel writes them itself) and the pass events, on first use
-    for (int i = 0; i < 2; i++) {
-      if (hipHostMalloc((void **)&c->p_mask[i], (size_t)mask_words(std::max<size_t>(c->max_rows, c->row_cap)) * 8 + 64) != hipSuccess ||
-          hipHostMalloc((void **)&c->p_tally[i], 128) != hipSuccess)
-        return IBFT_E_NOMEM;
+  // mapped result slots (the tally kernel writes them itself) and the pass events, on first use — piece by piece, so that a
+  // failure half way leaves nothing to leak and nothing half set up for the next call
+  for (int i = 0; i < 2; i++) {
+    if (!c->p_mask[i] &&
+        hipHostMalloc((void **)&c->p_mask[i], (size_t)mask_words(std::max<size_t>(c->max_rows, c->row_cap)) * 8 + 64) != hipSuccess)
+      return IBFT_E_NOMEM;
+    if (!c->p_tally[i] && hipHostMalloc((void **)&c->p_tally[i], 128) != hipSuccess) return IBFT_E_NOMEM;
+    if (!c->dp_mask[i] || !c->dp_tally[i]) {
       void *dm = nullptr, *dt = nullptr;
       if (hipHostGetDevicePointer(&dm, c->p_mask[i], 0) != hipSuccess || hipHostGetDevicePointer(&dt, c->p_tally[i], 0) != hipSuccess)
         return IBFT_E_HIP;
       c->dp_mask[i] = (uint64_t *)dm;
       c->dp_tally[i] = (uint64_t *)dt;
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_pass[i], hipEventDisableTiming));
     }
+    if (!c->ev_pass[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_pass[i], hipEventDisableTiming));
   }
   if (c->ev_used >= 4096) c->ev_used = 0;
   const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
@@ -1926,6 +1929,7 @@ int ibft_seals_submit(ibft_ctx *c) {
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev_pass[s], c->stream));
   c->pass_n[s] = c->staged_n;
+  c->launched_n = c->staged_n;  // (an ibft_seals_fetch behind a submit delivers this pass through the copy route)
   c->pass_issued++;
   return IBFT_OK;
 }
