@@ -66,10 +66,10 @@ DRY_RUN = os.environ.get("IBFT_BENCH_DRYRUN") == "1"
 COMM_INIT_TIMEOUT_S = 180   # ncclCommInitRank blocks until every rank has joined: a rank that never arrives must not hang the job
 
 
-def bv_module_round(n_total: int):
+def bv_module_round(n_total: int, byzantine: bool = False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import bench_stub
-    return bench_stub.make_round(n_total)
+    return bench_stub.make_round(n_total, byzantine)
 
 
 def comm_init_or_die(bv, uid, rank: int, world: int) -> None:
@@ -112,10 +112,10 @@ def load_round(bv, n_total: int, lo: int, hi: int, byzantine: bool = False):
     a 65 536-validator round in milliseconds — no rank signs with host code at bench time, nothing of the oracle is on the
     path).  Rows [lo, hi) are this rank's shard."""
     if DRY_RUN:
-        r = bv_module_round(n_total)
+        r = bv_module_round(n_total, byzantine)
         return {"addrs": r.addrs, "power": r.power, "hash32": r.hash32[lo:hi], "seal65": r.seal65[lo:hi],
-                "signer20": r.signer20[lo:hi], "pre": None, "src": "DRY RUN: unsigned rows, stub verifier", "fx": None,
-                "expect": None}
+                "signer20": r.signer20[lo:hi], "pre": r.pre_flags[lo:hi] if byzantine else None,
+                "src": "DRY RUN: unsigned rows, stub verifier", "fx": None, "expect": r.expect[lo:hi]}
     if n_total == 4096 and not byzantine and os.path.exists(FIXTURE):
         with np.load(FIXTURE) as z:
             g = {k: z[k] for k in z.files}   # materialised once: an NpzFile re-reads the archive on every g[k]
@@ -915,7 +915,9 @@ def main():
                 lat_h2d.append(time.perf_counter() - s0)
         # correctness of what was timed (outside the timed region)
         expect = None
-        if byzantine:
+        if byzantine and DRY_RUN:
+            expect = rd["expect"]                      # (the stub's decree: rows without a pre-flag are "valid")
+        elif byzantine:
             from oracle import binding as B
             expect = B.verify_seals(B.ValSet(addrs, power), rd["hash32"], rd["seal65"], rd["signer20"], rd["pre"],
                                     nthreads=usable_cores()).astype(bool)

@@ -30,14 +30,16 @@ def bool_to_mask(v: np.ndarray) -> np.ndarray:
     return np.packbits(bits, bitorder="little").view(np.uint64)
 
 
-def make_round(n_total: int):
-    """n_total validators with distinct addresses and power 1, one (unsigned) row each"""
+def make_round(n_total: int, byzantine: bool = False):
+    """n_total validators with distinct addresses and power 1, one (unsigned) row each; byzantine: every fifth row carries a
+    pre-flag (the stub's stand-in for a bad seal)"""
     idx = np.arange(n_total, dtype=np.uint64)
     addrs = np.zeros((n_total, 20), dtype=np.uint8)
     addrs[:, :8] = idx.view(np.uint8).reshape(-1, 8)
+    pre = ((idx % 5) == 0).astype(np.uint8) if byzantine else np.zeros(n_total, np.uint8)
     return SimpleNamespace(addrs=addrs, power=np.ones(n_total, dtype=np.uint64), hash32=np.zeros((n_total, 32), np.uint8),
                            seal65=np.zeros((n_total, 65), np.uint8), signer20=addrs.copy(),
-                           pre_flags=np.zeros(n_total, np.uint8), expect=np.ones(n_total, bool))
+                           pre_flags=pre, expect=pre == 0)
 
 
 class BatchVerifier:

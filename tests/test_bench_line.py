@@ -85,7 +85,7 @@ def test_dry_run_one_rank_prints_detail_then_headline():
     assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_dry_run_gpus_n_relaunches_shards_exchanges_and_merges(world):
     """`python bench.py --gpus N` from a bare shell → N ranks under torch.distributed.run; every rank verifies its 64-aligned
     shard, the exchange buffer of go_ibft_amd/shard.py crosses a real (gloo) all-reduce, rank 0 prints the merged line"""
@@ -99,5 +99,8 @@ def test_dry_run_gpus_n_relaunches_shards_exchanges_and_merges(world):
     assert rec["config"]["parallelism"] == f"rows sharded x{world}"
     if world == 4:
         assert "BASELINE config #4" in rec["config"]["workload"]
+    if world == 8:                                  # the driver's largest run also carries BASELINE config #5 (8 x 8 192 rows, 20 % bad)
+        c5 = rec["config5"]
+        assert (c5["validators"], c5["rows_per_gpu"], c5["rccl_nranks"]) == (65536, 8192, 8) and 0.79 < c5["valid_fraction"] < 0.81
     # value = rows of ALL ranks per second of the slowest rank
     assert rec["value"] == pytest.approx(4096 * world * 5 / (rec["ms_per_step"] * 5e-3), rel=1e-3)
