@@ -467,6 +467,12 @@ template <int MODE, int G>
 __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) {
   constexpr int ROWS = 64 / G;                    // signatures per wavefront
   constexpr int POINTS = QTAB_WINDOWS + GTAB_WINDOWS;
+  // Round 5: the kernel's CODE has to fit the 64 KB instruction cache — on one lease in four a fetch past it costs 65 % more
+  // and a 60 KB kernel ran 0.132 instead of 0.110 ms.  Both point additions inlined (11 + 16 multiplications
+  // of 224 instructions) made 60.5 KB; only the one that dominates a lane's work is pasted now — the butterfly for G ≥ 16 (4–5
+  // folds of 16 multiplications against 2–3 mixed additions of 11), the mixed addition for G ≤ 8 — and the other one calls the
+  // outlined multiply (≈ 25 instructions per call: +2 % of this kernel's instructions).
+  constexpr bool INL_FOLD = G >= 16, INL_MADD = !INL_FOLD;
   const uint32_t lane = threadIdx.x;
   const uint32_t sub = lane % G;
   const uint32_t row_raw = blockIdx.x * ROWS + lane / G;
@@ -531,13 +537,13 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
       entry = a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt);
     }
     aff pt = load_affine(entry);
-    jac sum = secp::jac_add_aff_t<true>(acc, pt);  // (the one inlined copy of the mixed addition: secp256k1_dev.h)
+    jac sum = secp::jac_add_aff_t<INL_MADD>(acc, pt);  // (the one inlined copy of the mixed addition: secp256k1_dev.h)
     acc = secp::jac_select(has && dgt != 0, sum, acc);
   }
 #pragma unroll 1
   for (int off = G / 2; off >= 1; off >>= 1) {
     jac other = shfl_xor_jac(acc, off);
-    acc = secp::jac_add_t<true>(acc, other);  // (one inlined copy in the rolled butterfly)
+    acc = secp::jac_add_t<INL_FOLD>(acc, other);  // (one inlined copy in the rolled butterfly)
   }
   if (ROW_INV) {
     // The butterfly left the SUM in every lane of the group, but not one REPRESENTATION of it: P + Q and Q + P come out
