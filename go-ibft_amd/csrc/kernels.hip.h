@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
   y = secp::fe_normalize(y);
   y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
   // u1 = −z/r, u2 = s/r, u2 = k1 + k2·λ
-  secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));
+  secp::sc rinv = secp::sc_from_u256(secp::modinv_shared<secp::ModN>(r));
   u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z), rinv)));
   u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   secp::glv_split sp = secp::sc_split_lambda(u2);

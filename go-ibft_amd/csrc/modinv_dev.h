@@ -304,6 +304,110 @@ HD u256 modinv(const u256 &x) {
   return s30_to_u256(d);
 }
 
+// ---- ONE copy for both moduli (round 5) --------------------------------------------------------------------------------
+// A lane-layout kernel inverts twice per signature — s or r mod n at the start, Z mod p at the end — and the two template
+// instances above are two pasted copies of ≈ 1 050 instructions (6.6 KB each).  On one lease in four an instruction fetch
+// past the 64 KB instruction cache costs 65 % more, so kernel CODE is a resource: here the modulus is a
+// (wave-uniform) run-time value and the device build calls ONE outlined copy.  Same algorithm, same batches, same results
+// (tests/test_dev_arith_host.py checks it against the template form and big ints).
+struct mod_rt {
+  int32_t m[9];
+  uint32_t inv30;
+};
+HD mod_rt mod_rt_select(bool is_p) {
+  mod_rt r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.m[i] = is_p ? ModP::limb(i) : ModN::limb(i);
+  r.inv30 = is_p ? ModP::inv30() : ModN::inv30();
+  return r;
+}
+HD void update_de_30_rt(s30 &d, s30 &e, const trans2x2 &t, const mod_rt &M) {
+  const int64_t u = t.u, v = t.v, q = t.q, r = t.r;
+  const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+  int32_t md = (t.u & sd) + (t.v & se);
+  int32_t me = (t.q & sd) + (t.r & se);
+  int64_t cd = u * d.v[0] + v * e.v[0];
+  int64_t ce = q * d.v[0] + r * e.v[0];
+  md -= (int32_t)((M.inv30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+  me -= (int32_t)((M.inv30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+  cd += (int64_t)M.m[0] * md;
+  ce += (int64_t)M.m[0] * me;
+  cd >>= 30;
+  ce >>= 30;
+#pragma unroll
+  for (int i = 1; i < 9; i++) {
+    cd += u * d.v[i] + v * e.v[i] + (int64_t)M.m[i] * md;
+    ce += q * d.v[i] + r * e.v[i] + (int64_t)M.m[i] * me;
+    d.v[i - 1] = (int32_t)cd & M30;
+    e.v[i - 1] = (int32_t)ce & M30;
+    cd >>= 30;
+    ce >>= 30;
+  }
+  d.v[8] = (int32_t)cd;
+  e.v[8] = (int32_t)ce;
+}
+HD void normalize_30_rt(s30 &r, bool neg, const mod_rt &M) {
+  int32_t add = r.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] += M.m[i] & add;
+  int32_t nm = neg ? -1 : 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = (r.v[i] ^ nm) - nm;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.v[i + 1] += r.v[i] >> 30;
+    r.v[i] &= M30;
+  }
+  add = r.v[8] >> 31;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] += M.m[i] & add;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.v[i + 1] += r.v[i] >> 30;
+    r.v[i] &= M30;
+  }
+}
+HD u256 modinv_rt(const u256 &x, bool is_p) {
+  const mod_rt M = mod_rt_select(is_p);
+  s30 d, e, f, g = s30_from_u256(x);
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    d.v[i] = 0;
+    e.v[i] = 0;
+    f.v[i] = M.m[i];
+  }
+  e.v[0] = 1;
+  int32_t zeta = -1;
+  for (int b = 0; b < 20; b++) {
+    trans2x2 t;
+    zeta = divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+    update_de_30_rt(d, e, t, M);
+    update_fg_30(f, g, t);
+  }
+  normalize_30_rt(d, f.v[8] < 0, M);
+  return s30_to_u256(d);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __attribute__((noinline)) u256 modinv_rt_fn(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4,
+                                                             uint32_t x5, uint32_t x6, uint32_t x7, uint32_t is_p) {
+  u256 x;
+  x.v[0] = x0; x.v[1] = x1; x.v[2] = x2; x.v[3] = x3; x.v[4] = x4; x.v[5] = x5; x.v[6] = x6; x.v[7] = x7;
+  return modinv_rt(x, is_p != 0);
+}
+#endif
+template <class MOD> struct mod_is_p;
+template <> struct mod_is_p<ModP> { static constexpr uint32_t value = 1; };
+template <> struct mod_is_p<ModN> { static constexpr uint32_t value = 0; };
+// x⁻¹ mod M through the shared copy (device) / the run-time form pasted in (host tests)
+template <class MOD>
+HD u256 modinv_shared(const u256 &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return modinv_rt_fn(x.v[0], x.v[1], x.v[2], x.v[3], x.v[4], x.v[5], x.v[6], x.v[7], mod_is_p<MOD>::value);
+#else
+  return modinv_rt(x, mod_is_p<MOD>::value != 0);
+#endif
+}
+
 // ---- variable-time divsteps ----------------------------------------------------------------------------
 // Same 30 divsteps, but runs of even g are stripped with one count-trailing-zeros.  Control flow
 // depends on the data, so this is for code where a whole wavefront works on ONE value
@@ -346,9 +450,9 @@ HD int32_t divsteps_30_var(int32_t zeta, uint32_t f0, uint32_t g0, trans2x2 &t) 
   return zeta;
 }
 HD fe fe_inv_safegcd(const fe &a) {  // a of magnitude ≤ 32
-  return fe_from_u256(modinv<ModP>(fe_to_u256(a)));
+  return fe_from_u256(modinv_shared<ModP>(fe_to_u256(a)));
 }
-HD sc sc_inv_safegcd(const sc &a) { return sc_from_u256(modinv<ModN>(sc_canon(a))); }
+HD sc sc_inv_safegcd(const sc &a) { return sc_from_u256(modinv_shared<ModN>(sc_canon(a))); }
 
 // Jacobian → affine with the safegcd inverse; r.x / r.y canonical; false for infinity
 HD bool jac_to_aff_fast(aff &r, const jac &p) {

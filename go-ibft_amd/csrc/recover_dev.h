@@ -383,7 +383,7 @@ __host__ __device__ __forceinline__ bool recover_pubkey_with(const uint32_t *__r
   R.x = rx;
   R.y = y;
   // u1 = -z/r, u2 = s/r (mod n)
-  secp::sc rinv = secp::sc_from_u256(secp::modinv<secp::ModN>(r));  // r is canonical, in [1, n)
+  secp::sc rinv = secp::sc_from_u256(secp::modinv_shared<secp::ModN>(r));  // r is canonical, in [1, n)
   u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   jac Q = var_mult(R, u2);

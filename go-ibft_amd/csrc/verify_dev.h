@@ -61,7 +61,7 @@ __host__ __device__ __forceinline__ bool sig_in_range(const u256 &r, const u256 
 // u1 = z/s, u2 = r/s (mod n), canonical
 __host__ __device__ __forceinline__ void verify_scalars(const u256 &z_raw, const u256 &r, const u256 &s, u256 &u1,
                                                         u256 &u2) {
-  secp::sc sinv = secp::sc_from_u256(secp::modinv<secp::ModN>(s));
+  secp::sc sinv = secp::sc_from_u256(secp::modinv_shared<secp::ModN>(s));
   u1 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), sinv));
   u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(r), sinv));
 }
