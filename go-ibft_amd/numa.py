@@ -90,6 +90,6 @@ def pin_to_device_node(device: int = 0) -> dict:
             return info
         os.sched_setaffinity(0, cpus)
         info.update(pinned=True, numa_node=got[1], cpus=got[0])
-    except (OSError, ValueError) as e:
+    except Exception as e:  # noqa: BLE001 — a placement hint must never take the caller down
         info["why"] = repr(e)
     return info
