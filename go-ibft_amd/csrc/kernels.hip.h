@@ -764,7 +764,9 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
 #pragma unroll 1
   for (int off = G / 2; off >= 1; off >>= 1) {
     jac other = shfl_xor_jac(acc, off);
-    acc = secp::jac_add_t<true>(acc, other);  // (one inlined copy in the rolled butterfly)
+    // (round 5: through the outlined multiply — one to three folds per signature do not pay for 28 KB of pasted code in a
+    // kernel that is far over the 64 KB instruction cache already: DESIGN.md §5.8)
+    acc = secp::jac_add_t<false>(acc, other);
   }
   aff Qa;
   ok = secp::jac_to_aff_fast(Qa, acc) && ok;
