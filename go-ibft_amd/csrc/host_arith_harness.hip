@@ -185,6 +185,17 @@ const uint32_t *dev_gtab_ptr(void) {
 }
 
 // returns 1 and the 20-byte address on success
+// the same recover with the window table in "LDS" (the lane kernel's form since round 5)
+int dev_recover_address_lds(const uint8_t *digest32, const uint8_t *sig65, uint32_t flags, uint8_t *addr20) {
+  std::vector<uint32_t> mem((size_t)ibftk::LTAB_WORDS * 2, 0u);
+  uint32_t a[5];
+  ibftk::aff Qa;
+  bool ok = ibftk::recover_pubkey_with(g_gtab.data(), secp::from_be32(digest32), secp::from_be32(sig65), secp::from_be32(sig65 + 32),
+                                       sig65[64], flags, a, Qa, ibftk::var_mult_lds<2>{mem.data() + 1});
+  memcpy(addr20, a, 20);
+  return ok ? 1 : 0;
+}
+
 int dev_recover_address(const uint8_t *digest32, const uint8_t *sig65, uint32_t flags, uint8_t *addr20) {
   dev_gtab_init();
   uint32_t a[5];

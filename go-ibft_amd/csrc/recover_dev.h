@@ -348,14 +348,23 @@ __host__ __device__ __forceinline__ jac ecmult_var_v1(const aff &R, const u256 &
 // is rejected (same rejection list as oracle/secp256k1.c:orc_ecrecover).
 // how u2·R is computed: the table in the private segment (PREFETCH: its entries read in front of the doublings — one resident
 // wavefront per SIMD; without: two) or in the workgroup's LDS
+// (each returns u2·R + u1·G)
 template <bool PREFETCH>
 struct var_mult_private {
-  __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k) const { return ecmult_var_t<PREFETCH>(R, k); }
+  __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
+                                                     const u256 &u1) const {
+    return ecmult_gen(gtab, u1, ecmult_var_t<PREFETCH>(R, k));
+  }
 };
 template <int TPB>
 struct var_mult_lds {
   uint32_t *col;
-  __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k) const { return ecmult_var_lds<TPB>(R, k, col); }
+  __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
+                                                     const u256 &u1) const {
+    // (u1·G as further iterations of the window loop — ONE pasted mixed addition instead of two, 104 → 84 KB of code — was
+    // measured and not adopted: −2.6 % on a lease of the slow kind, +1.5 % on the fast kind; profiles/r05la_, r05lb_lane_merge_ab.txt)
+    return ecmult_gen(gtab, u1, ecmult_var_lds<TPB>(R, k, col));
+  }
 };
 template <class VARMULT>
 __host__ __device__ __forceinline__ bool recover_pubkey_with(const uint32_t *__restrict__ gtab, const u256 &z_raw,
@@ -386,8 +395,7 @@ __host__ __device__ __forceinline__ bool recover_pubkey_with(const uint32_t *__r
   secp::sc rinv = secp::sc_from_u256(secp::modinv_shared<secp::ModN>(r));  // r is canonical, in [1, n)
   u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
-  jac Q = var_mult(R, u2);
-  Q = ecmult_gen(gtab, u1, Q);
+  jac Q = var_mult(R, u2, gtab, u1);
   ok = secp::jac_to_aff_fast(Qa, Q) && ok;
   u256 qx = secp::l26_to_u256(Qa.x), qy = secp::l26_to_u256(Qa.y);
   keccak::address_from_xy(qx.v, qy.v, addr);

@@ -288,6 +288,12 @@ def test_recover_address_matches_oracle(dev, oracle):
             assert (ref is not None) == bool(ok), (i, fl)
             if ref is not None:
                 assert o.raw == ref, (i, fl)
+            # round 5, the lane kernel's form: window table in "LDS"
+            o2 = C.create_string_buffer(20)
+            ok2 = dev.dev_recover_address_lds(d, sig, fl, o2)
+            assert bool(ok2) == bool(ok), (i, fl)
+            if ref is not None:
+                assert o2.raw == ref, (i, fl)
 
 
 def test_variable_time_divsteps_match_constant_time(dev):

@@ -14,7 +14,7 @@ import go_ibft_amd.numa as NUMA
 NUMA.pin_to_device_node(0)
 import go_ibft_amd.verifier as V, go_ibft_amd.simulate as SIM
 out = {}
-for n, flags in ((16384, 0), (32768, 0), (65536, 0), (4096, 2), (16384, 2)):
+for n, flags in ((16384, 0), (65536, 0), (40000, 0)):
     bv = V.BatchVerifier(flags=flags, max_rows=n)
     r = SIM.make_round(bv, n, 600 + n)
     bv.set_validators(1, r.addrs, r.power); bv.seals_stage(r.hash32, r.seal65, r.signer20, None)
