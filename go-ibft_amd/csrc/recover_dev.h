@@ -362,7 +362,7 @@ struct var_mult_lds {
   __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
                                                      const u256 &u1) const {
     // (u1·G as further iterations of the window loop — ONE pasted mixed addition instead of two, 104 → 84 KB of code — was
-    // measured and not adopted: −2.6 % on a lease of the slow kind, +1.5 % on the fast kind; profiles/r05la_, r05lb_lane_merge_ab.txt)
+    // measured and not adopted: −2.6 % on a lease of the slow kind, +1.5 % on the fast kind; profiles/r05la_lane_merge_ab.txt, archive/r05lb_…)
     return ecmult_gen(gtab, u1, ecmult_var_lds<TPB>(R, k, col));
   }
 };
