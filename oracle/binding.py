@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libibft_oracle.so")
-_SRCS = ["keccak.c", "secp256k1.c", "ibft_oracle.c", "ibft_oracle.h"]
+_SRCS = ["keccak.c", "sha256.c", "secp256k1.c", "ibft_oracle.c", "ibft_oracle.h"]
 
 FLAG_STRICT_LOW_S = 1
 ROW_NIL, ROW_BADLEN, ROW_HASH_BAD = 1, 2, 4
@@ -107,6 +107,26 @@ def sign(sk32: bytes, digest32: bytes) -> bytes:
     out = C.create_string_buffer(65)
     if not lib().orc_sign(sk32, digest32, out):
         raise ValueError("orc_sign failed")
+    return out.raw
+
+
+def sign_rfc6979(sk32: bytes, digest32: bytes) -> bytes:
+    """r ‖ s ‖ v with the deterministic nonce of RFC 6979 (HMAC-SHA-256): what the published secp256k1 vectors were made with"""
+    out = C.create_string_buffer(65)
+    if not lib().orc_sign_rfc6979(sk32, digest32, out):
+        raise ValueError("orc_sign_rfc6979 failed")
+    return out.raw
+
+
+def sha256(data: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_sha256(bytes(data), C.c_size_t(len(data)), out)
+    return out.raw
+
+
+def hmac_sha256(key: bytes, msg: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_hmac_sha256(bytes(key), C.c_size_t(len(key)), bytes(msg), C.c_size_t(len(msg)), None, C.c_size_t(0), out)
     return out.raw
 
 

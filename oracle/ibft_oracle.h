@@ -54,6 +54,10 @@ void orc_address(const uint8_t pub64[64], uint8_t addr20[20]);
  * mod n (a vector GENERATOR — any valid k yields a valid signature).  Emits
  * low-s, v = parity(R.y) adjusted for the s-negation. Returns 1 on success. */
 int orc_sign(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[65]);
+/* the same with the nonce of RFC 6979 (HMAC-SHA-256): pins the signing path against the published secp256k1 vectors */
+int orc_sign_rfc6979(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[65]);
+void orc_sha256(const uint8_t *in, size_t len, uint8_t out[32]);
+void orc_hmac_sha256(const uint8_t *key, size_t klen, const uint8_t *msg1, size_t n1, const uint8_t *msg2, size_t n2, uint8_t out[32]);
 /* ECDSA public-key recovery.  Returns 1 and fills pub64 on success, else 0.
  * Rejects: r or s == 0, r or s >= n, v > 1, r^3+7 non-residue, Q at infinity,
  * and (with ORC_FLAG_STRICT_LOW_S) s > n/2. */

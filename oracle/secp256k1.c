@@ -475,6 +475,34 @@ void orc_address(const uint8_t pub64[64], uint8_t addr20[20]) {
   memcpy(addr20, h + 12, 20);
 }
 
+/* the signature of digest z under key d with nonce k (0 < k < n): r = (k·G).x mod n, s = (z + r·d)/k, low-s, v = parity of R.y
+ * after the low-s flip; 0 when this nonce cannot be used (r = 0, s = 0, or r would need recovery id ≥ 2) */
+static int sign_with_nonce(const u256 *d, const u256 *z, const u256 *k, uint8_t sig65[65]) {
+  jac_t R;
+  aff_t Ra;
+  u256 zero = {{0, 0, 0, 0}};
+  ecmult2(&R, k, &zero, NULL);
+  if (!jac_to_aff(&Ra, &R)) return 0;
+  if (u256_cmp(&Ra.x, &SC_N) >= 0) return 0; /* r overflow would need v>=2: skip */
+  u256 r = Ra.x;
+  if (u256_is_zero(&r)) return 0;
+  u256 kinv, s, t;
+  sc_inv(&kinv, k);
+  sc_mul(&t, &r, d);
+  sc_add(&t, &t, z);
+  sc_mul(&s, &kinv, &t);
+  if (u256_is_zero(&s)) return 0;
+  unsigned v = (unsigned)(Ra.y.d[0] & 1);
+  if (u256_cmp(&s, &SC_HALF) > 0) {
+    sc_neg(&s, &s);
+    v ^= 1;
+  }
+  u256_to_be(sig65, &r);
+  u256_to_be(sig65 + 32, &s);
+  sig65[64] = (uint8_t)v;
+  return 1;
+}
+
 int orc_sign(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[65]) {
   u256 d, z;
   u256_from_be(&d, sk32);
@@ -493,29 +521,41 @@ int orc_sign(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[6
     u256_from_be(&k, kh);
     if (u256_cmp(&k, &SC_N) >= 0) u256_sub(&k, &k, &SC_N);
     if (u256_is_zero(&k)) continue;
-    jac_t R;
-    aff_t Ra;
-    u256 zero = {{0, 0, 0, 0}};
-    ecmult2(&R, &k, &zero, NULL);
-    if (!jac_to_aff(&Ra, &R)) continue;
-    if (u256_cmp(&Ra.x, &SC_N) >= 0) continue; /* r overflow would need v>=2: skip */
-    u256 r = Ra.x;
-    if (u256_is_zero(&r)) continue;
-    u256 kinv, s, t;
-    sc_inv(&kinv, &k);
-    sc_mul(&t, &r, &d);
-    sc_add(&t, &t, &z);
-    sc_mul(&s, &kinv, &t);
-    if (u256_is_zero(&s)) continue;
-    unsigned v = (unsigned)(Ra.y.d[0] & 1);
-    if (u256_cmp(&s, &SC_HALF) > 0) {
-      sc_neg(&s, &s);
-      v ^= 1;
-    }
-    u256_to_be(sig65, &r);
-    u256_to_be(sig65 + 32, &s);
-    sig65[64] = (uint8_t)v;
-    return 1;
+    if (sign_with_nonce(&d, &z, &k, sig65)) return 1;
+  }
+  return 0;
+}
+
+/* The same signature with the nonce of RFC 6979 §3.2 (HMAC-SHA-256 DRBG, hlen = qlen = 256: bits2octets(h1) = h1 mod n) — the
+ * recipe SURVEY.md §8d names for synthetic seals.  It exists to PIN the oracle's signing path (k·G, the inversion of k, the
+ * arithmetic mod n) against the published RFC 6979 secp256k1 vectors (tests/golden/kats.json: private key, message digest → the
+ * exact r, s of bitcoinjs-lib's / btcd's suites); the product's batch signer and the committed fixtures keep orc_sign's nonce. */
+int orc_sign_rfc6979(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[65]) {
+  u256 d, z;
+  u256_from_be(&d, sk32);
+  if (u256_is_zero(&d) || u256_cmp(&d, &SC_N) >= 0) return 0;
+  sc_from_be_mod(&z, digest32);
+  uint8_t h1[32], V[32], K[32], buf[97];
+  u256_to_be(h1, &z); /* bits2octets: the digest reduced mod n */
+  memset(V, 0x01, 32);
+  memset(K, 0x00, 32);
+  for (int round = 0; round < 2; round++) { /* K = HMAC_K(V ‖ 0x00 / 0x01 ‖ int2octets(x) ‖ bits2octets(h1)); V = HMAC_K(V) */
+    memcpy(buf, V, 32);
+    buf[32] = (uint8_t)round;
+    memcpy(buf + 33, sk32, 32);
+    memcpy(buf + 65, h1, 32);
+    orc_hmac_sha256(K, 32, buf, 97, NULL, 0, K);
+    orc_hmac_sha256(K, 32, V, 32, NULL, 0, V);
+  }
+  for (int tries = 0; tries < 1024; tries++) {
+    orc_hmac_sha256(K, 32, V, 32, NULL, 0, V); /* T = V (tlen = qlen after one block) */
+    u256 k;
+    u256_from_be(&k, V);
+    if (!u256_is_zero(&k) && u256_cmp(&k, &SC_N) < 0 && sign_with_nonce(&d, &z, &k, sig65)) return 1;
+    memcpy(buf, V, 32);
+    buf[32] = 0x00;
+    orc_hmac_sha256(K, 32, buf, 33, NULL, 0, K);
+    orc_hmac_sha256(K, 32, V, 32, NULL, 0, V);
   }
   return 0;
 }

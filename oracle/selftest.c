@@ -96,6 +96,17 @@ int main(void) {
   orc_valset_free(vs);
   uint64_t zero[2] = {0, 0};
   CHECK(orc_valset_new(addrs, zero, 2) == NULL);
+  /* RFC 6979: SHA-256("abc") (FIPS 180-4 appendix B.1) and the published secp256k1 vector sk = 1, "Satoshi Nakamoto" */
+  orc_sha256((const uint8_t *)"abc", 3, h);
+  hex(h, 32, s);
+  CHECK(strcmp(s, "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad") == 0);
+  memset(sk, 0, 32);
+  sk[31] = 1;
+  orc_sha256((const uint8_t *)"Satoshi Nakamoto", 16, h);
+  CHECK(orc_sign_rfc6979(sk, h, sig));
+  hex(sig, 65, s);
+  CHECK(strcmp(s, "934b1ea10a4b3c1757e2b0c017d0b6143ce3c9a7e6a4a49860d7a6ab210ee3d8"
+                  "2442ce9d2b916064108014783e923ec36b49743e2ffa1c4496f01a512aafd9e501") == 0);
   printf(fails ? "oracle selftest: %d failure(s)\n" : "oracle selftest: ok\n", fails);
   return fails ? 1 : 0;
 }

@@ -93,6 +93,37 @@ def test_public_key_point_and_keccak_vectors(oracle):
             assert oracle.ecrecover(bytes.fromhex(v["digest"]), flipped) != bytes.fromhex(v["pub64"])
 
 
+def test_rfc6979_vectors_pin_the_signing_path(oracle):
+    """private key, message → the EXACT r, s, v of the published RFC 6979 secp256k1 vectors (tests/golden/kats.json): pins k·G,
+    the inversion of the nonce and the arithmetic mod n of the oracle's signer (the part of the synthetic workload's
+    generation that recover-only vectors leave open), after its SHA-256 / HMAC are checked against Python's own."""
+    import hashlib
+    import hmac
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000):
+        m = rng.bytes(n)
+        assert oracle.sha256(m) == hashlib.sha256(m).digest(), n
+        for klen in (0, 32, 64, 65, 200):
+            key = rng.bytes(klen)
+            assert oracle.hmac_sha256(key, m) == hmac.new(key, m, hashlib.sha256).digest(), (klen, n)
+    k = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+    seen = 0
+    for v in k["public_recover_vectors"]:
+        if "message" not in v:
+            continue
+        sk, digest = bytes.fromhex(v["private_key"]), bytes.fromhex(v["digest"])
+        assert oracle.sha256(v["message"].encode()) == digest
+        sig = oracle.sign_rfc6979(sk, digest)
+        assert sig.hex() == v["sig65"], v["source"]
+        assert oracle.recover_address(digest, sig).hex() == v["address"]
+        seen += 1
+    assert seen == 5
+    # and the two signers differ only in the nonce: both signatures of one digest recover the same key
+    sk, d = rng.bytes(32), rng.bytes(32)
+    a, b = oracle.sign(sk, d), oracle.sign_rfc6979(sk, d)
+    assert a[:32] != b[:32] and oracle.recover_address(d, a) == oracle.recover_address(d, b)
+
+
 def test_sign_recover_roundtrip_and_rejections(oracle):
     n = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
     rng = np.random.default_rng(5)
