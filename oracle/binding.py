@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libibft_oracle.so")
-_SRCS = ["keccak.c", "sha256.c", "secp256k1.c", "ibft_oracle.c", "ibft_oracle.h"]
+_SRCS = ["keccak.c", "sha256.c", "secp256k1.c", "recover_tuned.inc", "ibft_oracle.c", "ibft_oracle.h"]
 
 FLAG_STRICT_LOW_S = 1
 ROW_NIL, ROW_BADLEN, ROW_HASH_BAD = 1, 2, 4
@@ -206,6 +206,74 @@ def verify_hashes(raw: bytes, round_: int, hash32: np.ndarray, hash_len: np.ndar
     out = np.zeros(n, dtype=np.uint8)
     lib().orc_verify_hashes(raw, len(raw), round_, _p(hash32), _p(hash_len), n, _p(out))
     return out
+
+
+# ---- the tuned recovery (recover_tuned.inc): bench.py's cpu_baseline leg and its own tests; never the checker ----
+def ecrecover_tuned(digest32: bytes, sig65: bytes, flags: int = 0) -> bytes | None:
+    out = C.create_string_buffer(64)
+    return out.raw if lib().orc_ecrecover_tuned(digest32, sig65, C.c_uint32(flags), out) else None
+
+
+def recover_address_tuned(digest32: bytes, sig65: bytes, flags: int = 0) -> bytes | None:
+    out = C.create_string_buffer(20)
+    return out.raw if lib().orc_recover_address_tuned(digest32, sig65, C.c_uint32(flags), out) else None
+
+
+def verify_seals_tuned(vs: ValSet, hash32, sig65, signer20, pre_flags=None, flags: int = 0, nthreads: int = 1) -> np.ndarray:
+    hash32 = _u8(hash32, (-1, 32)); sig65 = _u8(sig65, (-1, 65)); signer20 = _u8(signer20, (-1, 20))
+    n = len(sig65)
+    pre = None if pre_flags is None else _u8(pre_flags)
+    out = np.zeros(n, dtype=np.uint8)
+    lib().orc_verify_seals_tuned_mt.argtypes = lib().orc_verify_seals_mt.argtypes
+    lib().orc_verify_seals_tuned_mt(vs.h, _p(hash32), _p(sig65), _p(signer20), _p(pre), n, flags, _p(out), nthreads)
+    return out
+
+
+def tuned_fe_ops(a32: bytes, b32: bytes):
+    """(a·b, a², a⁻¹ (0 for a = 0), √a or None) mod p from the tuned path's field code"""
+    m, q, i, r = (C.create_string_buffer(32) for _ in range(4))
+    ok = C.c_int(0)
+    lib().orc_tuned_fe_ops(a32, b32, m, q, i, r, C.byref(ok))
+    return m.raw, q.raw, i.raw, (r.raw if ok.value else None)
+
+
+def tuned_fe_lazy(a32: bytes, b32: bytes) -> bytes:
+    """(8·(a + b) − b)·(2·(b − 3a))² mod p through unreduced sums, negations and small multiples of the lazy field"""
+    out = C.create_string_buffer(32)
+    lib().orc_tuned_fe_lazy(a32, b32, out)
+    return out.raw
+
+
+def tuned_fe_inv_gcd(a32: bytes) -> bytes:
+    """a⁻¹ mod p by divsteps (computed as 5·(5a)⁻¹ from an unreduced operand)"""
+    out = C.create_string_buffer(32)
+    lib().orc_tuned_fe_inv_gcd(a32, out)
+    return out.raw
+
+
+def tuned_sc_inv(a32: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().orc_tuned_sc_inv(a32, out)
+    return out.raw
+
+
+def tuned_glv_split(k32: bytes):
+    """(|k1|, negative?, |k2|, negative?) with k ≡ k1 + k2·λ (mod n)"""
+    k1, k2 = C.create_string_buffer(32), C.create_string_buffer(32)
+    n1, n2 = C.c_int(0), C.c_int(0)
+    lib().orc_tuned_glv_split(k32, k1, k2, C.byref(n1), C.byref(n2))
+    return int.from_bytes(k1.raw, "big"), bool(n1.value), int.from_bytes(k2.raw, "big"), bool(n2.value)
+
+
+def tuned_wnaf5(k32: bytes) -> list[int]:
+    d = (C.c_int8 * 132)()
+    n = lib().orc_tuned_wnaf5(k32, d)
+    return [int(d[i]) for i in range(n)]
+
+
+def tuned_ecmult_var(k32: bytes, p64: bytes) -> bytes | None:
+    out = C.create_string_buffer(64)
+    return out.raw if lib().orc_tuned_ecmult_var(k32, p64, out) else None
 
 
 def verify_seals(vs: ValSet, hash32, sig65, signer20, pre_flags=None, flags: int = 0,

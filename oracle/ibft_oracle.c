@@ -103,13 +103,18 @@ void orc_verify_hashes(const uint8_t *raw, size_t raw_len, uint64_t round, const
 }
 
 /* ---- a2: IsValidCommittedSeal ------------------------------------------------ */
-static uint8_t seal_row(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
-                        const uint8_t *signer20, uint8_t pre, uint32_t flags) {
+typedef int (*recover_fn)(const uint8_t *, const uint8_t *, uint32_t, uint8_t *);
+static inline uint8_t seal_row_with(recover_fn recover, const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
+                                    const uint8_t *signer20, uint8_t pre, uint32_t flags) {
   if (pre) return 0; /* nil seal / bad length / a1 short-circuit: ibft.go:938-943 */
   uint8_t addr[20];
-  if (!orc_recover_address(hash32, sig65, flags, addr)) return 0;
+  if (!recover(hash32, sig65, flags, addr)) return 0;
   if (memcmp(addr, signer20, 20) != 0) return 0;
   return orc_valset_index(vs, signer20) >= 0 ? 1 : 0;
+}
+static uint8_t seal_row(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
+                        const uint8_t *signer20, uint8_t pre, uint32_t flags) {
+  return seal_row_with(orc_recover_address, vs, hash32, sig65, signer20, pre, flags);
 }
 
 void orc_verify_seals(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
@@ -126,19 +131,20 @@ typedef struct {
   size_t lo, hi;
   uint32_t flags;
   uint8_t *verdict;
+  recover_fn recover;
 } seal_job_t;
 
 static void *seal_worker(void *arg) {
   seal_job_t *j = (seal_job_t *)arg;
   for (size_t i = j->lo; i < j->hi; i++)
-    j->verdict[i] = seal_row(j->vs, j->hash32 + 32 * i, j->sig65 + 65 * i, j->signer20 + 20 * i,
-                             j->pre ? j->pre[i] : 0, j->flags);
+    j->verdict[i] = seal_row_with(j->recover, j->vs, j->hash32 + 32 * i, j->sig65 + 65 * i, j->signer20 + 20 * i,
+                                  j->pre ? j->pre[i] : 0, j->flags);
   return NULL;
 }
 
-void orc_verify_seals_mt(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
-                         const uint8_t *signer20, const uint8_t *pre_flags, size_t n,
-                         uint32_t flags, uint8_t *verdict, int nthreads) {
+static void verify_seals_threads(recover_fn recover, const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
+                                 const uint8_t *signer20, const uint8_t *pre_flags, size_t n, uint32_t flags,
+                                 uint8_t *verdict, int nthreads) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 256) nthreads = 256;
   uint8_t dummy_pub[64], one[32] = {0};
@@ -148,10 +154,23 @@ void orc_verify_seals_mt(const orc_valset_t *vs, const uint8_t *hash32, const ui
   seal_job_t jobs[256];
   for (int t = 0; t < nthreads; t++) {
     jobs[t] = (seal_job_t){vs, hash32, sig65, signer20, pre_flags, n * (size_t)t / nthreads,
-                           n * (size_t)(t + 1) / nthreads, flags, verdict};
+                           n * (size_t)(t + 1) / nthreads, flags, verdict, recover};
     pthread_create(&th[t], NULL, seal_worker, &jobs[t]);
   }
   for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+
+void orc_verify_seals_mt(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
+                         const uint8_t *signer20, const uint8_t *pre_flags, size_t n,
+                         uint32_t flags, uint8_t *verdict, int nthreads) {
+  verify_seals_threads(orc_recover_address, vs, hash32, sig65, signer20, pre_flags, n, flags, verdict, nthreads);
+}
+
+/* the same rows through the tuned recovery (recover_tuned.inc): bench.py's cpu_baseline only, never the checker */
+void orc_verify_seals_tuned_mt(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
+                               const uint8_t *signer20, const uint8_t *pre_flags, size_t n,
+                               uint32_t flags, uint8_t *verdict, int nthreads) {
+  verify_seals_threads(orc_recover_address_tuned, vs, hash32, sig65, signer20, pre_flags, n, flags, verdict, nthreads);
 }
 
 /* ---- a3: IsValidValidator ------------------------------------------------------ */

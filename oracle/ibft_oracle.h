@@ -56,6 +56,10 @@ void orc_address(const uint8_t pub64[64], uint8_t addr20[20]);
 int orc_sign(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[65]);
 /* the same with the nonce of RFC 6979 (HMAC-SHA-256): pins the signing path against the published secp256k1 vectors */
 int orc_sign_rfc6979(const uint8_t sk32[32], const uint8_t digest32[32], uint8_t sig65[65]);
+/* the TUNED form of the recovery (recover_tuned.inc: endomorphism split, width-5 NAF, addition chains, binary Euclid) — for
+ * bench.py's cpu_baseline leg only; the checker is orc_ecrecover, against which tests/test_oracle_tuned.py holds this one */
+int orc_ecrecover_tuned(const uint8_t digest32[32], const uint8_t sig65[65], uint32_t flags, uint8_t pub64[64]);
+int orc_recover_address_tuned(const uint8_t digest32[32], const uint8_t sig65[65], uint32_t flags, uint8_t addr20[20]);
 void orc_sha256(const uint8_t *in, size_t len, uint8_t out[32]);
 void orc_hmac_sha256(const uint8_t *key, size_t klen, const uint8_t *msg1, size_t n1, const uint8_t *msg2, size_t n2, uint8_t out[32]);
 /* ECDSA public-key recovery.  Returns 1 and fills pub64 on success, else 0.
@@ -115,6 +119,11 @@ void orc_verify_seals(const orc_valset_t *vs, const uint8_t *hash32, const uint8
 void orc_verify_seals_mt(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
                          const uint8_t *signer20, const uint8_t *pre_flags, size_t n,
                          uint32_t flags, uint8_t *verdict, int nthreads);
+
+/* same rows through orc_recover_address_tuned: the cpu_baseline leg of bench.py, never the checker */
+void orc_verify_seals_tuned_mt(const orc_valset_t *vs, const uint8_t *hash32, const uint8_t *sig65,
+                               const uint8_t *signer20, const uint8_t *pre_flags, size_t n,
+                               uint32_t flags, uint8_t *verdict, int nthreads);
 
 /* a3: IsValidValidator over a batch (/root/reference/core/backend.go:41-45):
  * payload = concatenated PayloadNoSig bytes, row i = payload[off[i]..off[i+1]). */

@@ -655,3 +655,5 @@ int orc_ecmult2(const uint8_t k1[32], const uint8_t k2[32], const uint8_t p64[64
   u256_to_be(out64 + 32, &o.y);
   return 1;
 }
+
+#include "recover_tuned.inc"

@@ -71,6 +71,15 @@ int main(void) {
   static uint8_t v2[N];
   orc_verify_seals_mt(vs, hash32, seal, signer, pre, N, 0, v2, 4);
   CHECK(memcmp(verdict, v2, N) == 0);
+  memset(v2, 7, N);
+  orc_verify_seals_tuned_mt(vs, hash32, seal, signer, pre, N, 0, v2, 3); /* the tuned recovery: same verdicts, and clean under
+                                                                            the sanitizers (signed limbs, 128-bit carries) */
+  CHECK(memcmp(verdict, v2, N) == 0);
+  for (int i = 0; i < N; i++) {
+    uint8_t p1[64], p2[64];
+    const int a = orc_ecrecover(hash32 + 32 * i, seal + 65 * i, 0, p1), b = orc_ecrecover_tuned(hash32 + 32 * i, seal + 65 * i, 0, p2);
+    CHECK(a == b && (!a || memcmp(p1, p2, 64) == 0));
+  }
   orc_tally_t t;
   orc_tally(vs, signer, verdict, N, &t);
   CHECK((int)t.valid_rows == good && t.distinct_senders == (uint32_t)good);
