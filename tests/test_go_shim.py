@@ -52,3 +52,54 @@ def test_checker_counts_arguments_and_knows_the_host_header(tmp_path):
     assert "ibft_host_rows_keptt is not declared" in out.stdout
     assert "ibft_verify_messages called with 18 arguments, the prototype has 19" in out.stdout
     assert "documented sequence" in out.stdout                      # … and the method's documented C sequence no longer matches
+
+
+CGO_TOOL = os.path.join(ROOT, "tools", "cgo_typecheck.py")
+
+
+def test_cgo_boundary_typechecks_under_a_c_compiler():
+    """every argument of every C.f(...) call, every composite-literal field, every field read from a C struct and every
+    //export signature of shim/go, as `_Static_assert(__builtin_types_compatible_p(…))` compiled by gcc against include/*.h"""
+    out = subprocess.run([sys.executable, CGO_TOOL], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    last = out.stdout.strip().splitlines()[-1]
+    n_checked, n_left = (int(x) for x in __import__("re").findall(r"(\d+) assertions compiled, (\d+) arguments", last)[0])
+    assert n_checked >= 300 and n_left == 0, last           # nothing the tool could not type is hiding behind the pass
+
+
+def test_cgo_typecheck_catches_seeded_boundary_defects(tmp_path):
+    dst = tmp_path / "go"
+    shutil.copytree(os.path.join(ROOT, "shim", "go"), dst)
+    g = dst / "ibftgpu" / "ibftgpu.go"
+    src = g.read_text()
+    seeds = [
+        # a pointer of the wrong width (uint32 offsets handed over as uint64)
+        ("rc := C.ibft_verify_senders(c.h, ptr8(payload), (*C.uint32_t)(unsafe.Pointer(&off[0]))",
+         "rc := C.ibft_verify_senders(c.h, ptr8(payload), (*C.uint64_t)(unsafe.Pointer(&off[0]))", "C.ibft_verify_senders argument 3"),
+        # an integer of the wrong C type: Go has no implicit widening
+        ("C.ibft_set_seal_digest(c.h, mode, ptr8(suffix), C.size_t(len(suffix)))",
+         "C.ibft_set_seal_digest(c.h, mode, ptr8(suffix), C.uint32_t(len(suffix)))", "C.ibft_set_seal_digest argument 4"),
+        # a field that the C struct does not have
+        ("max_rows: C.uint32_t(o.MaxRows)}", "max_row: C.uint32_t(o.MaxRows)}", "max_row"),
+        # nil where the prototype takes an integer
+        ("return c.check(C.ibft_seals_swap(c.h, 1))", "return c.check(C.ibft_seals_swap(c.h, nil))", "nil passed"),
+    ]
+    for old, new, _ in seeds:
+        assert src.count(old) == 1, old
+        src = src.replace(old, new)
+    g.write_text(src)
+    cb = dst / "hoststore" / "callbacks.go"
+    cs = cb.read_text()
+    assert "func hoststoreSignal(user unsafe.Pointer, msgType C.uint32_t, height, round C.uint64_t)" in cs
+    cb.write_text(cs.replace("func hoststoreSignal(user unsafe.Pointer, msgType C.uint32_t, height, round C.uint64_t)",
+                             "func hoststoreSignal(user unsafe.Pointer, msgType C.uint64_t, height, round C.uint64_t)"))
+    hs = dst / "hoststore" / "hoststore.go"
+    hsrc = hs.read_text()
+    assert "C.ibft_host_use_batch(h, 1)" in hsrc
+    hs.write_text(hsrc.replace("C.ibft_host_use_batch(h, 1)", "C.ibft_host_use_batch(1, h)"))        # arguments swapped
+    out = subprocess.run([sys.executable, CGO_TOOL, str(dst)], capture_output=True, text=True)
+    assert out.returncode == 1, out.stdout
+    for _, _, needle in seeds:
+        assert needle in out.stdout, (needle, out.stdout)
+    assert "//export hoststoreSignal parameter 2" in out.stdout
+    assert "C.ibft_host_use_batch argument 1" in out.stdout and "C.ibft_host_use_batch argument 2" in out.stdout
