@@ -103,3 +103,38 @@ def test_cgo_typecheck_catches_seeded_boundary_defects(tmp_path):
         assert needle in out.stdout, (needle, out.stdout)
     assert "//export hoststoreSignal parameter 2" in out.stdout
     assert "C.ibft_host_use_batch argument 1" in out.stdout and "C.ibft_host_use_batch argument 2" in out.stdout
+
+
+ARITY_TOOL = os.path.join(ROOT, "tools", "go_arity_check.py")
+
+
+def test_go_calls_fit_their_definitions():
+    """every call of shim/go whose receiver the tool can type (parameters, receivers, type assertions, struct fields, first
+    results; interfaces and methods of the overlay and of the reference) passes as many arguments as the definition takes and
+    assigns as many names as it returns"""
+    out = subprocess.run([sys.executable, ARITY_TOOL], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    judged = int(__import__("re").search(r"(\d+) calls judged", out.stdout).group(1))
+    assert judged >= (200 if os.path.isdir("/root/reference") else 60), out.stdout
+
+
+def test_go_arity_check_catches_seeded_defects(tmp_path):
+    dst = tmp_path / "go"
+    shutil.copytree(os.path.join(ROOT, "shim", "go"), dst)
+    glue = dst / "core" / "hoststore_glue.go"
+    gs = glue.read_text()
+    assert "q, prepared := hs.HandlePrepare(view)" in gs
+    glue.write_text(gs.replace("q, prepared := hs.HandlePrepare(view)", "q := hs.HandlePrepare(view)"))       # two results, one name
+    wi = dst / "core" / "wire_ingest.go"
+    ws = wi.read_text()
+    assert "mask, rows, ok := wv.VerifySendersWire(wire, off)" in ws and "case !ibftgpu.Bit(mask, k):" in ws
+    wi.write_text(ws.replace("mask, rows, ok := wv.VerifySendersWire(wire, off)", "mask, rows, ok := wv.VerifySendersWire(wire)")
+                    .replace("case !ibftgpu.Bit(mask, k):", "case !ibftgpu.Bit(mask):")
+                    .replace("i.addWireStock(stock, nil)", "i.addWireStockRenamed(stock, nil)", 1))
+    out = subprocess.run([sys.executable, ARITY_TOOL, str(dst)], capture_output=True, text=True)
+    assert out.returncode == 1, out.stdout
+    assert "1 names receive the 2 results of hs.HandlePrepare" in out.stdout
+    assert "wv.VerifySendersWire called with 1 arguments, the definition takes 2" in out.stdout
+    assert "ibftgpu.Bit called with 1 arguments, the definition takes 2" in out.stdout
+    if os.path.isdir("/root/reference"):
+        assert "i.addWireStockRenamed is not defined on core.IBFT" in out.stdout
