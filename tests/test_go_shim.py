@@ -131,8 +131,17 @@ def test_go_arity_check_catches_seeded_defects(tmp_path):
     wi.write_text(ws.replace("mask, rows, ok := wv.VerifySendersWire(wire, off)", "mask, rows, ok := wv.VerifySendersWire(wire)")
                     .replace("case !ibftgpu.Bit(mask, k):", "case !ibftgpu.Bit(mask):")
                     .replace("i.addWireStock(stock, nil)", "i.addWireStockRenamed(stock, nil)", 1))
+    hs = dst / "hoststore" / "hoststore.go"
+    hsrc = hs.read_text()
+    old_sig = "func (s *Store) HandleCommit(view *proto.View) (quorum bool, seals []*messages.CommittedSeal) {"
+    assert old_sig in hsrc and "func (s *Store) PruneByHeight(height uint64) {" in hsrc
+    hs.write_text(hsrc.replace(old_sig, "func (s *Store) HandleCommit(view *proto.View) (quorum bool, seals [][]byte) {")
+                      .replace("func (s *Store) PruneByHeight(height uint64) {", "func (s *Store) PruneByHeight(height uint32) {"))
     out = subprocess.run([sys.executable, ARITY_TOOL, str(dst)], capture_output=True, text=True)
     assert out.returncode == 1, out.stdout
+    assert "*hoststore.Store.HandleCommit has the signature" in out.stdout and "core.hostStore wants" in out.stdout
+    if os.path.isdir("/root/reference"):
+        assert "*hoststore.Store.PruneByHeight has the signature (uint32) ()" in out.stdout       # core.Messages is the reference's
     assert "1 names receive the 2 results of hs.HandlePrepare" in out.stdout
     assert "wv.VerifySendersWire called with 1 arguments, the definition takes 2" in out.stdout
     assert "ibftgpu.Bit called with 1 arguments, the definition takes 2" in out.stdout

@@ -16,6 +16,8 @@ tool resolves what it can without implementing Go's type system:
                whole right-hand side of an assignment, the number of names on the left must be the number of results
 
 A call whose receiver does not resolve is counted, not judged.  Exit code 0 = every resolved call fits.
+Also: the methods of the types the overlay assigns to interfaces (*hoststore.Store → core.Messages, core.hostStore;
+*messages.Messages → core.Messages, core.batchStore) compared with those interfaces parameter type by parameter type.
 usage: go_arity_check.py [shim root] [-v]"""
 from __future__ import annotations
 
@@ -32,6 +34,45 @@ REF = "/root/reference"
 IMPORT_TO_PKG = {"github.com/0xPolygon/go-ibft/messages/proto": "proto", "github.com/0xPolygon/go-ibft/messages": "messages",
                  "github.com/0xPolygon/go-ibft/ibftgpu": "ibftgpu", "github.com/0xPolygon/go-ibft/core": "core",
                  "github.com/0xPolygon/go-ibft/hoststore": "hoststore"}
+
+
+def norm_type(t: str) -> str:
+    """a Go type with the parameter names inside func types dropped and white space removed"""
+    t = " ".join(t.split())
+    out, k = "", 0
+    while True:
+        j = t.find("func(", k)
+        if j < 0:
+            return (out + t[k:]).replace(" ", "")
+        close = T.matching(t, j + 4)
+        inner = t[j + 5:close].strip().rstrip(",")
+        out += t[k:j] + "func(" + ",".join(type_list(inner)) + ")"
+        k = close + 1
+
+
+def type_list(plist: str) -> list[str]:
+    """`a, b T, c func(x U) V` → [T, T, func(U)V]; `T, U` (unnamed) → [T, U]"""
+    plist = " ".join(plist.split()).rstrip(",").strip()
+    if not plist:
+        return []
+    items = T.split_top(plist)
+    named = T.parse_go_params(plist)
+    # unnamed lists: every item is a type (an item like `x T` has a space outside brackets; `[]*p.T`, `func(A) B` need care)
+    def is_named(it):
+        parts = it.split(None, 1)
+        return len(parts) == 2 and re.fullmatch(r"\w+", parts[0]) is not None and parts[0] not in ("func", "chan", "map", "struct", "interface")
+    if any(is_named(it) for it in items) and len(named) == len(items):
+        return [norm_type(t) for _, t in named]
+    return [norm_type(it) for it in items]
+
+
+def result_types(result: str) -> list[str]:
+    result = result.strip()
+    if not result:
+        return []
+    if result.startswith("(") and T.matching(result, 0) == len(result) - 1:
+        return type_list(result[1:-1])
+    return [norm_type(result)]
 
 
 def n_results(result: str) -> int:
@@ -63,14 +104,19 @@ class Package:
         self.fields: dict[str, dict[str, str]] = {}           # struct → {field: type}
         self.embedded: dict[str, list[str]] = {}              # struct / interface → embedded type names
         self.aliases: dict[str, str] = {}                     # import alias → package name, per file merged (last wins)
+        self.types: set[str] = set()                          # every declared type name
 
     def add_source(self, code: str):
         for m in re.finditer(r'^\s*(?:(\w+)\s+)?"([^"]+)"\s*$', code, re.M):
             pkg = IMPORT_TO_PKG.get(m.group(2))
             if pkg:
                 self.aliases[m.group(1) or pkg] = pkg
+        self.types |= set(re.findall(r"^type\s+(\w+)\s", code, re.M))
+        for blk in re.finditer(r"^type\s*\(", code, re.M):
+            self.types |= set(re.findall(r"^\s*(\w+)\s+\S", code[blk.end():T.matching(code, blk.end() - 1)], re.M))
         for name, recv, params, result, body, _ in T.go_functions(code):
-            sig = (len(params), any(t.startswith("...") for _, t in params), n_results(result), first_result_type(result))
+            sig = (len(params), any(t.startswith("...") for _, t in params), n_results(result), first_result_type(result),
+                   [norm_type(t) for _, t in params], result_types(result))
             if recv:
                 self.methods[(recv[1].lstrip("*"), name)] = sig
             else:
@@ -91,7 +137,8 @@ class Package:
                     eol = ibody.find("\n", close)
                     eol = len(ibody) if eol < 0 else eol
                     res = ibody[close + 1:eol].strip()
-                    meths[mm.group(1)] = (len(params), any(t.startswith("...") for _, t in params), n_results(res), first_result_type(res))
+                    meths[mm.group(1)] = (len(params), any(t.startswith("...") for _, t in params), n_results(res), first_result_type(res),
+                                          type_list(plist), result_types(res))
                     k = eol + 1
                     continue
                 eol = ibody.find("\n", k)
@@ -319,17 +366,77 @@ def check(shim_root: str, verbose: bool = False) -> tuple[list[str], int, int]:
     return errors, judged, unresolved
 
 
+# what the overlay promises to be assignable: T implements I  ⇔  `var _ I = (*T)(nil)` compiles
+IMPLEMENTS = [(("hoststore", "Store"), ("core", "Messages")), (("hoststore", "Store"), ("core", "hostStore")),
+              (("messages", "Messages"), ("core", "batchStore")), (("messages", "Messages"), ("core", "Messages"))]
+
+
+def interface_methods(W: World, it: tuple[str, str], depth: int = 0) -> dict[str, tuple]:
+    P = W.pkgs.get(it[0])
+    if P is None or it[1] not in P.interfaces or depth > 4:
+        return {}
+    out = dict(P.interfaces[it[1]])
+    for e in P.embedded.get(it[1], []):
+        et = W.resolve_type(e, it[0])
+        if et:
+            out.update(interface_methods(W, et, depth + 1))
+    return out
+
+
+def qualify(types: list[str], pkg: str, W: World) -> list[str]:
+    """type names written inside package `pkg` made absolute, so that `Messages` in package messages = `messages.Messages`"""
+    P = W.pkg(pkg)
+    local = set(P.fields) | set(P.interfaces) | {k[0] for k in P.methods} | P.types
+    out = []
+    for t in types:
+        t = re.sub(r"(?<![\w\.])(\w+)\.(\w+)", lambda m: P.aliases.get(m.group(1), m.group(1)) + "." + m.group(2), t)
+        t = re.sub(r"(?<![\w\.])([A-Z]\w*)(?![\w\.])", lambda m: pkg + "." + m.group(1) if m.group(1) in local else m.group(1), t)
+        out.append(t)
+    return out
+
+
+def check_implements(shim_root: str) -> tuple[list[str], int]:
+    W = World(shim_root)
+    errors, compared = [], 0
+    for ty, it in IMPLEMENTS:
+        want = interface_methods(W, it)
+        if not want or not W.known_type(ty):
+            continue                                                           # (the reference is absent: nothing to compare with)
+        for name, isig in sorted(want.items()):
+            msig = W.method(ty, name)
+            if msig is None:
+                if W.have_ref or ty[0] in ("ibftgpu", "hoststore") and not W.pkgs[ty[0]].embedded.get(ty[1]):
+                    errors.append("*%s.%s lacks %s of %s.%s" % (ty[0], ty[1], name, it[0], it[1]))
+                continue
+            # where the method was found decides how its unqualified names read
+            owner = ty[0]
+            if (ty[1], name) not in W.pkgs[ty[0]].methods:
+                for e in W.pkgs[ty[0]].embedded.get(ty[1], []):
+                    et = W.resolve_type(e, ty[0])
+                    if et and W.method(et, name):
+                        owner = et[0]
+            got = (qualify(msig[4], owner, W), qualify(msig[5], owner, W))
+            exp = (qualify(isig[4], it[0], W), qualify(isig[5], it[0], W))
+            compared += 1
+            if got != exp:
+                errors.append("*%s.%s.%s has the signature (%s) (%s), %s.%s wants (%s) (%s)"
+                              % (ty[0], ty[1], name, ", ".join(got[0]), ", ".join(got[1]), it[0], it[1], ", ".join(exp[0]), ", ".join(exp[1])))
+    return errors, compared
+
+
 def main(argv: list[str]) -> int:
     verbose = "-v" in argv
     argv = [a for a in argv if a != "-v"]
     shim_root = argv[0] if argv else os.path.join(ROOT, "shim", "go")
     errors, judged, unresolved = check(shim_root, verbose)
+    ierrors, compared = check_implements(shim_root)
+    errors += ierrors
     if not os.path.isdir(REF):
         print("note: /root/reference absent — calls into the reference's own types are not judged")
     for e in errors:
         print("ERROR:", e)
-    print("go arity: %d calls judged against their definitions, %d with a receiver this tool cannot type, %d problems"
-          % (judged, unresolved, len(errors)))
+    print("go arity: %d calls judged against their definitions, %d with a receiver this tool cannot type; %d method signatures "
+          "compared with the interfaces their types are assigned to; %d problems" % (judged, unresolved, compared, len(errors)))
     return 1 if errors else 0
 
 
