@@ -104,3 +104,35 @@ def test_dry_run_gpus_n_relaunches_shards_exchanges_and_merges(world):
         assert (c5["validators"], c5["rows_per_gpu"], c5["rccl_nranks"]) == (65536, 8192, 8) and 0.79 < c5["valid_fraction"] < 0.81
     # value = rows of ALL ranks per second of the slowest rank
     assert rec["value"] == pytest.approx(4096 * world * 5 / (rec["ms_per_step"] * 5e-3), rel=1e-3)
+
+
+def test_cpu_baseline_leg_times_the_tuned_path_only_after_it_agreed(oracle, monkeypatch):
+    """bench.py's CPU leg: the tuned recovery is timed when it agrees with the checker on a sample with corrupted rows; when it
+    does not (here: a doctored tuned path), the plain path is timed instead and the record says why"""
+    import importlib
+    bench = importlib.import_module("bench")
+    from oracle import workload as W
+    rd = W.make_round(256, seed=77)
+    out = bench.cpu_baseline(rd.addrs, rd.power, rd.hash32, rd.seal65, rd.signer20, budget_s=0.3)
+    assert out["path"] == "tuned" and out["kind"] == "port" and out["value"] > 0 and out["plain_path"] > 0
+    assert out["value"] > 1.5 * out["plain_path"] and "tuned_path_refused" not in out and "error" not in out
+    rec = bench.headline_record({"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+                                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                                 "config": {"workload": "w"}, "roofline": {"bound": "hbm", "achieved": 1, "peak": 1, "unit": "GB/s", "frac": 1, "traffic": None},
+                                 "cpu_baseline": out})
+    assert rec["cpu_baseline"]["path"] == "tuned" and abs(rec["cpu_baseline"]["plain_path"] - out["plain_path"]) < 1.0
+    real = oracle.verify_seals_tuned
+
+    def doctored(vs, h, s, f, pre_flags=None, flags=0, nthreads=1):
+        v = real(vs, h, s, f, pre_flags, flags, nthreads)
+        v[0] ^= 1
+        return v
+    monkeypatch.setattr(oracle, "verify_seals_tuned", doctored)
+    out = bench.cpu_baseline(rd.addrs, rd.power, rd.hash32, rd.seal65, rd.signer20, budget_s=0.3)
+    assert out["path"] == "plain" and "differ" in out["tuned_path_refused"] and out["plain_path"] is None and "error" not in out
+
+    def broken(*a, **k):
+        raise OSError("no such symbol")
+    monkeypatch.setattr(oracle, "verify_seals_tuned", broken)
+    out = bench.cpu_baseline(rd.addrs, rd.power, rd.hash32, rd.seal65, rd.signer20, budget_s=0.3)
+    assert out["path"] == "plain" and "no such symbol" in out["tuned_path_refused"] and out["value"] > 0
