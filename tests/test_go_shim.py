@@ -32,6 +32,20 @@ def test_checker_catches_the_round1_defects(tmp_path):
         assert "addVerifiedMessage" in out.stdout
 
 
+def test_checker_knows_what_the_go_compiler_refuses_outright(tmp_path):
+    """an import nothing uses and a local nothing reads are compile errors in Go"""
+    dst = tmp_path / "go"
+    shutil.copytree(os.path.join(ROOT, "shim", "go"), dst)
+    f = dst / "core" / "hoststore_glue.go"
+    src = f.read_text()
+    assert "q, prepared := hs.HandlePrepare(view)" in src
+    f.write_text(src.replace("q, prepared := hs.HandlePrepare(view)", "q, prepared := hs.HandlePrepare(view)\n\tleftover := len(prepared)")
+                    .replace('import (', 'import (\n\t"sort"', 1))
+    out = subprocess.run([sys.executable, TOOL, str(dst)], capture_output=True, text=True)
+    assert out.returncode == 1
+    assert '"sort" imported and not used' in out.stdout and "leftover declared and not used" in out.stdout
+
+
 def test_checker_counts_arguments_and_knows_the_host_header(tmp_path):
     """round 4: C.ibft_host_* resolve against include/ibft_host.h, and a C call with the wrong number of arguments — what a
     changed prototype leaves behind in a file no compiler sees — is reported"""

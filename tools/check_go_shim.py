@@ -11,6 +11,7 @@ DEFINED somewhere a Go compiler would find it —
   hoststore              *Store has every method of core.Messages and of core.hostStore; the "C call sequence" each method
                          documents is the one its body makes (tests/test_hoststore_sequence.py replays those sequences)
   import paths           the overlay layout documented in shim/go/ibftgpu/ibftgpu.go
+  compile errors         an import nothing uses, a local variable declared and never read
 
 Exit code 0 = consistent.  The reference checks are skipped (with a note) when /root/reference is absent."""
 import glob
@@ -223,6 +224,33 @@ def main(shim_root: str | None = None) -> int:
         for name in sorted(set(re.findall(r"\bctx\.(\w+)\(", text)) | set(re.findall(r"\(\*Ctx\)\.(\w+)", text))):
             if not defined_method("Ctx", name, gpu_shim):
                 errors.append(f"{doc} mentions ctx.{name}() which shim/go/ibftgpu does not define")
+    # what the Go compiler refuses outright: an import nothing uses, a local variable declared and never read
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cgo_typecheck as CT
+    for path in sorted(shim):
+        rel = os.path.relpath(path, ROOT)
+        text = CT.strip_go_comments(open(path).read())
+        nostr = re.sub(r'`[^`]*`', '``', re.sub(r'"(?:[^"\\\n]|\\.)*"', '""', text))
+        imports = []
+        for m in re.finditer(r'^import\s*\((.*?)^\)', text, re.M | re.S):
+            imports += re.findall(r'^\s*(?:(\w+|_|\.)\s+)?"([^"]+)"', m.group(1), re.M)
+        imports += re.findall(r'^import\s+(?:(\w+)\s+)?"([^"]+)"\s*$', text, re.M)
+        for alias, ipath in imports:
+            name = alias or ipath.split("/")[-1]
+            if ipath == "C" or alias in ("_", "."):
+                continue
+            if not re.search(r"(?<![\w\.])%s\." % re.escape(name), nostr):
+                errors.append(f"{rel}: \"{ipath}\" imported and not used")
+        for fname, _, _, _, body, _ in CT.go_functions(text):
+            b = re.sub(r'"(?:[^"\\\n]|\\.)*"', '""', body)
+            declared = set()
+            for m in re.finditer(r"(?:^|[;{]|\bif\s|\bfor\s|\bswitch\s)\s*([\w, ]+?)\s*:=", b, re.M):
+                declared |= {n.strip() for n in m.group(1).split(",") if re.fullmatch(r"[A-Za-z]\w*", n.strip())}
+            for m in re.finditer(r"\bvar\s+([\w, ]+?)\s+[\*\[\w]", b):
+                declared |= {n.strip() for n in m.group(1).split(",") if re.fullmatch(r"[A-Za-z]\w*", n.strip())}
+            for n in sorted(declared):
+                if len(re.findall(r"(?<![\w\.])%s\b" % re.escape(n), b)) < 2:
+                    errors.append(f"{rel}: {fname}: {n} declared and not used")
     if not have_ref:
         print("note: /root/reference absent — only the intra-repo checks ran")
     for e in errors:
