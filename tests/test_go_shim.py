@@ -145,6 +145,9 @@ def test_go_arity_check_catches_seeded_defects(tmp_path):
     wi.write_text(ws.replace("mask, rows, ok := wv.VerifySendersWire(wire, off)", "mask, rows, ok := wv.VerifySendersWire(wire)")
                     .replace("case !ibftgpu.Bit(mask, k):", "case !ibftgpu.Bit(mask):")
                     .replace("i.addWireStock(stock, nil)", "i.addWireStockRenamed(stock, nil)", 1))
+    gs2 = glue.read_text()
+    assert "func (i *IBFT) AddWireMessagesQueued(raw [][]byte) bool {" in gs2 and "return hs.AddWireMessages(raw) == nil" in gs2
+    glue.write_text(gs2.replace("func (i *IBFT) AddWireMessagesQueued(raw [][]byte) bool {", "func (i *IBFT) AddWireMessagesQueued(raw []byte) bool {"))
     hs = dst / "hoststore" / "hoststore.go"
     hsrc = hs.read_text()
     old_sig = "func (s *Store) HandleCommit(view *proto.View) (quorum bool, seals []*messages.CommittedSeal) {"
@@ -156,6 +159,7 @@ def test_go_arity_check_catches_seeded_defects(tmp_path):
     assert "*hoststore.Store.HandleCommit has the signature" in out.stdout and "core.hostStore wants" in out.stdout
     if os.path.isdir("/root/reference"):
         assert "*hoststore.Store.PruneByHeight has the signature (uint32) ()" in out.stdout       # core.Messages is the reference's
+    assert "hs.AddWireMessages argument 1: raw is []byte, the parameter is [][]byte" in out.stdout
     assert "1 names receive the 2 results of hs.HandlePrepare" in out.stdout
     assert "wv.VerifySendersWire called with 1 arguments, the definition takes 2" in out.stdout
     assert "ibftgpu.Bit called with 1 arguments, the definition takes 2" in out.stdout

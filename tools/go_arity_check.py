@@ -239,20 +239,36 @@ class World:
         return bool(P) and (ty[1] in P.fields or ty[1] in P.interfaces or any(k[0] == ty[1] for k in P.methods))
 
 
+BUILTIN_SHAPED = re.compile(r"^(\[\]|\*)*(byte|uint8|uint16|uint32|uint64|int|int32|int64|bool|string|uintptr|float64|error)$")
+typed_args = 0
+
+
 def fits(nargs: int, sig) -> bool:
     np_, variadic = sig[0], sig[1]
     return nargs >= np_ - 1 if variadic else nargs == np_
 
 
 def check(shim_root: str, verbose: bool = False) -> tuple[list[str], int, int]:
+    global typed_args
     W = World(shim_root)
     errors, judged, unresolved = [], 0, 0
+    typed_args = 0
     for path, pkg, code in W.files:
         rel = os.path.relpath(path, ROOT)
         P = W.pkg(pkg)
         for fn in T.go_functions(code):
             name, recv, params, result, body, body_pos = fn
             env: dict[str, tuple[str, str]] = {}
+            plain: dict[str, str] = {}                                         # names whose declared type is made of builtins only
+            for n_, t_ in params + (T.parse_go_params(result.strip()[1:-1]) if result.strip().startswith("(") else []):
+                if BUILTIN_SHAPED.match(norm_type(t_)):
+                    plain[n_] = norm_type(t_).replace("uint8", "byte")
+            for m_ in re.finditer(r"\bvar\s+(\w+)\s+([\[\]\*\w]+)", body):
+                if BUILTIN_SHAPED.match(m_.group(2)):
+                    plain[m_.group(1)] = m_.group(2).replace("uint8", "byte")
+            for m_ in re.finditer(r"\b(\w+)\s*:=\s*make\(\s*([\[\]\*\w]+)\s*,", body):
+                if BUILTIN_SHAPED.match(m_.group(2)):
+                    plain[m_.group(1)] = m_.group(2).replace("uint8", "byte")
 
             def bind(n, t):
                 rt = W.resolve_type(t, pkg)
@@ -355,6 +371,15 @@ def check(shim_root: str, verbose: bool = False) -> tuple[list[str], int, int]:
                 if not fits(len(args), sig) and not (spread and sig[0] > 1):
                     errors.append("%s:%d: %s called with %d arguments, the definition takes %d%s"
                                   % (rel, line, ".".join(qual + [fname]), len(args), sig[0], " (variadic)" if sig[1] else ""))
+                # arguments that are plain names of a builtin-shaped declared type, against builtin-shaped parameter types
+                if len(args) == len(sig[4]) and not sig[1]:
+                    for k_, (a_, pt_) in enumerate(zip(args, sig[4])):
+                        pt_ = pt_.replace("uint8", "byte")
+                        if a_ in plain and BUILTIN_SHAPED.match(pt_):
+                            typed_args += 1
+                            if plain[a_] != pt_:
+                                errors.append("%s:%d: %s argument %d: %s is %s, the parameter is %s"
+                                              % (rel, line, ".".join(qual + [fname]), k_ + 1, a_, plain[a_], pt_))
                 # the call as the whole right-hand side of an assignment
                 ls = body.rfind("\n", 0, m.start()) + 1
                 prefix, rest = body[ls:m.start()], body[end + 1:body.find("\n", end) if body.find("\n", end) > 0 else len(body)]
@@ -435,8 +460,9 @@ def main(argv: list[str]) -> int:
         print("note: /root/reference absent — calls into the reference's own types are not judged")
     for e in errors:
         print("ERROR:", e)
-    print("go arity: %d calls judged against their definitions, %d with a receiver this tool cannot type; %d method signatures "
-          "compared with the interfaces their types are assigned to; %d problems" % (judged, unresolved, compared, len(errors)))
+    print("go arity: %d calls judged against their definitions (%d arguments of builtin-shaped types compared with their parameters), "
+          "%d with a receiver this tool cannot type; %d method signatures compared with the interfaces their types are assigned to; "
+          "%d problems" % (judged, typed_args, unresolved, compared, len(errors)))
     return 1 if errors else 0
 
 
