@@ -92,6 +92,13 @@ def keccak256(data: bytes) -> bytes:
     return out.raw
 
 
+def sponge256(data: bytes, pad: int) -> bytes:
+    """rate-136 sponge with the first padding byte given: 0x01 = keccak256, 0x06 = NIST SHA3-256"""
+    out = C.create_string_buffer(32)
+    lib().orc_sponge256(bytes(data), C.c_size_t(len(data)), C.c_uint8(pad), out)
+    return out.raw
+
+
 def pubkey(sk32: bytes) -> bytes | None:
     out = C.create_string_buffer(64)
     return out.raw if lib().orc_pubkey(sk32, out) else None

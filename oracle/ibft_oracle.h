@@ -43,6 +43,9 @@ extern "C" {
 /* ---- keccak.c ---------------------------------------------------------- */
 void orc_keccak_f1600(uint64_t state[25]);
 void orc_keccak256(const uint8_t *in, size_t len, uint8_t out[32]);
+/* the same sponge with the first padding byte given: 0x01 = Keccak-256, 0x06 = NIST SHA3-256 (the form a third-party
+ * implementation can check on arbitrary inputs) */
+void orc_sponge256(const uint8_t *in, size_t len, uint8_t pad, uint8_t out[32]);
 
 /* ---- secp256k1.c ------------------------------------------------------- */
 #define ORC_FLAG_STRICT_LOW_S 1u

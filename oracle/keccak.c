@@ -12,8 +12,9 @@
  * multi-rate padding 0x01…0x80 (Ethereum's Keccak-256), rate 136 bytes,
  * capacity 512 bits — NOT NIST SHA3-256 (0x06 pad).  It is pinned by public
  * known-answer vectors in tests/test_oracle_kat.py (keccak256("") =
- * c5d24601…, keccak256("abc") = 4e03657a…) and by an independent pure-Python
- * derivation in oracle/pyref.py.
+ * c5d24601…, keccak256("abc") = 4e03657a…), by an independent pure-Python
+ * derivation in oracle/pyref.py, and — permutation, absorption and squeezing, on
+ * arbitrary inputs — by Python's hashlib.sha3_256 through orc_sponge256(…, 0x06).
  */
 #include "ibft_oracle.h"
 #include <string.h>
@@ -59,7 +60,12 @@ void orc_keccak_f1600(uint64_t A[25]) {
   }
 }
 
-void orc_keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {
+void orc_keccak256(const uint8_t *in, size_t len, uint8_t out[32]) { orc_sponge256(in, len, 0x01, out); }
+
+/* the sponge at rate 136 / capacity 512 with the first padding byte as a parameter: 0x01 = Keccak-256 (Ethereum), 0x06 =
+ * NIST SHA3-256 — the same permutation, absorption and squeezing, so that tests can hold this code against a third-party
+ * SHA3-256 (Python's hashlib) on arbitrary inputs; only the domain byte then rests on the Keccak known answers */
+void orc_sponge256(const uint8_t *in, size_t len, uint8_t pad, uint8_t out[32]) {
   enum { RATE = 136 };
   uint64_t A[25];
   uint8_t block[RATE];
@@ -76,7 +82,7 @@ void orc_keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {
   }
   memset(block, 0, RATE);
   if (len) memcpy(block, in, len);
-  block[len] ^= 0x01;      /* Keccak (pre-NIST) domain/pad start */
+  block[len] ^= pad;       /* 0x01: Keccak (pre-NIST) domain/pad start */
   block[RATE - 1] ^= 0x80; /* pad end */
   for (int i = 0; i < RATE / 8; i++) {
     uint64_t w = 0;

@@ -23,6 +23,18 @@ def test_keccak_kats(oracle):
     assert oracle.keccak256(b"transfer(address,uint256)").hex()[:8] == "a9059cbb"
 
 
+def test_keccak_sponge_against_a_third_party_sha3(oracle):
+    """permutation, absorption across block boundaries and squeezing of the oracle's sponge = hashlib's SHA3-256 on arbitrary
+    inputs when the domain byte is NIST's 0x06; with 0x01 the same code IS keccak256 (one parameter apart)"""
+    import hashlib
+    rng = np.random.default_rng(2)
+    for n in list(range(0, 300)) + [407, 408, 409, 543, 544, 545, 1024, 4096, 65537]:
+        m = rng.bytes(n)
+        assert oracle.sponge256(m, 0x06) == hashlib.sha3_256(m).digest(), n
+        assert oracle.sponge256(m, 0x01) == oracle.keccak256(m)
+        assert oracle.sponge256(m, 0x01) != oracle.sponge256(m, 0x06)
+
+
 def test_curve_kats(oracle):
     one = (1).to_bytes(32, "big")
     pub = oracle.pubkey(one)
