@@ -175,3 +175,18 @@ def test_oracle_selftest_under_asan_ubsan():
     subprocess.check_call(["make", "-C", d, "asan_selftest"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = subprocess.run([os.path.join(d, "asan_selftest")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "selftest: ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_oracle_selftest_under_msan():
+    """… and under clang's MemorySanitizer (no branch or address depends on an uninitialised value — the tuned recovery keeps
+    points with an `inf` flag and otherwise unset coordinates)"""
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no clang")
+    d = os.path.join(os.path.dirname(HERE), "oracle")
+    built = subprocess.run(["make", "-C", d, "msan_selftest"], capture_output=True, text=True)
+    if built.returncode != 0:
+        pytest.skip("MemorySanitizer runtime not available: " + built.stderr[-200:])
+    out = subprocess.run([os.path.join(d, "msan_selftest")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "oracle selftest: ok" in out.stdout, out.stdout + out.stderr
