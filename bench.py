@@ -19,7 +19,8 @@ Inputs are resident in HBM when the timed region starts.
         partials are all-reduced over RCCL (disjoint shards: sum ≡ OR).  The exchange of pass k runs
         on its own stream and overlaps with the kernels of pass k+1.  At N=8 the line also carries
         `config5`: 65 536 validators, 8192 rows per GPU, 20 % Byzantine seals, checked against the
-        CPU oracle outside the timed region.
+        CPU oracle outside the timed region.  Round 6: every N > 1 line carries `sharded_sweep` — N_total ∈
+        {16 384, 65 536} split over the ranks (config #4 at N = 4, config #5 at N = 8 fall out of it).
   `python bench.py --gpus N` from a bare shell re-launches itself under torch.distributed.run.
   torch is imported only for N > 1 and only as torch.distributed over gloo (communicator id, barriers, max over ranks): the
   process runs ONE HIP runtime and ONE RCCL, the image's ROCm 7.2 ones the library was built for (torch 2.10+rocm7.0 bundles
@@ -56,6 +57,7 @@ SEQ_ROUNDS = 1000            # latency p50 over ≥1000 rounds
 SWEEP_PREWARM_MIN_PASSES, SWEEP_PREWARM_MIN_S = 100, 0.1   # untimed passes in front of every sweep entry (clock ramp)
 PREWARM_STEPS = 150         # untimed passes in front of the W warm-up steps of the headline legs (see run_config)
 CONFIG5_TIMEOUT_S = 240     # the N = 8 extra leg (config #5) is abandoned after this long; the headline line goes out regardless
+CANARY_HEALTHY_NS = 1.79     # profiles/r05a_ubench_wave.txt: an aligned 8-byte VALU instruction at one wavefront per SIMD (4.16 cycles at 2.39 GHz)
 KERNEL_TIMING_EVERY = 4      # HIP-event pair around the verdict kernel of every 4th timed pass (≥ 50 samples at --steps 200)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 
@@ -266,18 +268,70 @@ def _attachment_files(suffix: str):
     return live + sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}")), reverse=True)
 
 
-def collect_live_counters(rows: int) -> str:
-    """--profile: the rocprofv3 passes of tools/profile.sh (kernel stats, FETCH_SIZE, WRITE_SIZE: separate runs) and
-    tools/pmc_wave.sh (instruction counters, one counter set per run) as sub-steps of this run, over the same command line
-    they always use; their summaries land in gpurun_out/profiles/live_n<rows>_* and are what this line then attaches."""
+LIVE_BUDGET_S = 200   # the default run's counter sub-steps are abandoned after this long (the line then attaches the committed files)
+
+
+def collect_live_counters(rows: int, lean: bool) -> tuple[str | None, dict]:
+    """The rocprofv3 passes of tools/profile.sh (kernel stats, FETCH_SIZE, WRITE_SIZE: separate runs) and tools/pmc_wave.sh
+    (instruction counters, one counter set per run) as sub-steps of THIS run, over the same command line they always use; their
+    summaries land in gpurun_out/profiles/live_n<rows>_* and are what this line then attaches.  lean (the default run, round 6:
+    the driver's own line must carry counters from the driver's own box): the headline stats pass, the two traffic passes and
+    two counter sets — five short processes, ≈ 40 s; --profile: the full series (≈ 2 minutes).  Returns (tag or None, what happened)."""
+    import shutil
+    info = {"mode": "lean" if lean else "full"}
+    if shutil.which("rocprofv3") is None:
+        info["skipped"] = "rocprofv3 is not on PATH"
+        return None, info
     tag = f"live_n{rows}"
-    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT)
+    for old_file in glob.glob(os.path.join(ROOT, "gpurun_out", "profiles", tag + "_*")):   # never a previous run's files
+        try:
+            os.remove(old_file)
+        except OSError:
+            pass
+    env = dict(os.environ, GRAFT_REPO_ROOT=ROOT, LEAN="1" if lean else "0")
+    t0 = time.time()
     for cmd in (["bash", os.path.join(ROOT, "tools", "profile.sh"), tag, str(rows)],
                 ["bash", os.path.join(ROOT, "tools", "pmc_wave.sh"), str(rows), tag]):
-        rc = subprocess.call(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        left = (LIVE_BUDGET_S if lean else 900) - (time.time() - t0)
+        if left < 20:
+            info["skipped_step"] = os.path.basename(cmd[1]) + ": time budget spent"
+            break
+        try:
+            # (a process group of its own: on a timeout the whole sub-tree goes, not just the shell)
+            pr = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                rc = -9
+        except OSError as e:
+            rc, info["error"] = -1, repr(e)
         if rc != 0:
-            print(f"bench: {' '.join(cmd[1:])} returned {rc}; attaching the committed counters", file=sys.stderr)
-    return tag
+            info[os.path.basename(cmd[1])] = f"returned {rc}"
+            print(f"bench: {' '.join(cmd[1:])} returned {rc}; attaching the committed counters where this run has none", file=sys.stderr)
+    info["seconds"] = round(time.time() - t0, 1)
+    have = [os.path.basename(x) for x in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "profiles", tag + "_*")))]
+    info["files"] = have
+    return (tag if have else None), info
+
+
+def rocprof_avg_kernel_ms(kname: str):
+    """average duration of `kname` in THIS run's rocprofv3 --kernel-trace --stats summary (the contract: it must agree with
+    the HIP-event average) → (ms, calls) or None"""
+    import csv
+    if not LIVE_TAG:
+        return None
+    path = os.path.join(ROOT, "gpurun_out", "profiles", f"{LIVE_TAG}_kernel_stats.csv")
+    needle = kname.replace(",", ", ")
+    try:
+        for row in csv.DictReader(open(path)):
+            if needle in row.get("Name", ""):
+                return float(row["AverageNs"]) / 1e6, int(row["Calls"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def _static_mix(kname: str):
@@ -642,7 +696,7 @@ def certificates_leg(V, n: int = 256, reps: int = 30):
 LINE_LIMIT = 6144   # the driver keeps the last 8 081 bytes of stdout: the LAST line must parse on its own (round-4 review)
 DETAIL_PATH = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
 _ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_kernel_ms", "kernel_samples",
-                  "algorithmic_bytes_per_launch", "counters")
+                  "rocprof_avg_kernel_ms", "rocprof_calls", "algorithmic_bytes_per_launch", "counters", "counters_live")
 _VALU_KEYS = ("wave_insts_per_launch", "achieved_ginst_s", "peak_guide_ginst_s", "frac_of_guide_peak",
               "frac_of_full_occupancy_ceiling", "frac_of_ceiling_at_this_occupancy", "wavefronts_resident_per_simd", "source")
 
@@ -678,6 +732,12 @@ def headline_record(rec: dict) -> dict:
     cb = rec.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "path", "sample", "os_cpu_count", "plain_path", "tuned_path_refused", "error") if k in cb}
+    if rec.get("extended"):   # the 400-step sample of the same leg (the K-step leg above has K/4 kernel-time samples)
+        out["extended"] = {k: rec["extended"][k] for k in ("steps", "value", "ms_per_step", "avg_kernel_ms", "kernel_samples")
+                           if k in rec["extended"]}
+    if rec.get("device_canary"):
+        out["device_canary"] = {k: rec["device_canary"][k] for k in ("issue_ns", "healthy_ns", "off", "flag", "error")
+                                if k in rec["device_canary"]}
     ql = rec.get("quorum_latency") or {}
     if "message_sets_warm" in ql:
         out["quorum_latency_warm_ms_p50"] = ql["message_sets_warm"].get("p50_ms")
@@ -695,6 +755,12 @@ def headline_record(rec: dict) -> dict:
         c5 = rec["config5"]
         out["config5"] = {k: c5[k] for k in ("validators", "rows_per_gpu", "byzantine_fraction", "rccl_nranks", "value",
                                              "ms_per_step", "kernel", "valid_fraction", "error") if k in c5}
+    ss = (rec.get("sharded_sweep") or {}).get("sizes")
+    if ss:   # one row per size: [N_total, rows per GPU, verifies/s, ms per step, synchronous step p50 ms, kernel] (or the error)
+        out["sharded_sweep"] = [[e.get("validators"), e.get("rows_per_gpu"), e.get("value"), e.get("ms_per_step"),
+                                 e.get("step_latency_ms_p50"), e.get("kernel")] if "error" not in e else
+                                [e.get("validators"), "error", e["error"][:120]] for e in ss]
+        out["sharded_sweep_columns"] = "N_total, rows/GPU, verifies/s, ms/step, sync step p50 ms, kernel"
     if "build" in rec:
         out["build"] = rec["build"]
     if rec.get("dry_run"):
@@ -703,7 +769,8 @@ def headline_record(rec: dict) -> dict:
     out["detail"] = "gpurun_out/bench_detail.json (also the previous stdout line)"
     out = _r(out)
     # never let an extra take the line over the limit: drop optional objects, widest first
-    for k in ("sweep", "sweep_columns", "warm_path", "config5", "sustained_incl_h2d", "build", "parity"):
+    for k in ("sweep", "sweep_columns", "warm_path", "config5", "sustained_incl_h2d", "build", "parity", "sharded_sweep_columns",
+              "sharded_sweep", "extended", "device_canary"):
         if len(json.dumps(out)) < LINE_LIMIT:
             break
         out.pop(k, None)
@@ -744,8 +811,10 @@ def main():
     ap.add_argument("--rows", type=int, default=ROWS_PER_GPU, help="rows (validators) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile", action="store_true",
-                    help="N = 1: collect roofline.traffic / valu_issue with rocprofv3 sub-steps of this run (tools/profile.sh, "
-                         "tools/pmc_wave.sh; ≈2 minutes) instead of attaching the committed profiles/ files")
+                    help="N = 1: the FULL series of rocprofv3 sub-steps (tools/profile.sh, tools/pmc_wave.sh; ≈2 minutes).  Without "
+                         "it the run still collects roofline.traffic / valu_issue itself with a lean series (≈40 s)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="no rocprofv3 sub-steps at all: attach the committed profiles/ files (what the sub-steps themselves run with)")
     ap.add_argument("--no-sequence", action="store_true", help="skip the config-#3 sequence latency legs")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm-path leg")
     ap.add_argument("--seq-rounds", type=int, default=SEQ_ROUNDS)
@@ -972,7 +1041,13 @@ def main():
         if path == "warm":
             bv.cache_stats()
             warm_lanes = bv.lanes_per_signature
-        res = {"n_total": n_total, "rows": rows, "elapsed": elapsed, "steps": steps, "lat": lat, "lat_h2d": lat_h2d,
+        canary = None
+        if not DRY_RUN and hasattr(bv, "issue_probe"):
+            try:      # the device canary right behind the timed passes (clocks up): ns per aligned VALU instruction per SIMD
+                canary = bv.issue_probe()
+            except Exception as e:  # noqa: BLE001 — a diagnostic: its failure is recorded, nothing else
+                canary = repr(e)
+        res = {"n_total": n_total, "rows": rows, "elapsed": elapsed, "steps": steps, "lat": lat, "lat_h2d": lat_h2d, "canary": canary,
                "intervals": intervals if dist is None else [],
                "rccl": comm_info,
                "kernel_ms": kernel_ms, "kernel_launches": kernel_launches,
@@ -1002,9 +1077,21 @@ def main():
         value = n_total * m["steps"] / m["elapsed"]
         avg_kernel_s = (m["kernel_ms"] / 1e3) / max(m["kernel_launches"], 1)
         achieved = rows * ALGO_BYTES_PER_VERIFY / avg_kernel_s / 1e9  # GB/s, per launch on this rank
-        if args.profile and world == 1 and dist is None and not DRY_RUN:
-            LIVE_TAG = collect_live_counters(rows)        # (behind the timed legs: the sub-steps are processes of their own)
+        live_info = None
+        if world == 1 and dist is None and not DRY_RUN and not args.no_live_counters and args.path == "cold" and \
+                os.environ.get("IBFT_BENCH_NO_LIVE") != "1":
+            # (behind the timed legs: the sub-steps are processes of their own.  Round 6: the DEFAULT, so that the line the
+            # driver parses carries counters collected on the driver's own box in the driver's own run)
+            LIVE_TAG, live_info = collect_live_counters(rows, lean=not args.profile)
         traffic, valu = profile_attachments(m["kname"], rows, avg_kernel_s)
+        live_traffic = live_valu = False
+        if LIVE_TAG:   # which of the two really came from this run's files
+            live_valu = bool(valu) and str(valu.get("source", "")).startswith("gpurun_out")
+            try:
+                lt = json.load(open(os.path.join(ROOT, "gpurun_out", "profiles", f"{LIVE_TAG}_traffic.json")))
+                live_traffic = traffic is not None and any(v.get("hbm_bytes_per_launch") == traffic for v in lt.values())
+            except (OSError, ValueError):
+                pass
         workload = (f"BASELINE config #3: N={n_total} validators, 1xMI355X — value: one round of COMMIT seals per step "
                     f"(ECDSA recover+compare+membership+quorum tally); quorum_latency_ms_p50: the full PREPARE+COMMIT "
                     f"sequence with Keccak proposal-hash check") if world == 1 and rows == 4096 else \
@@ -1030,12 +1117,21 @@ def main():
                                           f"{KERNEL_TIMING_EVERY if world == 1 else 1}th timed pass ({m['kernel_launches']} samples)",
                          "algorithmic_bytes_per_launch": rows * ALGO_BYTES_PER_VERIFY,
                          "valu_issue": valu,
-                         "counters": ("rocprofv3 sub-steps of this run (--profile): gpurun_out/profiles/" + LIVE_TAG + "_*") if LIVE_TAG
-                                     else "attached: the newest committed profiles/ file of this kernel and batch size "
-                                          "(valu_issue.source names it; --profile collects them in this run instead)",
+                         "counters": (f"sub-steps of this run (rocprofv3, {live_info['mode']} series, {live_info.get('seconds')} s): "
+                                      f"gpurun_out/profiles/{LIVE_TAG}_*" +
+                                      ("" if (live_traffic and live_valu) else
+                                       f" — but {'traffic' if not live_traffic else ''}{' and ' if not (live_traffic or live_valu) else ''}"
+                                       f"{'valu_issue' if not live_valu else ''} attached from the committed profiles/ (that pass failed)"))
+                                     if LIVE_TAG else
+                                     ("attached: the newest committed profiles/ file of this kernel and batch size (valu_issue.source "
+                                      "names it)" + (f"; live collection: {json.dumps(live_info)}" if live_info else "")),
+                         "counters_live": bool(LIVE_TAG and live_traffic and live_valu),
                          "note": "integer-VALU-bound path: HBM fraction is reported as required; valu_issue is "
                                  "the bound that applies (DESIGN.md §5)"},
         }
+        rp = rocprof_avg_kernel_ms(m["kname"])
+        if rp:   # the rocprofv3 --kernel-trace --stats average of the same kernel in this run's own sub-step
+            rec["roofline"]["rocprof_avg_kernel_ms"], rec["roofline"]["rocprof_calls"] = rp
         rec["quorum_latency_ms_p50"] = rec["step_latency_ms_p50"]   # replaced by the sequence below at N=1
         if DRY_RUN:
             rec["dry_run"] = True
@@ -1048,6 +1144,15 @@ def main():
             pass
         if m["rccl"] is not None:   # N > 1 (or forced): the collective is the library's ncclAllReduce over this communicator
             rec["rccl_nranks"], rec["rccl_rank0_device"] = m["rccl"][0], m["rccl"][2]
+        if isinstance(m.get("canary"), tuple):
+            ns = m["canary"][0]
+            rec["device_canary"] = {"issue_ns": ns, "healthy_ns": CANARY_HEALTHY_NS, "off": ns / CANARY_HEALTHY_NS - 1.0,
+                                    "flag": abs(ns / CANARY_HEALTHY_NS - 1.0) > 0.05, "probe_kernel_ms": m["canary"][1],
+                                    "what": "ibft_issue_probe: wall ns per aligned 8-byte VALU instruction per SIMD, one wavefront per SIMD, "
+                                            "median of 5 launches right behind the timed passes; flag = more than 5 % off — every "
+                                            "throughput figure of this line is then off by about as much (DESIGN.md §5.8)"}
+        elif m.get("canary") is not None:
+            rec["device_canary"] = {"error": m["canary"]}
         if long_leg is not None:
             L = long_leg
             lk = (L["kernel_ms"] / 1e3) / max(L["kernel_launches"], 1)
@@ -1134,41 +1239,62 @@ def main():
             rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = hm
         except Exception as e:  # noqa: BLE001
             rec.setdefault("quorum_latency", {})["host_mirror_from_wire"] = {"error": repr(e)}
-    if (world == 8 or (dist is not None and os.environ.get("IBFT_BENCH_CONFIG5") == "1")) and \
-            os.environ.get("IBFT_BENCH_SKIP_CONFIG5") != "1":
-        # BASELINE config #5: 65 536 validators, 8 × 8192 rows, 20 % Byzantine seals, parity vs the CPU oracle.
-        # IBFT_BENCH_CONFIG5=1 runs the same leg at any world size that divides 65 536 (with IBFT_BENCH_FORCE_DIST=1 on one
-        # GPU: the whole set as ONE shard through the sharded code path and a real one-rank RCCL communicator — what
-        # profiles/r04_forcedist_config5.json holds)
-        # This leg has never met a multi-GPU node before the driver's run: should a rank stall in it (a collective one rank
+    if dist is not None and (world > 1 or os.environ.get("IBFT_BENCH_CONFIG5") == "1" or os.environ.get("IBFT_BENCH_SHARDED_SWEEP") == "1") \
+            and os.environ.get("IBFT_BENCH_SKIP_SHARDED_SWEEP") != "1" and os.environ.get("IBFT_BENCH_SKIP_CONFIG5") != "1":
+        # north star: "sig-verifies/sec on synthetic rounds of N ∈ {64 … 65 536} validators reported at 1/2/4/8 GPUs".  Beyond
+        # one GPU's share of the headline (4 096 rows per rank) the line carries a SHARDED SWEEP: N_total ∈ {16 384, 65 536}
+        # split over the ranks in 64-aligned shards — BASELINE config #4 falls out of it at G = 4 (16 384 validators, all
+        # valid) and config #5 at G = 8 (65 536 validators, 20 % Byzantine seals, every rank's shard of the merged mask held
+        # against the CPU oracle outside the timed region).  With IBFT_BENCH_FORCE_DIST=1 on one GPU the same legs run as ONE
+        # shard through the sharded code path and a real one-rank RCCL communicator.
+        # These legs meet a multi-GPU node for the first time in the driver's run: should a rank stall (a collective one rank
         # never reaches), the headline line — complete by now — must still go out.  A timer on every rank ends the process;
         # rank 0 prints the line first, with the stall recorded.
         import threading
+        sweep_out = []
+        if rank == 0:
+            rec["sharded_sweep"] = {"definition": "N_total validators split over the ranks in 64-aligned shards, one resident COMMIT "
+                                                  "batch, recover + tally on every rank, ONE ncclAllReduce of verdict words + distinct-sender "
+                                                  "bitmaps per step (exchange k overlaps the kernels of pass k+1); value = N_total x steps / "
+                                                  "max-over-ranks time; 65 536: 20 % Byzantine seals, merged mask vs the CPU oracle",
+                                    "sizes": sweep_out}
 
         def give_up():
             if rank == 0:
-                rec["config5"] = {"error": f"no result within {CONFIG5_TIMEOUT_S} s (leg abandoned, headline unaffected)"}
+                sweep_out.append({"error": f"no result within {CONFIG5_TIMEOUT_S} s (leg abandoned, headline unaffected)"})
                 sys.stdout.flush()
                 emit(rec)
             os._exit(0)
         watchdog = threading.Timer(CONFIG5_TIMEOUT_S, give_up)
         watchdog.daemon = True
         watchdog.start()
-        try:
-            c5 = run_config(65536 // world, True, max(10, args.steps // 4), 3, "cold")
-            watchdog.cancel()
-            if rank == 0:
-                rec["config5"] = {"validators": c5["n_total"], "rows_per_gpu": 65536 // world, "byzantine_fraction": 0.2,
-                                  "rccl_nranks": c5["rccl"][0] if c5["rccl"] else None,
-                                  "value": c5["n_total"] * c5["steps"] / c5["elapsed"], "unit": "verifies/s",
-                                  "ms_per_step": c5["elapsed"] / c5["steps"] * 1e3, "kernel": c5["kname"],
-                                  "valid_fraction": c5["valid_fraction"],
-                                  "parity": "every rank's shard of the merged verdict mask equals the CPU oracle's verdicts; "
-                                            "merged quorum flag recomputed from the merged power"}
-        except Exception as e:  # noqa: BLE001 — the extra leg must never take the headline line down
-            watchdog.cancel()
-            if rank == 0:
-                rec["config5"] = {"error": repr(e)}
+        for n_sw, byz in ((16384, False), (65536, True)):
+            if n_sw % (64 * world) != 0:
+                continue
+            try:
+                c5 = run_config(n_sw // world, byz, max(10, args.steps // 4), 3, "cold")
+                if rank == 0:
+                    ent = {"validators": c5["n_total"], "rows_per_gpu": n_sw // world, "byzantine_fraction": 0.2 if byz else 0.0,
+                           "rccl_nranks": c5["rccl"][0] if c5["rccl"] else None,
+                           "value": c5["n_total"] * c5["steps"] / c5["elapsed"], "unit": "verifies/s",
+                           "ms_per_step": c5["elapsed"] / c5["steps"] * 1e3, "kernel": c5["kname"],
+                           "step_latency_ms_p50": float(np.median(c5["lat"]) * 1e3) if c5["lat"] else None,
+                           "valid_fraction": c5["valid_fraction"],
+                           "parity": ("every rank's shard of the merged verdict mask equals the CPU oracle's verdicts; merged quorum "
+                                      "flag recomputed from the merged power") if byz else
+                                     "every merged verdict bit set, merged power = total power, quorum"}
+                    if (world, n_sw) == (4, 16384):
+                        ent["baseline_config"] = 4
+                    if (world, n_sw) == (8, 65536):
+                        ent["baseline_config"] = 5
+                    sweep_out.append(ent)
+                    if byz:
+                        rec["config5"] = dict(ent)     # (the key earlier rounds' records carry)
+            except Exception as e:  # noqa: BLE001 — an extra leg must never take the headline line down
+                if rank == 0:
+                    sweep_out.append({"validators": n_sw, "error": repr(e)})
+                break                                  # (a failed collective: do not enter another one)
+        watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         rd = main_leg["rd"]
         try:

@@ -103,6 +103,7 @@ struct ibft_ctx {
   uint64_t *p_mask[2] = {nullptr, nullptr}, *p_tally[2] = {nullptr, nullptr}, *dp_mask[2] = {nullptr, nullptr}, *dp_tally[2] = {nullptr, nullptr};
   hipEvent_t ev_pass[2] = {nullptr, nullptr};
   uint32_t pass_issued = 0, pass_collected = 0, pass_n[2] = {0, 0};
+  int learn_rc = IBFT_OK;  // a table build behind a DELIVERED pass failed: reported by the next ibft_seals_submit
   int tally_slot = -1;      // ≥ 0: the next tally delivers into pipeline slot `tally_slot` instead of h_mask / h_tally
   uint32_t launched_n = 0;  // rows of the last ibft_seals_launch: what ibft_seals_fetch delivers (a swap may have changed staged_n since)
   DevBuf d_mask, d_vidx, d_tally, d_H;
@@ -1257,7 +1258,8 @@ extern "C" {
 
 static void key_cache_unmap(ibft_ctx *c);
 
-int ibft_version(void) { return 2; }  // 2: ibft_tally_t.proposer_rows, proposer20 arguments, ibft_tally_prepare, ibft_comm_info
+int ibft_version(void) { return 3; }  // 2: ibft_tally_t.proposer_rows, proposer20 arguments, ibft_tally_prepare, ibft_comm_info;
+                                      // 3: ibft_seals_stage_next / _swap / _submit / _collect, ibft_last_cold_table, ibft_comm_preload, ibft_seals_rows, ibft_issue_probe
 
 const char *ibft_strerror(int code) {
   switch (code) {
@@ -1901,6 +1903,11 @@ int ibft_seals_submit(ibft_ctx *c) {
     c->last_error = "two passes already in flight: call ibft_seals_collect first";
     return IBFT_E_INVAL;
   }
+  if (c->learn_rc != IBFT_OK) {  // the table build behind an already delivered pass failed (ibft_seals_collect): say so once
+    const int rc = c->learn_rc;
+    c->learn_rc = IBFT_OK;
+    return rc;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t s = c->pass_issued & 1u;
   // mapped result slots (the tally kernel writes them itself) and the pass events, on first use — piece by piece, so that a
@@ -1944,13 +1951,7 @@ int ibft_seals_collect(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t s = c->pass_collected & 1u;
   HIPCHK(c, hipEventSynchronize(c->ev_pass[s]));
-  c->pass_collected++;
   const uint64_t *hm = c->p_mask[s], *ht = c->p_tally[s];
-  if (c->cache_on) {  // keys this pass taught the device (passed on by its tally kernel) → tables
-    const uint32_t *lw = reinterpret_cast<const uint32_t *>(ht + 4);
-    int rcb = build_new_tables(c, lw[0], lw[1]);
-    if (rcb) return rcb;
-  }
   const uint32_t n = c->pass_n[s];
   const size_t mw = (size_t)mask_words(n);
   if (out_mask && mw) {
@@ -1969,6 +1970,27 @@ int ibft_seals_collect(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
     tally->has_quorum = (uint32_t)ht[3];
     tally->proposer_rows = (uint32_t)ht[ibftk::TALLY_OUT_PROPOSER_ROWS];
   }
+  // The pass is DELIVERED (its verdict words and tally are in the caller's buffers) before anything else can fail
+  // (the count used to move first and a failing table build dropped a finished pass for good).
+  c->pass_collected++;
+  if (c->cache_on) {  // keys this pass taught the device (passed on by its tally kernel) → tables
+    // (build_new_tables waits for the context's whole stream when keys were learned — also for a newer pass in flight:
+    // the cold-to-warm transition costs one full drain, include/ibftgpu.h.)  A failure here takes nothing from the verdicts
+    // just delivered: the next ibft_seals_submit reports it.
+    const uint32_t *lw = reinterpret_cast<const uint32_t *>(ht + 4);
+    const int rcb = build_new_tables(c, lw[0], lw[1]);
+    if (rcb) c->learn_rc = rcb;
+  }
+  return IBFT_OK;
+}
+
+// Rows of the resident batch and of the oldest submitted pass (0 when none is in flight): a binding sizes its verdict
+// buffers from THESE, never from a count its caller passes along (shim/go/ibftgpu).
+int ibft_seals_rows(ibft_ctx *c, uint32_t *resident_rows, uint32_t *oldest_pass_rows) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (resident_rows) *resident_rows = c->staged_n;
+  if (oldest_pass_rows) *oldest_pass_rows = c->pass_collected == c->pass_issued ? 0u : c->pass_n[c->pass_collected & 1u];
   return IBFT_OK;
 }
 
@@ -2285,6 +2307,40 @@ int ibft_sign_seals(ibft_ctx *c, const uint8_t *sk32, const uint8_t *hash32, siz
   // the batch is staged (rows whose key was refused carry a zero signature, which every verifier rejects)
   c->staged_n = (uint32_t)n;
   c->staged_pre = false;
+  return IBFT_OK;
+}
+
+// Device canary: see issue_probe_kernel (kernels.hip.h).  Three untimed launches, then the median of five timed ones.
+int ibft_issue_probe(ibft_ctx *c, float *ns_per_inst, float *kernel_ms) {
+  if (!c || !ns_per_inst) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t *d_out = nullptr;
+  HIPCHK(c, hipMalloc(&d_out, 64));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = IBFT_OK;
+  float t[5] = {0, 0, 0, 0, 0};
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) rc = IBFT_E_HIP;
+  for (int k = 0; k < 8 && rc == IBFT_OK; k++) {
+    if (k >= 3 && hipEventRecord(e0, c->stream) != hipSuccess) rc = IBFT_E_HIP;
+    hipLaunchKernelGGL(ibftk::issue_probe_kernel, dim3(256), dim3(256), 0, c->stream, d_out, (uint32_t)(k + 1));
+    if (k >= 3) {
+      if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+          hipEventElapsedTime(&t[k - 3], e0, e1) != hipSuccess)
+        rc = IBFT_E_HIP;
+    }
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) rc = IBFT_E_HIP;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(d_out);
+  if (rc != IBFT_OK) {
+    c->last_error = "ibft_issue_probe: a HIP call failed";
+    return rc;
+  }
+  std::sort(t, t + 5);
+  if (kernel_ms) *kernel_ms = t[2];
+  *ns_per_inst = t[2] * 1e6f / (float)(ibftk::ISSUE_PROBE_ITERS * 64);
   return IBFT_OK;
 }
 

@@ -718,11 +718,21 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
       ltab<64> lt;
       lt.col = ldsw + lane;
       ecmult_table_lds<64>(b1, lt);
+      // this lane's digits — nibbles piece·NIBS … piece·NIBS + NIBS of kb — as a shift register whose current digit is the low
+      // nibble of word NW (round 6: nothing indexed by `at`, no select chain per digit, no private segment)
+      constexpr int NW = NIBS / 8;  // 4 words (G = 2), 2 (G = 4)
+      u256 kr = secp::zero256();
+#pragma unroll
+      for (int i = 0; i <= NW; i++) {
+        kr.v[i] = kb.v[i];
+#pragma unroll
+        for (int j = 1; j < P; j++) kr.v[i] = piece == (uint32_t)j ? kb.v[i + NW * j] : kr.v[i];
+      }
 #pragma unroll 1
       for (int nib = NIBS; nib >= 0; nib--) {
-        const int at = (int)(piece * NIBS) + nib;
         const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
-        const int e = mine ? (int)secp::nibble5(kb, at) - 8 : 0;
+        const int e = mine ? (int)secp::top_nibble<NW + 1>(kr) - 8 : 0;
+        secp::shl4<NW + 1>(kr);
         if (nib != NIBS) {
 #pragma unroll 1
           for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
@@ -750,16 +760,30 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
       acc.z = secp::fe_mul(acc.z, secp::fe_mul(wt.zc, base.z));
     }
   }
-  // u1·G: the fixed-base windows are dealt to the lanes of the group
+  // u1·G: the fixed-base windows are dealt to the lanes of the group — lane `sub` takes windows sub, sub + G, … .  Round 6: u1 is
+  // a shift register (this lane's current window in the low bits of word 0: shifted down by GTAB_BITS·sub once, by GTAB_BITS·G
+  // per step — nothing indexed), and the table entry of the NEXT step is asked for before the addition of this one runs.
+  {
+    constexpr int STEPS = (GTAB_WINDOWS + G - 1) / G;
+    constexpr int LOG2G = G == 8 ? 3 : (G == 4 ? 2 : 1);
+    u256 ug = u1;
+    secp::shr_units<GTAB_BITS, LOG2G>(ug, sub);
+    uint32_t dg = ug.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+    bool has = (int)sub < GTAB_WINDOWS;
+    gtab_raw cur = gtab_load(a.gtab, has ? (int)sub : 0, has ? dg : 0u);
 #pragma unroll 1
-  for (int it = 0; it < (GTAB_WINDOWS + G - 1) / G; it++) {
-    const int w = it * G + (int)sub;
-    const bool has = w < GTAB_WINDOWS;
-    const int ww = has ? w : 0;
-    const uint32_t dg = (secp::word_sel<8>(u1, (uint32_t)(ww * GTAB_BITS) >> 5) >> ((ww * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
-    aff pt = load_affine(a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)ww * GTAB_ENTRIES + dg));
-    jac sum = secp::jac_add_aff(acc, pt);
-    acc = secp::jac_select(has && dg != 0, sum, acc);
+    for (int it = 0; it < STEPS; it++) {
+      secp::shr_const<GTAB_BITS * G>(ug);
+      const int wn = (it + 1) * G + (int)sub;
+      const bool hasn = it + 1 < STEPS && wn < GTAB_WINDOWS;
+      const uint32_t dn = ug.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+      const gtab_raw nxt = gtab_load(a.gtab, hasn ? wn : 0, hasn ? dn : 0u);  // (past the end: entry 0 of window 0, never added)
+      const jac sum = secp::jac_add_aff(acc, gtab_point(cur));
+      acc = secp::jac_select(has && dg != 0, sum, acc);
+      cur = nxt;
+      dg = dn;
+      has = hasn;
+    }
   }
 #pragma unroll 1
   for (int off = G / 2; off >= 1; off >>= 1) {
@@ -1942,6 +1966,31 @@ __global__ void lookup_kernel(const uint8_t *__restrict__ signer20, const uint32
   if (prop.on && v < 0 && a[0] == prop.a[0] && a[1] == prop.a[1] && a[2] == prop.a[2] && a[3] == prop.a[3] && a[4] == prop.a[4])
     v = VIDX_PROPOSER_OUTSIDER;
   vidx[row] = v;
+}
+
+// ---- device canary (ibft_issue_probe) ------------------------------------------------------------------------------
+// The verdict kernels are bound by VALU issue, so a device that issues slower than its kind (round 5 met one lease in ≈ 35
+// whose every throughput-bound kernel ran 1.3–1.45 × slower) shows in ONE number: the time of a plain
+// 8-byte VALU instruction that starts on an 8-byte boundary with one resident wavefront per SIMD — 1.79 ns on a healthy
+// MI355X (profiles/r05a_ubench_wave.txt: 4.16 cycles at 2.39 GHz).  ISSUE_PROBE_ITERS × 64 independent v_add_u32 per
+// wavefront ≈ 0.24 ms per launch; the launch shape is the rows kernel's at N = 4 096 (256 workgroups of four wavefronts).
+constexpr int ISSUE_PROBE_ITERS = 2048;
+__global__ void __launch_bounds__(256) issue_probe_kernel(uint32_t *out, uint32_t seed) {
+  uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 7, a3 = a0 * 7 + 3;
+  uint32_t b0 = a0 ^ 0x1234567, b1 = a1 ^ 0x89abcde, b2 = a2 ^ 0x13579bd, b3 = a3 ^ 0x2468ace;
+#pragma unroll 1
+  for (int i = 0; i < ISSUE_PROBE_ITERS; i++) {
+#define IBFT_P8(x) x x x x x x x x
+    // (no .p2align here: go-ibft_amd/phase_align.py keeps 8-byte instructions on 8-byte boundaries itself, and an assembler
+    // directive that emits padding breaks its instruction count)
+    asm volatile(IBFT_P8("v_add_u32_e64 %0, %0, %8\n v_add_u32_e64 %1, %1, %8\n v_add_u32_e64 %2, %2, %8\n"
+                                        "v_add_u32_e64 %3, %3, %8\n v_add_u32_e64 %4, %4, %8\n v_add_u32_e64 %5, %5, %8\n"
+                                        "v_add_u32_e64 %6, %6, %8\n v_add_u32_e64 %7, %7, %8\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)
+                 : "v"(seed | 1));
+#undef IBFT_P8
+  }
+  if ((a0 ^ a1 ^ a2 ^ a3 ^ b0 ^ b1 ^ b2 ^ b3) == 0x9e3779b9u) out[0] = a0;  // keeps the chain alive
 }
 
 }  // namespace ibftk

@@ -72,21 +72,41 @@ __host__ __device__ inline void gtab_entry(int w, int e, uint32_t *out) {
 }
 
 // u1*G from the fixed-base table (GTAB_WINDOWS mixed adds, no doublings); one inlined copy of the mixed addition
-// in a rolled loop (secp256k1_dev.h: the INL code shape)
+// in a rolled loop (secp256k1_dev.h: the INL code shape).
+// Round 6: (1) software-pipelined by one — entry w + 1 is asked for before the addition of entry w runs: a dependent read of
+// the 84 MB table takes ≈ 1.8 µs with one resident wavefront per SIMD and used to be waited out sixteen times per signature
+// (the addition itself takes 4.4 µs in this layout and now covers it); (2) the scalar is a shift register, its current
+// window in the low bits of word 0 — nothing is indexed, nothing lives in the private segment.
+struct gtab_raw {
+  uint4 t0, t1, t2, t3, t4;
+};
+__host__ __device__ __forceinline__ gtab_raw gtab_load(const uint32_t *__restrict__ gtab, int w, uint32_t dgt) {
+  const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
+  return gtab_raw{e[0], e[1], e[2], e[3], e[4]};
+}
+__host__ __device__ __forceinline__ aff gtab_point(const gtab_raw &g) {
+  aff q;
+  q.x.n[0] = g.t0.x; q.x.n[1] = g.t0.y; q.x.n[2] = g.t0.z; q.x.n[3] = g.t0.w;
+  q.x.n[4] = g.t1.x; q.x.n[5] = g.t1.y; q.x.n[6] = g.t1.z; q.x.n[7] = g.t1.w;
+  q.x.n[8] = g.t2.x; q.x.n[9] = g.t2.y; q.y.n[0] = g.t2.z; q.y.n[1] = g.t2.w;
+  q.y.n[2] = g.t3.x; q.y.n[3] = g.t3.y; q.y.n[4] = g.t3.z; q.y.n[5] = g.t3.w;
+  q.y.n[6] = g.t4.x; q.y.n[7] = g.t4.y; q.y.n[8] = g.t4.z; q.y.n[9] = g.t4.w;
+  return q;
+}
 __host__ __device__ __forceinline__ jac ecmult_gen(const uint32_t *__restrict__ gtab, const u256 &k, jac acc) {
+  u256 kk = k;
+  uint32_t dgt = kk.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+  gtab_raw cur = gtab_load(gtab, 0, dgt);
 #pragma unroll 1
   for (int w = 0; w < GTAB_WINDOWS; w++) {
-    uint32_t dgt = (secp::word_sel<8>(k, (uint32_t)(w * GTAB_BITS) >> 5) >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
-    const uint4 *e = reinterpret_cast<const uint4 *>(gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt));
-    uint4 t0 = e[0], t1 = e[1], t2 = e[2], t3 = e[3], t4 = e[4];
-    aff q;
-    q.x.n[0] = t0.x; q.x.n[1] = t0.y; q.x.n[2] = t0.z; q.x.n[3] = t0.w;
-    q.x.n[4] = t1.x; q.x.n[5] = t1.y; q.x.n[6] = t1.z; q.x.n[7] = t1.w;
-    q.x.n[8] = t2.x; q.x.n[9] = t2.y; q.y.n[0] = t2.z; q.y.n[1] = t2.w;
-    q.y.n[2] = t3.x; q.y.n[3] = t3.y; q.y.n[4] = t3.z; q.y.n[5] = t3.w;
-    q.y.n[6] = t4.x; q.y.n[7] = t4.y; q.y.n[8] = t4.z; q.y.n[9] = t4.w;
-    jac sum = secp::jac_add_aff_t<true>(acc, q);
+    secp::shr_bits<GTAB_BITS>(kk);
+    const bool last = w + 1 == GTAB_WINDOWS;
+    const uint32_t dn = last ? dgt : kk.v[0] & (uint32_t)(GTAB_ENTRIES - 1);  // (the last step re-reads its own entry)
+    const gtab_raw nxt = gtab_load(gtab, last ? w : w + 1, dn);
+    const jac sum = secp::jac_add_aff_t<true>(acc, gtab_point(cur));
     acc = secp::jac_select(dgt != 0, sum, acc);
+    cur = nxt;
+    dgt = dn;
   }
   return acc;
 }
@@ -296,13 +316,16 @@ __host__ __device__ __forceinline__ jac ecmult_var_lds(const aff &R, const u256 
   const u256 k1 = window_bias(sp.k1), k2 = window_bias(sp.k2);
   const secp::fe beta = secp::GLV_CONST(1);
   jac acc = secp::jac_inf();
+  u256 r1 = k1, r2 = k2;  // shift registers: the current digit is the low nibble of word 4 (secp256k1_dev.h: top_nibble)
 #pragma unroll 1
   for (int i = WINDOW_DIGITS - 1; i >= 0; i--) {
     if (i != WINDOW_DIGITS - 1) {
 #pragma unroll 1
       for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
     }
-    const int e1 = (int)secp::nibble5(k1, i) - 8, e2 = (int)secp::nibble5(k2, i) - 8;
+    const int e1 = (int)secp::top_nibble<5>(r1) - 8, e2 = (int)secp::top_nibble<5>(r2) - 8;
+    secp::shl4<5>(r1);
+    secp::shl4<5>(r2);
 #pragma unroll 1
     for (int h = 0; h < 2; h++) {  // (one inlined copy of the mixed addition; h is uniform: the β product is no divergent call)
       const int e = h ? e2 : e1;

@@ -153,6 +153,50 @@ HD uint32_t word_sel(const u256 &k, uint32_t w) {
 HD uint32_t nibble5(const u256 &k, int idx) {  // nibble idx of a value below 2^160 (a biased 128-bit scalar: 33 digits)
   return (word_sel<5>(k, (uint32_t)idx >> 3) >> (4 * (idx & 7))) & 15u;
 }
+// Digits WITHOUT an index (round 6): a loop that walks the digits of a scalar keeps the scalar in a shift register — the
+// current digit sits at a fixed place, a handful of funnel shifts per step move the next one there.  word_sel's select chain
+// on a wave-uniform index was turned back into an indexed private-segment array by the compiler (the lane kernel's last
+// 112 B of scratch: 18 words written, one read per window); a shift register has nothing to index.
+// top digit of a value below 2^(32·(WORDS−1)+4) whose top nibble sits in the low four bits of its top word
+template <int WORDS>
+HD uint32_t top_nibble(const u256 &k) { return k.v[WORDS - 1] & 15u; }
+template <int WORDS>
+HD void shl4(u256 &k) {  // k ← k·16 (within WORDS words)
+#pragma unroll
+  for (int i = WORDS - 1; i >= 1; i--) k.v[i] = (k.v[i] << 4) | (k.v[i - 1] >> 28);
+  k.v[0] <<= 4;
+}
+template <int BITS>
+HD void shr_bits(u256 &k) {  // k ← k >> BITS, 0 < BITS < 32
+#pragma unroll
+  for (int i = 0; i < 7; i++) k.v[i] = (k.v[i] >> BITS) | (k.v[i + 1] << (32 - BITS));
+  k.v[7] >>= BITS;
+}
+template <int WORDS_DOWN>
+HD void shr_words(u256 &k) {  // k ← k >> 32·WORDS_DOWN
+#pragma unroll
+  for (int i = 0; i < 8; i++) k.v[i] = i + WORDS_DOWN < 8 ? k.v[i + WORDS_DOWN] : 0u;
+}
+template <int BITS>
+HD void shr_const(u256 &k) {  // k ← k >> BITS, any constant 0 < BITS ≤ 256
+  if constexpr (BITS >= 256) {
+    k = u256{{0, 0, 0, 0, 0, 0, 0, 0}};
+  } else {
+    if constexpr (BITS / 32 > 0) shr_words<BITS / 32>(k);
+    if constexpr (BITS % 32 > 0) shr_bits<BITS % 32>(k);
+  }
+}
+// k ← k >> (UNIT·m) for a per-lane m < 2^LEVELS: binary decomposition, each level computed and selected (no divergence)
+template <int UNIT, int LEVELS>
+HD void shr_units(u256 &k, uint32_t m) {
+  if constexpr (LEVELS > 0) {
+    u256 t = k;
+    shr_const<UNIT>(t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k.v[i] = (m & 1u) ? t.v[i] : k.v[i];
+    shr_units<UNIT * 2, LEVELS - 1>(k, m >> 1);
+  }
+}
 
 // ------------------------------------------------------------------ 10×26 limbs
 constexpr uint32_t M26 = 0x3FFFFFFu;

@@ -875,22 +875,39 @@ WVF bool wjac_to_aff(aff &r, const wjac &p, const wk &k) {
 }
 
 // u1·G summed into acc: the GTAB_WINDOWS fixed-base windows dealt to the four rows (rows hold partial sums: the caller joins)
-WVF wjac gen_windows_wave(const uint32_t *__restrict__ gtab, const u256 &u1, wjac acc, const wk &k) {
+// Table point t of this row's share (window row·WPR + t) — the load only; gen_windows_wave consumes it.
+WVF waff gen_window_point(const uint32_t *__restrict__ gtab, const u256 &u1, int t, const wk &k) {
   constexpr int WPR = ibftk::GTAB_WINDOWS / 4;
+  const int win = (int)k.row * WPR + t;
+  const int bit = win * ibftk::GTAB_BITS;
+  const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+  const uint32_t *e = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt);
+  const uint32_t ld = k.li < 10 ? k.li : 0u;
+  waff pt;
+  pt.x = e[ld] & k.act;
+  pt.y = e[10 + ld] & k.act;
+  return pt;
+}
+// Round 6: software-pipelined by one — the point of window t + 1 is asked for before the addition of window t runs, and the
+// FIRST point is handed in by the caller, who asked for it as soon as u1 was known (in front of the main loop): a dependent
+// read of the 84 MB table takes ≈ 1.8 µs with one resident wavefront per SIMD, the same order as the addition it used to
+// wait in front of (four times per signature on the latency-bound path of the small batches).
+WVF wjac gen_windows_wave(const uint32_t *__restrict__ gtab, const u256 &u1, wjac acc, waff first, const wk &k) {
+  constexpr int WPR = ibftk::GTAB_WINDOWS / 4;
+  waff cur = first;
 #pragma unroll 1
   for (int t = 0; t < WPR; t++) {
-    const int win = (int)k.row * WPR + t;
-    const int bit = win * ibftk::GTAB_BITS;
+    const waff nxt = gen_window_point(gtab, u1, t + 1 < WPR ? t + 1 : t, k);  // (the last iteration re-reads its own point)
+    const int bit = ((int)k.row * WPR + t) * ibftk::GTAB_BITS;
     const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
-    const uint32_t *e = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt);
-    const uint32_t ld = k.li < 10 ? k.li : 0u;
-    waff pt;
-    pt.x = e[ld] & k.act;
-    pt.y = e[10 + ld] & k.act;
-    const wjac sum = wjac_add_aff(acc, pt, k);  // (called multiply: four iterations do not pay for 6 KB of code)
+    const wjac sum = wjac_add_aff(acc, cur, k);  // (called multiply: four iterations do not pay for 6 KB of code)
     acc = wjac_select(dgt != 0, sum, acc);
+    cur = nxt;
   }
   return acc;
+}
+WVF wjac gen_windows_wave(const uint32_t *__restrict__ gtab, const u256 &u1, wjac acc, const wk &k) {
+  return gen_windows_wave(gtab, u1, acc, gen_window_point(gtab, u1, 0, k), k);
 }
 #ifndef IBFT_WAVE_COMMON_Z
 #define IBFT_WAVE_COMMON_Z 1  // 1: the one-wavefront recover brings each row's table to one common Z (mixed additions); 0: A/B
@@ -948,6 +965,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   // u1 = −z/r, u2 = s/r (mod n); u2 = k1 + k2·λ — computed here, or (PAIR) by the helper wavefront while the prefix ran
   u256 u1 = secp::zero256();
   secp::glv_split sp;
+  waff gfirst = waff{0u, 0u};  // this row's first table point of u1·G (not PAIR)
   if constexpr (PAIR) {
     sync();  // barrier 1: the helper has written the split scalars
     sp.k1 = sp.k2 = secp::zero256();
@@ -962,6 +980,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
     const secp::sc rinv = secp::sc_from_u256(modinv_wave<secp::ModN>(r, k));
     u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
     const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
+    gfirst = gen_window_point(gtab, u1, 0, k);  // on its way while the split, the table and the main loop run
     sp = secp::sc_split_lambda(u2);
   }
   WV_STAGE(2, PX ^ PY ^ PZ ^ yc ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
@@ -1065,7 +1084,7 @@ WVF bool recover_pubkey_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   y = secp::l26_select((y.n[0] & 1u) != v, secp::fe_normalize_weak(secp::fe_neg(y, 1)), y);
   acc.z = wfe_mul(acc.z, scatter(y, k), k);
   // u1·G: the fixed-base windows are dealt to the rows (PAIR: the helper wavefront has summed them meanwhile)
-  if constexpr (!PAIR) acc = gen_windows_wave(gtab, u1, acc, k);
+  if constexpr (!PAIR) acc = gen_windows_wave(gtab, u1, acc, gfirst, k);
   acc = wjac_add(acc, wjac_lane_xor(acc, 16), k);
   acc = wjac_add(acc, wjac_lane_xor(acc, 32), k);
   if constexpr (PAIR) {
@@ -1116,6 +1135,30 @@ WVF void recover_helper_wave(const uint32_t *__restrict__ gtab, const u256 &z_ra
   }
   if (lane_id() == 0) sh->ginf = acc.inf ? 1u : 0u;
   sync();  // barrier 2
+}
+
+// One dword per lane from global memory straight into LDS — no VGPR in between, nothing for the wavefront to wait for until it
+// says so: on gfx950 `global_load_lds_dword` (LDS address = M0 + 4·lane, the global address is per lane); the load is asynchronous
+// and counted by vmcnt.  Written as an asm statement on purpose: hipcc does not count it, so it puts NO wait in front of later
+// LDS reads (it would wait vmcnt(0) at the very next one if it knew) — the reader says lds_prefetch_wait() before it reads
+// what was prefetched.  dst64: a wave-uniform pointer to 64 dwords of LDS (one per lane).  The emulator copies.
+WVF void lds_prefetch_dword(uint32_t *dst64, const uint32_t *src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)dst64);
+  uint32_t keep;  // (M0 is the compiler's: saved and restored inside the statement that borrows it)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(m0v)
+               : "memory");
+#else
+  dst64[lane_id()] = *src;
+#endif
+}
+WVF void lds_prefetch_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 WVF waff load_waff(const uint32_t *__restrict__ e20, const wk &k) {
@@ -1223,15 +1266,21 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
 #ifndef IBFT_ROWS_DEFER_SQRT
 #define IBFT_ROWS_DEFER_SQRT 1  // 1: √ and the final inversion from one exponentiation at the end (rows_finish_deferred); 0: √ first, safegcd last (A/B)
 #endif
-constexpr int ROW_TAB_SLOTS = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products
+#ifndef IBFT_ROWS_G_PREFETCH
+#define IBFT_ROWS_G_PREFETCH 1  // 1: the table points of u1·G go into LDS as soon as u1 is known (round 6); 0: read where they are added (A/B)
+#endif
+constexpr int ROW_TAB_G0 = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products, then (x, y) of the GTAB_WINDOWS points of u1·G
+constexpr int ROW_TAB_SLOTS = ROW_TAB_G0 + (IBFT_ROWS_G_PREFETCH ? 2 * ibftk::GTAB_WINDOWS : 0);
 template <int STOP = 99>
 WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
                            uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa, uint32_t *wtab) {
 #define WV_STAGE(n, keep)     \
   if (STOP == (n)) {          \
+    lds_prefetch_wait();      \
     addr[0] = (keep);         \
     return ok;                \
   }
+  // (the wait: a wavefront must not end with a prefetch into its LDS still on its way)
   const wk k = wk_init();
 #if defined(__HIP_DEVICE_COMPILE__) && defined(IBFT_ROWS_PAD_DWORDS)
   // code-placement experiment (profiles/r04n_*): every instruction behind this point moves by 4·IBFT_ROWS_PAD_DWORDS bytes
@@ -1264,6 +1313,23 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   const u256 u1 = secp::sc_neg_canon(secp::sc_canon(secp::sc_mul(secp::sc_from_u256(z_raw), rinv)));
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   WV_STAGE(22, skeep ^ u1.v[0] ^ u2.v[3])
+#if IBFT_ROWS_G_PREFETCH
+  // Round 6: the sixteen table points of u1·G are asked for NOW — global memory → wave-private LDS, no register, no wait —
+  // and are long there when the G additions come, ≈ 0.25 ms later.  Read where they were added they cost a dependent ≈ 1.8 µs
+  // fetch from an 84 MB table in front of each of the fifteen additions (one resident wavefront per SIMD: nobody to run
+  // meanwhile): 0.035 ms for fifteen additions of 1.3 µs (profiles/r05k_rows_stage_ms.txt).
+  {
+    const uint32_t ld = k.li < 10 ? k.li : 0u;  // (idle lanes fetch limb 0 and are masked at use)
+#pragma unroll
+    for (int win = 0; win < ibftk::GTAB_WINDOWS; win++) {
+      const int bit = win * ibftk::GTAB_BITS;
+      const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+      const uint32_t *e = gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt) + ld;
+      lds_prefetch_dword(wtab + (ROW_TAB_G0 + 2 * win) * 64, e);
+      lds_prefetch_dword(wtab + (ROW_TAB_G0 + 2 * win + 1) * 64, e + 10);
+    }
+  }
+#endif
   const secp::glv_split sp = secp::sc_split_lambda(u2);
   WV_STAGE(2, skeep ^ u1.v[0] ^ sp.k1.v[0] ^ sp.k2.v[1])
   // signed radix-16 digits of |k1|, |k2|: k + 0x88…8 has nibbles d_j + 8, bit 128 is digit 32
@@ -1453,11 +1519,18 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
 #else
   wjac &accg = acc;
 #endif
+#if IBFT_ROWS_G_PREFETCH
+  lds_prefetch_wait();  // (issued a quarter of a millisecond ago)
+  const uint32_t gl_ = lane_id();
+#define WV_GPOINT(win) waff{wtab[(ROW_TAB_G0 + 2 * (win)) * 64 + gl_] & k.act, wtab[(ROW_TAB_G0 + 2 * (win) + 1) * 64 + gl_] & k.act}
+#else
+#define WV_GPOINT(win) load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)(win) * ibftk::GTAB_ENTRIES + dgt), k)
+#endif
 #if IBFT_ROWS_PEEL && IBFT_ROWS_DEFER_SQRT
   // window 0 into an accumulator at infinity is the table point itself (or still infinity for a zero digit)
   {
     const uint32_t dgt = u1.v[0] & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
-    const waff pt = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * (size_t)dgt, k);
+    const waff pt = WV_GPOINT(0);
     accg = wjac_select(dgt != 0, wjac_from_aff(pt, k), accg);
   }
 #pragma unroll 1
@@ -1468,10 +1541,11 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
 #endif
     const int bit = win * ibftk::GTAB_BITS;
     const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
-    const waff pt = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + dgt), k);
+    const waff pt = WV_GPOINT(win);
     const wjac sum = wjac_add_aff<true>(accg, pt, k);
     accg = wjac_select(dgt != 0, sum, accg);
   }
+#undef WV_GPOINT
   WV_STAGE(5, acc.x ^ acc.y ^ acc.z ^ accg.x ^ accg.z)
 #if IBFT_ROWS_DEFER_SQRT
   ok = rows_finish_deferred(Qa, accg, acc, rhs, v, k) && ok;

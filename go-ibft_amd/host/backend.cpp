@@ -75,9 +75,18 @@ static void unpack_mask(const std::vector<uint64_t> &mask, size_t n, std::vector
   for (size_t i = 0; i < n; i++) v[i] = (mask[i >> 6] >> (i & 63)) & 1;
 }
 
+GpuBackend::GpuBackend(ibft_ctx *ctx) : ctx_(ctx) {
+  if (const char *e = getenv("IBFT_MIN_DEVICE_ROWS")) {
+    char *end = nullptr;
+    const unsigned long long v = strtoull(e, &end, 10);
+    if (end != e && *end == '\0') min_device_rows = (size_t)v;
+  }
+}
+
 bool GpuBackend::VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
                                     std::vector<uint8_t> &verdict) {
   verdict.assign(msgs.size(), 0);
+  if (declines(msgs.size())) return false;
   if (!proposal || msgs.empty()) return true;  // nil proposal: every hash check is false
   SealColumns c;
   flatten_prepares(msgs, c);
@@ -92,6 +101,7 @@ bool GpuBackend::VerifyPrepareBatch(const Proposal *proposal, const std::vector<
 bool GpuBackend::VerifyCommitBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
                                    std::vector<uint8_t> &verdict) {
   verdict.assign(msgs.size(), 0);
+  if (declines(msgs.size())) return false;
   if (!proposal || msgs.empty()) return true;
   SealColumns c;
   flatten_commits(msgs, c);
@@ -110,6 +120,7 @@ bool GpuBackend::VerifyCommitBatch(const Proposal *proposal, const std::vector<M
 }
 
 int GpuBackend::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) {
+  if (declines(senders.size())) return -1;  // (a map walk over a handful of senders beats a launch)
   if (proposer && proposer->size() != 20) return -1;
   std::vector<uint8_t> col(senders.size() * 20);
   for (size_t i = 0; i < senders.size(); i++) {
@@ -125,6 +136,11 @@ int GpuBackend::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *
 }
 
 bool GpuBackend::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &verdict) {
+  verdict.assign(msgs.size(), 0);
+  if (declines(msgs.size())) return false;
+  return sender_batch(msgs, verdict);
+}
+bool GpuBackend::sender_batch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &verdict) {
   verdict.assign(msgs.size(), 0);
   if (msgs.empty()) return true;
   SenderColumns c;
@@ -142,6 +158,7 @@ bool GpuBackend::VerifyMessageSet(const Proposal *proposal, MessageType type, co
   sender.assign(msgs.size(), 0);
   closure.assign(msgs.size(), 0);
   if ((type != PREPARE && type != COMMIT) || !proposal) return false;  // nothing to check the hashes against
+  if (declines(msgs.size())) return false;
   if (msgs.empty()) return true;
   SenderColumns sc;
   flatten_senders(msgs, sc);
@@ -162,6 +179,7 @@ bool GpuBackend::VerifyMessageSet(const Proposal *proposal, MessageType type, co
 bool GpuBackend::VerifySendersWire(const uint8_t *wire, const uint32_t *off, size_t n, std::vector<uint8_t> &verdict,
                                    WireStats *stats) {
   verdict.assign(n, 0);
+  if (declines(n)) return false;
   if (n == 0) return true;
   std::vector<uint64_t> mask((n + 63) / 64, 0);
   std::vector<ibft_wire_row_t> rows(n);
@@ -185,7 +203,7 @@ bool GpuBackend::VerifySendersWire(const uint8_t *wire, const uint32_t *off, siz
   }
   if (msgs.empty()) return true;
   std::vector<uint8_t> v2;
-  if (!VerifySenderBatch(msgs, v2)) return false;
+  if (!sender_batch(msgs, v2)) return false;  // (the few rows of an accepted batch that take the stock route: no min-rows rule)
   for (size_t j = 0; j < idx.size(); j++) verdict[idx[j]] = v2[j];
   return true;
 }
@@ -196,6 +214,7 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
   sender.assign(n, 0);
   closure.assign(n, 0);
   judged.assign(n, 0);
+  if (declines(n)) return false;
   if (n == 0) return true;
   std::vector<uint64_t> ms((n + 63) / 64, 0), mv((n + 63) / 64, 0);
   std::vector<uint8_t> cls(n, 0);
@@ -220,7 +239,7 @@ bool GpuBackend::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, si
   }
   if (msgs.empty()) return true;
   std::vector<uint8_t> v2;
-  if (!VerifySenderBatch(msgs, v2)) return false;
+  if (!sender_batch(msgs, v2)) return false;
   for (size_t j = 0; j < idx.size(); j++) sender[idx[j]] = v2[j];
   return true;
 }
@@ -466,14 +485,14 @@ bool LoopBatch::VerifyCertificatesWire(const uint8_t *wire, const uint32_t *off,
 }
 
 bool LoopBatch::VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
-  if (fail_hashes) return false;
+  if (fail_hashes || declines(msgs.size())) return false;
   calls++;
   v.assign(msgs.size(), 0);
   for (size_t i = 0; i < msgs.size(); i++) v[i] = v_->IsValidProposalHash(proposal, extract_prepare_hash(*msgs[i]));
   return true;
 }
 bool LoopBatch::VerifyCommitBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
-  if (fail_hashes || fail_seals) return false;
+  if (fail_hashes || fail_seals || declines(msgs.size())) return false;
   calls++;
   v.assign(msgs.size(), 0);
   for (size_t i = 0; i < msgs.size(); i++) {
@@ -484,7 +503,7 @@ bool LoopBatch::VerifyCommitBatch(const Proposal *proposal, const std::vector<Ms
   return true;
 }
 int LoopBatch::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *proposer) {
-  if (!quorum_vm || fail_quorum || !quorum_vm->initialized()) return -1;
+  if (!quorum_vm || fail_quorum || !quorum_vm->initialized() || declines(senders.size())) return -1;
   quorum_calls++;
   std::unordered_set<std::string_view, sv_hash> set;
   if (proposer) set.emplace(proposer->data(), proposer->size());
@@ -500,7 +519,7 @@ int LoopBatch::QuorumOfSenders(const std::vector<bytes> &senders, const bytes *p
 }
 
 bool LoopBatch::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<uint8_t> &v) {
-  if (fail_senders) return false;
+  if (fail_senders || declines(msgs.size())) return false;
   calls++;
   v.assign(msgs.size(), 0);
   for (size_t i = 0; i < msgs.size(); i++) v[i] = v_->IsValidValidator(*msgs[i]);
@@ -509,7 +528,7 @@ bool LoopBatch::VerifySenderBatch(const std::vector<MsgPtr> &msgs, std::vector<u
 
 bool LoopBatch::VerifyMessageSet(const Proposal *proposal, MessageType type, const std::vector<MsgPtr> &msgs,
                                  std::vector<uint8_t> &sender, std::vector<uint8_t> &closure) {
-  if (fail_sets || !proposal || (type != PREPARE && type != COMMIT)) return false;
+  if (fail_sets || !proposal || (type != PREPARE && type != COMMIT) || declines(msgs.size())) return false;
   calls++;
   set_calls++;
   sender.assign(msgs.size(), 0);
@@ -530,7 +549,7 @@ bool LoopBatch::VerifyMessageSet(const Proposal *proposal, MessageType type, con
 bool LoopBatch::VerifyMessagesWire(const uint8_t *wire, const uint32_t *off, size_t n, uint64_t height, uint64_t round,
                                    const Proposal &proposal, std::vector<uint8_t> &sender, std::vector<uint8_t> &closure,
                                    std::vector<uint8_t> &judged) {
-  if (fail_sets) return false;
+  if (fail_sets || declines(n)) return false;
   calls++;
   set_calls++;
   sender.assign(n, 0);

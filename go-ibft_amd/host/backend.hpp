@@ -42,6 +42,19 @@ struct CertVerdicts {
 
 struct BatchVerifier {
   virtual ~BatchVerifier() = default;
+  // SURVEY §5 "min batch for GPU" (round 6).  A launch has a floor of ≈ 0.2 ms whatever the row count, one core recovers a
+  // signature in ≈ 31–50 µs: below a handful of rows the per-message Verifier is FASTER than the device — and every validator
+  // count the reference itself tests lives there (4: core/consensus_test.go:139, 6: core/byzantine_test.go:21, ≤ 30:
+  // core/rapid_test.go:156).  A batch with fewer than min_device_rows rows is DECLINED: the batch method answers false /
+  // −1, exactly what it answers when the device is unavailable, and the caller runs the stock closures (same verdicts by
+  // construction — the fallback path of every handler).  0 = never decline.  The measured crossover: INTEGRATION.md §2.
+  size_t min_device_rows = 0;
+  size_t declined = 0;  // batches answered "not offered" for being too small
+  bool declines(size_t rows) {
+    if (rows == 0 || rows >= min_device_rows) return false;
+    declined++;
+    return true;
+  }
   // verdict[i] == what handlePrepare's closure would return for msgs[i] (ibft.go:856-862)
   virtual bool VerifyPrepareBatch(const Proposal *proposal, const std::vector<MsgPtr> &msgs,
                                   std::vector<uint8_t> &verdict) = 0;
@@ -98,7 +111,8 @@ void flatten_senders(const std::vector<MsgPtr> &msgs, SenderColumns &out);
 
 class GpuBackend : public BatchVerifier {
  public:
-  explicit GpuBackend(ibft_ctx *ctx) : ctx_(ctx) {}
+  // IBFT_MIN_DEVICE_ROWS (environment): the node operator's knob, read once per backend; ibft_host_set_min_device_rows overrides
+  explicit GpuBackend(ibft_ctx *ctx);
   bool VerifyPrepareBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifyCommitBatch(const Proposal *, const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
   bool VerifySenderBatch(const std::vector<MsgPtr> &, std::vector<uint8_t> &) override;
@@ -128,6 +142,7 @@ class GpuBackend : public BatchVerifier {
   int last_rc = 0;
 
  private:
+  bool sender_batch(const std::vector<MsgPtr> &, std::vector<uint8_t> &);  // VerifySenderBatch without the min-rows rule
   ibft_ctx *ctx_;
 };
 

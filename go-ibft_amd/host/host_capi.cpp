@@ -216,6 +216,8 @@ struct ibft_host {
   CallbackVerifier cbv;
   std::unique_ptr<GpuBackend> gpu;
   std::unique_ptr<LoopBatch> loop;
+  size_t min_device_rows = 0;        // ibft_host_set_min_device_rows (the environment's IBFT_MIN_DEVICE_ROWS otherwise)
+  bool min_device_rows_set = false;
   size_t last_set_rows = 0;
   std::unique_ptr<IngestQueue> queue;  // declared last: its worker is joined before anything above is destroyed
 };
@@ -567,6 +569,7 @@ void ibft_host_set_verifier(ibft_host *h, const ibft_host_verifier *v) {
 void ibft_host_attach_gpu(ibft_host *h, ibft_ctx *ctx) {
   std::lock_guard<std::recursive_mutex> lk_(h->mu);
   h->gpu = ctx ? std::make_unique<GpuBackend>(ctx) : nullptr;
+  if (h->gpu && h->min_device_rows_set) h->gpu->min_device_rows = h->min_device_rows;
   h->hp.batch = h->gpu.get();
 }
 void ibft_host_use_batch(ibft_host *h, int on) { std::lock_guard<std::recursive_mutex> lk_(h->mu); h->hp.use_batch = on != 0; }
@@ -737,7 +740,21 @@ void ibft_host_use_loop_batch(ibft_host *h, int fail_mask) {
   h->loop->fail_certs = (fail_mask & 16) != 0;
   h->loop->fail_quorum = (fail_mask & 32) != 0;
   h->loop->wrong_quorum = (fail_mask & 64) != 0;
+  if (h->min_device_rows_set) h->loop->min_device_rows = h->min_device_rows;
   h->hp.batch = h->loop.get();
+}
+// SURVEY §5 "min batch for GPU": batches below `rows` rows are declined by the batch verifier (device or loop) and the stock
+// closures run — backend.hpp: BatchVerifier::min_device_rows.  Applies to the verifier attached NOW and to any attached later.
+void ibft_host_set_min_device_rows(ibft_host *h, size_t rows) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  h->min_device_rows = rows;
+  h->min_device_rows_set = true;
+  if (h->gpu) h->gpu->min_device_rows = rows;
+  if (h->loop) h->loop->min_device_rows = rows;
+}
+size_t ibft_host_declined_batches(ibft_host *h) {
+  std::lock_guard<std::recursive_mutex> lk_(h->mu);
+  return (h->gpu ? h->gpu->declined : 0) + (h->loop ? h->loop->declined : 0);
 }
 size_t ibft_host_loop_batch_calls(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->loop ? h->loop->calls : 0; }
 size_t ibft_host_fallbacks(ibft_host *h) { std::lock_guard<std::recursive_mutex> lk_(h->mu); return h->hp.fallbacks; }

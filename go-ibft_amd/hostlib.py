@@ -143,6 +143,8 @@ def lib() -> C.CDLL:
         L.ibft_host_use_loop_batch.argtypes = [vp, C.c_int]
         L.ibft_host_loop_batch_calls.argtypes = [vp]; L.ibft_host_loop_batch_calls.restype = C.c_size_t
         L.ibft_host_fallbacks.argtypes = [vp]; L.ibft_host_fallbacks.restype = C.c_size_t
+        L.ibft_host_set_min_device_rows.argtypes = [vp, C.c_size_t]; L.ibft_host_set_min_device_rows.restype = None
+        L.ibft_host_declined_batches.argtypes = [vp]; L.ibft_host_declined_batches.restype = C.c_size_t
         L.ibft_host_use_sets.argtypes = [vp, C.c_int]; L.ibft_host_use_sets.restype = None
         for nm in ('ibft_host_last_set_rows', 'ibft_host_closure_hits', 'ibft_host_loop_batch_set_calls',
                    'ibft_host_loop_batch_cert_calls'):
@@ -611,3 +613,10 @@ class Host:
 
     def fallbacks(self) -> int:
         return self.L.ibft_host_fallbacks(self.h)
+
+    def set_min_device_rows(self, rows: int):
+        """SURVEY §5 "min batch for GPU": batches below `rows` rows are declined by the batch backend, the stock closures run"""
+        self.L.ibft_host_set_min_device_rows(self.h, rows)
+
+    def declined_batches(self) -> int:
+        return self.L.ibft_host_declined_batches(self.h)

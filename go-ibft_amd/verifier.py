@@ -41,7 +41,7 @@ EXPORTS = [
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
     "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info", "ibft_set_seal_digest", "ibft_group_set_seal_digest",
     "ibft_seals_stage_next", "ibft_seals_swap", "ibft_last_cold_table", "ibft_seals_submit", "ibft_seals_collect",
-    "ibft_comm_preload",
+    "ibft_comm_preload", "ibft_issue_probe", "ibft_seals_rows",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -107,7 +107,7 @@ def powers_be32(powers) -> np.ndarray:
 
 
 _lib = None
-ABI_VERSION = 2   # include/ibftgpu.h: ibft_version()
+ABI_VERSION = 3   # include/ibftgpu.h: ibft_version()  (3: the round-5/6 exports — a version-2 library lacks them)
 
 
 def load_library() -> C.CDLL:
@@ -123,6 +123,9 @@ def load_library() -> C.CDLL:
     L.ibft_version.restype = C.c_int
     if L.ibft_version() < ABI_VERSION:   # a stale .so writes past the caller's ibft_tally_t (48 → 56 bytes at version 2)
         raise GpuUnavailable(f"{lib_path}: ibft_version() = {L.ibft_version()}, this binding needs >= {ABI_VERSION} — rebuild")
+    missing = [name for name in EXPORTS if not hasattr(L, name)]   # BEFORE the prototypes below touch any of them
+    if missing:
+        raise GpuUnavailable(f"{lib_path} lacks {', '.join(missing)} — a stale build: rebuild")
     L.ibft_strerror.argtypes = [C.c_int]; L.ibft_strerror.restype = C.c_char_p
     L.ibft_last_error.argtypes = [vp]; L.ibft_last_error.restype = C.c_char_p
     L.ibft_ctx_create.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
@@ -164,6 +167,8 @@ def load_library() -> C.CDLL:
     L.ibft_cache_stats.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.ibft_last_dispatch.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_sync.argtypes = [vp]
+    L.ibft_issue_probe.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ibft_seals_rows.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_verify_senders_wire.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(Tally)]
     L.ibft_wire_stage_seals.argtypes = [vp]
     L.ibft_verify_certificates_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp, vp]
@@ -580,6 +585,12 @@ class BatchVerifier:
         self._submitted.pop(0)
         return mask_to_bool(mask, n), t
 
+    def seals_rows(self):
+        """ibft_seals_rows: (rows of the resident batch, rows of the oldest submitted pass or 0) as the LIBRARY counts them"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self._chk(self._L.ibft_seals_rows(self._h, C.byref(a), C.byref(b)), "ibft_seals_rows")
+        return int(a.value), int(b.value)
+
     def seals_launch(self, repeat: int = 1) -> None:
         self._chk(self._L.ibft_seals_launch(self._h, repeat), "ibft_seals_launch")
         self._launched = self._staged
@@ -697,6 +708,13 @@ class BatchVerifier:
 
     def sync(self):
         self._chk(self._L.ibft_sync(self._h), "ibft_sync")
+
+    def issue_probe(self):
+        """ibft_issue_probe: (ns per aligned 8-byte VALU instruction per SIMD at one wavefront per SIMD, ms of the probe
+        kernel) — 1.79 ns on a healthy MI355X"""
+        ns, ms = C.c_float(0), C.c_float(0)
+        self._chk(self._L.ibft_issue_probe(self._h, C.byref(ns), C.byref(ms)), "ibft_issue_probe")
+        return float(ns.value), float(ms.value)
 
 
 class DeviceGroup:

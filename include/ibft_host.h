@@ -273,6 +273,16 @@ void ibft_host_use_loop_batch(ibft_host *h, int fail_mask);
 size_t ibft_host_loop_batch_calls(ibft_host *h);
 /* batches that fell back to the per-message verifier because the batch backend reported failure            */
 size_t ibft_host_fallbacks(ibft_host *h);
+/* SURVEY.md §5 "min batch for GPU" (round 6): a batch of fewer than `rows` rows is DECLINED by the batch backend — it
+ * answers "not offered", as it does when the device is unavailable — and the stock per-message closures of
+ * core/ibft.go:856-862 / 932-944 / 1128 run: a launch has a floor of ≈ 0.2 ms whatever the row count, one host core
+ * recovers a signature in 31–50 µs, and every validator count the reference itself tests (4, 6, ≤ 30:
+ * core/consensus_test.go:139, core/byzantine_test.go:21, core/rapid_test.go:156) lies around that crossover
+ * (INTEGRATION.md §2 has the measured table).  0 = never decline (the default; the environment variable
+ * IBFT_MIN_DEVICE_ROWS sets it for every mirror of the process that does not call this).  Verdicts are the same either
+ * way — the declined batch takes the fallback path every handler has.                                                   */
+void ibft_host_set_min_device_rows(ibft_host *h, size_t rows);
+size_t ibft_host_declined_batches(ibft_host *h);
 /* Certificate checks (core/ibft.go: validPC :1162-1231, proposalMatchesCertificate :516-551,
  * validateProposal0 :658-680, validateProposal :683-788).  NULL wire pointers are Go nils.  With
  * ibft_host_use_batch(1) and a GPU attached, all sender signatures / hashes of the certificate go

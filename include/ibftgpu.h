@@ -314,9 +314,17 @@ int ibft_seals_run(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
  * flight the launch of pass k+1 overlaps the completion, result delivery and host handling of pass k: the device runs
  * back to back, as a node's does when batches arrive faster than one host round trip (and as a rank's does in the
  * sharded form, where exchange k overlaps the kernels of pass k+1).  Combines with the staging slots:
- * submit(k) → stage_next(k+1) → collect(k−1) → swap.                                                                  */
+ * submit(k) → stage_next(k+1) → collect(k−1) → swap.
+ * out_mask of a collect holds ⌈rows/64⌉ words for the rows of THAT pass (the batch resident when it was submitted —
+ * ibft_seals_rows says how many; a swap in between may have changed the resident batch's size).  With the key cache on, a
+ * collect whose pass taught the device new keys builds their tables before it returns, which drains the context's whole
+ * stream — the newer pass in flight included: the cold-to-warm transition costs one full wait.  A failure of that table
+ * build takes nothing from the pass just delivered (IBFT_OK, verdicts valid); the next ibft_seals_submit returns it.   */
 int ibft_seals_submit(ibft_ctx *ctx);
 int ibft_seals_collect(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
+/* Rows of the resident seal batch, and of the oldest pass submitted and not yet collected (0: none in flight): what a
+ * binding sizes the out_mask of ibft_seals_run / _fetch / _collect from.                                              */
+int ibft_seals_rows(ibft_ctx *ctx, uint32_t *resident_rows, uint32_t *oldest_pass_rows);
 int ibft_seals_stage_next(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
                           const uint8_t *signer20, const uint8_t *pre_flags, size_t n);
 int ibft_seals_swap(ibft_ctx *ctx, int wait_for_copy);
@@ -520,6 +528,12 @@ int ibft_sign_seals(ibft_ctx *ctx, const uint8_t *sk32, const uint8_t *hash32, s
                     uint8_t *out_signer20, uint8_t *out_ok);
 /* Block the host until the context's stream is idle.                               */
 int ibft_sync(ibft_ctx *ctx);
+/* Device canary (diagnostic; no reference counterpart — a Backend may log it at start-up and a bench line carries it):
+ * the verdict kernels are bound by VALU issue, so a sick or shared device shows in one number.  Runs a 0.24 ms kernel
+ * of independent 8-byte VALU instructions at one wavefront per SIMD (three untimed launches, median of five timed)
+ * on the context's stream and reports the wall time per instruction per SIMD: 1.79 ns on a healthy MI355X
+ * (profiles/r05a_ubench_wave.txt); > 5 % off means every throughput figure of that device is off by as much.   */
+int ibft_issue_probe(ibft_ctx *ctx, float *ns_per_inst, float *kernel_ms);
 
 /* ---- multi-GPU (BASELINE configs #4 / #5) -------------------------------------------
  * Rows are independent, so a batch of n_total rows is split into `world` contiguous row ranges whose

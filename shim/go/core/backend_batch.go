@@ -10,9 +10,31 @@
 package core
 
 import (
+	"os"
+	"strconv"
+
 	"github.com/0xPolygon/go-ibft/messages"
 	"github.com/0xPolygon/go-ibft/messages/proto"
 )
+
+// MinDeviceRows is SURVEY §5's "min batch for GPU" knob (the environment's IBFT_MIN_DEVICE_ROWS, 0 = never decline).  A launch
+// has a floor of ≈ 0.2 ms whatever the row count, one host core recovers a signature in 31–50 µs: below a handful of rows the
+// stock closures are FASTER than the device, and every validator count the reference itself tests lives there (4:
+// core/consensus_test.go:139, 6: core/byzantine_test.go:21, ≤ 30: core/rapid_test.go:156).  A batch with fewer rows is not
+// offered to the BatchVerifier at all — the callers below treat it exactly like ok == false and run the per-message closure
+// (same verdicts by construction).  The measured crossover and the recommended value: INTEGRATION.md §2.  The C++ mirror's
+// statement of the same rule: go-ibft_amd/host/backend.hpp (BatchVerifier::declines), tests/test_host_device_quorum.py.
+var MinDeviceRows = envRows("IBFT_MIN_DEVICE_ROWS")
+
+func envRows(name string) int {
+	if v, err := strconv.Atoi(os.Getenv(name)); err == nil && v > 0 {
+		return v
+	}
+	return 0
+}
+
+// tooFewForDevice reports whether a batch of n rows stays on the host (MinDeviceRows).
+func tooFewForDevice(n int) bool { return n < MinDeviceRows }
 
 // BatchVerifier is type-asserted on the Backend passed to NewIBFT.
 type BatchVerifier interface {
@@ -57,8 +79,12 @@ func (i *IBFT) commitMessagesFor(view *proto.View) []*proto.IbftMessage {
 				if len(rest) == 0 {
 					return verdicts
 				}
-				vr, ok := bv.VerifyCommitBatch(i.state.getProposal(), rest)
-				if !ok || len(vr) != len(rest) { // device unavailable: the per-message verifier, same lock held
+				var vr []bool
+				ok := false
+				if !tooFewForDevice(len(rest)) {
+					vr, ok = bv.VerifyCommitBatch(i.state.getProposal(), rest)
+				}
+				if !ok || len(vr) != len(rest) { // device unavailable or batch too small: the per-message verifier, same lock held
 					fellBack = true
 					vr = make([]bool, len(rest))
 					for k, m := range rest {
@@ -90,7 +116,11 @@ func (i *IBFT) prepareMessagesFor(view *proto.View) []*proto.IbftMessage {
 				if len(rest) == 0 {
 					return verdicts
 				}
-				vr, ok := bv.VerifyPrepareBatch(i.state.getProposal(), rest)
+				var vr []bool
+				ok := false
+				if !tooFewForDevice(len(rest)) {
+					vr, ok = bv.VerifyPrepareBatch(i.state.getProposal(), rest)
+				}
 				if !ok || len(vr) != len(rest) {
 					vr = make([]bool, len(rest))
 					for k, m := range rest {

@@ -107,7 +107,11 @@ func (i *IBFT) AddMessages(batch []*proto.IbftMessage) {
 		if len(ofType[k]) == 0 {
 			continue
 		}
-		sender, closure, ok := sv.VerifyMessageSet(proposal, t, ofType[k])
+		var sender, closure []bool
+		ok := false
+		if !tooFewForDevice(len(ofType[k])) { // (MinDeviceRows, backend_batch.go)
+			sender, closure, ok = sv.VerifyMessageSet(proposal, t, ofType[k])
+		}
 		if !ok || len(sender) != len(ofType[k]) || len(closure) != len(ofType[k]) {
 			for _, m := range ofType[k] {
 				i.AddMessage(m)

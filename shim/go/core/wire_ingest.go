@@ -46,13 +46,13 @@ func (i *IBFT) AddWireMessages(raw [][]byte) {
 			return
 		}
 	}
-	if ws, hasSets := i.backend.(WireSetVerifier); hasSets && i.state.getProposal() != nil {
+	if ws, hasSets := i.backend.(WireSetVerifier); hasSets && i.state.getProposal() != nil && !tooFewForDevice(len(raw)) {
 		if i.addWireSets(ws, raw) {
 			return
 		}
 	}
 	wv, hasWire := i.backend.(WireVerifier)
-	if !hasWire {
+	if !hasWire || tooFewForDevice(len(raw)) { // (MinDeviceRows, backend_batch.go: a handful of messages stays on the host)
 		i.addWireStock(raw, nil)
 		return
 	}

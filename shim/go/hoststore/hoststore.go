@@ -103,9 +103,11 @@ func (s *Store) Close() {
 		C.ibft_host_free(s.h)
 		s.h = nil
 		s.self.Delete()
-	}
-	if s.Messages != nil {
-		s.Messages.Close()
+		// once, with the handle: the reference's eventManager.close() closes every subscription's doneCh and leaves the
+		// subscriptions in the map, so a second call (a deferred Close plus an explicit one) would close a closed channel
+		if s.Messages != nil {
+			s.Messages.Close()
+		}
 	}
 }
 
@@ -177,11 +179,15 @@ func (s *Store) AddWireMessages(raw [][]byte) error {
 	for _, m := range raw {
 		total += len(m)
 	}
-	// offsets are 32 bits on the C side: a batch past that is split in two pushes (a single message that large is
-	// refused — the queue's own byte cap, ibft_host_queue_set_caps, is far below it)
+	// offsets are 32 bits on the C side: a batch past that is split in two pushes.  A single message that large can
+	// never be pushed (the queue's own byte cap, ibft_host_queue_set_caps, is far below it): every message is checked
+	// BEFORE anything is queued, so that a refusal never leaves the first half of the batch ingested and the caller unable
+	// to tell (ADVICE round 5).
 	if uint64(total) > maxPushBytes {
-		if len(raw) == 1 {
-			return ErrUnavailable
+		for _, m := range raw {
+			if uint64(len(m)) > maxPushBytes {
+				return ErrUnavailable
+			}
 		}
 		if err := s.AddWireMessages(raw[:len(raw)/2]); err != nil {
 			return err

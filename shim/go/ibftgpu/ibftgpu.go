@@ -62,7 +62,13 @@ type Tally struct {
 // core/ibft.go:335-347 — from a FIXED set (a buffered channel of contexts, not a sync.Pool: the validator
 // table and the key cache live in the context, so SetValidators must reach every one of them and none
 // may be dropped by the garbage collector; INTEGRATION.md §2).
-type Ctx struct{ h *C.ibft_ctx }
+type Ctx struct {
+	h *C.ibft_ctx
+	// the Go slices of a batch handed to SealsStageNext: the library's copy stream reads them AFTER the cgo call has
+	// returned, so they are pinned (runtime.Pinner: the collector neither moves nor frees them) until SealsSwap has waited
+	// for that copy
+	next runtime.Pinner
+}
 
 // Options mirrors ibft_cfg.  KeyCache turns on the warm path (IBFT_FLAG_PUBKEY_CACHE): the
 // first valid signature of a validator teaches the device its public key, later ones are verified
@@ -75,8 +81,9 @@ type Options struct {
 }
 
 // abiVersion is what this binding was written against (include/ibftgpu.h: ibft_version; 2 = ibft_tally_t with
-// proposer_rows, 56 bytes): an older library would write a shorter struct, a binding older than the library a longer one.
-const abiVersion = 2
+// proposer_rows, 56 bytes: an older library would write a shorter struct; 3 = the staged / pipelined pass calls,
+// ibft_seals_rows, ibft_issue_probe: a version-2 library lacks symbols this file links against).
+const abiVersion = 3
 
 func New(o Options) (*Ctx, error) {
 	if v := int(C.ibft_version()); v < abiVersion {
@@ -100,9 +107,10 @@ func New(o Options) (*Ctx, error) {
 
 func (c *Ctx) Close() {
 	if c.h != nil {
-		C.ibft_ctx_destroy(c.h)
+		C.ibft_ctx_destroy(c.h) // (drains the context's streams: nothing reads the pinned slices any more)
 		c.h = nil
 	}
+	c.next.Unpin()
 }
 
 // SetSealDigest tells the context WHAT a committed seal signs in this Backend (core/backend.go:53-55 leaves it open):
@@ -351,9 +359,30 @@ func (c *Ctx) VerifySendersWire(wire []byte, off []uint32) ([]uint64, []WireRow,
 // follow with SealsRun (IsValidCommittedSeal without a second upload).
 func (c *Ctx) StageWireSeals() error { return c.check(C.ibft_wire_stage_seals(c.h)) }
 
-// SealsRun = one pass of IsValidCommittedSeal + HasQuorum over the RESIDENT seal batch of n rows
-// (ibft_seals_run: launch + fetch).
-func (c *Ctx) SealsRun(n int) ([]uint64, Tally, error) {
+// sealRows asks the LIBRARY how many rows the resident batch and the oldest submitted pass have (ibft_seals_rows): verdict
+// buffers are sized from these, never from a count the caller passes along — a count that is too small would let C write
+// past the Go slice (ADVICE round 5).
+func (c *Ctx) sealRows() (resident, oldest int, err error) {
+	var a, b C.uint32_t
+	if err = c.check(C.ibft_seals_rows(c.h, &a, &b)); err != nil {
+		return 0, 0, err
+	}
+	return int(a), int(b), nil
+}
+
+// SealsRows = rows of the resident seal batch as the library counts them.
+func (c *Ctx) SealsRows() (int, error) {
+	n, _, err := c.sealRows()
+	return n, err
+}
+
+// SealsRun = one pass of IsValidCommittedSeal + HasQuorum over the RESIDENT seal batch
+// (ibft_seals_run: launch + fetch); the mask has a word per 64 resident rows (SealsRows).
+func (c *Ctx) SealsRun() ([]uint64, Tally, error) {
+	n, _, err := c.sealRows()
+	if err != nil {
+		return nil, Tally{}, err
+	}
 	mask := make([]uint64, (n+63)/64+1)
 	var t C.ibft_tally_t
 	rc := C.ibft_seals_run(c.h, (*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
@@ -363,11 +392,27 @@ func (c *Ctx) SealsRun(n int) ([]uint64, Tally, error) {
 // SealsStageNext copies the NEXT seal batch into the context's spare column set on a copy stream of its own while the
 // kernels of the resident batch run; SealsSwap makes it the resident batch.  Per step of a sustained stream of COMMIT
 // sets (one GetValidMessages walk per wake-up, core/ibft.go:931-946): SealsLaunch(k) → SealsStageNext(k+1) →
-// SealsFetch(k) → SealsSwap.  The columns must stay untouched until SealsSwap returns (it waits for the copy); allocate
-// them with PinnedAlloc for the copy to overlap.
+// SealsFetch(k) → SealsSwap.  Every column must hold exactly n = len(sig65)/65 rows (ErrFallback otherwise: the copy would
+// read past a slice); preFlags may be nil.  The copy is asynchronous — the library reads the slices after this call has
+// returned — so they are pinned here until SealsSwap (cgo's pointer rule; the caller must not write to them before
+// either).  Slices carved from PinnedBytes are page-locked as well, and only then does the copy overlap the kernels.
 func (c *Ctx) SealsStageNext(hash32, sig65, signer20, preFlags []byte) error {
 	n := len(sig65) / 65
-	return c.check(C.ibft_seals_stage_next(c.h, ptr8(hash32), ptr8(sig65), ptr8(signer20), ptr8(preFlags), C.size_t(n)))
+	if n == 0 || len(sig65) != 65*n || len(hash32) != 32*n || len(signer20) != 20*n || (preFlags != nil && len(preFlags) != n) {
+		return ErrFallback
+	}
+	c.next.Unpin() // (a batch staged and never swapped in is replaced: the library restarts the copy)
+	c.next.Pin(&hash32[0])
+	c.next.Pin(&sig65[0])
+	c.next.Pin(&signer20[0])
+	if preFlags != nil {
+		c.next.Pin(&preFlags[0])
+	}
+	err := c.check(C.ibft_seals_stage_next(c.h, ptr8(hash32), ptr8(sig65), ptr8(signer20), ptr8(preFlags), C.size_t(n)))
+	if err != nil {
+		c.next.Unpin()
+	}
+	return err
 }
 
 // SealsSubmit enqueues one more pass over the resident seal batch and returns at once (at most two in flight);
@@ -375,16 +420,36 @@ func (c *Ctx) SealsStageNext(hash32, sig65, signer20, preFlags []byte) error {
 // lets the device run back to back while Go handles the previous pass's result (ibft_seals_submit / ibft_seals_collect).
 func (c *Ctx) SealsSubmit() error { return c.check(C.ibft_seals_submit(c.h)) }
 
-// SealsCollect: see SealsSubmit.  n = rows of the batch that pass ran over.
-func (c *Ctx) SealsCollect(n int) ([]uint64, Tally, error) {
-	mask := make([]uint64, (n+63)/64+1)
-	var t C.ibft_tally_t
-	rc := C.ibft_seals_collect(c.h, (*C.uint64_t)(unsafe.Pointer(&mask[0])), &t)
-	return mask, tally(t), c.check(rc)
+// SealsCollect: see SealsSubmit.  The mask is sized for the rows of THAT pass as the library recorded them at submit time
+// (a SealsSwap to a batch of another size may have come in between); rows = that count.
+func (c *Ctx) SealsCollect() (mask []uint64, rows int, t Tally, err error) {
+	_, rows, err = c.sealRows()
+	if err != nil {
+		return nil, 0, Tally{}, err
+	}
+	if rows == 0 {
+		return nil, 0, Tally{}, ErrFallback // nothing submitted
+	}
+	mask = make([]uint64, (rows+63)/64+1)
+	var ct C.ibft_tally_t
+	rc := C.ibft_seals_collect(c.h, (*C.uint64_t)(unsafe.Pointer(&mask[0])), &ct)
+	return mask, rows, tally(ct), c.check(rc)
 }
 
-// SealsSwap: see SealsStageNext.
-func (c *Ctx) SealsSwap() error { return c.check(C.ibft_seals_swap(c.h, 1)) }
+// SealsSwap: see SealsStageNext.  Waits for the copy of the staged batch, after which its Go slices are released.
+func (c *Ctx) SealsSwap() error {
+	err := c.check(C.ibft_seals_swap(c.h, 1))
+	c.next.Unpin()
+	return err
+}
+
+// IssueProbe = the device canary (ibft_issue_probe): wall nanoseconds per aligned 8-byte VALU instruction per SIMD at one
+// wavefront per SIMD — 1.79 on a healthy MI355X; a Backend logs it at start-up.
+func (c *Ctx) IssueProbe() (nsPerInst float32, err error) {
+	var ns, ms C.float
+	err = c.check(C.ibft_issue_probe(c.h, &ns, &ms))
+	return float32(ns), err
+}
 
 // SignSeals = n × Backend.BuildCommitMessage's committed seal (core/backend.go:12-34) for a SIMULATOR that plays
 // n validators in one process: sk and hashes are n×32 bytes; returns the n×65 seals, the n×20 signer addresses

@@ -99,9 +99,17 @@ def test_dry_run_gpus_n_relaunches_shards_exchanges_and_merges(world):
     assert rec["config"]["parallelism"] == f"rows sharded x{world}"
     if world == 4:
         assert "BASELINE config #4" in rec["config"]["workload"]
-    if world == 8:                                  # the driver's largest run also carries BASELINE config #5 (8 x 8 192 rows, 20 % bad)
-        c5 = rec["config5"]
-        assert (c5["validators"], c5["rows_per_gpu"], c5["rccl_nranks"]) == (65536, 8192, 8) and 0.79 < c5["valid_fraction"] < 0.81
+    # round 6: every N > 1 line carries the sharded sweep — N_total = 16 384 and 65 536 split over the ranks (config #4 at
+    # G = 4 and config #5 at G = 8 fall out of it); one row per size in the headline, the full entries in the detail record
+    sw = rec["sharded_sweep"]
+    assert [(r[0], r[1]) for r in sw] == [(16384, 16384 // world), (65536, 65536 // world)] and "N_total" in rec["sharded_sweep_columns"]
+    assert all(isinstance(r[2], float) and r[2] > 0 and r[3] > 0 and r[4] > 0 for r in sw)
+    detail = _strict(lines[-2])["bench_detail"]["sharded_sweep"]["sizes"]
+    assert [e["rccl_nranks"] for e in detail] == [world, world] and detail[0]["valid_fraction"] == 1.0
+    assert 0.79 < detail[1]["valid_fraction"] < 0.81 and detail[1]["byzantine_fraction"] == 0.2
+    assert detail[0].get("baseline_config") == (4 if world == 4 else None) and detail[1].get("baseline_config") == (5 if world == 8 else None)
+    c5 = rec["config5"]                             # BASELINE config #5's shape (65 536 validators, 20 % bad) at this world size
+    assert (c5["validators"], c5["rows_per_gpu"], c5["rccl_nranks"]) == (65536, 65536 // world, world) and 0.79 < c5["valid_fraction"] < 0.81
     # value = rows of ALL ranks per second of the slowest rank
     assert rec["value"] == pytest.approx(4096 * world * 5 / (rec["ms_per_step"] * 5e-3), rel=1e-3)
 

@@ -96,7 +96,7 @@ def test_cgo_typecheck_catches_seeded_boundary_defects(tmp_path):
         # a field that the C struct does not have
         ("max_rows: C.uint32_t(o.MaxRows)}", "max_row: C.uint32_t(o.MaxRows)}", "max_row"),
         # nil where the prototype takes an integer
-        ("return c.check(C.ibft_seals_swap(c.h, 1))", "return c.check(C.ibft_seals_swap(c.h, nil))", "nil passed"),
+        ("err := c.check(C.ibft_seals_swap(c.h, 1))", "err := c.check(C.ibft_seals_swap(c.h, nil))", "nil passed"),
     ]
     for old, new, _ in seeds:
         assert src.count(old) == 1, old

@@ -1,18 +1,25 @@
-"""GPU: the bit-parity soak of SURVEY.md §8d in the driver-run suite (reduced: tools/soak.py runs the full 10 300 rounds).
+"""GPU: the bit-parity soak of SURVEY.md §8d in the driver-run suite — the FULL job list of tools/soak.py (round 6; until
+round 5 this test ran 1 011 rounds and the 10 000 were builder-attested only): BASELINE.json's target text is "bit-identical
+quorum decisions vs reference across 10k synthetic rounds".
 
-1 000 Byzantine rounds at N = 64 (seeds 1…1000, odd seeds weighted, every third with a forged envelope) + 10 rounds at
-N = 4 096: every round through ibft_verify_seals twice on a key-caching context (recover kernels, then known-key kernels)
-and twice as a whole COMMIT set through ibft_verify_messages — every verdict bit, Σ power, valid rows, distinct senders
-and the quorum flag against the CPU oracle.  Rounds and oracle answers are produced by worker processes (spawned: they
-never touch the HIP runtime of this process) while the GPU consumes."""
+10 000 Byzantine rounds at N = 64 (seeds 1…10000, odd seeds weighted, every third with a forged envelope) + 100 rounds each at
+N = 256 / 1 024 / 4 096 + 8 rounds at N = 16 384 + 4 at N = 40 000 (the lane-group and lane kernels): every round through
+ibft_verify_seals twice on a key-caching context (recover kernels, then known-key kernels), twice as a whole COMMIT set through
+ibft_verify_messages, and once through ibft_tally_prepare — every verdict bit, Σ power, valid rows, distinct senders and the
+quorum flag against the CPU oracle.  Rounds and oracle answers are produced by worker processes (spawned: they never touch the
+HIP runtime of this process) while the GPU consumes; ≈ 95 s with 16 workers.  IBFT_SOAK_ROUNDS=<k> shortens the N = 64 series
+(the assertion on the total then fails on purpose unless IBFT_SOAK_ALLOW_SHORT=1: a shortened soak is not the evidence)."""
+import json
 import os
+import time
 from concurrent.futures import ProcessPoolExecutor
 import multiprocessing as mp
 
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _cores():
@@ -26,39 +33,65 @@ def _cores():
     return n
 
 
-def test_reduced_soak_bit_identical_with_the_oracle():
+def soak_jobs(rounds_n64: int = 10000):
+    """tools/soak.py's default job list, the long jobs first (the pool's tail is then short jobs)"""
+    jobs = [(40000, s) for s in range(1, 5)] + [(16384, s) for s in range(1, 9)]
+    for n in (4096, 1024, 256):
+        jobs += [(n, s) for s in range(1, 101)]
+    return jobs + [(64, s) for s in range(1, rounds_n64 + 1)]
+
+
+def test_full_soak_bit_identical_with_the_oracle():
     import go_ibft_amd.verifier as V
     from oracle.soak_job import make
-    # the long jobs first; 20 000 rows: the lane-group kernels (round 4: signed windows over a common-Z table)
-    jobs = [(20000, 1), (4096, 1)] + [(4096, s) for s in range(2, 11)] + [(64, s) for s in range(1, 1001)]
+    rounds_n64 = int(os.environ.get("IBFT_SOAK_ROUNDS", "10000"))
+    jobs = soak_jobs(rounds_n64)
     stat = {"rounds": 0, "rows": 0, "bad_rows": 0, "mismatches": 0, "quorum_true": 0, "quorum_false": 0, "prepare_true": 0,
-            "prepare_voided": 0}
-    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=20000)
+            "prepare_voided": 0, "passes": 0}
+    by_n = {}
+    t0 = time.time()
+    procs = min(16, _cores())
+    bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=40000)
     try:
-        with ProcessPoolExecutor(max_workers=min(16, _cores()), mp_context=mp.get_context("spawn")) as ex:
-            for (n, seed, addrs, power, h, s, f, pre, exp, et, env) in ex.map(make, jobs, chunksize=4):
+        with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
+            for (n, seed, addrs, power, h, s, f, pre, exp, et, env) in ex.map(make, jobs, chunksize=8):
+                bad = 0
                 bv.set_validators(seed, addrs, power)
                 for _ in range(2):
                     got, t = bv.is_valid_committed_seal(h, s, f, pre)
-                    stat["mismatches"] += int((got != exp).sum())
-                    stat["mismatches"] += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != et)
+                    bad += int((got != exp).sum())
+                    bad += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != et)
                 payload, off, msig, hlen, raw, rnd, snd, clo, ets, hpq = env
                 for _ in range(2):
                     gs, gv, t = bv.verify_messages(payload, off, msig, f, h, hlen, s, valid_pre=pre, raw=raw, round_=rnd)
-                    stat["mismatches"] += int((gs != snd).sum()) + int((gv != clo).sum())
-                    stat["mismatches"] += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != ets)
+                    bad += int((gs != snd).sum()) + int((gv != clo).sum())
+                    bad += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != ets)
                 # HasPrepareQuorum on the device (ibft_tally_prepare) over the rows both verdicts accept, validator seed mod n
                 # as the proposer: decision, Σ power with the proposer's seat, rows sent by the proposer
                 tp = bv.has_prepare_quorum(f, snd & clo, hpq[3])
-                stat["mismatches"] += int((tp.has_quorum, tp.power, tp.proposer_rows) != hpq[:3])
+                bad += int((tp.has_quorum, tp.power, tp.proposer_rows) != hpq[:3])
+                stat["mismatches"] += bad
                 stat["prepare_true"] += hpq[0]
                 stat["prepare_voided"] += int(hpq[2] > 0)
                 stat["rounds"] += 1
+                stat["passes"] += 5
                 stat["rows"] += n
                 stat["bad_rows"] += int((~exp).sum())
                 stat["quorum_true" if et[4] else "quorum_false"] += 1
+                e = by_n.setdefault(n, {"rounds": 0, "mismatches": 0})
+                e["rounds"] += 1
+                e["mismatches"] += bad
     finally:
         bv.close()
-    assert stat["rounds"] == 1011 and stat["mismatches"] == 0, stat
+    stat.update({"seconds": round(time.time() - t0, 1), "procs": procs, "by_n": {str(k): v for k, v in sorted(by_n.items())}})
+    try:    # the record of THIS run, for whoever collects gpurun_out/ (the assertion below is the verdict)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "soak_in_suite.json"), "w") as fh:
+            json.dump(stat, fh)
+    except OSError:
+        pass
+    print("soak:", json.dumps(stat))
+    assert stat["rounds"] == len(jobs) and stat["mismatches"] == 0, stat
+    assert stat["rounds"] >= 10000 or os.environ.get("IBFT_SOAK_ALLOW_SHORT") == "1", stat
     assert stat["prepare_true"] > 0 and stat["prepare_voided"] > 0, stat
     assert stat["bad_rows"] > 0.15 * stat["rows"] and stat["quorum_true"] > 0 and stat["quorum_false"] > 0, stat

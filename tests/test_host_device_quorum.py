@@ -109,3 +109,40 @@ def test_no_proposal_message_is_decided_without_asking():
     assert not h.handle_prepare(1, 0)[0]
     assert h.device_quorum_stats() == (0, 0)
     h.close()
+
+
+@pytest.mark.parametrize("n,threshold,declined", [(4, 8, True), (6, 8, True), (7, 7, True), (30, 8, False), (4, 0, False)])
+@pytest.mark.parametrize("rows", [False, True])
+def test_min_device_rows_declines_small_batches_and_the_stock_closures_decide(n, threshold, declined, rows):
+    """SURVEY §5 "min batch for GPU" (ibft_host_set_min_device_rows / IBFT_MIN_DEVICE_ROWS): a batch below the threshold is
+    answered "not offered" by the backend — what it answers when the device is unavailable — and handlePrepare / handleCommit
+    run the per-message closures of /root/reference/core/ibft.go:856-862, 932-944 instead: same prepared set, same seals, same
+    quorum decision as a mirror without the knob, at the validator counts the reference itself tests (4: core/consensus_test.go:139,
+    6: core/byzantine_test.go:21, ≤ 30: core/rapid_test.go:156).  At or above the threshold the backend answers as before."""
+    w, proposal, prepares, commits = _world(n, silent=(n - 1,))
+    plain = _host(w, proposal, 0, True)
+    knob = _host(w, proposal, 0, True)
+    knob.set_min_device_rows(threshold)
+    for h in (plain, knob):
+        h.use_rows(rows)
+        wires = [m.encode() for m in prepares + commits]
+        if rows:
+            h.ingest_wire(wires)
+        else:
+            for x in wires:
+                h.store_add(x)
+    before = knob.loop_batch_calls()
+    a, b = plain.handle_prepare(1, 0), knob.handle_prepare(1, 0)
+    assert a[0] == b[0] and sorted(a[1]) == sorted(b[1])
+    qa, sa = plain.handle_commit(1, 0)
+    qb, sb = knob.handle_commit(1, 0)
+    assert qa == qb and sorted(sa) == sorted(sb) and qa == (n - 1 >= 2 * n // 3 + 1)
+    assert plain.declined_batches() == 0
+    if declined:
+        assert knob.declined_batches() > 0
+        if not rows:                                  # object mode: the two walks went to the callbacks, not to the backend
+            assert knob.loop_batch_calls() == before and knob.fallbacks() >= 2
+    else:
+        assert knob.declined_batches() == 0 and knob.fallbacks() == 0
+    for h in (plain, knob):
+        h.close()

@@ -10,9 +10,17 @@ SUM=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 cd /tmp
-for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_IFETCH" "GRBM_GUI_ACTIVE"; do
+# LEAN=1 (bench.py's default run): the instruction counts and the cycle counters only, cold kernel only, 90 s per pass at most
+LEAN=${LEAN:-0}
+SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_IFETCH" "GRBM_GUI_ACTIVE")
+T=300; EXTRA=""
+if [ "$LEAN" = 1 ]; then
+  SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY")
+  T=90; EXTRA="--no-warm"
+fi
+for set in "${SETS[@]}"; do
   tag=$(echo $set | tr ' ' '_')
-  timeout 300 rocprofv3 --pmc $set -d "$OUT/$tag" -o p --output-format csv -- python $ROOT/bench.py --rows $ROWS --steps 20 --warmup 3 --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0 > "$OUT/$tag.log" 2>&1
+  timeout $T rocprofv3 --pmc $set -d "$OUT/$tag" -o p --output-format csv -- python $ROOT/bench.py --rows $ROWS --steps 20 --warmup 3 $EXTRA --no-live-counters --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0 > "$OUT/$tag.log" 2>&1
 done
 cd "$ROOT"
 ROWS=$ROWS OUTDIR=$OUT python - > "$SUM/${TAG}_pmc_instruction_mix.txt" <<'PY'
