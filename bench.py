@@ -565,6 +565,54 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
             "sizes": out}
 
 
+def small_n_leg(V, sizes=(4, 6, 8, 12, 16, 30, 64, 128, 256), calls: int = 300):
+    """What a node with the reference's OWN validator counts gets (round-5 review, item 6): one round of COMMIT seals at N = 4, 6,
+    30 (core/consensus_test.go:139, core/byzantine_test.go:21, core/rapid_test.go:156) and the sizes around them, host columns →
+    host-visible verdicts through ONE ibft_verify_seals call (H2D, launch, kernel, tally, D2H: what a BatchVerifier call costs),
+    cold (every row recovered) and warm (keys known), p50 of `calls` calls behind 100 untimed ones — next to the TUNED CPU
+    recovery (oracle/recover_tuned.inc, libsecp256k1-class) on ONE core for the same rows: what the Go closure of
+    core/ibft.go:932-944 costs with go-ethereum's secp256k1 behind IsValidCommittedSeal.  crossover_* = the smallest N at which
+    the device call is faster than that loop — the value for IBFT_MIN_DEVICE_ROWS (shim/go/core/backend_batch.go,
+    go-ibft_amd/host/backend.hpp).  The CPU figure uses the oracle as the CPU baseline, like cpu_baseline."""
+    from oracle import binding as B, workload as W
+    out = {"definition": "p50 ms of ONE ibft_verify_seals call (pinned host columns -> host-visible verdict words + tally) on N rows; "
+                         "cold = key cache off, warm = keys known; cpu_one_core_ms = the same rows through the tuned CPU recovery on one "
+                         "thread (p50 of 30); crossover_* = smallest N with device < cpu (the IBFT_MIN_DEVICE_ROWS to set)",
+           "sizes": []}
+    ctx = {"cold": V.BatchVerifier(flags=0, max_rows=1024), "warm": V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=1024)}
+    try:
+        for n in sizes:
+            r = W.make_round(n, 4000 + n)
+            vs = B.ValSet(r.addrs, r.power)
+            cols = tuple(V.pinned_copy(x) for x in (r.hash32, r.seal65, r.signer20))
+            ent = {"validators": n}
+            for name, bv in ctx.items():
+                bv.set_validators(n, r.addrs, r.power)
+                for _ in range(100):
+                    got, t = bv.is_valid_committed_seal(*cols)
+                assert got.all() and t.has_quorum == 1 and t.distinct_senders == n
+                lat = np.empty(calls)
+                for i in range(calls):
+                    t0 = time.perf_counter()
+                    bv.is_valid_committed_seal(*cols)
+                    lat[i] = time.perf_counter() - t0
+                ent[name + "_ms_p50"] = float(np.median(lat) * 1e3)
+            cpu = np.empty(30)
+            for i in range(30):
+                t0 = time.perf_counter()
+                v = B.verify_seals_tuned(vs, r.hash32, r.seal65, r.signer20, nthreads=1)
+                cpu[i] = time.perf_counter() - t0
+            assert v.all()
+            ent["cpu_one_core_ms"] = float(np.median(cpu) * 1e3)
+            out["sizes"].append(ent)
+    finally:
+        for bv in ctx.values():
+            bv.close()
+    for name in ("cold", "warm"):
+        out["crossover_" + name] = next((e["validators"] for e in out["sizes"] if e[name + "_ms_p50"] < e["cpu_one_core_ms"]), None)
+    return out
+
+
 def sustained_leg(V, rd, steps: int = 400, sizes=(4096, 65536)):
     """Round-4 review, item 7: the headline is "inputs resident in HBM"; a node gets NEW messages at every wake-up
     (core/ibft.go:931-946), so a sustained stream pays an upload per batch.  With the context's two staging slots
@@ -751,6 +799,12 @@ def headline_record(rec: dict) -> dict:
         out["sweep"] = [[e["validators"], e.get("cold", {}).get("verifies_per_s"), e.get("cold", {}).get("kernel_ms"),
                          e.get("warm", {}).get("verifies_per_s"), e.get("warm", {}).get("kernel_ms")] for e in sw]
         out["sweep_columns"] = "N, cold verifies/s, cold kernel ms, warm verifies/s, warm kernel ms"
+    sn = rec.get("small_n") or {}
+    if sn.get("sizes"):   # one row per size: [N, cold call ms, warm call ms, one CPU core ms] + the crossovers
+        out["small_n"] = {"rows": [[e["validators"], e.get("cold_ms_p50"), e.get("warm_ms_p50"), e.get("cpu_one_core_ms")] for e in sn["sizes"]
+                                   if e["validators"] in (4, 6, 30)],
+                          "columns": "N, one device call cold ms, warm ms, the same rows on ONE CPU core ms",
+                          "crossover_cold": sn.get("crossover_cold"), "crossover_warm": sn.get("crossover_warm")}
     if "config5" in rec:
         c5 = rec["config5"]
         out["config5"] = {k: c5[k] for k in ("validators", "rows_per_gpu", "byzantine_fraction", "rccl_nranks", "value",
@@ -769,7 +823,7 @@ def headline_record(rec: dict) -> dict:
     out["detail"] = "gpurun_out/bench_detail.json (also the previous stdout line)"
     out = _r(out)
     # never let an extra take the line over the limit: drop optional objects, widest first
-    for k in ("sweep", "sweep_columns", "warm_path", "config5", "sustained_incl_h2d", "build", "parity", "sharded_sweep_columns",
+    for k in ("sweep", "sweep_columns", "small_n", "warm_path", "config5", "sustained_incl_h2d", "build", "parity", "sharded_sweep_columns",
               "sharded_sweep", "extended", "device_canary"):
         if len(json.dumps(out)) < LINE_LIMIT:
             break
@@ -1205,6 +1259,11 @@ def main():
             rec["sustained_incl_h2d"] = sustained_leg(V, main_leg["rd"])
         except Exception as e:  # noqa: BLE001
             rec["sustained_incl_h2d"] = {"error": repr(e)}
+    if world == 1 and rank == 0 and not args.no_sweep and not args.no_cpu_baseline:
+        try:
+            rec["small_n"] = small_n_leg(V)
+        except Exception as e:  # noqa: BLE001
+            rec["small_n"] = {"error": repr(e)}
     if world == 1 and rank == 0 and not args.no_sweep:
         try:
             rec["set_change"] = set_change_leg(V)

@@ -521,24 +521,35 @@ __global__ void __launch_bounds__(64) verify_known_group_kernel(recover_args a) 
   }
   const uint32_t *qt = a.qtab + QTAB_DWORDS_PER_VALIDATOR * (crypto ? (uint32_t)sl : a.dummy_validator);
   jac acc = secp::jac_inf();
-#pragma unroll 1
-  for (int it = 0; it < (POINTS + G - 1) / G; it++) {  // wave-uniform trip count
+  // this lane's table point of step `it` (point it·G + sub of the 48): where it lies, its digit, whether it exists
+  auto point_of = [&](int it, uint32_t &dgt, bool &has) -> const uint32_t * {
     const int p = it * G + (int)sub;
-    const bool has = p < POINTS;
+    has = p < POINTS;
     const int pp = has ? p : 0;
-    uint32_t dgt;
-    const uint32_t *entry;
     if (pp < QTAB_WINDOWS) {
       dgt = (u2.v[pp >> 2] >> (8 * (pp & 3))) & 255u;
-      entry = qt + (size_t)GTAB_ENTRY_DWORDS * (pp * QTAB_ENTRIES + dgt);
-    } else {
-      const int w = pp - QTAB_WINDOWS;
-      dgt = (u1.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
-      entry = a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt);
+      return qt + (size_t)GTAB_ENTRY_DWORDS * (pp * QTAB_ENTRIES + dgt);
     }
-    aff pt = load_affine(entry);
-    jac sum = secp::jac_add_aff_t<INL_MADD>(acc, pt);  // (the one inlined copy of the mixed addition: secp256k1_dev.h)
+    const int w = pp - QTAB_WINDOWS;
+    dgt = (u1.v[(w * GTAB_BITS) >> 5] >> ((w * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
+    return a.gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)w * GTAB_ENTRIES + dgt);
+  };
+  // Round 6: software-pipelined by one — the entry of step it + 1 is asked for before the addition of step it runs (a
+  // dependent read of a validator's table, far beyond any cache, used to open every step: ≈ 2 µs in front of each addition)
+  constexpr int STEPS = (POINTS + G - 1) / G;  // wave-uniform trip count
+  uint32_t dgt;
+  bool has;
+  aff cur = load_affine(point_of(0, dgt, has));
+#pragma unroll 1
+  for (int it = 0; it < STEPS; it++) {
+    uint32_t dn;
+    bool hasn;
+    const aff nxt = load_affine(point_of(it + 1 < STEPS ? it + 1 : it, dn, hasn));  // (the last step re-reads its own entry)
+    jac sum = secp::jac_add_aff_t<INL_MADD>(acc, cur);  // (the one inlined copy of the mixed addition: secp256k1_dev.h)
     acc = secp::jac_select(has && dgt != 0, sum, acc);
+    cur = nxt;
+    dgt = dn;
+    has = hasn;
   }
 #pragma unroll 1
   for (int off = G / 2; off >= 1; off >>= 1) {
@@ -728,20 +739,53 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
 #pragma unroll
         for (int j = 1; j < P; j++) kr.v[i] = piece == (uint32_t)j ? kb.v[i + NW * j] : kr.v[i];
       }
+      // Round 6: the window additions and this lane's share of the fixed-base additions are steps of ONE loop around ONE pasted
+      // copy of the mixed addition (recover_dev.h: ecmult_var_gen_lds has the reasoning) — the G additions used to go through
+      // the outlined multiply in a loop of their own.  u1 is a shift register (this lane's current window in the low bits of
+      // word 0: shifted down by GTAB_BITS·sub once, by GTAB_BITS·G per step), the table entry of the next G step is asked for
+      // before the addition of this one runs, the first one before the window loop starts.
+      constexpr int GSTEPS = (GTAB_WINDOWS + G - 1) / G;
+      constexpr int LOG2G = G == 8 ? 3 : (G == 4 ? 2 : 1);
+      u256 ug = u1;
+      secp::shr_units<GTAB_BITS, LOG2G>(ug, sub);
+      uint32_t dg = ug.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+      bool has = (int)sub < GTAB_WINDOWS;
+      gtab_raw cur = gtab_load(a.gtab, has ? (int)sub : 0, has ? dg : 0u);
 #pragma unroll 1
-      for (int nib = NIBS; nib >= 0; nib--) {
-        const bool mine = nib < NIBS || piece == (uint32_t)(P - 1);
-        const int e = mine ? (int)secp::top_nibble<NW + 1>(kr) - 8 : 0;
-        secp::shl4<NW + 1>(kr);
-        if (nib != NIBS) {
+      for (int st = 0; st <= NIBS + GSTEPS; st++) {
+        aff q;
+        bool take;
+        gtab_raw nxt = cur;
+        uint32_t dn = dg;
+        bool hasn = has;
+        if (st <= NIBS) {  // (wave-uniform) window step: digit NIBS − st of this lane's piece
+          const bool mine = st > 0 || piece == (uint32_t)(P - 1);
+          const int e = mine ? (int)secp::top_nibble<NW + 1>(kr) - 8 : 0;
+          secp::shl4<NW + 1>(kr);
+          if (st != 0) {
 #pragma unroll 1
-          for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+            for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+          }
+          q = window_operand_lds<64>(lt, e, flip);
+          q.x = secp::l26_select(half != 0, secp::fe_mul(q.x, beta), q.x);
+          take = e != 0;
+        } else {           // fixed-base step: window (st − NIBS − 1)·G + sub of u1
+          const int it = st - NIBS - 1;
+          if (it == 0) acc.z = secp::fe_mul(acc.z, secp::fe_mul(lt.zc, base.z));  // back from the isomorphic curve first
+          secp::shr_const<GTAB_BITS * G>(ug);
+          const int wn = (it + 1) * G + (int)sub;
+          hasn = it + 1 < GSTEPS && wn < GTAB_WINDOWS;
+          dn = ug.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+          nxt = gtab_load(a.gtab, hasn ? wn : 0, hasn ? dn : 0u);  // (past the end: entry 0 of window 0, never added)
+          q = gtab_point(cur);
+          take = has && dg != 0;
         }
-        aff q = window_operand_lds<64>(lt, e, flip);
-        q.x = secp::l26_select(half != 0, secp::fe_mul(q.x, beta), q.x);
-        acc = window_add_q(acc, q, e);
+        const jac sum = secp::jac_add_aff_t<true>(acc, q);
+        acc = secp::jac_select(take, sum, acc);
+        cur = nxt;
+        dg = dn;
+        has = hasn;
       }
-      acc.z = secp::fe_mul(acc.z, secp::fe_mul(lt.zc, base.z));
     } else {
       wtab wt;
       ecmult_table(b1, wt);
@@ -763,7 +807,7 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
   // u1·G: the fixed-base windows are dealt to the lanes of the group — lane `sub` takes windows sub, sub + G, … .  Round 6: u1 is
   // a shift register (this lane's current window in the low bits of word 0: shifted down by GTAB_BITS·sub once, by GTAB_BITS·G
   // per step — nothing indexed), and the table entry of the NEXT step is asked for before the addition of this one runs.
-  {
+  if (!(WBITS == 4 && TAB == TAB_LDS)) {  // (the LDS-table form has run them as steps of its window loop)
     constexpr int STEPS = (GTAB_WINDOWS + G - 1) / G;
     constexpr int LOG2G = G == 8 ? 3 : (G == 4 ? 2 : 1);
     u256 ug = u1;
@@ -1975,7 +2019,15 @@ __global__ void lookup_kernel(const uint8_t *__restrict__ signer20, const uint32
 // MI355X (profiles/r05a_ubench_wave.txt: 4.16 cycles at 2.39 GHz).  ISSUE_PROBE_ITERS × 64 independent v_add_u32 per
 // wavefront ≈ 0.24 ms per launch; the launch shape is the rows kernel's at N = 4 096 (256 workgroups of four wavefronts).
 constexpr int ISSUE_PROBE_ITERS = 2048;
+// 96 KB of LDS per workgroup: more than half of a compute unit's 160 KB, so the dispatcher cannot put two of these
+// workgroups on one compute unit — 256 workgroups of four wavefronts are ONE wavefront per SIMD on 256 compute units by
+// construction.  (A kernel this small — 9 registers, no LDS — is otherwise packed several workgroups to a compute unit, and
+// four wavefronts on a SIMD issue a plain instruction every 6.2 cycles each: the first version of this probe read 2.53 ns on a
+// healthy device, profiles/r06a_kernel_ab.txt.)
+constexpr int ISSUE_PROBE_LDS_WORDS = 96 * 1024 / 4;
 __global__ void __launch_bounds__(256) issue_probe_kernel(uint32_t *out, uint32_t seed) {
+  __shared__ uint32_t hold[ISSUE_PROBE_LDS_WORDS];
+  hold[threadIdx.x] = seed;
   uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 7, a3 = a0 * 7 + 3;
   uint32_t b0 = a0 ^ 0x1234567, b1 = a1 ^ 0x89abcde, b2 = a2 ^ 0x13579bd, b3 = a3 ^ 0x2468ace;
 #pragma unroll 1
@@ -1990,7 +2042,7 @@ __global__ void __launch_bounds__(256) issue_probe_kernel(uint32_t *out, uint32_
                  : "v"(seed | 1));
 #undef IBFT_P8
   }
-  if ((a0 ^ a1 ^ a2 ^ a3 ^ b0 ^ b1 ^ b2 ^ b3) == 0x9e3779b9u) out[0] = a0;  // keeps the chain alive
+  if ((a0 ^ a1 ^ a2 ^ a3 ^ b0 ^ b1 ^ b2 ^ b3) == 0x9e3779b9u) out[0] = a0 + hold[(threadIdx.x * 97u) % ISSUE_PROBE_LDS_WORDS];  // keeps the chain (and the LDS block) alive
 }
 
 }  // namespace ibftk

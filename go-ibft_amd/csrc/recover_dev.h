@@ -256,43 +256,71 @@ __host__ __device__ __forceinline__ secp::fe ltab_get(const ltab<TPB> &t, int s)
   return v;
 }
 // entry e (1…8): x in slot 2(e−1), y in slot 2(e−1)+1
+//
+// Round 6 — the table is built with CO-Z additions (Meloni 2007; the "ZADDU" form of Goundar, Joye, Miyaji), in place, by
+// rolled loops.  Until round 5 the seven multiples were computed as Jacobian points (4 doublings, 3 mixed additions), their
+// seven Z's kept in 70 registers and brought to one common Z by prefix / suffix products: ≈ 111 multiplications written out as
+// 21 KB of straight-line code (a register array cannot be indexed by a loop counter without going to the private segment), every
+// line of it fetched once per launch by every instruction cache — on a lease whose instruction fetch is slow that is what the
+// kernel waits for.  Two points that SHARE their Z add in 5M + 2S, and the addition hands back its first
+// operand rescaled to the sum's Z for nothing:
+//     C = (X1−X2)²   W1 = X1·C   W2 = X2·C   D = (Y1−Y2)²   A1 = Y1·(W1−W2)
+//     X3 = D − W1 − W2     Y3 = (Y1−Y2)·(W1−X3) − A1     Z3 = Z·(X1−X2)        P′ = (W1, A1) ≡ P at Z3
+// so the table can be kept at ONE Z all the time: k·R = (k−1)·R + R with both operands at the current Z, then the older
+// entries are brought along by λ = X1 − X2 (x·λ², y·λ³: two multiplications each; λ² = C is there already).  The Z of the
+// last addition IS the common Z.  ≈ 100 multiplications, no Z kept but the current one, every entry addressed in LDS by a
+// loop counter: 4 KB of code instead of 21.  No exceptional case exists: (k−1)·R = ±R would make R a point of order ≤ 9, and the
+// curve's order is prime (a row whose r is no x coordinate computes garbage here and is rejected by its failed square root).
 template <int TPB>
 __host__ __device__ __forceinline__ void ecmult_table_lds(const aff &R1, ltab<TPB> &t) {
-  secp::fe z[9];
-  ltab_put(t, 0, R1.x);
-  ltab_put(t, 1, R1.y);
+  // 2R from the affine R (Z = 1: mdbl-2007-bl), then R brought to 2R's Z = 2y — for which nothing has to be multiplied but
+  // x: Z² = 4·y², Z³·y = 8·y⁴, and y², y⁴ are the doubling's own YY, YYYY.  Seven multiplications for both.
+  secp::fe z;
   {
-    const jac m2 = secp::jac_dbl(secp::jac_from_aff(R1));
-    ltab_put(t, 2, m2.x); ltab_put(t, 3, m2.y); z[2] = m2.z;
-    const jac m3 = secp::jac_add_aff(m2, R1);
-    ltab_put(t, 4, m3.x); ltab_put(t, 5, m3.y); z[3] = m3.z;
-    const jac m4 = secp::jac_dbl(m2);
-    ltab_put(t, 6, m4.x); ltab_put(t, 7, m4.y); z[4] = m4.z;
-    const jac m6 = secp::jac_dbl(m3);
-    ltab_put(t, 10, m6.x); ltab_put(t, 11, m6.y); z[6] = m6.z;
-    const jac m5 = secp::jac_add_aff(m4, R1);
-    ltab_put(t, 8, m5.x); ltab_put(t, 9, m5.y); z[5] = m5.z;
-    const jac m8 = secp::jac_dbl(m4);
-    ltab_put(t, 14, m8.x); ltab_put(t, 15, m8.y); z[8] = m8.z;
-    const jac m7 = secp::jac_add_aff(m6, R1);
-    ltab_put(t, 12, m7.x); ltab_put(t, 13, m7.y); z[7] = m7.z;
+    const secp::fe xx = secp::fe_sqr(R1.x), yy = secp::fe_sqr(R1.y), yyyy = secp::fe_sqr(yy);
+    secp::fe tt = secp::fe_sqr(secp::fe_add(R1.x, yy));                                        // in 2 → 1
+    tt = secp::fe_add(secp::fe_add(tt, secp::fe_neg(xx, 1)), secp::fe_neg(yyyy, 1));           // 5
+    const secp::fe sS = secp::fe_normalize_weak(secp::fe_mul_int(tt, 2));                      // 10 → 1
+    const secp::fe mM = secp::fe_mul_int(xx, 3);                                               // 3
+    const secp::fe x3 = secp::fe_normalize_weak(secp::fe_add(secp::fe_sqr(mM), secp::fe_neg(secp::fe_mul_int(sS, 2), 2)));  // 4 → 1
+    const secp::fe y8 = secp::fe_mul_int(yyyy, 8);                                             // 8
+    const secp::fe y3 = secp::fe_normalize_weak(
+        secp::fe_add(secp::fe_mul(mM, secp::fe_add(sS, secp::fe_neg(x3, 1))), secp::fe_neg(y8, 8)));  // 1 + 9 → 1
+    ltab_put(t, 2, x3);
+    ltab_put(t, 3, y3);
+    z = secp::fe_normalize_weak(secp::fe_mul_int(R1.y, 2));
+    ltab_put(t, 0, secp::fe_mul(R1.x, secp::fe_mul_int(yy, 4)));   // x·Z²
+    ltab_put(t, 1, secp::fe_normalize_weak(y8));                  // y·Z³ = 8·y⁴
   }
-  // Zc = z₂·…·z₈, s_i = Zc / z_i = (z₂…z_{i−1})·(z_{i+1}…z₈): prefix products forward, the suffix product while walking down
-  secp::fe pre[8];  // pre[i] = z₂·…·z_i
-  pre[2] = z[2];
-#pragma unroll
-  for (int i = 3; i <= 7; i++) pre[i] = secp::fe_mul(pre[i - 1], z[i]);
-  secp::fe suf = z[8];  // z_{i+1}·…·z₈ on entry of step i (set for i = 7 here; step 8 has an empty suffix)
-#pragma unroll
-  for (int i = 8; i >= 1; i--) {
-    const secp::fe sc = i == 8 ? pre[7] : (i <= 2 ? suf : secp::fe_mul(pre[i - 1], suf));
-    const secp::fe s2 = secp::fe_sqr(sc);
-    const int sl = 2 * (i - 1);
-    ltab_put(t, sl, secp::fe_mul(ltab_get(t, sl), s2));
-    ltab_put(t, sl + 1, secp::fe_mul(ltab_get(t, sl + 1), secp::fe_mul(s2, sc)));
-    if (i <= 7 && i >= 2) suf = secp::fe_mul(suf, z[i]);  // after step i: z_i·…·z₈ — what step i − 1 needs; after step 2: Zc
+#pragma unroll 1
+  for (int k = 3; k <= 8; k++) {  // entry k = entry (k − 1) + entry 1, both at Z = z
+    const int sp = 2 * (k - 2);   // slots of P = entry k − 1; its sum goes to sp + 2
+    const secp::fe x1 = ltab_get(t, sp), y1 = ltab_get(t, sp + 1), x2 = ltab_get(t, 0), y2 = ltab_get(t, 1);
+    const secp::fe dx = secp::fe_add(x1, secp::fe_neg(x2, 1));  // 3
+    const secp::fe dy = secp::fe_add(y1, secp::fe_neg(y2, 1));  // 3
+    const secp::fe c = secp::fe_sqr(dx);
+    const secp::fe w1 = secp::fe_mul(x1, c), w2 = secp::fe_mul(x2, c);
+    const secp::fe d = secp::fe_sqr(dy);
+    const secp::fe a1 = secp::fe_mul(y1, secp::fe_add(w1, secp::fe_neg(w2, 1)));
+    const secp::fe x3 = secp::fe_normalize_weak(secp::fe_add(secp::fe_add(d, secp::fe_neg(w1, 1)), secp::fe_neg(w2, 1)));  // 5 → 1
+    const secp::fe y3 = secp::fe_normalize_weak(
+        secp::fe_add(secp::fe_mul(dy, secp::fe_add(w1, secp::fe_neg(x3, 1))), secp::fe_neg(a1, 1)));  // 3 → 1
+    z = secp::fe_mul(z, dx);
+    ltab_put(t, sp, w1);  // entry k − 1 at the new Z: free
+    ltab_put(t, sp + 1, a1);
+    ltab_put(t, sp + 2, x3);
+    ltab_put(t, sp + 3, y3);
+    const secp::fe c3 = secp::fe_mul(c, dx);  // λ³
+    ltab_put(t, 0, w2);   // entry 1 at the new Z: x2·λ² is W2
+    ltab_put(t, 1, secp::fe_mul(y2, c3));
+#pragma unroll 1
+    for (int j = 2; j <= k - 2; j++) {  // entries 2 … k − 2 follow
+      const int sj = 2 * (j - 1);
+      ltab_put(t, sj, secp::fe_mul(ltab_get(t, sj), c));
+      ltab_put(t, sj + 1, secp::fe_mul(ltab_get(t, sj + 1), c3));
+    }
   }
-  t.zc = suf;
+  t.zc = z;
 }
 template <int TPB>
 __host__ __device__ __forceinline__ aff window_operand_lds(const ltab<TPB> &t, int e, bool flip) {
@@ -337,6 +365,74 @@ __host__ __device__ __forceinline__ jac ecmult_var_lds(const aff &R, const u256 
   acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve
   return acc;
 }
+// ---- u2·R + u1·G in ONE loop of mixed additions (round 6) -----------------------------------------------------------------
+// The lane kernel carried TWO pasted copies of the mixed addition — one in the window loop above, one in ecmult_gen's loop —
+// 18.5 KB each, in a kernel whose code has to be fetched through a 64 KB instruction cache.  Here the 66
+// window additions and the 16 fixed-base additions are steps of one loop around one copy: what differs from step to step is
+// where the operand comes from (an LDS table entry, with β·X on the odd steps — or the G-table entry asked for one step
+// earlier) and whether four doublings run first; all of that hangs on the step number, which is wave-uniform.  The first
+// G-table entry is asked for before the window table is even built.
+#ifndef IBFT_LANE_MERGED
+#define IBFT_LANE_MERGED 1  // 0: ecmult_gen(ecmult_var_lds(…)) — two copies of the mixed addition (round 5; A/B)
+#endif
+template <int TPB>
+__host__ __device__ __forceinline__ jac ecmult_var_gen_lds(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
+                                                           const u256 &u1, uint32_t *col) {
+  u256 kk = u1;  // shift register: the current 16-bit window of u1 in the low bits of word 0
+  uint32_t dgt = kk.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+  gtab_raw cur = gtab_load(gtab, 0, dgt);
+  secp::glv_split sp = secp::sc_split_lambda(k);
+  aff R1 = R;
+  R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
+  const bool flip2 = sp.neg1 != sp.neg2;
+  ltab<TPB> t;
+  t.col = col;
+  ecmult_table_lds<TPB>(R1, t);
+  u256 r1 = window_bias(sp.k1), r2 = window_bias(sp.k2);  // shift registers: the current digit is the low nibble of word 4
+  const secp::fe beta = secp::GLV_CONST(1);
+  jac acc = secp::jac_inf();
+  int e1 = 0, e2 = 0;
+  constexpr int WSTEPS = 2 * WINDOW_DIGITS;
+#pragma unroll 1
+  for (int st = 0; st < WSTEPS + GTAB_WINDOWS; st++) {
+    aff q;
+    bool take;
+    gtab_raw nxt = cur;
+    uint32_t dn = dgt;
+    if (st < WSTEPS) {  // (wave-uniform)
+      const bool h = (st & 1) != 0;
+      if (!h) {
+        if (st != 0) {
+#pragma unroll 1
+          for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+        }
+        e1 = (int)secp::top_nibble<5>(r1) - 8;
+        e2 = (int)secp::top_nibble<5>(r2) - 8;
+        secp::shl4<5>(r1);
+        secp::shl4<5>(r2);
+      }
+      const int e = h ? e2 : e1;
+      q = window_operand_lds<TPB>(t, e, h && flip2);
+      if (h) q.x = secp::fe_mul(q.x, beta);
+      take = e != 0;
+    } else {
+      if (st == WSTEPS) acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve: the G-table points live on the curve itself
+      const int w = st - WSTEPS;
+      const bool last = w + 1 == GTAB_WINDOWS;
+      secp::shr_bits<GTAB_BITS>(kk);
+      dn = last ? dgt : kk.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+      nxt = gtab_load(gtab, last ? w : w + 1, dn);  // asked for before this step's addition runs (the last step re-reads its own)
+      q = gtab_point(cur);
+      take = dgt != 0;
+    }
+    const jac sum = secp::jac_add_aff_t<true>(acc, q);
+    acc = secp::jac_select(take, sum, acc);
+    cur = nxt;
+    dgt = dn;
+  }
+  return acc;
+}
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Round 1's u2·R (4-bit unsigned windows over 15 Jacobian multiples, full additions): host builds only — the CPU
 // harness checks the new form against it on random and adversarial scalars (tests/test_dev_arith_host.py)
@@ -384,9 +480,13 @@ struct var_mult_lds {
   uint32_t *col;
   __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
                                                      const u256 &u1) const {
-    // (u1·G as further iterations of the window loop — ONE pasted mixed addition instead of two, 104 → 84 KB of code — was
-    // measured and not adopted: −2.6 % on a lease of the slow kind, +1.5 % on the fast kind; profiles/r05la_lane_merge_ab.txt, archive/r05lb_…)
+#if IBFT_LANE_MERGED
+    return ecmult_var_gen_lds<TPB>(R, k, gtab, u1, col);
+#else
+    // (round 5 measured a first form of the merged loop at −2.6 % on a lease of the slow kind, +1.5 % on the fast kind and kept
+    // the two copies: profiles/r05la_lane_merge_ab.txt)
     return ecmult_gen(gtab, u1, ecmult_var_lds<TPB>(R, k, col));
+#endif
   }
 };
 template <class VARMULT>

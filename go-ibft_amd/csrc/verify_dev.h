@@ -85,22 +85,36 @@ __host__ __device__ __forceinline__ bool verify_known(const uint32_t *__restrict
   u256 u1, u2;
   verify_scalars(z_raw, r, s, u1, u2);
   jac acc = secp::jac_inf();
-  // ONE rolled loop over the 32 + GTAB_WINDOWS table points (one inlined copy of the mixed addition: secp256k1_dev.h)
+  // ONE rolled loop over the 32 + GTAB_WINDOWS table points (one inlined copy of the mixed addition: secp256k1_dev.h).
+  // Round 6: software-pipelined by one — the entry of step w + 1 is asked for before the addition of step w runs.  Every step
+  // used to open with a dependent read of a table far beyond any cache (655 KB per validator: 43 GB at 65 536 validators;
+  // ≈ 2 µs with one resident wavefront per SIMD) in front of a 4.4 µs addition: a third of this kernel's time was that wait.
+  // The scalars are shift registers (the current window in the low bits of word 0): nothing is indexed by w, nothing lives
+  // in the private segment (the 80 B of scratch this kernel had were u1 and u2).
+  u256 k2 = u2, k1 = u1;
+  uint32_t dgt = k2.v[0] & 255u;
+  const uint32_t *entry = qtab_v + (size_t)GTAB_ENTRY_DWORDS * dgt;
+  aff cur = load_affine(entry);
+  constexpr int POINTS = QTAB_WINDOWS + GTAB_WINDOWS;
 #pragma unroll 1
-  for (int w = 0; w < QTAB_WINDOWS + GTAB_WINDOWS; w++) {
-    uint32_t dgt;
-    const uint32_t *entry;
-    if (w < QTAB_WINDOWS) {
-      dgt = (u2.v[w >> 2] >> (8 * (w & 3))) & 255u;
-      entry = qtab_v + (size_t)GTAB_ENTRY_DWORDS * (w * QTAB_ENTRIES + dgt);
-    } else {
-      const int g = w - QTAB_WINDOWS;
-      dgt = (u1.v[(g * GTAB_BITS) >> 5] >> ((g * GTAB_BITS) & 31)) & (uint32_t)(GTAB_ENTRIES - 1);
-      entry = gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)g * GTAB_ENTRIES + dgt);
+  for (int w = 0; w < POINTS; w++) {
+    uint32_t dn = dgt;                  // (the last step re-reads its own entry)
+    const int wn = w + 1;
+    if (wn < QTAB_WINDOWS) {            // (wave-uniform)
+      secp::shr_bits<8>(k2);
+      dn = k2.v[0] & 255u;
+      entry = qtab_v + (size_t)GTAB_ENTRY_DWORDS * (wn * QTAB_ENTRIES + dn);
+    } else if (wn < POINTS) {
+      const int g = wn - QTAB_WINDOWS;
+      if (g > 0) secp::shr_bits<GTAB_BITS>(k1);
+      dn = k1.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+      entry = gtab + (size_t)GTAB_ENTRY_DWORDS * ((size_t)g * GTAB_ENTRIES + dn);
     }
-    aff q = load_affine(entry);
-    jac sum = secp::jac_add_aff_t<true>(acc, q);
+    const aff nxt = load_affine(entry);
+    jac sum = secp::jac_add_aff_t<true>(acc, cur);
     acc = secp::jac_select(dgt != 0, sum, acc);
+    cur = nxt;
+    dgt = dn;
   }
   return verify_finish(acc, r, v) && ok;
 }

@@ -78,10 +78,47 @@ def instruction_sizes(obj: str) -> dict[str, list[tuple[int, str]]]:
 _LABEL = re.compile(r"^([A-Za-z_.$][\w.$]*):")
 
 
+HOT_ONLY = os.environ.get("IBFT_PHASE_HOT_ONLY", "1") != "0"
+_BRANCH = re.compile(r"^s_(?:branch|cbranch_\w+)\s+([A-Za-z_.$][\w.$]*)")
+
+
+def hot_lines(lines: list[str]) -> list[bool]:
+    """Round 6: which lines are worth aligning.  Widening and padding make the code ≈ 5 % longer; inside a loop (or inside an
+    outlined function, which the loops call) that buys issue slots, in code a launch runs through ONCE it only adds cache lines
+    to fetch — and the lane / group cold kernels are measured against the 64 KB instruction cache.  A line is
+    hot when it lies between a local label and a branch back to it, or in a function that is not a kernel."""
+    kernels = {m.group(1) for l in lines for m in [re.match(r"^\s*\.amdhsa_kernel\s+(\S+)", l)] if m}
+    hot = [False] * len(lines)
+    labels: dict[str, int] = {}
+    in_kernel = None
+    for i, line in enumerate(lines):
+        s = line.strip()
+        m = _LABEL.match(s)
+        if m:
+            name = m.group(1)
+            if not name.startswith(".L"):
+                in_kernel = name in kernels
+                labels = {}
+            else:
+                labels[name] = i
+            continue
+        if in_kernel is None:
+            continue
+        if not in_kernel:
+            hot[i] = True          # an outlined function: called from the loops
+            continue
+        b = _BRANCH.match(s)
+        if b and b.group(1) in labels:   # a branch to a label seen earlier in this function: a loop
+            for j in range(labels[b.group(1)], i + 1):
+                hot[j] = True
+    return hot
+
+
 def align_text(lines: list[str], sizes: dict[str, list[tuple[int, str]]], stats: dict, skip: set[str] = frozenset()) -> list[str]:
     out: list[str] = []
     cur, k, phase = None, 0, 0
     seq: list[tuple[int, str]] = []
+    hot = hot_lines(lines) if HOT_ONLY else [True] * len(lines)
     for idx, line in enumerate(lines):
         s = line.strip()
         m = _LABEL.match(s)
@@ -114,6 +151,11 @@ def align_text(lines: list[str], sizes: dict[str, list[tuple[int, str]]], stats:
         if phase == 4:
             phase = 0
             out.append(line)
+            continue
+        if not hot[idx]:           # code that runs once per launch: left as the compiler wrote it, only the phase is tracked
+            phase = 4
+            out.append(line)
+            stats["cold_left_alone"] = stats.get("cold_left_alone", 0) + 1
             continue
         # an even run of 4-byte instructions restores the phase by itself: nothing to do for its members
         n4, j = 0, k - 1

@@ -79,3 +79,15 @@ if has soak; then
   timeout 1500 python tools/soak.py > gpurun_out/profiles/${TAG}_soak.json 2> gpurun_out/${TAG}_soak.err
   echo "soak rc=$?"; tail -c 500 gpurun_out/profiles/${TAG}_soak.json; tail -2 gpurun_out/${TAG}_soak.err
 fi
+if has ubench; then
+  timeout 600 tools/ubench_wave > gpurun_out/profiles/${TAG}_ubench_wave.txt 2>&1; echo "ubench rc=$?"
+  grep -E "^class" gpurun_out/profiles/${TAG}_ubench_wave.txt | head -8
+fi
+if has parity; then
+  timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_warm_path.py tests/test_gpu_arith.py tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/profiles/${TAG}_pytest_parity.log 2>&1
+  echo "parity tests rc=$?"; tail -3 gpurun_out/profiles/${TAG}_pytest_parity.log
+fi
+if has fresh; then
+  timeout 1500 python tools/fresh_batch_ab.py ${IBFT_AB_OLD:-ab/libibftgpu_r05.so} ${IBFT_AB_NEW:-go-ibft_amd/csrc/libibftgpu.so} ${IBFT_AB_ROUNDS:-3} > gpurun_out/profiles/${TAG}_fresh_batch_ab.txt 2> gpurun_out/${TAG}_fresh_ab.err
+  echo "fresh-batch A/B rc=$?"; cat gpurun_out/profiles/${TAG}_fresh_batch_ab.txt; tail -3 gpurun_out/${TAG}_fresh_ab.err
+fi

@@ -34,4 +34,5 @@ timeout $T rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -
 timeout $T rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" -o w --output-format csv -- $PMC > "$OUT/write.log" 2>&1
 cd "$ROOT"
 python tools/summarize_prof.py "$OUT" "$SUM" "$TAG" "$ROWS"
-f=$(find "$OUT/stats_seq" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$SUM/${TAG}_seq_kernel_stats.csv"
+f=$(find "$OUT/stats_seq" -name "*kernel_stats.csv" 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" "$SUM/${TAG}_seq_kernel_stats.csv"
+[ -e "$SUM/${TAG}_kernel_stats.csv" ] && [ -e "$SUM/${TAG}_traffic.json" ]   # the exit code: did the passes bench.py reads leave their summaries
