@@ -57,7 +57,8 @@ SEQ_ROUNDS = 1000            # latency p50 over ≥1000 rounds
 SWEEP_PREWARM_MIN_PASSES, SWEEP_PREWARM_MIN_S = 100, 0.1   # untimed passes in front of every sweep entry (clock ramp)
 PREWARM_STEPS = 150         # untimed passes in front of the W warm-up steps of the headline legs (see run_config)
 CONFIG5_TIMEOUT_S = 240     # the N = 8 extra leg (config #5) is abandoned after this long; the headline line goes out regardless
-CANARY_HEALTHY_NS = 1.79     # profiles/r05a_ubench_wave.txt: an aligned 8-byte VALU instruction at one wavefront per SIMD (4.16 cycles at 2.39 GHz)
+CANARY_HEALTHY_NS = 1.89     # ibft_issue_probe on healthy devices (profiles/r06b_kernel_ab.txt: 1.886 / 1.887 / 1.889 ns in three processes; the
+                             # bare instruction stream of tools/ubench_wave.hip measures 1.78 ns on the same lease: the probe's loop and LDS set-up are the 6 %)
 KERNEL_TIMING_EVERY = 4      # HIP-event pair around the verdict kernel of every 4th timed pass (≥ 50 samples at --steps 200)
 FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_round_n4096.npz")
 

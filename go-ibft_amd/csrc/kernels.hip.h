@@ -782,9 +782,11 @@ __global__ void __launch_bounds__(64) ecrecover_group_kernel(recover_args a) {
         }
         const jac sum = secp::jac_add_aff_t<true>(acc, q);
         acc = secp::jac_select(take, sum, acc);
-        cur = nxt;
-        dg = dn;
-        has = hasn;
+        if (st > NIBS) {  // (only the fixed-base steps move the pipeline)
+          cur = nxt;
+          dg = dn;
+          has = hasn;
+        }
       }
     } else {
       wtab wt;
@@ -2015,8 +2017,8 @@ __global__ void lookup_kernel(const uint8_t *__restrict__ signer20, const uint32
 // ---- device canary (ibft_issue_probe) ------------------------------------------------------------------------------
 // The verdict kernels are bound by VALU issue, so a device that issues slower than its kind (round 5 met one lease in ≈ 35
 // whose every throughput-bound kernel ran 1.3–1.45 × slower) shows in ONE number: the time of a plain
-// 8-byte VALU instruction that starts on an 8-byte boundary with one resident wavefront per SIMD — 1.79 ns on a healthy
-// MI355X (profiles/r05a_ubench_wave.txt: 4.16 cycles at 2.39 GHz).  ISSUE_PROBE_ITERS × 64 independent v_add_u32 per
+// 8-byte VALU instruction that starts on an 8-byte boundary with one resident wavefront per SIMD — 1.89 ns through this
+// probe on a healthy MI355X (the bare stream: 1.78 ns = 4.16 cycles at 2.39 GHz, profiles/r06b_ubench_wave.txt).  ISSUE_PROBE_ITERS × 64 independent v_add_u32 per
 // wavefront ≈ 0.24 ms per launch; the launch shape is the rows kernel's at N = 4 096 (256 workgroups of four wavefronts).
 constexpr int ISSUE_PROBE_ITERS = 2048;
 // 96 KB of LDS per workgroup: more than half of a compute unit's 160 KB, so the dispatcher cannot put two of these

@@ -427,8 +427,10 @@ __host__ __device__ __forceinline__ jac ecmult_var_gen_lds(const aff &R, const u
     }
     const jac sum = secp::jac_add_aff_t<true>(acc, q);
     acc = secp::jac_select(take, sum, acc);
-    cur = nxt;
-    dgt = dn;
+    if (st >= WSTEPS) {  // (only the fixed-base steps move the pipeline: the 66 window steps copy nothing)
+      cur = nxt;
+      dgt = dn;
+    }
   }
   return acc;
 }

@@ -1266,8 +1266,15 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
 #ifndef IBFT_ROWS_DEFER_SQRT
 #define IBFT_ROWS_DEFER_SQRT 1  // 1: √ and the final inversion from one exponentiation at the end (rows_finish_deferred); 0: √ first, safegcd last (A/B)
 #endif
+// IBFT_ROWS_G_PREFETCH = 1: the sixteen table points of u1·G go into wave-private LDS as soon as u1 is known (global → LDS
+// directly, no register, no wait: lds_prefetch_dword) and are long there when the G additions come.  BUILT AND MEASURED in round
+// 6, NOT ADOPTED: the dependent table reads in front of the fifteen additions are not what those additions wait for — with the
+// prefetch the kernel is 0.9 % SLOWER on a resident batch (0.3329 → 0.3360 ms: 32 DMA instructions, 32 KB more LDS per
+// workgroup) and 0.4 % slower on fresh batches whose entries come from beyond the L2 (0.3349 → 0.3362 ms), and the stage
+// between the main loop and the closing exponentiation takes 0.038 ms as before (profiles/r06b_kernel_ab.txt,
+// r06b_fresh_batch_ab.txt, r06b_rows_stage_ms.txt).  Kept behind the macro for the A/B.
 #ifndef IBFT_ROWS_G_PREFETCH
-#define IBFT_ROWS_G_PREFETCH 1  // 1: the table points of u1·G go into LDS as soon as u1 is known (round 6); 0: read where they are added (A/B)
+#define IBFT_ROWS_G_PREFETCH 0
 #endif
 constexpr int ROW_TAB_G0 = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products, then (x, y) of the GTAB_WINDOWS points of u1·G
 constexpr int ROW_TAB_SLOTS = ROW_TAB_G0 + (IBFT_ROWS_G_PREFETCH ? 2 * ibftk::GTAB_WINDOWS : 0);
@@ -1314,10 +1321,8 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
   const u256 u2 = secp::sc_canon(secp::sc_mul(secp::sc_from_u256(s), rinv));
   WV_STAGE(22, skeep ^ u1.v[0] ^ u2.v[3])
 #if IBFT_ROWS_G_PREFETCH
-  // Round 6: the sixteen table points of u1·G are asked for NOW — global memory → wave-private LDS, no register, no wait —
-  // and are long there when the G additions come, ≈ 0.25 ms later.  Read where they were added they cost a dependent ≈ 1.8 µs
-  // fetch from an 84 MB table in front of each of the fifteen additions (one resident wavefront per SIMD: nobody to run
-  // meanwhile): 0.035 ms for fifteen additions of 1.3 µs (profiles/r05k_rows_stage_ms.txt).
+  // (A/B form, see the macro: the sixteen table points of u1·G are asked for NOW — global memory → wave-private LDS — and are
+  // long there when the G additions come, ≈ 0.25 ms later)
   {
     const uint32_t ld = k.li < 10 ? k.li : 0u;  // (idle lanes fetch limb 0 and are masked at use)
 #pragma unroll

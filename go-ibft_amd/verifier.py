@@ -711,7 +711,7 @@ class BatchVerifier:
 
     def issue_probe(self):
         """ibft_issue_probe: (ns per aligned 8-byte VALU instruction per SIMD at one wavefront per SIMD, ms of the probe
-        kernel) — 1.79 ns on a healthy MI355X"""
+        kernel) — 1.89 ns on a healthy MI355X"""
         ns, ms = C.c_float(0), C.c_float(0)
         self._chk(self._L.ibft_issue_probe(self._h, C.byref(ns), C.byref(ms)), "ibft_issue_probe")
         return float(ns.value), float(ms.value)

@@ -531,8 +531,8 @@ int ibft_sync(ibft_ctx *ctx);
 /* Device canary (diagnostic; no reference counterpart — a Backend may log it at start-up and a bench line carries it):
  * the verdict kernels are bound by VALU issue, so a sick or shared device shows in one number.  Runs a 0.24 ms kernel
  * of independent 8-byte VALU instructions at one wavefront per SIMD (three untimed launches, median of five timed)
- * on the context's stream and reports the wall time per instruction per SIMD: 1.79 ns on a healthy MI355X
- * (profiles/r05a_ubench_wave.txt); > 5 % off means every throughput figure of that device is off by as much.   */
+ * on the context's stream and reports the wall time per instruction per SIMD: 1.89 ns on a healthy MI355X
+ * (profiles/r06b_kernel_ab.txt; the bare instruction stream: 1.78 ns, profiles/r06b_ubench_wave.txt); > 5 % off means every throughput figure of that device is off by as much.   */
 int ibft_issue_probe(ibft_ctx *ctx, float *ns_per_inst, float *kernel_ms);
 
 /* ---- multi-GPU (BASELINE configs #4 / #5) -------------------------------------------

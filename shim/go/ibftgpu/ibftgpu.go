@@ -444,7 +444,7 @@ func (c *Ctx) SealsSwap() error {
 }
 
 // IssueProbe = the device canary (ibft_issue_probe): wall nanoseconds per aligned 8-byte VALU instruction per SIMD at one
-// wavefront per SIMD — 1.79 on a healthy MI355X; a Backend logs it at start-up.
+// wavefront per SIMD — 1.89 on a healthy MI355X; a Backend logs it at start-up.
 func (c *Ctx) IssueProbe() (nsPerInst float32, err error) {
 	var ns, ms C.float
 	err = c.check(C.ibft_issue_probe(c.h, &ns, &ms))

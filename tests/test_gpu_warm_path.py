@@ -159,7 +159,7 @@ def test_config5_n65536_byzantine_cold_and_warm(oracle):
             bytes_, used, cap, sharing = bv.cache_memory()
             # (the pool is the DEVICE's: its capacity is the largest number of slots this process ever held at once — the full
             # soak earlier in the suite leaves it at 80 000 slots = 52 GB — and never four times the validators' 43 GB)
-            assert used == n and bytes_ < 64e9 and bytes_ <= (cap + 1) * 656000 and sharing >= 4, (bytes_, used, cap, sharing)
+            assert used == n and bytes_ < 64e9 and bytes_ <= (cap + 1) * 660000 and sharing >= 4, (bytes_, used, cap, sharing)
             got, t = more[2].is_valid_committed_seal(r1.hash32, r1.seal65, r1.signer20, r1.pre_flags)
             exp1 = oracle.verify_seals(vs, r1.hash32, r1.seal65, r1.signer20, r1.pre_flags, nthreads=16).astype(bool)
             assert (got == exp1).all() and more[2].last_dispatch()[1] == 1 and more[2].cache_stats()[0] == tables
