@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 for ROWS in $SIZES; do
   OUT=$ROOT/gpurun_out/prof_${TAG}_n$ROWS
   mkdir -p "$OUT"
-  CMD="python $ROOT/bench.py --rows $ROWS --steps 30 --warmup 3 --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0"
+  CMD="python $ROOT/bench.py --rows $ROWS --steps 30 --warmup 3 --no-live-counters --no-cpu-baseline --no-sequence --no-sweep --no-sustained --no-certificates --no-host-mirror --extended-steps 0"
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s --output-format csv -- $CMD > "$OUT/stats.log" 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" -o f --output-format csv -- $CMD > "$OUT/fetch.log" 2>&1
