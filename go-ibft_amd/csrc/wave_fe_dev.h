@@ -485,7 +485,9 @@ WVF wjac wjac_add(const wjac &p, const wjac &q, const wk &k) {
 }
 // madd-2007-bl (q affine, never infinity) with Z3 = (Z1 + H)² − Z1Z1 − HH written as 2·Z1·H (S = M here) and
 // Y3 = r·(V − X3) − 2·Y1·J as ONE fused multiply-add: nine multiplications and a fused pair instead of eleven.
-template <bool INL = false>
+// RARE_INL: the doubling of the exceptional case P = Q with its multiplications pasted in too — for a caller that must stay a
+// LEAF function (rows_two_adds_fn: a nested call makes the compiler save a register to the stack on every entry)
+template <bool INL = false, bool RARE_INL = false>
 WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
   const uint32_t z1z1 = wfe_sqr<INL>(p.z, k);
   const uint32_t u2 = wfe_mul<INL>(q.x, z1z1, k);
@@ -511,11 +513,46 @@ WVF wjac wjac_add_aff(const wjac &p, const waff &q, const wk &k) {
     bool rz = false;
     if (any(hz)) rz = wfe_is_zero(rr);
     const bool same = hz && rz, opposite = hz && !rz;
-    if (any(same)) r = wjac_select(same, wjac_dbl<false>(qj, k), r);
+    if (any(same)) r = wjac_select(same, wjac_dbl<RARE_INL>(qj, k), r);
     r = wjac_select(opposite, wjac_inf(), r);
   }
   r = wjac_select(p.inf, qj, r);
   return r;
+}
+// Two mixed additions in a row — acc ← acc + q1 (if t1), then + q2 (if t2) — as ONE outlined leaf function with the
+// multiplications pasted in (round 6, the A/B form IBFT_ROWS_SHARED_ADDS: see the macro for what it measured).  The idea: the
+// row-per-signature recover runs this pair 32 times in its main loop and 8 times for the fixed-base windows, whose own pasted copy
+// issues at 3.5 ns per instruction where the main loop's identical additions take 2.0 (profiles/r06e_rows_stage_issue.txt).
+#if defined(__HIP_DEVICE_COMPILE__)
+struct wjac4 {
+  uint32_t x, y, z, inf;
+};
+static __device__ __attribute__((noinline)) wjac4 rows_two_adds_fn(uint32_t x, uint32_t y, uint32_t z, uint32_t inf, uint32_t q1x,
+                                                                  uint32_t q1y, uint32_t q2x, uint32_t q2y, uint32_t t1, uint32_t t2,
+                                                                  uint32_t li, uint32_t row, uint32_t act, uint32_t m3, uint32_t lt3,
+                                                                  uint32_t lt9, uint32_t kr, uint32_t k1, uint32_t k2, uint32_t k8) {
+  wk k;
+  k.li = li; k.row = row; k.act = act; k.m3 = m3; k.lt3 = lt3; k.lt9 = lt9; k.kr = kr; k.k1 = k1; k.k2 = k2; k.k8 = k8;
+  wjac acc = wjac{x, y, z, inf != 0};
+  const wjac s1 = wjac_add_aff<true, true>(acc, waff{q1x, q1y}, k);
+  acc = wjac_select(t1 != 0, s1, acc);
+  const wjac s2 = wjac_add_aff<true, true>(acc, waff{q2x, q2y}, k);
+  acc = wjac_select(t2 != 0, s2, acc);
+  return wjac4{acc.x, acc.y, acc.z, acc.inf ? 1u : 0u};
+}
+#endif
+WVF wjac rows_two_adds(const wjac &acc, const waff &q1, const waff &q2, bool t1, bool t2, const wk &k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const wjac4 r = rows_two_adds_fn(acc.x, acc.y, acc.z, acc.inf ? 1u : 0u, q1.x, q1.y, q2.x, q2.y, t1 ? 1u : 0u, t2 ? 1u : 0u, k.li,
+                                   k.row, k.act, k.m3, k.lt3, k.lt9, k.kr, k.k1, k.k2, k.k8);
+  return wjac{r.x, r.y, r.z, r.inf != 0};
+#else
+  wjac a = acc;
+  const wjac s1 = wjac_add_aff<true>(a, q1, k);
+  a = wjac_select(t1, s1, a);
+  const wjac s2 = wjac_add_aff<true>(a, q2, k);
+  return wjac_select(t2, s2, a);
+#endif
 }
 HD wjac wjac_lane_xor(const wjac &p, int off) {
   wjac r;
@@ -1276,6 +1313,26 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
 #ifndef IBFT_ROWS_G_PREFETCH
 #define IBFT_ROWS_G_PREFETCH 0
 #endif
+// IBFT_ROWS_G_MERGED = 1 (round 6): the fixed-base additions run as further iterations of the MAIN LOOP — two table points per
+// iteration through the main loop's own two pasted mixed additions, no doublings — instead of a loop of their own around a third
+// pasted copy.  What the per-stage counters showed (profiles/r06e_rows_stage_issue.txt): the G stage issues 10.2 k instructions in
+// 36 µs, 3.5 ns each where the main loop's identical additions take 2.0 — and the excess does not move when the table points are
+// prefetched (profiles/r06f_gpre_stage_ab.txt): it is the first walk through 5.5 KB of code the instruction cache has never
+// seen, by every wavefront of the chip at once (so the reading went).
+// — BUILT AND MEASURED, NOT ADOPTED: the fixed-base stage fell from 0.035 to 0.023 ms, the main loop rose from 0.205 to 0.216 ms
+// (≈ 110 more instructions per iteration for the phase logic, and a worse schedule): N = 4 096 0.3338 → 0.3402 ms
+// (profiles/r06g_kernel_ab.txt, r06g_rows_stage_ms.txt).  What replaced it: IBFT_ROWS_SHARED_ADDS.
+#ifndef IBFT_ROWS_G_MERGED
+#define IBFT_ROWS_G_MERGED 0
+#endif
+// IBFT_ROWS_SHARED_ADDS = 1: both loops keep their shape and CALL one outlined pair of pasted mixed additions (rows_two_adds,
+// a leaf function: no stack).  BUILT AND MEASURED, NOT ADOPTED either: the main loop loses the same 0.010 ms (its two additions
+// no longer share a scheduling region with the doublings and the table reads around them) and the fixed-base stage gains
+// nothing: N = 4 096 0.3337 → 0.3406 ms (profiles/r06h_kernel_ab.txt, r06h_rows_stage_ms.txt).  The three pasted copies of the
+// mixed addition are a local optimum of THIS compiler's schedule; DESIGN.md §9 has the table.
+#ifndef IBFT_ROWS_SHARED_ADDS
+#define IBFT_ROWS_SHARED_ADDS 0
+#endif
 constexpr int ROW_TAB_G0 = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products, then (x, y) of the GTAB_WINDOWS points of u1·G
 constexpr int ROW_TAB_SLOTS = ROW_TAB_G0 + (IBFT_ROWS_G_PREFETCH ? 2 * ibftk::GTAB_WINDOWS : 0);
 template <int STOP = 99>
@@ -1489,12 +1546,64 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     const wjac s2 = wjac_add_aff(acc, waff{WT(2), sp.neg2 ? yn : y1}, k);
     acc = wjac_select((w2[4] & 1u) != 0, s2, acc);
   }
+#endif
+#if IBFT_ROWS_G_MERGED
+  // iterations jd = 31 … 0: digit jd of both scalars (four doublings, two table additions); iterations jd = −1 … −GIT: the
+  // fixed-base windows 2g, 2g + 1 (g = −1 − jd) of u1 into an accumulator of their own — the u2·R′ sum steps aside at jd = −1.
+  // The two table points of an iteration are asked for one iteration earlier.
+  static_assert(ibftk::GTAB_WINDOWS % 2 == 0, "two fixed-base windows per iteration");
+  constexpr int GIT = ibftk::GTAB_WINDOWS / 2;
+  wjac hold = wjac_inf();
+  waff pre1 = waff{0u, 0u}, pre2 = waff{0u, 0u};
+  auto g_digit = [&](int win) -> uint32_t {
+    const int bit = win * ibftk::GTAB_BITS;
+    return (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+  };
 #pragma unroll 1
-  for (int jd = 31; jd >= 0; jd--) {
+  for (int jd = 31; jd >= -GIT; jd--) {
+    waff q1, q2;
+    bool t1, t2;
+    if (jd >= 0) {  // (wave-uniform)
+      const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
+      const int d1 = n1 - 8, d2 = n2 - 8;
+      const uint32_t m1 = (uint32_t)(d1 < 0 ? -d1 : d1), m2 = (uint32_t)(d2 < 0 ? -d2 : d2);
+      const int e1 = 3 * (int)((m1 ? m1 : 1u) - 1u), e2 = 3 * (int)((m2 ? m2 : 1u) - 1u);
+      q1 = waff{WT(e1), WT(e1 + 1)};  // (read before the doublings that hide the latency)
+      q2 = waff{WT(e2 + 2), WT(e2 + 1)};
+#pragma unroll 1
+      for (int d = 0; d < 4; d++) acc = wjac_dbl<true>(acc, k);
+      q1.y = ((d1 < 0) != sp.neg1) ? wfe_neg1(q1.y, k) : q1.y;  // magnitude ≤ 2
+      q2.y = ((d2 < 0) != sp.neg2) ? wfe_neg1(q2.y, k) : q2.y;
+      t1 = m1 != 0;
+      t2 = m2 != 0;
+    } else {
+      if (jd == -1) {
+        acc.z = wfe_mul(acc.z, Zc, k);  // back from the isomorphic curve (an accumulator at infinity keeps its flag)
+        WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
+        hold = acc;
+        acc = wjac_inf();
+      }
+      const int g = -1 - jd;
+      q1 = pre1;
+      q2 = pre2;
+      t1 = g_digit(2 * g) != 0;
+      t2 = g_digit(2 * g + 1) != 0;
+    }
+    if (jd <= 0 && jd > -GIT) {  // the two points of the NEXT iteration: on their way while this one's additions run
+      const int g = -jd;
+      pre1 = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)(2 * g) * ibftk::GTAB_ENTRIES + g_digit(2 * g)), k);
+      pre2 = load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)(2 * g + 1) * ibftk::GTAB_ENTRIES + g_digit(2 * g + 1)), k);
+    }
+    const wjac s1 = wjac_add_aff<true>(acc, q1, k);
+    acc = wjac_select(t1, s1, acc);
+    const wjac s2 = wjac_add_aff<true>(acc, q2, k);
+    acc = wjac_select(t2, s2, acc);
+  }
+  const wjac accg_merged = acc;
+  acc = hold;
 #else
 #pragma unroll 1
-  for (int jd = 32; jd >= 0; jd--) {
-#endif
+  for (int jd = IBFT_ROWS_PEEL ? 31 : 32; jd >= 0; jd--) {
     // digit jd of both scalars (digit 32 is the carry bit, never negative); the table reads are issued before the
     // doublings that hide their latency
     const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
@@ -1508,13 +1617,21 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     }
     q1.y = ((d1 < 0) != sp.neg1) ? wfe_neg1(q1.y, k) : q1.y;  // magnitude ≤ 2
     q2.y = ((d2 < 0) != sp.neg2) ? wfe_neg1(q2.y, k) : q2.y;
+#if IBFT_ROWS_SHARED_ADDS
+    acc = rows_two_adds(acc, q1, q2, m1 != 0, m2 != 0, k);
+#else
     const wjac s1 = wjac_add_aff<true>(acc, q1, k);
     acc = wjac_select(m1 != 0, s1, acc);
     const wjac s2 = wjac_add_aff<true>(acc, q2, k);
     acc = wjac_select(m2 != 0, s2, acc);
+#endif
   }
+#endif  // IBFT_ROWS_G_MERGED
 #undef WT
 #endif
+#if IBFT_ROWS_G_MERGED
+  const wjac accg = accg_merged;
+#else
   acc.z = wfe_mul(acc.z, Zc, k);  // back from the isomorphic curve (an accumulator at infinity keeps its flag)
   WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
   // u1·G: all the fixed-base windows in this row — into the accumulator itself, or (deferred √) into one of its own: the
@@ -1531,6 +1648,29 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
 #else
 #define WV_GPOINT(win) load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)(win) * ibftk::GTAB_ENTRIES + dgt), k)
 #endif
+#if IBFT_ROWS_SHARED_ADDS
+  // two windows per step through the main loop's own pair of additions (rows_two_adds); the two table points of the next
+  // step are asked for before this step's additions run
+  {
+    static_assert(ibftk::GTAB_WINDOWS % 2 == 0, "two fixed-base windows per step");
+    auto g_digit = [&](int win) -> uint32_t {
+      const int bit = win * ibftk::GTAB_BITS;
+      return (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    };
+    auto g_point = [&](int win) -> waff {
+      return load_waff(gtab + (size_t)ibftk::GTAB_ENTRY_DWORDS * ((size_t)win * ibftk::GTAB_ENTRIES + g_digit(win)), k);
+    };
+    waff c1 = g_point(0), c2 = g_point(1);
+#pragma unroll 1
+    for (int g = 0; g < ibftk::GTAB_WINDOWS / 2; g++) {
+      const int gn = g + 1 < ibftk::GTAB_WINDOWS / 2 ? g + 1 : g;  // (the last step re-reads its own points)
+      const waff n1 = g_point(2 * gn), n2 = g_point(2 * gn + 1);
+      accg = rows_two_adds(accg, c1, c2, g_digit(2 * g) != 0, g_digit(2 * g + 1) != 0, k);
+      c1 = n1;
+      c2 = n2;
+    }
+  }
+#else
 #if IBFT_ROWS_PEEL && IBFT_ROWS_DEFER_SQRT
   // window 0 into an accumulator at infinity is the table point itself (or still infinity for a zero digit)
   {
@@ -1538,19 +1678,18 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     const waff pt = WV_GPOINT(0);
     accg = wjac_select(dgt != 0, wjac_from_aff(pt, k), accg);
   }
-#pragma unroll 1
-  for (int win = 1; win < ibftk::GTAB_WINDOWS; win++) {
-#else
-#pragma unroll 1
-  for (int win = 0; win < ibftk::GTAB_WINDOWS; win++) {
 #endif
+#pragma unroll 1
+  for (int win = (IBFT_ROWS_PEEL && IBFT_ROWS_DEFER_SQRT) ? 1 : 0; win < ibftk::GTAB_WINDOWS; win++) {
     const int bit = win * ibftk::GTAB_BITS;
     const uint32_t dgt = (u1.v[bit >> 5] >> (bit & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
     const waff pt = WV_GPOINT(win);
     const wjac sum = wjac_add_aff<true>(accg, pt, k);
     accg = wjac_select(dgt != 0, sum, accg);
   }
+#endif  // IBFT_ROWS_SHARED_ADDS
 #undef WV_GPOINT
+#endif  // IBFT_ROWS_G_MERGED
   WV_STAGE(5, acc.x ^ acc.y ^ acc.z ^ accg.x ^ accg.z)
 #if IBFT_ROWS_DEFER_SQRT
   ok = rows_finish_deferred(Qa, accg, acc, rhs, v, k) && ok;

@@ -91,3 +91,17 @@ if has fresh; then
   timeout 1500 python tools/fresh_batch_ab.py ${IBFT_AB_OLD:-ab/libibftgpu_r05.so} ${IBFT_AB_NEW:-go-ibft_amd/csrc/libibftgpu.so} ${IBFT_AB_ROUNDS:-3} > gpurun_out/profiles/${TAG}_fresh_batch_ab.txt 2> gpurun_out/${TAG}_fresh_ab.err
   echo "fresh-batch A/B rc=$?"; cat gpurun_out/profiles/${TAG}_fresh_batch_ab.txt; tail -3 gpurun_out/${TAG}_fresh_ab.err
 fi
+if has stageissue; then
+  timeout 600 python tools/rows_stage_issue.py 4096 > gpurun_out/profiles/${TAG}_rows_stage_issue.txt 2> gpurun_out/${TAG}_stage_issue.err; echo "stage issue rc=$?"
+  cat gpurun_out/profiles/${TAG}_rows_stage_issue.txt; tail -3 gpurun_out/${TAG}_stage_issue.err
+fi
+if has gpre; then
+  # the row recover's stage times with the G-table prefetch (IBFT_ROWS_G_PREFETCH=1: ab/libibft_devtest_gpre.so) and without, alternating
+  for r in 1 2 3; do
+    for which in off on; do
+      so=""; [ $which = on ] && so="$ROOT/ab/libibft_devtest_gpre.so"
+      echo "== prefetch $which (round $r)"; DEVTEST_SO=$so timeout 300 python tools/rows_stages.py 4096 2>&1 | grep -E "main loop|G additions|Z\^-1|complete|tables"
+    done
+  done > gpurun_out/profiles/${TAG}_gpre_stage_ab.txt 2>&1
+  echo "gpre rc=$?"; cat gpurun_out/profiles/${TAG}_gpre_stage_ab.txt
+fi

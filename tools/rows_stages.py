@@ -2,7 +2,7 @@
 product's launch shape; run on the GPU box.  Usage: python tools/rows_stages.py [n_rows=4096]"""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (works from any directory: rocprofv3 runs it from /tmp)
 import go_ibft_amd.build as build
 from oracle import binding as B, workload as W
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
