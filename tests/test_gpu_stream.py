@@ -101,6 +101,9 @@ def test_pipelined_passes_deliver_every_pass_in_order_through_two_result_slots(o
         for i, cur in enumerate(order):
             bv.seals_submit()                                  # pass over batch `cur`
             expected.append(cur)
+            # ibft_seals_rows (round 6): the LIBRARY's own counts — the resident batch, and the oldest pass not yet collected —
+            # are what a binding sizes its verdict buffers from, whatever was swapped in between
+            assert bv.seals_rows() == (len(batches[cur][4]), len(batches[expected[0]][4]))
             if i + 1 < len(order):
                 bv.seals_stage_next(*host[order[i + 1]])
             if len(expected) == 2:
@@ -115,6 +118,7 @@ def test_pipelined_passes_deliver_every_pass_in_order_through_two_result_slots(o
         verdict, t = bv.seals_collect()
         want, wt = batches[expected.pop(0)][4:6]
         assert (verdict == want).all() and t.power == wt.power
+        assert bv.seals_rows() == (len(batches[order[-1]][4]), 0)      # nothing in flight
         # the synchronous calls still work next to the pipeline, warm path included
         verdict, t = bv.seals_run()
         assert (verdict == batches[order[-1]][4]).all()
@@ -132,3 +136,23 @@ def test_pipelined_passes_deliver_every_pass_in_order_through_two_result_slots(o
         assert wv.cache_stats()[0] > 0
     finally:
         wv.close()
+
+
+def test_device_canary_reads_a_healthy_issue_time():
+    """ibft_issue_probe (round 6): wall ns per aligned 8-byte VALU instruction per SIMD with one wavefront per SIMD — 1.89 through
+    this probe on a healthy MI355X (profiles/r06*_kernel_ab.txt); the bench line flags a device more than 5 % off.  Here: a sane
+    number (the probe really ran one wavefront per SIMD: the first version, packed four workgroups to a compute unit, read 2.53),
+    stable across calls, and the context still verifies afterwards."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W
+    bv = V.BatchVerifier(max_rows=1024)
+    try:
+        ns = [bv.issue_probe()[0] for _ in range(3)]
+        assert all(1.6 < x < 2.3 for x in ns), ns
+        assert max(ns) - min(ns) < 0.1, ns
+        r = W.make_round(64, 77)
+        bv.set_validators(1, r.addrs, r.power)
+        got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20)
+        assert got.all() and t.has_quorum == 1
+    finally:
+        bv.close()
