@@ -196,6 +196,17 @@ int dev_recover_address_lds(const uint8_t *digest32, const uint8_t *sig65, uint3
   return ok ? 1 : 0;
 }
 
+// the same recover with the table in the private segment, co-Z build, one loop (round 6: the lane kernel's form beyond 65 536 rows)
+int dev_recover_address_private(const uint8_t *digest32, const uint8_t *sig65, uint32_t flags, uint8_t *addr20) {
+  dev_gtab_init();
+  uint32_t a[5];
+  ibftk::aff Qa;
+  bool ok = ibftk::recover_pubkey_with(g_gtab.data(), secp::from_be32(digest32), secp::from_be32(sig65), secp::from_be32(sig65 + 32),
+                                       sig65[64], flags, a, Qa, ibftk::var_mult_private<false>{});
+  memcpy(addr20, a, 20);
+  return ok ? 1 : 0;
+}
+
 int dev_recover_address(const uint8_t *digest32, const uint8_t *sig65, uint32_t flags, uint8_t *addr20) {
   dev_gtab_init();
   uint32_t a[5];

@@ -255,6 +255,20 @@ __host__ __device__ __forceinline__ secp::fe ltab_get(const ltab<TPB> &t, int s)
   for (int w = 0; w < 10; w++) v.n[w] = t.col[(size_t)(10 * s + w) * TPB];
   return v;
 }
+// The same sixteen slots in the lane's PRIVATE segment (plus eight for β·x of the entries: memory is not scarce there) — the
+// lane kernel's form beyond 65 536 rows, where two wavefronts per SIMD are resident and LDS cannot hold two tables per lane.
+// A private array indexed by a loop counter is exactly what the private segment is for.
+struct ptab {
+  secp::fe e[24];  // slots 0…15: (x, y) of entries 1…8; 16…23: β·x of entries 1…8
+  secp::fe zc;
+};
+template <int TPB>
+__host__ __device__ __forceinline__ void tab_put(ltab<TPB> &t, int s, const secp::fe &v) { ltab_put(t, s, v); }
+template <int TPB>
+__host__ __device__ __forceinline__ secp::fe tab_get(const ltab<TPB> &t, int s) { return ltab_get(t, s); }
+__host__ __device__ __forceinline__ void tab_put(ptab &t, int s, const secp::fe &v) { t.e[s] = v; }
+__host__ __device__ __forceinline__ secp::fe tab_get(const ptab &t, int s) { return t.e[s]; }
+
 // entry e (1…8): x in slot 2(e−1), y in slot 2(e−1)+1
 //
 // Round 6 — the table is built with CO-Z additions (Meloni 2007; the "ZADDU" form of Goundar, Joye, Miyaji), in place, by
@@ -271,8 +285,8 @@ __host__ __device__ __forceinline__ secp::fe ltab_get(const ltab<TPB> &t, int s)
 // last addition IS the common Z.  ≈ 100 multiplications, no Z kept but the current one, every entry addressed in LDS by a
 // loop counter: 4 KB of code instead of 21.  No exceptional case exists: (k−1)·R = ±R would make R a point of order ≤ 9, and the
 // curve's order is prime (a row whose r is no x coordinate computes garbage here and is rejected by its failed square root).
-template <int TPB>
-__host__ __device__ __forceinline__ void ecmult_table_lds(const aff &R1, ltab<TPB> &t) {
+template <class TAB>
+__host__ __device__ __forceinline__ void ecmult_table_coz(const aff &R1, TAB &t) {
   // 2R from the affine R (Z = 1: mdbl-2007-bl), then R brought to 2R's Z = 2y — for which nothing has to be multiplied but
   // x: Z² = 4·y², Z³·y = 8·y⁴, and y², y⁴ are the doubling's own YY, YYYY.  Seven multiplications for both.
   secp::fe z;
@@ -286,16 +300,16 @@ __host__ __device__ __forceinline__ void ecmult_table_lds(const aff &R1, ltab<TP
     const secp::fe y8 = secp::fe_mul_int(yyyy, 8);                                             // 8
     const secp::fe y3 = secp::fe_normalize_weak(
         secp::fe_add(secp::fe_mul(mM, secp::fe_add(sS, secp::fe_neg(x3, 1))), secp::fe_neg(y8, 8)));  // 1 + 9 → 1
-    ltab_put(t, 2, x3);
-    ltab_put(t, 3, y3);
+    tab_put(t, 2, x3);
+    tab_put(t, 3, y3);
     z = secp::fe_normalize_weak(secp::fe_mul_int(R1.y, 2));
-    ltab_put(t, 0, secp::fe_mul(R1.x, secp::fe_mul_int(yy, 4)));   // x·Z²
-    ltab_put(t, 1, secp::fe_normalize_weak(y8));                  // y·Z³ = 8·y⁴
+    tab_put(t, 0, secp::fe_mul(R1.x, secp::fe_mul_int(yy, 4)));   // x·Z²
+    tab_put(t, 1, secp::fe_normalize_weak(y8));                  // y·Z³ = 8·y⁴
   }
 #pragma unroll 1
   for (int k = 3; k <= 8; k++) {  // entry k = entry (k − 1) + entry 1, both at Z = z
     const int sp = 2 * (k - 2);   // slots of P = entry k − 1; its sum goes to sp + 2
-    const secp::fe x1 = ltab_get(t, sp), y1 = ltab_get(t, sp + 1), x2 = ltab_get(t, 0), y2 = ltab_get(t, 1);
+    const secp::fe x1 = tab_get(t, sp), y1 = tab_get(t, sp + 1), x2 = tab_get(t, 0), y2 = tab_get(t, 1);
     const secp::fe dx = secp::fe_add(x1, secp::fe_neg(x2, 1));  // 3
     const secp::fe dy = secp::fe_add(y1, secp::fe_neg(y2, 1));  // 3
     const secp::fe c = secp::fe_sqr(dx);
@@ -306,22 +320,24 @@ __host__ __device__ __forceinline__ void ecmult_table_lds(const aff &R1, ltab<TP
     const secp::fe y3 = secp::fe_normalize_weak(
         secp::fe_add(secp::fe_mul(dy, secp::fe_add(w1, secp::fe_neg(x3, 1))), secp::fe_neg(a1, 1)));  // 3 → 1
     z = secp::fe_mul(z, dx);
-    ltab_put(t, sp, w1);  // entry k − 1 at the new Z: free
-    ltab_put(t, sp + 1, a1);
-    ltab_put(t, sp + 2, x3);
-    ltab_put(t, sp + 3, y3);
+    tab_put(t, sp, w1);  // entry k − 1 at the new Z: free
+    tab_put(t, sp + 1, a1);
+    tab_put(t, sp + 2, x3);
+    tab_put(t, sp + 3, y3);
     const secp::fe c3 = secp::fe_mul(c, dx);  // λ³
-    ltab_put(t, 0, w2);   // entry 1 at the new Z: x2·λ² is W2
-    ltab_put(t, 1, secp::fe_mul(y2, c3));
+    tab_put(t, 0, w2);   // entry 1 at the new Z: x2·λ² is W2
+    tab_put(t, 1, secp::fe_mul(y2, c3));
 #pragma unroll 1
     for (int j = 2; j <= k - 2; j++) {  // entries 2 … k − 2 follow
       const int sj = 2 * (j - 1);
-      ltab_put(t, sj, secp::fe_mul(ltab_get(t, sj), c));
-      ltab_put(t, sj + 1, secp::fe_mul(ltab_get(t, sj + 1), c3));
+      tab_put(t, sj, secp::fe_mul(tab_get(t, sj), c));
+      tab_put(t, sj + 1, secp::fe_mul(tab_get(t, sj + 1), c3));
     }
   }
   t.zc = z;
 }
+template <int TPB>
+__host__ __device__ __forceinline__ void ecmult_table_lds(const aff &R1, ltab<TPB> &t) { ecmult_table_coz(R1, t); }
 template <int TPB>
 __host__ __device__ __forceinline__ aff window_operand_lds(const ltab<TPB> &t, int e, bool flip) {
   const uint32_t mag = (uint32_t)(e < 0 ? -e : e);
@@ -435,6 +451,75 @@ __host__ __device__ __forceinline__ jac ecmult_var_gen_lds(const aff &R, const u
   return acc;
 }
 
+// The same loop over a table in the private segment (the lane kernel beyond 65 536 rows: two resident wavefronts per SIMD).
+// The co-Z build works in place there too; β·x of the eight entries is computed once behind it (memory is not scarce in the
+// private segment), so the λ steps multiply nothing.  101 → 58 KB of code for the last kernel the AUTO rule dispatches that
+// was larger than the instruction cache.
+__host__ __device__ __forceinline__ jac ecmult_var_gen_private(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
+                                                               const u256 &u1) {
+  u256 kk = u1;
+  uint32_t dgt = kk.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+  gtab_raw cur = gtab_load(gtab, 0, dgt);
+  secp::glv_split sp = secp::sc_split_lambda(k);
+  aff R1 = R;
+  R1.y = secp::l26_select(sp.neg1, secp::fe_normalize_weak(secp::fe_neg(R.y, 1)), R.y);
+  const bool flip2 = sp.neg1 != sp.neg2;
+  ptab t;
+  ecmult_table_coz(R1, t);
+  {
+    const secp::fe beta = secp::GLV_CONST(1);
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) t.e[16 + j] = secp::fe_mul(t.e[2 * j], beta);
+  }
+  u256 r1 = window_bias(sp.k1), r2 = window_bias(sp.k2);
+  jac acc = secp::jac_inf();
+  int e1 = 0, e2 = 0;
+  constexpr int WSTEPS = 2 * WINDOW_DIGITS;
+#pragma unroll 1
+  for (int st = 0; st < WSTEPS + GTAB_WINDOWS; st++) {
+    aff q;
+    bool take;
+    gtab_raw nxt = cur;
+    uint32_t dn = dgt;
+    if (st < WSTEPS) {  // (wave-uniform)
+      const bool h = (st & 1) != 0;
+      if (!h) {
+        if (st != 0) {
+#pragma unroll 1
+          for (int d = 0; d < 4; d++) acc = secp::jac_dbl_t<true>(acc);
+        }
+        e1 = (int)secp::top_nibble<5>(r1) - 8;
+        e2 = (int)secp::top_nibble<5>(r2) - 8;
+        secp::shl4<5>(r1);
+        secp::shl4<5>(r2);
+      }
+      const int e = h ? e2 : e1;
+      const int mag = e < 0 ? -e : e;
+      const int ent = (mag ? mag : 1) - 1;  // (a dummy operand for e = 0: the sum is computed and dropped)
+      q.x = t.e[h ? 16 + ent : 2 * ent];
+      const secp::fe y = t.e[2 * ent + 1];
+      q.y = secp::l26_select((e < 0) != (h && flip2), secp::fe_neg(y, 1), y);  // magnitude ≤ 2
+      take = e != 0;
+    } else {
+      if (st == WSTEPS) acc.z = secp::fe_mul(acc.z, t.zc);  // back from the isomorphic curve
+      const int w = st - WSTEPS;
+      const bool last = w + 1 == GTAB_WINDOWS;
+      secp::shr_bits<GTAB_BITS>(kk);
+      dn = last ? dgt : kk.v[0] & (uint32_t)(GTAB_ENTRIES - 1);
+      nxt = gtab_load(gtab, last ? w : w + 1, dn);
+      q = gtab_point(cur);
+      take = dgt != 0;
+    }
+    const jac sum = secp::jac_add_aff_t<true>(acc, q);
+    acc = secp::jac_select(take, sum, acc);
+    if (st >= WSTEPS) {
+      cur = nxt;
+      dgt = dn;
+    }
+  }
+  return acc;
+}
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // Round 1's u2·R (4-bit unsigned windows over 15 Jacobian multiples, full additions): host builds only — the CPU
 // harness checks the new form against it on random and adversarial scalars (tests/test_dev_arith_host.py)
@@ -474,7 +559,10 @@ template <bool PREFETCH>
 struct var_mult_private {
   __host__ __device__ __forceinline__ jac operator()(const aff &R, const u256 &k, const uint32_t *__restrict__ gtab,
                                                      const u256 &u1) const {
-    return ecmult_gen(gtab, u1, ecmult_var_t<PREFETCH>(R, k));
+#if IBFT_LANE_MERGED
+    if constexpr (!PREFETCH) return ecmult_var_gen_private(R, k, gtab, u1);  // (the form the AUTO rule dispatches beyond 65 536 rows)
+#endif
+    return ecmult_gen(gtab, u1, ecmult_var_t<PREFETCH>(R, k));  // (round 4's form with the entries read in front of the doublings: A/B)
   }
 };
 template <int TPB>

@@ -294,6 +294,12 @@ def test_recover_address_matches_oracle(dev, oracle):
             assert bool(ok2) == bool(ok), (i, fl)
             if ref is not None:
                 assert o2.raw == ref, (i, fl)
+            # round 6, the lane kernel's form beyond 65 536 rows: the co-Z table in the private segment, one loop
+            o3 = C.create_string_buffer(20)
+            ok3 = dev.dev_recover_address_private(d, sig, fl, o3)
+            assert bool(ok3) == bool(ok), (i, fl)
+            if ref is not None:
+                assert o3.raw == ref, (i, fl)
 
 
 def test_variable_time_divsteps_match_constant_time(dev):
