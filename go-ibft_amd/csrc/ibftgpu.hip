@@ -104,6 +104,8 @@ struct ibft_ctx {
   hipEvent_t ev_pass[2] = {nullptr, nullptr};
   uint32_t pass_issued = 0, pass_collected = 0, pass_n[2] = {0, 0};
   int learn_rc = IBFT_OK;  // a table build behind a DELIVERED pass failed: reported by the next ibft_seals_submit
+  bool split_large = true;    // batches of 65 537 … 98 304 rows as two launches (enqueue_recover); IBFT_SPLIT_LARGE=0 turns it off (A/B)
+  uint32_t split_launches = 0;
   int tally_slot = -1;      // ≥ 0: the next tally delivers into pipeline slot `tally_slot` instead of h_mask / h_tally
   uint32_t launched_n = 0;  // rows of the last ibft_seals_launch: what ibft_seals_fetch delivers (a swap may have changed staged_n since)
   DevBuf d_mask, d_vidx, d_tally, d_H;
@@ -351,8 +353,34 @@ void recount_built(ibft_ctx *c) {  // c->dev->mu held
   c->seen_build_epoch = c->dev->build_epoch;
 }
 
+// Batches just beyond what one wavefront per SIMD can take (65 536 rows through the lane kernel with its tables in LDS): the
+// private-segment form that serves everything larger keeps TWO wavefronts on as many SIMDs as there are rows beyond 65 536 — and
+// the launch lasts as long as those: 1.72 ms for 70 000 rows where 65 536 take 0.92 (profiles/r06j_kernel_ab.txt).  Up to
+// SPLIT_ROWS_MAX rows the batch is two launches instead — 65 536 rows through the LDS-table lane kernel, the rest through whatever
+// the AUTO rule picks for that many rows (rows 65 536 … n are a batch of their own: every kernel takes a row base): 0.92 + 0.33 ms at
+// 70 000 rows, 0.92 + 0.75 at 98 304; beyond that the private-segment form wins again (131 072: 1.76 ms).  Cold contexts without
+// pinned kernels only (round 6).
+constexpr uint32_t SPLIT_ROWS_MIN = 65536u, SPLIT_ROWS_MAX = 98304u;
+
 int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_it, uint32_t row_base = 0, bool keep_mask = false) {
   if (n == 0) return IBFT_OK;
+  if (n > SPLIT_ROWS_MIN && n <= SPLIT_ROWS_MAX && !c->cache_on && c->cold_group_auto && !c->cold_group_force && !c->cold_table_force &&
+      row_base % 64 == 0 && c->split_large) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (time_it) {
+      int rc = next_events(c, &e0, &e1);
+      if (rc) return rc;
+      HIPCHK(c, hipEventRecord(e0, c->stream));
+    }
+    int rc = enqueue_recover(c, SPLIT_ROWS_MIN, with_pre, mode, false, row_base, keep_mask);
+    if (rc) return rc;
+    if ((rc = enqueue_recover(c, n - SPLIT_ROWS_MIN, with_pre, mode, false, row_base + SPLIT_ROWS_MIN, true))) return rc;
+    if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
+    c->last_cold_group = 1;   // (what ibft_last_dispatch reports for a split batch: the lane kernel took the bulk)
+    c->last_cold_table = 1;
+    c->split_launches++;
+    return IBFT_OK;
+  }
   std::unique_lock<std::mutex> dev_lk(c->dev->mu, std::defer_lock);
   if (c->cache_on) {
     dev_lk.lock();
@@ -1300,6 +1328,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->max_rows = (cfg && cfg->max_rows) ? cfg->max_rows : DEFAULT_MAX_ROWS;
   c->kernel = cfg ? cfg->kernel : IBFT_KERNEL_AUTO;
   c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
+  if (const char *e = getenv("IBFT_SPLIT_LARGE")) c->split_large = strcmp(e, "0") != 0;
   if (const char *e = getenv("IBFT_COLD_TABLE")) {
     if (!strcmp(e, "lds")) c->cold_table_force = 1;
     else if (!strcmp(e, "private")) c->cold_table_force = 2;

@@ -366,6 +366,9 @@ int ibft_cache_memory(ibft_ctx *ctx, uint64_t *device_bytes, uint32_t *slots_in_
  * 2/4/8 = ecrecover_group_kernel, 16 = ecrecover_rows_kernel, 64 = ecrecover_wave_kernel, 128 = ecrecover_wave2_kernel)
  * and warm kernel (0 = none ran, 1 = lane, 2..64 = group).                                        */
 int ibft_last_dispatch(ibft_ctx *ctx, uint32_t *cold_lanes, uint32_t *warm_lanes);
+/* (A cold batch of 65 537 … 98 304 rows is two launches — 65 536 rows through the lane kernel with its tables in LDS, the rest
+ * through the kernel the rule above picks for that many rows — and reports cold_lanes = 1, table 1; IBFT_SPLIT_LARGE=0 in the
+ * environment pins one launch of the private-segment lane kernel.)                                                        */
 /* Where the last lane / group cold kernel kept the per-lane window table of u2·R: 0 = no such kernel ran, 1 = the
  * workgroup's LDS (default up to one wavefront per SIMD: no private segment), 2 = private segment with the entries read in
  * front of the doublings (round 4's form; IBFT_COLD_TABLE=private), 3 = private segment without that prefetch — two

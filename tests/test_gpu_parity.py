@@ -127,20 +127,28 @@ def test_every_table_placement_of_the_lane_and_group_kernels(oracle, lanes, tabl
         bv.close()
 
 
-def test_lane_kernel_beyond_one_wavefront_per_simd_takes_the_two_resident_form(oracle):
-    """n > 65 536: the lane kernel with the table in the private segment and no prefetch (256 registers, two resident wavefronts
-    per SIMD) — verdicts at 70 000 rows with 20 % Byzantine seals against the oracle (16 host threads)"""
+@pytest.mark.parametrize("n,split,table", [(70000, "1", 1), (70000, "0", 3), (98304, "1", 1), (100000, "1", 3)])
+def test_batches_beyond_one_wavefront_per_simd(oracle, monkeypatch, n, split, table):
+    """n > 65 536.  Up to 98 304 rows the batch is TWO launches (round 6): 65 536 rows through the lane kernel with its tables in
+    LDS, the rest through whatever the AUTO rule picks for that many rows (here: the row-per-signature kernel for 4 464 rows, the
+    2-lane group kernel for 32 768) — ibft_last_cold_table says 1; beyond that, or with IBFT_SPLIT_LARGE=0, ONE launch of the lane
+    kernel with the table in the private segment (co-Z build in place, two resident wavefronts per SIMD) — table 3.  Verdicts with
+    20 % Byzantine seals against the oracle (16 host threads), every row of both launches."""
     import go_ibft_amd.verifier as V
     import go_ibft_amd.simulate as SIM
-    n = 70000
+    monkeypatch.setenv("IBFT_SPLIT_LARGE", split)
     bv = V.BatchVerifier(max_rows=n)
     try:
         r = SIM.make_round(bv, n, 77, byzantine=True)
         bv.set_validators(1, r.addrs, r.power)
         got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
-        assert bv.last_dispatch() == (1, 0)
+        assert bv.last_dispatch() == (1, 0) and bv.last_cold_table() == table
         exp = oracle.verify_seals(oracle.ValSet(r.addrs, r.power), r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=16).astype(bool)
         assert (got == exp).all() and (exp == r.expect).all()
+        te = oracle.tally(oracle.ValSet(r.addrs, r.power), r.signer20, exp.astype(np.uint8))
+        assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == (te.power, te.valid_rows, te.distinct_senders, te.has_quorum)
+        got2, _ = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)      # a second pass over a mask the tally left clean
+        assert (got2 == exp).all()
     finally:
         bv.close()
 
