@@ -372,8 +372,13 @@ int enqueue_recover(ibft_ctx *c, uint32_t n, bool with_pre, int mode, bool time_
       if (rc) return rc;
       HIPCHK(c, hipEventRecord(e0, c->stream));
     }
-    int rc = enqueue_recover(c, SPLIT_ROWS_MIN, with_pre, mode, false, row_base, keep_mask);
+    // The work mask is cleared HERE, once, for both launches: the lane kernel of the first part stores whole verdict words and
+    // never asks for a clean mask, the kernel of the second part ORs its bits into words it expects to be zero (a dirty or
+    // freshly allocated mask gave wrong verdicts in the rows beyond 65 536: caught by the Byzantine parity test, not by the
+    // all-valid A/B rounds).
+    int rc = keep_mask ? (int)IBFT_OK : clean_mask(c);
     if (rc) return rc;
+    if ((rc = enqueue_recover(c, SPLIT_ROWS_MIN, with_pre, mode, false, row_base, true))) return rc;
     if ((rc = enqueue_recover(c, n - SPLIT_ROWS_MIN, with_pre, mode, false, row_base + SPLIT_ROWS_MIN, true))) return rc;
     if (time_it) HIPCHK(c, hipEventRecord(e1, c->stream));
     c->last_cold_group = 1;   // (what ibft_last_dispatch reports for a split batch: the lane kernel took the bulk)

@@ -453,7 +453,7 @@ func (c *Ctx) IssueProbe() (nsPerInst float32, err error) {
 
 // SignSeals = n × Backend.BuildCommitMessage's committed seal (core/backend.go:12-34) for a SIMULATOR that plays
 // n validators in one process: sk and hashes are n×32 bytes; returns the n×65 seals, the n×20 signer addresses
-// and ok[i] == 0 for a key outside [1, n).  Leaves the batch resident: SealsRun(n) verifies it without an upload.
+// and ok[i] == 0 for a key outside [1, n).  Leaves the batch resident: SealsRun() verifies it without an upload.
 // Not for a production validator's key (include/ibftgpu.h, ibft_sign_seals).
 func (c *Ctx) SignSeals(sk, hashes []byte) (seals, signers, ok []byte, err error) {
 	n := len(sk) / 32

@@ -141,6 +141,10 @@ def test_batches_beyond_one_wavefront_per_simd(oracle, monkeypatch, n, split, ta
     try:
         r = SIM.make_round(bv, n, 77, byzantine=True)
         bv.set_validators(1, r.addrs, r.power)
+        # a hash batch first: it leaves its verdict bits in the context's work mask (no tally consumes them) — the second launch of
+        # a split batch ORs its bits into that mask and must find it cleared (the first version of the split did not clear it)
+        hv = bv.is_valid_proposal_hash(r.raw, r.round, r.hash32, np.full(n, 32, np.uint8))
+        assert hv.sum() > 0.7 * n
         got, t = bv.is_valid_committed_seal(r.hash32, r.seal65, r.signer20, r.pre_flags)
         assert bv.last_dispatch() == (1, 0) and bv.last_cold_table() == table
         exp = oracle.verify_seals(oracle.ValSet(r.addrs, r.power), r.hash32, r.seal65, r.signer20, r.pre_flags, nthreads=16).astype(bool)
