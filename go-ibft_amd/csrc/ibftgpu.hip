@@ -299,7 +299,7 @@ ibftk::recover_args make_args(ibft_ctx *c, uint32_t n, bool with_pre, uint32_t r
   a.signer20 = (const uint8_t *)c->d_signer.p + 20ull * row_base;
   a.pre_flags = with_pre ? (const uint8_t *)c->d_pre.p + row_base : nullptr;
   a.payload = (const uint8_t *)c->d_payload.p;
-  a.off = (const uint32_t *)c->d_off.p;
+  a.off = (const uint32_t *)c->d_off.p + row_base;  // (the offsets themselves are absolute positions in `payload`)
   a.gtab = (const uint32_t *)c->dev->d_gtab.p;
   a.vtab = (const uint32_t *)c->d_vtab.p;
   a.vslot_mask = c->vslot_mask;

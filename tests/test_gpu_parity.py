@@ -157,6 +157,40 @@ def test_batches_beyond_one_wavefront_per_simd(oracle, monkeypatch, n, split, ta
         bv.close()
 
 
+_ENVELOPE_ROUND = {}
+
+
+def _envelope_round(n, seed):
+    """(19 s of oracle signing at 70 000 rows: made once for both forms)"""
+    from oracle import workload as W
+    if (n, seed) not in _ENVELOPE_ROUND:
+        _ENVELOPE_ROUND[(n, seed)] = W.make_round(n, seed, with_envelopes=True)
+    return _ENVELOPE_ROUND[(n, seed)]
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_senders_beyond_one_wavefront_per_simd(oracle, monkeypatch, split):
+    """IsValidValidator over 70 000 envelopes (Keccak of PayloadNoSig fused, MODE = 1) — as two launches and as one: the second
+    launch of the split form reads its payload offsets from row 65 536 on (a row base that was never applied to the offset column
+    before round 6: only seal batches had used one)."""
+    import go_ibft_amd.verifier as V
+    n = 70000
+    monkeypatch.setenv("IBFT_SPLIT_LARGE", split)
+    r = _envelope_round(n, 4242)
+    sig = np.array(r.msg_sig65, copy=True)
+    bad = np.arange(0, n, 7)
+    sig[bad, 9] ^= 0x20                                   # every seventh envelope signature forged, beyond row 65 536 too
+    bv = V.BatchVerifier(max_rows=n)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        got, _ = bv.is_valid_validator(r.payload, r.off, sig, r.signer20)
+        assert bv.last_dispatch() == (1, 0) and bv.last_cold_table() == (1 if split == "1" else 3)
+        exp = oracle.verify_senders(oracle.ValSet(r.addrs, r.power), r.payload, r.off, sig, r.signer20, nthreads=16).astype(bool)
+        assert (got == exp).all() and not exp[bad].any() and exp.sum() == n - len(bad)
+    finally:
+        bv.close()
+
+
 @pytest.mark.parametrize("n,expect_group", [(1, 128), (61, 128), (512, 128), (513, 64), (1500, 64), (3000, 16), (5000, 16), (8192, 16),
                                             (12000, 4), (20000, 2), (40000, 1)])
 def test_cold_group_sizes(oracle, n, expect_group):

@@ -9,6 +9,7 @@ ibft_verify_messages, and once through ibft_tally_prepare — every verdict bit,
 quorum flag against the CPU oracle.  Rounds and oracle answers are produced by worker processes (spawned: they never touch the
 HIP runtime of this process) while the GPU consumes; ≈ 95 s with 16 workers.  IBFT_SOAK_ROUNDS=<k> shortens the N = 64 series
 (the assertion on the total then fails on purpose unless IBFT_SOAK_ALLOW_SHORT=1: a shortened soak is not the evidence)."""
+import itertools
 import json
 import os
 import time
@@ -54,7 +55,11 @@ def test_full_soak_bit_identical_with_the_oracle():
     bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=40000)
     try:
         with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
-            for (n, seed, addrs, power, h, s, f, pre, exp, et, env) in ex.map(make, jobs, chunksize=8):
+            # the twelve long jobs one per task (a chunk of eight of them kept ONE worker busy for a minute while the consumer
+            # waited for it: results come back in submission order), the short ones in chunks of eight; both maps submit at once
+            n_long = sum(1 for j in jobs if j[0] >= 16384)
+            results = itertools.chain(ex.map(make, jobs[:n_long], chunksize=1), ex.map(make, jobs[n_long:], chunksize=8))
+            for (n, seed, addrs, power, h, s, f, pre, exp, et, env) in results:
                 bad = 0
                 bv.set_validators(seed, addrs, power)
                 for _ in range(2):
