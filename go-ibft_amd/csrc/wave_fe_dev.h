@@ -1322,6 +1322,8 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
 // — BUILT AND MEASURED, NOT ADOPTED: the fixed-base stage fell from 0.035 to 0.023 ms, the main loop rose from 0.205 to 0.216 ms
 // (≈ 110 more instructions per iteration for the phase logic, and a worse schedule): N = 4 096 0.3338 → 0.3402 ms
 // (profiles/r06g_kernel_ab.txt, r06g_rows_stage_ms.txt).  What replaced it: IBFT_ROWS_SHARED_ADDS.
+// IBFT_ROWS_G_MERGED = 2 (with IBFT_ROWS_G_PREFETCH = 1): the uniform form — both phases read their operands from LDS by slot
+// number; 0.3336 → 0.3415 ms (profiles/r06p_kernel_ab.txt), not adopted either.
 #ifndef IBFT_ROWS_G_MERGED
 #define IBFT_ROWS_G_MERGED 0
 #endif
@@ -1334,7 +1336,10 @@ WVF bool rows_finish_deferred(aff &Qa, const wjac &p1, const wjac &p2, uint32_t 
 #define IBFT_ROWS_SHARED_ADDS 0
 #endif
 constexpr int ROW_TAB_G0 = 32;  // 8 entries × (x, y, z → X·β) + 8 prefix products, then (x, y) of the GTAB_WINDOWS points of u1·G
-constexpr int ROW_TAB_SLOTS = ROW_TAB_G0 + (IBFT_ROWS_G_PREFETCH ? 2 * ibftk::GTAB_WINDOWS : 0);
+#ifndef IBFT_ROWS_TAB_PAD_SLOTS
+#define IBFT_ROWS_TAB_PAD_SLOTS 0  // experiment: unused slots (what does a workgroup's LDS SIZE alone cost?)
+#endif
+constexpr int ROW_TAB_SLOTS = ROW_TAB_G0 + (IBFT_ROWS_G_PREFETCH ? 2 * ibftk::GTAB_WINDOWS : 0) + IBFT_ROWS_TAB_PAD_SLOTS;
 template <int STOP = 99>
 WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw, const u256 &r, const u256 &s,
                            uint32_t v, uint32_t flags, uint32_t addr[5], aff &Qa, uint32_t *wtab) {
@@ -1547,7 +1552,50 @@ WVF bool recover_pubkey_row(const uint32_t *__restrict__ gtab, const u256 &z_raw
     acc = wjac_select((w2[4] & 1u) != 0, s2, acc);
   }
 #endif
-#if IBFT_ROWS_G_MERGED
+#if IBFT_ROWS_G_MERGED == 2
+  // The UNIFORM form (needs IBFT_ROWS_G_PREFETCH): both phases read their two operands from wave-private LDS by slot number —
+  // table entries in the window iterations, the prefetched G-table points in the fixed-base ones — so an iteration is the same
+  // instruction stream in both phases: a slot computation, 4 or 0 doublings, two additions.  No operand path of its own for the
+  // fixed-base phase, no preload logic: what the first merged form (IBFT_ROWS_G_MERGED = 1) paid the main loop.
+  static_assert(ibftk::GTAB_WINDOWS % 2 == 0 && IBFT_ROWS_G_PREFETCH, "two prefetched fixed-base windows per iteration");
+  constexpr int GIT = ibftk::GTAB_WINDOWS / 2;
+  wjac hold = wjac_inf();
+#pragma unroll 1
+  for (int it = 0; it < 32 + GIT; it++) {
+    const bool is_g = it >= 32;  // (wave-uniform)
+    const int jd = is_g ? 0 : 31 - it, g = is_g ? it - 32 : 0;
+    const int n1 = (int)((w1[jd >> 3] >> (4 * (jd & 7))) & 15u), n2 = (int)((w2[jd >> 3] >> (4 * (jd & 7))) & 15u);
+    const int d1 = n1 - 8, d2 = n2 - 8;
+    const uint32_t m1 = (uint32_t)(d1 < 0 ? -d1 : d1), m2 = (uint32_t)(d2 < 0 ? -d2 : d2);
+    const int b1 = 3 * (int)((m1 ? m1 : 1u) - 1u), b2 = 3 * (int)((m2 ? m2 : 1u) - 1u);
+    const int gs = ROW_TAB_G0 + 4 * g;
+    const int s1x = is_g ? gs : b1, s1y = is_g ? gs + 1 : b1 + 1, s2x = is_g ? gs + 2 : b2 + 2, s2y = is_g ? gs + 3 : b2 + 1;
+    if (it == 32) {
+      acc.z = wfe_mul(acc.z, Zc, k);  // back from the isomorphic curve (an accumulator at infinity keeps its flag)
+      WV_STAGE(4, acc.x ^ acc.y ^ acc.z ^ u1.v[0])
+      hold = acc;
+      acc = wjac_inf();
+      lds_prefetch_wait();  // (asked for a quarter of a millisecond ago)
+    }
+    waff q1 = waff{WT(s1x) & k.act, WT(s1y) & k.act}, q2 = waff{WT(s2x) & k.act, WT(s2y) & k.act};
+    const int ndbl = is_g ? 0 : 4;
+#pragma unroll 1
+    for (int d = 0; d < ndbl; d++) acc = wjac_dbl<true>(acc, k);
+    const bool f1 = !is_g && ((d1 < 0) != sp.neg1), f2 = !is_g && ((d2 < 0) != sp.neg2);
+    q1.y = f1 ? wfe_neg1(q1.y, k) : q1.y;  // magnitude ≤ 2
+    q2.y = f2 ? wfe_neg1(q2.y, k) : q2.y;
+    const int bit1 = (2 * g) * ibftk::GTAB_BITS, bit2 = (2 * g + 1) * ibftk::GTAB_BITS;
+    const uint32_t gd1 = (u1.v[bit1 >> 5] >> (bit1 & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    const uint32_t gd2 = (u1.v[bit2 >> 5] >> (bit2 & 31)) & (uint32_t)(ibftk::GTAB_ENTRIES - 1);
+    const bool t1 = is_g ? gd1 != 0 : m1 != 0, t2 = is_g ? gd2 != 0 : m2 != 0;
+    const wjac s1 = wjac_add_aff<true>(acc, q1, k);
+    acc = wjac_select(t1, s1, acc);
+    const wjac s2 = wjac_add_aff<true>(acc, q2, k);
+    acc = wjac_select(t2, s2, acc);
+  }
+  const wjac accg_merged = acc;
+  acc = hold;
+#elif IBFT_ROWS_G_MERGED
   // iterations jd = 31 … 0: digit jd of both scalars (four doublings, two table additions); iterations jd = −1 … −GIT: the
   // fixed-base windows 2g, 2g + 1 (g = −1 − jd) of u1 into an accumulator of their own — the u2·R′ sum steps aside at jd = −1.
   // The two table points of an iteration are asked for one iteration earlier.
