@@ -1161,7 +1161,9 @@ def main():
                        "prewarm_steps": PREWARM_STEPS if (carry is not None or world > 1 or dist is not None) else 0,
                        "kernel": m["kname"], "parallelism": f"rows sharded x{world}" if world > 1 else "single GPU",
                        "pipeline": "one pass kept in flight, every pass's results delivered to the host (N = 1: ibft_seals_submit / "
-                                   "_collect; N > 1: exchange k overlaps the kernels of pass k+1); step_latency_ms_p50 = one synchronous pass",
+                                   "_collect, the tally of pass k on a stream of its own next to the verdict kernel of pass k+1 (round 6; "
+                                   "IBFT_SIDE_TALLY=0 turns that off); N > 1: exchange k overlaps the kernels of pass k+1); "
+                                   "step_latency_ms_p50 = one synchronous pass",
                        "numa_pin": numa_pin},
             "step_latency_ms_p50": float(np.median(m["lat"]) * 1e3),
             "step_latency_ms_p50_incl_h2d": float(np.median(m["lat_h2d"]) * 1e3) if m["lat_h2d"] else None,

@@ -107,6 +107,27 @@ struct ibft_ctx {
   bool split_large = true;    // batches of 65 537 … 98 304 rows as two launches (enqueue_recover); IBFT_SPLIT_LARGE=0 turns it off (A/B)
   uint32_t split_launches = 0;
   int tally_slot = -1;      // ≥ 0: the next tally delivers into pipeline slot `tally_slot` instead of h_mask / h_tally
+  // The tally of a pipelined pass on a stream of its own (round 6): pass k's tally (one small workgroup, 9–15 µs with its
+  // dependency gap) runs NEXT TO pass k + 1's verdict kernel instead of in front of it.  What the two would share is doubled:
+  // the work mask and the validator-index column exist twice (d_mask / d_vidx are the pair the next verdict launch writes,
+  // d_mask_b / d_vidx_b the pair the tally in flight reads and zeroes; ibft_seals_submit swaps them), and pair P(k) = P(k − 2) is
+  // free again because pass k − 2 was collected before pass k could be submitted (at most two in flight).  Every OTHER entry
+  // point puts the main stream behind the side stream's tallies first (ctx_lock → join_side).
+  // MEASURED (profiles/r06v…r06y_side_tally_ab.txt, r06v_side_tally_trace.txt).  Two things had to be learned: (1) the tally
+  // must FIT next to a resident verdict kernel — the one-workgroup form (sixteen wavefronts of 126 registers) fits next to
+  // nothing and simply waited for the NEXT verdict kernel to end (N = 4 096: 0.351 → 0.505 ms per step); the ticket form (42
+  // registers) does, so a side-stream tally always takes that one (enqueue_tally); (2) the lane / group cold kernels fill the
+  // LDS of every compute unit with their window tables: a tally workgroup placed first takes the room of a verdict workgroup,
+  // which then runs as a second round (N = 16 384: 0.71 → 1.37 ms, 65 536: 0.92 → 1.87).  Behind everything else it pays:
+  // cold N = 64 … 8 192 −0.8 … −1.7 % per step, warm N = 1 024 … 65 536 −2.3 … −6 %.  Hence side_tally: 0 never, 1 always
+  // (A/B), 2 = AUTO (ibft_seals_submit).  IBFT_SIDE_TALLY=0|1 pins it.
+  int side_tally = 2;
+  bool side_pending = false;
+  hipStream_t tstream = nullptr;
+  hipEvent_t ev_rec[2] = {nullptr, nullptr};   // pass k's verdict kernels are done (recorded on the main stream)
+  DevBuf d_mask_b, d_vidx_b;
+  uint32_t mask_dirty_words_b = ~0u;
+  uint32_t side_tallies = 0;                   // passes whose tally ran on the side stream (ibft_last_dispatch-style counter)
   uint32_t launched_n = 0;  // rows of the last ibft_seals_launch: what ibft_seals_fetch delivers (a swap may have changed staged_n since)
   DevBuf d_mask, d_vidx, d_tally, d_H;
   DevBuf d_mask_out;        // verdict words after the tally consumed d_mask (what fetch / export read)
@@ -282,6 +303,12 @@ int alloc_rows(ibft_ctx *c, uint32_t rows) {
   // than 256 bytes, so growing row_cap need not reallocate it): the next verdict launch zeroes the whole mask first
   if (c->d_mask.p != old_mask || rows > c->row_cap) c->mask_dirty_words = ~0u;
   if ((rc = ensure(c, c->d_vidx, m * 4))) return rc;
+  {  // the pair a side-stream tally works on (ibft_seals_submit): same sizes, same rule for fresh words
+    const void *old_b = c->d_mask_b.p;
+    if ((rc = ensure(c, c->d_mask_b, (size_t)mask_words(m) * 8))) return rc;
+    if (c->d_mask_b.p != old_b || rows > c->row_cap) c->mask_dirty_words_b = ~0u;
+    if ((rc = ensure(c, c->d_vidx_b, m * 4))) return rc;
+  }
   if ((rc = ensure(c, c->d_tally, (size_t)ibftk::TALLY_OUT_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_acc, (size_t)ibftk::TALLY_ACC_WORDS * 8))) return rc;
   if ((rc = ensure(c, c->d_quorum, (size_t)ibftk::TALLY_SUM_WORDS * 8))) return rc;
@@ -339,6 +366,28 @@ int clean_mask(ibft_ctx *c) {
   c->mask_dirty_words = 0;
   return IBFT_OK;
 }
+
+// The main stream behind every tally the pipeline put on the side stream (a device-side wait; nothing when none is pending).
+int join_side(ibft_ctx *c) {
+  if (!c->side_pending) return IBFT_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int i = 0; i < 2; i++)
+    if (c->ev_pass[i] && hipStreamWaitEvent(c->stream, c->ev_pass[i], 0) != hipSuccess) HIPCHK(c, hipStreamSynchronize(c->tstream));
+  c->side_pending = false;
+  return IBFT_OK;
+}
+// The lock every entry point takes — and, for all but the pipeline's own calls (ibft_seals_submit / _collect / _stage_next /
+// _swap / _rows, the timing getters), the join above: whatever the call enqueues on the main stream finds the buffers a side
+// tally works on (work mask, validator indices, tally sums, verdict words) finished with.
+struct ctx_lock {
+  std::lock_guard<std::mutex> g;
+  explicit ctx_lock(ibft_ctx *c) : g(c->mu) {
+    if (c->side_pending && join_side(c) != IBFT_OK) {  // (cannot report from here: drain the side stream the hard way)
+      (void)hipStreamSynchronize(c->tstream);
+      c->side_pending = false;
+    }
+  }
+};
 
 // enqueue the verdict kernels over the resident columns: warm kernel first when tables exist
 // (its rows are then skipped by the recover kernel), recover kernel for everything else
@@ -574,9 +623,11 @@ int build_new_tables(ibft_ctx *c, uint32_t learned_total, uint32_t any_slot) {
   return IBFT_OK;
 }
 
-int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr) {
+// `on`: the stream the tally is enqueued on (default: the context's main stream; ibft_seals_submit passes the side stream)
+int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr, hipStream_t on = nullptr) {
+  const hipStream_t ts = on ? on : c->stream;
   if (c->read_pending) {  // a consumer stream is still copying the previous results (ibft_seals_export_on / exchange)
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_read, 0));
+    HIPCHK(c, hipStreamWaitEvent(ts, c->ev_read, 0));
     c->read_pending = false;
   }
   ibftk::tally_args t{};
@@ -608,7 +659,7 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
     if (bytes > c->d_seen_out.cap) {
       int rc = ensure(c, c->d_seen_out, bytes);
       if (rc) return rc;
-      HIPCHK(c, hipMemsetAsync(c->d_seen_out.p, 0, c->d_seen_out.cap, c->stream));  // (an odd trailing 32-bit word stays 0)
+      HIPCHK(c, hipMemsetAsync(c->d_seen_out.p, 0, c->d_seen_out.cap, ts));  // (an odd trailing 32-bit word stays 0)
     }
     t.seen_out = (uint32_t *)c->d_seen_out.p;
   }
@@ -619,17 +670,19 @@ int enqueue_tally(ibft_ctx *c, uint32_t n, const ibftk::set_args *set = nullptr)
   const size_t lds = (size_t)((c->n_validators + 31) / 32) * 4;
   t.lds_bitmap = lds <= 49152 ? 1u : 0u;
   const size_t dyn = t.lds_bitmap ? lds : 0;
-  const bool single = grid.x == 1 && t.lds_bitmap;
+  // (a side-stream tally has to FIT next to a resident verdict kernel: the one-workgroup form holds 126 registers in each of its
+  // sixteen wavefronts — nothing else fits a compute unit beside it —, the ticket form 42)
+  const bool single = grid.x == 1 && t.lds_bitmap && !on;
   if (single) {
     if (c->power_words == 1)
-      hipLaunchKernelGGL((ibftk::tally_kernel<1, false>), grid, block, dyn, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<1, false>), grid, block, dyn, ts, t);
     else
-      hipLaunchKernelGGL((ibftk::tally_kernel<4, false>), grid, block, dyn, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<4, false>), grid, block, dyn, ts, t);
   } else {
     if (c->power_words == 1)
-      hipLaunchKernelGGL((ibftk::tally_kernel<1, true>), grid, block, dyn, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<1, true>), grid, block, dyn, ts, t);
     else
-      hipLaunchKernelGGL((ibftk::tally_kernel<4, true>), grid, block, dyn, c->stream, t);
+      hipLaunchKernelGGL((ibftk::tally_kernel<4, true>), grid, block, dyn, ts, t);
   }
   HIPCHK(c, hipGetLastError());
   c->host_direct = c->dh_mask != nullptr && c->tally_slot < 0;  // results of THIS tally are on their way to h_mask / h_tally
@@ -1291,8 +1344,9 @@ extern "C" {
 
 static void key_cache_unmap(ibft_ctx *c);
 
-int ibft_version(void) { return 3; }  // 2: ibft_tally_t.proposer_rows, proposer20 arguments, ibft_tally_prepare, ibft_comm_info;
-                                      // 3: ibft_seals_stage_next / _swap / _submit / _collect, ibft_last_cold_table, ibft_comm_preload, ibft_seals_rows, ibft_issue_probe
+int ibft_version(void) { return 4; }  // 2: ibft_tally_t.proposer_rows, proposer20 arguments, ibft_tally_prepare, ibft_comm_info;
+                                      // 3: ibft_seals_stage_next / _swap / _submit / _collect, ibft_last_cold_table, ibft_comm_preload, ibft_seals_rows, ibft_issue_probe;
+                                      // 4: ibft_pipeline_stats (the side-stream tally of submitted passes changes no signature)
 
 const char *ibft_strerror(int code) {
   switch (code) {
@@ -1334,6 +1388,7 @@ int ibft_ctx_create(const ibft_cfg *cfg, ibft_ctx **out) {
   c->kernel = cfg ? cfg->kernel : IBFT_KERNEL_AUTO;
   c->cold_group_auto = c->kernel != IBFT_KERNEL_LANE;
   if (const char *e = getenv("IBFT_SPLIT_LARGE")) c->split_large = strcmp(e, "0") != 0;
+  if (const char *e = getenv("IBFT_SIDE_TALLY")) c->side_tally = strcmp(e, "0") == 0 ? 0 : strcmp(e, "1") == 0 ? 1 : 2;
   if (const char *e = getenv("IBFT_COLD_TABLE")) {
     if (!strcmp(e, "lds")) c->cold_table_force = 1;
     else if (!strcmp(e, "private")) c->cold_table_force = 2;
@@ -1421,6 +1476,7 @@ void ibft_ctx_destroy(ibft_ctx *c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->hstream) (void)hipStreamSynchronize(c->hstream);
+  if (c->tstream) (void)hipStreamSynchronize(c->tstream);
   for (DevBuf *b : {&c->d_hash, &c->d_sig, &c->d_signer, &c->d_pre, &c->d_hash_len, &c->d_payload,
                     &c->d_off, &c->d_raw, &c->d_mask, &c->d_mask_out, &c->d_vidx, &c->d_tally, &c->d_H,
                     &c->d_vtab, &c->d_vpower, &c->d_vslot,
@@ -1428,8 +1484,14 @@ void ibft_ctx_destroy(ibft_ctx *c) {
                     &c->d_xbuf[0], &c->d_xbuf[1], &c->d_xres[0], &c->d_xres[1], &c->d_set, &c->d_noseal, &c->d_class,
                     &c->d_cert_nodes, &c->d_cert_span, &c->d_cert_count, &c->d_cert_prop, &c->d_cert_masks, &c->d_cert_total,
                     &c->d_cert_slot, &c->d_cert_tiles, &c->d_hash_copy, &c->d_seen_out, &c->d_hash_nx, &c->d_sig_nx,
-                    &c->d_signer_nx, &c->d_pre_nx})
+                    &c->d_signer_nx, &c->d_pre_nx, &c->d_mask_b, &c->d_vidx_b})
     release(*b);
+  if (c->tstream) {
+    (void)hipStreamSynchronize(c->tstream);
+    (void)hipStreamDestroy(c->tstream);
+  }
+  for (int i = 0; i < 2; i++)
+    if (c->ev_rec[i]) (void)hipEventDestroy(c->ev_rec[i]);
   if (c->cstream) {
     (void)hipStreamSynchronize(c->cstream);
     (void)hipStreamDestroy(c->cstream);
@@ -1609,7 +1671,7 @@ static int key_cache_map(ibft_ctx *c, const std::vector<KeyAddr> &vaddr) {
 
 static int set_validators_impl(ibft_ctx *c, uint64_t height, const uint8_t *addrs20, const uint64_t *power, uint32_t pw,
                                size_t n) {
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   // Host-side build of the open-addressing table; a repeated address keeps the LAST
   // power (a Go map assignment in a loop), mirroring oracle/ibft_oracle.c.
@@ -1725,7 +1787,7 @@ int ibft_set_validators_u256(ibft_ctx *c, uint64_t height, const uint8_t *addrs2
 
 int ibft_last_tally_wide(ibft_ctx *c, ibft_tally_wide_t *out) {
   if (!c || !out) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   memset(out, 0, sizeof *out);
   for (int i = 0; i < ibftk::TALLY_SUM_WORDS; i++) {
     out->quorum[i] = c->quorum_w[i];
@@ -1749,7 +1811,7 @@ int ibft_keccak256(const uint8_t *a, size_t na, const uint8_t *b, size_t nb, uin
 
 int ibft_proposal_hash(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t round, uint8_t out32[32]) {
   if (!c || (raw_len && !raw) || !out32 || raw_len > (1ull << 31)) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   if ((rc = ensure_proposal_hash(c, raw, raw_len, round))) return rc;
@@ -1790,7 +1852,7 @@ static int hash_eq_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t *has
 
 int ibft_forget_proposal(ibft_ctx *c) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   c->have_H = false;
   return IBFT_OK;
 }
@@ -1799,7 +1861,7 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
                        const uint8_t *hash32, const uint8_t *hash_len, size_t n, uint64_t *out_mask) {
   if (!c || (raw_len && !raw) || (n && (!hash32 || !hash_len || !out_mask)) || raw_len > (1ull << 31))
     return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);  // context state is only read inside the critical section
+  ctx_lock lk(c);  // context state is only read inside the critical section
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
@@ -1810,7 +1872,7 @@ int ibft_verify_hashes(ibft_ctx *c, const uint8_t *raw, size_t raw_len, uint64_t
 int ibft_verify_hashes_digest(ibft_ctx *c, const uint8_t digest32[32], const uint8_t *hash32, const uint8_t *hash_len,
                               size_t n, uint64_t *out_mask) {
   if (!c || !digest32 || (n && (!hash32 || !hash_len || !out_mask))) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
   {
@@ -1848,7 +1910,7 @@ static int seals_stage_locked(ibft_ctx *c, const uint8_t *hash32, const uint8_t 
 int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
                      const uint8_t *pre_flags, size_t n) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   return seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n, true);
 }
 
@@ -1856,7 +1918,7 @@ int ibft_seals_stage(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, c
 int ibft_seals_stage_next(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
                           const uint8_t *pre_flags, size_t n) {
   if (!c || (n && (!hash32 || !sig65 || !signer20))) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->cstream) {
@@ -1888,7 +1950,7 @@ int ibft_seals_stage_next(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig
 
 int ibft_seals_swap(ibft_ctx *c, int wait_for_copy) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   if (!c->next_valid) {
     c->last_error = "ibft_seals_swap without a batch staged by ibft_seals_stage_next";
     return IBFT_E_INVAL;
@@ -1931,7 +1993,7 @@ static int seals_launch_locked(ibft_ctx *c, uint32_t repeat) {
 // collect waits for the OLDEST submitted pass only (the event behind its tally, not the stream).
 int ibft_seals_submit(ibft_ctx *c) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   if (!c->have_valset) return IBFT_E_NOVALSET;
   if (c->pass_issued - c->pass_collected >= 2) {
     c->last_error = "two passes already in flight: call ibft_seals_collect first";
@@ -1963,12 +2025,41 @@ int ibft_seals_submit(ibft_ctx *c) {
   if (c->ev_used >= 4096) c->ev_used = 0;
   const bool time_it = c->time_every && (c->pass_counter++ % c->time_every) == 0;
   int rc;
+  // The verdict launch writes the CURRENT pair of work mask / validator indices; its last reader was the tally of pass k − 2
+  // (collected, or the two-in-flight check above would have refused) or something the main stream is already behind.
   if ((rc = enqueue_recover(c, c->staged_n, c->staged_pre, 0, time_it))) return rc;
-  c->tally_slot = (int)s;
-  rc = enqueue_tally(c, c->staged_n);
-  c->tally_slot = -1;
-  if (rc) return rc;
-  HIPCHK(c, hipEventRecord(c->ev_pass[s], c->stream));
+  // Side-stream tally: not for a rank of a sharded batch (its exchange follows the tally on the main stream) and not while
+  // keys are still being learned (the tally passes the device's learned-key counter on; with every table built nothing moves it)
+  const bool all_warm = c->cache_on && c->my_built >= c->n_validators;
+  // AUTO: behind the warm kernels, and behind the cold kernels that leave the tally room (rows / wave / two-wave forms: a quarter
+  // of the LDS, a third of the registers) — NOT behind the lane / group kernels whose tables fill the LDS (see side_tally above)
+  const bool side = !c->comm && !c->xlocal && (!c->cache_on || all_warm) &&
+                    (c->side_tally == 1 || (c->side_tally == 2 && (all_warm || (!c->cache_on && c->last_cold_group >= 16))));
+  if (side) {
+    if (!c->tstream) HIPCHK(c, hipStreamCreateWithFlags(&c->tstream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++)
+      if (!c->ev_rec[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rec[i], hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_rec[s], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->tstream, c->ev_rec[s], 0));
+    c->tally_slot = (int)s;
+    rc = enqueue_tally(c, c->staged_n, nullptr, c->tstream);
+    c->tally_slot = -1;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_pass[s], c->tstream));
+    // the next verdict launch gets the other pair; this one belongs to the tally just enqueued until the pass is collected
+    std::swap(c->d_mask, c->d_mask_b);
+    std::swap(c->d_vidx, c->d_vidx_b);
+    std::swap(c->mask_dirty_words, c->mask_dirty_words_b);
+    c->side_pending = true;
+    c->side_tallies++;
+  } else {
+    if ((rc = join_side(c))) return rc;   // a main-stream tally shares the sums and verdict words with the side stream's
+    c->tally_slot = (int)s;
+    rc = enqueue_tally(c, c->staged_n);
+    c->tally_slot = -1;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_pass[s], c->stream));
+  }
   c->pass_n[s] = c->staged_n;
   c->launched_n = c->staged_n;  // (an ibft_seals_fetch behind a submit delivers this pass through the copy route)
   c->pass_issued++;
@@ -1977,7 +2068,7 @@ int ibft_seals_submit(ibft_ctx *c) {
 
 int ibft_seals_collect(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   if (c->pass_collected == c->pass_issued) {
     c->last_error = "ibft_seals_collect without a submitted pass";
     return IBFT_E_INVAL;
@@ -2022,7 +2113,7 @@ int ibft_seals_collect(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
 // buffers from THESE, never from a count its caller passes along (shim/go/ibftgpu).
 int ibft_seals_rows(ibft_ctx *c, uint32_t *resident_rows, uint32_t *oldest_pass_rows) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   if (resident_rows) *resident_rows = c->staged_n;
   if (oldest_pass_rows) *oldest_pass_rows = c->pass_collected == c->pass_issued ? 0u : c->pass_n[c->pass_collected & 1u];
   return IBFT_OK;
@@ -2030,20 +2121,20 @@ int ibft_seals_rows(ibft_ctx *c, uint32_t *resident_rows, uint32_t *oldest_pass_
 
 int ibft_seals_launch(ibft_ctx *c, uint32_t repeat) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   return seals_launch_locked(c, repeat);
 }
 
 int ibft_seals_fetch(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   return fetch_results(c, c->launched_n, out_mask, tally, true);
 }
 
 int ibft_seals_run(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   int rc = seals_launch_locked(c, 1);
   if (rc) return rc;
   return fetch_results(c, c->staged_n, out_mask, tally, true);
@@ -2051,7 +2142,7 @@ int ibft_seals_run(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
 
 int ibft_seals_device_ptrs(ibft_ctx *c, void **d_mask, size_t *mask_words_out, void **d_tally) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (d_mask) *d_mask = c->d_mask_out.p;
   if (mask_words_out) *mask_words_out = (size_t)mask_words(c->staged_n);
   if (d_tally) *d_tally = c->d_tally.p;
@@ -2060,7 +2151,7 @@ int ibft_seals_device_ptrs(ibft_ctx *c, void **d_mask, size_t *mask_words_out, v
 
 int ibft_seals_export(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   size_t mw = (size_t)mask_words(c->staged_n);
   if (d_mask_dst && mw)
@@ -2073,7 +2164,7 @@ int ibft_seals_export(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst) {
 
 int ibft_seals_export_on(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst, void *consumer_stream) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t cs = (hipStream_t)consumer_stream;
   {
@@ -2092,7 +2183,7 @@ int ibft_seals_export_on(ibft_ctx *c, void *d_mask_dst, void *d_tally_dst, void 
 
 int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
   if (!c || !ms) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float total = 0.f;
@@ -2109,7 +2200,7 @@ int ibft_last_kernel_ms(ibft_ctx *c, float *ms, uint32_t *launches) {
 
 int ibft_set_kernel_timing(ibft_ctx *c, uint32_t every_n) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   c->time_every = every_n;
   c->pass_counter = 0;
   return IBFT_OK;
@@ -2118,7 +2209,7 @@ int ibft_set_kernel_timing(ibft_ctx *c, uint32_t every_n) {
 int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint32_t *cold_passes,
                      uint32_t *lanes_per_signature) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (tables) *tables = c->cache_on ? c->my_built : 0;
   if (warm_passes) *warm_passes = c->warm_passes;
   if (cold_passes) *cold_passes = c->cold_passes;
@@ -2129,7 +2220,7 @@ int ibft_cache_stats(ibft_ctx *c, uint32_t *tables, uint32_t *warm_passes, uint3
 int ibft_cache_memory(ibft_ctx *c, uint64_t *device_bytes, uint32_t *slots_in_use, uint32_t *slots_allocated,
                       uint32_t *contexts_sharing) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   std::lock_guard<std::mutex> dlk(c->dev->mu);
   const DeviceShared &d = *c->dev;
   if (device_bytes) *device_bytes = (uint64_t)d.d_gtab.cap + d.d_qtab.cap + d.d_pub.cap + d.d_state.cap + d.d_learned.cap;
@@ -2141,7 +2232,7 @@ int ibft_cache_memory(ibft_ctx *c, uint64_t *device_bytes, uint32_t *slots_in_us
 
 int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   if (cold_lanes) *cold_lanes = c->last_cold_group;
   if (warm_lanes) *warm_lanes = c->last_group;
   return IBFT_OK;
@@ -2149,14 +2240,22 @@ int ibft_last_dispatch(ibft_ctx *c, uint32_t *cold_lanes, uint32_t *warm_lanes) 
 
 int ibft_last_cold_table(ibft_ctx *c, uint32_t *table) {
   if (!c || !table) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
   *table = (c->last_cold_group == 1 || c->last_cold_group == 2 || c->last_cold_group == 4) ? c->last_cold_table : 0u;
+  return IBFT_OK;
+}
+
+int ibft_pipeline_stats(ibft_ctx *c, uint32_t *side_tallies, uint32_t *split_batches) {
+  if (!c) return IBFT_E_INVAL;
+  std::lock_guard<std::mutex> lk(c->mu);  // (a call of the pipeline itself: no join_side)
+  if (side_tallies) *side_tallies = c->side_tallies;
+  if (split_batches) *split_batches = c->split_launches;
   return IBFT_OK;
 }
 
 int ibft_column_stats(ibft_ctx *c, uint32_t *gather_batches) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (gather_batches) *gather_batches = c->gathers;
   return IBFT_OK;
 }
@@ -2281,7 +2380,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
                          const uint8_t *digest32, const uint8_t *proposer20, uint64_t *out_sender_mask,
                          uint64_t *out_valid_mask, ibft_tally_t *tally) {
   if (!c || (n && (!out_sender_mask || !out_valid_mask))) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   note_proposer(c, proposer20);
   int rc = messages_launch_locked(c, payload, off, msg_sig65, from20, hash32, hash_len, seal65, sender_pre, valid_pre, n, raw,
                                   raw_len, round, digest32);
@@ -2311,7 +2410,7 @@ int ibft_verify_messages(ibft_ctx *c, const uint8_t *payload, const uint32_t *of
 int ibft_sign_seals(ibft_ctx *c, const uint8_t *sk32, const uint8_t *hash32, size_t n, uint8_t *out_sig65,
                     uint8_t *out_signer20, uint8_t *out_ok) {
   if (!c || (n && (!sk32 || !hash32 || !out_sig65))) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   HIPCHK(c, hipSetDevice(c->device));
   c->wire_valid = false;
@@ -2347,7 +2446,7 @@ int ibft_sign_seals(ibft_ctx *c, const uint8_t *sk32, const uint8_t *hash32, siz
 // Device canary: see issue_probe_kernel (kernels.hip.h).  Three untimed launches, then the median of five timed ones.
 int ibft_issue_probe(ibft_ctx *c, float *ns_per_inst, float *kernel_ms) {
   if (!c || !ns_per_inst) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t *d_out = nullptr;
   HIPCHK(c, hipMalloc(&d_out, 64));
@@ -2380,7 +2479,7 @@ int ibft_issue_probe(ibft_ctx *c, float *ns_per_inst, float *kernel_ms) {
 
 int ibft_sync(ibft_ctx *c) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->xstream) HIPCHK(c, hipStreamSynchronize(c->xstream));  // exchanges in flight (ibft_seals_exchange)
@@ -2391,7 +2490,7 @@ int ibft_sync(ibft_ctx *c) {
 int ibft_verify_seals(ibft_ctx *c, const uint8_t *hash32, const uint8_t *sig65, const uint8_t *signer20,
                       const uint8_t *pre_flags, size_t n, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c || (n && !out_mask)) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);  // one critical section: stage + launch + fetch
+  ctx_lock lk(c);  // one critical section: stage + launch + fetch
   if (!c->have_valset) return IBFT_E_NOVALSET;
   int rc;
   if ((rc = seals_stage_locked(c, hash32, sig65, signer20, pre_flags, n, false))) return rc;
@@ -2431,7 +2530,7 @@ int ibft_verify_senders(ibft_ctx *c, const uint8_t *payload, const uint32_t *off
                         const uint8_t *from20, const uint8_t *pre_flags, size_t n, uint64_t *out_mask,
                         ibft_tally_t *tally) {
   if (!c || (n && (!off || !out_mask))) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   int rc = senders_launch_locked(c, payload, off, sig65, from20, pre_flags, n);
   if (rc) return rc;
   return fetch_results(c, (uint32_t)n, out_mask, tally, true);
@@ -2444,7 +2543,7 @@ int ibft_verify_senders_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint3
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2486,7 +2585,7 @@ int ibft_verify_messages_wire(ibft_ctx *c, const uint8_t *wire_bytes, const uint
   for (size_t i = 0; i < n; i++)
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2600,7 +2699,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
     if (off[i + 1] < off[i]) return IBFT_E_INVAL;
   if (n && off[n] && !wire_bytes) return IBFT_E_INVAL;
   *out_n_rows = 0;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   const size_t cap = std::min<size_t>(rows_cap, c->max_rows);
   if (n > cap) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
@@ -2755,7 +2854,7 @@ int ibft_verify_certificates_wire(ibft_ctx *c, const uint8_t *wire_bytes, const 
 
 int ibft_wire_stage_seals(ibft_ctx *c) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (!c->wire_valid) return IBFT_E_INVAL;  // no parsed batch resident (another call restaged the columns)
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t n = c->wire_n;
@@ -2784,7 +2883,7 @@ int ibft_tally_prepare(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mas
 static int tally_impl(ibft_ctx *c, const uint8_t *sender20, const uint64_t *mask, size_t n, const uint8_t *proposer20,
                       ibft_tally_t *tally) {
   if (!c || !tally || (n && (!sender20 || !mask))) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (n > c->max_rows) return IBFT_E_TOOBIG;
   if (!c->have_valset) return IBFT_E_NOVALSET;
   HIPCHK(c, hipSetDevice(c->device));
@@ -2847,7 +2946,7 @@ int ibft_comm_init(ibft_ctx *c, const uint8_t id[IBFT_COMM_ID_BYTES], uint32_t r
   if (!c || !id || !world || rank >= world) return IBFT_E_INVAL;
   RcclApi *api = rccl();
   if (!api) return IBFT_E_RCCL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   if (c->comm) return IBFT_E_INVAL;
   HIPCHK(c, hipSetDevice(c->device));
   ncclUniqueId u;
@@ -2859,7 +2958,7 @@ int ibft_comm_init(ibft_ctx *c, const uint8_t id[IBFT_COMM_ID_BYTES], uint32_t r
 
 int ibft_comm_destroy(ibft_ctx *c) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   (void)hipSetDevice(c->device);
   if (c->xstream) (void)hipStreamSynchronize(c->xstream);
   comm_release(c);
@@ -2871,7 +2970,7 @@ int ibft_seals_exchange(ibft_ctx *c, uint64_t n_total) {
   if (c->xlocal) return IBFT_E_INVAL;  // a rank of a local group: only the group can run the collective
   RcclApi *api = rccl();
   if (!api) return IBFT_E_RCCL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   xplan x{};
   int rc;
   if ((rc = exchange_pre(c, n_total, x))) return rc;
@@ -2881,7 +2980,7 @@ int ibft_seals_exchange(ibft_ctx *c, uint64_t n_total) {
 
 int ibft_comm_info(ibft_ctx *c, uint32_t *rccl_nranks, uint32_t *rccl_rank, int32_t *rccl_device) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   RcclApi *api = rccl();
   if (!c->comm || !api || !api->CommCount || !api->CommUserRank || !api->CommCuDevice) return IBFT_E_INVAL;
   int n = 0, r = 0, d = 0;
@@ -2896,7 +2995,7 @@ int ibft_comm_info(ibft_ctx *c, uint32_t *rccl_nranks, uint32_t *rccl_rank, int3
 
 int ibft_seals_fetch_merged(ibft_ctx *c, uint64_t *out_mask, ibft_tally_t *tally) {
   if (!c) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   return fetch_merged_locked(c, out_mask, tally);
 }
 
@@ -2973,7 +3072,7 @@ ibft_ctx *ibft_group_ctx(ibft_group *g, uint32_t i) { return (g && i < g->ctx.si
 
 int ibft_set_seal_digest(ibft_ctx *c, uint32_t mode, const uint8_t *suffix, size_t suffix_len) {
   if (!c || mode > IBFT_SEAL_DIGEST_KECCAK_SUFFIX || (suffix_len && !suffix) || suffix_len > IBFT_SEAL_SUFFIX_MAX) return IBFT_E_INVAL;
-  std::lock_guard<std::mutex> lk(c->mu);
+  ctx_lock lk(c);
   uint8_t block[72] = {0};
   if (mode == IBFT_SEAL_DIGEST_KECCAK_SUFFIX) {
     if (suffix_len) memcpy(block, suffix, suffix_len);

@@ -41,7 +41,7 @@ EXPORTS = [
     "ibft_verify_messages_wire", "ibft_forget_proposal", "ibft_verify_certificates_wire", "ibft_keccak256",
     "ibft_cache_memory", "ibft_tally_prepare", "ibft_comm_info", "ibft_set_seal_digest", "ibft_group_set_seal_digest",
     "ibft_seals_stage_next", "ibft_seals_swap", "ibft_last_cold_table", "ibft_seals_submit", "ibft_seals_collect",
-    "ibft_comm_preload", "ibft_issue_probe", "ibft_seals_rows",
+    "ibft_comm_preload", "ibft_issue_probe", "ibft_seals_rows", "ibft_pipeline_stats",
 ]
 COMM_ID_BYTES = 128
 E_RCCL = -8
@@ -107,7 +107,7 @@ def powers_be32(powers) -> np.ndarray:
 
 
 _lib = None
-ABI_VERSION = 3   # include/ibftgpu.h: ibft_version()  (3: the round-5/6 exports — a version-2 library lacks them)
+ABI_VERSION = 4   # include/ibftgpu.h: ibft_version()  (3: the round-5/6 exports; 4: ibft_pipeline_stats)
 
 
 def load_library() -> C.CDLL:
@@ -169,6 +169,7 @@ def load_library() -> C.CDLL:
     L.ibft_sync.argtypes = [vp]
     L.ibft_issue_probe.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ibft_seals_rows.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ibft_pipeline_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_verify_senders_wire.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(Tally)]
     L.ibft_wire_stage_seals.argtypes = [vp]
     L.ibft_verify_certificates_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp, vp]
@@ -589,6 +590,12 @@ class BatchVerifier:
         """ibft_seals_rows: (rows of the resident batch, rows of the oldest submitted pass or 0) as the LIBRARY counts them"""
         a, b = C.c_uint32(0), C.c_uint32(0)
         self._chk(self._L.ibft_seals_rows(self._h, C.byref(a), C.byref(b)), "ibft_seals_rows")
+        return int(a.value), int(b.value)
+
+    def pipeline_stats(self):
+        """ibft_pipeline_stats: (passes whose tally ran on the side stream, batches that went out as two launches)"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self._chk(self._L.ibft_pipeline_stats(self._h, C.byref(a), C.byref(b)), "ibft_pipeline_stats")
         return int(a.value), int(b.value)
 
     def seals_launch(self, repeat: int = 1) -> None:

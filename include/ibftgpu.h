@@ -325,6 +325,15 @@ int ibft_seals_collect(ibft_ctx *ctx, uint64_t *out_mask, ibft_tally_t *tally);
 /* Rows of the resident seal batch, and of the oldest pass submitted and not yet collected (0: none in flight): what a
  * binding sizes the out_mask of ibft_seals_run / _fetch / _collect from.                                              */
 int ibft_seals_rows(ibft_ctx *ctx, uint32_t *resident_rows, uint32_t *oldest_pass_rows);
+/* Round 6: the TALLY of a submitted pass (HasQuorum over the rows that passed, core/validator_manager.go:77-96) runs on a
+ * stream of its own, next to the verdict kernel of the pass submitted after it, on a second copy of the work buffers the
+ * two would share — the device goes from verdict kernel to verdict kernel without the tally and its two dependency gaps in
+ * between (9–15 µs per pass).  Same results, slot for slot; every other entry point first puts the context's main stream
+ * behind the tallies still in flight.  Not for a rank of a sharded batch (its exchange follows the tally) and not while
+ * the key cache is still learning.  IBFT_SIDE_TALLY=0 keeps everything on one stream (A/B).
+ * ibft_pipeline_stats: passes whose tally took the side stream, and batches of 65 537 … 98 304 rows that went out as two
+ * launches (both since the context was created; either pointer may be NULL).                                             */
+int ibft_pipeline_stats(ibft_ctx *ctx, uint32_t *side_tallies, uint32_t *split_batches);
 int ibft_seals_stage_next(ibft_ctx *ctx, const uint8_t *hash32, const uint8_t *sig65,
                           const uint8_t *signer20, const uint8_t *pre_flags, size_t n);
 int ibft_seals_swap(ibft_ctx *ctx, int wait_for_copy);

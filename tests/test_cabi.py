@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.ibft_version() == 3   # 3: the staged / pipelined pass calls, ibft_seals_rows, ibft_issue_probe
+    assert lib.ibft_version() == 4   # 3: the staged / pipelined pass calls, ibft_seals_rows, ibft_issue_probe; 4: ibft_pipeline_stats
     assert lib.ibft_strerror(0) == b"ok"
     assert b"device" in lib.ibft_strerror(-2)
 

@@ -156,3 +156,84 @@ def test_device_canary_reads_a_healthy_issue_time():
         assert got.all() and t.has_quorum == 1
     finally:
         bv.close()
+
+
+@pytest.mark.parametrize("n", [300, 4096, 20000])
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_side_stream_tally_delivers_the_same_passes_and_other_calls_join_it(oracle, monkeypatch, n, side):
+    """Round 6: the tally of a submitted pass runs on a stream of its own, next to the verdict kernel of the next pass, on a second
+    pair of work mask / validator-index buffers (ibftgpu.hip: ibft_seals_submit).  Batches of different content and size change
+    under the pipeline, and between the pipeline's calls come calls that are NOT part of it — a synchronous pass, a one-shot
+    ibft_verify_seals over other rows, a plain tally — which share the tally's buffers and must find them finished with: every
+    verdict word and every tally equals the CPU oracle's for ITS batch (HasQuorum, /root/reference/core/validator_manager.go:77-96).
+    IBFT_SIDE_TALLY=0 (one stream, as until round 5) is held to the same answers."""
+    import go_ibft_amd.verifier as V
+    from oracle import binding as B
+    monkeypatch.setenv("IBFT_SIDE_TALLY", side)
+    r, batches = _batches(n)
+    vs = B.ValSet(r.addrs, r.power)
+    host = [tuple(None if a is None else V.pinned_copy(a) for a in b[:4]) for b in batches]
+    bv = V.BatchVerifier(max_rows=max(n, 1024))
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        order = [0, 2, 1, 4, 0, 3, 2, 4, 1, 0, 2, 2]
+        bv.seals_stage(*host[order[0]])
+        in_flight = []
+
+        def check(got, idx):
+            verdict, t = got
+            want, wt = batches[idx][4:6]
+            assert len(verdict) == len(want) and (verdict == want).all(), idx
+            assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == (wt.power, wt.valid_rows, wt.distinct_senders, wt.has_quorum), idx
+
+        for i, cur in enumerate(order):
+            bv.seals_submit()
+            in_flight.append(cur)
+            if i % 4 == 1:      # a synchronous pass over the resident batch while two pipelined passes are in flight
+                check(bv.seals_run(), cur)
+            if i % 4 == 2:      # a one-shot call over OTHER rows: restages the columns, runs verdict kernel + tally on the main stream
+                h, s, f, p = batches[(cur + 1) % 5][:4]
+                check(bv.is_valid_committed_seal(h, s, f, p), (cur + 1) % 5)
+                bv.seals_stage(*host[cur])
+            if i % 4 == 3:      # a tally of its own over a caller's verdicts (ibft_tally)
+                e = batches[cur][4]
+                t = bv.has_quorum(batches[cur][2], e)
+                te = B.tally(vs, batches[cur][2], e.astype(np.uint8))
+                assert (t.power, t.distinct_senders, t.has_quorum) == (te.power, te.distinct_senders, te.has_quorum)
+            if i + 1 < len(order):
+                bv.seals_stage_next(*host[order[i + 1]])
+            if len(in_flight) == 2:
+                check(bv.seals_collect(), in_flight.pop(0))
+            if i + 1 < len(order):
+                bv.seals_swap()
+        check(bv.seals_collect(), in_flight.pop(0))
+        sides, _ = bv.pipeline_stats()
+        assert sides == (len(order) if side == "1" else 0)
+        check(bv.seals_run(), order[-1])
+    finally:
+        bv.close()
+
+
+def test_side_stream_tally_serves_the_warm_path_once_every_table_is_built(oracle):
+    """With the key cache on the tally stays on the main stream while keys are being learned (it hands the device's learned-key
+    counter on) and moves to the side stream once every validator has its table; verdicts and tallies are the oracle's throughout."""
+    import go_ibft_amd.verifier as V
+    r, batches = _batches(1024)
+    wv = V.BatchVerifier(max_rows=1024, flags=V.FLAG_PUBKEY_CACHE)
+    try:
+        wv.set_validators(r.height, r.addrs, r.power)
+        wv.seals_stage(*[x for x in batches[0][:4]])
+        seen = []
+        for _ in range(6):
+            wv.seals_submit(); wv.seals_submit()
+            for _ in range(2):
+                verdict, t = wv.seals_collect()
+                assert (verdict == batches[0][4]).all() and (t.power, t.has_quorum) == (batches[0][5].power, batches[0][5].has_quorum)
+            seen.append(wv.pipeline_stats()[0])
+        assert seen[0] == 0, seen                       # learning passes: one stream
+        # Byzantine rows never teach a key, so some validators stay without a table and the cold kernel keeps running behind the
+        # warm one: the side stream is taken only when EVERY validator of the set has a table
+        built, total = wv.cache_stats()[0], len(r.addrs)
+        assert (seen[-1] > 0) == (built >= total), (seen, built, total)
+    finally:
+        wv.close()
