@@ -528,6 +528,9 @@ def sweep_sizes(V, sizes=(64, 256, 1024, 4096, 16384, 65536), steps: int = 50, w
                 while n_pre < SWEEP_PREWARM_MIN_PASSES or time.perf_counter() - t_pre < SWEEP_PREWARM_MIN_S:
                     bv.seals_run()
                     n_pre += 1
+                for _ in range(2):                       # the pipeline's own first-use work (result slots, events, the tally's
+                    bv.seals_submit()                    # stream) belongs to no size: two untimed pipelined passes
+                    bv.seals_collect()
                 bv.set_kernel_timing(1)
                 bv.last_kernel_ms()
                 t0 = time.perf_counter()

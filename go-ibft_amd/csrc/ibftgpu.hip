@@ -2039,8 +2039,13 @@ int ibft_seals_submit(ibft_ctx *c) {
     if (!c->tstream) HIPCHK(c, hipStreamCreateWithFlags(&c->tstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++)
       if (!c->ev_rec[i]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_rec[i], hipEventDisableTiming));
-    HIPCHK(c, hipEventRecord(c->ev_rec[s], c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->tstream, c->ev_rec[s], 0));
+    // (a timed pass already has an event right behind its verdict kernels — the stop event of the pair: one marker less)
+    hipEvent_t after = time_it && c->ev_used > 0 ? c->ev[(size_t)(c->ev_used - 1) * 2 + 1] : nullptr;
+    if (!after) {
+      after = c->ev_rec[s];
+      HIPCHK(c, hipEventRecord(after, c->stream));
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->tstream, after, 0));
     c->tally_slot = (int)s;
     rc = enqueue_tally(c, c->staged_n, nullptr, c->tstream);
     c->tally_slot = -1;

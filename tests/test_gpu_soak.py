@@ -4,8 +4,9 @@ quorum decisions vs reference across 10k synthetic rounds".
 
 10 000 Byzantine rounds at N = 64 (seeds 1…10000, odd seeds weighted, every third with a forged envelope) + 100 rounds each at
 N = 256 / 1 024 / 4 096 + 8 rounds at N = 16 384 + 4 at N = 40 000 (the lane-group and lane kernels): every round through
-ibft_verify_seals twice on a key-caching context (recover kernels, then known-key kernels), twice as a whole COMMIT set through
-ibft_verify_messages, and once through ibft_tally_prepare — every verdict bit, Σ power, valid rows, distinct senders and the
+ibft_verify_seals twice on a key-caching context (recover kernels, then known-key kernels), twice through the pipeline of a cold
+context (ibft_seals_submit × 2, ibft_seals_collect × 2: the tally on its own stream up to 8 192 rows), twice as a whole COMMIT set
+through ibft_verify_messages, and once through ibft_tally_prepare — every verdict bit, Σ power, valid rows, distinct senders and the
 quorum flag against the CPU oracle.  Rounds and oracle answers are produced by worker processes (spawned: they never touch the
 HIP runtime of this process) while the GPU consumes; ≈ 95 s with 16 workers.  IBFT_SOAK_ROUNDS=<k> shortens the N = 64 series
 (the assertion on the total then fails on purpose unless IBFT_SOAK_ALLOW_SHORT=1: a shortened soak is not the evidence)."""
@@ -53,6 +54,9 @@ def test_full_soak_bit_identical_with_the_oracle():
     t0 = time.time()
     procs = min(16, _cores())
     bv = V.BatchVerifier(flags=V.FLAG_PUBKEY_CACHE, max_rows=40000)
+    # a second, cold context takes every round through the PIPELINE as well (ibft_seals_submit / _collect, two passes in flight):
+    # up to 8 192 rows the tally of each pass then runs on a stream of its own next to the next pass's verdict kernel (round 6)
+    pv = V.BatchVerifier(max_rows=40000)
     try:
         with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as ex:
             # the twelve long jobs one per task (a chunk of eight of them kept ONE worker busy for a minute while the consumer
@@ -64,6 +68,13 @@ def test_full_soak_bit_identical_with_the_oracle():
                 bv.set_validators(seed, addrs, power)
                 for _ in range(2):
                     got, t = bv.is_valid_committed_seal(h, s, f, pre)
+                    bad += int((got != exp).sum())
+                    bad += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != et)
+                pv.set_validators(seed, addrs, power)
+                pv.seals_stage(h, s, f, pre)
+                pv.seals_submit(); pv.seals_submit()
+                for _ in range(2):
+                    got, t = pv.seals_collect()
                     bad += int((got != exp).sum())
                     bad += int((t.power, t.quorum, t.valid_rows, t.distinct_senders, t.has_quorum) != et)
                 payload, off, msig, hlen, raw, rnd, snd, clo, ets, hpq = env
@@ -79,15 +90,17 @@ def test_full_soak_bit_identical_with_the_oracle():
                 stat["prepare_true"] += hpq[0]
                 stat["prepare_voided"] += int(hpq[2] > 0)
                 stat["rounds"] += 1
-                stat["passes"] += 5
+                stat["passes"] += 7
                 stat["rows"] += n
                 stat["bad_rows"] += int((~exp).sum())
                 stat["quorum_true" if et[4] else "quorum_false"] += 1
                 e = by_n.setdefault(n, {"rounds": 0, "mismatches": 0})
                 e["rounds"] += 1
                 e["mismatches"] += bad
+        stat["side_stream_tallies"] = pv.pipeline_stats()[0]
     finally:
         bv.close()
+        pv.close()
     stat.update({"seconds": round(time.time() - t0, 1), "procs": procs, "by_n": {str(k): v for k, v in sorted(by_n.items())}})
     try:    # the record of THIS run, for whoever collects gpurun_out/ (the assertion below is the verdict)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -97,6 +110,7 @@ def test_full_soak_bit_identical_with_the_oracle():
         pass
     print("soak:", json.dumps(stat))
     assert stat["rounds"] == len(jobs) and stat["mismatches"] == 0, stat
+    assert stat["side_stream_tallies"] >= 2 * sum(1 for j in jobs if j[0] <= 8192) or os.environ.get("IBFT_SIDE_TALLY") == "0", stat
     assert stat["rounds"] >= 10000 or os.environ.get("IBFT_SOAK_ALLOW_SHORT") == "1", stat
     assert stat["prepare_true"] > 0 and stat["prepare_voided"] > 0, stat
     assert stat["bad_rows"] > 0.15 * stat["rows"] and stat["quorum_true"] > 0 and stat["quorum_false"] > 0, stat
