@@ -43,6 +43,7 @@ EXPORTS = [
     "ibft_seals_stage_next", "ibft_seals_swap", "ibft_last_cold_table", "ibft_seals_submit", "ibft_seals_collect",
     "ibft_comm_preload", "ibft_issue_probe", "ibft_seals_rows", "ibft_pipeline_stats",
 ]
+EXPORTS_SINCE = {"ibft_pipeline_stats": 4}   # exports younger than version 3: the version that brought them
 COMM_ID_BYTES = 128
 E_RCCL = -8
 
@@ -121,9 +122,13 @@ def load_library() -> C.CDLL:
     L = C.CDLL(lib_path)
     vp = C.c_void_p
     L.ibft_version.restype = C.c_int
-    if L.ibft_version() < ABI_VERSION:   # a stale .so writes past the caller's ibft_tally_t (48 → 56 bytes at version 2)
-        raise GpuUnavailable(f"{lib_path}: ibft_version() = {L.ibft_version()}, this binding needs >= {ABI_VERSION} — rebuild")
-    missing = [name for name in EXPORTS if not hasattr(L, name)]   # BEFORE the prototypes below touch any of them
+    # IBFT_MIN_ABI (A/B tools only: tools/kernel_ab.py against an OLDER build of the library): accept a library of that version and
+    # do without the exports that came after it — never below 3 (the struct layouts changed there)
+    need = max(3, min(ABI_VERSION, int(os.environ.get("IBFT_MIN_ABI", ABI_VERSION))))
+    if L.ibft_version() < need:   # a stale .so writes past the caller's ibft_tally_t (48 → 56 bytes at version 2)
+        raise GpuUnavailable(f"{lib_path}: ibft_version() = {L.ibft_version()}, this binding needs >= {need} — rebuild")
+    later = {name for name, since in EXPORTS_SINCE.items() if since > need}
+    missing = [name for name in EXPORTS if name not in later and not hasattr(L, name)]   # BEFORE the prototypes below touch any of them
     if missing:
         raise GpuUnavailable(f"{lib_path} lacks {', '.join(missing)} — a stale build: rebuild")
     L.ibft_strerror.argtypes = [C.c_int]; L.ibft_strerror.restype = C.c_char_p
@@ -169,7 +174,8 @@ def load_library() -> C.CDLL:
     L.ibft_sync.argtypes = [vp]
     L.ibft_issue_probe.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ibft_seals_rows.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    L.ibft_pipeline_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if hasattr(L, "ibft_pipeline_stats"):
+        L.ibft_pipeline_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ibft_verify_senders_wire.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(Tally)]
     L.ibft_wire_stage_seals.argtypes = [vp]
     L.ibft_verify_certificates_wire.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, vp, vp, vp, vp]
@@ -198,7 +204,8 @@ def load_library() -> C.CDLL:
     L.ibft_keccak256.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
     L.ibft_cache_memory.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     for name in EXPORTS:  # fail loudly on a stale build that lacks a declared symbol
-        getattr(L, name)
+        if name not in later:
+            getattr(L, name)
     _lib = L
     return L
 
@@ -595,6 +602,8 @@ class BatchVerifier:
     def pipeline_stats(self):
         """ibft_pipeline_stats: (passes whose tally ran on the side stream, batches that went out as two launches)"""
         a, b = C.c_uint32(0), C.c_uint32(0)
+        if not hasattr(self._L, "ibft_pipeline_stats"):    # (an older build under IBFT_MIN_ABI: it has no side stream either)
+            return 0, 0
         self._chk(self._L.ibft_pipeline_stats(self._h, C.byref(a), C.byref(b)), "ibft_pipeline_stats")
         return int(a.value), int(b.value)
 

@@ -46,7 +46,7 @@ sizes = sys.argv[4:] or ["64", "1024", "4096", "16384", "32768", "65536", "w1024
 acc = {"old": {}, "new": {}}
 for rd in range(rounds):
     for name, lib in (("old", old), ("new", new)):
-        env = dict(os.environ, IBFT_GPU_LIB=os.path.abspath(lib))
+        env = dict(os.environ, IBFT_GPU_LIB=os.path.abspath(lib), IBFT_MIN_ABI="3")   # (an older build: without the exports that came later)
         p = subprocess.run([sys.executable, "-c", CHILD] + sizes, env=env, capture_output=True, text=True, timeout=600)
         line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
         print(name, line or p.stderr[-400:], flush=True)
