@@ -2050,7 +2050,13 @@ int ibft_seals_submit(ibft_ctx *c) {
     rc = enqueue_tally(c, c->staged_n, nullptr, c->tstream);
     c->tally_slot = -1;
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_pass[s], c->tstream));
+    if (hipEventRecord(c->ev_pass[s], c->tstream) != hipSuccess) {
+      // the tally is on its way without an event anybody could wait for: drain its stream before reporting, or the next call on
+      // the main stream would share its buffers with it
+      (void)hipStreamSynchronize(c->tstream);
+      c->last_error = "hipEventRecord behind a side-stream tally failed";
+      return IBFT_E_HIP;
+    }
     // the next verdict launch gets the other pair; this one belongs to the tally just enqueued until the pass is collected
     std::swap(c->d_mask, c->d_mask_b);
     std::swap(c->d_vidx, c->d_vidx_b);
