@@ -82,8 +82,8 @@ type Options struct {
 
 // abiVersion is what this binding was written against (include/ibftgpu.h: ibft_version; 2 = ibft_tally_t with
 // proposer_rows, 56 bytes: an older library would write a shorter struct; 3 = the staged / pipelined pass calls,
-// ibft_seals_rows, ibft_issue_probe: a version-2 library lacks symbols this file links against).
-const abiVersion = 3
+// ibft_seals_rows, ibft_issue_probe: a version-2 library lacks symbols this file links against; 4 = ibft_pipeline_stats).
+const abiVersion = 4
 
 func New(o Options) (*Ctx, error) {
 	if v := int(C.ibft_version()); v < abiVersion {
@@ -365,6 +365,16 @@ func (c *Ctx) StageWireSeals() error { return c.check(C.ibft_wire_stage_seals(c.
 func (c *Ctx) sealRows() (resident, oldest int, err error) {
 	var a, b C.uint32_t
 	if err = c.check(C.ibft_seals_rows(c.h, &a, &b)); err != nil {
+		return 0, 0, err
+	}
+	return int(a), int(b), nil
+}
+
+// PipelineStats = how many submitted passes had their tally on the side stream (next to the following pass's verdict kernel,
+// DESIGN.md §5.10) and how many batches of 65 537 … 98 304 rows went out as two launches, since the context was created.
+func (c *Ctx) PipelineStats() (sideTallies, splitBatches int, err error) {
+	var a, b C.uint32_t
+	if err = c.check(C.ibft_pipeline_stats(c.h, &a, &b)); err != nil {
 		return 0, 0, err
 	}
 	return int(a), int(b), nil
