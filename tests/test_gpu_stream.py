@@ -237,3 +237,42 @@ def test_side_stream_tally_serves_the_warm_path_once_every_table_is_built(oracle
         assert (seen[-1] > 0) == (built >= total), (seen, built, total)
     finally:
         wv.close()
+
+
+@pytest.mark.parametrize("side", ["1", "0"])
+def test_pipeline_at_ragged_and_empty_sizes(oracle, monkeypatch, side):
+    """The pipelined pass at the sizes where word and workgroup boundaries sit — 1, 63, 64, 65 rows, one row short of and one row
+    past the one-workgroup tally's 4 096, an EMPTY batch between two full ones (no verdict kernel at all: the tally alone reports
+    zero rows and no quorum, /root/reference/core/validator_manager.go:77-96 with an empty message list) — every pass against the
+    oracle, with the tally on its own stream and on the main one."""
+    import go_ibft_amd.verifier as V
+    from oracle import workload as W, binding as B
+    monkeypatch.setenv("IBFT_SIDE_TALLY", side)
+    r = W.make_round(4200, 777, byzantine=True, weighted=True)
+    vs = B.ValSet(r.addrs, r.power)
+    bv = V.BatchVerifier(max_rows=8192)
+    try:
+        bv.set_validators(r.height, r.addrs, r.power)
+        sizes = [1, 63, 0, 64, 65, 4095, 0, 4097, 4200, 1]
+        cols = lambda n: tuple(np.ascontiguousarray(c[:n]) for c in (r.hash32, r.seal65, r.signer20, r.pre_flags))
+        want = {}
+        for n in set(sizes):
+            h, s, f, p = cols(n)
+            e = B.verify_seals(vs, h, s, f, p) if n else np.zeros(0, np.uint8)
+            want[n] = (e.astype(bool), B.tally(vs, f, e))
+        in_flight = []
+        for n in sizes:
+            bv.seals_stage(*cols(n))
+            bv.seals_submit()
+            in_flight.append(n)
+            if len(in_flight) == 2:
+                m = in_flight.pop(0)
+                verdict, t = bv.seals_collect()
+                assert len(verdict) == m and (verdict == want[m][0]).all(), m
+                wt = want[m][1]
+                assert (t.power, t.valid_rows, t.distinct_senders, t.has_quorum) == (wt.power, wt.valid_rows, wt.distinct_senders, wt.has_quorum), m
+        m = in_flight.pop(0)
+        verdict, t = bv.seals_collect()
+        assert len(verdict) == m and (verdict == want[m][0]).all() and t.power == want[m][1].power
+    finally:
+        bv.close()
