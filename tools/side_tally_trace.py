@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tools/side_tally_trace.py N — 30 pipelined passes (ibft_seals_submit / _collect, one kept in flight) over N rows, cold, for a
+rocprofv3 --kernel-trace run: which queue ran what when (tools/trace_timeline.py prints it; IBFT_SIDE_TALLY as set in the
+environment).  profiles/r06v_side_tally_trace.txt came from this."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import go_ibft_amd.verifier as V, go_ibft_amd.simulate as SIM
