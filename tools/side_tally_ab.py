@@ -4,7 +4,8 @@ bench's headline step) with the tally on a stream of its own (IBFT_SIDE_TALLY=1,
 (IBFT_SIDE_TALLY=0), ONE library, one lease, separate processes alternating.  Per size: ms per step over 400 delivered passes
 behind 150 untimed ones, the verdict kernel's HIP-event time sampled on every fourth pass of a second series (the tally of the
 pass before now runs NEXT TO it: does it slow it down?), and the synchronous step (launch → results on the host) that the side
-stream must not make worse.  A size written wN is the warm path (keys known).
+stream must not make worse.  A size written wN is the warm path (keys known).  IBFT_AB_ENV=<NAME> switches another 0 / 1 knob of the library instead
+(IBFT_EXT_STOP_EVENTS: the event a side-stream tally waits for attached to the verdict dispatch, or recorded behind it).
 
     python tools/side_tally_ab.py 3 > gpurun_out/profiles/r06v_side_tally_ab.txt"""
 import json
@@ -61,7 +62,7 @@ sizes = sys.argv[2:] or ["1024", "4096", "16384", "65536", "w4096", "w65536"]
 acc = {"0": {}, "1": {}}
 for rd in range(rounds):
     for side in ("0", "1"):
-        env = dict(os.environ, IBFT_SIDE_TALLY=side)
+        env = dict(os.environ, **{os.environ.get("IBFT_AB_ENV", "IBFT_SIDE_TALLY"): side})   # IBFT_AB_ENV: A/B another 0 / 1 knob the same way
         p = subprocess.run([sys.executable, "-c", CHILD] + sizes, env=env, capture_output=True, text=True, timeout=900)
         line = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else ""
         print(f"side={side}", line or p.stderr[-600:], flush=True)
