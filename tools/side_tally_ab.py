@@ -5,7 +5,8 @@ bench's headline step) with the tally on a stream of its own (IBFT_SIDE_TALLY=1,
 behind 150 untimed ones, the verdict kernel's HIP-event time sampled on every fourth pass of a second series (the tally of the
 pass before now runs NEXT TO it: does it slow it down?), and the synchronous step (launch → results on the host) that the side
 stream must not make worse.  A size written wN is the warm path (keys known).  IBFT_AB_ENV=<NAME> switches another 0 / 1 knob of the library instead
-(IBFT_EXT_STOP_EVENTS: the event a side-stream tally waits for attached to the verdict dispatch, or recorded behind it).
+(round 6 compared a build with IBFT_EXT_STOP_EVENTS that way — the event a side-stream tally waits for attached to the verdict
+dispatch instead of recorded behind it: profiles/r06zi_ext_stop_ab.txt, not adopted, the knob is gone).
 
     python tools/side_tally_ab.py 3 > gpurun_out/profiles/r06v_side_tally_ab.txt"""
 import json
